@@ -1,0 +1,84 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of the LoRA train-step hot path.
+// wave = 64 lanes everywhere; bf16 storage, fp32 accumulate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B operand (8 bf16 = 4 VGPR)
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;     // 16x16 MFMA accumulator
+
+#define AITK_OK 0
+#define AITK_ERR_SHAPE (-1)
+#define AITK_ERR_ALIGN (-2)
+#define AITK_ERR_ARG (-3)
+
+#define AITK_LAUNCH_CHECK()                                  \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return (int)e__;                  \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+
+// D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[i=l&31][k=8*(l>>5)..+8] and B[k=8*(l>>5)..+8][j=l&31];
+// lane l receives D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31] in register r (guide: cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x16_t mfma32(s16x8_t a, s16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// 16x16x32: lane l supplies A[i=l&15][k=8*(l>>4)..+8], B[k=8*(l>>4)..+8][j=l&15]; receives D[i=4*(l>>4)+r][j=l&15].
+__device__ __forceinline__ f32x4_t mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximate GELU exactly as torch.nn.functional.gelu(approximate="tanh") evaluates it in fp32.
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float inner = k0 * (x + k1 * x * x2);
+  float t = tanhf(inner);
+  float dinner = k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * dinner;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// bijective XCD-aware remap of a linear block id: blocks that land on one XCD (bid % 8) get a contiguous
+// chunk of the logical tile order so neighbouring tiles share that XCD's L2 (guide §5.5 T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  if (nwg < NX) return bid;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nwg / NX, r = nwg % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

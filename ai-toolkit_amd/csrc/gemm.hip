@@ -1,0 +1,264 @@
+// bf16 MFMA GEMM with the rank-r LoRA path fused into the same output tile (gfx950 / MI355X).
+//
+//   C[M,N] = epi( A[M,K] * B[N,K]^T  +  A2[M,K2] * B2[N,K2]^T  + bias[N] )
+//
+// A/B are the frozen-base operands (activation x, weight W in torch Linear layout [out,in]); A2/B2 is the
+// LoRA K-slab: A2 = T = s*m_b*(x*lora_down^T) (bf16, produced by aitk_lora_down) and B2 = lora_up (bf16 shadow
+// [out,r]).  Concatenating the rank-r slab onto the K loop is the MFMA-native form of the reference's
+//   org_forward(x) + lora_up(lora_down(x.float())) * scale * multiplier      (toolkit/network_mixins.py:304-342)
+// and, for the backward data-gradient, of  dX = dY*W + (s*m*dY*B)*A  (SURVEY.md §3.2).
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16.
+// LDS: double-buffered 2 x (16 KiB A + 16 KiB B), rows of 128 B XOR-swizzled at 16-B granularity
+// (chunk ^= row&7) so the ds_read_b128 fragment reads are <=2-way conflicted (guide §5.5 T2).
+// Staging: STAGE=0 global->VGPR->LDS with the global loads issued before the MFMA phase (T14);
+//          STAGE=1 global_load_lds_dwordx4 (LDS-DMA, lane-linear destination, swizzle on the source address).
+// blockIdx -> tile: bijective XCD remap + grouped (8 row-tiles) ordering for per-XCD L2 reuse (T1).
+#include "common.h"
+#include "aitk_args.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
+
+__device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
+  if (seg_rows > 0) {
+    int s = m / seg_rows;
+    int w = m - s * seg_rows;
+    return base + (long)s * seg_stride + (long)w * ld;
+  }
+  return base + (long)m * ld;
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nwg);
+  const int GROUP = 8;
+  const int group_sz = GROUP * tiles_n;
+  const int gid = lid / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (lid % group_sz) % gm;
+  const int tn = (lid % group_sz) / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging geometry: thread owns physical chunk pc of rows r_i = (tid>>3) + 32 i, i = 0..3 ----
+  const int srow = tid >> 3;
+  const int pc = tid & 7;
+  const int cc = pc ^ (srow & 7);  // logical 16-B chunk held at physical slot pc (row&7 == srow&7 for all i)
+  const bf16_t* pa[4];
+  const bf16_t* pb[4];
+  const bf16_t* pa2[4];
+  const bf16_t* pb2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ra = min(m0 + srow + 32 * i, p.M - 1);
+    int rb = min(n0 + srow + 32 * i, p.N - 1);
+    pa[i] = seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra);
+    pb[i] = p.B + (long)rb * p.ldb;
+    pa2[i] = p.K2 > 0 ? p.A2 + (long)ra * p.lda2 : nullptr;
+    pb2[i] = p.K2 > 0 ? p.B2 + (long)rb * p.ldb2 : nullptr;
+  }
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
+  const int nsteps = nk1 + nk2;
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra_reg[4], rb_reg[4];
+
+  auto step_info = [&](int s, int& k0, int& Kseg, bool& second) {
+    second = s >= nk1;
+    k0 = (second ? s - nk1 : s) * BK;
+    Kseg = second ? p.K2 : p.K;
+  };
+
+  auto load_regs = [&](int s) {
+    int k0, Kseg;
+    bool second;
+    step_info(s, k0, Kseg, second);
+    const int kk = k0 + cc * 8;
+    const bool valid = kk < Kseg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* a = second ? pa2[i] : pa[i];
+      const bf16_t* b = second ? pb2[i] : pb[i];
+      ra_reg[i] = valid ? *reinterpret_cast<const uint4*>(a + kk) : make_uint4(0, 0, 0, 0);
+      rb_reg[i] = valid ? *reinterpret_cast<const uint4*>(b + kk) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto write_lds = [&](int buf) {
+    char* sa = smem + buf * 2 * TILE_BYTES;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sa + (tid + 256 * i) * 16) = ra_reg[i];
+      *reinterpret_cast<uint4*>(sb + (tid + 256 * i) * 16) = rb_reg[i];
+    }
+  };
+  auto issue_glds = [&](int s, int buf) {
+    int k0, Kseg;
+    bool second;
+    step_info(s, k0, Kseg, second);
+    int kk = k0 + cc * 8;
+    if (kk >= Kseg) kk = 0;  // in-bounds garbage; those k-steps are skipped by the compute phase
+    char* sa = smem + buf * 2 * TILE_BYTES;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* a = second ? pa2[i] : pa[i];
+      const bf16_t* b = second ? pb2[i] : pb[i];
+      // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + kk),
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + kk),
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+    }
+  };
+  auto compute = [&](int s, int buf) {
+    int k0, Kseg;
+    bool second;
+    step_info(s, k0, Kseg, second);
+    const int kvalid = min(BK, Kseg - k0);
+    const char* sa = smem + buf * 2 * TILE_BYTES;
+    const char* sb = sa + TILE_BYTES;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks * 16 < kvalid) {
+        s16x8_t af[2], bfr[2];
+        const int c = ks * 2 + h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          int row = wr * 64 + mi * 32 + l31;
+          af[mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          int row = wc * 64 + ni * 32 + l31;
+          bfr[ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+        // swapped operands: D rows = n, D cols = m  -> each lane owns one m and 4 consecutive n per group
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma32(bfr[ni], af[mi], acc[mi][ni]);
+      }
+    }
+  };
+
+  if (STAGE == 0) {
+    load_regs(0);
+    write_lds(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) load_regs(s + 1);
+      compute(s, s & 1);
+      if (s + 1 < nsteps) write_lds((s + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    issue_glds(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) issue_glds(s + 1, (s + 1) & 1);
+      compute(s, s & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---------------- epilogue ----------------
+  const int l31 = lane & 31, h = lane >> 5;
+  const int flags = p.flags;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wr * 64 + mi * 32 + l31;
+    if (m >= p.M) continue;
+    bf16_t* crow = const_cast<bf16_t*>(seg_row(p.C, p.ldc, p.c_seg_rows, p.c_seg_stride, m));
+    const bf16_t* gate_row = (flags & AITK_EPI_GATE_RES) ? p.gate + (long)(m / p.gate_rows) * p.ld_gate : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wc * 64 + ni * 32 + 8 * g + 4 * h;
+        if (nb >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+        if (flags & AITK_EPI_BIAS) {
+          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + nb);
+          v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
+          v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
+        }
+        if (flags & AITK_EPI_ACCUM) {
+          uint2 cc2 = *reinterpret_cast<const uint2*>(crow + nb);
+          v[0] += bf2f(cc2.x & 0xffff); v[1] += bf2f(cc2.x >> 16);
+          v[2] += bf2f(cc2.y & 0xffff); v[3] += bf2f(cc2.y >> 16);
+        }
+        if (flags & AITK_EPI_GELU) {
+          // u = bf16(pre-activation) is saved for backward; h = gelu_tanh(u) (torch evaluates GELU on the bf16 value)
+          uint2 uo;
+          uo.x = pack2bf(v[0], v[1]); uo.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(p.aux_out + (long)m * p.ld_aux_out + nb) = uo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(bfround(v[e]));
+        }
+        if (flags & AITK_EPI_DGELU) {
+          uint2 uu = *reinterpret_cast<const uint2*>(p.aux_in + (long)m * p.ld_aux_in + nb);
+          v[0] *= gelu_tanh_grad_f(bf2f(uu.x & 0xffff)); v[1] *= gelu_tanh_grad_f(bf2f(uu.x >> 16));
+          v[2] *= gelu_tanh_grad_f(bf2f(uu.y & 0xffff)); v[3] *= gelu_tanh_grad_f(bf2f(uu.y >> 16));
+        }
+        if (flags & AITK_EPI_GATE_RES) {
+          // y = bf16(linear out) saved (d_gate needs it); x_new = res + gate[b] * y
+          uint2 yo;
+          yo.x = pack2bf(v[0], v[1]); yo.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(p.aux_out + (long)m * p.ld_aux_out + nb) = yo;
+          uint2 rr = *reinterpret_cast<const uint2*>(p.aux_in + (long)m * p.ld_aux_in + nb);
+          uint2 gg = *reinterpret_cast<const uint2*>(gate_row + nb);
+          v[0] = bf2f(rr.x & 0xffff) + bf2f(gg.x & 0xffff) * bfround(v[0]);
+          v[1] = bf2f(rr.x >> 16) + bf2f(gg.x >> 16) * bfround(v[1]);
+          v[2] = bf2f(rr.y & 0xffff) + bf2f(gg.y & 0xffff) * bfround(v[2]);
+          v[3] = bf2f(rr.y >> 16) + bf2f(gg.y >> 16) * bfround(v[3]);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(crow + nb) = o;
+      }
+    }
+  }
+}
+
+extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return AITK_ERR_SHAPE;
+  if ((a->K % 8) || (a->K2 % 8) || (a->N % 4)) return AITK_ERR_SHAPE;
+  if ((a->lda % 8) || (a->ldb % 8) || (a->ldc % 4)) return AITK_ERR_ALIGN;
+  if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return AITK_ERR_ARG;
+  if ((a->flags & AITK_EPI_BIAS) && !a->bias) return AITK_ERR_ARG;
+  if ((a->flags & (AITK_EPI_GELU | AITK_EPI_GATE_RES)) && !a->aux_out) return AITK_ERR_ARG;
+  if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
+  if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
+  if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  const size_t lds = 4 * TILE_BYTES;
+  if (a->stage_mode == 1) {
+    if (a->K % 8) return AITK_ERR_SHAPE;
+    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3(tiles), dim3(256), lds, stream, *a);
+  } else {
+    hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3(tiles), dim3(256), lds, stream, *a);
+  }
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
