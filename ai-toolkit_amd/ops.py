@@ -9,7 +9,7 @@ from . import _capi
 from ._capi import EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GATE_RES, EPI_GELU  # noqa: F401
 
 BF16 = torch.bfloat16
-STAGE_MODE = int(os.environ.get("AITK_GEMM_STAGE", "0"))
+STAGE_MODE = int(os.environ.get("AITK_GEMM_STAGE", "1"))  # 1 = LDS-DMA staging (faster, profiles/r01_gpu_check_01)
 
 
 def _ptr(t):
