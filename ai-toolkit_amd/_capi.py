@@ -26,9 +26,134 @@ class GemmArgs(C.Structure):
     ]
 
 
+class LoraDownArgs(C.Structure):
+    _fields_ = [
+        ("X", vp), ("ldx", i64), ("x_seg_rows", i32), ("_pad0", i32), ("x_seg_stride", i64),
+        ("P", vp), ("ldp", i64),
+        ("T", vp), ("ldt", i64),
+        ("mult", vp), ("scale", C.c_float), ("rows_per_batch", i32),
+        ("M", i32), ("K", i32), ("R", i32), ("_pad1", i32),
+    ]
+
+
+class LoraWgradArgs(C.Structure):
+    _fields_ = [
+        ("S", vp), ("lds", i64),
+        ("G", vp), ("ldg", i64), ("g_seg_rows", i32), ("_pad0", i32), ("g_seg_stride", i64),
+        ("partial", vp),
+        ("out", vp), ("out_stride_r", i64), ("out_stride_l", i64),
+        ("accumulate", i32),
+        ("M", i32), ("R", i32), ("L", i32),
+    ]
+
+
+class LnModArgs(C.Structure):
+    _fields_ = [
+        ("x", vp), ("ldx", i64),
+        ("shift", vp), ("scale", vp), ("ld_mod", i64),
+        ("out", vp), ("ld_out", i64),
+        ("mean", vp), ("rstd", vp),
+        ("eps", C.c_float), ("rows_per_batch", i32), ("M", i32), ("C", i32),
+    ]
+
+
+class LnModBwdArgs(C.Structure):
+    _fields_ = [
+        ("dxn", vp), ("ld_dxn", i64),
+        ("x", vp), ("ldx", i64),
+        ("mean", vp), ("rstd", vp),
+        ("scale", vp), ("ld_mod", i64),
+        ("dres", vp), ("ld_dres", i64),
+        ("dx", vp), ("ld_dx", i64),
+        ("partial", vp),
+        ("S", i32), ("B", i32), ("C", i32), ("_pad", i32),
+    ]
+
+
+class GateBwdArgs(C.Structure):
+    _fields_ = [
+        ("dx", vp), ("ld_dx", i64),
+        ("y", vp), ("ld_y", i64),
+        ("gate", vp), ("ld_gate", i64),
+        ("dy", vp), ("ld_dy", i64),
+        ("partial", vp),
+        ("S", i32), ("B", i32), ("C", i32), ("_pad", i32),
+    ]
+
+
+class ColsumFinishArgs(C.Structure):
+    _fields_ = [
+        ("partial", vp),
+        ("out0", vp), ("out1", vp), ("ld_out", i64),
+        ("B", i32), ("nchunk", i32), ("V", i32), ("C", i32),
+    ]
+
+
+class QkvJob(C.Structure):
+    _fields_ = [("src", vp), ("ld_src", i64), ("dst", vp), ("ld_dst", i64), ("weight", vp), ("raw", vp), ("ld_raw", i64)]
+
+
+class QkvPostArgs(C.Structure):
+    _fields_ = [
+        ("job", QkvJob * 3),
+        ("cos", vp), ("sin", vp),
+        ("eps", C.c_float), ("njobs", i32),
+        ("B", i32), ("H", i32), ("D", i32), ("S_src", i32), ("S_dst", i32), ("s_off", i32),
+    ]
+
+
+class EwArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("a", vp), ("lda", i64), ("y", vp), ("ldy", i64),
+                ("rows", i32), ("C", i32), ("op", i32), ("_pad", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", vp), ("K", vp), ("V", vp), ("ldq", i64), ("ldk", i64), ("ldv", i64),
+        ("O", vp), ("ldo", i64),
+        ("LSE", vp),
+        ("dO", vp), ("lddo", i64),
+        ("dQ", vp), ("dK", vp), ("dV", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
+        ("delta", vp),
+        ("scale", C.c_float), ("B", i32), ("H", i32), ("S", i32), ("D", i32), ("_pad", i32),
+    ]
+
+
+class GemvArgs(C.Structure):
+    _fields_ = [
+        ("X", vp), ("ldx", i64), ("W", vp), ("ldw", i64), ("bias", vp),
+        ("T", vp), ("ldt", i64), ("Bl", vp), ("ldbl", i64),
+        ("out", vp), ("ldo", i64),
+        ("Bm", i32), ("N", i32), ("K", i32), ("R", i32), ("accumulate", i32), ("cols_per_group", i32),
+    ]
+
+
+class NoisePackArgs(C.Structure):
+    _fields_ = [("latents", vp), ("noise", vp), ("t", vp), ("noisy", vp), ("target", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32)]
+
+
+class MseArgs(C.Structure):
+    _fields_ = [("pred", vp), ("target", vp), ("weight", vp), ("dpred", vp), ("partial", vp),
+                ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("_pad", i32)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("ema", vp),
+                ("norm_partial", vp), ("norm_partial2", vp), ("norm_out", vp), ("n", i64)] + [
+        (k, C.c_float) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1",
+                                 "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale")]
+
+
+class ShadowDesc(C.Structure):
+    _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
+
+
 EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 1, 2, 4, 8, 16
 
-_STRUCTS = {0: GemmArgs}
+_STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
+            6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
+            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc}
 
 
 def lib():
@@ -51,6 +176,16 @@ def lib():
         n = L.aitk_sizeof(which)
         if n != C.sizeof(st):
             raise RuntimeError(f"ABI mismatch: struct {st.__name__} is {C.sizeof(st)} B in Python, {n} B in C")
+    L.aitk_lora_wgrad_workspace_bytes.restype = C.c_int64
+    L.aitk_lora_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
+    L.aitk_rows_per_block.restype = i32
+    L.aitk_mse_workspace_bytes.restype = C.c_int64
+    L.aitk_mse_workspace_bytes.argtypes = [i32, i64]
+    L.aitk_adamw_workspace_bytes.restype = C.c_int64
+    L.aitk_adamw_workspace_bytes.argtypes = [i64]
+    L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]
+    L.aitk_timestep_embed.argtypes = [vp, vp, i32, i32, C.c_float, vp]
+    L.aitk_copy2d.argtypes = [vp, i64, vp, i64, i64, i64, vp]
     _lib = L
     return L
 

@@ -1,0 +1,252 @@
+// Rank-r LoRA side kernels (gfx950): the skinny projections and the weight gradients.
+//
+//   aitk_lora_down : T[M,R]  = bf16( c[m] * (X[M,K] * P[R,K]^T) ),  c[m] = scale * mult[m / rows_per_batch]
+//        forward : X = layer input,  P = lora_down.weight (bf16 shadow)  -> T feeds the GEMM K-slab
+//        backward: X = dY,           P = lora_up.weight^T (bf16 shadow)  -> dT = c*(dY*B) feeds dgrad K-slab and dA
+//        (reference: lora_down -> lora_up -> *scale -> *multiplier, toolkit/network_mixins.py:197-239, 309-321)
+//   aitk_lora_wgrad: out[r][l] += sum_m S[m][r] * G[m][l]   (fp32, arbitrary output strides)
+//        dA[r][k] = sum_m dT[m][r] * X[m][k]     (S = dT, G = X)
+//        dB[n][r] = sum_m dY[m][n] * T[m][r]     (S = T,  G = dY, transposed output strides)
+//        = what autograd produces for lora_down.weight / lora_up.weight in the reference.
+//
+// Both are HBM-bound (they stream X / dY once); MFMA is used only because the contraction is matmul-shaped.
+// The contraction of wgrad runs over the ROW index of row-major tiles, so both operands are consumed through
+// ds_read_b64_tr_b16 (hardware transpose read; lane mapping verified by aitk_probe_tr16).
+#include "common.h"
+#include "aitk_args.h"
+
+__device__ __forceinline__ const bf16_t* seg_row2(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
+  if (seg_rows > 0) {
+    int s = m / seg_rows;
+    return base + (long)s * seg_stride + (long)(m - s * seg_rows) * ld;
+  }
+  return base + (long)m * ld;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// lora_down: one workgroup = 32 rows; wave w contracts K-quarter w straight from global (fragment-shaped loads,
+// no LDS in the main loop), partials combined through LDS.  RB = number of 32-wide rank blocks (R <= 32*RB).
+// ------------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * RB * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32;
+  const int mrow = min(m0 + l31, p.M - 1);
+  const bf16_t* xrow = seg_row2(p.X, p.ldx, p.x_seg_rows, p.x_seg_stride, mrow);
+  const bf16_t* prow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 32 + l31, p.R - 1) * p.ldp;
+
+  f32x16_t acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+
+  // K split: wave w owns k-steps [w*ksteps/4, (w+1)*ksteps/4) of 16 elements each (K % 16 == 0)
+  const int ksteps = p.K / 16;
+  const int kbeg = (ksteps * wave) / 4, kend = (ksteps * (wave + 1)) / 4;
+  int ks = kbeg;
+  for (; ks + 4 <= kend; ks += 4) {
+    s16x8_t xa[4];
+    s16x8_t pa[4][RB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = (ks + u) * 16 + 8 * h;
+      xa[u] = *reinterpret_cast<const s16x8_t*>(xrow + k);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pa[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma32(pa[u][rb], xa[u], acc[rb]);  // D rows = r, cols = m
+  }
+  for (; ks < kend; ++ks) {
+    const int k = ks * 16 + 8 * h;
+    s16x8_t xa = *reinterpret_cast<const s16x8_t*>(xrow + k);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      s16x8_t pa = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
+      acc[rb] = mfma32(pa, xa, acc[rb]);
+    }
+  }
+  // partials -> LDS [wave][rb][reg][lane]
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave * RB + rb) * 16 + r) * 64 + lane] = acc[rb][r];
+  __syncthreads();
+  // wave w finishes register group g = w (4 consecutive ranks) for every rank block
+  const int m = m0 + l31;
+  float c = p.scale;
+  if (p.mult) c *= p.mult[min(m, p.M - 1) / p.rows_per_batch];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * wave + e;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * RB + rb) * 16 + r) * 64 + lane];
+      v[e] = s * c;
+    }
+    const int rr = rb * 32 + 8 * wave + 4 * h;  // rank index of v[0]
+    if (m < p.M && rr < p.R) {
+      uint2 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(p.T + (long)m * p.ldt + rr) = o;
+    }
+  }
+}
+
+extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->K <= 0 || a->R <= 0) return AITK_ERR_SHAPE;
+  if ((a->K % 16) || (a->R % 4) || a->R > 64) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldp % 8) || (a->ldt % 4)) return AITK_ERR_ALIGN;
+  if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
+  const int grid = (a->M + 31) / 32;
+  if (a->R <= 32)
+    hipLaunchKernelGGL(lora_down_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(lora_down_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// lora_wgrad: grid = (L/128 column tiles, row chunks of WG_MC rows).  Per 64-row sub-tile the block stages
+// G[64][128] and S[64][R] row-major into LDS and runs v_mfma_f32_16x16x32_bf16 with BOTH operands read through
+// ds_read_b64_tr_b16 (the contraction index is the tile row).  Chunk partials go to `partial`
+// [nchunks][R][L] fp32; aitk_lora_wgrad_finish adds them (deterministic order) into the gradient arena.
+// ------------------------------------------------------------------------------------------------------------
+#define WG_MC 256
+#define WG_LT 128
+#define WG_GPITCH 144  // elements (288 B): 4 consecutive rows land on disjoint bank octets for the tr reads
+#define WG_SPITCH 72   // elements (144 B), R <= 64
+
+__device__ __forceinline__ s16x4_t tr16(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+// 8 contraction rows x 16 columns fragment for mfma16: lane l (g = l>>4, i = l&15) gets rows row0+8g+0..7 of
+// column col0+i from a row-major LDS tile with `pitch` elements per row.
+__device__ __forceinline__ s16x8_t load_frag_tr(const bf16_t* tile, int pitch, int row0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const bf16_t* p = tile + (row0 + 8 * g + (i >> 2)) * pitch + col0 + (i & 3) * 4;
+  s16x4_t lo = tr16(p);
+  s16x4_t hi = tr16(p + 4 * pitch);
+  s16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <int RB16>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t gt[64 * WG_GPITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t st[64 * WG_SPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l0 = blockIdx.x * WG_LT;
+  const int mbeg = blockIdx.y * WG_MC;
+  const int mend = min(p.M, mbeg + WG_MC);
+
+  f32x4_t acc[RB16][2];
+#pragma unroll
+  for (int a = 0; a < RB16; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+  for (int ms = mbeg; ms < mend; ms += 64) {
+    // stage G: 64 rows x 128 cols = 1024 16-B chunks, 4 per thread; rows beyond M / cols beyond L are zero
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q >> 4, ch = q & 15;
+      const int m = ms + row, col = l0 + ch * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < mend && col < p.L) v = *reinterpret_cast<const uint4*>(seg_row2(p.G, p.ldg, p.g_seg_rows, p.g_seg_stride, m) + col);
+      *reinterpret_cast<uint4*>(gt + row * WG_GPITCH + ch * 8) = v;
+    }
+    // stage S: 64 rows x R cols (R/8 chunks per row)
+    {
+      const int chunks_per_row = p.R / 8;
+      for (int q = tid; q < 64 * chunks_per_row; q += 256) {
+        const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
+        const int m = ms + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < mend) v = *reinterpret_cast<const uint4*>(p.S + (long)m * p.lds + ch * 8);
+        *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // two 32-row contraction steps
+      s16x8_t bfr[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) bfr[cb] = load_frag_tr(gt, WG_GPITCH, kk * 32, (wave * 2 + cb) * 16, lane);
+#pragma unroll
+      for (int rb = 0; rb < RB16; ++rb) {
+        s16x8_t af = load_frag_tr(st, WG_SPITCH, kk * 32, rb * 16, lane);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma16(af, bfr[cb], acc[rb][cb]);  // D[i=r][j=l]
+      }
+    }
+    __syncthreads();
+  }
+  // partial[chunk][r][l]
+  float* part = p.partial + (long)blockIdx.y * p.R * p.L;
+  const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+  for (int rb = 0; rb < RB16; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = l0 + (wave * 2 + cb) * 16 + i;
+      if (col < p.L) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(long)(rb * 16 + 4 * g + r) * p.L + col] = acc[rb][cb][r];
+      }
+    }
+}
+
+__global__ void lora_wgrad_finish_kernel(AitkLoraWgradArgs p, int nchunks) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.R * p.L;
+  if (idx >= total) return;
+  const int r = (int)(idx / p.L), l = (int)(idx - (long)r * p.L);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += p.partial[(long)c * total + idx];
+  float* o = p.out + (long)r * p.out_stride_r + (long)l * p.out_stride_l;
+  *o = p.accumulate ? (*o + s) : s;
+}
+
+extern "C" int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t L) {
+  const int64_t nchunks = (M + WG_MC - 1) / WG_MC;
+  return nchunks * (int64_t)R * L * 4;
+}
+
+extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->R <= 0 || a->L <= 0) return AITK_ERR_SHAPE;
+  if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
+  if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
+  if (!a->partial || !a->out) return AITK_ERR_ARG;
+  const int nchunks = (a->M + WG_MC - 1) / WG_MC;
+  dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->R / 16) {
+    case 1: hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, s, *a); break;
+    case 2: hipLaunchKernelGGL(lora_wgrad_kernel<2>, grid, dim3(256), 0, s, *a); break;
+    case 3: hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, s, *a); break;
+    default: hipLaunchKernelGGL(lora_wgrad_kernel<4>, grid, dim3(256), 0, s, *a); break;
+  }
+  AITK_LAUNCH_CHECK();
+  const long total = (long)a->R * a->L;
+  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *a, nchunks);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}

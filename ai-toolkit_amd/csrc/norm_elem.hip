@@ -1,0 +1,430 @@
+// HBM-bound row kernels of the DiT block (gfx950): adaLN LayerNorm+modulate, gate/residual backward, per-head
+// QK RMSNorm + RoPE, column-sum finish.  One wave (64 lanes) per token row, 16-B (8 x bf16) accesses, wave-level
+// shuffle reductions only (no LDS in the row math); per-batch column sums are accumulated in registers across the
+// rows a wave visits and combined once per workgroup.
+//
+// Reference math being restated (all in diffusers, called from toolkit/stable_diffusion_model.py:2192-2205):
+//   AdaLayerNormZero / ZeroSingle / Continuous:  LN(x; eps=1e-6, no affine) * (1 + scale[b]) + shift[b]
+//   gate residual:                               x + gate[b] * y
+//   attention pre-processing:                    RMSNorm(head_dim, eps=1e-6, weight) on q,k then rotary embedding
+//                                                (order: toolkit/models/flux_sage_attn.py:36-74;
+//                                                 rotation: extensions_built_in/diffusion_models/chroma/src/math.py:47-51)
+#include "common.h"
+#include "aitk_args.h"
+
+#define MAXI 8  // C <= 64 lanes * 8 elems * MAXI = 4096
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bf2f(v.x & 0xffff); f[1] = bf2f(v.x >> 16);
+  f[2] = bf2f(v.y & 0xffff); f[3] = bf2f(v.y >> 16);
+  f[4] = bf2f(v.z & 0xffff); f[5] = bf2f(v.z >> 16);
+  f[6] = bf2f(v.w & 0xffff); f[7] = bf2f(v.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+// ---------------------------------------------------------------- LN + modulate forward
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(AitkLnModArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= p.M) return;
+  const int b = m / p.rows_per_batch;
+  const bf16_t* xr = p.x + (long)m * p.ldx;
+  float xv[MAXI][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+      unpack8(v, xv[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[i][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)p.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = xv[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)p.C + p.eps);
+  if (lane == 0 && p.mean) {
+    p.mean[m] = mean;
+    p.rstd[m] = rstd;
+  }
+  const bf16_t* sh = p.shift + (long)b * p.ld_mod;
+  const bf16_t* sc = p.scale + (long)b * p.ld_mod;
+  bf16_t* orow = p.out + (long)m * p.ld_out;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      float s8[8], h8[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(sc + c), s8);
+      unpack8(*reinterpret_cast<const uint4*>(sh + c), h8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (xv[i][e] - mean) * rstd * (1.0f + s8[e]) + h8[e];
+      *reinterpret_cast<uint4*>(orow + c) = pack8(o);
+    }
+  }
+}
+
+extern "C" int aitk_ln_mod_fwd(const AitkLnModArgs* a, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->C <= 0 || (a->C % 8) || a->C > 64 * 8 * MAXI) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ld_out % 8) || (a->ld_mod % 8) || a->rows_per_batch <= 0) return AITK_ERR_ALIGN;
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- LN + modulate backward
+// xn = xhat*(1+scale)+shift  =>  g = dxn*(1+scale);  dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dres)
+//                                dshift[b][c] = sum_s dxn ;  dscale[b][c] = sum_s dxn*xhat
+// grid = (ceil(S/RPB), B).  Phase 1 (wave per row): the two row means.  Phase 2 (thread per 8-column chunk,
+// walks the block's rows): dx and the column partials in registers -> deterministic, no atomics.
+#define RPB 16
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(AitkLnModBwdArgs p) {
+  __shared__ float rowstat[RPB][4];  // c1, c2, mean, rstd
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int s0 = blockIdx.x * RPB;
+  const int nrows = min(RPB, p.S - s0);
+  const long mbase = (long)b * p.S + s0;
+  const bf16_t* sc = p.scale + (long)b * p.ld_mod;
+  for (int r = wave; r < nrows; r += 4) {
+    const long m = mbase + r;
+    const float mean = p.mean[m], rstd = p.rstd[m];
+    const bf16_t* xr = p.x + m * p.ldx;
+    const bf16_t* gr = p.dxn + m * p.ld_dxn;
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = lane * 8; c < p.C; c += 512) {
+      float xv[8], gv[8], s8[8];
+      unpack8(*reinterpret_cast<const uint4*>(xr + c), xv);
+      unpack8(*reinterpret_cast<const uint4*>(gr + c), gv);
+      unpack8(*reinterpret_cast<const uint4*>(sc + c), s8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = gv[e] * (1.0f + s8[e]);
+        a1 += g;
+        a2 += g * (xv[e] - mean) * rstd;
+      }
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+      rowstat[r][0] = a1 / (float)p.C;
+      rowstat[r][1] = a2 / (float)p.C;
+      rowstat[r][2] = mean;
+      rowstat[r][3] = rstd;
+    }
+  }
+  __syncthreads();
+  const int nch = p.C / 8;
+  for (int ch = tid; ch < nch; ch += 256) {
+    const int c = ch * 8;
+    float s8[8], dsh[8], dsc[8];
+    unpack8(*reinterpret_cast<const uint4*>(sc + c), s8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dsh[e] = 0.f; dsc[e] = 0.f; }
+    for (int r = 0; r < nrows; ++r) {
+      const long m = mbase + r;
+      const float c1 = rowstat[r][0], c2 = rowstat[r][1], mean = rowstat[r][2], rstd = rowstat[r][3];
+      float xv[8], gv[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.x + m * p.ldx + c), xv);
+      unpack8(*reinterpret_cast<const uint4*>(p.dxn + m * p.ld_dxn + c), gv);
+      if (p.dres) unpack8(*reinterpret_cast<const uint4*>(p.dres + m * p.ld_dres + c), o);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        const float g = gv[e] * (1.0f + s8[e]);
+        o[e] += rstd * (g - c1 - xh * c2);
+        dsh[e] += gv[e];
+        dsc[e] += gv[e] * xh;
+      }
+      *reinterpret_cast<uint4*>(p.dx + m * p.ld_dx + c) = pack8(o);
+    }
+    if (p.partial) {
+      float* pp = p.partial + (((long)b * gridDim.x + blockIdx.x) * 2) * p.C + c;
+      *reinterpret_cast<float4*>(pp) = make_float4(dsh[0], dsh[1], dsh[2], dsh[3]);
+      *reinterpret_cast<float4*>(pp + 4) = make_float4(dsh[4], dsh[5], dsh[6], dsh[7]);
+      *reinterpret_cast<float4*>(pp + p.C) = make_float4(dsc[0], dsc[1], dsc[2], dsc[3]);
+      *reinterpret_cast<float4*>(pp + p.C + 4) = make_float4(dsc[4], dsc[5], dsc[6], dsc[7]);
+    }
+  }
+}
+
+extern "C" int32_t aitk_rows_per_block(void) { return RPB; }
+
+extern "C" int aitk_ln_mod_bwd(const AitkLnModBwdArgs* a, aitk_stream_t stream) {
+  if (!a || a->S <= 0 || a->B <= 0 || a->C <= 0 || (a->C % 8)) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ld_dxn % 8) || (a->ld_dx % 8) || (a->ld_mod % 8) || (a->dres && (a->ld_dres % 8))) return AITK_ERR_ALIGN;
+  dim3 grid((a->S + RPB - 1) / RPB, a->B);
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- gate/residual backward
+// x_new = res + gate[b]*y :  dy = gate*dx_new ;  dgate[b][c] = sum_s dx_new*y      (dres = dx_new, same buffer)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(AitkGateBwdArgs p) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int s0 = blockIdx.x * RPB;
+  const int nrows = min(RPB, p.S - s0);
+  const long mbase = (long)b * p.S + s0;
+  const bf16_t* gt = p.gate + (long)b * p.ld_gate;
+  const int nch = p.C / 8;
+  for (int ch = tid; ch < nch; ch += 256) {
+    const int c = ch * 8;
+    float g8[8], acc[8];
+    unpack8(*reinterpret_cast<const uint4*>(gt + c), g8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int r = 0; r < nrows; ++r) {
+      const long m = mbase + r;
+      float dv[8], yv[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.dx + m * p.ld_dx + c), dv);
+      unpack8(*reinterpret_cast<const uint4*>(p.y + m * p.ld_y + c), yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = g8[e] * dv[e];
+        acc[e] += dv[e] * yv[e];
+      }
+      *reinterpret_cast<uint4*>(p.dy + m * p.ld_dy + c) = pack8(o);
+    }
+    float* pp = p.partial + ((long)b * gridDim.x + blockIdx.x) * p.C + c;
+    *reinterpret_cast<float4*>(pp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
+
+extern "C" int aitk_gate_bwd(const AitkGateBwdArgs* a, aitk_stream_t stream) {
+  if (!a || a->S <= 0 || a->B <= 0 || a->C <= 0 || (a->C % 8)) return AITK_ERR_SHAPE;
+  if ((a->ld_dx % 8) || (a->ld_y % 8) || (a->ld_dy % 8) || (a->ld_gate % 8)) return AITK_ERR_ALIGN;
+  dim3 grid((a->S + RPB - 1) / RPB, a->B);
+  hipLaunchKernelGGL(gate_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- column-sum finish
+// partial [B][nchunk][V][C] fp32 -> out_v[b*ld_out + c] (bf16), v < V <= 2
+__global__ void colsum_finish_kernel(AitkColsumFinishArgs p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.B * p.V * p.C;
+  if (idx >= total) return;
+  const int c = (int)(idx % p.C);
+  const int v = (int)((idx / p.C) % p.V);
+  const int b = (int)(idx / ((long)p.C * p.V));
+  const float* src = p.partial + ((long)b * p.nchunk * p.V + v) * p.C + c;
+  float s = 0.f;
+  for (int k = 0; k < p.nchunk; ++k) s += src[(long)k * p.V * p.C];
+  bf16_t* o = (v == 0 ? p.out0 : p.out1) + (long)b * p.ld_out + c;
+  *o = f2bf(s);
+}
+
+extern "C" int aitk_colsum_finish(const AitkColsumFinishArgs* a, aitk_stream_t stream) {
+  if (!a || a->B <= 0 || a->C <= 0 || a->V <= 0 || a->V > 2 || a->nchunk <= 0) return AITK_ERR_SHAPE;
+  if (!a->out0 || (a->V == 2 && !a->out1)) return AITK_ERR_ARG;
+  const long total = (long)a->B * a->V * a->C;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- per-head RMSNorm + RoPE (q,k) / copy (v)
+// One 16-lane group per (token, head); D = 128 = 16 lanes x 8.  Rounding points mirror diffusers' RMSNorm
+// (normalise in fp32 -> cast to the bf16 weight dtype -> * weight) and apply_rotary_emb (fp32 -> bf16).
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void qkv_post_fwd_kernel(AitkQkvPostArgs p) {
+  const AitkQkvJob job = p.job[blockIdx.y];
+  const int sub = threadIdx.x & 15;
+  const long pair0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const long npairs = (long)p.B * p.S_src * p.H;
+  for (long pair = pair0; pair < npairs; pair += (long)gridDim.x * 16) {
+    const int hd = (int)(pair % p.H);
+    const long tok = pair / p.H;
+    const int s = (int)(tok % p.S_src);
+    const int b = (int)(tok / p.S_src);
+    const bf16_t* src = job.src + ((long)b * p.S_src + s) * job.ld_src + hd * 128 + sub * 8;
+    bf16_t* dst = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + hd * 128 + sub * 8;
+    uint4 raw = *reinterpret_cast<const uint4*>(src);
+    if (!job.weight) {
+      *reinterpret_cast<uint4*>(dst) = raw;
+      continue;
+    }
+    float x[8], w[8], o[8];
+    unpack8(raw, x);
+    unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+    const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
+    const float* cs = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
+    const float* sn = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = bfround(bfround(x[e] * rstd) * w[e]);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      o[e] = t[e] * cs[e] - t[e + 1] * sn[e];
+      o[e + 1] = t[e + 1] * cs[e + 1] + t[e] * sn[e + 1];
+    }
+    *reinterpret_cast<uint4*>(dst) = pack8(o);
+  }
+}
+
+// backward: src = grad wrt the joint (roped) tensor, raw = the forward input, dst = grad wrt raw
+__global__ __launch_bounds__(256) void qkv_post_bwd_kernel(AitkQkvPostArgs p) {
+  const AitkQkvJob job = p.job[blockIdx.y];
+  const int sub = threadIdx.x & 15;
+  const long pair0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const long npairs = (long)p.B * p.S_src * p.H;
+  for (long pair = pair0; pair < npairs; pair += (long)gridDim.x * 16) {
+    const int hd = (int)(pair % p.H);
+    const long tok = pair / p.H;
+    const int s = (int)(tok % p.S_src);
+    const int b = (int)(tok / p.S_src);
+    // here "dst" layout = joint grad (read), "src" layout = raw-side (write); see ops.qkv_post_bwd
+    const bf16_t* gj = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + hd * 128 + sub * 8;
+    bf16_t* graw = const_cast<bf16_t*>(job.src) + ((long)b * p.S_src + s) * job.ld_src + hd * 128 + sub * 8;
+    uint4 gv = *reinterpret_cast<const uint4*>(gj);
+    if (!job.weight) {
+      *reinterpret_cast<uint4*>(graw) = gv;
+      continue;
+    }
+    const bf16_t* rawp = job.raw + ((long)b * p.S_src + s) * job.ld_raw + hd * 128 + sub * 8;
+    float g[8], x[8], w[8], dt[8], o[8];
+    unpack8(gv, g);
+    unpack8(*reinterpret_cast<const uint4*>(rawp), x);
+    unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
+    const float* cs = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
+    const float* sn = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      // o_e = t_e c_e - t_{e+1} s_e ; o_{e+1} = t_{e+1} c_{e+1} + t_e s_{e+1}
+      dt[e] = g[e] * cs[e] + g[e + 1] * sn[e + 1];
+      dt[e + 1] = -g[e] * sn[e] + g[e + 1] * cs[e + 1];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+    const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dt[e] *= w[e];              // through "* weight"
+      dot += dt[e] * x[e] * rstd; // sum_i dt1_i * xhat_i
+    }
+    dot = group16_sum(dot) / 128.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = rstd * (dt[e] - x[e] * rstd * dot);
+    *reinterpret_cast<uint4*>(graw) = pack8(o);
+  }
+}
+
+static int qkv_post_check(const AitkQkvPostArgs* a) {
+  if (!a || a->njobs <= 0 || a->njobs > 3 || a->B <= 0 || a->H <= 0 || a->S_src <= 0) return AITK_ERR_SHAPE;
+  if (a->D != 128) return AITK_ERR_SHAPE;
+  for (int j = 0; j < a->njobs; ++j)
+    if ((a->job[j].ld_src % 8) || (a->job[j].ld_dst % 8)) return AITK_ERR_ALIGN;
+  return AITK_OK;
+}
+extern "C" int aitk_qkv_post_fwd(const AitkQkvPostArgs* a, aitk_stream_t stream) {
+  int rc = qkv_post_check(a);
+  if (rc) return rc;
+  const long npairs = (long)a->B * a->S_src * a->H;
+  dim3 grid((unsigned)min((npairs + 15) / 16, (long)8192), a->njobs);
+  hipLaunchKernelGGL(qkv_post_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+extern "C" int aitk_qkv_post_bwd(const AitkQkvPostArgs* a, aitk_stream_t stream) {
+  int rc = qkv_post_check(a);
+  if (rc) return rc;
+  const long npairs = (long)a->B * a->S_src * a->H;
+  dim3 grid((unsigned)min((npairs + 15) / 16, (long)8192), a->njobs);
+  hipLaunchKernelGGL(qkv_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- small element-wise ops on [rows, C] bf16
+// op 0: y = silu(x)                      (AdaLayerNorm*: linear(silu(temb)))
+// op 1: y = x                            (copy / cast helper)
+// op 2: y = a + x                        (sum of embedder outputs)
+__global__ void ew_kernel(AitkEwArgs p) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long total = (long)p.rows * p.C;
+  if (i >= total) return;
+  const long r = i / p.C;
+  const int c = (int)(i - r * p.C);
+  float x[8], o[8], a8[8];
+  unpack8(*reinterpret_cast<const uint4*>(p.x + r * p.ldx + c), x);
+  if (p.op == 2) unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.lda + c), a8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (p.op == 0) o[e] = x[e] / (1.0f + expf(-x[e]));
+    else if (p.op == 1) o[e] = x[e];
+    else o[e] = a8[e] + x[e];
+  }
+  *reinterpret_cast<uint4*>(p.y + r * p.ldy + c) = pack8(o);
+}
+extern "C" int aitk_ew(const AitkEwArgs* a, aitk_stream_t stream) {
+  if (!a || a->rows <= 0 || a->C <= 0 || (a->C % 8)) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldy % 8) || (a->op == 2 && (!a->a || (a->lda % 8)))) return AITK_ERR_ALIGN;
+  const long n = (long)a->rows * a->C / 8;
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// sinusoidal timestep projection (diffusers Timesteps(256, flip_sin_to_cos=True, shift 0)): out[b] = [cos | sin]
+// restated from extensions_built_in/diffusion_models/chroma/src/layers.py:30-53
+__global__ void timestep_embed_kernel(const float* t, bf16_t* out, int B, int dim, float tscale) {
+  const int b = blockIdx.x;
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float freq = expf(-logf(10000.0f) * (float)i / (float)half);
+    const float ang = t[b] * tscale * freq;
+    out[(long)b * dim + i] = f2bf(cosf(ang));
+    out[(long)b * dim + half + i] = f2bf(sinf(ang));
+  }
+}
+extern "C" int aitk_timestep_embed(const float* t, aitk_bf16* out, int32_t B, int32_t dim, float tscale, aitk_stream_t stream) {
+  if (B <= 0 || dim <= 0 || (dim & 1)) return AITK_ERR_SHAPE;
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, t, out, B, dim, tscale);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// strided 2-D copy (device to device) for the few layout moves of the block graph (cat/split of text|image rows)
+extern "C" int aitk_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes,
+                           int64_t width_bytes, int64_t rows, aitk_stream_t stream) {
+  hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch_bytes, src, (size_t)src_pitch_bytes, (size_t)width_bytes,
+                                  (size_t)rows, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return (int)e;
+}

@@ -68,6 +68,20 @@ extern "C" int aitk_probe_mfma32(const aitk_bf16* a, const aitk_bf16* b, float* 
 extern "C" int aitk_sizeof(int32_t which) {
   switch (which) {
     case 0: return (int)sizeof(AitkGemmArgs);
+    case 1: return (int)sizeof(AitkLoraDownArgs);
+    case 2: return (int)sizeof(AitkLoraWgradArgs);
+    case 3: return (int)sizeof(AitkLnModArgs);
+    case 4: return (int)sizeof(AitkLnModBwdArgs);
+    case 5: return (int)sizeof(AitkGateBwdArgs);
+    case 6: return (int)sizeof(AitkColsumFinishArgs);
+    case 7: return (int)sizeof(AitkQkvPostArgs);
+    case 8: return (int)sizeof(AitkEwArgs);
+    case 9: return (int)sizeof(AitkAttnArgs);
+    case 10: return (int)sizeof(AitkGemvArgs);
+    case 11: return (int)sizeof(AitkNoisePackArgs);
+    case 12: return (int)sizeof(AitkMseArgs);
+    case 13: return (int)sizeof(AitkAdamWArgs);
+    case 14: return (int)sizeof(AitkShadowDesc);
     default: return -1;
   }
 }

@@ -1,0 +1,300 @@
+// Step-level kernels around the DiT (gfx950): small-batch projections (adaLN / embedders), flow-matching noise mix +
+// 2x2 patchify, MSE loss + gradient, and the fused clip -> AdamW -> EMA -> bf16-shadow update over the flat LoRA
+// parameter arena.  All HBM-bound; 16-B accesses, wave64 shuffles, deterministic two-stage reductions.
+//
+// Reference behaviour being replaced:
+//   add_noise ............ toolkit/samplers/custom_flowmatch_sampler.py:91-102
+//   pack / unpack ........ toolkit/stable_diffusion_model.py:2157-2163, 2210-2219
+//   loss ................. extensions_built_in/sd_trainer/SDTrainer.py:644-646, 916, 987-990, 1013
+//   clip / AdamW / EMA ... SDTrainer.py:2278-2293; toolkit/optimizer.py:78-79 (torch.optim.AdamW, eps=1e-6);
+//                          toolkit/ema.py:116-152
+#include "common.h"
+#include "aitk_args.h"
+
+// ------------------------------------------------------------------------------------------------ small-M GEMV
+// out[Bm,N] (+)= X[Bm,K] W[N,K]^T + bias[N] + T[Bm,R] Bl[N,R]^T ; Bm <= 8.  One 16-lane group per output column,
+// W rows streamed once with 16-B loads (weights dominate the bytes), X staged in LDS.
+#define GEMV_MAXB 8
+__global__ __launch_bounds__(256) void gemv_nt_kernel(AitkGemvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);  // [Bm][K]
+  const int tid = threadIdx.x;
+  const int kch = p.K / 8;
+  for (int q = tid; q < p.Bm * kch; q += 256) {
+    const int bb = q / kch, c = q - bb * kch;
+    *reinterpret_cast<uint4*>(xs + (long)bb * p.K + c * 8) = *reinterpret_cast<const uint4*>(p.X + (long)bb * p.ldx + c * 8);
+  }
+  __syncthreads();
+  const int grp = tid >> 4, sub = tid & 15;
+  const int ncol_per_block = 16 * p.cols_per_group;
+  for (int ci = 0; ci < p.cols_per_group; ++ci) {
+    const int n = blockIdx.x * ncol_per_block + ci * 16 + grp;
+    if (n >= p.N) continue;  // whole 16-lane group leaves together
+    const bf16_t* wrow = p.W + (long)n * p.ldw;
+    float acc[GEMV_MAXB];
+#pragma unroll
+    for (int bb = 0; bb < GEMV_MAXB; ++bb) acc[bb] = 0.f;
+    for (int c = sub; c < kch; c += 16) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(wrow + c * 8);
+      float w[8];
+      w[0] = bf2f(wv.x & 0xffff); w[1] = bf2f(wv.x >> 16); w[2] = bf2f(wv.y & 0xffff); w[3] = bf2f(wv.y >> 16);
+      w[4] = bf2f(wv.z & 0xffff); w[5] = bf2f(wv.z >> 16); w[6] = bf2f(wv.w & 0xffff); w[7] = bf2f(wv.w >> 16);
+#pragma unroll
+      for (int bb = 0; bb < GEMV_MAXB; ++bb) {
+        if (bb < p.Bm) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(xs + (long)bb * p.K + c * 8);
+          acc[bb] += w[0] * bf2f(xv.x & 0xffff) + w[1] * bf2f(xv.x >> 16) + w[2] * bf2f(xv.y & 0xffff) + w[3] * bf2f(xv.y >> 16) +
+                     w[4] * bf2f(xv.z & 0xffff) + w[5] * bf2f(xv.z >> 16) + w[6] * bf2f(xv.w & 0xffff) + w[7] * bf2f(xv.w >> 16);
+        }
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < GEMV_MAXB; ++bb) {
+      float v = acc[bb];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 1, 64);
+      acc[bb] = v;
+    }
+    if (sub < p.Bm) {
+      const int bb = sub;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < GEMV_MAXB; ++k)
+        if (k == bb) v = acc[k];
+      if (p.bias) v += bf2f(p.bias[n]);
+      if (p.R > 0) {
+        float lv = 0.f;
+        for (int r = 0; r < p.R; ++r) lv += bf2f(p.T[(long)bb * p.ldt + r]) * bf2f(p.Bl[(long)n * p.ldbl + r]);
+        v += lv;
+      }
+      bf16_t* o = p.out + (long)bb * p.ldo + n;
+      if (p.accumulate) v += bf2f(*o);
+      *o = f2bf(v);
+    }
+  }
+}
+
+extern "C" int aitk_gemv_nt(const AitkGemvArgs* a, aitk_stream_t stream) {
+  if (!a || a->Bm <= 0 || a->Bm > GEMV_MAXB || a->N <= 0 || a->K <= 0 || (a->K % 8)) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldw % 8)) return AITK_ERR_ALIGN;
+  if (a->R > 0 && (!a->T || !a->Bl)) return AITK_ERR_ARG;
+  const size_t lds = (size_t)a->Bm * a->K * 2;
+  if (lds > 64 * 1024) return AITK_ERR_SHAPE;
+  AitkGemvArgs args = *a;
+  args.cols_per_group = 4;
+  const int ncol = 16 * args.cols_per_group;
+  hipLaunchKernelGGL(gemv_nt_kernel, dim3((a->N + ncol - 1) / ncol), dim3(256), lds, (hipStream_t)stream, args);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ noise mix + patchify
+// latents/noise [B, C, H, W] bf16; t [B] fp32 in [0,1000].
+//   noisy[b, (h/2)(w/2), c*4 + 2*ph + pw] = bf16((1 - t/1000) x0 + (t/1000) eps)          (fp32 math like the reference)
+//   target (same packing)                 = bf16(eps - x0)
+__global__ void flow_noise_pack_kernel(AitkNoisePackArgs p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.B * p.C * p.H * p.W;
+  if (idx >= total) return;
+  const int w = (int)(idx % p.W);
+  const int hh = (int)((idx / p.W) % p.H);
+  const int c = (int)((idx / ((long)p.W * p.H)) % p.C);
+  const int b = (int)(idx / ((long)p.W * p.H * p.C));
+  const float x0 = bf2f(p.latents[idx]);
+  const float e = bf2f(p.noise[idx]);
+  const float t01 = p.t[b] / 1000.0f;
+  const long tok = (long)(hh >> 1) * (p.W >> 1) + (w >> 1);
+  const int ch = c * 4 + ((hh & 1) << 1) + (w & 1);
+  const long o = ((long)b * (p.H >> 1) * (p.W >> 1) + tok) * (p.C * 4) + ch;
+  p.noisy[o] = f2bf((1.0f - t01) * x0 + t01 * e);
+  p.target[o] = f2bf(e - x0);
+}
+extern "C" int aitk_flow_noise_pack(const AitkNoisePackArgs* a, aitk_stream_t stream) {
+  if (!a || a->B <= 0 || a->C <= 0 || a->H <= 0 || a->W <= 0 || (a->H & 1) || (a->W & 1)) return AITK_ERR_SHAPE;
+  const long total = (long)a->B * a->C * a->H * a->W;
+  hipLaunchKernelGGL(flow_noise_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ MSE loss + gradient
+// per-sample loss_b = mean_j (pred - target)^2 ; loss = mean_b (w_b * loss_b) ; dpred = 2 (pred - target) w_b / (n B)
+#define LOSS_CHUNK 8192
+__global__ __launch_bounds__(256) void mse_partial_kernel(AitkMseArgs p, int nchunk) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const long base = (long)b * p.n_per_sample + (long)blockIdx.x * LOSS_CHUNK;
+  const long end = min((long)(b + 1) * p.n_per_sample, base + LOSS_CHUNK);
+  const float wb = p.weight ? p.weight[b] : 1.0f;
+  const float gs = 2.0f * wb / ((float)p.n_per_sample * (float)p.B);
+  float acc = 0.f;
+  for (long i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
+    const uint4 pv = *reinterpret_cast<const uint4*>(p.pred + i);
+    const uint4 tv = *reinterpret_cast<const uint4*>(p.target + i);
+    float d[8];
+    d[0] = bf2f(pv.x & 0xffff) - bf2f(tv.x & 0xffff); d[1] = bf2f(pv.x >> 16) - bf2f(tv.x >> 16);
+    d[2] = bf2f(pv.y & 0xffff) - bf2f(tv.y & 0xffff); d[3] = bf2f(pv.y >> 16) - bf2f(tv.y >> 16);
+    d[4] = bf2f(pv.z & 0xffff) - bf2f(tv.z & 0xffff); d[5] = bf2f(pv.z >> 16) - bf2f(tv.z >> 16);
+    d[6] = bf2f(pv.w & 0xffff) - bf2f(tv.w & 0xffff); d[7] = bf2f(pv.w >> 16) - bf2f(tv.w >> 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += d[e] * d[e];
+    uint4 g;
+    g.x = pack2bf(d[0] * gs, d[1] * gs); g.y = pack2bf(d[2] * gs, d[3] * gs);
+    g.z = pack2bf(d[4] * gs, d[5] * gs); g.w = pack2bf(d[6] * gs, d[7] * gs);
+    *reinterpret_cast<uint4*>(p.dpred + i) = g;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) p.partial[(long)b * nchunk + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void mse_finish_kernel(AitkMseArgs p, int nchunk) {
+  // one thread per sample, then thread 0 averages: tiny
+  const int b = threadIdx.x;
+  __shared__ float ls[64];
+  float s = 0.f;
+  if (b < p.B) {
+    for (int k = 0; k < nchunk; ++k) s += p.partial[(long)b * nchunk + k];
+    s /= (float)p.n_per_sample;
+    p.loss_per_sample[b] = s;
+    ls[b] = s * (p.weight ? p.weight[b] : 1.0f);
+  }
+  __syncthreads();
+  if (b == 0) {
+    float t = 0.f;
+    for (int k = 0; k < p.B; ++k) t += ls[k];
+    p.loss[0] = t / (float)p.B;
+  }
+}
+extern "C" int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample) {
+  return (int64_t)B * ((n_per_sample + LOSS_CHUNK - 1) / LOSS_CHUNK) * 4;
+}
+extern "C" int aitk_mse_loss_grad(const AitkMseArgs* a, aitk_stream_t stream) {
+  if (!a || a->B <= 0 || a->B > 64 || a->n_per_sample <= 0 || (a->n_per_sample % 8)) return AITK_ERR_SHAPE;
+  if (!a->pred || !a->target || !a->dpred || !a->partial || !a->loss || !a->loss_per_sample) return AITK_ERR_ARG;
+  const int nchunk = (int)((a->n_per_sample + LOSS_CHUNK - 1) / LOSS_CHUNK);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(nchunk, a->B), dim3(256), 0, (hipStream_t)stream, *a, nchunk);
+  AITK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, nchunk);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// flat fp32 arenas p, g, m, v (, ema).  Stage 1: per-block sum of squares.  Stage 2: every block re-reduces the (few)
+// partials -> total norm -> clip coefficient (torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm/(norm+1e-6)))
+// -> AdamW (decoupled weight decay, bias correction as torch.optim.AdamW) -> EMA (s -= (1-d)(s-p)).
+#define OPT_BLOCK_ELEMS 4096
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partial) {
+  __shared__ float red[4];
+  const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < OPT_BLOCK_ELEMS / (256 * 4); ++i) {
+    const long j = base + (long)(i * 256 + threadIdx.x) * 4;
+    if (j + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + j);
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long k = j; k < n; ++k) acc += g[k] * g[k];
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// second-level reduce so the update kernel only sums <= 1024 values
+__global__ __launch_bounds__(256) void sumsq_level2_kernel(const float* partial, int n1, float* out2) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(n1, (blockIdx.x + 1) * 1024); i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, int n2) {
+  __shared__ float s_coef;
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < n2; ++i) tot += p.norm_partial2[i];
+    const float norm = sqrtf(tot);
+    float coef = 1.0f;
+    if (p.max_norm > 0.f) coef = fminf(1.0f, p.max_norm / (norm + 1e-6f));
+    s_coef = coef * p.grad_scale;
+    if (blockIdx.x == 0 && p.norm_out) p.norm_out[0] = norm * fabsf(p.grad_scale);
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
+#pragma unroll
+  for (int i = 0; i < OPT_BLOCK_ELEMS / 256; ++i) {
+    const long j = base + i * 256 + threadIdx.x;
+    if (j < p.n) {
+      const float g = p.g[j] * coef;
+      float w = p.p[j];
+      w -= p.lr * p.weight_decay * w;
+      const float m = p.beta1 * p.m[j] + (1.0f - p.beta1) * g;
+      const float v = p.beta2 * p.v[j] + (1.0f - p.beta2) * g * g;
+      const float denom = sqrtf(v) / p.bias_correction2_sqrt + p.eps;
+      w -= (p.lr / p.bias_correction1) * (m / denom);
+      p.p[j] = w;
+      p.m[j] = m;
+      p.v[j] = v;
+      if (p.ema) {
+        const float s = p.ema[j];
+        p.ema[j] = s - (1.0f - p.ema_decay) * (s - w);
+      }
+    }
+  }
+}
+
+extern "C" int64_t aitk_adamw_workspace_bytes(int64_t n) {
+  const int64_t n1 = (n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS;
+  const int64_t n2 = (n1 + 1023) / 1024;
+  return (n1 + n2) * 4;
+}
+
+extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream) {
+  if (!a || a->n <= 0) return AITK_ERR_SHAPE;
+  if (!a->p || !a->g || !a->m || !a->v || !a->norm_partial) return AITK_ERR_ARG;
+  const long n1 = (a->n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS;
+  const int n2 = (int)((n1 + 1023) / 1024);
+  if (n2 > 4096) return AITK_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  AitkAdamWArgs args = *a;
+  args.norm_partial2 = a->norm_partial + n1;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)n1), dim3(256), 0, s, a->g, (long)a->n, a->norm_partial);
+  AITK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_level2_kernel, dim3(n2), dim3(256), 0, s, a->norm_partial, (int)n1, args.norm_partial2);
+  AITK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)n1), dim3(256), 0, s, args, n2);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ bf16 shadows
+// For every LoRA matrix in the fp32 arena (row-major [rows, cols]) write bf16 copies in both orientations; the
+// forward K-slab / lora_down read the direct one, the backward dT / dgrad K-slab read the transposed one.
+__global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena, bf16_t* shadow, const AitkShadowDesc* table) {
+  const AitkShadowDesc d = table[blockIdx.y];
+  const long n = (long)d.rows * d.cols;
+  const float* src = arena + d.src_off;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const bf16_t v = f2bf(src[i]);
+    shadow[d.dst_off + i] = v;
+    const long r = i / d.cols, c = i - r * d.cols;
+    shadow[d.dstT_off + c * d.rows + r] = v;
+  }
+}
+extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
+                                         aitk_stream_t stream) {
+  if (!arena || !shadow || !table || ntensors <= 0) return AITK_ERR_ARG;
+  hipLaunchKernelGGL(refresh_shadows_kernel, dim3(16, ntensors), dim3(256), 0, (hipStream_t)stream, arena, shadow, table);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}

@@ -65,3 +65,282 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
     _capi.check(_capi.lib().aitk_gemm_nt(C.byref(g), _capi.stream_ptr()), "aitk_gemm_nt")
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only fp32 scratch owned by torch (the C ABI never allocates)."""
+    key = (tag, str(device))
+    n = (nbytes + 3) // 4
+    t = _ws.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def rows_per_block():
+    return _capi.lib().aitk_rows_per_block()
+
+
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None):
+    """out[M,R] = bf16(scale * mult[m // rows_per_batch] * (x[M,K] @ pmat[R,K]^T))."""
+    a = _capi.LoraDownArgs()
+    a.ldx = _row_major(x, "x")
+    a.ldp = _row_major(pmat, "pmat")
+    a.ldt = _row_major(out, "out")
+    R, K = pmat.shape
+    assert x.shape[1] == K and out.shape[1] == R
+    a.X, a.P, a.T = _ptr(x), _ptr(pmat), _ptr(out)
+    if x_seg is not None:
+        a.x_seg_rows, a.x_seg_stride = x_seg
+    if mult is not None:
+        assert mult.dtype == torch.float32 and mult.is_contiguous()
+        a.mult, a.rows_per_batch = _ptr(mult), rows_per_batch
+    a.scale = float(scale)
+    a.M, a.K, a.R = (x.shape[0] if M is None else M), K, R
+    _capi.check(_capi.lib().aitk_lora_down(C.byref(a), _capi.stream_ptr()), "aitk_lora_down")
+    return out
+
+
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None):
+    """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad)."""
+    a = _capi.LoraWgradArgs()
+    a.lds = _row_major(s, "s")
+    a.ldg = _row_major(g, "g")
+    R, L = s.shape[1], g.shape[1]
+    M = s.shape[0] if M is None else M
+    assert out.dtype == torch.float32 and out.is_contiguous()
+    if transpose_out:
+        assert tuple(out.shape) == (L, R)
+        a.out_stride_r, a.out_stride_l = 1, R
+    else:
+        assert tuple(out.shape) == (R, L)
+        a.out_stride_r, a.out_stride_l = L, 1
+    if g_seg is not None:
+        a.g_seg_rows, a.g_seg_stride = g_seg
+    nbytes = _capi.lib().aitk_lora_wgrad_workspace_bytes(M, R, L)
+    ws = workspace(nbytes, s.device, "wgrad")
+    a.S, a.G, a.partial, a.out = _ptr(s), _ptr(g), _ptr(ws), _ptr(out)
+    a.accumulate = int(accumulate)
+    a.M, a.R, a.L = M, R, L
+    _capi.check(_capi.lib().aitk_lora_wgrad(C.byref(a), _capi.stream_ptr()), "aitk_lora_wgrad")
+    return out
+
+
+def ln_mod_fwd(x, shift, scale, out, *, rows_per_batch, mean=None, rstd=None, eps=1e-6):
+    """out = LayerNorm(x) * (1 + scale[b]) + shift[b]; shift/scale are [B, C] views sharing one row stride."""
+    a = _capi.LnModArgs()
+    a.ldx = _row_major(x, "x")
+    a.ld_out = _row_major(out, "out")
+    a.ld_mod = _row_major(shift, "shift")
+    assert _row_major(scale, "scale") == a.ld_mod
+    a.x, a.shift, a.scale, a.out = _ptr(x), _ptr(shift), _ptr(scale), _ptr(out)
+    a.mean, a.rstd = _ptr(mean), _ptr(rstd)
+    a.eps, a.rows_per_batch = eps, rows_per_batch
+    a.M, a.C = x.shape
+    _capi.check(_capi.lib().aitk_ln_mod_fwd(C.byref(a), _capi.stream_ptr()), "aitk_ln_mod_fwd")
+    return out
+
+
+def colsum_finish(partial, nchunk, B, V, Cc, out0, out1=None):
+    a = _capi.ColsumFinishArgs()
+    a.partial, a.out0, a.out1 = _ptr(partial), _ptr(out0), _ptr(out1)
+    a.ld_out = _row_major(out0, "out0")
+    if out1 is not None:
+        assert _row_major(out1, "out1") == a.ld_out
+    a.B, a.nchunk, a.V, a.C = B, nchunk, V, Cc
+    _capi.check(_capi.lib().aitk_colsum_finish(C.byref(a), _capi.stream_ptr()), "aitk_colsum_finish")
+
+
+def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, dscale=None):
+    """dx = LN-modulate backward (+ dres);  dshift/dscale [B,C] bf16 views (column sums over the S rows of a batch)."""
+    a = _capi.LnModBwdArgs()
+    a.ld_dxn, a.ldx, a.ld_dx = _row_major(dxn, "dxn"), _row_major(x, "x"), _row_major(dx, "dx")
+    a.ld_mod = _row_major(scale, "scale")
+    Cc = x.shape[1]
+    a.dxn, a.x, a.mean, a.rstd, a.scale, a.dx = _ptr(dxn), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(dx)
+    if dres is not None:
+        a.dres, a.ld_dres = _ptr(dres), _row_major(dres, "dres")
+    nchunk = (S + rows_per_block() - 1) // rows_per_block()
+    part = None
+    if dshift is not None:
+        part = workspace(B * nchunk * 2 * Cc * 4, x.device, "colsum")
+        a.partial = _ptr(part)
+    a.S, a.B, a.C = S, B, Cc
+    _capi.check(_capi.lib().aitk_ln_mod_bwd(C.byref(a), _capi.stream_ptr()), "aitk_ln_mod_bwd")
+    if dshift is not None:
+        colsum_finish(part, nchunk, B, 2, Cc, dshift, dscale)
+    return dx
+
+
+def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
+    """dy = gate[b] * dx ; dgate[b] = sum_s dx * y."""
+    a = _capi.GateBwdArgs()
+    a.ld_dx, a.ld_y, a.ld_dy, a.ld_gate = _row_major(dx, "dx"), _row_major(y, "y"), _row_major(dy, "dy"), _row_major(gate, "gate")
+    Cc = dx.shape[1]
+    nchunk = (S + rows_per_block() - 1) // rows_per_block()
+    part = workspace(B * nchunk * Cc * 4, dx.device, "colsum")
+    a.dx, a.y, a.gate, a.dy, a.partial = _ptr(dx), _ptr(y), _ptr(gate), _ptr(dy), _ptr(part)
+    a.S, a.B, a.C = S, B, Cc
+    _capi.check(_capi.lib().aitk_gate_bwd(C.byref(a), _capi.stream_ptr()), "aitk_gate_bwd")
+    colsum_finish(part, nchunk, B, 1, Cc, dgate)
+    return dy
+
+
+def _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps):
+    a = _capi.QkvPostArgs()
+    assert 1 <= len(jobs) <= 3
+    for i, j in enumerate(jobs):
+        src, dst, weight = j["src"], j["dst"], j.get("weight")
+        a.job[i].src, a.job[i].ld_src = _ptr(src), _row_major(src, "src")
+        a.job[i].dst, a.job[i].ld_dst = _ptr(dst), _row_major(dst, "dst")
+        a.job[i].weight = _ptr(weight)
+        raw = j.get("raw")
+        if raw is not None:
+            a.job[i].raw, a.job[i].ld_raw = _ptr(raw), _row_major(raw, "raw")
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (S_dst, 128)
+    a.cos, a.sin = _ptr(cos), _ptr(sin)
+    a.eps, a.njobs = eps, len(jobs)
+    a.B, a.H, a.D, a.S_src, a.S_dst, a.s_off = B, H, 128, S_src, S_dst, s_off
+    return a
+
+
+def qkv_post_fwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
+    """jobs: dicts {src [B*S_src, >=H*128], dst [B*S_dst, >=H*128], weight [128] or None (= plain copy)}."""
+    a = _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps)
+    _capi.check(_capi.lib().aitk_qkv_post_fwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_fwd")
+
+
+def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
+    """jobs: {src: raw-side grad (written), dst: joint-side grad (read), weight, raw: forward input}."""
+    a = _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps)
+    _capi.check(_capi.lib().aitk_qkv_post_bwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_bwd")
+
+
+def ew(op, x, y, a=None):
+    """op 0: y = silu(x); 1: y = x; 2: y = a + x   ([rows, C] bf16 views)."""
+    g = _capi.EwArgs()
+    g.x, g.ldx, g.y, g.ldy = _ptr(x), _row_major(x, "x"), _ptr(y), _row_major(y, "y")
+    if a is not None:
+        g.a, g.lda = _ptr(a), _row_major(a, "a")
+    g.rows, g.C = x.shape
+    g.op = op
+    _capi.check(_capi.lib().aitk_ew(C.byref(g), _capi.stream_ptr()), "aitk_ew")
+    return y
+
+
+def timestep_embed(t, out, tscale=1.0):
+    assert t.dtype == torch.float32 and out.dtype == BF16 and out.is_contiguous()
+    B, dim = out.shape
+    _capi.check(_capi.lib().aitk_timestep_embed(_ptr(t), _ptr(out), B, dim, float(tscale), _capi.stream_ptr()), "aitk_timestep_embed")
+    return out
+
+
+def copy_rows(dst, src):
+    """dst[:, :] = src[:, :] for 2-D views with unit inner stride (strided rows) via hipMemcpy2DAsync."""
+    assert dst.shape == src.shape and dst.dtype == src.dtype and dst.stride(1) == 1 and src.stride(1) == 1
+    es = dst.element_size()
+    _capi.check(_capi.lib().aitk_copy2d(_ptr(dst), dst.stride(0) * es, _ptr(src), src.stride(0) * es,
+                                        dst.shape[1] * es, dst.shape[0], _capi.stream_ptr()), "aitk_copy2d")
+    return dst
+
+
+def _attn_args(q, k, v, o, lse, B, H, S, scale):
+    a = _capi.AttnArgs()
+    a.Q, a.K, a.V, a.O, a.LSE = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
+    a.ldq, a.ldk, a.ldv, a.ldo = _row_major(q, "q"), _row_major(k, "k"), _row_major(v, "v"), _row_major(o, "o")
+    assert lse.dtype == torch.float32 and lse.numel() == B * H * S
+    a.scale, a.B, a.H, a.S, a.D = scale, B, H, S, 128
+    return a
+
+
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale):
+    """q,k,v,o: 2-D [B*S, >=H*128] bf16 views (row stride = token stride); lse [B,H,S] fp32."""
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale)
+    _capi.check(_capi.lib().aitk_attn_fwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_fwd")
+    return o
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale):
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale)
+    a.dO, a.lddo = _ptr(do), _row_major(do, "do")
+    a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
+    a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")
+    delta = workspace(B * H * S * 4, q.device, "attn_delta")
+    a.delta = _ptr(delta)
+    _capi.check(_capi.lib().aitk_attn_bwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_bwd")
+
+
+def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
+    """out[Bm,N] (+)= x[Bm,K] @ w[N,K]^T + bias + t[Bm,R] @ bl[N,R]^T   (Bm <= 8)."""
+    a = _capi.GemvArgs()
+    a.ldx, a.ldw, a.ldo = _row_major(x, "x"), _row_major(w, "w"), _row_major(out, "out")
+    a.X, a.W, a.out, a.bias = _ptr(x), _ptr(w), _ptr(out), _ptr(bias)
+    a.Bm, a.K = x.shape
+    a.N = w.shape[0]
+    assert w.shape[1] == a.K and out.shape == (a.Bm, a.N)
+    if t is not None:
+        a.T, a.ldt, a.Bl, a.ldbl, a.R = _ptr(t), _row_major(t, "t"), _ptr(bl), _row_major(bl, "bl"), t.shape[1]
+    a.accumulate = int(accumulate)
+    _capi.check(_capi.lib().aitk_gemv_nt(C.byref(a), _capi.stream_ptr()), "aitk_gemv_nt")
+    return out
+
+
+def flow_noise_pack(latents, noise, t, noisy, target):
+    """latents/noise [B,C,H,W] bf16, t [B] fp32 (0..1000) -> noisy/target packed [B,(H/2)(W/2),4C] bf16."""
+    a = _capi.NoisePackArgs()
+    assert latents.is_contiguous() and noise.is_contiguous() and noisy.is_contiguous() and target.is_contiguous()
+    assert latents.dtype == BF16 and noise.dtype == BF16 and t.dtype == torch.float32
+    a.latents, a.noise, a.t, a.noisy, a.target = _ptr(latents), _ptr(noise), _ptr(t), _ptr(noisy), _ptr(target)
+    a.B, a.C, a.H, a.W = latents.shape
+    _capi.check(_capi.lib().aitk_flow_noise_pack(C.byref(a), _capi.stream_ptr()), "aitk_flow_noise_pack")
+
+
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None):
+    """loss_b = mean((pred-target)^2), loss = mean_b(w_b loss_b); dpred = dloss/dpred (bf16)."""
+    a = _capi.MseArgs()
+    B = pred.shape[0]
+    n = pred[0].numel()
+    assert pred.is_contiguous() and target.is_contiguous() and dpred.is_contiguous()
+    ws = workspace(_capi.lib().aitk_mse_workspace_bytes(B, n), pred.device, "mse")
+    a.pred, a.target, a.weight, a.dpred, a.partial = _ptr(pred), _ptr(target), _ptr(weight), _ptr(dpred), _ptr(ws)
+    a.loss_per_sample, a.loss = _ptr(loss_per_sample), _ptr(loss)
+    a.n_per_sample, a.B = n, B
+    _capi.check(_capi.lib().aitk_mse_loss_grad(C.byref(a), _capi.stream_ptr()), "aitk_mse_loss_grad")
+
+
+def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
+                   grad_scale=1.0, norm_out=None):
+    """In-place clip_grad_norm_ -> AdamW -> EMA over flat fp32 arenas (step is the 1-based AdamW step count)."""
+    a = _capi.AdamWArgs()
+    n = p.numel()
+    for t_ in (p, g, m, v):
+        assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == n
+    ws = workspace(_capi.lib().aitk_adamw_workspace_bytes(n), p.device, "adamw")
+    a.p, a.g, a.m, a.v, a.ema = _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema)
+    a.norm_partial, a.norm_out, a.n = _ptr(ws), _ptr(norm_out), n
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, beta1, beta2, eps, weight_decay
+    a.bias_correction1 = 1.0 - beta1 ** step
+    a.bias_correction2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    a.max_norm, a.ema_decay, a.grad_scale = max_norm, ema_decay, grad_scale
+    _capi.check(_capi.lib().aitk_adamw_ema_step(C.byref(a), _capi.stream_ptr()), "aitk_adamw_ema_step")
+
+
+def make_shadow_table(entries, device):
+    """entries: list of (src_off, dst_off, dstT_off, rows, cols) -> device table for refresh_shadows."""
+    arr = (_capi.ShadowDesc * len(entries))()
+    for i, (so, do, dto, r, c) in enumerate(entries):
+        arr[i].src_off, arr[i].dst_off, arr[i].dstT_off, arr[i].rows, arr[i].cols = so, do, dto, r, c
+    raw = bytes(arr)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return t, len(entries)
+
+
+def refresh_shadows(arena, shadow, table):
+    tab, n = table
+    _capi.check(_capi.lib().aitk_lora_refresh_shadows(_ptr(arena), _ptr(shadow), _ptr(tab), n, _capi.stream_ptr()),
+                "aitk_lora_refresh_shadows")

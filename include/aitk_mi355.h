@@ -58,8 +58,192 @@ typedef struct AitkGemmArgs {
 } AitkGemmArgs;
 
 int aitk_abi_version(void);
-int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs — struct-size handshake for FFI mirrors */
+int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */
 int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
+
+
+/*
+ * T[M,R] = bf16( scale * mult[m / rows_per_batch] * (X[M,K] P[R,K]^T) )     R <= 64, R % 4 == 0, K % 16 == 0
+ * forward : P = lora_down.weight            -> T   (reference: toolkit/network_mixins.py:197-239, 309-321)
+ * backward: X = dY, P = lora_up.weight^T    -> dT  (autograd of the same lines)
+ * mult may be NULL (multiplier 1); X rows may be segmented like AitkGemmArgs.A.
+ */
+typedef struct AitkLoraDownArgs {
+  const aitk_bf16* X; int64_t ldx; int32_t x_seg_rows; int32_t _pad0; int64_t x_seg_stride;
+  const aitk_bf16* P; int64_t ldp;
+  aitk_bf16* T; int64_t ldt;
+  const float* mult; float scale; int32_t rows_per_batch;
+  int32_t M, K, R, _pad1;
+} AitkLoraDownArgs;
+int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
+
+/*
+ * out[r * out_stride_r + l * out_stride_l] (+)= sum_m S[m][r] * G[m][l]        fp32 out, R in {16,32,48,64}, L % 8 == 0
+ *   lora_down.weight.grad [R,K]: S = dT, G = X,  strides (K, 1)
+ *   lora_up.weight.grad   [N,R]: S = T,  G = dY, strides (1, R)
+ * `partial` is caller-provided scratch of aitk_lora_wgrad_workspace_bytes(M,R,L) bytes.
+ */
+typedef struct AitkLoraWgradArgs {
+  const aitk_bf16* S; int64_t lds;
+  const aitk_bf16* G; int64_t ldg; int32_t g_seg_rows; int32_t _pad0; int64_t g_seg_stride;
+  float* partial;
+  float* out; int64_t out_stride_r; int64_t out_stride_l;
+  int32_t accumulate;
+  int32_t M, R, L;
+} AitkLoraWgradArgs;
+int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t L);
+int aitk_lora_wgrad(const AitkLoraWgradArgs* args, aitk_stream_t stream);
+
+
+/* ---- adaLN LayerNorm + modulate: out = LN(x; eps, no affine) * (1 + scale[b]) + shift[b],  b = m / rows_per_batch.
+ * Replaces diffusers AdaLayerNormZero/ZeroSingle/Continuous bodies reached from
+ * toolkit/stable_diffusion_model.py:2192-2205; mean/rstd (fp32 [M], may be NULL) are saved for backward. */
+typedef struct AitkLnModArgs {
+  const aitk_bf16* x; int64_t ldx;
+  const aitk_bf16* shift; const aitk_bf16* scale; int64_t ld_mod;
+  aitk_bf16* out; int64_t ld_out;
+  float* mean; float* rstd;
+  float eps; int32_t rows_per_batch; int32_t M, C;
+} AitkLnModArgs;
+int aitk_ln_mod_fwd(const AitkLnModArgs* args, aitk_stream_t stream);
+
+/* backward of the above for B batches of S rows: dx = LN'(dxn*(1+scale)) + dres (dres may be NULL or alias dx);
+ * partial (may be NULL) receives per-row-block column sums [B][nchunk][2][C] fp32 of (dshift, dscale),
+ * nchunk = ceil(S / aitk_rows_per_block()); aitk_colsum_finish reduces them. */
+typedef struct AitkLnModBwdArgs {
+  const aitk_bf16* dxn; int64_t ld_dxn;
+  const aitk_bf16* x; int64_t ldx;
+  const float* mean; const float* rstd;
+  const aitk_bf16* scale; int64_t ld_mod;
+  const aitk_bf16* dres; int64_t ld_dres;
+  aitk_bf16* dx; int64_t ld_dx;
+  float* partial;
+  int32_t S, B, C, _pad;
+} AitkLnModBwdArgs;
+int aitk_ln_mod_bwd(const AitkLnModBwdArgs* args, aitk_stream_t stream);
+int32_t aitk_rows_per_block(void);
+
+/* x_new = res + gate[b]*y  (forward is the GEMM epilogue AITK_EPI_GATE_RES):  dy = gate*dx ;
+ * partial [B][nchunk][C] fp32 = per-row-block sums of dx*y (-> dgate). */
+typedef struct AitkGateBwdArgs {
+  const aitk_bf16* dx; int64_t ld_dx;
+  const aitk_bf16* y; int64_t ld_y;
+  const aitk_bf16* gate; int64_t ld_gate;
+  aitk_bf16* dy; int64_t ld_dy;
+  float* partial;
+  int32_t S, B, C, _pad;
+} AitkGateBwdArgs;
+int aitk_gate_bwd(const AitkGateBwdArgs* args, aitk_stream_t stream);
+
+/* partial [B][nchunk][V][C] fp32 -> out_v[b*ld_out + c] bf16 (V <= 2) */
+typedef struct AitkColsumFinishArgs {
+  const float* partial;
+  aitk_bf16* out0; aitk_bf16* out1; int64_t ld_out;
+  int32_t B, nchunk, V, C;
+} AitkColsumFinishArgs;
+int aitk_colsum_finish(const AitkColsumFinishArgs* args, aitk_stream_t stream);
+
+/* ---- attention pre-processing: per-head RMSNorm(eps, weight[128]) + rotary embedding for q,k; plain copy for v
+ * (weight == NULL).  Reads src rows [B*S_src, ld_src], writes rows (b*S_dst + s_off + s) of the joint buffer.
+ * Order restated from toolkit/models/flux_sage_attn.py:36-74.  Backward uses the same struct: joint-side grads are
+ * read from `dst`, raw-side grads written to `src`, `raw` = the forward input. */
+typedef struct AitkQkvJob {
+  const aitk_bf16* src; int64_t ld_src;
+  aitk_bf16* dst; int64_t ld_dst;
+  const aitk_bf16* weight;
+  const aitk_bf16* raw; int64_t ld_raw;
+} AitkQkvJob;
+typedef struct AitkQkvPostArgs {
+  AitkQkvJob job[3];
+  const float* cos; const float* sin; /* [S_dst, 128] fp32 */
+  float eps; int32_t njobs;
+  int32_t B, H, D, S_src, S_dst, s_off;
+} AitkQkvPostArgs;
+int aitk_qkv_post_fwd(const AitkQkvPostArgs* args, aitk_stream_t stream);
+int aitk_qkv_post_bwd(const AitkQkvPostArgs* args, aitk_stream_t stream);
+
+/* small element-wise ops on [rows, C] bf16: op 0 y=silu(x); 1 y=x; 2 y=a+x */
+typedef struct AitkEwArgs {
+  const aitk_bf16* x; int64_t ldx;
+  const aitk_bf16* a; int64_t lda;
+  aitk_bf16* y; int64_t ldy;
+  int32_t rows, C, op, _pad;
+} AitkEwArgs;
+int aitk_ew(const AitkEwArgs* args, aitk_stream_t stream);
+/* out[b] = [cos(t*tscale*f_i) | sin(...)], f_i = 10000^(-i/(dim/2))   (diffusers Timesteps, flip_sin_to_cos) */
+int aitk_timestep_embed(const float* t, aitk_bf16* out, int32_t B, int32_t dim, float tscale, aitk_stream_t stream);
+int aitk_copy2d(void* dst, int64_t dst_pitch_bytes, const void* src, int64_t src_pitch_bytes, int64_t width_bytes,
+                int64_t rows, aitk_stream_t stream);
+
+
+/* ---- attention (non-causal, unmasked, head_dim 128): O = softmax(Q K^T * scale) V over [B, S, H, 128] views
+ * (row stride ld* elements, head h at column h*128).  Replaces F.scaled_dot_product_attention in the diffusers Flux
+ * attention processor (order restated in toolkit/models/flux_sage_attn.py:76-93) and its autograd backward.
+ * LSE [B,H,S] fp32 is in the scaled log2 domain: max2 + log2(sum exp2(s2 - max2)), s2 = q.k*scale*log2(e).
+ * aitk_attn_bwd needs O, LSE from forward plus dO; writes dQ,dK,dV (same layout family) and delta [B,H,S] scratch. */
+typedef struct AitkAttnArgs {
+  const aitk_bf16* Q; const aitk_bf16* K; const aitk_bf16* V; int64_t ldq, ldk, ldv;
+  aitk_bf16* O; int64_t ldo;
+  float* LSE;
+  const aitk_bf16* dO; int64_t lddo;
+  aitk_bf16* dQ; aitk_bf16* dK; aitk_bf16* dV; int64_t lddq, lddk, lddv;
+  float* delta;
+  float scale; int32_t B, H, S, D, _pad;
+} AitkAttnArgs;
+int aitk_attn_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
+int aitk_attn_bwd(const AitkAttnArgs* args, aitk_stream_t stream);
+
+
+/* ---- small-batch projection (Bm <= 8 rows): out[Bm,N] (+)= X W^T + bias + T Bl^T   (adaLN linears with LoRA, timestep /
+ * guidance / pooled-text embedders).  Same math as AitkGemmArgs, shaped for weight streaming. */
+typedef struct AitkGemvArgs {
+  const aitk_bf16* X; int64_t ldx;
+  const aitk_bf16* W; int64_t ldw;
+  const aitk_bf16* bias;
+  const aitk_bf16* T; int64_t ldt;
+  const aitk_bf16* Bl; int64_t ldbl;
+  aitk_bf16* out; int64_t ldo;
+  int32_t Bm, N, K, R;
+  int32_t accumulate; int32_t cols_per_group; /* cols_per_group: set by the library */
+} AitkGemvArgs;
+int aitk_gemv_nt(const AitkGemvArgs* args, aitk_stream_t stream);
+
+/* ---- flow-matching noise mix + 2x2 patchify (toolkit/samplers/custom_flowmatch_sampler.py:91-102,
+ * toolkit/stable_diffusion_model.py:2157-2163): noisy = (1-t/1000) x0 + (t/1000) eps, target = eps - x0, both packed
+ * [B, (H/2)(W/2), 4C] bf16. */
+typedef struct AitkNoisePackArgs {
+  const aitk_bf16* latents; const aitk_bf16* noise; const float* t;
+  aitk_bf16* noisy; aitk_bf16* target;
+  int32_t B, C, H, W;
+} AitkNoisePackArgs;
+int aitk_flow_noise_pack(const AitkNoisePackArgs* args, aitk_stream_t stream);
+
+/* ---- MSE loss (SDTrainer.py:916, 987-990, 1013) and its gradient wrt pred (bf16).  weight[b] (may be NULL) is the
+ * per-sample loss multiplier.  partial: aitk_mse_workspace_bytes() scratch. */
+typedef struct AitkMseArgs {
+  const aitk_bf16* pred; const aitk_bf16* target; const float* weight;
+  aitk_bf16* dpred; float* partial; float* loss_per_sample; float* loss;
+  int64_t n_per_sample; int32_t B, _pad;
+} AitkMseArgs;
+int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample);
+int aitk_mse_loss_grad(const AitkMseArgs* args, aitk_stream_t stream);
+
+/* ---- clip_grad_norm_(max_norm) -> torch.optim.AdamW(eps=1e-6 by default in the toolkit) -> EMA over flat fp32 arenas
+ * (SDTrainer.py:2278-2293, toolkit/optimizer.py:78-79, toolkit/ema.py:116-152).  g is multiplied by grad_scale before
+ * clipping semantics (norm_out reports ||g * grad_scale||).  norm_partial: aitk_adamw_workspace_bytes(n) scratch. */
+typedef struct AitkAdamWArgs {
+  float* p; const float* g; float* m; float* v; float* ema;
+  float* norm_partial; float* norm_partial2; float* norm_out;
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, max_norm, ema_decay, grad_scale;
+} AitkAdamWArgs;
+int64_t aitk_adamw_workspace_bytes(int64_t n);
+int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
+
+/* bf16 shadows (direct + transposed) of every LoRA matrix of the fp32 arena, refreshed after each optimizer step */
+typedef struct AitkShadowDesc { int64_t src_off; int64_t dst_off; int64_t dstT_off; int32_t rows, cols; } AitkShadowDesc;
+int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
+                              aitk_stream_t stream);
 
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);

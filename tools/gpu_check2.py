@@ -1,0 +1,360 @@
+"""GPU battery #2: LoRA skinny kernels, norm/elementwise kernels, attention fwd/bwd vs fp32 torch math."""
+import json
+import math
+import os
+import sys
+import time
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import ai_toolkit_amd  # noqa: E402,F401
+from ai_toolkit_amd import ops  # noqa: E402
+
+OUT = {}
+dev = "cuda"
+bf = torch.bfloat16
+
+
+def rec(name, fn):
+    t0 = time.time()
+    try:
+        OUT[name] = fn()
+    except Exception as e:  # noqa: BLE001
+        OUT[name] = {"ok": False, "error": repr(e), "tb": traceback.format_exc()[-1200:]}
+    OUT[name]["secs"] = round(time.time() - t0, 3)
+    print(name, json.dumps(OUT[name])[:500], flush=True)
+
+
+def rel(x, ref):
+    x, ref = x.float(), ref.float()
+    return ((x - ref).norm() / (ref.norm() + 1e-30)).item()
+
+
+def R(*shape, s=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * s)
+
+
+def t_lora_down(M, K, Rk, mult=False, seg=False):
+    x = R(M, K, seed=1).to(bf).to(dev)
+    pm = R(Rk, K, s=0.05, seed=2).to(bf).to(dev)
+    out = torch.full((M, Rk), float("nan"), dtype=bf, device=dev)
+    kw = {}
+    ref = x.float() @ pm.float().t() * 0.5
+    if mult:
+        nb = 2
+        m = torch.tensor([0.7, -1.3], device=dev)
+        kw = dict(mult=m, rows_per_batch=M // nb)
+        ref = ref * m.repeat_interleave(M // nb)[:, None]
+    if seg:
+        half = M // 2
+        buf = torch.zeros(2, half + 3, K, dtype=bf, device=dev)
+        buf[:, 1:1 + half] = x.view(2, half, K)
+        ops.lora_down(buf[0, 1:], pm, out, scale=0.5, x_seg=(half, (half + 3) * K), M=M, **kw)
+    else:
+        ops.lora_down(x, pm, out, scale=0.5, **kw)
+    torch.cuda.synchronize()
+    e = rel(out, ref)
+    return {"rel_err": e, "ok": e < 5e-3}
+
+
+def t_lora_wgrad(M, Rk, L, transpose=False, accumulate=False):
+    s = R(M, Rk, seed=3).to(bf).to(dev)
+    g = R(M, L, seed=4).to(bf).to(dev)
+    ref = s.float().t() @ g.float()
+    if transpose:
+        out = torch.full((L, Rk), 2.0 if accumulate else float("nan"), device=dev)
+        ref = ref.t()
+    else:
+        out = torch.full((Rk, L), 2.0 if accumulate else float("nan"), device=dev)
+    if accumulate:
+        ref = ref + 2.0
+    ops.lora_wgrad(s, g, out, transpose_out=transpose, accumulate=accumulate)
+    torch.cuda.synchronize()
+    e = rel(out, ref)
+    return {"rel_err": e, "ok": e < 1e-4}
+
+
+def t_ln_mod(B, S, Cc):
+    M = B * S
+    x = (R(M, Cc, seed=5) * 2 + 0.3).to(bf).to(dev)
+    mod = R(B, 3 * Cc, s=0.5, seed=6).to(bf).to(dev)
+    shift, scale = mod[:, :Cc], mod[:, Cc:2 * Cc]
+    out = torch.empty(M, Cc, dtype=bf, device=dev)
+    mean = torch.empty(M, device=dev)
+    rstd = torch.empty(M, device=dev)
+    ops.ln_mod_fwd(x, shift, scale, out, rows_per_batch=S, mean=mean, rstd=rstd)
+    xf = x.float().view(B, S, Cc).requires_grad_(True)
+    shf = shift.float().requires_grad_(True)
+    scf = scale.float().requires_grad_(True)
+    ref = F.layer_norm(xf, (Cc,), eps=1e-6) * (1 + scf[:, None]) + shf[:, None]
+    e_f = rel(out.view(B, S, Cc), ref)
+    dxn = R(M, Cc, seed=7).to(bf).to(dev)
+    dres = R(M, Cc, seed=8).to(bf).to(dev)
+    ref.backward(dxn.float().view(B, S, Cc))
+    dx = torch.empty(M, Cc, dtype=bf, device=dev)
+    dmod = torch.zeros(B, 2 * Cc, dtype=bf, device=dev)
+    ops.ln_mod_bwd(dxn, x, mean, rstd, scale, dx, B=B, S=S, dres=dres, dshift=dmod[:, :Cc], dscale=dmod[:, Cc:])
+    torch.cuda.synchronize()
+    e_dx = rel(dx, xf.grad.view(M, Cc) + dres.float())
+    e_sh = rel(dmod[:, :Cc], shf.grad)
+    e_sc = rel(dmod[:, Cc:], scf.grad)
+    return {"fwd": e_f, "dx": e_dx, "dshift": e_sh, "dscale": e_sc, "ok": max(e_f, e_dx, e_sh, e_sc) < 6e-3}
+
+
+def t_gate_bwd(B, S, Cc):
+    M = B * S
+    dx = R(M, Cc, seed=9).to(bf).to(dev)
+    y = R(M, Cc, seed=10).to(bf).to(dev)
+    gate = R(B, Cc, seed=11).to(bf).to(dev)
+    dy = torch.empty(M, Cc, dtype=bf, device=dev)
+    dgate = torch.empty(B, Cc, dtype=bf, device=dev)
+    ops.gate_bwd(dx, y, gate, dy, dgate, B=B, S=S)
+    torch.cuda.synchronize()
+    ref_dy = gate.float().repeat_interleave(S, 0) * dx.float()
+    ref_dg = (dx.float() * y.float()).view(B, S, Cc).sum(1)
+    e1, e2 = rel(dy, ref_dy), rel(dgate, ref_dg)
+    return {"dy": e1, "dgate": e2, "ok": max(e1, e2) < 6e-3}
+
+
+def rope_tables(S, seed=12):
+    ang = R(S, 64, s=3.0, seed=seed)
+    return ang.cos().repeat_interleave(2, 1).contiguous().to(dev), ang.sin().repeat_interleave(2, 1).contiguous().to(dev)
+
+
+def ref_norm_rope(x, w, cos, sin):
+    # x [B,S,H,128] fp32 (bf16-valued); mirrors diffusers RMSNorm + apply_rotary_emb rounding points
+    var = x.pow(2).mean(-1, keepdim=True)
+    t = (x * torch.rsqrt(var + 1e-6)).to(bf) * w.to(bf)
+    tf = t.float()
+    xr, xi = tf.reshape(*tf.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], -1).flatten(-2)
+    return tf * cos[None, :, None, :] + rot * sin[None, :, None, :]
+
+
+def t_qkv_post(B, S_txt, S_img, H):
+    S = S_txt + S_img
+    cos, sin = rope_tables(S)
+    ld = 3 * H * 128
+    raw_img = R(B * S_img, ld, seed=13).to(bf).to(dev)
+    raw_txt = R(B * S_txt, ld, seed=14).to(bf).to(dev)
+    wq = (1 + 0.1 * R(128, seed=15)).to(bf).to(dev)
+    wk = (1 + 0.1 * R(128, seed=16)).to(bf).to(dev)
+    joint = torch.full((B * S, ld), float("nan"), dtype=bf, device=dev)
+    HD = H * 128
+    for raw, Ss, off in ((raw_txt, S_txt, 0), (raw_img, S_img, S_txt)):
+        jobs = [dict(src=raw[:, :HD], dst=joint[:, :HD], weight=wq), dict(src=raw[:, HD:2 * HD], dst=joint[:, HD:2 * HD], weight=wk),
+                dict(src=raw[:, 2 * HD:], dst=joint[:, 2 * HD:], weight=None)]
+        ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=off)
+    torch.cuda.synchronize()
+    rawj = torch.cat([raw_txt.view(B, S_txt, ld), raw_img.view(B, S_img, ld)], 1).float().requires_grad_(True)
+    q_ref = ref_norm_rope(rawj[..., :HD].reshape(B, S, H, 128), wq.float(), cos, sin)
+    k_ref = ref_norm_rope(rawj[..., HD:2 * HD].reshape(B, S, H, 128), wk.float(), cos, sin)
+    jv = joint.view(B, S, ld)
+    e_q = rel(jv[..., :HD].reshape(B, S, H, 128), q_ref)
+    e_k = rel(jv[..., HD:2 * HD].reshape(B, S, H, 128), k_ref)
+    e_v = rel(jv[..., 2 * HD:], rawj[..., 2 * HD:])
+    # backward (reference without the bf16 rounding points so autograd is smooth)
+    gj = R(B * S, ld, seed=17).to(bf).to(dev)
+    def smooth(x, w):
+        var = x.pow(2).mean(-1, keepdim=True)
+        t = x * torch.rsqrt(var + 1e-6) * w
+        xr, xi = t.reshape(*t.shape[:-1], -1, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], -1).flatten(-2)
+        return t * cos[None, :, None, :] + rot * sin[None, :, None, :]
+    qs = smooth(rawj[..., :HD].reshape(B, S, H, 128), wq.float())
+    ks = smooth(rawj[..., HD:2 * HD].reshape(B, S, H, 128), wk.float())
+    gjv = gj.float().view(B, S, ld)
+    loss = (qs * gjv[..., :HD].reshape(B, S, H, 128)).sum() + (ks * gjv[..., HD:2 * HD].reshape(B, S, H, 128)).sum() + (rawj[..., 2 * HD:] * gjv[..., 2 * HD:]).sum()
+    loss.backward()
+    g_img = torch.full((B * S_img, ld), float("nan"), dtype=bf, device=dev)
+    g_txt = torch.full((B * S_txt, ld), float("nan"), dtype=bf, device=dev)
+    for graw, raw, Ss, off in ((g_txt, raw_txt, S_txt, 0), (g_img, raw_img, S_img, S_txt)):
+        jobs = [dict(src=graw[:, :HD], dst=gj[:, :HD], weight=wq, raw=raw[:, :HD]), dict(src=graw[:, HD:2 * HD], dst=gj[:, HD:2 * HD], weight=wk, raw=raw[:, HD:2 * HD]),
+                dict(src=graw[:, 2 * HD:], dst=gj[:, 2 * HD:], weight=None)]
+        ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=off)
+    torch.cuda.synchronize()
+    gref = rawj.grad
+    e_gt = rel(g_txt.view(B, S_txt, ld), gref[:, :S_txt])
+    e_gi = rel(g_img.view(B, S_img, ld), gref[:, S_txt:])
+    return {"q": e_q, "k": e_k, "v": e_v, "g_txt": e_gt, "g_img": e_gi, "ok": max(e_q, e_k, e_gt, e_gi) < 8e-3 and e_v == 0.0}
+
+
+def t_small():
+    x = R(3, 256, seed=20).to(bf).to(dev)
+    y = torch.empty_like(x)
+    ops.ew(0, x, y)
+    e0 = rel(y, F.silu(x.float()))
+    a = R(3, 256, seed=21).to(bf).to(dev)
+    ops.ew(2, x, y, a=a)
+    e2 = rel(y, x.float() + a.float())
+    t = torch.tensor([0.0, 500.0, 999.0], device=dev)
+    te = torch.empty(3, 256, dtype=bf, device=dev)
+    ops.timestep_embed(t, te)
+    half = 128
+    ex = -math.log(10000) * torch.arange(half, device=dev, dtype=torch.float32) / half
+    em = t[:, None] * torch.exp(ex)[None]
+    ref = torch.cat([em.cos(), em.sin()], -1)
+    et = (te.float() - ref).abs().max().item()
+    src = R(6, 40, seed=22).to(bf).to(dev)
+    dst = torch.zeros(6, 64, dtype=bf, device=dev)
+    ops.copy_rows(dst[:, 8:48], src)
+    torch.cuda.synchronize()
+    ec = float((dst[:, 8:48] != src).sum().item() + (dst[:, :8] != 0).sum().item() + (dst[:, 48:] != 0).sum().item())
+    return {"silu": e0, "add": e2, "temb_maxabs": et, "copy_bad": ec, "ok": e0 < 5e-3 and e2 < 5e-3 and et < 2e-2 and ec == 0}
+
+
+def t_attn(B, H, S, bwd=True, ldmul=3):
+    HD = H * 128
+    ld = ldmul * HD
+    qkv = R(B * S, ld, s=1.0, seed=30).to(bf).to(dev)
+    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, (ldmul - 1) * HD:]
+    o = torch.full((B * S, HD), float("nan"), dtype=bf, device=dev)
+    lse = torch.empty(B, H, S, device=dev)
+    scale = 1.0 / math.sqrt(128)
+    ops.attn_fwd(q, k, v, o, lse, B=B, H=H, S=S, scale=scale)
+    torch.cuda.synchronize()
+    def heads(t):
+        return t.float().reshape(B, S, H, 128).transpose(1, 2)
+    qf, kf, vf = heads(q).requires_grad_(True), heads(k).requires_grad_(True), heads(v).requires_grad_(True)
+    sc = (qf @ kf.transpose(-1, -2)) * scale
+    pr = sc.softmax(-1)
+    oref = pr @ vf
+    e_o = rel(heads(o), oref)
+    lse_ref = torch.logsumexp(sc, -1) / math.log(2)
+    e_l = (lse - lse_ref).abs().max().item()
+    res = {"o": e_o, "lse_maxabs": e_l}
+    ok = e_o < 1e-2 and e_l < 2e-2
+    if bwd:
+        do = R(B * S, HD, seed=31).to(bf).to(dev)
+        oref.backward(heads(do))
+        dqkv = torch.full((B * S, 3 * HD), float("nan"), dtype=bf, device=dev)
+        ops.attn_bwd(q, k, v, o, lse, do, dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], B=B, H=H, S=S, scale=scale)
+        torch.cuda.synchronize()
+        res["dq"] = rel(heads(dqkv[:, :HD]), qf.grad)
+        res["dk"] = rel(heads(dqkv[:, HD:2 * HD]), kf.grad)
+        res["dv"] = rel(heads(dqkv[:, 2 * HD:]), vf.grad)
+        ok = ok and max(res["dq"], res["dk"], res["dv"]) < 2e-2
+    res["ok"] = ok
+    return res
+
+
+def bench_attn(B, H, S, iters=10):
+    HD = H * 128
+    qkv = torch.randn(B * S, 3 * HD, device=dev).to(bf)
+    q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+    o = torch.empty(B * S, HD, dtype=bf, device=dev)
+    do = torch.randn(B * S, HD, device=dev).to(bf)
+    dqkv = torch.empty_like(qkv)
+    lse = torch.empty(B, H, S, device=dev)
+    scale = 1.0 / math.sqrt(128)
+    def run_f():
+        ops.attn_fwd(q, k, v, o, lse, B=B, H=H, S=S, scale=scale)
+    def run_b():
+        ops.attn_bwd(q, k, v, o, lse, do, dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], B=B, H=H, S=S, scale=scale)
+    res = {}
+    for name, fn, mult in (("fwd", run_f, 4.0), ("bwd", run_b, 10.0)):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res[name + "_ms"] = ms
+        res[name + "_tflops_alg"] = mult * B * H * S * S * 128 / ms / 1e9
+    qh = q.reshape(B, S, H, 128).transpose(1, 2)
+    kh = k.reshape(B, S, H, 128).transpose(1, 2)
+    vh = v.reshape(B, S, H, 128).transpose(1, 2)
+    for _ in range(2):
+        F.scaled_dot_product_attention(qh, kh, vh)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        F.scaled_dot_product_attention(qh, kh, vh)
+    e1.record()
+    torch.cuda.synchronize()
+    res["torch_sdpa_fwd_ms"] = e0.elapsed_time(e1) / iters
+    res["ok"] = True
+    return res
+
+
+def bench_misc():
+    res = {}
+    M, K = 4608, 3072
+    x = torch.randn(M, K, device=dev).to(bf)
+    pm = torch.randn(16, K, device=dev).to(bf)
+    t = torch.empty(M, 16, dtype=bf, device=dev)
+    g = torch.empty(16, K, device=dev)
+    mod = torch.randn(1, 2 * K, device=dev).to(bf)
+    out = torch.empty_like(x)
+    mean = torch.empty(M, device=dev)
+    rstd = torch.empty(M, device=dev)
+    dm = torch.empty(1, 2 * K, dtype=bf, device=dev)
+    fns = {
+        "lora_down_4608x3072_r16": (lambda: ops.lora_down(x, pm, t), M * K * 2),
+        "lora_wgrad_4608x3072_r16": (lambda: ops.lora_wgrad(t, x, g), M * K * 2),
+        "ln_mod_fwd_4608x3072": (lambda: ops.ln_mod_fwd(x, mod[:, :K], mod[:, K:], out, rows_per_batch=M, mean=mean, rstd=rstd), M * K * 4),
+        "ln_mod_bwd_4608x3072": (lambda: ops.ln_mod_bwd(out, x, mean, rstd, mod[:, K:], out, B=1, S=M, dres=x, dshift=dm[:, :K], dscale=dm[:, K:]), M * K * 8),
+    }
+    for name, (fn, nbytes) in fns.items():
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res[name] = {"ms": ms, "GBps": nbytes / ms / 1e6}
+    res["ok"] = True
+    return res
+
+
+def main():
+    only = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None
+    def want(k):
+        return only is None or k in only
+    if want("skinny"):
+        rec("lora_down_r16", lambda: t_lora_down(4608, 3072, 16))
+        rec("lora_down_r16_ragged", lambda: t_lora_down(1000, 12288, 16))
+        rec("lora_down_r48_mult", lambda: t_lora_down(512, 3072, 48, mult=True))
+        rec("lora_down_r64_seg", lambda: t_lora_down(600, 1024, 64, seg=True))
+        rec("lora_down_smallM", lambda: t_lora_down(2, 18432, 16))
+        rec("lora_wgrad_r16", lambda: t_lora_wgrad(4608, 16, 3072))
+        rec("lora_wgrad_r16_T", lambda: t_lora_wgrad(1000, 16, 3072, transpose=True))
+        rec("lora_wgrad_r48_acc", lambda: t_lora_wgrad(700, 48, 1024, accumulate=True))
+        rec("lora_wgrad_r64", lambda: t_lora_wgrad(300, 64, 520))
+        rec("lora_wgrad_smallM", lambda: t_lora_wgrad(2, 16, 18432, transpose=True))
+    if want("norm"):
+        rec("ln_mod_2x200x3072", lambda: t_ln_mod(2, 200, 3072))
+        rec("ln_mod_1x37x1536", lambda: t_ln_mod(1, 37, 1536))
+        rec("gate_bwd", lambda: t_gate_bwd(2, 200, 3072))
+        rec("qkv_post", lambda: t_qkv_post(2, 24, 100, 4))
+        rec("small_ops", t_small)
+    if want("attn"):
+        rec("attn_fwd_1x2x256", lambda: t_attn(1, 2, 256, bwd=False))
+        rec("attn_1x2x256", lambda: t_attn(1, 2, 256))
+        rec("attn_2x3x200_ragged", lambda: t_attn(2, 3, 200))
+        rec("attn_1x2x1111", lambda: t_attn(1, 2, 1111))
+        rec("attn_1x4x4608", lambda: t_attn(1, 4, 4608))
+    if want("bench"):
+        rec("bench_attn_1x24x4608", lambda: bench_attn(1, 24, 4608))
+        rec("bench_misc", bench_misc)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/gpu_check2.json", "w") as fh:
+        json.dump(OUT, fh, indent=1)
+    print("FAILED:", [k for k, v in OUT.items() if not v.get("ok")])
+
+
+if __name__ == "__main__":
+    main()
