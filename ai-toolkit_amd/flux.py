@@ -1,0 +1,580 @@
+"""FLUX.1 DiT forward / backward as an explicit op graph over the gfx950 kernels (host logic only).
+
+Module tree, class names and parameter names are those of diffusers' FluxTransformer2DModel (the class the reference
+loads at toolkit/stable_diffusion_model.py:667-673 and calls at 2192-2205), so diffusers checkpoints load by key and
+the LoRA network produces the reference's state-dict keys.  The forward below restates the same computation as
+oracle/flux_ref.py, but every arithmetic step is one C-ABI kernel call (ai-toolkit_amd/ops.py):
+
+  Linear (+LoRA)  -> lora_down (skinny) + gemm_nt with the rank-r K-slab and fused epilogue (bias / GELU / gate-residual)
+  adaLN           -> gemv_nt (B rows) + ln_mod_fwd
+  attention       -> qkv_post_fwd (per-head RMSNorm + RoPE into the joint [txt|img] buffer) + attn_fwd
+and the backward is written out explicitly (no autograd inside): dgrad GEMMs against pre-transposed frozen weights
+(2x weight memory — 48 GB of the 288 GB HBM — buys a single NT kernel for fwd and dgrad), LoRA weight gradients by
+lora_wgrad straight into the flat fp32 gradient arena, all activations kept resident (no gradient checkpointing).
+
+`ops` is the kernel table: ai_toolkit_amd.ops on MI355X.  Tests inject oracle/ref_ops.py (same signatures, plain
+torch) to check this host logic against autograd of the oracle on CPU; the product never does.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 2, 4, 8, 16
+
+
+# ============================================================================================ module tree (names only)
+class Linear(nn.Module):
+    """Frozen base projection: holds weight [out,in] / bias in the model dtype; `lora` is set by LoRAModule.apply_to."""
+
+    def __init__(self, in_features, out_features, bias=True, dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(out_features, dtype=dtype, device=device), requires_grad=False) if bias else None
+        self.lora = None
+        self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
+
+    def forward(self, x):
+        raise RuntimeError("fused path: Linear is executed inside FluxTransformer2DModel.forward")
+
+
+class RMSNormW(nn.Module):
+    def __init__(self, dim, dtype, device):
+        super().__init__()
+        self.eps = 1e-6
+        self.weight = nn.Parameter(torch.ones(dim, dtype=dtype, device=device), requires_grad=False)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _ada(dim, mult, dtype, device):
+    h = _Holder()
+    h.linear = Linear(dim, mult * dim, True, dtype, device)
+    return h
+
+
+def _attention(dim, heads, dim_head, added_kv, pre_only, dtype, device):
+    a = _Holder()
+    inner = heads * dim_head
+    a.norm_q = RMSNormW(dim_head, dtype, device)
+    a.norm_k = RMSNormW(dim_head, dtype, device)
+    a.to_q = Linear(dim, inner, True, dtype, device)
+    a.to_k = Linear(dim, inner, True, dtype, device)
+    a.to_v = Linear(dim, inner, True, dtype, device)
+    if added_kv:
+        a.add_k_proj = Linear(dim, inner, True, dtype, device)
+        a.add_v_proj = Linear(dim, inner, True, dtype, device)
+        a.add_q_proj = Linear(dim, inner, True, dtype, device)
+        a.norm_added_q = RMSNormW(dim_head, dtype, device)
+        a.norm_added_k = RMSNormW(dim_head, dtype, device)
+    if not pre_only:
+        a.to_out = nn.ModuleList([Linear(inner, dim, True, dtype, device), nn.Identity()])
+    if added_kv:
+        a.to_add_out = Linear(inner, dim, True, dtype, device)
+    return a
+
+
+def _ff(dim, dtype, device):
+    f = _Holder()
+    g = _Holder()
+    g.proj = Linear(dim, 4 * dim, True, dtype, device)
+    f.net = nn.ModuleList([g, nn.Identity(), Linear(4 * dim, dim, True, dtype, device)])
+    return f
+
+
+class FluxTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, dtype, device):
+        super().__init__()
+        self.norm1 = _ada(dim, 6, dtype, device)
+        self.norm1_context = _ada(dim, 6, dtype, device)
+        self.attn = _attention(dim, heads, dim_head, True, False, dtype, device)
+        self.ff = _ff(dim, dtype, device)
+        self.ff_context = _ff(dim, dtype, device)
+
+
+class FluxSingleTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, dtype, device):
+        super().__init__()
+        self.norm = _ada(dim, 3, dtype, device)
+        self.proj_mlp = Linear(dim, 4 * dim, True, dtype, device)
+        self.proj_out = Linear(5 * dim, dim, True, dtype, device)
+        self.attn = _attention(dim, heads, dim_head, False, True, dtype, device)
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim, dtype, device):
+        super().__init__()
+        self.linear_1 = Linear(cin, dim, True, dtype, device)
+        self.linear_2 = Linear(dim, dim, True, dtype, device)
+
+
+class _TextProj(nn.Module):
+    def __init__(self, cin, dim, dtype, device):
+        super().__init__()
+        self.linear_1 = Linear(cin, dim, True, dtype, device)
+        self.linear_2 = Linear(dim, dim, True, dtype, device)
+
+
+class FluxTransformer2DModel(nn.Module):
+    def __init__(self, in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128,
+                 num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
+                 axes_dims_rope=(16, 56, 56), dtype=torch.bfloat16, device=None, ops=None):
+        super().__init__()
+        assert attention_head_dim == 128, "attention kernels are specialised for head_dim 128"
+        assert guidance_embeds
+        self.config = dict(in_channels=in_channels, num_layers=num_layers, num_single_layers=num_single_layers,
+                           attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
+                           joint_attention_dim=joint_attention_dim, pooled_projection_dim=pooled_projection_dim,
+                           guidance_embeds=guidance_embeds, axes_dims_rope=tuple(axes_dims_rope))
+        self.heads, self.dim = num_attention_heads, num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.dt = dtype
+        d = self.dim
+        tte = _Holder()
+        tte.timestep_embedder = _TimestepEmbedding(256, d, dtype, device)
+        tte.guidance_embedder = _TimestepEmbedding(256, d, dtype, device)
+        tte.text_embedder = _TextProj(pooled_projection_dim, d, dtype, device)
+        self.time_text_embed = tte
+        self.context_embedder = Linear(joint_attention_dim, d, True, dtype, device)
+        self.x_embedder = Linear(in_channels, d, True, dtype, device)
+        self.transformer_blocks = nn.ModuleList(
+            [FluxTransformerBlock(d, num_attention_heads, attention_head_dim, dtype, device) for _ in range(num_layers)])
+        self.single_transformer_blocks = nn.ModuleList(
+            [FluxSingleTransformerBlock(d, num_attention_heads, attention_head_dim, dtype, device) for _ in range(num_single_layers)])
+        self.norm_out = _ada(d, 2, dtype, device)
+        self.proj_out = Linear(d, in_channels, True, dtype, device)
+        self.ops = ops
+        self.network = None
+        self._rope_cache = {}
+        self._prepared = False
+        self.ctx = None
+
+    # ------------------------------------------------------------------ setup
+    def set_ops(self, ops):
+        self.ops = ops
+
+    def attach_network(self, network):
+        self.network = network
+
+    def prepare(self):
+        """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""
+        need_t = []
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            need_t += [a.to_q, a.to_k, a.to_v, a.add_q_proj, a.add_k_proj, a.add_v_proj, a.to_out[0], a.to_add_out,
+                       blk.ff.net[0].proj, blk.ff.net[2], blk.ff_context.net[0].proj, blk.ff_context.net[2]]
+        for blk in self.single_transformer_blocks:
+            a = blk.attn
+            need_t += [a.to_q, a.to_k, a.to_v, blk.proj_mlp, blk.proj_out]
+        need_t.append(self.proj_out)
+        for lin in need_t:
+            lin.weight_t = lin.weight.data.t().contiguous()
+        self._prepared = True
+        return self
+
+    def rope_tables(self, img_ids, txt_ids):
+        """FluxPosEmbed in float64 on the host, cached per (shape) bucket; fp32 [S, 128] cos/sin on device."""
+        key = (tuple(img_ids.shape), tuple(txt_ids.shape), float(img_ids.sum()), float(img_ids[-1].sum()))
+        hit = self._rope_cache.get(key)
+        if hit is not None:
+            return hit
+        ids = torch.cat((txt_ids, img_ids), dim=0).to("cpu", torch.float64)
+        cos_out, sin_out = [], []
+        for i, dd in enumerate(self.config["axes_dims_rope"]):
+            freqs = 1.0 / (10000.0 ** (torch.arange(0, dd, 2, dtype=torch.float64)[: dd // 2] / dd))
+            ang = torch.outer(ids[:, i], freqs)
+            cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+            sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+        dev = self.x_embedder.weight.device
+        out = (torch.cat(cos_out, -1).contiguous().to(dev), torch.cat(sin_out, -1).contiguous().to(dev))
+        self._rope_cache[key] = out
+        return out
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dt, device=self.x_embedder.weight.device)
+
+    def _lora_active(self, lin):
+        net = self.network
+        return (lin.lora is not None and net is not None and net.is_active and not net.is_merged_in
+                and net._multiplier != 0)
+
+    def _mult(self, rows_per_batch, B):
+        """per-sample multiplier vector (network.torch_multiplier, shape [1] or [B]) -> (tensor|None, rows_per_batch)."""
+        tm = self.network.torch_multiplier
+        if tm.numel() == 1:
+            mv = self.network._multiplier
+            if float(mv[0] if isinstance(mv, (list, tuple)) else mv) == 1.0:
+                return None, 0
+            tm = tm.expand(B).contiguous()
+        elif tm.numel() != B:
+            tm = tm.repeat_interleave(B // tm.numel()).contiguous()
+        return tm, rows_per_batch
+
+    def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
+                 a_seg=None, c_seg=None):
+        """out = epi(x W^T + b + T B^T); returns T (saved for the weight gradient) or None."""
+        ops = self.ops
+        T = None
+        kw = {}
+        if self._lora_active(lin):
+            lo = lin.lora
+            T = self._new(M, lo.lora_dim)
+            mult, rpb = self._mult(rows_per_batch, B)
+            ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
+            kw = dict(a2=T, b2=lo.sh_up)
+        ops.gemm_nt(x, lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out, aux_in=aux_in, gate=gate,
+                    gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
+        return T
+
+    def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None):
+        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None."""
+        if T is None:
+            return None
+        ops = self.ops
+        lo = lin.lora
+        dT = self._new(M, lo.lora_dim)
+        mult, rpb = self._mult(rows_per_batch, B)
+        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
+        ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M)
+        ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
+        return dT
+
+    def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
+        """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""
+        kw = {}
+        if dT is not None:
+            shT = lin.lora.sh_downT
+            kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
+        wt = lin.weight_t if w_rows is None else lin.weight_t[w_rows[0]:w_rows[1]]
+        self.ops.gemm_nt(dy, wt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, **kw)
+
+    def _lin_bwd(self, lin, dy, T, x_in, dx, *, M, rows_per_batch, B, flags=0, aux_in=None, x_seg=None, dx_seg=None):
+        dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, x_seg=x_seg)
+        self._lin_dgrad(lin, dy, dT, dx, M=M, flags=flags, aux_in=aux_in, dx_seg=dx_seg)
+
+    def _ada_fwd(self, ada_lin, silu_temb, B):
+        """mod[B, k*dim] = linear(silu(temb)) (+LoRA): small-batch GEMV; returns (mod, T)."""
+        ops = self.ops
+        mod = self._new(B, ada_lin.out_features)
+        T = None
+        kw = {}
+        if self._lora_active(ada_lin):
+            lo = ada_lin.lora
+            T = self._new(B, lo.lora_dim)
+            mult, rpb = self._mult(1, B)
+            ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
+            kw = dict(t=T, bl=lo.sh_up)
+        ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, **kw)
+        return mod, T
+
+    def _ada_bwd(self, ada_lin, dmod, T, silu_temb, B):
+        """Only the adapter gradients: temb has no trainable ancestor, so no data gradient is propagated."""
+        if T is None:
+            return
+        ops = self.ops
+        lo = ada_lin.lora
+        dT = self._new(B, lo.lora_dim)
+        mult, rpb = self._mult(1, B)
+        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
+        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B)
+        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance,
+                return_dict=False, **kwargs):
+        pred = self.forward_native(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                                   guidance, save_for_backward=torch.is_grad_enabled())
+        if torch.is_grad_enabled() and self.network is not None and self.network.is_active:
+            pred = _FluxGraphFn.apply(pred, self, self.network.arena_p.requires_grad_(True))
+        return (pred,)
+
+    def forward_native(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
+                       guidance, save_for_backward=True):
+        ops, dt, d, H = self.ops, self.dt, self.dim, self.heads
+        if not self._prepared:
+            self.prepare()
+        B, Si, Cin = hidden_states.shape
+        St = encoder_hidden_states.shape[1]
+        S = St + Si
+        Mi, Mt, Mj = B * Si, B * St, B * S
+        cos, sin = self.rope_tables(img_ids, txt_ids)
+        scale = 1.0 / math.sqrt(128.0)
+        ctx = {"B": B, "Si": Si, "St": St, "cos": cos, "sin": sin, "dbl": [], "sgl": []} if save_for_backward else None
+
+        # ---- conditioning vector (no trainable ancestors; nothing saved)
+        tte = self.time_text_embed
+        # the pinned diffusers casts timestep/guidance to the model dtype BEFORE the *1000
+        t_eff = (timestep.to(dt) * 1000).float().contiguous()
+        g_eff = (guidance.to(dt) * 1000).float().contiguous()
+        temb = self._new(B, d)
+        first = True
+        for emb, src in ((tte.timestep_embedder, t_eff), (tte.guidance_embedder, g_eff)):
+            proj = self._new(B, 256)
+            ops.timestep_embed(src, proj)
+            h1 = self._new(B, d)
+            ops.gemv_nt(proj, emb.linear_1.weight, h1, bias=emb.linear_1.bias)
+            ops.ew(0, h1, h1)
+            ops.gemv_nt(h1, emb.linear_2.weight, temb, bias=emb.linear_2.bias, accumulate=not first)
+            first = False
+        h1 = self._new(B, d)
+        pooled = pooled_projections.to(dt).contiguous()
+        ops.gemv_nt(pooled, tte.text_embedder.linear_1.weight, h1, bias=tte.text_embedder.linear_1.bias)
+        ops.ew(0, h1, h1)
+        ops.gemv_nt(h1, tte.text_embedder.linear_2.weight, temb, bias=tte.text_embedder.linear_2.bias, accumulate=True)
+        silu_temb = self._new(B, d)
+        ops.ew(0, temb, silu_temb)
+
+        # ---- token embedders
+        x_img = self._new(Mi, d)
+        ops.gemm_nt(hidden_states.to(dt).reshape(Mi, Cin), self.x_embedder.weight, x_img, bias=self.x_embedder.bias)
+        x_txt = self._new(Mt, d)
+        ops.gemm_nt(encoder_hidden_states.to(dt).reshape(Mt, -1), self.context_embedder.weight, x_txt,
+                    bias=self.context_embedder.bias)
+
+        # ---- double-stream blocks
+        for blk in self.transformer_blocks:
+            rec = {}
+            qkv_j = self._new(Mj, 3 * d)
+            o_j = self._new(Mj, d)
+            lse = self._new(B, H, S, dtype=torch.float32)
+            streams = (("img", x_img, Mi, Si, St, blk.norm1, (blk.attn.to_q, blk.attn.to_k, blk.attn.to_v),
+                        (blk.attn.norm_q, blk.attn.norm_k)),
+                       ("txt", x_txt, Mt, St, 0, blk.norm1_context,
+                        (blk.attn.add_q_proj, blk.attn.add_k_proj, blk.attn.add_v_proj),
+                        (blk.attn.norm_added_q, blk.attn.norm_added_k)))
+            for name, x, M, Ss, s_off, norm1, qkv_lins, qk_norms in streams:
+                r = {}
+                mod, r["T_mod"] = self._ada_fwd(norm1.linear, silu_temb, B)
+                r["mod"] = mod
+                mean, rstd = self._new(M, dtype=torch.float32), self._new(M, dtype=torch.float32)
+                xn = self._new(M, d)
+                ops.ln_mod_fwd(x, mod[:, 0:d], mod[:, d:2 * d], xn, rows_per_batch=Ss, mean=mean, rstd=rstd)
+                qkv_raw = self._new(M, 3 * d)
+                r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=M, rows_per_batch=Ss, B=B)
+                              for j, lin in enumerate(qkv_lins)]
+                jobs = [dict(src=qkv_raw[:, 0:d], dst=qkv_j[:, 0:d], weight=qk_norms[0].weight),
+                        dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=qk_norms[1].weight),
+                        dict(src=qkv_raw[:, 2 * d:], dst=qkv_j[:, 2 * d:], weight=None)]
+                ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=s_off)
+                r.update(x=x, mean1=mean, rstd1=rstd, xn=xn, qkv_raw=qkv_raw)
+                rec[name] = r
+            ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], o_j, lse, B=B, H=H, S=S, scale=scale)
+            rec.update(qkv_j=qkv_j, o_j=o_j, lse=lse)
+            outs = {}
+            for name, M, Ss, s_off, out_lin, ff in (("img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
+                                                     ("txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)):
+                r = rec[name]
+                mod, x = r["mod"], r["x"]
+                seg = (Ss, S * d)
+                o_view = o_j[s_off:]
+                y_attn = self._new(M, d)
+                x1 = self._new(M, d)
+                r["T_o"] = self._lin_fwd(out_lin, o_view, x1, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
+                                         aux_out=y_attn, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=Ss, a_seg=seg)
+                mean, rstd = self._new(M, dtype=torch.float32), self._new(M, dtype=torch.float32)
+                xn2 = self._new(M, d)
+                ops.ln_mod_fwd(x1, mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], xn2, rows_per_batch=Ss, mean=mean, rstd=rstd)
+                u = self._new(M, 4 * d)
+                hbuf = self._new(M, 4 * d)
+                r["T_ff1"] = self._lin_fwd(ff.net[0].proj, xn2, hbuf, M=M, rows_per_batch=Ss, B=B, flags=EPI_GELU, aux_out=u)
+                y_ff = self._new(M, d)
+                x2 = self._new(M, d)
+                r["T_ff2"] = self._lin_fwd(ff.net[2], hbuf, x2, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
+                                           aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss)
+                r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=hbuf, y_ff=y_ff)
+                outs[name] = x2
+            x_img, x_txt = outs["img"], outs["txt"]
+            if ctx is not None:
+                ctx["dbl"].append(rec)
+
+        # ---- joint stream
+        x = self._new(Mj, d)
+        xv = x.view(B, S, d)
+        for b in range(B):
+            ops.copy_rows(xv[b, :St], x_txt.view(B, St, d)[b])
+            ops.copy_rows(xv[b, St:], x_img.view(B, Si, d)[b])
+        for blk in self.single_transformer_blocks:
+            r = {}
+            mod, r["T_mod"] = self._ada_fwd(blk.norm.linear, silu_temb, B)
+            mean, rstd = self._new(Mj, dtype=torch.float32), self._new(Mj, dtype=torch.float32)
+            xn = self._new(Mj, d)
+            ops.ln_mod_fwd(x, mod[:, 0:d], mod[:, d:2 * d], xn, rows_per_batch=S, mean=mean, rstd=rstd)
+            qkv_raw = self._new(Mj, 3 * d)
+            a = blk.attn
+            r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=Mj, rows_per_batch=S, B=B)
+                          for j, lin in enumerate((a.to_q, a.to_k, a.to_v))]
+            cat = self._new(Mj, 5 * d)
+            u = self._new(Mj, 4 * d)
+            r["T_mlp"] = self._lin_fwd(blk.proj_mlp, xn, cat[:, d:], M=Mj, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u)
+            qkv_j = self._new(Mj, 3 * d)
+            jobs = [dict(src=qkv_raw[:, 0:d], dst=qkv_j[:, 0:d], weight=a.norm_q.weight),
+                    dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=a.norm_k.weight),
+                    dict(src=qkv_raw[:, 2 * d:], dst=qkv_j[:, 2 * d:], weight=None)]
+            ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
+            lse = self._new(B, H, S, dtype=torch.float32)
+            ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], cat[:, 0:d], lse, B=B, H=H, S=S, scale=scale)
+            y = self._new(Mj, d)
+            x_new = self._new(Mj, d)
+            r["T_out"] = self._lin_fwd(blk.proj_out, cat, x_new, M=Mj, rows_per_batch=S, B=B, flags=EPI_GATE_RES,
+                                       aux_out=y, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=S)
+            r.update(mod=mod, x=x, mean=mean, rstd=rstd, xn=xn, qkv_raw=qkv_raw, cat=cat, u=u, qkv_j=qkv_j, lse=lse, y=y)
+            if ctx is not None:
+                ctx["sgl"].append(r)
+            x = x_new
+
+        # ---- output head (frozen): AdaLayerNormContinuous ([scale, shift]) + proj_out on the image tokens
+        x_out = self._new(Mi, d)
+        xv = x.view(B, S, d)
+        for b in range(B):
+            ops.copy_rows(x_out.view(B, Si, d)[b], xv[b, St:])
+        mod_out = self._new(B, 2 * d)
+        ops.gemv_nt(silu_temb, self.norm_out.linear.weight, mod_out, bias=self.norm_out.linear.bias)
+        mean, rstd = self._new(Mi, dtype=torch.float32), self._new(Mi, dtype=torch.float32)
+        xn = self._new(Mi, d)
+        ops.ln_mod_fwd(x_out, mod_out[:, d:2 * d], mod_out[:, 0:d], xn, rows_per_batch=Si, mean=mean, rstd=rstd)
+        pred = self._new(Mi, Cin)
+        ops.gemm_nt(xn, self.proj_out.weight, pred, bias=self.proj_out.bias)
+        if ctx is not None:
+            ctx.update(silu_temb=silu_temb, x_out=x_out, mod_out=mod_out, mean_out=mean, rstd_out=rstd)
+            self.ctx = ctx
+        return pred.view(B, Si, Cin)
+
+    # ------------------------------------------------------------------ backward
+    def backward_native(self, dpred):
+        """dpred [B, Si, Cin]: accumulates every adapter gradient into network.arena_g (fp32).  Frees the saved graph."""
+        ops, d, H = self.ops, self.dim, self.heads
+        ctx = self.ctx
+        assert ctx is not None, "forward_native(save_for_backward=True) must run first"
+        B, Si, St = ctx["B"], ctx["Si"], ctx["St"]
+        S = St + Si
+        Mi, Mt, Mj = B * Si, B * St, B * S
+        cos, sin, silu_temb = ctx["cos"], ctx["sin"], ctx["silu_temb"]
+        scale = 1.0 / math.sqrt(128.0)
+        Cin = self.in_channels
+
+        # ---- head
+        dxn = self._new(Mi, d)
+        ops.gemm_nt(dpred.to(self.dt).reshape(Mi, Cin).contiguous(), self.proj_out.weight_t, dxn)
+        dx_out = self._new(Mi, d)
+        ops.ln_mod_bwd(dxn, ctx["x_out"], ctx["mean_out"], ctx["rstd_out"], ctx["mod_out"][:, 0:d], dx_out, B=B, S=Si)
+        dx = torch.zeros(Mj, d, dtype=self.dt, device=dx_out.device)
+        dxv = dx.view(B, S, d)
+        for b in range(B):
+            ops.copy_rows(dxv[b, St:], dx_out.view(B, Si, d)[b])
+
+        # ---- single-stream blocks (reverse)
+        for blk, r in zip(reversed(self.single_transformer_blocks), reversed(ctx["sgl"])):
+            mod = r["mod"]
+            dmod = self._new(B, 3 * d)
+            dy = self._new(Mj, d)
+            ops.gate_bwd(dx, r["y"], mod[:, 2 * d:3 * d], dy, dmod[:, 2 * d:3 * d], B=B, S=S)
+            dcat_o = self._new(Mj, d)
+            du = self._new(Mj, 4 * d)
+            # proj_out: adapter grads once, then the two column ranges of d[attn | mlp]
+            dT = self._lora_grads(blk.proj_out, dy, r["T_out"], r["cat"], M=Mj, rows_per_batch=S, B=B)
+            self._lin_dgrad(blk.proj_out, dy, dT, dcat_o, M=Mj, w_rows=(0, d))
+            self._lin_dgrad(blk.proj_out, dy, dT, du, M=Mj, w_rows=(d, 5 * d), flags=EPI_DGELU, aux_in=r["u"])
+            qkv_j = r["qkv_j"]
+            dqkv_j = self._new(Mj, 3 * d)
+            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], r["cat"][:, 0:d], r["lse"], dcat_o,
+                         dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_j[:, 2 * d:], B=B, H=H, S=S, scale=scale)
+            dqkv_raw = self._new(Mj, 3 * d)
+            a = blk.attn
+            qkv_raw = r["qkv_raw"]
+            jobs = [dict(src=dqkv_raw[:, 0:d], dst=dqkv_j[:, 0:d], weight=a.norm_q.weight, raw=qkv_raw[:, 0:d]),
+                    dict(src=dqkv_raw[:, d:2 * d], dst=dqkv_j[:, d:2 * d], weight=a.norm_k.weight, raw=qkv_raw[:, d:2 * d]),
+                    dict(src=dqkv_raw[:, 2 * d:], dst=dqkv_j[:, 2 * d:], weight=None)]
+            ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
+            dxn = self._new(Mj, d)
+            self._lin_bwd(blk.proj_mlp, du, r["T_mlp"], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B)
+            for j, lin in enumerate((a.to_q, a.to_k, a.to_v)):
+                self._lin_bwd(lin, dqkv_raw[:, j * d:(j + 1) * d], r["T_qkv"][j], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B,
+                              flags=EPI_ACCUM)
+            dx_prev = self._new(Mj, d)
+            ops.ln_mod_bwd(dxn, r["x"], r["mean"], r["rstd"], mod[:, d:2 * d], dx_prev, B=B, S=S, dres=dx,
+                           dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
+            self._ada_bwd(blk.norm.linear, dmod, r["T_mod"], silu_temb, B)
+            dx = dx_prev
+            r.clear()
+
+        # ---- split the joint gradient
+        dx_img, dx_txt = self._new(Mi, d), self._new(Mt, d)
+        dxv = dx.view(B, S, d)
+        for b in range(B):
+            ops.copy_rows(dx_txt.view(B, St, d)[b], dxv[b, :St])
+            ops.copy_rows(dx_img.view(B, Si, d)[b], dxv[b, St:])
+
+        # ---- double-stream blocks (reverse)
+        for blk, rec in zip(reversed(self.transformer_blocks), reversed(ctx["dbl"])):
+            do_j = self._new(Mj, d)
+            grads = {"img": dx_img, "txt": dx_txt}
+            dmods, dx1s = {}, {}
+            for name, M, Ss, s_off, out_lin, ff in (("img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
+                                                     ("txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)):
+                r = rec[name]
+                mod = r["mod"]
+                dx2 = grads[name]
+                dmod = self._new(B, 6 * d)
+                dy = self._new(M, d)
+                ops.gate_bwd(dx2, r["y_ff"], mod[:, 5 * d:6 * d], dy, dmod[:, 5 * d:6 * d], B=B, S=Ss)
+                du = self._new(M, 4 * d)
+                self._lin_bwd(ff.net[2], dy, r["T_ff2"], r["h"], du, M=M, rows_per_batch=Ss, B=B, flags=EPI_DGELU, aux_in=r["u"])
+                dxn2 = self._new(M, d)
+                self._lin_bwd(ff.net[0].proj, du, r["T_ff1"], r["xn2"], dxn2, M=M, rows_per_batch=Ss, B=B)
+                dx1 = self._new(M, d)
+                ops.ln_mod_bwd(dxn2, r["x1"], r["mean2"], r["rstd2"], mod[:, 4 * d:5 * d], dx1, B=B, S=Ss, dres=dx2,
+                               dshift=dmod[:, 3 * d:4 * d], dscale=dmod[:, 4 * d:5 * d])
+                ops.gate_bwd(dx1, r["y_attn"], mod[:, 2 * d:3 * d], dy, dmod[:, 2 * d:3 * d], B=B, S=Ss)
+                seg = (Ss, S * d)
+                self._lin_bwd(out_lin, dy, r["T_o"], rec["o_j"][s_off:], do_j[s_off:], M=M, rows_per_batch=Ss, B=B,
+                              x_seg=seg, dx_seg=seg)
+                dmods[name], dx1s[name] = dmod, dx1
+            qkv_j = rec["qkv_j"]
+            dqkv_j = self._new(Mj, 3 * d)
+            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], rec["o_j"], rec["lse"], do_j,
+                         dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_j[:, 2 * d:], B=B, H=H, S=S, scale=scale)
+            new_grads = {}
+            for name, M, Ss, s_off, norm1, qkv_lins, qk_norms in (
+                    ("img", Mi, Si, St, blk.norm1, (blk.attn.to_q, blk.attn.to_k, blk.attn.to_v), (blk.attn.norm_q, blk.attn.norm_k)),
+                    ("txt", Mt, St, 0, blk.norm1_context, (blk.attn.add_q_proj, blk.attn.add_k_proj, blk.attn.add_v_proj),
+                     (blk.attn.norm_added_q, blk.attn.norm_added_k))):
+                r = rec[name]
+                mod, dmod = r["mod"], dmods[name]
+                qkv_raw = r["qkv_raw"]
+                dqkv_raw = self._new(M, 3 * d)
+                jobs = [dict(src=dqkv_raw[:, 0:d], dst=dqkv_j[:, 0:d], weight=qk_norms[0].weight, raw=qkv_raw[:, 0:d]),
+                        dict(src=dqkv_raw[:, d:2 * d], dst=dqkv_j[:, d:2 * d], weight=qk_norms[1].weight, raw=qkv_raw[:, d:2 * d]),
+                        dict(src=dqkv_raw[:, 2 * d:], dst=dqkv_j[:, 2 * d:], weight=None)]
+                ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=s_off)
+                dxn = self._new(M, d)
+                for j, lin in enumerate(qkv_lins):
+                    self._lin_bwd(lin, dqkv_raw[:, j * d:(j + 1) * d], r["T_qkv"][j], r["xn"], dxn, M=M, rows_per_batch=Ss, B=B,
+                                  flags=EPI_ACCUM if j else 0)
+                dx0 = self._new(M, d)
+                ops.ln_mod_bwd(dxn, r["x"], r["mean1"], r["rstd1"], mod[:, d:2 * d], dx0, B=B, S=Ss, dres=dx1s[name],
+                               dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
+                self._ada_bwd(norm1.linear, dmod, r["T_mod"], silu_temb, B)
+                new_grads[name] = dx0
+            dx_img, dx_txt = new_grads["img"], new_grads["txt"]
+            rec.clear()
+        self.ctx = None
+
+
+class _FluxGraphFn(torch.autograd.Function):
+    """Lets reference-style code call loss.backward(): the explicit backward runs when autograd reaches pred.
+    Adapter gradients are written into the arena views that back every lora_down / lora_up Parameter's .grad."""
+
+    @staticmethod
+    def forward(ctx_, pred, model, arena_p):
+        ctx_.model = model
+        return pred.clone()
+
+    @staticmethod
+    def backward(ctx_, dpred):
+        ctx_.model.backward_native(dpred)
+        return None, None, None

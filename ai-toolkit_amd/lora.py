@@ -1,0 +1,312 @@
+"""LoRA network surface for the fused MI355X path.
+
+Mirrors the Python-visible contract of the reference's adapter layer so trainer code, optimizers, EMA and saved files
+keep working:
+
+  * LoRAModule            <- toolkit/lora_special.py:46-135 (attributes, init order, `alpha` buffer, fp32 params)
+                             toolkit/network_mixins.py:170-195 (`scale` float + non-persistent `_runtime_scale` buffer)
+  * FusedLoRANetwork      <- toolkit/lora_special.py:276-775 (module discovery / naming), toolkit/network_mixins.py:491-932
+                             (multiplier -> torch_multiplier, context-manager activation, state-dict I/O, PEFT renaming),
+                             toolkit/kohya_lora.py:1030-1074 (prepare_optimizer_params)
+
+What is different underneath: all lora_down / lora_up weights live in ONE flat fp32 arena (plus flat grad / Adam / EMA
+arenas and a bf16 shadow arena holding every matrix in both orientations).  The nn.Parameters are views into that
+arena, so a fused optimizer kernel and a single RCCL all-reduce can treat the adapter as one tensor while
+`state_dict()`, `torch.optim.*` and `clip_grad_norm_` still see ordinary per-layer parameters.
+"""
+import json
+import math
+import os
+import weakref
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+LINEAR_MODULES = ["Linear", "LoRACompatibleLinear", "QLinear", "OstrisLinear"]  # toolkit/lora_special.py:29-35
+
+
+class LoRAModule(nn.Module):
+    """State holder for one wrapped Linear.  The arithmetic is NOT here: the fused GEMM reads the bf16 shadows."""
+
+    def __init__(self, lora_name, org_module, multiplier=1.0, lora_dim=4, alpha=1, dropout=None, rank_dropout=None,
+                 module_dropout=None, network=None, use_bias=False, **kwargs):
+        super().__init__()
+        self.can_merge_in = True
+        self.network_ref = weakref.ref(network) if network is not None else (lambda: None)
+        self.is_checkpointing = False
+        self._multiplier = None
+        self.lora_name = lora_name
+        self.orig_module_ref = weakref.ref(org_module)
+        if getattr(org_module, "bias", None) is None:
+            use_bias = False
+        if use_bias:
+            raise NotImplementedError("use_bias LoRA is not on the fused path")
+        in_dim, out_dim = org_module.in_features, org_module.out_features
+        self.lora_dim = lora_dim
+        self.full_rank = False
+        # same construction (hence same RNG consumption) as toolkit/lora_special.py:105-122
+        self.lora_down = nn.Linear(in_dim, lora_dim, bias=False)
+        self.lora_up = nn.Linear(lora_dim, out_dim, bias=False)
+        if isinstance(alpha, torch.Tensor):
+            alpha = float(alpha.detach().float().item())
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self._set_runtime_scale(float(alpha) / lora_dim)
+        self.register_buffer("alpha", torch.tensor(alpha))
+        nn.init.kaiming_uniform_(self.lora_down.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_up.weight)
+        self.multiplier = multiplier
+        self.org_module = [org_module]  # list keeps it out of state_dict (reference lines 125-126)
+        self.dropout, self.rank_dropout, self.module_dropout = dropout, rank_dropout, module_dropout
+        if dropout or rank_dropout or module_dropout:
+            raise NotImplementedError("dropout variants are not on the fused path (reference default: None)")
+        # arena bookkeeping (filled by FusedLoRANetwork._build_arena)
+        self.off_down = self.off_up = -1
+        self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
+        self.g_down = self.g_up = None
+
+    def _set_runtime_scale(self, value):
+        self.scale = float(value)
+        rs = getattr(self, "_runtime_scale", None)
+        if rs is None:
+            self.register_buffer("_runtime_scale", torch.tensor(self.scale, dtype=torch.float32), persistent=False)
+        else:
+            with torch.no_grad():
+                rs.fill_(self.scale)
+
+    def apply_to(self):
+        """The reference swaps org_module.forward; the fused path instead tags the base layer with its adapter."""
+        self.org_module[0].lora = self
+
+    @property
+    def in_features(self):
+        return self.lora_down.weight.shape[1]
+
+    @property
+    def out_features(self):
+        return self.lora_up.weight.shape[0]
+
+
+class FusedLoRANetwork(nn.Module):
+    """Drop-in for LoRASpecialNetwork on transformer (PEFT-format) models."""
+
+    def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
+                 transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
+                 is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1"):
+        super().__init__()
+        assert peft_format and is_transformer, "kohya-format UNet naming is a later row (SURVEY.md §8f.3)"
+        self.lora_dim = lora_dim
+        self.network_type = network_type
+        self.peft_format = True
+        self.is_transformer = True
+        self.is_lorm = False
+        self.is_active = False
+        self.is_merged_in = False
+        self.base_model_version = base_model_version
+        # PEFT format: alpha forced to rank => scale 1 (toolkit/lora_special.py:428-433)
+        self.alpha = lora_dim
+        self._multiplier = 1.0
+        self.torch_multiplier = None
+        self.unet_loras: List[LoRAModule] = []
+        self.text_encoder_loras: List[LoRAModule] = []
+        ignore_if_contains = ignore_if_contains or []
+        prefix = "transformer"
+        names = set()
+        for name, module in unet.named_modules():
+            if module.__class__.__name__ not in target_lin_modules:
+                continue
+            for child_name, child in module.named_modules():
+                if child.__class__.__name__ not in LINEAR_MODULES:
+                    continue
+                clean = ".".join([x for x in (prefix, name, child_name) if x])
+                lora_name = clean.replace(".", "$$")
+                if any(w in clean for w in ignore_if_contains):
+                    continue
+                if transformer_only:
+                    blocks = transformer_block_names
+                    if blocks is not None:
+                        if not any(b in clean for b in blocks):
+                            continue
+                    elif "transformer_blocks" not in lora_name:
+                        continue
+                if only_if_contains is not None and not any(w in clean for w in only_if_contains):
+                    continue
+                if lora_name in names:
+                    continue
+                names.add(lora_name)
+                lora = LoRAModule(lora_name, child, multiplier, lora_dim, self.alpha, network=self)
+                self.unet_loras.append(lora)
+        for lora in self.unet_loras:
+            self.add_module(lora.lora_name, lora)
+        self._arena_built = False
+        self.multiplier = multiplier
+
+    # ------------------------------------------------------------------ arena
+    def get_all_modules(self):
+        return self.text_encoder_loras + self.unet_loras
+
+    def apply_to(self, *args, **kwargs):
+        for lora in self.get_all_modules():
+            lora.apply_to()
+
+    def build_arena(self, device, ema: bool = False):
+        """Move every adapter matrix into flat fp32 arenas on `device` (reference: network.force_to(device, fp32),
+        jobs/process/BaseSDTrainProcess.py:1982-1983) and create grad / Adam / EMA / bf16-shadow arenas."""
+        mods = self.get_all_modules()
+        n = sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in mods)
+        self.arena_p = torch.empty(n, dtype=torch.float32, device=device)
+        self.arena_g = torch.zeros(n, dtype=torch.float32, device=device)
+        self.arena_m = torch.zeros(n, dtype=torch.float32, device=device)
+        self.arena_v = torch.zeros(n, dtype=torch.float32, device=device)
+        self.arena_ema = None
+        dt = torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
+        self.shadow_dtype = dt
+        self.arena_shadow = torch.empty(2 * n, dtype=dt, device=device)
+        entries = []
+        off = 0
+        for m in mods:
+            for which in ("down", "up"):
+                lin = m.lora_down if which == "down" else m.lora_up
+                w = lin.weight.data
+                rows, cols = w.shape
+                cnt = rows * cols
+                view = self.arena_p[off:off + cnt].view(rows, cols)
+                view.copy_(w)
+                lin.weight = nn.Parameter(view, requires_grad=True)
+                gview = self.arena_g[off:off + cnt].view(rows, cols)
+                lin.weight.grad = gview
+                sh = self.arena_shadow[2 * off:2 * off + cnt].view(rows, cols)
+                shT = self.arena_shadow[2 * off + cnt:2 * off + 2 * cnt].view(cols, rows)
+                entries.append((off, 2 * off, 2 * off + cnt, rows, cols))
+                if which == "down":
+                    m.off_down, m.g_down, m.sh_down, m.sh_downT = off, gview, sh, shT
+                else:
+                    m.off_up, m.g_up, m.sh_up, m.sh_upT = off, gview, sh, shT
+                off += cnt
+            m.alpha = m.alpha.to(device)
+            m._runtime_scale = m._runtime_scale.to(device)
+        self._shadow_entries = entries
+        self._shadow_table = None
+        if ema:
+            self.arena_ema = self.arena_p.clone()
+        self._arena_built = True
+        self._update_torch_multiplier()
+        return self
+
+    def refresh_shadows(self, ops):
+        """bf16 copies (both orientations) of every adapter matrix; call after each optimizer step / weight load."""
+        if self._shadow_table is None:
+            self._shadow_table = ops.make_shadow_table(self._shadow_entries, self.arena_p.device)
+        ops.refresh_shadows(self.arena_p, self.arena_shadow, self._shadow_table)
+
+    def zero_grad_arena(self):
+        self.arena_g.zero_()
+        for m in self.get_all_modules():  # optimizer.zero_grad(set_to_none=True) may have dropped the views
+            m.lora_down.weight.grad = m.g_down
+            m.lora_up.weight.grad = m.g_up
+
+    # ------------------------------------------------------------------ multiplier / activation (network_mixins.py:791-853)
+    @property
+    def multiplier(self):
+        return self._multiplier
+
+    @multiplier.setter
+    def multiplier(self, value):
+        if isinstance(value, torch.Tensor):
+            value = value.detach().cpu().tolist()
+        self._multiplier = value
+        self._update_torch_multiplier()
+
+    def _update_torch_multiplier(self):
+        if not getattr(self, "_arena_built", False):
+            return
+        v = self._multiplier
+        vals = [float(x) for x in v] if isinstance(v, (list, tuple)) else [float(v)]
+        self.torch_multiplier = torch.tensor(vals, dtype=torch.float32, device=self.arena_p.device)
+
+    def __enter__(self):
+        self.is_active = True
+
+    def __exit__(self, exc_type, exc_value, tb):
+        self.is_active = False
+
+    def force_to(self, device, dtype):
+        assert dtype == torch.float32, "adapter weights are fp32 in the reference (BaseSDTrainProcess.py:1983)"
+        if not self._arena_built:
+            self.build_arena(device)
+        return self
+
+    def prepare_grad_etc(self, *args, **kwargs):
+        self.requires_grad_(True)
+
+    def enable_gradient_checkpointing(self):
+        pass  # the fused step keeps activations resident in HBM (288 GB); nothing to recompute
+
+    def prepare_optimizer_params(self, text_encoder_lr=None, unet_lr=None, default_lr=None):
+        """One group with every adapter weight (toolkit/kohya_lora.py:1030-1074, unet branch)."""
+        params = []
+        for m in self.unet_loras:
+            params.extend([m.lora_down.weight, m.lora_up.weight])
+        group = {"params": params}
+        lr = unet_lr if unet_lr is not None else default_lr
+        if lr is not None:
+            group["lr"] = lr
+        return [group]
+
+    # ------------------------------------------------------------------ state-dict I/O (network_mixins.py:581-789)
+    def get_state_dict(self, extra_state_dict=None, dtype=torch.float16, use_ema=False):
+        src = self.arena_ema if (use_ema and self.arena_ema is not None) else None
+        sd = OrderedDict()
+        for m in self.get_all_modules():
+            base = m.lora_name.replace("$$", ".")
+            for which, lin, off in (("lora_A", m.lora_down, m.off_down), ("lora_B", m.lora_up, m.off_up)):
+                w = lin.weight.detach()
+                if src is not None:
+                    w = src[off:off + w.numel()].view_as(w)
+                sd[f"{base}.{which}.weight"] = w.clone().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
+        if extra_state_dict is not None:
+            for k, v in extra_state_dict.items():
+                sd[k] = v.detach().clone().to("cpu").to(dtype)
+        return sd
+
+    def save_weights(self, file, dtype=torch.float16, metadata=None, extra_state_dict=None, use_ema=False):
+        from safetensors.torch import save_file
+
+        sd = self.get_state_dict(extra_state_dict, dtype, use_ema)
+        meta = OrderedDict()
+        for k, v in (metadata or {}).items():  # every value JSON-stringified (toolkit/metadata.py:13-29)
+            meta[k] = v if isinstance(v, str) else json.dumps(v)
+        meta.setdefault("format", "pt")
+        os.makedirs(os.path.dirname(os.path.abspath(file)), exist_ok=True)
+        save_file(sd, file, meta)
+
+    def load_weights(self, file):
+        """Accepts the PEFT keys this class writes; rank grow/shrink by zero-pad / truncate (network_mixins.py:737-775)."""
+        from safetensors.torch import load_file
+
+        sd = file if isinstance(file, dict) else load_file(file)
+        extra = OrderedDict()
+        by_name = {m.lora_name.replace("$$", "."): m for m in self.get_all_modules()}
+        used = set()
+        with torch.no_grad():
+            for k, v in sd.items():
+                hit = False
+                for which, attr in ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up")):
+                    if k.endswith(which) and k[: -len(which)] in by_name:
+                        w = getattr(by_name[k[: -len(which)]], attr).weight
+                        v = v.to(w.device, torch.float32)
+                        if v.shape != w.shape:
+                            new = torch.zeros_like(w)
+                            r0, r1 = min(v.shape[0], w.shape[0]), min(v.shape[1], w.shape[1])
+                            new[:r0, :r1] = v[:r0, :r1]
+                            v = new
+                        w.copy_(v)
+                        used.add(k)
+                        hit = True
+                if not hit:
+                    extra[k] = v
+        return extra if len(extra) else None
+
+    def set_multiplier(self, multiplier):
+        self.multiplier = multiplier

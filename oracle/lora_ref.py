@@ -1,0 +1,91 @@
+"""ORACLE (test infrastructure): restatement of the reference LoRA layer on plain nn.Linear modules.
+
+Follows toolkit/lora_special.py:46-135 (construction / init) and toolkit/network_mixins.py:197-239, 274-348 (forward):
+    org = org_forward(x)
+    lx  = lora_up(lora_down(x.to(fp32))) * scale
+    out = org + (lx * multiplier[b]).to(org.dtype)
+Pinned against the reference classes themselves by tests/golden/make_golden.py.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+
+class RefLoRAModule(nn.Module):
+    def __init__(self, lora_name, org_module, lora_dim, alpha, network):
+        super().__init__()
+        self.lora_name = lora_name
+        self.lora_dim = lora_dim
+        self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
+        self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self.scale = float(alpha) / lora_dim
+        self.register_buffer("alpha", torch.tensor(alpha))
+        nn.init.kaiming_uniform_(self.lora_down.weight, a=math.sqrt(5))
+        nn.init.zeros_(self.lora_up.weight)
+        self.org_module = [org_module]
+        self.network = [network]
+
+    def apply_to(self):
+        self.org_forward = self.org_module[0].forward
+        self.org_module[0].forward = self.forward
+
+    def forward(self, x, *args, **kwargs):
+        net = self.network[0]
+        if not net.is_active or net.multiplier_is_zero():
+            return self.org_forward(x, *args, **kwargs)
+        org = self.org_forward(x, *args, **kwargs)
+        lx = self.lora_up(self.lora_down(x.to(self.lora_down.weight.dtype))) * self.scale
+        m = net.torch_multiplier
+        if lx.size(0) != m.size(0):
+            m = m.repeat_interleave(lx.size(0) // m.size(0))
+        lx = lx * m.view(-1, *([1] * (lx.dim() - 1)))
+        return org + lx.to(org.dtype)
+
+
+class RefLoRANetwork(nn.Module):
+    """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
+
+    def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",)):
+        super().__init__()
+        self.is_active = False
+        self.torch_multiplier = torch.tensor([float(multiplier)])
+        self.unet_loras = []
+        for name, module in unet.named_modules():
+            if module.__class__.__name__ not in target:
+                continue
+            for child_name, child in module.named_modules():
+                if child.__class__.__name__ != "Linear":
+                    continue
+                clean = ".".join([x for x in ("transformer", name, child_name) if x])
+                lora_name = clean.replace(".", "$$")
+                if "transformer_blocks" not in lora_name:
+                    continue
+                self.unet_loras.append(RefLoRAModule(lora_name, child, lora_dim, lora_dim, self))
+        for lo in self.unet_loras:
+            self.add_module(lo.lora_name, lo)
+
+    def multiplier_is_zero(self):
+        return bool((self.torch_multiplier == 0).all())
+
+    def apply_to(self):
+        for lo in self.unet_loras:
+            lo.apply_to()
+
+    def __enter__(self):
+        self.is_active = True
+
+    def __exit__(self, *a):
+        self.is_active = False
+
+    def peft_state_dict(self, dtype=torch.float16):
+        """PEFT renaming of toolkit/network_mixins.py:607-624."""
+        sd = OrderedDict()
+        for k, v in self.state_dict().items():
+            if k.endswith(".alpha"):
+                continue
+            k = k.replace("lora_down", "lora_A").replace("lora_up", "lora_B").replace("$$", ".")
+            sd[k] = v.detach().clone().to("cpu").to(dtype)
+        return sd

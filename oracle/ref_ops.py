@@ -1,0 +1,302 @@
+"""ORACLE (test infrastructure): plain-PyTorch restatement of every kernel in ai-toolkit_amd/ops.py, same signatures.
+
+Used only by tests/ (and __graft_entry__.smoke / bench cpu_baseline as the checker) in two ways:
+  1. per-kernel parity on the GPU: HIP kernel output vs the function of the same name here;
+  2. host-logic parity on the CPU: ai_toolkit_amd.flux.FluxTransformer2DModel driven by THIS table in fp32 must
+     reproduce autograd of oracle/flux_ref.py, which proves the hand-written backward graph independent of any GPU.
+Each function cites the reference line it restates.  Math is done in fp32 (fp64 where noted) and cast to the output
+dtype, i.e. one rounding per kernel output like the HIP kernels.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 1, 2, 4, 8, 16
+
+
+def _seg_view(t, seg, M):
+    """logical [M, C] tensor for a (seg_rows, seg_stride)-segmented 2-D view `t` (first segment)."""
+    if seg is None:
+        return t[:M]
+    seg_rows, seg_stride = seg
+    nseg = (M + seg_rows - 1) // seg_rows
+    v = torch.as_strided(t, (nseg, seg_rows, t.shape[1]), (seg_stride, t.stride(0), 1))
+    return v.reshape(nseg * seg_rows, t.shape[1])[:M]
+
+
+def _seg_store(t, seg, M, value):
+    if seg is None:
+        t[:M].copy_(value.to(t.dtype))
+        return
+    seg_rows, seg_stride = seg
+    nseg = M // seg_rows
+    assert nseg * seg_rows == M
+    v = torch.as_strided(t, (nseg, seg_rows, t.shape[1]), (seg_stride, t.stride(0), 1))
+    v.copy_(value.view(nseg, seg_rows, -1).to(t.dtype))
+
+
+def rows_per_block():
+    return 16
+
+
+def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
+            a_seg=None, c_seg=None, M=None, stage_mode=None):
+    """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342)."""
+    if M is None:
+        M = a.shape[0]
+    A = _seg_view(a, a_seg, M).float()
+    v = A @ b.float().t()
+    if a2 is not None:
+        v = v + a2[:M].float() @ b2.float().t()
+    if bias is not None:
+        v = v + bias.float()
+    if flags & EPI_ACCUM:
+        v = v + _seg_view(out, c_seg, M).float()
+    if flags & EPI_GELU:
+        aux_out[:M].copy_(v.to(aux_out.dtype))
+        v = F.gelu(aux_out[:M].float(), approximate="tanh")
+    if flags & EPI_DGELU:
+        u = aux_in[:M].float().requires_grad_(True)
+        with torch.enable_grad():
+            F.gelu(u, approximate="tanh").sum().backward()
+        v = v * u.grad
+    if flags & EPI_GATE_RES:
+        aux_out[:M].copy_(v.to(aux_out.dtype))
+        g = gate.float().repeat_interleave(gate_rows, 0)[:M]
+        v = aux_in[:M].float() + g * aux_out[:M].float()
+    _seg_store(out, c_seg, M, v)
+    return out
+
+
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None):
+    """lora_down(x.float()) * scale * multiplier (toolkit/network_mixins.py:197-239, 309-318)."""
+    if M is None:
+        M = x.shape[0]
+    v = _seg_view(x, x_seg, M).float() @ pmat.float().t() * scale
+    if mult is not None:
+        v = v * mult.repeat_interleave(rows_per_batch)[:M, None]
+    out[:M].copy_(v.to(out.dtype))
+    return out
+
+
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None):
+    """autograd of lora_down / lora_up weights."""
+    if M is None:
+        M = s.shape[0]
+    v = s[:M].float().t() @ _seg_view(g, g_seg, M).float()
+    if transpose_out:
+        v = v.t()
+    if accumulate:
+        out.add_(v)
+    else:
+        out.copy_(v)
+    return out
+
+
+def ln_mod_fwd(x, shift, scale, out, *, rows_per_batch, mean=None, rstd=None, eps=1e-6):
+    xf = x.float()
+    mu = xf.mean(-1, keepdim=True)
+    var = ((xf - mu) ** 2).mean(-1, keepdim=True)
+    rs = torch.rsqrt(var + eps)
+    M = x.shape[0]
+    sc = scale.float().repeat_interleave(rows_per_batch, 0)[:M]
+    sh = shift.float().repeat_interleave(rows_per_batch, 0)[:M]
+    out.copy_(((xf - mu) * rs * (1 + sc) + sh).to(out.dtype))
+    if mean is not None:
+        mean.copy_(mu[:, 0])
+        rstd.copy_(rs[:, 0])
+    return out
+
+
+def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, dscale=None):
+    M = B * S
+    xh = (x[:M].float() - mean[:M, None]) * rstd[:M, None]
+    gr = dxn[:M].float()
+    sc = scale.float().repeat_interleave(S, 0)
+    g = gr * (1 + sc)
+    c1 = g.mean(-1, keepdim=True)
+    c2 = (g * xh).mean(-1, keepdim=True)
+    v = rstd[:M, None] * (g - c1 - xh * c2)
+    if dres is not None:
+        v = v + dres[:M].float()
+    if dshift is not None:
+        dshift.copy_(gr.view(B, S, -1).sum(1).to(dshift.dtype))
+        dscale.copy_((gr * xh).view(B, S, -1).sum(1).to(dscale.dtype))
+    dx[:M].copy_(v.to(dx.dtype))
+    return dx
+
+
+def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
+    M = B * S
+    d = dx[:M].float()
+    dgate.copy_((d * y[:M].float()).view(B, S, -1).sum(1).to(dgate.dtype))
+    dy[:M].copy_((gate.float().repeat_interleave(S, 0) * d).to(dy.dtype))
+    return dy
+
+
+def _rope(t, cos, sin):
+    a, b = t[..., 0::2], t[..., 1::2]
+    o = torch.empty_like(t)
+    o[..., 0::2] = a * cos[..., 0::2] - b * sin[..., 0::2]
+    o[..., 1::2] = b * cos[..., 1::2] + a * sin[..., 1::2]
+    return o
+
+
+def qkv_post_fwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
+    """diffusers RMSNorm + apply_rotary_emb (order: toolkit/models/flux_sage_attn.py:36-74)."""
+    HD = H * 128
+    c = cos[s_off:s_off + S_src][None, :, None, :]
+    s = sin[s_off:s_off + S_src][None, :, None, :]
+    for j in jobs:
+        src, dst, w = j["src"], j["dst"], j.get("weight")
+        x = src[: B * S_src, :HD].reshape(B, S_src, H, 128)
+        dv = dst[: B * S_dst].view(B, S_dst, -1)[:, s_off:s_off + S_src, :HD]
+        if w is None:
+            dv.copy_(x.reshape(B, S_src, HD))
+            continue
+        xf = x.float()
+        t = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
+        t = (t * w.to(x.dtype)).float()
+        dv.copy_(_rope(t, c, s).reshape(B, S_src, HD).to(dst.dtype))
+
+
+def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
+    HD = H * 128
+    c = cos[s_off:s_off + S_src][None, :, None, :]
+    s = sin[s_off:s_off + S_src][None, :, None, :]
+    for j in jobs:
+        graw, gj, w = j["src"], j["dst"], j.get("weight")
+        g = gj[: B * S_dst].view(B, S_dst, -1)[:, s_off:s_off + S_src, :HD]
+        if w is None:
+            graw[: B * S_src, :HD].copy_(g.reshape(B * S_src, HD))
+            continue
+        x = j["raw"][: B * S_src, :HD].reshape(B, S_src, H, 128).float().requires_grad_(True)
+        with torch.enable_grad():
+            t = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w.float()
+            o = _rope(t, c, s)
+            o.backward(g.reshape(B, S_src, H, 128).float())
+        graw[: B * S_src, :HD].copy_(x.grad.reshape(B * S_src, HD).to(graw.dtype))
+
+
+def ew(op, x, y, a=None):
+    xf = x.float()
+    if op == 0:
+        v = F.silu(xf)
+    elif op == 1:
+        v = xf
+    else:
+        v = a.float() + xf
+    y.copy_(v.to(y.dtype))
+    return y
+
+
+def timestep_embed(t, out, tscale=1.0):
+    """extensions_built_in/diffusion_models/chroma/src/layers.py:30-53 with flip_sin_to_cos (cos first)."""
+    half = out.shape[1] // 2
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    ang = t[:, None].float() * tscale * freq[None]
+    out.copy_(torch.cat([ang.cos(), ang.sin()], -1).to(out.dtype))
+    return out
+
+
+def copy_rows(dst, src):
+    dst.copy_(src)
+    return dst
+
+
+def _heads(t, B, S, H):
+    return t[: B * S, : H * 128].reshape(B, S, H, 128).transpose(1, 2).float()
+
+
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale):
+    """F.scaled_dot_product_attention (toolkit/models/flux_sage_attn.py:76; chroma/src/math.py:27)."""
+    qf, kf, vf = _heads(q, B, S, H), _heads(k, B, S, H), _heads(v, B, S, H)
+    sc = (qf @ kf.transpose(-1, -2)) * scale
+    lse.copy_(torch.logsumexp(sc, -1) / math.log(2.0))
+    out = sc.softmax(-1) @ vf
+    o[: B * S, : H * 128].copy_(out.transpose(1, 2).reshape(B * S, H * 128).to(o.dtype))
+    return o
+
+
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale):
+    qf = _heads(q, B, S, H).requires_grad_(True)
+    kf = _heads(k, B, S, H).requires_grad_(True)
+    vf = _heads(v, B, S, H).requires_grad_(True)
+    with torch.enable_grad():
+        out = ((qf @ kf.transpose(-1, -2)) * scale).softmax(-1) @ vf
+        out.backward(_heads(do, B, S, H))
+    for dst, src in ((dq, qf), (dk, kf), (dv, vf)):
+        dst[: B * S, : H * 128].copy_(src.grad.transpose(1, 2).reshape(B * S, H * 128).to(dst.dtype))
+
+
+def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
+    v = x.float() @ w.float().t()
+    if bias is not None:
+        v = v + bias.float()
+    if t is not None:
+        v = v + t.float() @ bl.float().t()
+    if accumulate:
+        v = v + out.float()
+    out.copy_(v.to(out.dtype))
+    return out
+
+
+def flow_noise_pack(latents, noise, t, noisy, target):
+    """add_noise (toolkit/samplers/custom_flowmatch_sampler.py:91-102), target noise - latents
+    (extensions_built_in/sd_trainer/SDTrainer.py:644-646), packing (toolkit/stable_diffusion_model.py:2157-2163)."""
+    B, Cc, Hh, W = latents.shape
+    t01 = (t.float() / 1000.0).view(B, 1, 1, 1)
+    x0, e = latents.float(), noise.float()
+
+    def pack(x):
+        x = x.view(B, Cc, Hh // 2, 2, W // 2, 2)
+        return x.permute(0, 2, 4, 1, 3, 5).reshape(B, (Hh // 2) * (W // 2), Cc * 4)
+
+    noisy.copy_(pack((1.0 - t01) * x0 + t01 * e).to(noisy.dtype))
+    target.copy_(pack(e - x0).to(target.dtype))
+
+
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None):
+    """mse(pred.float(), target.float()) -> mean over (C,H,W) -> * multiplier -> mean over batch (SDTrainer.py:916-1013)."""
+    B = pred.shape[0]
+    d = pred.float().reshape(B, -1) - target.float().reshape(B, -1)
+    n = d.shape[1]
+    lps = (d * d).mean(1)
+    w = weight.float() if weight is not None else torch.ones(B, device=pred.device)
+    loss_per_sample.copy_(lps)
+    loss.copy_((lps * w).mean().reshape(1))
+    dpred.copy_((2.0 * d * w[:, None] / (n * B)).reshape(dpred.shape).to(dpred.dtype))
+
+
+def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
+                   grad_scale=1.0, norm_out=None):
+    """clip_grad_norm_ + torch.optim.AdamW + EMA (SDTrainer.py:2278-2293, toolkit/optimizer.py:78-79, toolkit/ema.py:116-152)."""
+    gs = g * grad_scale
+    norm = gs.double().pow(2).sum().sqrt().float()
+    coef = 1.0
+    if max_norm > 0:
+        coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    gs = gs * coef
+    if norm_out is not None:
+        norm_out.copy_(norm.reshape(1))
+    p.mul_(1 - lr * weight_decay)
+    m.mul_(beta1).add_(gs, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gs, gs, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2s = math.sqrt(1 - beta2 ** step)
+    p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
+    if ema is not None:
+        ema.sub_((1 - ema_decay) * (ema - p))
+
+
+def make_shadow_table(entries, device):
+    return entries, len(entries)
+
+
+def refresh_shadows(arena, shadow, table):
+    entries, _ = table
+    for so, do, dto, r, c in entries:
+        w = arena[so:so + r * c].view(r, c)
+        shadow[do:do + r * c].view(r, c).copy_(w.to(shadow.dtype))
+        shadow[dto:dto + r * c].view(c, r).copy_(w.t().to(shadow.dtype))
