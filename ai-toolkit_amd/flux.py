@@ -152,6 +152,7 @@ class FluxTransformer2DModel(nn.Module):
         self._rope_cache = {}
         self._prepared = False
         self.ctx = None
+        self.grad_ready_hook = None  # called with 'single' / 'double' when that half of the adapter grads is final
 
     # ------------------------------------------------------------------ setup
     def set_ops(self, ops):
@@ -502,6 +503,9 @@ class FluxTransformer2DModel(nn.Module):
             dx = dx_prev
             r.clear()
 
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook("single")
+
         # ---- split the joint gradient
         dx_img, dx_txt = self._new(Mi, d), self._new(Mt, d)
         dxv = dx.view(B, S, d)
@@ -562,6 +566,8 @@ class FluxTransformer2DModel(nn.Module):
                 new_grads[name] = dx0
             dx_img, dx_txt = new_grads["img"], new_grads["txt"]
             rec.clear()
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook("double")
         self.ctx = None
 
 

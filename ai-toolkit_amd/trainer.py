@@ -1,0 +1,119 @@
+"""One LoRA training step for FLUX.1 on MI355X (host orchestration of the C-ABI kernels).
+
+Mirrors, in order, what the reference does per step:
+  process_general_training_batch .... jobs/process/BaseSDTrainProcess.py:1036-1478 (timesteps, noise, add_noise)
+  predict_noise (flux branch) ....... toolkit/stable_diffusion_model.py:2154-2222 (pack, ids, guidance = 1.0, unpack)
+  calculate_loss .................... extensions_built_in/sd_trainer/SDTrainer.py:644-646, 916, 987-1013
+  backward / clip / AdamW / EMA ..... SDTrainer.py:2238, 2278-2293; toolkit/optimizer.py:78-79; toolkit/ema.py:116-152
+
+Data parallelism: one process per GPU, identical frozen base + adapter state on every rank, each rank
+steps its own shard of the bucket batch, ONE all-reduce(mean) of the flat fp32 adapter-gradient arena (RCCL over
+xGMI), issued in two pieces so the single-stream half overlaps the double-stream blocks' backward; clip/AdamW/EMA then
+run redundantly on every rank (bit-identical adapter weights across ranks).
+"""
+import torch
+
+from .flowmatch import FlowMatchTrainSchedule
+
+
+class FluxLoRATrainStep:
+    def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
+                 max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
+                 seed=None):
+        self.model, self.network, self.ops = model, network, ops
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
+        self.timestep_type, self.guidance = timestep_type, guidance
+        self.schedule = FlowMatchTrainSchedule()
+        self.step_num = 0
+        self.pg = process_group
+        self.world = 1
+        self._pending = []
+        if process_group is not None:
+            import torch.distributed as dist
+
+            self.world = dist.get_world_size(process_group)
+        dev = network.arena_p.device
+        self.device = dev
+        self.gen = None
+        if seed is not None:
+            self.gen = torch.Generator(device=dev)
+            self.gen.manual_seed(seed)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_per_sample = None
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        if ema_decay > 0 and network.arena_ema is None:
+            network.arena_ema = network.arena_p.clone()
+        # arena split point: first single-stream adapter (its gradients are final first during backward)
+        self._split = network.arena_p.numel()
+        for m in network.unet_loras:
+            if "single_transformer_blocks" in m.lora_name:
+                self._split = m.off_down
+                break
+        model.grad_ready_hook = self._on_grads_ready if self.world > 1 else None
+
+    # ------------------------------------------------------------------ DP
+    def _on_grads_ready(self, which):
+        import torch.distributed as dist
+
+        g = self.network.arena_g
+        piece = g[self._split:] if which == "single" else g[: self._split]
+        if piece.numel() == 0:
+            return
+        self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _finish_allreduce(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    # ------------------------------------------------------------------ one step
+    def step(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None):
+        """latents [B,16,H,W] (scaled VAE latents), prompt_embeds [B,512,4096], pooled_embeds [B,768].
+        Returns the device-resident loss tensor (no host sync)."""
+        ops, model, net = self.ops, self.model, self.network
+        dt = model.dt
+        B, Cc, Hh, W = latents.shape
+        dev = latents.device
+        latents = latents.to(dt).contiguous()
+        self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
+        if timesteps is None:
+            timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
+        timesteps = timesteps.float().contiguous()
+        if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812)
+            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32, generator=self.gen)
+        noise = noise.to(dt).contiguous()
+        n_tok = (Hh // 2) * (W // 2)
+        noisy = torch.empty(B, n_tok, Cc * 4, dtype=dt, device=dev)
+        target = torch.empty_like(noisy)
+        ops.flow_noise_pack(latents, noise, timesteps, noisy, target)
+        img_ids, txt_ids = make_ids(Hh, W, prompt_embeds.shape[1], dev)
+        guidance = torch.full((B,), float(self.guidance), device=dev)
+        with net:
+            pred = model.forward_native(noisy, prompt_embeds, pooled_embeds, timesteps / 1000, img_ids, txt_ids, guidance)
+            dpred = torch.empty_like(pred)
+            if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
+                self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=dev)
+            ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight)
+            net.zero_grad_arena()
+            model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
+        self.step_num += 1
+        grad_scale = 1.0
+        if self.world > 1:
+            self._finish_allreduce()
+            grad_scale = 1.0 / self.world
+        ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
+                           max_norm=self.max_grad_norm, ema=net.arena_ema if self.ema_decay > 0 else None,
+                           ema_decay=self.ema_decay, grad_scale=grad_scale, norm_out=self.grad_norm)
+        net.refresh_shadows(ops)
+        return self.loss
+
+
+def make_ids(Hh, W, n_txt, device):
+    """img_ids (0,row,col) for the 2x2-packed grid, txt_ids zeros (toolkit/stable_diffusion_model.py:2165-2170)."""
+    h2, w2 = Hh // 2, W // 2
+    img_ids = torch.zeros(h2, w2, 3)
+    img_ids[..., 1] = img_ids[..., 1] + torch.arange(h2)[:, None]
+    img_ids[..., 2] = img_ids[..., 2] + torch.arange(w2)[None, :]
+    return img_ids.reshape(h2 * w2, 3).to(device), torch.zeros(n_txt, 3, device=device)

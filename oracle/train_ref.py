@@ -1,0 +1,48 @@
+"""ORACLE (test infrastructure): the reference's per-step sequence in plain PyTorch + autograd.
+
+Restates, for the FLUX / flow-matching branch:
+  add_noise ................ toolkit/samplers/custom_flowmatch_sampler.py:91-102 (per-sample loop collapsed; same math)
+  pack / ids / unpack ...... toolkit/stable_diffusion_model.py:2157-2170, 2210-2219
+  loss ..................... extensions_built_in/sd_trainer/SDTrainer.py:644-646 (target = noise - latents), 916 (mse on
+                             .float()), 987-990 (mean over C,H,W), 1013 (mean over batch)
+  clip / step / EMA ........ SDTrainer.py:2278-2293 ; toolkit/optimizer.py:78-79 (torch.optim.AdamW, eps=1e-6) ;
+                             toolkit/ema.py:116-152 (s -= (1-decay)(s-p))
+"""
+import torch
+
+from . import flux_ref
+
+
+class RefTrainStep:
+    def __init__(self, model, net, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0,
+                 ema_decay=0.0, guidance=1.0):
+        self.model, self.net = model, net
+        self.params = [p for m in net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)]
+        self.opt = torch.optim.AdamW(self.params, lr=lr, eps=eps, betas=betas, weight_decay=weight_decay)
+        self.max_grad_norm, self.ema_decay, self.guidance = max_grad_norm, ema_decay, guidance
+        self.ema = [p.detach().clone() for p in self.params] if ema_decay > 0 else None
+
+    def step(self, latents, prompt_embeds, pooled, noise, timesteps, dtype=torch.float32):
+        B, Cc, Hh, W = latents.shape
+        lat = latents.to(dtype)
+        noi = noise.to(dtype)
+        t01 = (timesteps.float() / 1000).view(B, 1, 1, 1)
+        noisy = (1.0 - t01) * lat + t01 * noi  # fp32 math, cast when fed to the model
+        target = (noi - lat).detach()
+        img_ids, txt_ids = flux_ref.make_ids(Hh, W, prompt_embeds.shape[1], latents.device)
+        guidance = torch.full((B,), float(self.guidance), device=latents.device)
+        self.opt.zero_grad()
+        with self.net:
+            pred = self.model(flux_ref.pack_latents(noisy.to(dtype)), prompt_embeds.to(dtype), pooled.to(dtype),
+                              timesteps.float() / 1000, img_ids, txt_ids, guidance)
+            pred = flux_ref.unpack_latents(pred, Hh, W)
+            loss = torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3]).mean()
+            loss.backward()
+        if self.max_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+        self.opt.step()
+        if self.ema is not None:
+            with torch.no_grad():
+                for s, p in zip(self.ema, self.params):
+                    s.sub_((1.0 - self.ema_decay) * (s - p))
+        return loss.detach()

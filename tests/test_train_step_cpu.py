@@ -1,0 +1,71 @@
+"""Train-step host logic on CPU (oracle kernel table, fp32): losses and adapter weights after K steps must equal the
+oracle's autograd + torch.optim.AdamW + clip_grad_norm_ + EMA sequence; 2-rank data parallel (gloo) must equal 1 rank
+on the concatenated batch."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.trainer import FluxLoRATrainStep
+from oracle import ref_ops, train_ref
+from tests.test_host_graph_cpu import CFG, build_pair
+
+
+def batch(B, seed=5, Hl=8, Wl=4, n_txt=6):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(B, 16, Hl, Wl, generator=g)
+    emb = torch.randn(B, n_txt, CFG["joint_attention_dim"], generator=g) * 0.5
+    pooled = torch.randn(B, CFG["pooled_projection_dim"], generator=g) * 0.5
+    noise = torch.randn(B, 16, Hl, Wl, generator=g)
+    ts = torch.tensor([700.0, 250.0, 999.0, 31.0][:B])
+    return lat, emb, pooled, noise, ts
+
+
+def test_three_steps_match_oracle_optimizer_sequence():
+    ref, ref_net, nat, net = build_pair(rank=4)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=0.5, ema_decay=0.9)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    for k in range(3):
+        lat, emb, pooled, noise, ts = batch(2, seed=10 + k)
+        l_ref = oracle.step(lat, emb, pooled, noise, ts)
+        l = ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        assert abs(l.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item()), (k, l.item(), l_ref.item())
+    i = 0
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for pa, pb in ((a.lora_down.weight, b.lora_down.weight), (a.lora_up.weight, b.lora_up.weight)):
+            assert torch.allclose(pa, pb, rtol=2e-3, atol=2e-6), (a.lora_name, (pa - pb).abs().max())
+            e = oracle.ema[i]
+            mine = net.arena_ema[(a.off_down if pa is a.lora_down.weight else a.off_up):][: pa.numel()].view_as(pa)
+            assert torch.allclose(mine, e, rtol=2e-3, atol=2e-6)
+            i += 1
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    ref, ref_net, nat, net = build_pair(rank=4)
+    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
+    for k in range(2):
+        lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
+        sl = slice(rank * 2, rank * 2 + 2)  # disjoint shard of the bucket batch
+        step.step(lat[sl], emb[sl], pooled[sl], noise=noise[sl], timesteps=ts[sl])
+    torch.save(net.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
+    port = 29400 + os.getpid() % 500
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1), "ranks must hold bit-identical adapter weights"
+    ref, ref_net, nat, net = build_pair(rank=4)
+    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5)
+    for k in range(2):
+        lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
+        step.step(lat, emb, pooled, noise=noise, timesteps=ts)
+    assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
