@@ -222,11 +222,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, int n2)
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int i = 0; i < n2; ++i) tot += p.norm_partial2[i];
-    const float norm = sqrtf(tot);
+    const float norm = sqrtf(tot) * fabsf(p.grad_scale);  // norm of the scaled (e.g. rank-averaged) gradient
     float coef = 1.0f;
     if (p.max_norm > 0.f) coef = fminf(1.0f, p.max_norm / (norm + 1e-6f));
     s_coef = coef * p.grad_scale;
-    if (blockIdx.x == 0 && p.norm_out) p.norm_out[0] = norm * fabsf(p.grad_scale);
+    if (blockIdx.x == 0 && p.norm_out) p.norm_out[0] = norm;
   }
   __syncthreads();
   const float coef = s_coef;

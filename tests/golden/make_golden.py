@@ -1,0 +1,123 @@
+"""Generates the golden fixtures in this directory by EXECUTING THE REFERENCE'S OWN CODE (read-only, under import
+shims) in this container:  python tests/golden/make_golden.py
+
+  lora_flux_tiny.safetensors   reference toolkit.lora_special.LoRASpecialNetwork attached to the oracle's tiny
+                               FluxTransformer2DModel (class / attribute names = diffusers'): adapter names, the init
+                               values it draws under torch.manual_seed(99), one forward output and every adapter
+                               gradient for fixed inputs, per-sample multiplier case, and the PEFT-format state dict
+                               it would save (keys + values).
+  flowmatch.safetensors        reference toolkit/samplers/custom_flowmatch_sampler.py executed with a stub diffusers
+                               base class: linear / sigmoid(seed) timestep tables and add_noise on a fixed batch.
+The reference is never imported at test or bench time; only these vectors travel.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+from oracle import flux_ref  # noqa: E402
+
+TINY = dict(in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2,
+            joint_attention_dim=64, pooled_projection_dim=32)
+
+
+def tiny_inputs():
+    g = torch.Generator().manual_seed(3)
+    Hl, Wl, n_txt, B = 4, 4, 5, 2
+    hidden = torch.randn(B, (Hl // 2) * (Wl // 2), 64, generator=g)
+    enc = torch.randn(B, n_txt, 64, generator=g)
+    pooled = torch.randn(B, 32, generator=g)
+    t = torch.tensor([0.3, 0.8])
+    img_ids, txt_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+    return hidden, enc, pooled, t, img_ids, txt_ids, torch.ones(B)
+
+
+def golden_lora():
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    torch.manual_seed(99)
+    net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=8, alpha=1.0, multiplier=1.0, train_text_encoder=False,
+                             train_unet=True, is_flux=True, target_lin_modules=["FluxTransformer2DModel"], transformer_only=True)
+    out = {}
+    names = [m.lora_name for m in net.unet_loras]
+    for m in net.unet_loras:
+        out[f"init/{m.lora_name}/down"] = m.lora_down.weight.detach().clone()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+            out[f"warm/{m.lora_name}/up"] = m.lora_up.weight.detach().clone()
+    net.force_to("cpu", torch.float32)  # order of jobs/process/BaseSDTrainProcess.py:1983-1993
+    net._update_torch_multiplier()
+    net.apply_to(None, model, False, True)
+    inp = tiny_inputs()
+    for tag, mult in (("m1", 1.0), ("mvec", [0.5, -1.5])):
+        net.multiplier = mult
+        for p in net.parameters():
+            p.grad = None
+        with net:
+            pred = model(*inp)
+            pred.square().sum().backward()
+        out[f"{tag}/pred"] = pred.detach().clone()
+        for m in net.unet_loras:
+            out[f"{tag}/grad/{m.lora_name}/down"] = m.lora_down.weight.grad.detach().clone()
+            out[f"{tag}/grad/{m.lora_name}/up"] = m.lora_up.weight.grad.detach().clone()
+    net.multiplier = 1.0
+    sd = net.get_state_dict(dtype=torch.float32)
+    for k, v in sd.items():
+        out[f"saved/{k}"] = v.clone()
+    meta = {"names": json.dumps(names), "saved_keys": json.dumps(list(sd.keys())), "scale": json.dumps(net.unet_loras[0].scale),
+            "alpha": json.dumps(float(net.unet_loras[0].alpha)), "peft_format": json.dumps(bool(net.peft_format)),
+            "state_dict_keys_first": json.dumps(list(net.state_dict().keys())[:6])}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "lora_flux_tiny.safetensors"), meta)
+    print("lora golden:", len(names), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale)
+
+
+def golden_flowmatch():
+    import diffusers
+
+    class _Cfg(dict):
+        __getattr__ = dict.get
+
+    class FlowMatchEulerDiscreteScheduler:  # minimal stand-in for the un-vendored diffusers base class
+        def __init__(self, num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False, **kw):
+            self.config = _Cfg(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=use_dynamic_shifting, **kw)
+            self.shift = shift
+
+    diffusers.FlowMatchEulerDiscreteScheduler = FlowMatchEulerDiscreteScheduler
+    sys.modules.pop("toolkit.samplers.custom_flowmatch_sampler", None)
+    from toolkit.samplers.custom_flowmatch_sampler import CustomFlowMatchEulerDiscreteScheduler, calculate_shift
+
+    s = CustomFlowMatchEulerDiscreteScheduler()
+    out = {"linear": s.set_train_timesteps(1000, "cpu", "linear").clone()}
+    torch.manual_seed(123)
+    out["sigmoid_seed123"] = s.set_train_timesteps(1000, "cpu", "sigmoid").clone()
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3, 16, 8, 8, generator=g)
+    eps = torch.randn(3, 16, 8, 8, generator=g)
+    ts = torch.tensor([1000.0, 417.25, 1.0])
+    out["x0"], out["eps"], out["ts"] = x0, eps, ts
+    noisy = torch.cat([s.add_noise(x0[i:i + 1], eps[i:i + 1], ts[i:i + 1]) for i in range(3)], 0)  # per-sample loop like
+    out["noisy"] = noisy  # toolkit/stable_diffusion_model.py:1861-1875
+    out["calc_shift"] = torch.tensor([calculate_shift(n) for n in (256, 1024, 4096, 3952)], dtype=torch.float64)
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "flowmatch.safetensors"))
+    print("flowmatch golden written")
+
+
+if __name__ == "__main__":
+    golden_lora()
+    golden_flowmatch()

@@ -1,0 +1,51 @@
+"""CPU-side checks of the C-ABI boundary: the in-tree library loads, exports every entry point declared in
+include/aitk_mi355.h, and the ctypes mirrors agree with the C struct sizes (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd import _capi
+
+
+def _declared(repo_root):
+    src = open(os.path.join(repo_root, "include", "aitk_mi355.h")).read()
+    return sorted(set(re.findall(r"\b(?:int|int32_t|int64_t)\s+(aitk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    names = _declared(repo_root)
+    assert len(names) >= 25, names
+    assert os.path.exists(_capi.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_struct_size_handshake_and_abi_version():
+    lib = _capi.lib()  # raises on any Python/C struct size mismatch
+    assert lib.aitk_abi_version() == 1
+    assert lib.aitk_sizeof(0) == ctypes.sizeof(_capi.GemmArgs)
+    assert lib.aitk_sizeof(99) == -1
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_gpu():
+    lib = _capi.lib()
+    g = _capi.GemmArgs()
+    g.M, g.N, g.K = 0, 128, 64
+    assert lib.aitk_gemm_nt(ctypes.byref(g), None) == -1  # AITK_ERR_SHAPE
+    g.M, g.K = 128, 60
+    assert lib.aitk_gemm_nt(ctypes.byref(g), None) == -1
+    a = _capi.AttnArgs()
+    a.B, a.H, a.S, a.D = 1, 2, 64, 64
+    assert lib.aitk_attn_fwd(ctypes.byref(a), None) == -1  # head_dim must be 128
+    assert lib.aitk_lora_wgrad_workspace_bytes(1000, 16, 3072) == 4 * 16 * 3072 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libaitk_mi355.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _capi.lib()

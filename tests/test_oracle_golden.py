@@ -1,0 +1,147 @@
+"""Pins the oracle (and the native host logic driven by the oracle's kernel table) to vectors produced by the
+REFERENCE'S OWN CODE (tests/golden/make_golden.py executed toolkit.lora_special / custom_flowmatch_sampler under shims)."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.flowmatch import FlowMatchTrainSchedule, calculate_shift
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+from ai_toolkit_amd.lora import FusedLoRANetwork
+from oracle import flux_ref, lora_ref, ref_ops
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TINY = dict(in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2,
+            joint_attention_dim=64, pooled_projection_dim=32)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    path = os.path.join(G, "lora_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    return load_file(path), meta
+
+
+def tiny_inputs():
+    g = torch.Generator().manual_seed(3)
+    Hl, Wl, n_txt, B = 4, 4, 5, 2
+    hidden = torch.randn(B, (Hl // 2) * (Wl // 2), 64, generator=g)
+    enc = torch.randn(B, n_txt, 64, generator=g)
+    pooled = torch.randn(B, 32, generator=g)
+    t = torch.tensor([0.3, 0.8])
+    img_ids, txt_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+    return hidden, enc, pooled, t, img_ids, txt_ids, torch.ones(B)
+
+
+def oracle_model():
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    return model
+
+
+def test_oracle_lora_matches_reference_names_init_forward_grads_and_saved_file(gold):
+    t, meta = gold
+    model = oracle_model()
+    torch.manual_seed(99)
+    net = lora_ref.RefLoRANetwork(model, 8)
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    assert meta["peft_format"] is True and meta["scale"] == 1.0  # alpha forced to rank (toolkit/lora_special.py:428-433)
+    for m in net.unet_loras:
+        assert torch.equal(m.lora_down.weight, t[f"init/{m.lora_name}/down"]), m.lora_name  # same RNG consumption
+        with torch.no_grad():
+            m.lora_up.weight.copy_(t[f"warm/{m.lora_name}/up"])
+    net.apply_to()
+    for tag, mult in (("m1", [1.0]), ("mvec", [0.5, -1.5])):
+        net.torch_multiplier = torch.tensor(mult)
+        net.zero_grad()
+        with net:
+            pred = model(*tiny_inputs())
+            pred.square().sum().backward()
+        assert torch.allclose(pred, t[f"{tag}/pred"], rtol=1e-5, atol=1e-6)
+        for m in net.unet_loras:
+            assert torch.allclose(m.lora_down.weight.grad, t[f"{tag}/grad/{m.lora_name}/down"], rtol=1e-4, atol=1e-6)
+            assert torch.allclose(m.lora_up.weight.grad, t[f"{tag}/grad/{m.lora_name}/up"], rtol=1e-4, atol=1e-6)
+    sd = net.peft_state_dict(torch.float32)
+    assert list(sd.keys()) == meta["saved_keys"]
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+
+
+def test_native_network_and_host_graph_match_reference_vectors(gold, tmp_path):
+    t, meta = gold
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=8, alpha=1.0)
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    for m in net.unet_loras:
+        assert torch.equal(m.lora_down.weight, t[f"init/{m.lora_name}/down"]), m.lora_name
+        assert m.scale == 1.0 and float(m.alpha) == meta["alpha"]
+        with torch.no_grad():
+            m.lora_up.weight.copy_(t[f"warm/{m.lora_name}/up"])
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    for tag, mult in (("m1", 1.0), ("mvec", [0.5, -1.5])):
+        net.multiplier = mult
+        with net:
+            pred = nat.forward_native(*tiny_inputs())
+            assert torch.allclose(pred, t[f"{tag}/pred"], rtol=1e-4, atol=1e-5)
+            net.zero_grad_arena()
+            nat.backward_native((2 * pred).detach())
+        for m in net.unet_loras:
+            assert torch.allclose(m.lora_down.weight.grad, t[f"{tag}/grad/{m.lora_name}/down"], rtol=2e-4, atol=1e-5), m.lora_name
+            assert torch.allclose(m.lora_up.weight.grad, t[f"{tag}/grad/{m.lora_name}/up"], rtol=2e-4, atol=1e-5), m.lora_name
+    # saved file: same keys, same values, loadable back (PEFT format, toolkit/network_mixins.py:607-624)
+    f = str(tmp_path / "lora.safetensors")
+    net.save_weights(f, dtype=torch.float32, metadata={"training_info": {"step": 3, "epoch": 0}, "name": "x"})
+    sd = load_file(f)
+    assert sorted(sd.keys()) == sorted(meta["saved_keys"])
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+    with safe_open(f, "pt") as fh:
+        md = fh.metadata()
+    assert md["format"] == "pt" and json.loads(md["training_info"]) == {"step": 3, "epoch": 0}
+    before = net.arena_p.clone()
+    net.arena_p.zero_()
+    assert net.load_weights(f) is None
+    assert torch.equal(net.arena_p, before)
+    # state_dict surface: <lora_name>.lora_down.weight / .lora_up.weight / .alpha ; _runtime_scale not persisted
+    keys = list(net.state_dict().keys())
+    assert keys[:3] == meta["state_dict_keys_first"][:3]
+    assert not any("_runtime_scale" in k for k in keys)
+
+
+def test_flowmatch_schedule_matches_reference_scheduler():
+    t = load_file(os.path.join(G, "flowmatch.safetensors"))
+    s = FlowMatchTrainSchedule()
+    assert torch.equal(s.set_train_timesteps(1000, "cpu", "linear"), t["linear"])
+    torch.manual_seed(123)
+    assert torch.equal(s.set_train_timesteps(1000, "cpu", "sigmoid"), t["sigmoid_seed123"])
+    x0, eps, ts = t["x0"], t["eps"], t["ts"]
+    B, Cc, Hh, W = x0.shape
+    noisy = torch.empty(B, Hh * W // 4, Cc * 4)
+    target = torch.empty_like(noisy)
+    ref_ops.flow_noise_pack(x0, eps, ts, noisy, target)
+    assert torch.allclose(flux_ref.unpack_latents(noisy, Hh, W), t["noisy"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(flux_ref.unpack_latents(target, Hh, W), eps - x0, rtol=1e-6, atol=1e-6)
+    cs = torch.tensor([calculate_shift(n) for n in (256, 1024, 4096, 3952)], dtype=torch.float64)
+    assert torch.allclose(cs, t["calc_shift"])
+
+
+def test_pack_unpack_roundtrip_and_ids():
+    x = torch.randn(2, 16, 8, 6)
+    p = flux_ref.pack_latents(x)
+    assert p.shape == (2, 12, 64)
+    assert torch.equal(flux_ref.unpack_latents(p, 8, 6), x)
+    img_ids, txt_ids = flux_ref.make_ids(8, 6, 5)
+    assert img_ids.shape == (12, 3) and txt_ids.shape == (5, 3)
+    assert img_ids[4].tolist() == [0.0, 1.0, 1.0]

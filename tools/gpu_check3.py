@@ -160,7 +160,8 @@ def main():
     rec("noise_mse", t_noise_mse)
     rec("adamw", t_adamw)
     rec("shadows", t_shadows)
-    rec("full_flux_B1", lambda: full_flux_step(1, 3))
+    if "--no-full" not in sys.argv:
+        rec("full_flux_B1", lambda: full_flux_step(1, 3))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/gpu_check3.json", "w") as fh:
         json.dump(OUT, fh, indent=1)
