@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
         ("aux_in", vp), ("ld_aux_in", i64),
         ("gate", vp), ("ld_gate", i64), ("gate_rows", i32),
         ("M", i32), ("N", i32), ("K", i32), ("K2", i32),
-        ("flags", i32), ("stage_mode", i32),
+        ("flags", i32), ("stage_mode", i32), ("tile_mode", i32), ("_pad2", i32),
     ]
 
 

@@ -85,16 +85,59 @@ struct TileStager {
   }
 };
 
+
+// ---- swizzled, unpadded tiles: [rows][128] bf16, 256-B rows, physical 16-B chunk = logical chunk ^ (row & 15).
+// Conflict-free for ds_read_b128 fragments and for tr16 reads, and lane-linear so LDS-DMA can fill them
+// (the XOR goes on the global SOURCE address, guide rule 21).
+__device__ __forceinline__ s16x8_t frag_rm_sw(const bf16_t* tile, int row0, int k0, int lane) {
+  const int row = row0 + (lane & 31);
+  const int c = (k0 >> 3) + (lane >> 5);
+  return *reinterpret_cast<const s16x8_t*>(reinterpret_cast<const char*>(tile) + row * 256 + ((c ^ (row & 15)) << 4));
+}
+__device__ __forceinline__ s16x8_t frag_tr_perm_sw(const bf16_t* tile, int kb, int col0, int lane) {
+  const int h = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15;
+  const int row = kb + 4 * h + (i >> 2);
+  const int col = col0 + gq * 16 + (i & 3) * 4;
+  const int c = col >> 3, off = (col & 7) * 2;
+  const char* base = reinterpret_cast<const char*>(tile);
+  s16x4_t lo = tr16a(reinterpret_cast<const bf16_t*>(base + row * 256 + ((c ^ (row & 15)) << 4) + off));
+  const int row2 = row + 8;
+  s16x4_t hi = tr16a(reinterpret_cast<const bf16_t*>(base + row2 * 256 + ((c ^ (row2 & 15)) << 4) + off));
+  s16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+// LDS-DMA fill of a [ROWS][128] swizzled tile from rows row0.. (clamped to S-1) of a [*, ld] matrix slice.
+template <int ROWS>
+__device__ __forceinline__ void glds_tile(bf16_t* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
+  constexpr int NI = ROWS / 4;  // wave-instructions per tile (4 rows = 1 KiB each)
+#pragma unroll
+  for (int ii = 0; ii < NI / 4; ++ii) {
+    const int ins = wave + 4 * ii;
+    const int row = ins * 4 + (lane >> 4);
+    const int pc = lane & 15;
+    const int c = pc ^ (row & 15);
+    const int r = min(row0 + row, S - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)r * ld + c * 8),
+                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + ins * 1024), 16, 0, 0);
+  }
+}
+
 // ============================================================================================ forward
-// grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, double-buffered in LDS.
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AitkAttnArgs p) {
+// grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
+// workgroups per CU, <=256 registers -> 2 waves per SIMD so one workgroup's softmax overlaps the other's MFMAs).
+// Online softmax with deferred rescale (guide T13, threshold 2^8): O/l are only rescaled when the running max grows by
+// more than 8 in the log2 domain; P is then bounded by 2^8 instead of 1, exact in fp32 accumulation.
+#define ATTN_DEFER_THR 8.0f
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* kt[2];
   bf16_t* vt[2];
   kt[0] = reinterpret_cast<bf16_t*>(smem);
-  vt[0] = kt[0] + 64 * KP;
-  kt[1] = vt[0] + 64 * VP;
-  vt[1] = kt[1] + 64 * KP;
+  vt[0] = kt[0] + 64 * 128;
+  kt[1] = vt[0] + 64 * 128;
+  vt[1] = kt[1] + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -104,7 +147,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AitkAttnArgs p) {
   const bf16_t* Kb = p.K + (long)b * S * p.ldk + hd * 128;
   const bf16_t* Vb = p.V + (long)b * S * p.ldv + hd * 128;
 
-  // Q^T operand fragments: lane holds Q[q0 + l31][16 ks + 8h .. +8]
   s16x8_t qf[8];
   {
     const int qr = min(q0 + l31, S - 1);
@@ -115,74 +157,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AitkAttnArgs p) {
   f32x16_t o[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) o[d] = zero16();
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // m_run in the scaled log2 domain
   const float c2 = p.scale * 1.4426950408889634f;
 
   const int ntiles = (S + 63) / 64;
-  TileStager<64> ks_, vs_;
-  ks_.load(Kb, p.ldk, 0, S, tid, false);
-  vs_.load(Vb, p.ldv, 0, S, tid, true);
-  ks_.store(kt[0], KP, tid);
-  vs_.store(vt[0], VP, tid);
+  glds_tile<64>(kt[0], Kb, p.ldk, 0, S, wave, lane);
+  glds_tile<64>(vt[0], Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntiles) {
-      ks_.load(Kb, p.ldk, (t + 1) * 64, S, tid, false);
-      vs_.load(Vb, p.ldv, (t + 1) * 64, S, tid, true);
+      glds_tile<64>(kt[cur ^ 1], Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(vt[cur ^ 1], Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
-    // ---- S^T = K Q^T : two 32-kv blocks
     f32x16_t s[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       s[j] = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) s[j] = mfma32(frag_rm(kt[cur], KP, 32 * j, 16 * ks, lane), qf[ks], s[j]);
+      for (int ks = 0; ks < 8; ++ks) s[j] = mfma32(frag_rm_sw(kt[cur], 32 * j, 16 * ks, lane), qf[ks], s[j]);
     }
-    // ---- online softmax (lane owns query row q0+l31; halves h hold disjoint kv subsets)
     const int kv0 = t * 64;
+    if (kv0 + 64 > S) {  // wave-uniform: only the last tile masks
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + 32 * j + crow(r, h) >= S) s[j][r] = -INFINITY;
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[j][r] * c2;
-        if (kv0 + 32 * j + crow(r, h) >= S) v = -INFINITY;
-        s[j][r] = v;
-        mt = fmaxf(mt, v);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[j][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;
+    if (!__all(mt - m_run <= ATTN_DEFER_THR)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      m_run = m_new;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float e = __builtin_amdgcn_exp2f(s[j][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[j][r], c2, -m_run));
         s[j][r] = e;
         ps += e;
       }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    // ---- O^T += V^T P^T : 4 d-blocks x 4 k-steps of 16 kv
+    l_run += ps;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const s16x8_t pf = pack_acc8(s[kk >> 1], 8 * (kk & 1));
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm(vt[cur], VP, 16 * kk, 32 * d, lane), pf, o[d]);
-    }
-    if (t + 1 < ntiles) {
-      ks_.store(kt[cur ^ 1], KP, tid);
-      vs_.store(vt[cur ^ 1], VP, tid);
+      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_sw(vt[cur], 16 * kk, 32 * d, lane), pf, o[d]);
     }
     __syncthreads();
   }
-  // ---- epilogue
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
@@ -236,10 +272,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   float* lt[2];
   float* dt[2];
   qt[0] = reinterpret_cast<bf16_t*>(smem);
-  dot_[0] = qt[0] + 32 * KP;
-  qt[1] = dot_[0] + 32 * KP;
-  dot_[1] = qt[1] + 32 * KP;
-  lt[0] = reinterpret_cast<float*>(dot_[1] + 32 * KP);
+  dot_[0] = qt[0] + 32 * 128;
+  qt[1] = dot_[0] + 32 * 128;
+  dot_[1] = qt[1] + 32 * 128;
+  lt[0] = reinterpret_cast<float*>(dot_[1] + 32 * 128);
   dt[0] = lt[0] + 32;
   lt[1] = dt[0] + 32;
   dt[1] = lt[1] + 32;
@@ -274,68 +310,64 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   }
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 31) / 32;
-  TileStager<32> qs_, ds_;
-  float lreg = 0.f;
-  auto load_stats = [&](int t) {
+  // rows >= S are clamped (finite data); their L2 = +inf makes P = 0 so they contribute nothing
+  auto stage = [&](int t, int buf) {
+    // 32-row tiles: 8 wave-instructions each; wave w issues instructions w and w+4 of both tiles
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int ins = wave + 4 * ii;
+      const int row = ins * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ (row & 15);
+      const int r = min(t * 32 + row, S - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + (long)r * p.ldq + c * 8),
+                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(qt[buf]) + ins * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dOb + (long)r * p.lddo + c * 8),
+                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dot_[buf]) + ins * 1024), 16, 0, 0);
+    }
     if (tid < 64) {
       const int q = t * 32 + (tid & 31);
-      if (tid < 32) lreg = q < S ? Lb[q] : INFINITY;
-      else lreg = q < S ? Db[q] : 0.f;
+      if (tid < 32) lt[buf][tid] = q < S ? Lb[q] : INFINITY;
+      else dt[buf][tid - 32] = q < S ? Db[q] : 0.f;
     }
   };
-  auto store_stats = [&](int buf) {
-    if (tid < 32) lt[buf][tid] = lreg;
-    else if (tid < 64) dt[buf][tid - 32] = lreg;
-  };
-  qs_.load(Qb, p.ldq, 0, S, tid, true);
-  ds_.load(dOb, p.lddo, 0, S, tid, true);
-  load_stats(0);
-  qs_.store(qt[0], KP, tid);
-  ds_.store(dot_[0], KP, tid);
-  store_stats(0);
+  stage(0, 0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) {
-      qs_.load(Qb, p.ldq, (t + 1) * 32, S, tid, true);
-      ds_.load(dOb, p.lddo, (t + 1) * 32, S, tid, true);
-      load_stats(t + 1);
-    }
-    // S[q][kv] and dP[q][kv] : D rows = q (tile rows), cols = kv (lane l31)
+    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
     f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      s = mfma32(frag_rm(qt[cur], KP, 0, 16 * ks, lane), kf[ks], s);
-      dp = mfma32(frag_rm(dot_[cur], KP, 0, 16 * ks, lane), vf[ks], dp);
+      s = mfma32(frag_rm_sw(qt[cur], 0, 16 * ks, lane), kf[ks], s);
+      dp = mfma32(frag_rm_sw(dot_[cur], 0, 16 * ks, lane), vf[ks], dp);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = crow(r, h);
-      const float pr = __builtin_amdgcn_exp2f(s[r] * c2 - lt[cur][qi]);
-      s[r] = pr;
-      dp[r] = pr * (dp[r] - dt[cur][qi]);
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4*>(lt[cur] + 8 * g + 4 * h);
+      const float4 d4 = *reinterpret_cast<const float4*>(dt[cur] + 8 * g + 4 * h);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+      const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
+        s[r] = pr;
+        dp[r] = pr * (dp[r] - ds[e]);
+      }
     }
-    // dV[kv][d] += sum_q P[q][kv] dO[q][d] ; dK[kv][d] += sum_q dS[q][kv] Q[q][d]
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const s16x8_t pf = pack_acc8(s, 8 * kk);
       const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        dv[d] = mfma32(pf, frag_tr_perm(dot_[cur], KP, 16 * kk, 32 * d, lane), dv[d]);
-        dk[d] = mfma32(df, frag_tr_perm(qt[cur], KP, 16 * kk, 32 * d, lane), dk[d]);
+        dv[d] = mfma32(pf, frag_tr_perm_sw(dot_[cur], 16 * kk, 32 * d, lane), dv[d]);
+        dk[d] = mfma32(df, frag_tr_perm_sw(qt[cur], 16 * kk, 32 * d, lane), dk[d]);
       }
-    }
-    if (t + 1 < ntiles) {
-      qs_.store(qt[cur ^ 1], KP, tid);
-      ds_.store(dot_[cur ^ 1], KP, tid);
-      store_stats(cur ^ 1);
     }
     __syncthreads();
   }
-  // dK/dV accumulators: D[i = kv (A rows = lane l31 of P^T)...]  -> rows = kv?  see layout note below
-  // mfma32(a = P^T frag (rows kv = l31), b = dO frag (cols d = l31)) gives D[i = kv][j = d]:
-  // lane holds column d = 32*blk + l31 and rows kv = crow(r, h).
+  // D[i = kv][j = d]: lane holds column d = 32*blk + l31 and rows kv = crow(r, h)
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -353,14 +385,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 // grid (ceil(S/128), H, B); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
 // loops over KV tiles of 64 rows (K, V row-major in LDS).  S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP^T - delta[q]);
 // dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q]  (K through tr16, dS^T straight from registers).
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AitkAttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* kt[2];
   bf16_t* vt[2];
   kt[0] = reinterpret_cast<bf16_t*>(smem);
-  vt[0] = kt[0] + 64 * KP;
-  kt[1] = vt[0] + 64 * KP;
-  vt[1] = kt[1] + 64 * KP;
+  vt[0] = kt[0] + 64 * 128;
+  kt[1] = vt[0] + 64 * 128;
+  vt[1] = kt[1] + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -388,42 +420,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   for (int d = 0; d < 4; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 63) / 64;
-  TileStager<64> ks_, vs_;
-  ks_.load(Kb, p.ldk, 0, S, tid, true);
-  vs_.load(Vb, p.ldv, 0, S, tid, true);
-  ks_.store(kt[0], KP, tid);
-  vs_.store(vt[0], KP, tid);
+  glds_tile<64>(kt[0], Kb, p.ldk, 0, S, wave, lane);
+  glds_tile<64>(vt[0], Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntiles) {
-      ks_.load(Kb, p.ldk, (t + 1) * 64, S, tid, true);
-      vs_.load(Vb, p.ldv, (t + 1) * 64, S, tid, true);
+      glds_tile<64>(kt[cur ^ 1], Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(vt[cur ^ 1], Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
+    const bool tail = t * 64 + 64 > S;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        s = mfma32(frag_rm(kt[cur], KP, 32 * j, 16 * ks, lane), qf[ks], s);
-        dp = mfma32(frag_rm(vt[cur], KP, 32 * j, 16 * ks, lane), gf[ks], dp);
+        s = mfma32(frag_rm_sw(kt[cur], 32 * j, 16 * ks, lane), qf[ks], s);
+        dp = mfma32(frag_rm_sw(vt[cur], 32 * j, 16 * ks, lane), gf[ks], dp);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kv = t * 64 + 32 * j + crow(r, h);
-        const float pr = kv < S ? __builtin_amdgcn_exp2f(s[r] * c2 - L2) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -L2));
+        if (tail && t * 64 + 32 * j + crow(r, h) >= S) pr = 0.f;
         dp[r] = pr * (dp[r] - dl);
       }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm(kt[cur], KP, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_sw(kt[cur], 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
       }
-    }
-    if (t + 1 < ntiles) {
-      ks_.store(kt[cur ^ 1], KP, tid);
-      vs_.store(vt[cur ^ 1], KP, tid);
     }
     __syncthreads();
   }
@@ -452,12 +478,7 @@ extern "C" int aitk_attn_fwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   int rc = attn_check(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->LSE) return AITK_ERR_ARG;
-  const size_t lds = 2 * (64 * KP + 64 * VP) * sizeof(bf16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  const size_t lds = 4 * 64 * 128 * sizeof(bf16_t);  // 64 KiB
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
@@ -474,15 +495,10 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((npairs + 15) / 16)), dim3(256), 0, s, *a);
   AITK_LAUNCH_CHECK();
   dim3 grid((a->S + 127) / 128, a->H, a->B);
-  const size_t lds1 = 4 * 32 * KP * sizeof(bf16_t) + 4 * 32 * sizeof(float);
+  const size_t lds1 = 4 * 32 * 128 * sizeof(bf16_t) + 4 * 32 * sizeof(float);
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), lds1, s, *a);
   AITK_LAUNCH_CHECK();
-  const size_t lds2 = 4 * 64 * KP * sizeof(bf16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    attr_set = true;
-  }
+  const size_t lds2 = 4 * 64 * 128 * sizeof(bf16_t);  // 64 KiB
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds2, s, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;

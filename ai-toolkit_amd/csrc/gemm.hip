@@ -17,10 +17,7 @@
 #include "common.h"
 #include "aitk_args.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
 
 __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
   if (seg_rows > 0) {
@@ -31,11 +28,18 @@ __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, in
   return base + (long)m * ld;
 }
 
-template <int STAGE>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
+// Tile configs: <128,128,2,2> (4 waves, 64x64 per wave, 64 KiB LDS, 2 workgroups/CU) for small / ragged problems and
+// <256,256,2,4> (8 waves, 128x64 per wave, 128 KiB LDS, 1 workgroup/CU): twice the operand reuse per LDS byte.
+template <int STAGE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
+  constexpr int NT = 64 * WM * WN;           // threads
+  constexpr int RPP = NT / 8;                // tile rows staged per pass (8 x 16-B chunks per 128-B row)
+  constexpr int PA = BM / RPP, PB = BN / RPP;  // staging passes per operand
+  constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   const int lid = xcd_remap(blockIdx.x, nwg);
@@ -52,32 +56,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
   const int srow = tid >> 3;
   const int pc = tid & 7;
   const int cc = pc ^ (srow & 7);  // logical 16-B chunk held at physical slot pc (row&7 == srow&7 for all i)
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
-  const bf16_t* pa2[4];
-  const bf16_t* pb2[4];
+  const bf16_t* pa[PA];
+  const bf16_t* pb[PB];
+  const bf16_t* pa2[PA];
+  const bf16_t* pb2[PB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ra = min(m0 + srow + 32 * i, p.M - 1);
-    int rb = min(n0 + srow + 32 * i, p.N - 1);
+  for (int i = 0; i < PA; ++i) {
+    int ra = min(m0 + srow + RPP * i, p.M - 1);
     pa[i] = seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra);
-    pb[i] = p.B + (long)rb * p.ldb;
     pa2[i] = p.K2 > 0 ? p.A2 + (long)ra * p.lda2 : nullptr;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    int rb = min(n0 + srow + RPP * i, p.N - 1);
+    pb[i] = p.B + (long)rb * p.ldb;
     pb2[i] = p.K2 > 0 ? p.B2 + (long)rb * p.ldb2 : nullptr;
   }
   const int nk1 = (p.K + BK - 1) / BK;
   const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
   const int nsteps = nk1 + nk2;
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra_reg[4], rb_reg[4];
+  uint4 ra_reg[PA], rb_reg[PB];
 
   auto step_info = [&](int s, int& k0, int& Kseg, bool& second) {
     second = s >= nk1;
@@ -92,21 +99,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
     const int kk = k0 + cc * 8;
     const bool valid = kk < Kseg;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PA; ++i) {
       const bf16_t* a = second ? pa2[i] : pa[i];
-      const bf16_t* b = second ? pb2[i] : pb[i];
       ra_reg[i] = valid ? *reinterpret_cast<const uint4*>(a + kk) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const bf16_t* b = second ? pb2[i] : pb[i];
       rb_reg[i] = valid ? *reinterpret_cast<const uint4*>(b + kk) : make_uint4(0, 0, 0, 0);
     }
   };
   auto write_lds = [&](int buf) {
-    char* sa = smem + buf * 2 * TILE_BYTES;
-    char* sb = sa + TILE_BYTES;
+    char* sa = smem + buf * BUF_BYTES;
+    char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sa + (tid + 256 * i) * 16) = ra_reg[i];
-      *reinterpret_cast<uint4*>(sb + (tid + 256 * i) * 16) = rb_reg[i];
-    }
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<uint4*>(sa + (tid + NT * i) * 16) = ra_reg[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<uint4*>(sb + (tid + NT * i) * 16) = rb_reg[i];
   };
   auto issue_glds = [&](int s, int buf) {
     int k0, Kseg;
@@ -114,17 +123,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
     step_info(s, k0, Kseg, second);
     int kk = k0 + cc * 8;
     if (kk >= Kseg) kk = 0;  // in-bounds garbage; those k-steps are skipped by the compute phase
-    char* sa = smem + buf * 2 * TILE_BYTES;
-    char* sb = sa + TILE_BYTES;
+    char* sa = smem + buf * BUF_BYTES;
+    char* sb = sa + A_BYTES;
+    // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PA; ++i) {
       const bf16_t* a = second ? pa2[i] : pa[i];
-      const bf16_t* b = second ? pb2[i] : pb[i];
-      // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + kk),
-                                       (__attribute__((address_space(3))) void*)(sa + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const bf16_t* b = second ? pb2[i] : pb[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + kk),
-                                       (__attribute__((address_space(3))) void*)(sb + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sb + (wave * 64 + NT * i) * 16), 16, 0, 0);
     }
   };
   auto compute = [&](int s, int buf) {
@@ -132,29 +144,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
     bool second;
     step_info(s, k0, Kseg, second);
     const int kvalid = min(BK, Kseg - k0);
-    const char* sa = smem + buf * 2 * TILE_BYTES;
-    const char* sb = sa + TILE_BYTES;
+    const char* sa = smem + buf * BUF_BYTES;
+    const char* sb = sa + A_BYTES;
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks * 16 < kvalid) {
-        s16x8_t af[2], bfr[2];
+        s16x8_t af[MI], bfr[NI];
         const int c = ks * 2 + h;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          int row = wr * 64 + mi * 32 + l31;
+        for (int mi = 0; mi < MI; ++mi) {
+          int row = wr * (32 * MI) + mi * 32 + l31;
           af[mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
         }
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          int row = wc * 64 + ni * 32 + l31;
+        for (int ni = 0; ni < NI; ++ni) {
+          int row = wc * (32 * NI) + ni * 32 + l31;
           bfr[ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
         }
         // swapped operands: D rows = n, D cols = m  -> each lane owns one m and 4 consecutive n per group
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma32(bfr[ni], af[mi], acc[mi][ni]);
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(bfr[ni], af[mi], acc[mi][ni]);
       }
     }
   };
@@ -183,16 +195,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AitkGemmArgs p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int flags = p.flags;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wr * 64 + mi * 32 + l31;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wr * (32 * MI) + mi * 32 + l31;
     if (m >= p.M) continue;
     bf16_t* crow = const_cast<bf16_t*>(seg_row(p.C, p.ldc, p.c_seg_rows, p.c_seg_stride, m));
     const bf16_t* gate_row = (flags & AITK_EPI_GATE_RES) ? p.gate + (long)(m / p.gate_rows) * p.ld_gate : nullptr;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wc * 64 + ni * 32 + 8 * g + 4 * h;
+        const int nb = n0 + wc * (32 * NI) + ni * 32 + 8 * g + 4 * h;
         if (nb >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -251,13 +263,31 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
-  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  const size_t lds = 4 * TILE_BYTES;
-  if (a->stage_mode == 1) {
-    if (a->K % 8) return AITK_ERR_SHAPE;
-    hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3(tiles), dim3(256), lds, stream, *a);
+  hipStream_t st = stream;
+  // tile choice: 256x256 when the problem fills the chip with big tiles (>= 1 full round of 256 CUs) or is overridden
+  int big = a->tile_mode == 2 ? 1 : 0;
+  if (a->tile_mode == 0) {
+    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    big = (a->M >= 1024 && a->N >= 512 && t256 >= 192) ? 1 : 0;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<0, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_set = true;
+  }
+  if (big) {
+    const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    if (a->stage_mode == 1)
+      hipLaunchKernelGGL((gemm_nt_kernel<1, 256, 256, 2, 4>), dim3(tiles), dim3(512), 131072, st, *a);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<0, 256, 256, 2, 4>), dim3(tiles), dim3(512), 131072, st, *a);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<0>, dim3(tiles), dim3(256), lds, stream, *a);
+    const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    if (a->stage_mode == 1)
+      hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 128, 2, 2>), dim3(tiles), dim3(256), 65536, st, *a);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<0, 128, 128, 2, 2>), dim3(tiles), dim3(256), 65536, st, *a);
   }
   AITK_LAUNCH_CHECK();
   return AITK_OK;

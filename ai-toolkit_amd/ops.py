@@ -9,6 +9,7 @@ from . import _capi
 from ._capi import EPI_ACCUM, EPI_BIAS, EPI_DGELU, EPI_GATE_RES, EPI_GELU  # noqa: F401
 
 BF16 = torch.bfloat16
+TILE_MODE = int(os.environ.get("AITK_GEMM_TILE", "0"))  # 0 auto, 1 = 128x128, 2 = 256x256
 STAGE_MODE = int(os.environ.get("AITK_GEMM_STAGE", "1"))  # 1 = LDS-DMA staging (faster, profiles/r01_gpu_check_01)
 
 
@@ -23,7 +24,7 @@ def _row_major(t, name):
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None,
-            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None):
+            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T + bias).
 
     a_seg / c_seg = (seg_rows, seg_stride_elems): logical row m lives at base + (m // seg_rows) * seg_stride
@@ -63,6 +64,7 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
         g.gate, g.gate_rows = _ptr(gate), gate_rows
     g.M, g.N, g.K, g.flags = M, N, K, flags
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
+    g.tile_mode = TILE_MODE if tile_mode is None else tile_mode
     _capi.check(_capi.lib().aitk_gemm_nt(C.byref(g), _capi.stream_ptr()), "aitk_gemm_nt")
     return out
 

@@ -55,6 +55,8 @@ typedef struct AitkGemmArgs {
   int32_t M, N, K, K2;
   int32_t flags;
   int32_t stage_mode; /* 0 = VGPR-staged, 1 = LDS-DMA (global_load_lds) */
+  int32_t tile_mode;  /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves) */
+  int32_t _pad2;
 } AitkGemmArgs;
 
 int aitk_abi_version(void);

@@ -41,7 +41,7 @@ def rows_per_block():
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-            a_seg=None, c_seg=None, M=None, stage_mode=None):
+            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None):
     """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342)."""
     if M is None:
         M = a.shape[0]
