@@ -272,13 +272,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   float* lt[2];
   float* dt[2];
   qt[0] = reinterpret_cast<bf16_t*>(smem);
-  dot_[0] = qt[0] + 32 * 128;
-  qt[1] = dot_[0] + 32 * 128;
-  dot_[1] = qt[1] + 32 * 128;
-  lt[0] = reinterpret_cast<float*>(dot_[1] + 32 * 128);
-  dt[0] = lt[0] + 32;
-  lt[1] = dt[0] + 32;
-  dt[1] = lt[1] + 32;
+  dot_[0] = qt[0] + 64 * 128;
+  qt[1] = dot_[0] + 64 * 128;
+  dot_[1] = qt[1] + 64 * 128;
+  lt[0] = reinterpret_cast<float*>(dot_[1] + 64 * 128);
+  dt[0] = lt[0] + 64;
+  lt[1] = dt[0] + 64;
+  dt[1] = lt[1] + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -309,25 +309,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
     dv[d] = zero16();
   }
   const float c2 = p.scale * 1.4426950408889634f;
-  const int ntiles = (S + 31) / 32;
+  const int ntiles = (S + 63) / 64;  // query tiles of 64 rows, processed as two 32-row halves per barrier
   // rows >= S are clamped (finite data); their L2 = +inf makes P = 0 so they contribute nothing
   auto stage = [&](int t, int buf) {
-    // 32-row tiles: 8 wave-instructions each; wave w issues instructions w and w+4 of both tiles
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      const int ins = wave + 4 * ii;
-      const int row = ins * 4 + (lane >> 4);
-      const int c = (lane & 15) ^ (row & 15);
-      const int r = min(t * 32 + row, S - 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Qb + (long)r * p.ldq + c * 8),
-                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(qt[buf]) + ins * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dOb + (long)r * p.lddo + c * 8),
-                                       (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(dot_[buf]) + ins * 1024), 16, 0, 0);
-    }
-    if (tid < 64) {
-      const int q = t * 32 + (tid & 31);
-      if (tid < 32) lt[buf][tid] = q < S ? Lb[q] : INFINITY;
-      else dt[buf][tid - 32] = q < S ? Db[q] : 0.f;
+    glds_tile<64>(qt[buf], Qb, p.ldq, t * 64, S, wave, lane);
+    glds_tile<64>(dot_[buf], dOb, p.lddo, t * 64, S, wave, lane);
+    if (tid < 128) {
+      const int q = t * 64 + (tid & 63);
+      if (tid < 64) lt[buf][tid] = q < S ? Lb[q] : INFINITY;
+      else dt[buf][tid - 64] = q < S ? Db[q] : 0.f;
     }
   };
   stage(0, 0);
@@ -335,34 +325,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
-    f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      s = mfma32(frag_rm_sw(qt[cur], 0, 16 * ks, lane), kf[ks], s);
-      dp = mfma32(frag_rm_sw(dot_[cur], 0, 16 * ks, lane), vf[ks], dp);
-    }
+    for (int sub = 0; sub < 2; ++sub) {
+      f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 l4 = *reinterpret_cast<const float4*>(lt[cur] + 8 * g + 4 * h);
-      const float4 d4 = *reinterpret_cast<const float4*>(dt[cur] + 8 * g + 4 * h);
-      const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-      const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
-        s[r] = pr;
-        dp[r] = pr * (dp[r] - ds[e]);
+      for (int ks = 0; ks < 8; ++ks) {
+        s = mfma32(frag_rm_sw(qt[cur], 32 * sub, 16 * ks, lane), kf[ks], s);
+        dp = mfma32(frag_rm_sw(dot_[cur], 32 * sub, 16 * ks, lane), vf[ks], dp);
       }
-    }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const s16x8_t pf = pack_acc8(s, 8 * kk);
-      const s16x8_t df = pack_acc8(dp, 8 * kk);
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *reinterpret_cast<const float4*>(lt[cur] + 32 * sub + 8 * g + 4 * h);
+        const float4 d4 = *reinterpret_cast<const float4*>(dt[cur] + 32 * sub + 8 * g + 4 * h);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        dv[d] = mfma32(pf, frag_tr_perm_sw(dot_[cur], 16 * kk, 32 * d, lane), dv[d]);
-        dk[d] = mfma32(df, frag_tr_perm_sw(qt[cur], 16 * kk, 32 * d, lane), dk[d]);
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
+          s[r] = pr;
+          dp[r] = pr * (dp[r] - ds[e]);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const s16x8_t pf = pack_acc8(s, 8 * kk);
+        const s16x8_t df = pack_acc8(dp, 8 * kk);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          dv[d] = mfma32(pf, frag_tr_perm_sw(dot_[cur], 32 * sub + 16 * kk, 32 * d, lane), dv[d]);
+          dk[d] = mfma32(df, frag_tr_perm_sw(qt[cur], 32 * sub + 16 * kk, 32 * d, lane), dk[d]);
+        }
       }
     }
     __syncthreads();
@@ -495,7 +488,12 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((npairs + 15) / 16)), dim3(256), 0, s, *a);
   AITK_LAUNCH_CHECK();
   dim3 grid((a->S + 127) / 128, a->H, a->B);
-  const size_t lds1 = 4 * 32 * 128 * sizeof(bf16_t) + 4 * 32 * sizeof(float);
+  const size_t lds1 = 4 * 64 * 128 * sizeof(bf16_t) + 4 * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), lds1, s, *a);
   AITK_LAUNCH_CHECK();
   const size_t lds2 = 4 * 64 * 128 * sizeof(bf16_t);  // 64 KiB

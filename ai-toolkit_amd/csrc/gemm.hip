@@ -10,7 +10,7 @@
 //
 // Tile: 128x128x64 per 256-thread workgroup (4 waves, 2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16.
 // LDS: double-buffered 2 x (16 KiB A + 16 KiB B), rows of 128 B XOR-swizzled at 16-B granularity
-// (chunk ^= row&7) so the ds_read_b128 fragment reads are <=2-way conflicted (guide §5.5 T2).
+// (chunk ^= (row>>1)&7) so the ds_read_b128 fragment reads are conflict-free (guide §5.5 T2).
 // Staging: STAGE=0 global->VGPR->LDS with the global loads issued before the MFMA phase (T14);
 //          STAGE=1 global_load_lds_dwordx4 (LDS-DMA, lane-linear destination, swizzle on the source address).
 // blockIdx -> tile: bijective XCD remap + grouped (8 row-tiles) ordering for per-XCD L2 reuse (T1).
@@ -55,7 +55,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   // ---- staging geometry: thread owns physical chunk pc of rows r_i = (tid>>3) + 32 i, i = 0..3 ----
   const int srow = tid >> 3;
   const int pc = tid & 7;
-  const int cc = pc ^ (srow & 7);  // logical 16-B chunk held at physical slot pc (row&7 == srow&7 for all i)
+  // logical 16-B chunk held at physical slot pc.  Key = (row>>1)&7: two 128-B rows share one 256-B bank line, so the
+  // 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B slots (conflict-free); same key for every pass i.
+  const int cc = pc ^ ((srow >> 1) & 7);
   const bf16_t* pa[PA];
   const bf16_t* pb[PB];
   const bf16_t* pa2[PA];
@@ -155,12 +157,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           int row = wr * (32 * MI) + mi * 32 + l31;
-          af[mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ (row & 7)) << 4));
+          af[mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           int row = wc * (32 * NI) + ni * 32 + l31;
-          bfr[ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ (row & 7)) << 4));
+          bfr[ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
         }
         // swapped operands: D rows = n, D cols = m  -> each lane owns one m and 4 consecutive n per group
 #pragma unroll
@@ -181,13 +183,36 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
       if (s + 1 < nsteps) write_lds((s + 1) & 1);
       __syncthreads();
     }
-  } else {
+  } else if (STAGE == 1) {
     issue_glds(0, 0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
       if (s + 1 < nsteps) issue_glds(s + 1, (s + 1) & 1);
       compute(s, s & 1);
       __syncthreads();
+    }
+  } else {
+    // STAGE 2: three-buffer LDS-DMA ring, two K-steps in flight across a raw s_barrier, counted vmcnt (guide T3+T4):
+    //   wait(tile s landed: at most the PA+PB DMAs of tile s+1 may stay outstanding) -> barrier (every wave's piece of
+    //   tile s is visible AND every wave finished reading buffer (s-1)%3) -> refill that buffer with tile s+2 -> compute.
+    static_assert(PA + PB == 6 || PA + PB == 4 || PA + PB == 8, "vmcnt immediates below");
+    issue_glds(0, 0);
+    if (nsteps > 1) issue_glds(1, 1);
+    int cur = 0, nxt2 = 2;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+        if (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < nsteps) issue_glds(s + 2, nxt2);
+      compute(s, cur);
+      cur = cur == 2 ? 0 : cur + 1;
+      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
   }
 
@@ -276,7 +301,15 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  if (big) {
+  if (a->stage_mode == 2) {
+    static bool attr3 = false;
+    if (!attr3) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2, 256, 128, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+      attr3 = true;
+    }
+    const int tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<2, 256, 128, 4, 2>), dim3(tiles), dim3(512), 147456, st, *a);
+  } else if (big) {
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     if (a->stage_mode == 1)
       hipLaunchKernelGGL((gemm_nt_kernel<1, 256, 256, 2, 4>), dim3(tiles), dim3(512), 131072, st, *a);

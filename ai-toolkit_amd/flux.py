@@ -195,6 +195,25 @@ class FluxTransformer2DModel(nn.Module):
         self._rope_cache[key] = out
         return out
 
+    def lora_groups(self):
+        """Adapters whose base layers read the same activation: (q, k, v) of each stream / (q, k, v, proj_mlp) of a
+        single block.  Passed to FusedLoRANetwork.build_arena so their lora_down matrices are adjacent."""
+        groups = []
+
+        def add(lins):
+            mods = [l.lora for l in lins]
+            if all(m is not None for m in mods):
+                groups.append(mods)
+
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            add((a.to_q, a.to_k, a.to_v))
+            add((a.add_q_proj, a.add_k_proj, a.add_v_proj))
+        for blk in self.single_transformer_blocks:
+            a = blk.attn
+            add((a.to_q, a.to_k, a.to_v, blk.proj_mlp))
+        return groups
+
     # ------------------------------------------------------------------ helpers
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dt, device=self.x_embedder.weight.device)
@@ -216,34 +235,73 @@ class FluxTransformer2DModel(nn.Module):
             tm = tm.repeat_interleave(B // tm.numel()).contiguous()
         return tm, rows_per_batch
 
+    def _group_down(self, lins, x, *, M, rows_per_batch, B):
+        """One skinny launch for every adapter of a same-input group: returns {id(lin): T view [M, r]} (or {} when the
+        group is not laid out adjacently / inactive)."""
+        if not all(self._lora_active(l) for l in lins):
+            return {}
+        grp = getattr(lins[0].lora, "group", None)
+        if grp is None or [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
+            return {}
+        Tcat = self._new(M, grp["R"])
+        mult, rpb = self._mult(rows_per_batch, B)
+        self.ops.lora_down(x, grp["sh_down"], Tcat, scale=grp["scale"], mult=mult, rows_per_batch=rpb, M=M)
+        out = {}
+        for l in lins:
+            c0 = grp["col"][id(l.lora)]
+            out[id(l)] = Tcat[:, c0:c0 + l.lora.lora_dim]
+        return out
+
     def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-                 a_seg=None, c_seg=None):
-        """out = epi(x W^T + b + T B^T); returns T (saved for the weight gradient) or None."""
+                 a_seg=None, c_seg=None, T=None):
+        """out = epi(x W^T + b + T B^T); returns T (saved for the weight gradient) or None.  A precomputed T (group
+        launch) may be passed in."""
         ops = self.ops
-        T = None
         kw = {}
         if self._lora_active(lin):
             lo = lin.lora
-            T = self._new(M, lo.lora_dim)
-            mult, rpb = self._mult(rows_per_batch, B)
-            ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
+            if T is None:
+                T = self._new(M, lo.lora_dim)
+                mult, rpb = self._mult(rows_per_batch, B)
+                ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
             kw = dict(a2=T, b2=lo.sh_up)
+        else:
+            T = None
         ops.gemm_nt(x, lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out, aux_in=aux_in, gate=gate,
                     gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
         return T
 
-    def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None):
-        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None."""
+    def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
+        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None.
+        With dT_out (a column slice of a group's dT buffer) the lora_down gradient is left to _group_wgrad."""
         if T is None:
             return None
         ops = self.ops
         lo = lin.lora
-        dT = self._new(M, lo.lora_dim)
+        dT = dT_out if dT_out is not None else self._new(M, lo.lora_dim)
         mult, rpb = self._mult(rows_per_batch, B)
         ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
         ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M)
-        ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
+        if dT_out is None:
+            ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
         return dT
+
+    def _group_bwd(self, lins, dys, Ts, x_in, dx, *, M, rows_per_batch, B, first_flags=0):
+        """Backward of several adapters+linears that read the same x_in: dx (+)= sum_j dy_j W_j + dT_j A_j, up-grads per
+        layer, ONE lora_down-gradient launch for the whole group when it is laid out adjacently."""
+        grp = getattr(lins[0].lora, "group", None) if all(t is not None for t in Ts) else None
+        if grp is not None and [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
+            grp = None
+        dTcat = self._new(M, grp["R"]) if grp is not None else None
+        for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
+            dT_out = None
+            if grp is not None:
+                c0 = grp["col"][id(lin.lora)]
+                dT_out = dTcat[:, c0:c0 + lin.lora.lora_dim]
+            dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dT_out)
+            self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
+        if grp is not None:
+            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M)
 
     def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
         """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""
@@ -356,8 +414,9 @@ class FluxTransformer2DModel(nn.Module):
                 xn = self._new(M, d)
                 ops.ln_mod_fwd(x, mod[:, 0:d], mod[:, d:2 * d], xn, rows_per_batch=Ss, mean=mean, rstd=rstd)
                 qkv_raw = self._new(M, 3 * d)
-                r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=M, rows_per_batch=Ss, B=B)
-                              for j, lin in enumerate(qkv_lins)]
+                Tg = self._group_down(qkv_lins, xn, M=M, rows_per_batch=Ss, B=B)
+                r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=M, rows_per_batch=Ss, B=B,
+                                            T=Tg.get(id(lin))) for j, lin in enumerate(qkv_lins)]
                 jobs = [dict(src=qkv_raw[:, 0:d], dst=qkv_j[:, 0:d], weight=qk_norms[0].weight),
                         dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=qk_norms[1].weight),
                         dict(src=qkv_raw[:, 2 * d:], dst=qkv_j[:, 2 * d:], weight=None)]
@@ -407,11 +466,13 @@ class FluxTransformer2DModel(nn.Module):
             ops.ln_mod_fwd(x, mod[:, 0:d], mod[:, d:2 * d], xn, rows_per_batch=S, mean=mean, rstd=rstd)
             qkv_raw = self._new(Mj, 3 * d)
             a = blk.attn
-            r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=Mj, rows_per_batch=S, B=B)
+            Tg = self._group_down((a.to_q, a.to_k, a.to_v, blk.proj_mlp), xn, M=Mj, rows_per_batch=S, B=B)
+            r["T_qkv"] = [self._lin_fwd(lin, xn, qkv_raw[:, j * d:(j + 1) * d], M=Mj, rows_per_batch=S, B=B, T=Tg.get(id(lin)))
                           for j, lin in enumerate((a.to_q, a.to_k, a.to_v))]
             cat = self._new(Mj, 5 * d)
             u = self._new(Mj, 4 * d)
-            r["T_mlp"] = self._lin_fwd(blk.proj_mlp, xn, cat[:, d:], M=Mj, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u)
+            r["T_mlp"] = self._lin_fwd(blk.proj_mlp, xn, cat[:, d:], M=Mj, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u,
+                                       T=Tg.get(id(blk.proj_mlp)))
             qkv_j = self._new(Mj, 3 * d)
             jobs = [dict(src=qkv_raw[:, 0:d], dst=qkv_j[:, 0:d], weight=a.norm_q.weight),
                     dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=a.norm_k.weight),
@@ -492,10 +553,9 @@ class FluxTransformer2DModel(nn.Module):
                     dict(src=dqkv_raw[:, 2 * d:], dst=dqkv_j[:, 2 * d:], weight=None)]
             ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
             dxn = self._new(Mj, d)
-            self._lin_bwd(blk.proj_mlp, du, r["T_mlp"], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B)
-            for j, lin in enumerate((a.to_q, a.to_k, a.to_v)):
-                self._lin_bwd(lin, dqkv_raw[:, j * d:(j + 1) * d], r["T_qkv"][j], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B,
-                              flags=EPI_ACCUM)
+            self._group_bwd((a.to_q, a.to_k, a.to_v, blk.proj_mlp),
+                            [dqkv_raw[:, 0:d], dqkv_raw[:, d:2 * d], dqkv_raw[:, 2 * d:], du],
+                            r["T_qkv"] + [r["T_mlp"]], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B)
             dx_prev = self._new(Mj, d)
             ops.ln_mod_bwd(dxn, r["x"], r["mean"], r["rstd"], mod[:, d:2 * d], dx_prev, B=B, S=S, dres=dx,
                            dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
@@ -556,9 +616,8 @@ class FluxTransformer2DModel(nn.Module):
                         dict(src=dqkv_raw[:, 2 * d:], dst=dqkv_j[:, 2 * d:], weight=None)]
                 ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=s_off)
                 dxn = self._new(M, d)
-                for j, lin in enumerate(qkv_lins):
-                    self._lin_bwd(lin, dqkv_raw[:, j * d:(j + 1) * d], r["T_qkv"][j], r["xn"], dxn, M=M, rows_per_batch=Ss, B=B,
-                                  flags=EPI_ACCUM if j else 0)
+                self._group_bwd(qkv_lins, [dqkv_raw[:, j * d:(j + 1) * d] for j in range(3)], r["T_qkv"], r["xn"], dxn,
+                                M=M, rows_per_batch=Ss, B=B)
                 dx0 = self._new(M, d)
                 ops.ln_mod_bwd(dxn, r["x"], r["mean1"], r["rstd1"], mod[:, d:2 * d], dx0, B=B, S=Ss, dres=dx1s[name],
                                dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])

@@ -150,9 +150,13 @@ class FusedLoRANetwork(nn.Module):
         for lora in self.get_all_modules():
             lora.apply_to()
 
-    def build_arena(self, device, ema: bool = False):
+    def build_arena(self, device, ema: bool = False, groups=None):
         """Move every adapter matrix into flat fp32 arenas on `device` (reference: network.force_to(device, fp32),
-        jobs/process/BaseSDTrainProcess.py:1982-1983) and create grad / Adam / EMA / bf16-shadow arenas."""
+        jobs/process/BaseSDTrainProcess.py:1982-1983) and create grad / Adam / EMA / bf16-shadow arenas.
+
+        groups: lists of LoRAModules whose base layers read the SAME activation (q/k/v[/proj_mlp]); their lora_down
+        matrices are laid out back to back so one skinny kernel launch produces T for the whole group and one wgrad
+        launch produces all their lora_down gradients (the activation is streamed once instead of 3-4 times)."""
         mods = self.get_all_modules()
         n = sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in mods)
         self.arena_p = torch.empty(n, dtype=torch.float32, device=device)
@@ -162,30 +166,59 @@ class FusedLoRANetwork(nn.Module):
         self.arena_ema = None
         dt = torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
         self.shadow_dtype = dt
+        # shadow arena: [0, n) direct copies at the fp32 arena's offsets, [n, 2n) transposed copies
         self.arena_shadow = torch.empty(2 * n, dtype=dt, device=device)
+        group_of = {}
+        for gi, grp in enumerate(groups or []):
+            for m in grp:
+                group_of[id(m)] = gi
+        order = []  # (module, which)
+        done_groups = set()
+        for m in mods:
+            gi = group_of.get(id(m))
+            if gi is None:
+                order += [(m, "down"), (m, "up")]
+            elif gi not in done_groups:
+                done_groups.add(gi)
+                order += [(x, "down") for x in groups[gi]] + [(x, "up") for x in groups[gi]]
         entries = []
         off = 0
+        for m, which in order:
+            lin = m.lora_down if which == "down" else m.lora_up
+            w = lin.weight.data
+            rows, cols = w.shape
+            cnt = rows * cols
+            view = self.arena_p[off:off + cnt].view(rows, cols)
+            view.copy_(w)
+            lin.weight = nn.Parameter(view, requires_grad=True)
+            gview = self.arena_g[off:off + cnt].view(rows, cols)
+            lin.weight.grad = gview
+            sh = self.arena_shadow[off:off + cnt].view(rows, cols)
+            shT = self.arena_shadow[n + off:n + off + cnt].view(cols, rows)
+            entries.append((off, off, n + off, rows, cols))
+            if which == "down":
+                m.off_down, m.g_down, m.sh_down, m.sh_downT = off, gview, sh, shT
+            else:
+                m.off_up, m.g_up, m.sh_up, m.sh_upT = off, gview, sh, shT
+            off += cnt
         for m in mods:
-            for which in ("down", "up"):
-                lin = m.lora_down if which == "down" else m.lora_up
-                w = lin.weight.data
-                rows, cols = w.shape
-                cnt = rows * cols
-                view = self.arena_p[off:off + cnt].view(rows, cols)
-                view.copy_(w)
-                lin.weight = nn.Parameter(view, requires_grad=True)
-                gview = self.arena_g[off:off + cnt].view(rows, cols)
-                lin.weight.grad = gview
-                sh = self.arena_shadow[2 * off:2 * off + cnt].view(rows, cols)
-                shT = self.arena_shadow[2 * off + cnt:2 * off + 2 * cnt].view(cols, rows)
-                entries.append((off, 2 * off, 2 * off + cnt, rows, cols))
-                if which == "down":
-                    m.off_down, m.g_down, m.sh_down, m.sh_downT = off, gview, sh, shT
-                else:
-                    m.off_up, m.g_up, m.sh_up, m.sh_upT = off, gview, sh, shT
-                off += cnt
             m.alpha = m.alpha.to(device)
             m._runtime_scale = m._runtime_scale.to(device)
+            m.group = None
+        self.groups = []
+        for grp in groups or []:
+            first = grp[0]
+            rtot = sum(x.lora_dim for x in grp)
+            cin = first.in_features
+            assert all(x.in_features == cin and x.scale == first.scale for x in grp)
+            o0 = first.off_down
+            assert [x.off_down for x in grp] == [o0 + sum(y.lora_dim for y in grp[:i]) * cin for i in range(len(grp))]
+            g = {"mods": grp, "R": rtot, "sh_down": self.arena_shadow[o0:o0 + rtot * cin].view(rtot, cin),
+                 "g_down": self.arena_g[o0:o0 + rtot * cin].view(rtot, cin), "scale": first.scale,
+                 "col": {id(x): sum(y.lora_dim for y in grp[:i]) for i, x in enumerate(grp)}}
+            for x in grp:
+                x.group = g
+            self.groups.append(g)
         self._shadow_entries = entries
         self._shadow_table = None
         if ema:

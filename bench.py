@@ -42,7 +42,7 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True):
         for m in net.unet_loras:
             m.lora_up.weight.normal_(0, 1e-3)
     net.apply_to()
-    net.build_arena(dev, ema=ema)
+    net.build_arena(dev, ema=ema, groups=model.lora_groups())
     net.refresh_shadows(ops)
     model.attach_network(net)
     model.prepare()

@@ -50,7 +50,7 @@ def _build(rank=16, dev="cuda"):
     ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
     ref_net.apply_to()
     net.apply_to()
-    net.build_arena(dev)
+    net.build_arena(dev, groups=nat.lora_groups())
     net.refresh_shadows(ops)
     nat.attach_network(net)
     nat.prepare()
@@ -145,3 +145,28 @@ def test_three_training_steps_track_oracle():
     print("LoRA delta rel err after 3 AdamW steps:", rel)
     assert rel < 0.15, rel  # sign flips of near-zero gradient entries dominate; see DESIGN.md "parity"
     assert net.arena_ema is not None and torch.isfinite(net.arena_ema).all()
+
+
+@pytest.mark.parametrize("hw", [(26, 18), (12, 44)])
+def test_ragged_bucket_shapes_match_oracle(hw):
+    """Aspect-ratio buckets change the token count every step (toolkit/dataloader_mixins.py:198-211): sequence lengths
+    that are not multiples of any tile size must give the same loss / gradients as the oracle."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import train_ref
+
+    ref, ref_net, nat, net = _build()
+    Hl, Wl = hw
+    lat, emb, pooled, noise, ts = _batch(2, Hl=Hl, Wl=Wl, n_txt=37)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = [p.grad.clone() for p in oracle.params]
+    ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1.5e-3 * abs(loss32), (loss, loss32)
+    mine = []
+    for m in net.unet_loras:
+        mine += [m.lora_down.weight.grad, m.lora_up.weight.grad]
+    num = sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32))
+    den = sum((b ** 2).sum().item() for b in g32)
+    assert math.sqrt(num / den) < 2e-2, math.sqrt(num / den)

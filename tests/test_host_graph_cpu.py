@@ -11,7 +11,7 @@ CFG = dict(in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim
            joint_attention_dim=64, pooled_projection_dim=32)
 
 
-def build_pair(rank=8, multiplier=1.0, seed=0):
+def build_pair(rank=8, multiplier=1.0, seed=0, grouped=True):
     torch.manual_seed(seed)
     ref = flux_ref.FluxTransformer2DModel(**CFG)
     flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
@@ -34,7 +34,7 @@ def build_pair(rank=8, multiplier=1.0, seed=0):
             a.lora_up.weight.copy_(b.lora_up.weight)
     ref_net.apply_to()
     net.apply_to()
-    net.build_arena("cpu")
+    net.build_arena("cpu", groups=nat.lora_groups() if grouped else None)
     net.refresh_shadows(ref_ops)
     nat.attach_network(net)
     nat.prepare()
@@ -75,7 +75,7 @@ def test_forward_and_lora_grads_match_oracle_autograd():
 
 
 def test_per_sample_multiplier_and_inactive_network():
-    ref, ref_net, nat, net = build_pair(multiplier=1.0)
+    ref, ref_net, nat, net = build_pair(multiplier=1.0, grouped=False)  # ungrouped arena layout path
     hidden, enc, pooled, t, img_ids, txt_ids, guid = inputs()
     # inactive network == base model
     p0 = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)

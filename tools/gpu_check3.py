@@ -129,7 +129,7 @@ def full_flux_step(B=1, steps=3):
         for m in net.unet_loras:
             m.lora_up.weight.normal_(0, 1e-3)
     net.apply_to()
-    net.build_arena(dev, ema=True)
+    net.build_arena(dev, ema=True, groups=model.lora_groups())
     net.refresh_shadows(ops)
     model.attach_network(net)
     model.prepare()

@@ -18,10 +18,17 @@ def correctness():
     import functools
     res = {}
     orig = ops.gemm_nt
-    ops.gemm_nt = functools.partial(orig, tile_mode=2)
     try:
+      for tag, part in (("t256", dict(tile_mode=2)), ("ring3", dict(stage_mode=2))):
+        def patched(a, b, out, **kw):
+            kw.pop("stage_mode", None)
+            kw.update(part)
+            return orig(a, b, out, **kw)
+        ops.gemm_nt = patched
         for name, fn in {
             "c256_plain": lambda: g.gemm_case(512, 512, 128, stage=1),
+            "c256_k64": lambda: g.gemm_case(512, 512, 64, stage=1),
+            "c256_k64_r16": lambda: g.gemm_case(300, 200, 64, r=16, stage=1),
             "c256_ragged": lambda: g.gemm_case(700, 1000, 192, r=16, stage=1),
             "c256_ragged_s0": lambda: g.gemm_case(700, 1000, 192, r=16, stage=0),
             "c256_gelu": lambda: g.gemm_case(512, 768, 128, r=16, flags=ops.EPI_GELU, stage=1),
@@ -31,10 +38,10 @@ def correctness():
             "c256_big": lambda: g.gemm_case(2048, 3072, 3072, r=16, stage=1),
         }.items():
             try:
-                res[name] = fn()
+                res[tag + "_" + name] = fn()
             except Exception as e:  # noqa: BLE001
-                res[name] = {"ok": False, "error": repr(e)}
-            print(name, res[name], flush=True)
+                res[tag + "_" + name] = {"ok": False, "error": repr(e)}
+            print(tag, name, res[tag + "_" + name], flush=True)
     finally:
         ops.gemm_nt = orig
     return res
@@ -47,26 +54,44 @@ def ab(M, N, K, rounds=5, iters=10, r=16):
     b2 = torch.randn(N, r, device=dev).to(torch.bfloat16)
     bias = torch.randn(N, device=dev).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    res = {1: [], 2: []}
-    for tm in (1, 2):
+    variants = {"t128": dict(tile_mode=1, stage_mode=1), "t256": dict(tile_mode=2, stage_mode=1), "ring3_256x128": dict(stage_mode=2)}
+    res = {k: [] for k in variants}
+    for k, kw in variants.items():
         for _ in range(3):
-            ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2, tile_mode=tm)
+            ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2, **kw)
     torch.cuda.synchronize()
     for _ in range(rounds):
-        for tm in (1, 2):
+        for k, kw in variants.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
-                ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2, tile_mode=tm)
+                ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2, **kw)
             e1.record()
             torch.cuda.synchronize()
-            res[tm].append(2.0 * M * N * K / (e0.elapsed_time(e1) / iters) / 1e9)
-    med = {tm: sorted(v)[len(v) // 2] for tm, v in res.items()}
-    return {"tf_128": med[1], "tf_256": med[2], "ok": True}
+            res[k].append(2.0 * M * N * K / (e0.elapsed_time(e1) / iters) / 1e9)
+    out_ = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
+    out_["ok"] = True
+    return out_
 
 
 if __name__ == "__main__":
     OUT["correctness"] = correctness()
+    # race screen for the counted-vmcnt ring: repeat larger cases, every run must be clean
+    import functools
+    orig = ops.gemm_nt
+    def ring(a, b, out, **kw):
+        kw.pop("stage_mode", None)
+        return orig(a, b, out, stage_mode=2, **kw)
+    ops.gemm_nt = ring
+    try:
+        for i in range(6):
+            for (M, N, K) in ((4608, 3072, 3072), (1024, 12288, 3072), (3000, 3072, 1024)):
+                r_ = g.gemm_case(M, N, K, r=16, stage=1, seed=i)
+                OUT["correctness"][f"race_{i}_{M}x{N}x{K}"] = r_
+                if not r_["ok"]:
+                    print("RACE/ERR", i, M, N, K, r_, flush=True)
+    finally:
+        ops.gemm_nt = orig
     for (M, N, K) in ((4608, 3072, 3072), (4608, 12288, 3072), (4608, 3072, 12288), (18432, 3072, 3072), (18432, 12288, 3072),
                       (18432, 3072, 12288), (18432, 3072, 15360), (4096, 3072, 3072), (2048, 3072, 3072), (9216, 3072, 3072)):
         OUT[f"ab_{M}x{N}x{K}"] = ab(M, N, K)
