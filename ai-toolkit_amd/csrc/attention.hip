@@ -89,20 +89,26 @@ struct TileStager {
 // ---- swizzled, unpadded tiles: [rows][128] bf16, 256-B rows, physical 16-B chunk = logical chunk ^ (row & 15).
 // Conflict-free for ds_read_b128 fragments and for tr16 reads, and lane-linear so LDS-DMA can fill them
 // (the XOR goes on the global SOURCE address, guide rule 21).
-__device__ __forceinline__ s16x8_t frag_rm_sw(const bf16_t* tile, int row0, int k0, int lane) {
+// All tile pointers are address_space(3): a generic pointer (e.g. selected from an array of buffers) would turn the
+// fragment loads into flat loads that wait on vmcnt and drain the LDS-DMA prefetch.
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ s16x8_t frag_rm_sw(const lds_char* tile, int row0, int k0, int lane) {
   const int row = row0 + (lane & 31);
   const int c = (k0 >> 3) + (lane >> 5);
-  return *reinterpret_cast<const s16x8_t*>(reinterpret_cast<const char*>(tile) + row * 256 + ((c ^ (row & 15)) << 4));
+  return *reinterpret_cast<const __attribute__((address_space(3))) s16x8_t*>(tile + row * 256 + ((c ^ (row & 15)) << 4));
 }
-__device__ __forceinline__ s16x8_t frag_tr_perm_sw(const bf16_t* tile, int kb, int col0, int lane) {
+__device__ __forceinline__ s16x4_t tr16l(const lds_char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+__device__ __forceinline__ s16x8_t frag_tr_perm_sw(const lds_char* tile, int kb, int col0, int lane) {
   const int h = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15;
   const int row = kb + 4 * h + (i >> 2);
   const int col = col0 + gq * 16 + (i & 3) * 4;
   const int c = col >> 3, off = (col & 7) * 2;
-  const char* base = reinterpret_cast<const char*>(tile);
-  s16x4_t lo = tr16a(reinterpret_cast<const bf16_t*>(base + row * 256 + ((c ^ (row & 15)) << 4) + off));
+  const lds_char* base = tile;
+  s16x4_t lo = tr16l(base + row * 256 + ((c ^ (row & 15)) << 4) + off);
   const int row2 = row + 8;
-  s16x4_t hi = tr16a(reinterpret_cast<const bf16_t*>(base + row2 * 256 + ((c ^ (row2 & 15)) << 4) + off));
+  s16x4_t hi = tr16l(base + row2 * 256 + ((c ^ (row2 & 15)) << 4) + off);
   s16x8_t f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -110,7 +116,7 @@ __device__ __forceinline__ s16x8_t frag_tr_perm_sw(const bf16_t* tile, int kb, i
 }
 // LDS-DMA fill of a [ROWS][128] swizzled tile from rows row0.. (clamped to S-1) of a [*, ld] matrix slice.
 template <int ROWS>
-__device__ __forceinline__ void glds_tile(bf16_t* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
+__device__ __forceinline__ void glds_tile(lds_char* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
   constexpr int NI = ROWS / 4;  // wave-instructions per tile (4 rows = 1 KiB each)
 #pragma unroll
   for (int ii = 0; ii < NI / 4; ++ii) {
@@ -120,7 +126,7 @@ __device__ __forceinline__ void glds_tile(bf16_t* tile, const bf16_t* base, long
     const int c = pc ^ (row & 15);
     const int r = min(row0 + row, S - 1);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)r * ld + c * 8),
-                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(tile) + ins * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(tile + ins * 1024), 16, 0, 0);
   }
 }
 
@@ -132,12 +138,7 @@ __device__ __forceinline__ void glds_tile(bf16_t* tile, const bf16_t* base, long
 #define ATTN_DEFER_THR 8.0f
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* kt[2];
-  bf16_t* vt[2];
-  kt[0] = reinterpret_cast<bf16_t*>(smem);
-  vt[0] = kt[0] + 64 * 128;
-  kt[1] = vt[0] + 64 * 128;
-  vt[1] = kt[1] + 64 * 128;
+  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile at b*32768, V tile at b*32768 + 16384
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -161,21 +162,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
 
   const int ntiles = (S + 63) / 64;
-  glds_tile<64>(kt[0], Kb, p.ldk, 0, S, wave, lane);
-  glds_tile<64>(vt[0], Vb, p.ldv, 0, S, wave, lane);
+  glds_tile<64>(sm, Kb, p.ldk, 0, S, wave, lane);
+  glds_tile<64>(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
+    const lds_char* ktc = sm + cur * 32768;
+    const lds_char* vtc = ktc + 16384;
     if (t + 1 < ntiles) {
-      glds_tile<64>(kt[cur ^ 1], Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_tile<64>(vt[cur ^ 1], Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * 32768, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * 32768 + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
+    // LDS fragment reads are issued in groups ahead of the MFMAs that consume them (the compiler otherwise emits
+    // read -> lgkmcnt(0) -> mfma one by one and every MFMA eats a full LDS round trip)
     f32x16_t s[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       s[j] = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) s[j] = mfma32(frag_rm_sw(kt[cur], 32 * j, 16 * ks, lane), qf[ks], s[j]);
+      for (int hh = 0; hh < 2; ++hh) {
+        s16x8_t kfr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kfr[u] = frag_rm_sw(ktc, 32 * j, 16 * (4 * hh + u), lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[j] = mfma32(kfr[u], qf[4 * hh + u], s[j]);
+      }
     }
     const int kv0 = t * 64;
     if (kv0 + 64 > S) {  // wave-uniform: only the last tile masks
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int kk = 0; kk < 4; ++kk) {
       const s16x8_t pf = pack_acc8(s[kk >> 1], 8 * (kk & 1));
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_sw(vt[cur], 16 * kk, 32 * d, lane), pf, o[d]);
+      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_sw(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
     }
     __syncthreads();
   }
@@ -267,18 +279,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AitkAttnArgs p) {
 // dV += P^T dO, dK += scale * dS^T Q  (Q/dO consumed via tr16 with the permuted order of the packed P / dS registers).
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* qt[2];
-  bf16_t* dot_[2];
-  float* lt[2];
-  float* dt[2];
-  qt[0] = reinterpret_cast<bf16_t*>(smem);
-  dot_[0] = qt[0] + 64 * 128;
-  qt[1] = dot_[0] + 64 * 128;
-  dot_[1] = qt[1] + 64 * 128;
-  lt[0] = reinterpret_cast<float*>(dot_[1] + 64 * 128);
-  dt[0] = lt[0] + 64;
-  lt[1] = dt[0] + 64;
-  dt[1] = lt[1] + 64;
+  lds_char* const sm = (lds_char*)smem;  // buffer b: Q tile at b*32768, dO tile at +16384; stats at 65536 + b*512
+  typedef __attribute__((address_space(3))) float lds_float;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -312,12 +314,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const int ntiles = (S + 63) / 64;  // query tiles of 64 rows, processed as two 32-row halves per barrier
   // rows >= S are clamped (finite data); their L2 = +inf makes P = 0 so they contribute nothing
   auto stage = [&](int t, int buf) {
-    glds_tile<64>(qt[buf], Qb, p.ldq, t * 64, S, wave, lane);
-    glds_tile<64>(dot_[buf], dOb, p.lddo, t * 64, S, wave, lane);
+    glds_tile<64>(sm + buf * 32768, Qb, p.ldq, t * 64, S, wave, lane);
+    glds_tile<64>(sm + buf * 32768 + 16384, dOb, p.lddo, t * 64, S, wave, lane);
     if (tid < 128) {
       const int q = t * 64 + (tid & 63);
-      if (tid < 64) lt[buf][tid] = q < S ? Lb[q] : INFINITY;
-      else dt[buf][tid - 64] = q < S ? Db[q] : 0.f;
+      lds_float* st = (lds_float*)(sm + 65536 + buf * 512);  // [0,64): L2, [64,128): delta
+      st[tid] = tid < 64 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
     }
   };
   stage(0, 0);
@@ -325,20 +327,43 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+    const lds_char* qtc = sm + cur * 32768;
+    const lds_char* dotc = qtc + 16384;
+    const lds_float* ltc = (const lds_float*)(sm + 65536 + cur * 512);
+    const lds_float* dtc = ltc + 64;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       f32x16_t s = zero16(), dp = zero16();
+      {
+        s16x8_t qa[8], da[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        s = mfma32(frag_rm_sw(qt[cur], 32 * sub, 16 * ks, lane), kf[ks], s);
-        dp = mfma32(frag_rm_sw(dot_[cur], 32 * sub, 16 * ks, lane), vf[ks], dp);
+        for (int ks = 0; ks < 8; ++ks) {
+          qa[ks] = frag_rm_sw(qtc, 32 * sub, 16 * ks, lane);
+          da[ks] = frag_rm_sw(dotc, 32 * sub, 16 * ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          s = mfma32(qa[ks], kf[ks], s);
+          dp = mfma32(da[ks], vf[ks], dp);
+        }
       }
+      // transposed operands of the dV / dK products: issued now so their LDS latency hides behind the softmax VALU
+      s16x8_t trd[2][4], trq[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          trd[kk][d] = frag_tr_perm_sw(dotc, 32 * sub + 16 * kk, 32 * d, lane);
+          trq[kk][d] = frag_tr_perm_sw(qtc, 32 * sub + 16 * kk, 32 * d, lane);
+        }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 l4 = *reinterpret_cast<const float4*>(lt[cur] + 32 * sub + 8 * g + 4 * h);
-        const float4 d4 = *reinterpret_cast<const float4*>(dt[cur] + 32 * sub + 8 * g + 4 * h);
-        const float ls[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float ds[4] = {d4.x, d4.y, d4.z, d4.w};
+        const f32x4_t l4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 32 * sub + 8 * g + 4 * h);
+        const f32x4_t d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(dtc + 32 * sub + 8 * g + 4 * h);
+        const float ls[4] = {l4[0], l4[1], l4[2], l4[3]};
+        const float ds[4] = {d4[0], d4[1], d4[2], d4[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -353,8 +378,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          dv[d] = mfma32(pf, frag_tr_perm_sw(dot_[cur], 32 * sub + 16 * kk, 32 * d, lane), dv[d]);
-          dk[d] = mfma32(df, frag_tr_perm_sw(qt[cur], 32 * sub + 16 * kk, 32 * d, lane), dk[d]);
+          dv[d] = mfma32(pf, trd[kk][d], dv[d]);
+          dk[d] = mfma32(df, trq[kk][d], dk[d]);
         }
       }
     }
@@ -380,12 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 // dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q]  (K through tr16, dS^T straight from registers).
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* kt[2];
-  bf16_t* vt[2];
-  kt[0] = reinterpret_cast<bf16_t*>(smem);
-  vt[0] = kt[0] + 64 * 128;
-  kt[1] = vt[0] + 64 * 128;
-  vt[1] = kt[1] + 64 * 128;
+  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile at b*32768, V tile at +16384
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -413,23 +433,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   for (int d = 0; d < 4; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 63) / 64;
-  glds_tile<64>(kt[0], Kb, p.ldk, 0, S, wave, lane);
-  glds_tile<64>(vt[0], Vb, p.ldv, 0, S, wave, lane);
+  glds_tile<64>(sm, Kb, p.ldk, 0, S, wave, lane);
+  glds_tile<64>(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
+    const lds_char* ktc = sm + cur * 32768;
+    const lds_char* vtc = ktc + 16384;
     if (t + 1 < ntiles) {
-      glds_tile<64>(kt[cur ^ 1], Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_tile<64>(vt[cur ^ 1], Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * 32768, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * 32768 + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
     const bool tail = t * 64 + 64 > S;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        s = mfma32(frag_rm_sw(kt[cur], 32 * j, 16 * ks, lane), qf[ks], s);
-        dp = mfma32(frag_rm_sw(vt[cur], 32 * j, 16 * ks, lane), gf[ks], dp);
+      for (int hh = 0; hh < 4; ++hh) {
+        s16x8_t kfr[2], vfr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          kfr[u] = frag_rm_sw(ktc, 32 * j, 16 * (2 * hh + u), lane);
+          vfr[u] = frag_rm_sw(vtc, 32 * j, 16 * (2 * hh + u), lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          s = mfma32(kfr[u], qf[2 * hh + u], s);
+          dp = mfma32(vfr[u], gf[2 * hh + u], dp);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
       for (int kk = 0; kk < 2; ++kk) {
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_sw(kt[cur], 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_sw(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
       }
     }
     __syncthreads();
