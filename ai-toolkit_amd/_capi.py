@@ -22,7 +22,10 @@ class GemmArgs(C.Structure):
         ("aux_in", vp), ("ld_aux_in", i64),
         ("gate", vp), ("ld_gate", i64), ("gate_rows", i32),
         ("M", i32), ("N", i32), ("K", i32), ("K2", i32),
-        ("flags", i32), ("stage_mode", i32), ("tile_mode", i32), ("_pad2", i32),
+        ("flags", i32), ("stage_mode", i32), ("tile_mode", i32), ("conv_mode", i32),
+        ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_Wo", i32), ("conv_HoWo", i32), ("conv_stride", i32),
+        ("conv_pad_t", i32), ("conv_pad_l", i32), ("_pad3", i32),
+        ("zero_page", vp),
     ]
 
 
@@ -145,15 +148,20 @@ class AdamWArgs(C.Structure):
                                  "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale")]
 
 
+class GroupNormArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("gamma", vp), ("beta", vp), ("partial", vp), ("stats", vp),
+                ("eps", C.c_float), ("silu", i32), ("B", i32), ("HW", i32), ("C", i32), ("G", i32)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
 
 
-EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX = 1, 2, 4, 8, 16, 32, 64
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
-            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc}
+            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs}
 
 
 def lib():
@@ -184,6 +192,11 @@ def lib():
     L.aitk_adamw_workspace_bytes.restype = C.c_int64
     L.aitk_adamw_workspace_bytes.argtypes = [i64]
     L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]
+    L.aitk_groupnorm_workspace_bytes.restype = C.c_int64
+    L.aitk_groupnorm_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.aitk_softmax_rows.argtypes = [vp, i64, i32, i32, C.c_float, vp]
+    L.aitk_image_to_nhwc8.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.aitk_latent_sample.argtypes = [vp, i64, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]
     L.aitk_timestep_embed.argtypes = [vp, vp, i32, i32, C.c_float, vp]
     L.aitk_copy2d.argtypes = [vp, i64, vp, i64, i64, i64, vp]
     _lib = L

@@ -30,7 +30,11 @@ __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, in
 
 // Tile configs: <128,128,2,2> (4 waves, 64x64 per wave, 64 KiB LDS, 2 workgroups/CU) for small / ragged problems and
 // <256,256,2,4> (8 waves, 128x64 per wave, 128 KiB LDS, 1 workgroup/CU): twice the operand reuse per LDS byte.
-template <int STAGE, int BM, int BN, int WM, int WN>
+// CONV: A is an NHWC image [B, H, W, Cin] and the K axis runs over (3x3 tap, Cin): implicit-GEMM convolution — row m is
+// output pixel (b, oy, ox), the 16-B chunk at k = tap*Cin + cin is fetched from input pixel (oy*stride+ky-pad_t,
+// ox*stride+kx-pad_l), out-of-image chunks come from a zero page.  Replaces nn.Conv2d inside the VAE encoder the reference
+// runs at toolkit/stable_diffusion_model.py:2567 (diffusers AutoencoderKL).
+template <int STAGE, int BM, int BN, int WM, int WN, bool CONV = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   constexpr int NT = 64 * WM * WN;           // threads
   constexpr int RPP = NT / 8;                // tile rows staged per pass (8 x 16-B chunks per 128-B row)
@@ -62,11 +66,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   const bf16_t* pb[PB];
   const bf16_t* pa2[PA];
   const bf16_t* pb2[PB];
+  int iy0[CONV ? PA : 1], ix0[CONV ? PA : 1];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     int ra = min(m0 + srow + RPP * i, p.M - 1);
-    pa[i] = seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra);
-    pa2[i] = p.K2 > 0 ? p.A2 + (long)ra * p.lda2 : nullptr;
+    if constexpr (CONV) {
+      const int b = ra / p.conv_HoWo, rem = ra - b * p.conv_HoWo;
+      const int oy = rem / p.conv_Wo, ox = rem - oy * p.conv_Wo;
+      iy0[i] = oy * p.conv_stride - p.conv_pad_t;
+      ix0[i] = ox * p.conv_stride - p.conv_pad_l;
+      pa[i] = p.A + (((long)b * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
+      pa2[i] = nullptr;
+    } else {
+      pa[i] = seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra);
+      pa2[i] = p.K2 > 0 ? p.A2 + (long)ra * p.lda2 : nullptr;
+    }
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -128,11 +142,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     char* sa = smem + buf * BUF_BYTES;
     char* sb = sa + A_BYTES;
     // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
+    if constexpr (CONV) {
+      const int kc = k0 + cc * 8;
+      const bool kin = kc < p.K;
+      const int tap = kin ? kc / p.conv_Cin : 0;
+      const int cin = kc - tap * p.conv_Cin;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const long toff = ((long)ky * p.conv_W + kx) * p.conv_Cin + cin;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const bf16_t* a = second ? pa2[i] : pa[i];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + kk),
-                                       (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      for (int i = 0; i < PA; ++i) {
+        const bool ok = kin && (unsigned)(iy0[i] + ky) < (unsigned)p.conv_H && (unsigned)(ix0[i] + kx) < (unsigned)p.conv_W;
+        const bf16_t* src = ok ? pa[i] + toff : p.zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const bf16_t* a = second ? pa2[i] : pa[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + kk),
+                                         (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -239,6 +269,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
           v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
           v[2] += bf2f(bb.y & 0xffff); v[3] += bf2f(bb.y >> 16);
         }
+        if (flags & AITK_EPI_BIAS_ROW) {
+          const float br = bf2f(p.bias[m]);
+          v[0] += br; v[1] += br; v[2] += br; v[3] += br;
+        }
+        if (flags & AITK_EPI_ADD_AUX) {
+          uint2 rr = *reinterpret_cast<const uint2*>(p.aux_in + (long)m * p.ld_aux_in + nb);
+          v[0] += bf2f(rr.x & 0xffff); v[1] += bf2f(rr.x >> 16);
+          v[2] += bf2f(rr.y & 0xffff); v[3] += bf2f(rr.y >> 16);
+        }
         if (flags & AITK_EPI_ACCUM) {
           uint2 cc2 = *reinterpret_cast<const uint2*>(crow + nb);
           v[0] += bf2f(cc2.x & 0xffff); v[1] += bf2f(cc2.x >> 16);
@@ -283,12 +322,35 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if ((a->K % 8) || (a->K2 % 8) || (a->N % 4)) return AITK_ERR_SHAPE;
   if ((a->lda % 8) || (a->ldb % 8) || (a->ldc % 4)) return AITK_ERR_ALIGN;
   if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return AITK_ERR_ARG;
-  if ((a->flags & AITK_EPI_BIAS) && !a->bias) return AITK_ERR_ARG;
+  if ((a->flags & (AITK_EPI_BIAS | AITK_EPI_BIAS_ROW)) && !a->bias) return AITK_ERR_ARG;
+  if ((a->flags & AITK_EPI_ADD_AUX) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_GELU | AITK_EPI_GATE_RES)) && !a->aux_out) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
   hipStream_t st = stream;
+  if (a->conv_mode) {
+    if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != 9 * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
+        a->conv_stride <= 0 || a->conv_Wo <= 0 || a->conv_HoWo <= 0)
+      return AITK_ERR_ARG;
+    static bool cattr = false;
+    if (!cattr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 256, 256, 2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      cattr = true;
+    }
+    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    if (a->tile_mode == 2 || (a->tile_mode == 0 && a->N >= 256 && t256 >= 192)) {
+      hipLaunchKernelGGL((gemm_nt_kernel<1, 256, 256, 2, 4, true>), dim3((unsigned)t256), dim3(512), 131072, st, *a);
+    } else {
+      const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+      hipLaunchKernelGGL((gemm_nt_kernel<1, 128, 128, 2, 2, true>), dim3(tiles), dim3(256), 65536, st, *a);
+    }
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
+  AitkGemmArgs tmp = *a;
+  if (tmp.stage_mode >= 1 && ((a->K % 16) || (a->K2 % 16))) tmp.stage_mode = 0;  // LDS-DMA cannot zero-fill an 8-wide K tail
+  a = &tmp;
   // tile choice: 256x256 when the problem fills the chip with big tiles (>= 1 full round of 256 CUs) or is overridden
   int big = a->tile_mode == 2 ? 1 : 0;
   if (a->tile_mode == 0) {

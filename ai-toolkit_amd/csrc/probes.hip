@@ -82,6 +82,7 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 12: return (int)sizeof(AitkMseArgs);
     case 13: return (int)sizeof(AitkAdamWArgs);
     case 14: return (int)sizeof(AitkShadowDesc);
+    case 15: return (int)sizeof(AitkGroupNormArgs);
     default: return -1;
   }
 }

@@ -50,8 +50,12 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
         assert a2.shape[1] == b2.shape[1] and b2.shape[0] == N and a2.shape[0] == M
         g.A2, g.B2, g.K2 = _ptr(a2), _ptr(b2), a2.shape[1]
     if bias is not None:
-        assert bias.dtype == BF16 and bias.numel() == N and bias.is_contiguous()
-        flags |= EPI_BIAS
+        assert bias.dtype == BF16 and bias.is_contiguous()
+        if flags & _capi.EPI_BIAS_ROW:
+            assert bias.numel() == M
+        else:
+            assert bias.numel() == N
+            flags |= EPI_BIAS
         g.bias = _ptr(bias)
     if aux_out is not None:
         g.ld_aux_out = _row_major(aux_out, "aux_out")
@@ -346,3 +350,75 @@ def refresh_shadows(arena, shadow, table):
     tab, n = table
     _capi.check(_capi.lib().aitk_lora_refresh_shadows(_ptr(arena), _ptr(shadow), _ptr(tab), n, _capi.stream_ptr()),
                 "aitk_lora_refresh_shadows")
+
+
+# ---------------------------------------------------------------------------------------------------------- VAE encoder
+EPI_BIAS_ROW, EPI_ADD_AUX = _capi.EPI_BIAS_ROW, _capi.EPI_ADD_AUX
+_zero_pages = {}
+
+
+def _zero_page(device):
+    z = _zero_pages.get(str(device))
+    if z is None:
+        z = torch.zeros(64, dtype=BF16, device=device)
+        _zero_pages[str(device)] = z
+    return z
+
+
+def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
+    """Implicit-GEMM 3x3 convolution on NHWC: x [B*H*W, Cin], w [Cout, 9*Cin] (k = (ky*3+kx)*Cin + cin), out [B*Ho*Wo, Cout]."""
+    g = _capi.GemmArgs()
+    Cin = x.shape[1]
+    assert x.is_contiguous() and x.dtype == BF16 and x.shape[0] == B * H * W
+    Ho = H if Ho is None else Ho
+    Wo = W if Wo is None else Wo
+    g.lda, g.ldb, g.ldc = Cin, _row_major(w, "w"), _row_major(out, "out")
+    N, K = w.shape
+    assert K == 9 * Cin and out.shape == (B * Ho * Wo, N)
+    g.A, g.B, g.C = _ptr(x), _ptr(w), _ptr(out)
+    if bias is not None:
+        flags |= EPI_BIAS
+        g.bias = _ptr(bias)
+    if aux_in is not None:
+        g.aux_in, g.ld_aux_in = _ptr(aux_in), _row_major(aux_in, "aux_in")
+    g.M, g.N, g.K, g.flags = B * Ho * Wo, N, K, flags
+    g.stage_mode, g.tile_mode = 1, TILE_MODE
+    g.conv_mode, g.conv_H, g.conv_W, g.conv_Cin = 1, H, W, Cin
+    g.conv_Wo, g.conv_HoWo, g.conv_stride, g.conv_pad_t, g.conv_pad_l = Wo, Ho * Wo, stride, pad_t, pad_l
+    g.zero_page = _ptr(_zero_page(x.device))
+    _capi.check(_capi.lib().aitk_gemm_nt(C.byref(g), _capi.stream_ptr()), "aitk_gemm_nt(conv)")
+    return out
+
+
+def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False):
+    """out = GroupNorm_G(x [B*HW, C]) * gamma + beta (+ SiLU)."""
+    a = _capi.GroupNormArgs()
+    Cc = x.shape[1]
+    a.x, a.ldx, a.y, a.ldy = _ptr(x), _row_major(x, "x"), _ptr(out), _row_major(out, "out")
+    a.gamma, a.beta = _ptr(gamma), _ptr(beta)
+    ws = workspace(_capi.lib().aitk_groupnorm_workspace_bytes(B, HW, Cc, G), x.device, "groupnorm")
+    a.partial = _ptr(ws)
+    a.eps, a.silu, a.B, a.HW, a.C, a.G = eps, int(silu), B, HW, Cc, G
+    _capi.check(_capi.lib().aitk_groupnorm(C.byref(a), _capi.stream_ptr()), "aitk_groupnorm")
+    return out
+
+
+def softmax_rows(x, scale):
+    ld = _row_major(x, "x")
+    _capi.check(_capi.lib().aitk_softmax_rows(_ptr(x), ld, x.shape[0], x.shape[1], float(scale), _capi.stream_ptr()), "aitk_softmax_rows")
+    return x
+
+
+def image_to_nhwc8(img, out):
+    B, Cc, H, W = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and out.shape == (B * H * W, 8)
+    _capi.check(_capi.lib().aitk_image_to_nhwc8(_ptr(img), _ptr(out), B, H, W, _capi.stream_ptr()), "aitk_image_to_nhwc8")
+    return out
+
+
+def latent_sample(moments, eps, out, *, scale, shift):
+    B, L, h, w = out.shape
+    assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == out.shape and out.is_contiguous()
+    _capi.check(_capi.lib().aitk_latent_sample(_ptr(moments), _row_major(moments, "moments"), _ptr(eps), _ptr(out), B, L, h * w,
+                                               float(scale), float(shift), _capi.stream_ptr()), "aitk_latent_sample")
+    return out

@@ -33,6 +33,8 @@ typedef uint16_t aitk_bf16;
 #define AITK_EPI_GELU 4      /* aux_out = u (pre-activation, bf16); C = gelu_tanh(u)             */
 #define AITK_EPI_DGELU 8     /* C = val * gelu_tanh'(aux_in)                                     */
 #define AITK_EPI_GATE_RES 16 /* aux_out = y; C = aux_in(residual) + gate[m / gate_rows][n] * y   */
+#define AITK_EPI_BIAS_ROW 32 /* + bias[m]  (transposed products, e.g. V^T = W_v x^T)             */
+#define AITK_EPI_ADD_AUX 64  /* + aux_in[m][n]  (residual add of ResnetBlock2D / VAE attention)  */
 
 /*
  * C[M,N] = epi( A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T + bias )       (bf16 in/out, fp32 accumulate)
@@ -56,7 +58,11 @@ typedef struct AitkGemmArgs {
   int32_t flags;
   int32_t stage_mode; /* 0 = VGPR-staged, 1 = LDS-DMA (global_load_lds) */
   int32_t tile_mode;  /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves) */
-  int32_t _pad2;
+  /* implicit-GEMM 3x3 convolution (conv_mode = 1): A = NHWC input [B, conv_H, conv_W, conv_Cin], M = B*Ho*Wo,
+   * K = 9*conv_Cin with k = (ky*3+kx)*Cin + cin, B = weight [Cout, K]; zero_page = >=16 B of zeros on the device */
+  int32_t conv_mode;
+  int32_t conv_H, conv_W, conv_Cin, conv_Wo, conv_HoWo, conv_stride, conv_pad_t, conv_pad_l, _pad3;
+  const aitk_bf16* zero_page;
 } AitkGemmArgs;
 
 int aitk_abi_version(void);
@@ -246,6 +252,29 @@ int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
 typedef struct AitkShadowDesc { int64_t src_off; int64_t dst_off; int64_t dstT_off; int32_t rows, cols; } AitkShadowDesc;
 int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                               aitk_stream_t stream);
+
+
+/* ---- VAE encoder side kernels (NHWC bf16): GroupNorm(G groups, eps, gamma/beta [C]) with optional SiLU over
+ * x [B, HW, C]; scratch from aitk_groupnorm_workspace_bytes.  Replaces nn.GroupNorm + SiLU of diffusers AutoencoderKL
+ * (reached from toolkit/stable_diffusion_model.py:2567). */
+typedef struct AitkGroupNormArgs {
+  const aitk_bf16* x; int64_t ldx;
+  aitk_bf16* y; int64_t ldy;
+  const aitk_bf16* gamma; const aitk_bf16* beta;
+  float* partial; float* stats; /* stats: set by the library (inside partial) */
+  float eps; int32_t silu;
+  int32_t B, HW, C, G;
+} AitkGroupNormArgs;
+int64_t aitk_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t C, int32_t G);
+int aitk_groupnorm(const AitkGroupNormArgs* args, aitk_stream_t stream);
+/* in-place softmax(scale * x) over the n columns of each row (VAE mid-block attention scores) */
+int aitk_softmax_rows(aitk_bf16* x, int64_t ld, int32_t rows, int32_t n, float scale, aitk_stream_t stream);
+/* image [B,3,H,W] fp32 -> NHWC bf16 with channels padded to 8 (conv_in operand) */
+int aitk_image_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t H, int32_t W, aitk_stream_t stream);
+/* DiagonalGaussianDistribution.sample() + scaling_factor * (z - shift_factor): moments NHWC [B*hw, >=2L] -> NCHW [B,L,h,w]
+ * (toolkit/stable_diffusion_model.py:2567-2573) */
+int aitk_latent_sample(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L, int32_t hw,
+                       float scale, float shift, aitk_stream_t stream);
 
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);

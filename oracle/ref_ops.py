@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX = 1, 2, 4, 8, 16, 32, 64
 
 
 def _seg_view(t, seg, M):
@@ -50,7 +50,9 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     if a2 is not None:
         v = v + a2[:M].float() @ b2.float().t()
     if bias is not None:
-        v = v + bias.float()
+        v = v + (bias.float()[:, None] if flags & EPI_BIAS_ROW else bias.float())
+    if flags & EPI_ADD_AUX:
+        v = v + aux_in[:M].float()
     if flags & EPI_ACCUM:
         v = v + _seg_view(out, c_seg, M).float()
     if flags & EPI_GELU:
@@ -300,3 +302,56 @@ def refresh_shadows(arena, shadow, table):
         w = arena[so:so + r * c].view(r, c)
         shadow[do:do + r * c].view(r, c).copy_(w.to(shadow.dtype))
         shadow[dto:dto + r * c].view(c, r).copy_(w.t().to(shadow.dtype))
+
+
+# ---------------------------------------------------------------------------------------------------------- VAE encoder
+def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
+    """nn.Conv2d 3x3 on NHWC rows (diffusers AutoencoderKL, reached from toolkit/stable_diffusion_model.py:2567)."""
+    Cin = x.shape[1]
+    Ho = H if Ho is None else Ho
+    Wo = W if Wo is None else Wo
+    xi = x.float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    wk = w.float().view(w.shape[0], 3, 3, Cin).permute(0, 3, 1, 2)
+    pad_b = (Ho - 1) * stride + 3 - H - pad_t
+    pad_r = (Wo - 1) * stride + 3 - W - pad_l
+    xi = F.pad(xi, (pad_l, max(pad_r, 0), pad_t, max(pad_b, 0)))
+    y = F.conv2d(xi, wk, None, stride=stride)[:, :, :Ho, :Wo]
+    v = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, -1)
+    if bias is not None:
+        v = v + bias.float()
+    if flags & EPI_ADD_AUX:
+        v = v + aux_in.float()
+    out.copy_(v.to(out.dtype))
+    return out
+
+
+def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False):
+    Cc = x.shape[1]
+    xi = x.float().view(B, HW, Cc).transpose(1, 2)
+    y = F.group_norm(xi, G, gamma.float(), beta.float(), eps)
+    if silu:
+        y = F.silu(y)
+    out.copy_(y.transpose(1, 2).reshape(B * HW, Cc).to(out.dtype))
+    return out
+
+
+def softmax_rows(x, scale):
+    x.copy_(torch.softmax(x.float() * scale, dim=-1).to(x.dtype))
+    return x
+
+
+def image_to_nhwc8(img, out):
+    B, Cc, H, W = img.shape
+    out.zero_()
+    out[:, :3].copy_(img.permute(0, 2, 3, 1).reshape(B * H * W, 3).to(out.dtype))
+    return out
+
+
+def latent_sample(moments, eps, out, *, scale, shift):
+    """DiagonalGaussianDistribution.sample + scaling (toolkit/stable_diffusion_model.py:2567-2573)."""
+    B, L, h, w = out.shape
+    m = moments.float().view(B, h * w, -1)
+    mean, logvar = m[..., :L], m[..., L:2 * L].clamp(-30.0, 20.0)
+    z = mean + torch.exp(0.5 * logvar) * eps.view(B, L, h * w).transpose(1, 2)
+    out.copy_((scale * (z - shift)).transpose(1, 2).reshape(B, L, h, w).to(out.dtype))
+    return out
