@@ -225,25 +225,36 @@ extern "C" int aitk_gate_bwd(const AitkGateBwdArgs* a, aitk_stream_t stream) {
 
 // ---------------------------------------------------------------- column-sum finish
 // partial [B][nchunk][V][C] fp32 -> out_v[b*ld_out + c] (bf16), v < V <= 2
-__global__ void colsum_finish_kernel(AitkColsumFinishArgs p) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// block = 64 columns x 4 chunk-groups: each thread sums a quarter of the row-block partials, LDS combines (fixed order)
+__global__ __launch_bounds__(256) void colsum_finish_kernel(AitkColsumFinishArgs p) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + col;
   const long total = (long)p.B * p.V * p.C;
-  if (idx >= total) return;
-  const int c = (int)(idx % p.C);
-  const int v = (int)((idx / p.C) % p.V);
-  const int b = (int)(idx / ((long)p.C * p.V));
-  const float* src = p.partial + ((long)b * p.nchunk * p.V + v) * p.C + c;
   float s = 0.f;
-  for (int k = 0; k < p.nchunk; ++k) s += src[(long)k * p.V * p.C];
-  bf16_t* o = (v == 0 ? p.out0 : p.out1) + (long)b * p.ld_out + c;
-  *o = f2bf(s);
+  int c = 0, v = 0, b = 0;
+  if (idx < total) {
+    c = (int)(idx % p.C);
+    v = (int)((idx / p.C) % p.V);
+    b = (int)(idx / ((long)p.C * p.V));
+    const float* src = p.partial + ((long)b * p.nchunk * p.V + v) * p.C + c;
+    const int k0 = (p.nchunk * grp) / 4, k1 = (p.nchunk * (grp + 1)) / 4;
+    for (int k = k0; k < k1; ++k) s += src[(long)k * p.V * p.C];
+  }
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && idx < total) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    bf16_t* o = (v == 0 ? p.out0 : p.out1) + (long)b * p.ld_out + c;
+    *o = f2bf(t);
+  }
 }
 
 extern "C" int aitk_colsum_finish(const AitkColsumFinishArgs* a, aitk_stream_t stream) {
   if (!a || a->B <= 0 || a->C <= 0 || a->V <= 0 || a->V > 2 || a->nchunk <= 0) return AITK_ERR_SHAPE;
   if (!a->out0 || (a->V == 2 && !a->out1)) return AITK_ERR_ARG;
   const long total = (long)a->B * a->V * a->C;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
