@@ -107,7 +107,7 @@ class QkvPostArgs(C.Structure):
 
 class EwArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("a", vp), ("lda", i64), ("y", vp), ("ldy", i64),
-                ("rows", i32), ("C", i32), ("op", i32), ("_pad", i32)]
+                ("rows", i32), ("C", i32), ("op", i32), ("alpha", C.c_float)]
 
 
 class AttnArgs(C.Structure):

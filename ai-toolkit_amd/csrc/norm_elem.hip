@@ -387,6 +387,7 @@ extern "C" int aitk_qkv_post_bwd(const AitkQkvPostArgs* a, aitk_stream_t stream)
 // op 0: y = silu(x)                      (AdaLayerNorm*: linear(silu(temb)))
 // op 1: y = x                            (copy / cast helper)
 // op 2: y = a + x                        (sum of embedder outputs)
+// op 3: y = alpha * x                    (scaled lora_up for merge_in / merge_out)
 __global__ void ew_kernel(AitkEwArgs p) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   const long total = (long)p.rows * p.C;
@@ -400,7 +401,8 @@ __global__ void ew_kernel(AitkEwArgs p) {
   for (int e = 0; e < 8; ++e) {
     if (p.op == 0) o[e] = x[e] / (1.0f + expf(-x[e]));
     else if (p.op == 1) o[e] = x[e];
-    else o[e] = a8[e] + x[e];
+    else if (p.op == 2) o[e] = a8[e] + x[e];
+    else o[e] = p.alpha * x[e];
   }
   *reinterpret_cast<uint4*>(p.y + r * p.ldy + c) = pack8(o);
 }

@@ -229,6 +229,7 @@ class FusedLoRANetwork(nn.Module):
 
     def refresh_shadows(self, ops):
         """bf16 copies (both orientations) of every adapter matrix; call after each optimizer step / weight load."""
+        self._ops = ops
         if self._shadow_table is None:
             self._shadow_table = ops.make_shadow_table(self._shadow_entries, self.arena_p.device)
         ops.refresh_shadows(self.arena_p, self.arena_shadow, self._shadow_table)
@@ -343,3 +344,66 @@ class FusedLoRANetwork(nn.Module):
 
     def set_multiplier(self, multiplier):
         self.multiplier = multiplier
+
+    # ------------------------------------------------------------------ merge (network_mixins.py:356-462, 894-906)
+    @torch.no_grad()
+    def merge_in(self, merge_weight=1.0, ops=None):
+        """W <- W + merge_weight * scale * (lora_up @ lora_down) for every wrapped Linear (and its transposed copy),
+        as a rank-r GEMM with the accumulate epilogue: C += (c*B) A  — the MFMA form of ToolkitModuleMixin.merge_in."""
+        ops = ops or self._ops
+        self.refresh_shadows(ops)
+        for m in self.get_all_modules():
+            lin = m.org_module[0]
+            if not m.can_merge_in:
+                continue
+            bs = torch.empty_like(m.sh_up)
+            ops.ew(3, m.sh_up, bs, alpha=float(merge_weight) * m.scale)
+            r = m.lora_dim
+            if r % 8:
+                raise NotImplementedError("merge needs rank % 8 == 0")
+            ops.gemm_nt(bs, m.sh_downT, lin.weight.data, flags=2)          # [out,in] += (cB)[out,r] . A^T[in,r]^T
+            if getattr(lin, "weight_t", None) is not None:
+                ops.gemm_nt(m.sh_downT, bs, lin.weight_t, flags=2)         # [in,out] += A^T[in,r] . (cB)[out,r]^T
+        self.is_merged_in = merge_weight > 0
+
+    @torch.no_grad()
+    def merge_out(self, merge_weight=1.0, ops=None):
+        self.merge_in(-abs(merge_weight), ops=ops)
+        self.is_merged_in = False
+
+    def reset_weights(self):
+        """kaiming-uniform lora_down, zero lora_up (network_mixins.py reset_weights), e.g. after a merge-and-reset cycle."""
+        with torch.no_grad():
+            for m in self.get_all_modules():
+                nn.init.kaiming_uniform_(m.lora_down.weight, a=math.sqrt(5))
+                nn.init.zeros_(m.lora_up.weight)
+
+    # ------------------------------------------------------------------ optimizer state checkpoint (BaseSDTrainProcess.py:701-714)
+    def optimizer_state_dict(self, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01):
+        """The fused AdamW state exported in torch.optim.AdamW.state_dict() layout (params in prepare_optimizer_params
+        order), so `optimizer.pt` written here can be loaded by the reference's torch optimizer and vice versa."""
+        state, ids = {}, []
+        i = 0
+        for m in self.unet_loras:
+            for lin, off in ((m.lora_down, m.off_down), (m.lora_up, m.off_up)):
+                n = lin.weight.numel()
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.arena_m[off:off + n].view_as(lin.weight).clone().cpu(),
+                            "exp_avg_sq": self.arena_v[off:off + n].view_as(lin.weight).clone().cpu()}
+                ids.append(i)
+                i += 1
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": ids}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Inverse of optimizer_state_dict; returns the step count."""
+        i, step = 0, 0
+        for m in self.unet_loras:
+            for lin, off in ((m.lora_down, m.off_down), (m.lora_up, m.off_up)):
+                n = lin.weight.numel()
+                st = sd["state"][i]
+                self.arena_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.arena_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(float(st["step"]))
+                i += 1
+        return step

@@ -227,9 +227,10 @@ def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
     _capi.check(_capi.lib().aitk_qkv_post_bwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_bwd")
 
 
-def ew(op, x, y, a=None):
-    """op 0: y = silu(x); 1: y = x; 2: y = a + x   ([rows, C] bf16 views)."""
+def ew(op, x, y, a=None, alpha=1.0):
+    """op 0: y = silu(x); 1: y = x; 2: y = a + x; 3: y = alpha * x   ([rows, C] bf16 views)."""
     g = _capi.EwArgs()
+    g.alpha = float(alpha)
     g.x, g.ldx, g.y, g.ldy = _ptr(x), _row_major(x, "x"), _ptr(y), _row_major(y, "y")
     if a is not None:
         g.a, g.lda = _ptr(a), _row_major(a, "a")

@@ -170,12 +170,12 @@ typedef struct AitkQkvPostArgs {
 int aitk_qkv_post_fwd(const AitkQkvPostArgs* args, aitk_stream_t stream);
 int aitk_qkv_post_bwd(const AitkQkvPostArgs* args, aitk_stream_t stream);
 
-/* small element-wise ops on [rows, C] bf16: op 0 y=silu(x); 1 y=x; 2 y=a+x */
+/* small element-wise ops on [rows, C] bf16: op 0 y=silu(x); 1 y=x; 2 y=a+x; 3 y=alpha*x */
 typedef struct AitkEwArgs {
   const aitk_bf16* x; int64_t ldx;
   const aitk_bf16* a; int64_t lda;
   aitk_bf16* y; int64_t ldy;
-  int32_t rows, C, op, _pad;
+  int32_t rows, C, op; float alpha;
 } AitkEwArgs;
 int aitk_ew(const AitkEwArgs* args, aitk_stream_t stream);
 /* out[b] = [cos(t*tscale*f_i) | sin(...)], f_i = 10000^(-i/(dim/2))   (diffusers Timesteps, flip_sin_to_cos) */

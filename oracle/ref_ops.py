@@ -181,14 +181,16 @@ def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
         graw[: B * S_src, :HD].copy_(x.grad.reshape(B * S_src, HD).to(graw.dtype))
 
 
-def ew(op, x, y, a=None):
+def ew(op, x, y, a=None, alpha=1.0):
     xf = x.float()
     if op == 0:
         v = F.silu(xf)
     elif op == 1:
         v = xf
-    else:
+    elif op == 2:
         v = a.float() + xf
+    else:
+        v = alpha * xf
     y.copy_(v.to(y.dtype))
     return y
 

@@ -47,3 +47,28 @@ def test_batches_are_single_bucket_padded_by_repetition_and_sharded_disjointly()
     # deterministic from (seed, epoch); different epochs reshuffle
     assert bk.epoch_batches(buckets, 4, 7, 0) == gb and bk.epoch_batches(buckets, 4, 7, 1) != gb
     assert bk.latent_shape(buckets["832x1216"]) == (16, 152, 104)
+
+
+def test_cached_dataset_yields_single_bucket_batches_in_reference_cache_formats(tmp_path):
+    import torch
+    from ai_toolkit_amd import batches as bt
+    from ai_toolkit_amd import vae as nvae
+
+    items, hw = [], []
+    for i in range(6):
+        h, w = (16, 16) if i % 2 == 0 else (12, 20)
+        lp = str(tmp_path / "_latent_cache" / f"img{i}_x.safetensors")
+        nvae.save_latent_cache(lp, torch.full((16, h, w), float(i)).to(torch.bfloat16))
+        tp = str(tmp_path / "_t_e_cache" / f"img{i}.safetensors")
+        bt.save_prompt_embeds(tp, torch.full((1, 8, 32), float(i)), torch.full((1, 4), float(i)))
+        items.append(bt.CachedItem(lp, tp))
+        hw.append((h, w))
+    seen = []
+    for r in range(2):
+        ds = bt.CachedDataset(items, hw, per_rank_batch=1, rank=r, world=2, seed=3)
+        for b in ds.epoch(0, "cpu", torch.float32):
+            assert b.latents.shape[0] == 1 and b.prompt_embeds.shape == (1, 8, 32) and b.pooled_embeds.shape == (1, 4)
+            i = int(b.latents[0, 0, 0, 0])
+            assert float(b.prompt_embeds[0, 0, 0]) == i and float(b.pooled_embeds[0, 0]) == i  # latents / embeds stay paired
+            seen.append(i)
+    assert sorted(set(seen)) == list(range(6))

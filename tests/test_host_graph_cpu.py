@@ -108,3 +108,35 @@ def test_autograd_bridge_populates_param_grads():
     # views: Parameter.grad is the arena slice
     m0 = net.unet_loras[0]
     assert m0.lora_down.weight.grad.data_ptr() == net.arena_g[m0.off_down:].data_ptr()
+
+
+def test_merge_in_equals_active_adapter_and_merge_out_restores():
+    ref, ref_net, nat, net = build_pair()
+    hidden, enc, pooled, t, img_ids, txt_ids, guid = inputs()
+    with net:
+        want = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)
+    w0 = nat.transformer_blocks[0].attn.to_q.weight.detach().clone()
+    net.merge_in(1.0, ops=ref_ops)
+    assert net.is_merged_in and not torch.equal(w0, nat.transformer_blocks[0].attn.to_q.weight)
+    with net:  # merged => adapters are skipped (toolkit/network_mixins.py:285-287)
+        got = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+    lin = nat.transformer_blocks[0].attn.to_q
+    assert torch.allclose(lin.weight_t, lin.weight.t(), rtol=0, atol=1e-6)
+    net.merge_out(1.0, ops=ref_ops)
+    assert torch.allclose(nat.transformer_blocks[0].attn.to_q.weight, w0, rtol=0, atol=1e-6)
+
+
+def test_optimizer_state_exports_as_torch_adamw_state_dict():
+    ref, ref_net, nat, net = build_pair(rank=4)
+    net.arena_m.normal_()
+    net.arena_v.uniform_()
+    sd = net.optimizer_state_dict(step=7, lr=1e-4)
+    opt = torch.optim.AdamW(net.prepare_optimizer_params()[0]["params"], lr=1e-4, eps=1e-6)
+    opt.load_state_dict(sd)  # the reference's optimizer can resume from our optimizer.pt
+    m0 = net.unet_loras[0]
+    st = opt.state[m0.lora_down.weight]
+    assert float(st["step"]) == 7 and torch.equal(st["exp_avg"], net.arena_m[m0.off_down:m0.off_down + m0.lora_down.weight.numel()].view_as(m0.lora_down.weight))
+    m_copy = net.arena_m.clone()
+    net.arena_m.zero_()
+    assert net.load_optimizer_state_dict(opt.state_dict()) == 7 and torch.equal(net.arena_m, m_copy)
