@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaitk_mi355.so")
+LIB_PATH = os.environ.get("AITK_LIB_PATH", os.path.join(_HERE, "libaitk_mi355.so"))  # override only for A/B of two builds
 _lib = None
 
 vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32

@@ -19,6 +19,10 @@
 
 #define BK 64
 
+// 128 B of zeros: source of LDS-DMA chunks that lie beyond K (A operand), so every K-step can run all four 16-wide
+// sub-steps branch-free (zeros x finite = 0) instead of branching on the K tail.
+__device__ __attribute__((aligned(128))) bf16_t g_zero_page[64];
+
 __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
   if (seg_rows > 0) {
     int s = m / seg_rows;
@@ -62,10 +66,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   // logical 16-B chunk held at physical slot pc.  Key = (row>>1)&7: two 128-B rows share one 256-B bank line, so the
   // 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B slots (conflict-free); same key for every pass i.
   const int cc = pc ^ ((srow >> 1) & 7);
-  const bf16_t* pa[PA];
-  const bf16_t* pb[PB];
-  const bf16_t* pa2[PA];
-  const bf16_t* pb2[PB];
+  // 32-bit element offsets from the (wave-uniform, SGPR) base pointers: half the address registers of 64-bit pointers
+  // and the loads can use the saddr+voffset form.  The launcher checks every operand spans < 2^32 elements.
+  long pa[PA];  // CONV: signed element offset (can be negative at the image border); else unsigned offsets below
+  unsigned ao[PA], bo[PB], ao2[PA], bo2[PB];
   int iy0[CONV ? PA : 1], ix0[CONV ? PA : 1];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
@@ -75,18 +79,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
       const int oy = rem / p.conv_Wo, ox = rem - oy * p.conv_Wo;
       iy0[i] = oy * p.conv_stride - p.conv_pad_t;
       ix0[i] = ox * p.conv_stride - p.conv_pad_l;
-      pa[i] = p.A + (((long)b * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
-      pa2[i] = nullptr;
+      pa[i] = (((long)b * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
+      ao[i] = 0;
+      ao2[i] = 0;
     } else {
-      pa[i] = seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra);
-      pa2[i] = p.K2 > 0 ? p.A2 + (long)ra * p.lda2 : nullptr;
+      pa[i] = 0;
+      ao[i] = (unsigned)(seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra) - p.A);
+      ao2[i] = p.K2 > 0 ? (unsigned)((long)ra * p.lda2) : 0u;
     }
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     int rb = min(n0 + srow + RPP * i, p.N - 1);
-    pb[i] = p.B + (long)rb * p.ldb;
-    pb2[i] = p.K2 > 0 ? p.B2 + (long)rb * p.ldb2 : nullptr;
+    bo[i] = (unsigned)((long)rb * p.ldb);
+    bo2[i] = p.K2 > 0 ? (unsigned)((long)rb * p.ldb2) : 0u;
   }
   const int nk1 = (p.K + BK - 1) / BK;
   const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
@@ -116,12 +122,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     const bool valid = kk < Kseg;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const bf16_t* a = second ? pa2[i] : pa[i];
+      const bf16_t* a = second ? p.A2 + ao2[i] : p.A + ao[i];
       ra_reg[i] = valid ? *reinterpret_cast<const uint4*>(a + kk) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const bf16_t* b = second ? pb2[i] : pb[i];
+      const bf16_t* b = second ? p.B2 + bo2[i] : p.B + bo[i];
       rb_reg[i] = valid ? *reinterpret_cast<const uint4*>(b + kk) : make_uint4(0, 0, 0, 0);
     }
   };
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     bool second;
     step_info(s, k0, Kseg, second);
     int kk = k0 + cc * 8;
-    if (kk >= Kseg) kk = 0;  // in-bounds garbage; those k-steps are skipped by the compute phase
+    const bool kvalid_chunk = kk < Kseg;
+    if (!kvalid_chunk) kk = 0;  // B: in-bounds finite data (multiplied by the zero A chunk); A: zero page below
     char* sa = smem + buf * BUF_BYTES;
     char* sb = sa + A_BYTES;
     // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
@@ -152,54 +159,56 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const bool ok = kin && (unsigned)(iy0[i] + ky) < (unsigned)p.conv_H && (unsigned)(ix0[i] + kx) < (unsigned)p.conv_W;
-        const bf16_t* src = ok ? pa[i] + toff : p.zero_page;
+        const bf16_t* src = ok ? p.A + (pa[i] + toff) : p.zero_page;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        const bf16_t* a = second ? pa2[i] : pa[i];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a + kk),
+        const bf16_t* a = kvalid_chunk ? (second ? p.A2 + ao2[i] : p.A + ao[i]) + kk : g_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
                                          (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const bf16_t* b = second ? pb2[i] : pb[i];
+      const bf16_t* b = second ? p.B2 + bo2[i] : p.B + bo[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + kk),
                                        (__attribute__((address_space(3))) void*)(sb + (wave * 64 + NT * i) * 16), 16, 0, 0);
     }
   };
   auto compute = [&](int s, int buf) {
-    int k0, Kseg;
-    bool second;
-    step_info(s, k0, Kseg, second);
-    const int kvalid = min(BK, Kseg - k0);
+    // Fragments are double-buffered in registers: the ds_read_b128 group of k-substep ks+1 is issued before the MFMA
+    // group of ks, so an MFMA only waits (counted lgkmcnt) for reads issued one group earlier.  K tails need no branch:
+    // A chunks beyond K are zero in LDS (zero-filled by the VGPR path / DMA'd from g_zero_page).
     const char* sa = smem + buf * BUF_BYTES;
     const char* sb = sa + A_BYTES;
     const int l31 = lane & 31, h = lane >> 5;
+    s16x8_t af[2][MI], bfr[2][NI];
+    auto ldfrag = [&](int ks, int slot) {
+      const int c = ks * 2 + h;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int row = wr * (32 * MI) + mi * 32 + l31;
+        af[slot][mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        int row = wc * (32 * NI) + ni * 32 + l31;
+        bfr[slot][ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+    };
+    ldfrag(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks * 16 < kvalid) {
-        s16x8_t af[MI], bfr[NI];
-        const int c = ks * 2 + h;
+      if (ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          int row = wr * (32 * MI) + mi * 32 + l31;
-          af[mi] = *reinterpret_cast<const s16x8_t*>(sa + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          int row = wc * (32 * NI) + ni * 32 + l31;
-          bfr[ni] = *reinterpret_cast<const s16x8_t*>(sb + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-        }
-        // swapped operands: D rows = n, D cols = m  -> each lane owns one m and 4 consecutive n per group
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(bfr[ni], af[mi], acc[mi][ni]);
-      }
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = mfma32(bfr[ks & 1][ni], af[ks & 1][mi], acc[mi][ni]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 

@@ -176,9 +176,13 @@ def main():
         "final_loss": final_loss,
         "step_mfma_frac": FLOP_PER_IMAGE * (ips / world) / (PEAK_BF16 * 1e12),
     }
+    rf = None
+    if not args.no_roofline:
+        rf = gemm_roofline(one, ops)  # every rank runs the instrumented step (it contains the gradient all-reduce)
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
     if rank == 0:
-        if not args.no_roofline:
-            rf = gemm_roofline(one, ops)
+        if rf is not None:
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<1> (LoRA-fused bf16 GEMM, all launches of one step)",
                                "achieved": rf["tflops"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": rf["tflops"] / PEAK_BF16,
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
