@@ -130,6 +130,46 @@ __device__ __forceinline__ void glds_tile(lds_char* tile, const bf16_t* base, lo
   }
 }
 
+
+// ---- sub-tiled tiles for operands consumed through ds_read_b64_tr_b16 (PMC: row-major tiles cost ~6 conflict cycles per
+// tr16 instruction, XOR swizzles do not help the transpose read — guide T10).  Layout [8 column blocks][64 rows][16 cols]:
+// a 16-lane group's 4 rows x 32 B are 128 contiguous bytes, the two groups of a 32-lane half sit 2176 B (= 128 mod 256)
+// apart -> conflict-free.  The two 16-B halves of a row are swapped for rows with bit 3 set so the ds_read_b128 row
+// fragments of the same tile stay conflict-free too.  Filled by LDS-DMA (1 KiB = 32 rows of one column block).
+#define SUBP 2176
+#define SUBTILE_BYTES (8 * SUBP)
+__device__ __forceinline__ s16x8_t frag_rm_st(const lds_char* tile, int row0, int k0, int lane) {
+  const int r = row0 + (lane & 31);
+  const int c = (k0 >> 3) + (lane >> 5);
+  return *reinterpret_cast<const __attribute__((address_space(3))) s16x8_t*>(tile + (c >> 1) * SUBP + r * 32 + (((c & 1) ^ ((r >> 3) & 1)) << 4));
+}
+__device__ __forceinline__ s16x8_t frag_tr_perm_st(const lds_char* tile, int kb, int col0, int lane) {
+  const int h = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15;
+  const int row = kb + 4 * h + (i >> 2);
+  const int sub = (col0 >> 4) + gq;
+  const int lh = (i & 3) >> 1, piece = (i & 1) * 8;
+  const lds_char* base = tile + sub * SUBP + piece;
+  s16x4_t lo = tr16l(base + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
+  const int row2 = row + 8;
+  s16x4_t hi = tr16l(base + row2 * 32 + ((lh ^ ((row2 >> 3) & 1)) << 4));
+  s16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+__device__ __forceinline__ void glds_subtile64(lds_char* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int ins = wave + 4 * ii;  // 16 wave-instructions: column block = ins>>1, row half = ins&1
+    const int sub = ins >> 1, rh = ins & 1;
+    const int r = rh * 32 + (lane >> 1);
+    const int lh = (lane & 1) ^ ((r >> 3) & 1);
+    const int rr = min(row0 + r, S - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)rr * ld + (2 * sub + lh) * 8),
+                                     (__attribute__((address_space(3))) void*)(tile + sub * SUBP + rh * 1024), 16, 0, 0);
+  }
+}
+
 // ============================================================================================ forward
 // grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
 // workgroups per CU, <=256 registers -> 2 waves per SIMD so one workgroup's softmax overlaps the other's MFMAs).
@@ -138,7 +178,8 @@ __device__ __forceinline__ void glds_tile(lds_char* tile, const bf16_t* base, lo
 #define ATTN_DEFER_THR 8.0f
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile at b*32768, V tile at b*32768 + 16384
+  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (row-major, swizzled) at b*FBUF, V tile (sub-tiled) at +16384
+  constexpr int FBUF = 16384 + SUBTILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -163,15 +204,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
 
   const int ntiles = (S + 63) / 64;
   glds_tile<64>(sm, Kb, p.ldk, 0, S, wave, lane);
-  glds_tile<64>(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
+  glds_subtile64(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    const lds_char* ktc = sm + cur * 32768;
+    const lds_char* ktc = sm + cur * FBUF;
     const lds_char* vtc = ktc + 16384;
     if (t + 1 < ntiles) {
-      glds_tile<64>(sm + (cur ^ 1) * 32768, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_tile<64>(sm + (cur ^ 1) * 32768 + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * FBUF, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_subtile64(sm + (cur ^ 1) * FBUF + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
     // LDS fragment reads are issued in groups ahead of the MFMAs that consume them (the compiler otherwise emits
     // read -> lgkmcnt(0) -> mfma one by one and every MFMA eats a full LDS round trip)
@@ -227,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int kk = 0; kk < 4; ++kk) {
       const s16x8_t pf = pack_acc8(s[kk >> 1], 8 * (kk & 1));
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_sw(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
+      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_st(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
     }
     __syncthreads();
   }
@@ -279,7 +320,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AitkAttnArgs p) {
 // dV += P^T dO, dK += scale * dS^T Q  (Q/dO consumed via tr16 with the permuted order of the packed P / dS registers).
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const sm = (lds_char*)smem;  // buffer b: Q tile at b*32768, dO tile at +16384; stats at 65536 + b*512
+  lds_char* const sm = (lds_char*)smem;  // buffer b: Q tile (sub-tiled) at b*2*ST, dO tile at +ST; stats at 4*ST + b*512
+  constexpr int ST = SUBTILE_BYTES;
   typedef __attribute__((address_space(3))) float lds_float;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -314,11 +356,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const int ntiles = (S + 63) / 64;  // query tiles of 64 rows, processed as two 32-row halves per barrier
   // rows >= S are clamped (finite data); their L2 = +inf makes P = 0 so they contribute nothing
   auto stage = [&](int t, int buf) {
-    glds_tile<64>(sm + buf * 32768, Qb, p.ldq, t * 64, S, wave, lane);
-    glds_tile<64>(sm + buf * 32768 + 16384, dOb, p.lddo, t * 64, S, wave, lane);
+    glds_subtile64(sm + buf * 2 * ST, Qb, p.ldq, t * 64, S, wave, lane);
+    glds_subtile64(sm + buf * 2 * ST + ST, dOb, p.lddo, t * 64, S, wave, lane);
     if (tid < 128) {
       const int q = t * 64 + (tid & 63);
-      lds_float* st = (lds_float*)(sm + 65536 + buf * 512);  // [0,64): L2, [64,128): delta
+      lds_float* st = (lds_float*)(sm + 4 * ST + buf * 512);  // [0,64): L2, [64,128): delta
       st[tid] = tid < 64 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
     }
   };
@@ -327,9 +369,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
-    const lds_char* qtc = sm + cur * 32768;
-    const lds_char* dotc = qtc + 16384;
-    const lds_float* ltc = (const lds_float*)(sm + 65536 + cur * 512);
+    const lds_char* qtc = sm + cur * 2 * ST;
+    const lds_char* dotc = qtc + ST;
+    const lds_float* ltc = (const lds_float*)(sm + 4 * ST + cur * 512);
     const lds_float* dtc = ltc + 64;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -338,8 +380,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         s16x8_t qa[8], da[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          qa[ks] = frag_rm_sw(qtc, 32 * sub, 16 * ks, lane);
-          da[ks] = frag_rm_sw(dotc, 32 * sub, 16 * ks, lane);
+          qa[ks] = frag_rm_st(qtc, 32 * sub, 16 * ks, lane);
+          da[ks] = frag_rm_st(dotc, 32 * sub, 16 * ks, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -354,8 +396,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          trd[kk][d] = frag_tr_perm_sw(dotc, 32 * sub + 16 * kk, 32 * d, lane);
-          trq[kk][d] = frag_tr_perm_sw(qtc, 32 * sub + 16 * kk, 32 * d, lane);
+          trd[kk][d] = frag_tr_perm_st(dotc, 32 * sub + 16 * kk, 32 * d, lane);
+          trq[kk][d] = frag_tr_perm_st(qtc, 32 * sub + 16 * kk, 32 * d, lane);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -405,7 +447,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 // dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q]  (K through tr16, dS^T straight from registers).
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile at b*32768, V tile at +16384
+  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (sub-tiled: b128 + tr16 reads) at b*DBUF, V tile (row-major) after it
+  constexpr int DBUF = SUBTILE_BYTES + 16384;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -433,16 +476,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   for (int d = 0; d < 4; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 63) / 64;
-  glds_tile<64>(sm, Kb, p.ldk, 0, S, wave, lane);
-  glds_tile<64>(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
+  glds_subtile64(sm, Kb, p.ldk, 0, S, wave, lane);
+  glds_tile<64>(sm + SUBTILE_BYTES, Vb, p.ldv, 0, S, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    const lds_char* ktc = sm + cur * 32768;
-    const lds_char* vtc = ktc + 16384;
+    const lds_char* ktc = sm + cur * DBUF;
+    const lds_char* vtc = ktc + SUBTILE_BYTES;
     if (t + 1 < ntiles) {
-      glds_tile<64>(sm + (cur ^ 1) * 32768, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_tile<64>(sm + (cur ^ 1) * 32768 + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_subtile64(sm + (cur ^ 1) * DBUF, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
     }
     const bool tail = t * 64 + 64 > S;
 #pragma unroll
@@ -453,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
         s16x8_t kfr[2], vfr[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          kfr[u] = frag_rm_sw(ktc, 32 * j, 16 * (2 * hh + u), lane);
+          kfr[u] = frag_rm_st(ktc, 32 * j, 16 * (2 * hh + u), lane);
           vfr[u] = frag_rm_sw(vtc, 32 * j, 16 * (2 * hh + u), lane);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -473,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
       for (int kk = 0; kk < 2; ++kk) {
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_sw(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_st(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
       }
     }
     __syncthreads();
@@ -503,7 +546,12 @@ extern "C" int aitk_attn_fwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   int rc = attn_check(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->LSE) return AITK_ERR_ARG;
-  const size_t lds = 4 * 64 * 128 * sizeof(bf16_t);  // 64 KiB
+  const size_t lds = 2 * (16384 + SUBTILE_BYTES);
+  static bool fattr = false;
+  if (!fattr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    fattr = true;
+  }
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
@@ -520,7 +568,7 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((npairs + 15) / 16)), dim3(256), 0, s, *a);
   AITK_LAUNCH_CHECK();
   dim3 grid((a->S + 127) / 128, a->H, a->B);
-  const size_t lds1 = 4 * 64 * 128 * sizeof(bf16_t) + 4 * 64 * sizeof(float);
+  const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
@@ -528,7 +576,12 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   }
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), lds1, s, *a);
   AITK_LAUNCH_CHECK();
-  const size_t lds2 = 4 * 64 * 128 * sizeof(bf16_t);  // 64 KiB
+  const size_t lds2 = 2 * (16384 + SUBTILE_BYTES);
+  static bool qattr = false;
+  if (!qattr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    qattr = true;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds2, s, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;

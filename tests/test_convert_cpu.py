@@ -1,0 +1,37 @@
+"""PEFT <-> kohya LoRA key conversion round trip on the adapter names the reference itself produced (golden)."""
+import json
+import os
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd import convert
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+
+G = os.path.join(os.path.dirname(__file__), "golden", "lora_flux_tiny.safetensors")
+TINY = dict(in_channels=64, num_layers=1, num_single_layers=1, attention_head_dim=128, num_attention_heads=2,
+            joint_attention_dim=64, pooled_projection_dim=32)
+
+
+def test_peft_kohya_roundtrip_on_reference_saved_keys():
+    t = load_file(G)
+    with safe_open(G, "pt") as f:
+        keys = json.loads(f.metadata()["saved_keys"])
+    peft = {k: t[f"saved/{k}"] for k in keys}
+    kohya = convert.peft_to_kohya(peft)
+    assert "lora_transformer_transformer_blocks_0_attn_to_q.lora_down.weight" in kohya
+    assert float(kohya["lora_transformer_transformer_blocks_0_attn_to_q.alpha"]) == 8.0
+    assert len(kohya) == len(peft) + len(peft) // 2
+    model = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu")
+    paths = [n for n, m in model.named_modules() if m.__class__.__name__ == "Linear"]
+    back = convert.kohya_to_peft(kohya, paths)
+    assert sorted(back) == sorted(peft) and all(torch.equal(back[k], peft[k]) for k in peft)
+
+
+def test_alpha_is_folded_into_lora_up():
+    sd = {"lora_transformer_x.lora_down.weight": torch.ones(4, 8), "lora_transformer_x.lora_up.weight": torch.ones(6, 4),
+          "lora_transformer_x.alpha": torch.tensor(2.0)}
+    out = convert.scale_for_alpha(sd)
+    assert torch.allclose(out["lora_transformer_x.lora_up.weight"], torch.full((6, 4), 0.5)) and float(out["lora_transformer_x.alpha"]) == 4.0

@@ -1,0 +1,36 @@
+"""Small fixed workload for rocprofv3 --pmc passes: 4 launches each of the dominant GEMM shape and attention fwd/bwd."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import ai_toolkit_amd  # noqa: E402,F401
+from ai_toolkit_amd import ops  # noqa: E402
+
+dev = "cuda"
+bf = torch.bfloat16
+M, N, K = 18432, 3072, 3072
+a = torch.randn(M, K, device=dev).to(bf)
+b = (torch.randn(N, K, device=dev) * 0.02).to(bf)
+a2 = torch.randn(M, 16, device=dev).to(bf)
+b2 = torch.randn(N, 16, device=dev).to(bf)
+bias = torch.randn(N, device=dev).to(bf)
+out = torch.empty(M, N, dtype=bf, device=dev)
+for _ in range(4):
+    ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2)
+B, H, S = 1, 24, 4608
+HD = H * 128
+qkv = torch.randn(B * S, 3 * HD, device=dev).to(bf)
+q, k, v = qkv[:, :HD], qkv[:, HD:2 * HD], qkv[:, 2 * HD:]
+o = torch.empty(B * S, HD, dtype=bf, device=dev)
+do = torch.randn(B * S, HD, device=dev).to(bf)
+dqkv = torch.empty_like(qkv)
+lse = torch.empty(B, H, S, device=dev)
+sc = 1 / math.sqrt(128)
+for _ in range(4):
+    ops.attn_fwd(q, k, v, o, lse, B=B, H=H, S=S, scale=sc)
+    ops.attn_bwd(q, k, v, o, lse, do, dqkv[:, :HD], dqkv[:, HD:2 * HD], dqkv[:, 2 * HD:], B=B, H=H, S=S, scale=sc)
+torch.cuda.synchronize()
+print("done")
