@@ -170,6 +170,29 @@ __device__ __forceinline__ void glds_subtile64(lds_char* tile, const bf16_t* bas
   }
 }
 
+
+// ---- tr16 reads hipcc does not see (guide §5.7 form ii): the builtin makes SIInsertWaitcnts drain vmcnt (= the in-flight
+// LDS-DMA prefetch of the NEXT tile) before the first transpose read of every iteration; the asm form leaves the prefetch in
+// flight for the whole iteration.  Safe because the tile being read was published by the previous barrier.  The matching
+// lgkmcnt wait names every destination register ("+v") and is followed by sched_barrier(0) (rule 18).
+__device__ __forceinline__ void tr16_issue(s16x4_t& out, const lds_char* p) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(out) : "v"((unsigned)(unsigned long)p));
+}
+__device__ __forceinline__ void frag_tr_perm_st_issue(s16x4_t& lo, s16x4_t& hi, const lds_char* tile, int kb, int col0, int lane) {
+  const int h = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15;
+  const int row = kb + 4 * h + (i >> 2);
+  const int sub = (col0 >> 4) + gq;
+  const int lh = (i & 3) >> 1, piece = (i & 1) * 8;
+  const lds_char* base = tile + sub * SUBP + piece;
+  tr16_issue(lo, base + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4));
+  const int row2 = row + 8;
+  tr16_issue(hi, base + row2 * 32 + ((lh ^ ((row2 >> 3) & 1)) << 4));
+}
+#define TR_PIN8(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+__device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // ============================================================================================ forward
 // grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
 // workgroups per CU, <=256 registers -> 2 waves per SIMD so one workgroup's softmax overlaps the other's MFMAs).
@@ -355,20 +378,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 63) / 64;  // query tiles of 64 rows, processed as two 32-row halves per barrier
   // rows >= S are clamped (finite data); their L2 = +inf makes P = 0 so they contribute nothing
-  auto stage = [&](int t, int buf) {
-    glds_subtile64(sm + buf * 2 * ST, Qb, p.ldq, t * 64, S, wave, lane);
-    glds_subtile64(sm + buf * 2 * ST + ST, dOb, p.lddo, t * 64, S, wave, lane);
+  // The per-row statistics are ordinary global loads: they are issued BEFORE the tile DMAs and stored to LDS at the
+  // END of the iteration, otherwise their vmcnt wait (in-order counter) would also drain the just-issued LDS-DMA
+  // prefetch and make it synchronous.
+  float stat = 0.f;
+  auto stage_load = [&](int t, int buf) {
     if (tid < 128) {
       const int q = t * 64 + (tid & 63);
-      lds_float* st = (lds_float*)(sm + 4 * ST + buf * 512);  // [0,64): L2, [64,128): delta
-      st[tid] = tid < 64 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
+      stat = tid < 64 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
     }
+    glds_subtile64(sm + buf * 2 * ST, Qb, p.ldq, t * 64, S, wave, lane);
+    glds_subtile64(sm + buf * 2 * ST + ST, dOb, p.lddo, t * 64, S, wave, lane);
   };
-  stage(0, 0);
+  auto stage_store = [&](int buf) {
+    if (tid < 128) ((lds_float*)(sm + 4 * ST + buf * 512))[tid] = stat;  // [0,64): L2, [64,128): delta
+  };
+  stage_load(0, 0);
+  stage_store(0);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+    if (t + 1 < ntiles) stage_load(t + 1, cur ^ 1);
     const lds_char* qtc = sm + cur * 2 * ST;
     const lds_char* dotc = qtc + ST;
     const lds_float* ltc = (const lds_float*)(sm + 4 * ST + cur * 512);
@@ -391,13 +421,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         }
       }
       // transposed operands of the dV / dK products: issued now so their LDS latency hides behind the softmax VALU
-      s16x8_t trd[2][4], trq[2][4];
+      s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];  // index = 4*kk + d
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          trd[kk][d] = frag_tr_perm_st(dotc, 32 * sub + 16 * kk, 32 * d, lane);
-          trq[kk][d] = frag_tr_perm_st(qtc, 32 * sub + 16 * kk, 32 * d, lane);
+          frag_tr_perm_st_issue(dlo[4 * kk + d], dhi[4 * kk + d], dotc, 32 * sub + 16 * kk, 32 * d, lane);
+          frag_tr_perm_st_issue(qlo[4 * kk + d], qhi[4 * kk + d], qtc, 32 * sub + 16 * kk, 32 * d, lane);
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -414,17 +444,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
           dp[r] = pr * (dp[r] - ds[e]);
         }
       }
+      // the transpose reads must have landed: wait names every destination so nothing that uses them is scheduled above
+      asm volatile("s_waitcnt lgkmcnt(0)" : TR_PIN8(dlo), TR_PIN8(dhi));
+      asm volatile("" : TR_PIN8(qlo), TR_PIN8(qhi));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const s16x8_t pf = pack_acc8(s, 8 * kk);
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          dv[d] = mfma32(pf, trd[kk][d], dv[d]);
-          dk[d] = mfma32(df, trq[kk][d], dk[d]);
+          dv[d] = mfma32(pf, join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);
+          dk[d] = mfma32(df, join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);
         }
       }
     }
+    if (t + 1 < ntiles) stage_store(cur ^ 1);
     __syncthreads();
   }
   // D[i = kv][j = d]: lane holds column d = 32*blk + l31 and rows kv = crow(r, h)
