@@ -26,6 +26,7 @@ class GemmArgs(C.Structure):
         ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_Wo", i32), ("conv_HoWo", i32), ("conv_stride", i32),
         ("conv_pad_t", i32), ("conv_pad_l", i32), ("_pad3", i32),
         ("zero_page", vp),
+        ("b_scale", vp), ("b_scale_mode", i32), ("_pad4", i32),
     ]
 
 

@@ -114,6 +114,68 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     Kseg = second ? p.K2 : p.K;
   };
 
+  // ---- STAGE 3: weight-only fp8 (OCP e4m3) base operand.  B holds bytes [N, K] plus a per-output-channel fp32 scale; the
+  // chunk is dequantised to bf16 (w = bf16(fp8 * scale), the value a weight-only-quantised Linear multiplies with — reference:
+  // optimum-quanto qfloat8 / torchao Float8WeightOnly, toolkit/util/quantize.py:43-75) while it moves VGPR -> LDS.  b_scale_mode 1:
+  // scale indexed by the B row (forward, rows = output channels); 2: by the contraction index (dgrad on W^T).
+  auto dequant8 = [&](uint2 q, const float* sc8, float sc_row) -> uint4 {
+    float f[8];
+    f[0] = __builtin_amdgcn_cvt_f32_fp8(q.x, 0); f[1] = __builtin_amdgcn_cvt_f32_fp8(q.x, 1);
+    f[2] = __builtin_amdgcn_cvt_f32_fp8(q.x, 2); f[3] = __builtin_amdgcn_cvt_f32_fp8(q.x, 3);
+    f[4] = __builtin_amdgcn_cvt_f32_fp8(q.y, 0); f[5] = __builtin_amdgcn_cvt_f32_fp8(q.y, 1);
+    f[6] = __builtin_amdgcn_cvt_f32_fp8(q.y, 2); f[7] = __builtin_amdgcn_cvt_f32_fp8(q.y, 3);
+    if (sc8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= sc8[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= sc_row;
+    }
+    uint4 o;
+    o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+    return o;
+  };
+  float brow_scale[STAGE == 3 ? PB : 1];
+  if constexpr (STAGE == 3) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) brow_scale[i] = p.b_scale_mode == 1 ? p.b_scale[min(n0 + srow + RPP * i, p.N - 1)] : 1.0f;
+  }
+  uint2 rb8_reg[STAGE == 3 ? PB : 1];
+  auto load_b8 = [&](int s) {  // issue the global loads of the B tile of step s (fp8 bytes, or bf16 for the LoRA slab)
+    int k0, Kseg;
+    bool second;
+    step_info(s, k0, Kseg, second);
+    const int kk = k0 + cc * 8;
+    const bool valid = kk < Kseg;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      if (second) {
+        rb_reg[i] = valid ? *reinterpret_cast<const uint4*>(p.B2 + bo2[i] + kk) : make_uint4(0, 0, 0, 0);
+      } else {
+        const uint8_t* b8 = reinterpret_cast<const uint8_t*>(p.B) + bo[i];
+        rb8_reg[i] = valid ? *reinterpret_cast<const uint2*>(b8 + kk) : make_uint2(0, 0);
+      }
+    }
+  };
+  auto write_b8 = [&](int s, int buf) {
+    int k0, Kseg;
+    bool second;
+    step_info(s, k0, Kseg, second);
+    const int kk = k0 + cc * 8;
+    char* sb = smem + buf * BUF_BYTES + A_BYTES;
+    float sc8[8];
+    const bool per_k = (!second) && p.b_scale_mode == 2;
+    if (per_k) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc8[e] = (kk + e < Kseg) ? p.b_scale[kk + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const uint4 v = second ? rb_reg[i] : dequant8(rb8_reg[i], per_k ? sc8 : nullptr, brow_scale[i]);
+      *reinterpret_cast<uint4*>(sb + (tid + NT * i) * 16) = v;
+    }
+  };
+
   auto load_regs = [&](int s) {
     int k0, Kseg;
     bool second;
@@ -171,11 +233,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
                                          (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
       }
     }
+    if constexpr (STAGE != 3) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const bf16_t* b = second ? p.B2 + bo2[i] : p.B + bo[i];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + kk),
-                                       (__attribute__((address_space(3))) void*)(sb + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      for (int i = 0; i < PB; ++i) {
+        const bf16_t* b = second ? p.B2 + bo2[i] : p.B + bo[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + kk),
+                                         (__attribute__((address_space(3))) void*)(sb + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      }
     }
   };
   auto compute = [&](int s, int buf) {
@@ -228,6 +292,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     for (int s = 0; s < nsteps; ++s) {
       if (s + 1 < nsteps) issue_glds(s + 1, (s + 1) & 1);
       compute(s, s & 1);
+      __syncthreads();
+    }
+  } else if (STAGE == 3) {
+    issue_glds(0, 0);
+    load_b8(0);
+    write_b8(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+        issue_glds(s + 1, (s + 1) & 1);
+        load_b8(s + 1);
+      }
+      compute(s, s & 1);
+      if (s + 1 < nsteps) write_b8(s + 1, (s + 1) & 1);
       __syncthreads();
     }
   } else {
@@ -336,7 +414,8 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if ((a->flags & (AITK_EPI_GELU | AITK_EPI_GATE_RES)) && !a->aux_out) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
-  if (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
+  if (((uintptr_t)a->A | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
+  if ((uintptr_t)a->B & (a->b_scale_mode ? 7 : 15)) return AITK_ERR_ALIGN;
   hipStream_t st = stream;
   if (a->conv_mode) {
     if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != 9 * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
@@ -358,6 +437,23 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     return AITK_OK;
   }
   AitkGemmArgs tmp = *a;
+  if (a->b_scale_mode) {
+    if (!a->b_scale || (a->ldb % 8) || (a->K % 16) || (a->K2 % 16)) return AITK_ERR_ARG;
+    static bool f8attr = false;
+    if (!f8attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<3, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      f8attr = true;
+    }
+    const long t256f = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    if (a->tile_mode == 2 || (a->tile_mode == 0 && a->M >= 1024 && a->N >= 512 && t256f >= 192)) {
+      hipLaunchKernelGGL((gemm_nt_kernel<3, 256, 256, 2, 4>), dim3((unsigned)t256f), dim3(512), 131072, st, *a);
+    } else {
+      const int tiles = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+      hipLaunchKernelGGL((gemm_nt_kernel<3, 128, 128, 2, 2>), dim3(tiles), dim3(256), 65536, st, *a);
+    }
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
   if (tmp.stage_mode >= 1 && ((a->K % 16) || (a->K2 % 16))) tmp.stage_mode = 0;  // LDS-DMA cannot zero-fill an 8-wide K tail
   a = &tmp;
   // tile choice: 256x256 when the problem fills the chip with big tiles (>= 1 full round of 256 CUs) or is overridden

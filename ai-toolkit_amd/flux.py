@@ -148,7 +148,7 @@ class FluxTransformer2DModel(nn.Module):
         self.norm_out = _ada(d, 2, dtype, device)
         self.proj_out = Linear(d, in_channels, True, dtype, device)
         self.ops = ops
-        self.network = None
+        object.__setattr__(self, "network", None)
         self._rope_cache = {}
         self._prepared = False
         self.ctx = None
@@ -159,7 +159,8 @@ class FluxTransformer2DModel(nn.Module):
         self.ops = ops
 
     def attach_network(self, network):
-        self.network = network
+        # not a registered sub-module: the adapter must stay out of the base model's state_dict / parameters()
+        object.__setattr__(self, "network", network)
 
     def prepare(self):
         """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""

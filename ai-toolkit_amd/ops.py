@@ -24,7 +24,7 @@ def _row_major(t, name):
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None,
-            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None):
+            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T + bias).
 
     a_seg / c_seg = (seg_rows, seg_stride_elems): logical row m lives at base + (m // seg_rows) * seg_stride
@@ -33,7 +33,12 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     """
     g = _capi.GemmArgs()
     g.lda = _row_major(a, "a")
-    g.ldb = _row_major(b, "b")
+    if b_scale is not None:  # weight-only fp8 base: b is uint8/float8 bytes [N, K]
+        assert b.element_size() == 1 and b.dim() == 2 and b.stride(1) == 1 and b_scale.dtype == torch.float32 and b_scale_mode in (1, 2)
+        g.ldb = b.stride(0)
+        g.b_scale, g.b_scale_mode = _ptr(b_scale), b_scale_mode
+    else:
+        g.ldb = _row_major(b, "b")
     g.ldc = _row_major(out, "out")
     N, K = b.shape
     assert a.shape[1] == K

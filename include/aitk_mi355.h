@@ -63,6 +63,9 @@ typedef struct AitkGemmArgs {
   int32_t conv_mode;
   int32_t conv_H, conv_W, conv_Cin, conv_Wo, conv_HoWo, conv_stride, conv_pad_t, conv_pad_l, _pad3;
   const aitk_bf16* zero_page;
+  /* weight-only fp8 base operand (b_scale_mode != 0): B points to OCP e4m3 bytes [N, K] (ldb in bytes), dequantised to
+   * bf16(fp8 * scale) on the way into LDS.  1: scale[n] per B row (forward); 2: scale[k] per contraction index (dgrad on W^T). */
+  const float* b_scale; int32_t b_scale_mode; int32_t _pad4;
 } AitkGemmArgs;
 
 int aitk_abi_version(void);

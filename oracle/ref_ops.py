@@ -41,11 +41,16 @@ def rows_per_block():
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None):
-    """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342)."""
+            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0):
+    """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342).  b_scale: weight-only fp8 base,
+    dequantised as (fp8 * scale) rounded to the activation dtype (quanto / torchao weight-only semantics)."""
     if M is None:
         M = a.shape[0]
     A = _seg_view(a, a_seg, M).float()
+    if b_scale is not None:
+        bq = b.view(torch.float8_e4m3fn).float()
+        bq = bq * (b_scale[:, None] if b_scale_mode == 1 else b_scale[None, :])
+        b = bq.to(a.dtype)
     v = A @ b.float().t()
     if a2 is not None:
         v = v + a2[:M].float() @ b2.float().t()

@@ -1,0 +1,46 @@
+"""Weight-only fp8 (e4m3) base operand of the GEMM (BASELINE config 5): in-flight dequant vs the oracle's dequantised-weight matmul."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+
+
+def quantize_rows(w):
+    """per-output-channel symmetric e4m3: scale[n] = amax|w[n,:]| / 448"""
+    scale = (w.float().abs().amax(dim=1).clamp_min(1e-12) / 448.0)
+    q = (w.float() / scale[:, None]).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+@pytest.mark.parametrize("shape", [(512, 768, 256, 16), (300, 200, 128, 0), (2048, 3072, 3072, 32), (4608, 3072, 3072, 16)])
+def test_fp8_base_forward_and_dgrad_layouts(shape):
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    M, N, K, r = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, K, generator=g).to(bf).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    bias = torch.randn(N, generator=g).to(bf).cuda()
+    q, scale = quantize_rows(w)
+    kw = {}
+    if r:
+        kw = dict(a2=torch.randn(M, r, generator=g).to(bf).cuda(), b2=(torch.randn(N, r, generator=g) * 0.1).to(bf).cuda())
+    out = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
+    ref = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(x, q.view(torch.uint8), out, bias=bias, b_scale=scale, b_scale_mode=1, **kw)
+    ref_ops.gemm_nt(x, q.view(torch.uint8), ref, bias=bias, b_scale=scale, b_scale_mode=1, **kw)
+    torch.cuda.synchronize()
+    e = ((out.float() - ref).norm() / ref.norm()).item()
+    assert e < 5e-3, e
+    # dgrad orientation: B = W^T bytes [K, N], scale indexed by the contraction index
+    dy = torch.randn(M, N, generator=g).to(bf).cuda()
+    qt = q.view(torch.uint8).t().contiguous()
+    dx = torch.full((M, K), float("nan"), dtype=bf, device="cuda")
+    dref = torch.empty(M, K, device="cuda")
+    ops.gemm_nt(dy, qt, dx, b_scale=scale, b_scale_mode=2)
+    ref_ops.gemm_nt(dy, qt, dref, b_scale=scale, b_scale_mode=2)
+    torch.cuda.synchronize()
+    e2 = ((dx.float() - dref).norm() / dref.norm()).item()
+    assert e2 < 5e-3, e2

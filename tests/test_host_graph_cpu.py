@@ -140,3 +140,9 @@ def test_optimizer_state_exports_as_torch_adamw_state_dict():
     m_copy = net.arena_m.clone()
     net.arena_m.zero_()
     assert net.load_optimizer_state_dict(opt.state_dict()) == 7 and torch.equal(net.arena_m, m_copy)
+
+
+def test_attached_network_stays_out_of_base_state_dict():
+    ref, ref_net, nat, net = build_pair()
+    assert not any("lora" in k or "network" in k for k in nat.state_dict().keys())
+    assert sorted(nat.state_dict().keys()) == sorted(ref.state_dict().keys())
