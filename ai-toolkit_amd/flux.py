@@ -33,8 +33,9 @@ class Linear(nn.Module):
         self.in_features, self.out_features = in_features, out_features
         self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=dtype, device=device), requires_grad=False) if bias else None
-        self.lora = None
+        object.__setattr__(self, "lora", None)
         self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
+        self.qweight = self.qweight_t = self.wscale = None  # weight-only fp8 base (quantize_base_fp8)
 
     def forward(self, x):
         raise RuntimeError("fused path: Linear is executed inside FluxTransformer2DModel.forward")
@@ -174,9 +175,45 @@ class FluxTransformer2DModel(nn.Module):
             need_t += [a.to_q, a.to_k, a.to_v, blk.proj_mlp, blk.proj_out]
         need_t.append(self.proj_out)
         for lin in need_t:
-            lin.weight_t = lin.weight.data.t().contiguous()
+            if lin.qweight is None:
+                lin.weight_t = lin.weight.data.t().contiguous()
         self._prepared = True
         return self
+
+    def _token_linears(self):
+        out = []
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            out += [a.to_q, a.to_k, a.to_v, a.add_q_proj, a.add_k_proj, a.add_v_proj, a.to_out[0], a.to_add_out,
+                    blk.ff.net[0].proj, blk.ff.net[2], blk.ff_context.net[0].proj, blk.ff_context.net[2]]
+        for blk in self.single_transformer_blocks:
+            a = blk.attn
+            out += [a.to_q, a.to_k, a.to_v, blk.proj_mlp, blk.proj_out]
+        return out
+
+    @torch.no_grad()
+    def quantize_base_fp8(self, release_bf16=False):
+        """Weight-only fp8 (OCP e4m3, per-output-channel scale) for every token-GEMM Linear of the blocks — BASELINE config 5;
+        the reference does this with optimum-quanto qfloat8 / torchao Float8WeightOnly (toolkit/util/quantize.py:43-75,
+        toolkit/stable_diffusion_model.py:794-801).  Activations and the LoRA adapter stay bf16 / fp32.  The GEMM dequantises
+        bf16(fp8 * scale) while staging, forward from `qweight` [out,in], dgrad from `qweight_t` [in,out].  adaLN / embedder
+        projections (B rows, weight streaming) keep bf16 weights."""
+        for lin in self._token_linears():
+            w = lin.weight.data.float()
+            scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
+            q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+            lin.qweight = q.view(torch.uint8).contiguous()
+            lin.qweight_t = q.view(torch.uint8).t().contiguous()
+            lin.wscale = scale
+            lin.weight_t = None
+            if release_bf16:
+                lin.weight.data = torch.empty(0, dtype=lin.weight.dtype, device=lin.weight.device)
+        self._prepared = True
+        self.is_quantized = True
+        return self
+
+    def dequantized_weight(self, lin):
+        return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)
 
     def rope_tables(self, img_ids, txt_ids):
         """FluxPosEmbed in float64 on the host, cached per (shape) bucket; fp32 [S, 128] cos/sin on device."""
@@ -268,8 +305,10 @@ class FluxTransformer2DModel(nn.Module):
             kw = dict(a2=T, b2=lo.sh_up)
         else:
             T = None
-        ops.gemm_nt(x, lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out, aux_in=aux_in, gate=gate,
-                    gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
+        if lin.qweight is not None:
+            kw.update(b_scale=lin.wscale, b_scale_mode=1)
+        ops.gemm_nt(x, lin.qweight if lin.qweight is not None else lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out,
+                    aux_in=aux_in, gate=gate, gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
         return T
 
     def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
@@ -310,7 +349,10 @@ class FluxTransformer2DModel(nn.Module):
         if dT is not None:
             shT = lin.lora.sh_downT
             kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
-        wt = lin.weight_t if w_rows is None else lin.weight_t[w_rows[0]:w_rows[1]]
+        wt_full = lin.qweight_t if lin.qweight is not None else lin.weight_t
+        if lin.qweight is not None:
+            kw.update(b_scale=lin.wscale, b_scale_mode=2)
+        wt = wt_full if w_rows is None else wt_full[w_rows[0]:w_rows[1]]
         self.ops.gemm_nt(dy, wt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, **kw)
 
     def _lin_bwd(self, lin, dy, T, x_in, dx, *, M, rows_per_batch, B, flags=0, aux_in=None, x_seg=None, dx_seg=None):

@@ -77,7 +77,7 @@ class LoRAModule(nn.Module):
 
     def apply_to(self):
         """The reference swaps org_module.forward; the fused path instead tags the base layer with its adapter."""
-        self.org_module[0].lora = self
+        object.__setattr__(self.org_module[0], "lora", self)  # plain attribute: keeps the adapter out of the base state_dict
 
     @property
     def in_features(self):

@@ -146,3 +146,24 @@ def test_attached_network_stays_out_of_base_state_dict():
     ref, ref_net, nat, net = build_pair()
     assert not any("lora" in k or "network" in k for k in nat.state_dict().keys())
     assert sorted(nat.state_dict().keys()) == sorted(ref.state_dict().keys())
+
+
+def test_fp8_weight_only_base_matches_oracle_with_dequantised_weights():
+    ref, ref_net, nat, net = build_pair()
+    nat.quantize_base_fp8()
+    with torch.no_grad():  # the oracle multiplies with the dequantised weights (weight-only quantisation semantics)
+        for (n, lin) in nat.named_modules():
+            if getattr(lin, "qweight", None) is not None:
+                dict(ref.named_modules())[n].weight.copy_(nat.dequantized_weight(lin))
+    hidden, enc, pooled, t, img_ids, txt_ids, guid = inputs()
+    with ref_net:
+        pred_ref = ref(hidden, enc, pooled, t, img_ids, txt_ids, guid)
+        pred_ref.square().sum().backward()
+    with net:
+        pred = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid)
+        assert torch.allclose(pred, pred_ref, rtol=1e-4, atol=1e-5)
+        net.zero_grad_arena()
+        nat.backward_native((2 * pred).detach())
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        err = (a.lora_down.weight.grad - b.lora_down.weight.grad).norm() / (b.lora_down.weight.grad.norm() + 1e-12)
+        assert err < 2e-4, (a.lora_name, err.item())
