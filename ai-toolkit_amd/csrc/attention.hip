@@ -206,11 +206,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
-  const int S = p.S;
+  const int S = p.S;                        // query rows per batch
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;  // key/value rows per batch (cross-attention: Skv != S)
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * S * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * S * p.ldv + hd * 128;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
 
   s16x8_t qf[8];
   {
@@ -225,17 +226,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   float m_run = -INFINITY, l_run = 0.f;  // m_run in the scaled log2 domain
   const float c2 = p.scale * 1.4426950408889634f;
 
-  const int ntiles = (S + 63) / 64;
-  glds_tile<64>(sm, Kb, p.ldk, 0, S, wave, lane);
-  glds_subtile64(sm + 16384, Vb, p.ldv, 0, S, wave, lane);
+  const int ntiles = (Skv + 63) / 64;
+  glds_tile<64>(sm, Kb, p.ldk, 0, Skv, wave, lane);
+  glds_subtile64(sm + 16384, Vb, p.ldv, 0, Skv, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const lds_char* ktc = sm + cur * FBUF;
     const lds_char* vtc = ktc + 16384;
     if (t + 1 < ntiles) {
-      glds_tile<64>(sm + (cur ^ 1) * FBUF, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_subtile64(sm + (cur ^ 1) * FBUF + 16384, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * FBUF, Kb, p.ldk, (t + 1) * 64, Skv, wave, lane);
+      glds_subtile64(sm + (cur ^ 1) * FBUF + 16384, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
     }
     // LDS fragment reads are issued in groups ahead of the MFMAs that consume them (the compiler otherwise emits
     // read -> lgkmcnt(0) -> mfma one by one and every MFMA eats a full LDS round trip)
@@ -254,12 +255,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
       }
     }
     const int kv0 = t * 64;
-    if (kv0 + 64 > S) {  // wave-uniform: only the last tile masks
+    if (kv0 + 64 > Skv) {  // wave-uniform: only the last tile masks
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kv0 + 32 * j + crow(r, h) >= S) s[j][r] = -INFINITY;
+          if (kv0 + 32 * j + crow(r, h) >= Skv) s[j][r] = -INFINITY;
     }
     float mt = -INFINITY;
 #pragma unroll
@@ -350,17 +351,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
   const int kvw = blockIdx.x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * S * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * S * p.ldv + hd * 128;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
   const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
   const float* Lb = p.LSE + ((long)b * p.H + hd) * S;
   const float* Db = p.delta + ((long)b * p.H + hd) * S;
 
   s16x8_t kf[8], vf[8];
   {
-    const int kr = min(kvw + l31, S - 1);
+    const int kr = min(kvw + l31, Skv - 1);
     const bf16_t* kp = Kb + (long)kr * p.ldk + 8 * h;
     const bf16_t* vp = Vb + (long)kr * p.ldv + 8 * h;
 #pragma unroll
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kv = kvw + crow(r, h);
-      if (kv < S) {
-        const long off = ((long)b * S + kv);
+      if (kv < Skv) {
+        const long off = ((long)b * Skv + kv);
         p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = f2bf(dk[d][r] * p.scale);
         p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = f2bf(dv[d][r]);
       }
@@ -488,10 +490,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
   const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * S * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * S * p.ldv + hd * 128;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
   const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
   const int qr = min(q0 + l31, S - 1);
   s16x8_t qf[8], gf[8];
@@ -510,19 +513,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
-  const int ntiles = (S + 63) / 64;
-  glds_subtile64(sm, Kb, p.ldk, 0, S, wave, lane);
-  glds_tile<64>(sm + SUBTILE_BYTES, Vb, p.ldv, 0, S, wave, lane);
+  const int ntiles = (Skv + 63) / 64;
+  glds_subtile64(sm, Kb, p.ldk, 0, Skv, wave, lane);
+  glds_tile<64>(sm + SUBTILE_BYTES, Vb, p.ldv, 0, Skv, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const lds_char* ktc = sm + cur * DBUF;
     const lds_char* vtc = ktc + SUBTILE_BYTES;
     if (t + 1 < ntiles) {
-      glds_subtile64(sm + (cur ^ 1) * DBUF, Kb, p.ldk, (t + 1) * 64, S, wave, lane);
-      glds_tile<64>(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, S, wave, lane);
+      glds_subtile64(sm + (cur ^ 1) * DBUF, Kb, p.ldk, (t + 1) * 64, Skv, wave, lane);
+      glds_tile<64>(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
     }
-    const bool tail = t * 64 + 64 > S;
+    const bool tail = t * 64 + 64 > Skv;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x16_t s = zero16(), dp = zero16();
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -L2));
-        if (tail && t * 64 + 32 * j + crow(r, h) >= S) pr = 0.f;
+        if (tail && t * 64 + 32 * j + crow(r, h) >= Skv) pr = 0.f;
         dp[r] = pr * (dp[r] - dl);
       }
 #pragma unroll
@@ -602,14 +605,16 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   const long npairs = (long)a->B * a->S * a->H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((npairs + 15) / 16)), dim3(256), 0, s, *a);
   AITK_LAUNCH_CHECK();
+  const int Skv = a->Skv > 0 ? a->Skv : a->S;
   dim3 grid((a->S + 127) / 128, a->H, a->B);
+  dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
   const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), lds1, s, *a);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid_kv, dim3(256), lds1, s, *a);
   AITK_LAUNCH_CHECK();
   const size_t lds2 = 2 * (16384 + SUBTILE_BYTES);
   static bool qattr = false;

@@ -158,6 +158,8 @@ class FusedLoRANetwork(nn.Module):
         matrices are laid out back to back so one skinny kernel launch produces T for the whole group and one wgrad
         launch produces all their lora_down gradients (the activation is streamed once instead of 3-4 times)."""
         mods = self.get_all_modules()
+        # the skinny kernels handle up to 64 ranks per launch: larger groups (e.g. q,k,v at rank 32) stay ungrouped
+        groups = [g for g in (groups or []) if sum(x.lora_dim for x in g) <= 64]
         n = sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in mods)
         self.arena_p = torch.empty(n, dtype=torch.float32, device=device)
         self.arena_g = torch.zeros(n, dtype=torch.float32, device=device)

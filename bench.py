@@ -24,7 +24,7 @@ FLOP_PER_IMAGE = 163.6e12  # fwd 74.4 + bwd 89.2 TFLOP, no reco
 PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
 
 
-def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True):
+def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -45,6 +45,8 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True):
     net.build_arena(dev, ema=ema, groups=model.lora_groups())
     net.refresh_shadows(ops)
     model.attach_network(net)
+    if fp8_base:  # BASELINE config 5: e4m3 weight-only base (per-output-channel scale) + bf16/fp32 adapter
+        model.quantize_base_fp8(release_bf16=True)
     model.prepare()
     return model, net, ops
 
@@ -113,6 +115,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AITK_BENCH_BATCH", "4")), help="per-GPU batch")
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--fp8-base", action="store_true", help="BASELINE config 5 variant (not the headline metric): fp8 e4m3 base weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -134,7 +138,7 @@ def main():
 
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
 
-    model, net, ops = build_flux(dev)
+    model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base)
     step = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99,
                              timestep_type="linear", process_group=pg, seed=1000 + rank)
     B = args.batch
@@ -166,10 +170,10 @@ def main():
     final_loss = float(loss.item())
     ips = world * B * args.steps / dt
     out = {
-        "metric": "train images/sec, FLUX.1-dev LoRA r16 @1024^2",
+        "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else ""),
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
+        "dtype": "bf16 (fp8 e4m3 base weights dequantised in the GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
         "config": {"workload": "FLUX.1-dev DiT LoRA r16, 1024x1024 (4096 img + 512 txt tokens), bf16, AdamW+EMA, clip 1.0",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
                    "lora_params": net.arena_p.numel(), "grad_checkpointing": False},

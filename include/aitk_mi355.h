@@ -199,7 +199,7 @@ typedef struct AitkAttnArgs {
   const aitk_bf16* dO; int64_t lddo;
   aitk_bf16* dQ; aitk_bf16* dK; aitk_bf16* dV; int64_t lddq, lddk, lddv;
   float* delta;
-  float scale; int32_t B, H, S, D, _pad;
+  float scale; int32_t B, H, S, D, Skv; /* Skv: key/value rows per batch (0 = S); cross-attention has Skv != S */
 } AitkAttnArgs;
 int aitk_attn_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
 int aitk_attn_bwd(const AitkAttnArgs* args, aitk_stream_t stream);

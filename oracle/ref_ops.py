@@ -218,9 +218,11 @@ def _heads(t, B, S, H):
     return t[: B * S, : H * 128].reshape(B, S, H, 128).transpose(1, 2).float()
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, S, scale):
-    """F.scaled_dot_product_attention (toolkit/models/flux_sage_attn.py:76; chroma/src/math.py:27)."""
-    qf, kf, vf = _heads(q, B, S, H), _heads(k, B, S, H), _heads(v, B, S, H)
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0):
+    """F.scaled_dot_product_attention (toolkit/models/flux_sage_attn.py:76; chroma/src/math.py:27; cross-attention:
+    toolkit/models/wan21/wan_attn.py:67-75)."""
+    Skv = Skv or S
+    qf, kf, vf = _heads(q, B, S, H), _heads(k, B, Skv, H), _heads(v, B, Skv, H)
     sc = (qf @ kf.transpose(-1, -2)) * scale
     lse.copy_(torch.logsumexp(sc, -1) / math.log(2.0))
     out = sc.softmax(-1) @ vf
@@ -228,15 +230,16 @@ def attn_fwd(q, k, v, o, lse, *, B, H, S, scale):
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
+    Skv = Skv or S
     qf = _heads(q, B, S, H).requires_grad_(True)
-    kf = _heads(k, B, S, H).requires_grad_(True)
-    vf = _heads(v, B, S, H).requires_grad_(True)
+    kf = _heads(k, B, Skv, H).requires_grad_(True)
+    vf = _heads(v, B, Skv, H).requires_grad_(True)
     with torch.enable_grad():
         out = ((qf @ kf.transpose(-1, -2)) * scale).softmax(-1) @ vf
         out.backward(_heads(do, B, S, H))
-    for dst, src in ((dq, qf), (dk, kf), (dv, vf)):
-        dst[: B * S, : H * 128].copy_(src.grad.transpose(1, 2).reshape(B * S, H * 128).to(dst.dtype))
+    for dst, src, n in ((dq, qf, S), (dk, kf, Skv), (dv, vf, Skv)):
+        dst[: B * n, : H * 128].copy_(src.grad.transpose(1, 2).reshape(B * n, H * 128).to(dst.dtype))
 
 
 def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
