@@ -154,6 +154,11 @@ class GroupNormArgs(C.Structure):
                 ("eps", C.c_float), ("silu", i32), ("B", i32), ("HW", i32), ("C", i32), ("G", i32)]
 
 
+class RmsFullArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("g", vp), ("ldg", i64), ("y", vp), ("ldy", i64), ("weight", vp), ("cos", vp), ("sin", vp),
+                ("eps", C.c_float), ("S", i32), ("M", i64), ("C", i32), ("_pad", i32)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
 
@@ -162,7 +167,7 @@ EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AU
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
-            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs}
+            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs}
 
 
 def lib():

@@ -66,3 +66,66 @@ def scale_for_alpha(sd):
                     out[base + ".lora_up.weight"] = (up.float() * s).to(up.dtype)
                     out[k] = torch.tensor(float(down.shape[0]), dtype=sd[k].dtype)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ Wan2.1 key formats
+# The reference saves Wan adapters under the ORIGINAL Wan repository's module names and converts back on load
+# (toolkit/models/wan21/wan21.py:726-730 -> toolkit/models/wan21/wan_lora_convert.py).  Same mapping, written as one
+# table of path-component pairs (diffusers name, original name) applied on '.'-separated components.
+_WAN_BLOCK_PARTS = (("attn1", "self_attn"), ("attn2", "cross_attn"))
+_WAN_PROJ_PARTS = (("to_q", "q"), ("to_k", "k"), ("to_v", "v"), ("add_k_proj", "k_img"), ("add_v_proj", "v_img"))
+
+
+def wan_lora_to_original(sd):
+    """diffusers/PEFT keys `transformer.blocks.N.attn1.to_q.lora_A.weight` -> `diffusion_model.blocks.N.self_attn.q...`."""
+    fwd = dict(_WAN_BLOCK_PARTS + _WAN_PROJ_PARTS)
+    out = OrderedDict()
+    for key, v in sd.items():
+        parts = key.split(".")
+        if parts[0] == "transformer":
+            parts[0] = "diffusion_model"
+        res = []
+        i = 0
+        while i < len(parts):
+            p = parts[i]
+            if p == "to_out" and i + 1 < len(parts) and parts[i + 1] == "0":
+                res.append("o")
+                i += 2
+            elif p == "ffn" and parts[i + 1:i + 4] == ["net", "0", "proj"]:
+                res += ["ffn", "0"]
+                i += 4
+            elif p == "ffn" and parts[i + 1:i + 3] == ["net", "2"]:
+                res += ["ffn", "2"]
+                i += 3
+            else:
+                res.append(fwd.get(p, p))
+                i += 1
+        out[".".join(res)] = v
+    return out
+
+
+def wan_lora_to_diffusers(sd):
+    """Inverse of wan_lora_to_original (adapter files written by the reference or by the original Wan tooling)."""
+    back = {b: a for a, b in _WAN_BLOCK_PARTS + _WAN_PROJ_PARTS}
+    out = OrderedDict()
+    for key, v in sd.items():
+        parts = key.split(".")
+        if parts[0] == "diffusion_model":
+            parts[0] = "transformer"
+        res = []
+        i = 0
+        while i < len(parts):
+            p = parts[i]
+            if p == "o":
+                res += ["to_out", "0"]
+            elif p == "ffn" and i + 1 < len(parts) and parts[i + 1] == "0":
+                res += ["ffn", "net", "0", "proj"]
+                i += 1
+            elif p == "ffn" and i + 1 < len(parts) and parts[i + 1] == "2":
+                res += ["ffn", "net", "2"]
+                i += 1
+            else:
+                res.append(back.get(p, p))
+            i += 1
+        out[".".join(res)] = v
+    return out

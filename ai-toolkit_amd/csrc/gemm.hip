@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
           // y = bf16(linear out) saved (d_gate needs it); x_new = res + gate[b] * y
           uint2 yo;
           yo.x = pack2bf(v[0], v[1]); yo.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(p.aux_out + (long)m * p.ld_aux_out + nb) = yo;
+          if (p.aux_out) *reinterpret_cast<uint2*>(p.aux_out + (long)m * p.ld_aux_out + nb) = yo;
           uint2 rr = *reinterpret_cast<const uint2*>(p.aux_in + (long)m * p.ld_aux_in + nb);
           uint2 gg = *reinterpret_cast<const uint2*>(gate_row + nb);
           v[0] = bf2f(rr.x & 0xffff) + bf2f(gg.x & 0xffff) * bfround(v[0]);
@@ -411,7 +411,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_BIAS | AITK_EPI_BIAS_ROW)) && !a->bias) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_ADD_AUX) && !a->aux_in) return AITK_ERR_ARG;
-  if ((a->flags & (AITK_EPI_GELU | AITK_EPI_GATE_RES)) && !a->aux_out) return AITK_ERR_ARG;
+  if ((a->flags & AITK_EPI_GELU) && !a->aux_out) return AITK_ERR_ARG;  // GATE_RES: aux_out optional (only d_gate needs y)
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;

@@ -182,6 +182,7 @@ extern "C" int aitk_ln_mod_bwd(const AitkLnModBwdArgs* a, aitk_stream_t stream) 
 
 // ---------------------------------------------------------------- gate/residual backward
 // x_new = res + gate[b]*y :  dy = gate*dx_new ;  dgate[b][c] = sum_s dx_new*y      (dres = dx_new, same buffer)
+// y == NULL: only dy (the gate has no trainable ancestor)
 __global__ __launch_bounds__(256) void gate_bwd_kernel(AitkGateBwdArgs p) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -200,14 +201,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(AitkGateBwdArgs p) {
       const long m = mbase + r;
       float dv[8], yv[8], o[8];
       unpack8(*reinterpret_cast<const uint4*>(p.dx + m * p.ld_dx + c), dv);
-      unpack8(*reinterpret_cast<const uint4*>(p.y + m * p.ld_y + c), yv);
+      if (p.y) unpack8(*reinterpret_cast<const uint4*>(p.y + m * p.ld_y + c), yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         o[e] = g8[e] * dv[e];
-        acc[e] += dv[e] * yv[e];
+        if (p.y) acc[e] += dv[e] * yv[e];
       }
       *reinterpret_cast<uint4*>(p.dy + m * p.ld_dy + c) = pack8(o);
     }
+    if (!p.y) continue;  // no d_gate wanted (frozen modulation, Wan2.1)
     float* pp = p.partial + ((long)b * gridDim.x + blockIdx.x) * p.C + c;
     *reinterpret_cast<float4*>(pp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *reinterpret_cast<float4*>(pp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
@@ -379,6 +381,132 @@ extern "C" int aitk_qkv_post_bwd(const AitkQkvPostArgs* a, aitk_stream_t stream)
   const long npairs = (long)a->B * a->S_src * a->H;
   dim3 grid((unsigned)min((npairs + 15) / 16, (long)8192), a->njobs);
   hipLaunchKernelGGL(qkv_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ---------------------------------------------------------------- RMSNorm across heads (+ RoPE)  (Wan2.1 attention)
+// y = rope( bf16(bf16(x * rsqrt(mean_C(x^2) + eps)) * w) ),  C = H*128 <= 4096, one wave per token; rope optional.
+// Restates the q/k path of toolkit/models/wan21/wan_attn.py:32-54 (norm_q/norm_k = diffusers RMSNorm over the full
+// projection, then view_as_complex(x) * freqs on (2i, 2i+1) pairs; we rotate in fp32 instead of fp64).
+__global__ __launch_bounds__(256) void rms_full_fwd_kernel(AitkRmsFullArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * 4 + wave;
+  if (m >= p.M) return;
+  const bf16_t* xr = p.x + m * p.ldx;
+  float xv[MAXI][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c), xv[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
+  const int s_pos = (int)(m % p.S);
+  bf16_t* yr = p.y + m * p.ldy;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      float w[8], t[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.weight + c), w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = bfround(bfround(xv[i][e] * rstd) * w[e]);
+      if (p.cos) {
+        const float* cs = p.cos + (long)s_pos * 128 + (c & 127);
+        const float* sn = p.sin + (long)s_pos * 128 + (c & 127);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          o[e] = t[e] * cs[e] - t[e + 1] * sn[e];
+          o[e + 1] = t[e + 1] * cs[e + 1] + t[e] * sn[e + 1];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = t[e];
+      }
+      *reinterpret_cast<uint4*>(yr + c) = pack8(o);
+    }
+  }
+}
+// backward: g = grad wrt y, x = forward input -> dx
+__global__ __launch_bounds__(256) void rms_full_bwd_kernel(AitkRmsFullArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long m = (long)blockIdx.x * 4 + wave;
+  if (m >= p.M) return;
+  const bf16_t* xr = p.x + m * p.ldx;
+  const bf16_t* gr = p.g + m * p.ldg;
+  const int s_pos = (int)(m % p.S);
+  float xv[MAXI][8], dt[MAXI][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      float g[8], w[8];
+      unpack8(*reinterpret_cast<const uint4*>(xr + c), xv[i]);
+      unpack8(*reinterpret_cast<const uint4*>(gr + c), g);
+      unpack8(*reinterpret_cast<const uint4*>(p.weight + c), w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += xv[i][e] * xv[i][e];
+      if (p.cos) {
+        const float* cs = p.cos + (long)s_pos * 128 + (c & 127);
+        const float* sn = p.sin + (long)s_pos * 128 + (c & 127);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          dt[i][e] = (g[e] * cs[e] + g[e + 1] * sn[e + 1]) * w[e];
+          dt[i][e + 1] = (-g[e] * sn[e] + g[e + 1] * cs[e + 1]) * w[e + 1];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dt[i][e] = g[e] * w[e];
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)p.C + p.eps);
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += dt[i][e] * xv[i][e] * rstd;
+    }
+  }
+  dot = wave_sum(dot) / (float)p.C;
+  bf16_t* yr = p.y + m * p.ldy;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < p.C) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (dt[i][e] - xv[i][e] * rstd * dot);
+      *reinterpret_cast<uint4*>(yr + c) = pack8(o);
+    }
+  }
+}
+static int rms_full_check(const AitkRmsFullArgs* a) {
+  if (!a || a->M <= 0 || a->C <= 0 || (a->C % 128) || a->C > 64 * 8 * MAXI || a->S <= 0) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldy % 8)) return AITK_ERR_ALIGN;
+  if (!a->x || !a->y || !a->weight) return AITK_ERR_ARG;
+  return AITK_OK;
+}
+extern "C" int aitk_rms_full_fwd(const AitkRmsFullArgs* a, aitk_stream_t stream) {
+  int rc = rms_full_check(a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rms_full_fwd_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+extern "C" int aitk_rms_full_bwd(const AitkRmsFullArgs* a, aitk_stream_t stream) {
+  int rc = rms_full_check(a);
+  if (rc) return rc;
+  if (!a->g || (a->ldg % 8)) return AITK_ERR_ARG;
+  hipLaunchKernelGGL(rms_full_bwd_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

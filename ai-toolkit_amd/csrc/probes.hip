@@ -83,6 +83,7 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 13: return (int)sizeof(AitkAdamWArgs);
     case 14: return (int)sizeof(AitkShadowDesc);
     case 15: return (int)sizeof(AitkGroupNormArgs);
+    case 16: return (int)sizeof(AitkRmsFullArgs);
     default: return -1;
   }
 }

@@ -21,35 +21,9 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES = 2, 4, 8, 16
 
 
-# ============================================================================================ module tree (names only)
-class Linear(nn.Module):
-    """Frozen base projection: holds weight [out,in] / bias in the model dtype; `lora` is set by LoRAModule.apply_to."""
-
-    def __init__(self, in_features, out_features, bias=True, dtype=torch.bfloat16, device=None):
-        super().__init__()
-        self.in_features, self.out_features = in_features, out_features
-        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype, device=device), requires_grad=False)
-        self.bias = nn.Parameter(torch.zeros(out_features, dtype=dtype, device=device), requires_grad=False) if bias else None
-        object.__setattr__(self, "lora", None)
-        self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
-        self.qweight = self.qweight_t = self.wscale = None  # weight-only fp8 base (quantize_base_fp8)
-
-    def forward(self, x):
-        raise RuntimeError("fused path: Linear is executed inside FluxTransformer2DModel.forward")
-
-
-class RMSNormW(nn.Module):
-    def __init__(self, dim, dtype, device):
-        super().__init__()
-        self.eps = 1e-6
-        self.weight = nn.Parameter(torch.ones(dim, dtype=dtype, device=device), requires_grad=False)
-
-
-class _Holder(nn.Module):
-    pass
+from .graph import (EPI_ACCUM, EPI_DGELU, EPI_GATE_RES, EPI_GELU, FusedGraphBase, Linear, RMSNormW, _Holder)  # noqa: F401
 
 
 def _ada(dim, mult, dtype, device):
@@ -120,7 +94,7 @@ class _TextProj(nn.Module):
         self.linear_2 = Linear(dim, dim, True, dtype, device)
 
 
-class FluxTransformer2DModel(nn.Module):
+class FluxTransformer2DModel(FusedGraphBase):
     def __init__(self, in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128,
                  num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
                  axes_dims_rope=(16, 56, 56), dtype=torch.bfloat16, device=None, ops=None):
@@ -133,7 +107,6 @@ class FluxTransformer2DModel(nn.Module):
                            guidance_embeds=guidance_embeds, axes_dims_rope=tuple(axes_dims_rope))
         self.heads, self.dim = num_attention_heads, num_attention_heads * attention_head_dim
         self.in_channels = in_channels
-        self.dt = dtype
         d = self.dim
         tte = _Holder()
         tte.timestep_embedder = _TimestepEmbedding(256, d, dtype, device)
@@ -148,38 +121,10 @@ class FluxTransformer2DModel(nn.Module):
             [FluxSingleTransformerBlock(d, num_attention_heads, attention_head_dim, dtype, device) for _ in range(num_single_layers)])
         self.norm_out = _ada(d, 2, dtype, device)
         self.proj_out = Linear(d, in_channels, True, dtype, device)
-        self.ops = ops
-        object.__setattr__(self, "network", None)
+        self._init_graph(ops, dtype)  # grad_ready_hook pieces: 'single' then 'double'
         self._rope_cache = {}
-        self._prepared = False
-        self.ctx = None
-        self.grad_ready_hook = None  # called with 'single' / 'double' when that half of the adapter grads is final
 
     # ------------------------------------------------------------------ setup
-    def set_ops(self, ops):
-        self.ops = ops
-
-    def attach_network(self, network):
-        # not a registered sub-module: the adapter must stay out of the base model's state_dict / parameters()
-        object.__setattr__(self, "network", network)
-
-    def prepare(self):
-        """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""
-        need_t = []
-        for blk in self.transformer_blocks:
-            a = blk.attn
-            need_t += [a.to_q, a.to_k, a.to_v, a.add_q_proj, a.add_k_proj, a.add_v_proj, a.to_out[0], a.to_add_out,
-                       blk.ff.net[0].proj, blk.ff.net[2], blk.ff_context.net[0].proj, blk.ff_context.net[2]]
-        for blk in self.single_transformer_blocks:
-            a = blk.attn
-            need_t += [a.to_q, a.to_k, a.to_v, blk.proj_mlp, blk.proj_out]
-        need_t.append(self.proj_out)
-        for lin in need_t:
-            if lin.qweight is None:
-                lin.weight_t = lin.weight.data.t().contiguous()
-        self._prepared = True
-        return self
-
     def _token_linears(self):
         out = []
         for blk in self.transformer_blocks:
@@ -191,29 +136,15 @@ class FluxTransformer2DModel(nn.Module):
             out += [a.to_q, a.to_k, a.to_v, blk.proj_mlp, blk.proj_out]
         return out
 
-    @torch.no_grad()
-    def quantize_base_fp8(self, release_bf16=False):
-        """Weight-only fp8 (OCP e4m3, per-output-channel scale) for every token-GEMM Linear of the blocks — BASELINE config 5;
-        the reference does this with optimum-quanto qfloat8 / torchao Float8WeightOnly (toolkit/util/quantize.py:43-75,
-        toolkit/stable_diffusion_model.py:794-801).  Activations and the LoRA adapter stay bf16 / fp32.  The GEMM dequantises
-        bf16(fp8 * scale) while staging, forward from `qweight` [out,in], dgrad from `qweight_t` [in,out].  adaLN / embedder
-        projections (B rows, weight streaming) keep bf16 weights."""
-        for lin in self._token_linears():
-            w = lin.weight.data.float()
-            scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
-            q = (w / scale[:, None]).to(torch.float8_e4m3fn)
-            lin.qweight = q.view(torch.uint8).contiguous()
-            lin.qweight_t = q.view(torch.uint8).t().contiguous()
-            lin.wscale = scale
-            lin.weight_t = None
-            if release_bf16:
-                lin.weight.data = torch.empty(0, dtype=lin.weight.dtype, device=lin.weight.device)
-        self._prepared = True
-        self.is_quantized = True
-        return self
+    def _dgrad_linears(self):
+        return self._token_linears() + [self.proj_out]
 
-    def dequantized_weight(self, lin):
-        return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)
+    def grad_split_offset(self, network):
+        """Arena offset of the first single-stream adapter: [split, n) is final first during backward ('single')."""
+        for m in network.unet_loras:
+            if "single_transformer_blocks" in m.lora_name:
+                return m.off_down
+        return network.arena_p.numel()
 
     def rope_tables(self, img_ids, txt_ids):
         """FluxPosEmbed in float64 on the host, cached per (shape) bucket; fp32 [S, 128] cos/sin on device."""
@@ -228,7 +159,7 @@ class FluxTransformer2DModel(nn.Module):
             ang = torch.outer(ids[:, i], freqs)
             cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
             sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
-        dev = self.x_embedder.weight.device
+        dev = self._device()
         out = (torch.cat(cos_out, -1).contiguous().to(dev), torch.cat(sin_out, -1).contiguous().to(dev))
         self._rope_cache[key] = out
         return out
@@ -251,140 +182,6 @@ class FluxTransformer2DModel(nn.Module):
             a = blk.attn
             add((a.to_q, a.to_k, a.to_v, blk.proj_mlp))
         return groups
-
-    # ------------------------------------------------------------------ helpers
-    def _new(self, *shape, dtype=None):
-        return torch.empty(*shape, dtype=dtype or self.dt, device=self.x_embedder.weight.device)
-
-    def _lora_active(self, lin):
-        net = self.network
-        return (lin.lora is not None and net is not None and net.is_active and not net.is_merged_in
-                and net._multiplier != 0)
-
-    def _mult(self, rows_per_batch, B):
-        """per-sample multiplier vector (network.torch_multiplier, shape [1] or [B]) -> (tensor|None, rows_per_batch)."""
-        tm = self.network.torch_multiplier
-        if tm.numel() == 1:
-            mv = self.network._multiplier
-            if float(mv[0] if isinstance(mv, (list, tuple)) else mv) == 1.0:
-                return None, 0
-            tm = tm.expand(B).contiguous()
-        elif tm.numel() != B:
-            tm = tm.repeat_interleave(B // tm.numel()).contiguous()
-        return tm, rows_per_batch
-
-    def _group_down(self, lins, x, *, M, rows_per_batch, B):
-        """One skinny launch for every adapter of a same-input group: returns {id(lin): T view [M, r]} (or {} when the
-        group is not laid out adjacently / inactive)."""
-        if not all(self._lora_active(l) for l in lins):
-            return {}
-        grp = getattr(lins[0].lora, "group", None)
-        if grp is None or [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
-            return {}
-        Tcat = self._new(M, grp["R"])
-        mult, rpb = self._mult(rows_per_batch, B)
-        self.ops.lora_down(x, grp["sh_down"], Tcat, scale=grp["scale"], mult=mult, rows_per_batch=rpb, M=M)
-        out = {}
-        for l in lins:
-            c0 = grp["col"][id(l.lora)]
-            out[id(l)] = Tcat[:, c0:c0 + l.lora.lora_dim]
-        return out
-
-    def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-                 a_seg=None, c_seg=None, T=None):
-        """out = epi(x W^T + b + T B^T); returns T (saved for the weight gradient) or None.  A precomputed T (group
-        launch) may be passed in."""
-        ops = self.ops
-        kw = {}
-        if self._lora_active(lin):
-            lo = lin.lora
-            if T is None:
-                T = self._new(M, lo.lora_dim)
-                mult, rpb = self._mult(rows_per_batch, B)
-                ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
-            kw = dict(a2=T, b2=lo.sh_up)
-        else:
-            T = None
-        if lin.qweight is not None:
-            kw.update(b_scale=lin.wscale, b_scale_mode=1)
-        ops.gemm_nt(x, lin.qweight if lin.qweight is not None else lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out,
-                    aux_in=aux_in, gate=gate, gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
-        return T
-
-    def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
-        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None.
-        With dT_out (a column slice of a group's dT buffer) the lora_down gradient is left to _group_wgrad."""
-        if T is None:
-            return None
-        ops = self.ops
-        lo = lin.lora
-        dT = dT_out if dT_out is not None else self._new(M, lo.lora_dim)
-        mult, rpb = self._mult(rows_per_batch, B)
-        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
-        ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M)
-        if dT_out is None:
-            ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
-        return dT
-
-    def _group_bwd(self, lins, dys, Ts, x_in, dx, *, M, rows_per_batch, B, first_flags=0):
-        """Backward of several adapters+linears that read the same x_in: dx (+)= sum_j dy_j W_j + dT_j A_j, up-grads per
-        layer, ONE lora_down-gradient launch for the whole group when it is laid out adjacently."""
-        grp = getattr(lins[0].lora, "group", None) if all(t is not None for t in Ts) else None
-        if grp is not None and [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
-            grp = None
-        dTcat = self._new(M, grp["R"]) if grp is not None else None
-        for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
-            dT_out = None
-            if grp is not None:
-                c0 = grp["col"][id(lin.lora)]
-                dT_out = dTcat[:, c0:c0 + lin.lora.lora_dim]
-            dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dT_out)
-            self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
-        if grp is not None:
-            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M)
-
-    def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
-        """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""
-        kw = {}
-        if dT is not None:
-            shT = lin.lora.sh_downT
-            kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
-        wt_full = lin.qweight_t if lin.qweight is not None else lin.weight_t
-        if lin.qweight is not None:
-            kw.update(b_scale=lin.wscale, b_scale_mode=2)
-        wt = wt_full if w_rows is None else wt_full[w_rows[0]:w_rows[1]]
-        self.ops.gemm_nt(dy, wt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, **kw)
-
-    def _lin_bwd(self, lin, dy, T, x_in, dx, *, M, rows_per_batch, B, flags=0, aux_in=None, x_seg=None, dx_seg=None):
-        dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, x_seg=x_seg)
-        self._lin_dgrad(lin, dy, dT, dx, M=M, flags=flags, aux_in=aux_in, dx_seg=dx_seg)
-
-    def _ada_fwd(self, ada_lin, silu_temb, B):
-        """mod[B, k*dim] = linear(silu(temb)) (+LoRA): small-batch GEMV; returns (mod, T)."""
-        ops = self.ops
-        mod = self._new(B, ada_lin.out_features)
-        T = None
-        kw = {}
-        if self._lora_active(ada_lin):
-            lo = ada_lin.lora
-            T = self._new(B, lo.lora_dim)
-            mult, rpb = self._mult(1, B)
-            ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
-            kw = dict(t=T, bl=lo.sh_up)
-        ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, **kw)
-        return mod, T
-
-    def _ada_bwd(self, ada_lin, dmod, T, silu_temb, B):
-        """Only the adapter gradients: temb has no trainable ancestor, so no data gradient is propagated."""
-        if T is None:
-            return
-        ops = self.ops
-        lo = ada_lin.lora
-        dT = self._new(B, lo.lora_dim)
-        mult, rpb = self._mult(1, B)
-        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
-        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B)
-        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B)
 
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance,

@@ -189,14 +189,20 @@ def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, d
 
 
 def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
-    """dy = gate[b] * dx ; dgate[b] = sum_s dx * y."""
+    """dy = gate[b] * dx ; dgate[b] = sum_s dx * y  (y = dgate = None: dy only)."""
     a = _capi.GateBwdArgs()
-    a.ld_dx, a.ld_y, a.ld_dy, a.ld_gate = _row_major(dx, "dx"), _row_major(y, "y"), _row_major(dy, "dy"), _row_major(gate, "gate")
+    a.ld_dx, a.ld_dy, a.ld_gate = _row_major(dx, "dx"), _row_major(dy, "dy"), _row_major(gate, "gate")
     Cc = dx.shape[1]
+    a.dx, a.gate, a.dy = _ptr(dx), _ptr(gate), _ptr(dy)
+    a.S, a.B, a.C = S, B, Cc
+    if y is None:
+        assert dgate is None
+        a.ld_y = 8
+        _capi.check(_capi.lib().aitk_gate_bwd(C.byref(a), _capi.stream_ptr()), "aitk_gate_bwd")
+        return dy
     nchunk = (S + rows_per_block() - 1) // rows_per_block()
     part = workspace(B * nchunk * Cc * 4, dx.device, "colsum")
-    a.dx, a.y, a.gate, a.dy, a.partial = _ptr(dx), _ptr(y), _ptr(gate), _ptr(dy), _ptr(part)
-    a.S, a.B, a.C = S, B, Cc
+    a.y, a.ld_y, a.partial = _ptr(y), _row_major(y, "y"), _ptr(part)
     _capi.check(_capi.lib().aitk_gate_bwd(C.byref(a), _capi.stream_ptr()), "aitk_gate_bwd")
     colsum_finish(part, nchunk, B, 1, Cc, dgate)
     return dy
@@ -429,3 +435,26 @@ def latent_sample(moments, eps, out, *, scale, shift):
     _capi.check(_capi.lib().aitk_latent_sample(_ptr(moments), _row_major(moments, "moments"), _ptr(eps), _ptr(out), B, L, h * w,
                                                float(scale), float(shift), _capi.stream_ptr()), "aitk_latent_sample")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------- Wan2.1
+def _rms_full_args(x, weight, y, cos, sin, S, eps):
+    a = _capi.RmsFullArgs()
+    a.x, a.ldx, a.y, a.ldy = _ptr(x), _row_major(x, "x"), _ptr(y), _row_major(y, "y")
+    a.weight, a.cos, a.sin = _ptr(weight), _ptr(cos), _ptr(sin)
+    a.eps, a.S, a.M, a.C = eps, S, x.shape[0], x.shape[1]
+    return a
+
+
+def rms_full_fwd(x, weight, y, *, S, cos=None, sin=None, eps=1e-6):
+    """y = rope(RMSNorm_C(x) * weight): norm across all heads of a token (C = H*128), rope on (2i,2i+1) pairs per head."""
+    a = _rms_full_args(x, weight, y, cos, sin, S, eps)
+    _capi.check(_capi.lib().aitk_rms_full_fwd(C.byref(a), _capi.stream_ptr()), "aitk_rms_full_fwd")
+    return y
+
+
+def rms_full_bwd(g, x, weight, dx, *, S, cos=None, sin=None, eps=1e-6):
+    a = _rms_full_args(x, weight, dx, cos, sin, S, eps)
+    a.g, a.ldg = _ptr(g), _row_major(g, "g")
+    _capi.check(_capi.lib().aitk_rms_full_bwd(C.byref(a), _capi.stream_ptr()), "aitk_rms_full_bwd")
+    return dx

@@ -16,15 +16,17 @@ import torch
 from .flowmatch import FlowMatchTrainSchedule
 
 
-class FluxLoRATrainStep:
+class _LoRATrainStepBase:
+    """State and the model-independent tail of a step: gradient all-reduce pieces, clip + AdamW + EMA, shadow refresh."""
+
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
-                 seed=None):
+                 seed=None, schedule=None):
         self.model, self.network, self.ops = model, network, ops
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.timestep_type, self.guidance = timestep_type, guidance
-        self.schedule = FlowMatchTrainSchedule()
+        self.schedule = schedule or FlowMatchTrainSchedule()
         self.step_num = 0
         self.pg = process_group
         self.world = 1
@@ -44,12 +46,8 @@ class FluxLoRATrainStep:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         if ema_decay > 0 and network.arena_ema is None:
             network.arena_ema = network.arena_p.clone()
-        # arena split point: first single-stream adapter (its gradients are final first during backward)
-        self._split = network.arena_p.numel()
-        for m in network.unet_loras:
-            if "single_transformer_blocks" in m.lora_name:
-                self._split = m.off_down
-                break
+        # arena split point: adapters at [split, n) get their final gradients first during backward
+        self._split = model.grad_split_offset(network)
         model.grad_ready_hook = self._on_grads_ready if self.world > 1 else None
 
     # ------------------------------------------------------------------ DP
@@ -57,7 +55,7 @@ class FluxLoRATrainStep:
         import torch.distributed as dist
 
         g = self.network.arena_g
-        piece = g[self._split:] if which == "single" else g[: self._split]
+        piece = g[self._split:] if which in ("single", "late") else g[: self._split]
         if piece.numel() == 0:
             return
         self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
@@ -67,6 +65,33 @@ class FluxLoRATrainStep:
             w.wait()
         self._pending = []
 
+    def _loss_backward_update(self, pred, target, loss_weight):
+        """MSE loss + explicit backward (caller holds `with network`), then all-reduce / clip / AdamW / EMA."""
+        ops, model, net = self.ops, self.model, self.network
+        B = pred.shape[0]
+        dpred = torch.empty_like(pred)
+        if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
+            self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
+        ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight)
+        net.zero_grad_arena()
+        model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
+
+    def _optimizer_step(self):
+        ops, net = self.ops, self.network
+        self.step_num += 1
+        grad_scale = 1.0
+        if self.world > 1:
+            self._finish_allreduce()
+            grad_scale = 1.0 / self.world
+        ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
+                           max_norm=self.max_grad_norm, ema=net.arena_ema if self.ema_decay > 0 else None,
+                           ema_decay=self.ema_decay, grad_scale=grad_scale, norm_out=self.grad_norm)
+        net.refresh_shadows(ops)
+        return self.loss
+
+
+class FluxLoRATrainStep(_LoRATrainStepBase):
     # ------------------------------------------------------------------ one step
     def step(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None):
         """latents [B,16,H,W] (scaled VAE latents), prompt_embeds [B,512,4096], pooled_embeds [B,768].
@@ -91,23 +116,44 @@ class FluxLoRATrainStep:
         guidance = torch.full((B,), float(self.guidance), device=dev)
         with net:
             pred = model.forward_native(noisy, prompt_embeds, pooled_embeds, timesteps / 1000, img_ids, txt_ids, guidance)
-            dpred = torch.empty_like(pred)
-            if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
-                self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=dev)
-            ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight)
-            net.zero_grad_arena()
-            model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
-        self.step_num += 1
-        grad_scale = 1.0
-        if self.world > 1:
-            self._finish_allreduce()
-            grad_scale = 1.0 / self.world
-        ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
-                           beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
-                           max_norm=self.max_grad_norm, ema=net.arena_ema if self.ema_decay > 0 else None,
-                           ema_decay=self.ema_decay, grad_scale=grad_scale, norm_out=self.grad_norm)
-        net.refresh_shadows(ops)
-        return self.loss
+            self._loss_backward_update(pred, target, loss_weight)
+        return self._optimizer_step()
+
+
+class WanLoRATrainStep(_LoRATrainStepBase):
+    """Wan2.1 T2V LoRA step (BASELINE config 4).  Per step the reference runs the same trainer with the Wan model class:
+    flow-matching scheduler with static shift 3.0 (toolkit/models/wan21/wan21.py:80-84, 338-342), noisy latents
+    (1-t)x0 + t*noise, `self.model(hidden_states, timestep 0..1000, encoder_hidden_states)` (wan21.py:578-603), target
+    noise - latents (wan21.py:717-724), MSE, backward, clip, AdamW."""
+
+    def __init__(self, model, network, ops, **kw):
+        kw.setdefault("schedule", FlowMatchTrainSchedule(shift=3.0, use_dynamic_shifting=False))
+        super().__init__(model, network, ops, **kw)
+
+    def step(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None):
+        """latents [B,16,F,H,W] (normalised Wan-VAE latents), prompt_embeds [B,512,4096] (UMT5).  Returns the loss tensor."""
+        ops, model, net = self.ops, self.model, self.network
+        dt = model.dt
+        B, Cc, Fr, Hh, W = latents.shape
+        dev = latents.device
+        self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
+        if timesteps is None:
+            timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
+        timesteps = timesteps.float().contiguous()
+        if noise is None:
+            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32, generator=self.gen)
+        # frame-major copies ([B*F, C, H, W]) so the 2x2 pack kernel emits tokens in (frame, row, col) order
+        lat_f = latents.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
+        noi_f = noise.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
+        n_tok = (Hh // 2) * (W // 2)
+        noisy = torch.empty(B * Fr, n_tok, Cc * 4, dtype=dt, device=dev)
+        target = torch.empty_like(noisy)
+        ops.flow_noise_pack(lat_f, noi_f, timesteps.repeat_interleave(Fr).contiguous(), noisy, target)
+        grid = (Fr, Hh // 2, W // 2)
+        with net:
+            pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, prompt_embeds, grid)
+            self._loss_backward_update(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight)
+        return self._optimizer_step()
 
 
 def make_ids(Hh, W, n_txt, device):

@@ -279,6 +279,21 @@ int aitk_image_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t H, 
 int aitk_latent_sample(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L, int32_t hw,
                        float scale, float shift, aitk_stream_t stream);
 
+
+/* ---- RMSNorm across heads (weight [C], C = H*128) + optional rotary embedding, one row per token (Wan2.1 q/k path,
+ * toolkit/models/wan21/wan_attn.py:32-54).  fwd: y = rope(norm(x)); bwd: y = d/dx given g = d/dy and the forward input x.
+ * cos/sin [S,128] fp32 (NULL = no rope), row m uses position m % S. */
+typedef struct AitkRmsFullArgs {
+  const aitk_bf16* x; int64_t ldx;
+  const aitk_bf16* g; int64_t ldg;
+  aitk_bf16* y; int64_t ldy;
+  const aitk_bf16* weight;
+  const float* cos; const float* sin;
+  float eps; int32_t S; int64_t M; int32_t C, _pad;
+} AitkRmsFullArgs;
+int aitk_rms_full_fwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
+int aitk_rms_full_bwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
+
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);
 int aitk_probe_glds(const int32_t* src /*[1024]*/, int32_t* out /*[1024]*/, aitk_stream_t stream);

@@ -48,7 +48,7 @@ class RefLoRAModule(nn.Module):
 class RefLoRANetwork(nn.Module):
     """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
 
-    def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",)):
+    def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",)):
         super().__init__()
         self.is_active = False
         self.torch_multiplier = torch.tensor([float(multiplier)])
@@ -61,7 +61,7 @@ class RefLoRANetwork(nn.Module):
                     continue
                 clean = ".".join([x for x in ("transformer", name, child_name) if x])
                 lora_name = clean.replace(".", "$$")
-                if "transformer_blocks" not in lora_name:
+                if not any(b in clean for b in block_names):
                     continue
                 self.unet_loras.append(RefLoRAModule(lora_name, child, lora_dim, lora_dim, self))
         for lo in self.unet_loras:

@@ -69,9 +69,11 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
             F.gelu(u, approximate="tanh").sum().backward()
         v = v * u.grad
     if flags & EPI_GATE_RES:
-        aux_out[:M].copy_(v.to(aux_out.dtype))
+        y = v.to(out.dtype)
+        if aux_out is not None:
+            aux_out[:M].copy_(y)
         g = gate.float().repeat_interleave(gate_rows, 0)[:M]
-        v = aux_in[:M].float() + g * aux_out[:M].float()
+        v = aux_in[:M].float() + g * y.float()
     _seg_store(out, c_seg, M, v)
     return out
 
@@ -137,7 +139,8 @@ def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, d
 def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
     M = B * S
     d = dx[:M].float()
-    dgate.copy_((d * y[:M].float()).view(B, S, -1).sum(1).to(dgate.dtype))
+    if y is not None:
+        dgate.copy_((d * y[:M].float()).view(B, S, -1).sum(1).to(dgate.dtype))
     dy[:M].copy_((gate.float().repeat_interleave(S, 0) * d).to(dy.dtype))
     return dy
 
@@ -365,3 +368,33 @@ def latent_sample(moments, eps, out, *, scale, shift):
     z = mean + torch.exp(0.5 * logvar) * eps.view(B, L, h * w).transpose(1, 2)
     out.copy_((scale * (z - shift)).transpose(1, 2).reshape(B, L, h, w).to(out.dtype))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------- Wan2.1
+def _rms_full(x, weight, S, cos, sin, eps, round_dtype):
+    xf = x.float() if not x.requires_grad else x
+    t = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    if round_dtype is not None:
+        t = (t.to(round_dtype) * weight.to(round_dtype)).float()
+    else:
+        t = t * weight.float()
+    if cos is not None:
+        M, Cc = t.shape
+        H = Cc // 128
+        pos = torch.arange(M, device=t.device) % S
+        t = _rope(t.view(M, H, 128), cos[pos][:, None, :], sin[pos][:, None, :]).reshape(M, Cc)
+    return t
+
+
+def rms_full_fwd(x, weight, y, *, S, cos=None, sin=None, eps=1e-6):
+    """norm_q / norm_k (RMSNorm across heads) + rotary embedding (toolkit/models/wan21/wan_attn.py:36-54)."""
+    y.copy_(_rms_full(x, weight, S, cos, sin, eps, x.dtype).to(y.dtype))
+    return y
+
+
+def rms_full_bwd(g, x, weight, dx, *, S, cos=None, sin=None, eps=1e-6):
+    xx = x.float().detach().requires_grad_(True)
+    with torch.enable_grad():
+        _rms_full(xx, weight, S, cos, sin, eps, None).backward(g.float())
+    dx.copy_(xx.grad.to(dx.dtype))
+    return dx

@@ -118,6 +118,28 @@ def golden_flowmatch():
     print("flowmatch golden written")
 
 
+def golden_wan_lora_keys():
+    """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("wlc", "/root/reference/toolkit/models/wan21/wan_lora_convert.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    keys = []
+    for n in range(3):
+        for a in ("attn1", "attn2"):
+            for pr in ("to_q", "to_k", "to_v", "to_out.0", "add_k_proj", "add_v_proj"):
+                keys.append(f"transformer.blocks.{n}.{a}.{pr}")
+        keys += [f"transformer.blocks.{n}.ffn.net.0.proj", f"transformer.blocks.{n}.ffn.net.2"]
+    sd = {k + sfx: i for i, k in enumerate(keys) for sfx in (".lora_A.weight", ".lora_B.weight")}
+    orig = m.convert_to_original(sd)
+    assert list(m.convert_to_diffusers(orig)) == list(sd)
+    json.dump({"diffusers": list(sd), "original": list(orig)}, open(os.path.join(HERE, "wan_lora_keys.json"), "w"), indent=0)
+    print("wan lora keys golden written")
+
+
 if __name__ == "__main__":
     golden_lora()
     golden_flowmatch()
+    golden_wan_lora_keys()

@@ -35,3 +35,15 @@ def test_alpha_is_folded_into_lora_up():
           "lora_transformer_x.alpha": torch.tensor(2.0)}
     out = convert.scale_for_alpha(sd)
     assert torch.allclose(out["lora_transformer_x.lora_up.weight"], torch.full((6, 4), 0.5)) and float(out["lora_transformer_x.alpha"]) == 4.0
+
+
+def test_wan_key_conversion_matches_reference_converter_golden():
+    """tests/golden/wan_lora_keys.json was produced by the reference's toolkit/models/wan21/wan_lora_convert.py."""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wan_lora_keys.json")))
+    sd = {k: i for i, k in enumerate(gold["diffusers"])}
+    orig = convert.wan_lora_to_original(sd)
+    assert list(orig) == gold["original"]
+    assert list(convert.wan_lora_to_diffusers(orig)) == gold["diffusers"]
