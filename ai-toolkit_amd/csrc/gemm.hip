@@ -403,6 +403,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   }
 }
 
+// gemm8.hip: persistent 8-phase kernel for big bf16 problems (returns 1 when the shape is outside its contract)
+extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st);
+
 extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return AITK_ERR_SHAPE;
@@ -468,6 +471,15 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
+  // stage_mode: 0 VGPR-staged, 1 auto (8-phase persistent kernel when the problem is big, else LDS-DMA 2-barrier), 2 ring3,
+  //             4 force the 8-phase kernel, 5 force the 2-barrier LDS-DMA kernels (A/B reference)
+  if ((a->stage_mode == 1 && big) || a->stage_mode == 4) {
+    if (aitk_gemm8_try_launch(a, st) == AITK_OK) {
+      AITK_LAUNCH_CHECK();
+      return AITK_OK;
+    }
+  }
+  if (a->stage_mode >= 4) tmp.stage_mode = 1;
   if (a->stage_mode == 2) {
     static bool attr3 = false;
     if (!attr3) {

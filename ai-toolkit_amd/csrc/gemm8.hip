@@ -1,0 +1,482 @@
+// Persistent 8-phase bf16 MFMA GEMM with the LoRA K-slab (gfx950 / MI355X) — the big-problem path of aitk_gemm_nt.
+//
+//   C[M,N] = epi( A[M,K] * B[N,K]^T  +  A2[M,K2] * B2[N,K2]^T  + bias[N] )          (same contract as gemm.hip)
+//
+// One 512-thread workgroup per CU (2 x 4 waves, 256 x 256 x 64 tile, two 64-KiB LDS tile buffers + 32 KiB epilogue
+// scratch) walks output tiles blockIdx.x, +gridDim.x, ... in the XCD-grouped order.
+//
+// K loop ("8-phase" schedule of the CDNA4 guide §5, two K-tiles = 8 phases): a K-tile is four phases, one 64x32
+// C-quadrant per wave each (8 x v_mfma_f32_32x32x16_bf16).  A phase is
+//     [ds_read this quadrant's new fragments | stage ONE 16-KiB half-tile by LDS-DMA | counted vmcnt]  s_barrier
+//     [counted lgkmcnt per k-substep | 8 MFMA]                                                          s_barrier
+// and waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so on each SIMD one wave is in its
+// MFMA segment while its partner is in its load segment.
+//   phase j   reads (LDS)               computes     stages (K-tile, half)    waits (after staging)
+//     0       A0 rows(8) + B0 cols(4)   Q(0,0)       B1 of tile t+1           vmcnt(8) -> B1(t) landed   (read in j=1)
+//     1       B1 cols (4)               Q(0,1)       A1 of tile t+1           vmcnt(8) -> A1(t) landed   (read in j=2)
+//     2       A1 rows (8)               Q(1,1)       A0 of tile t+2           -
+//     3       -  (B0 kept in VGPRs)     Q(1,0)       B0 of tile t+2           vmcnt(8) -> A0,B0(t+1)     (read in next j=0)
+// RAW: a half-tile is read one phase after the vmcnt that retires it (plus the barrier in between).  WAR: it is re-staged
+// >= 2 phases after its last ds_read.  Every stage call issues exactly two DMAs per wave so the vmcnt immediates are
+// exact; vmcnt(8) = "everything but the last four half-tiles has landed" (>= 4 phases old).
+// The K-tile counter runs across output tiles: "tile t+1 / t+2" past the end of this output tile are the first K-tiles
+// of the workgroup's NEXT output tile, so its prologue loads fly during this tile's last phases and epilogue.
+//
+// LDS half-tiles are interleaved so a wave owns a contiguous 128 x 64 block of C: LDS A row R = half*128 + wr*64 + r
+// holds tile row wr*128 + half*64 + r; LDS B row R = half*128 + wc*32 + r holds tile column wc*64 + half*32 + r.
+// Rows are 128 B, 16-B chunks XOR-swizzled by (row>>1)&7 (conflict-free ds_read_b128), written lane-linearly by
+// global_load_lds_dwordx4 with the swizzle applied on the global source address.
+//
+// Epilogue: each 32x32 accumulator block goes through a wave-private 4-KiB LDS patch (fp32, swizzled) so that a lane ends
+// up with 8 consecutive columns of one row: bias / residual / gate / GELU are applied in fp32 exactly as in gemm.hip and
+// C, aux_out are written (aux_in, C read) with 16-byte accesses covering 64-B row segments.
+#include "common.h"
+#include "aitk_args.h"
+
+#define BK 64
+#define BM 256
+#define BN 256
+#define NT 512
+#define A_BYTES (BM * BK * 2)
+#define BUF_BYTES (2 * A_BYTES)
+#define EPI_OFF (2 * BUF_BYTES)
+
+template <int V>
+struct IC { static constexpr int value = V; };
+
+// ds_read_b128 the compiler does not see as an LDS access: lgkmcnt is counted by hand in the K loop (the waitcnt pass
+// otherwise puts lgkmcnt(0) in front of the first MFMA of every phase).
+template <int OFF>
+__device__ __forceinline__ void lds_read128(s16x8_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+
+__device__ __forceinline__ const bf16_t* seg_row8(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
+  if (seg_rows > 0) {
+    int s = m / seg_rows;
+    int w = m - s * seg_rows;
+    return base + (long)s * seg_stride + (long)w * ld;
+  }
+  return base + (long)m * ld;
+}
+
+__device__ __forceinline__ void unpack8f(uint4 u, float* f) {
+  f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
+  f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8f(const float* f) {
+  uint4 o;
+  o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+  return o;
+}
+
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int ntiles = tiles_m * tiles_n;
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
+  const int nsteps = nk1 + nk2;   // >= 2 (launcher)
+  const int nfast = p.K / BK;     // K-tiles [0, nfast) are full 64-wide tiles of the base segment
+
+  // ---- staging geometry: thread owns physical 16-B chunk pc of LDS rows srow + 64 i (i = 0..3) of A and of B
+  // (recomputed from an opaque copy of tid at each use: these are needed once per output tile, and values the compiler
+  //  would otherwise hoist out of the tile loop cost VGPRs the K loop does not have)
+  auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+#define SROW(t_) ((t_) >> 3)
+#define CC(t_) (((t_) & 7) ^ ((SROW(t_) >> 1) & 7))  /* logical chunk at physical slot tid&7 (same key for rows srow + 64 i) */
+  // kernel arguments re-read through an opaque pointer where they are needed rarely (K tails, epilogue): keeping all ~45
+  // dwords of AitkGemmArgs live in SGPRs across the K loop spills
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) AitkGemmArgs* KArgsPtr;
+#else
+  typedef const AitkGemmArgs* KArgsPtr;
+#endif
+  auto kargs = [&]() -> KArgsPtr {
+#if defined(__HIP_DEVICE_COMPILE__)
+    KArgsPtr q = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // constant address space: scalar loads
+    asm volatile("" : "+s"(q));
+    return q;
+#else
+    return &p;
+#endif
+  };
+  unsigned va[4], vb[4];  // byte offsets of this thread's chunk (K-tile 0) in A / B for the tile being STAGED
+  int om0 = 0, on0 = 0;   // origin of that tile (the K-tail / LoRA-slab path recomputes its row offsets from it)
+  int m0 = 0, n0 = 0;
+  auto tile_origin = [&](int v, int& tm0, int& tn0) {
+    const int lid = xcd_remap(v, ntiles);
+    const int GROUP = 8;
+    const int group_sz = GROUP * tiles_n;
+    const int gid = lid / group_sz;
+    const int first_m = gid * GROUP;
+    const int gm = min(tiles_m - first_m, GROUP);
+    tm0 = (first_m + (lid % group_sz) % gm) * BM;
+    tn0 = ((lid % group_sz) / gm) * BN;
+  };
+  auto a_row = [&](int i, int srow) { return min(om0 + (i & 1) * 128 + (i >> 1) * 64 + srow, p.M - 1); };
+  auto b_row = [&](int i, int srow) { return min(on0 + ((srow >> 5) + 2 * (i & 1)) * 64 + (i >> 1) * 32 + (srow & 31), p.N - 1); };
+  auto set_offsets = [&](int tm0, int tn0) {
+    om0 = tm0;
+    on0 = tn0;
+    KArgsPtr q = kargs();
+    const int t_ = opaque_tid();
+    const int srow = SROW(t_), cc = CC(t_);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      va[i] = ((unsigned)(seg_row8(q->A, q->lda, q->a_seg_rows, q->a_seg_stride, a_row(i, srow)) - q->A) + cc * 8) * 2;
+      vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * 8) * 2;
+    }
+  };
+
+  // Raw buffer descriptors (stride 0, 2 GiB window): LDS-DMA through buffer_load ... lds takes base (SGPRs) + 32-bit lane
+  // offset (VGPR) + K offset (SGPR), and a lane whose offset is outside the window reads ZEROS — K tails, the narrow LoRA
+  // slab and dead tiles need no zero page and no per-lane 64-bit pointers.
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  auto make_srd = [&](const void* ptr) {
+    const unsigned long long a = (unsigned long long)ptr;
+    v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+    r.z = (int)0x80000000u;
+    r.w = 0x00020000;
+    return r;
+  };
+  const v4i srdA = make_srd(p.A), srdB = make_srd(p.B);
+  const unsigned OOB = 0x80000000u;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  auto dma = [&](unsigned ldst, unsigned voff, const v4i& srd, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(ldst), "v"(voff), "s"(srd), "s"(soff) : "memory");
+  };
+
+  // one 16-KiB half-tile (opnd 0 = A, 1 = B; half 0/1) of K-tile kt of the tile whose offsets are loaded, into tile
+  // buffer `buf`; dead = no such tile (past the workgroup's last output tile).  Always exactly two DMAs per wave.
+  auto stage_half = [&](int kt, int buf, int opnd, int half, bool dead) {
+    const unsigned ldst = lds_wave + buf * BUF_BYTES + (opnd ? A_BYTES : 0) + half * (2 * NT * 16);
+    if (!dead && kt < nfast) {  // full base-segment K-tile: no VALU at all
+      const unsigned soff = (unsigned)kt * (BK * 2);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * half + ii;
+        dma(ldst + ii * (NT * 16), opnd ? vb[i] : va[i], opnd ? srdB : srdA, soff);
+      }
+      return;
+    }
+    // K tail of the base segment / LoRA slab / dead tile: lanes whose chunk lies beyond the segment read zeros
+    const int t_ = opaque_tid();
+    const int srow = SROW(t_), cc = CC(t_);
+    const bool second = kt >= nk1;
+    const int k0 = (second ? kt - nk1 : kt) * BK;
+    const int Kseg = second ? p.K2 : p.K;
+    const bool kvalid = !dead && (k0 + cc * 8) < Kseg;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = 2 * half + ii;
+      unsigned voff;
+      if (second) voff = opnd ? ((unsigned)((long)b_row(i, srow) * p.ldb2) + cc * 8) * 2 : ((unsigned)((long)a_row(i, srow) * p.lda2) + cc * 8) * 2;
+      else voff = opnd ? vb[i] : va[i];
+      if (!kvalid) voff = OOB;
+      if (second) dma(ldst + ii * (NT * 16), voff, make_srd(opnd ? (const void*)p.B2 : (const void*)p.A2), (unsigned)k0 * 2);
+      else dma(ldst + ii * (NT * 16), voff, opnd ? srdB : srdA, (unsigned)k0 * 2);
+    }
+  };
+
+  // ---- fragment read addresses (current tile buffer; bit 16 toggles per K-tile); other quadrant +16 KiB, B +32 KiB
+  unsigned aaddr[4], baddr[4];  // (rows +32 keep the swizzle key: the second 32-row block is an immediate +4 KiB)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int rowa = wr * 64 + l31;
+    aaddr[ks] = lds0 + rowa * 128 + (((ks * 2 + h) ^ ((rowa >> 1) & 7)) << 4);
+    const int row = wc * 32 + l31;
+    baddr[ks] = lds0 + row * 128 + (((ks * 2 + h) ^ ((row >> 1) & 7)) << 4);
+  }
+  s16x8_t af[2][4], b0f[4], b1f[4];
+  f32x16_t acc[4][2];
+
+  auto read_frags = [&](auto qm_c, auto qn_c, s16x8_t (*bf)[4]) {  // ks-major: b[ks], a0[ks], a1[ks]
+    constexpr int qm = decltype(qm_c)::value, qn = decltype(qn_c)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (qn >= 0) lds_read128<A_BYTES + (qn > 0 ? 128 * 128 : 0)>((*bf)[ks], baddr[ks]);
+      if constexpr (qm >= 0) {
+        lds_read128<(qm > 0 ? 128 * 128 : 0)>(af[0][ks], aaddr[ks]);
+        lds_read128<(qm > 0 ? 128 * 128 : 0) + 32 * 128>(af[1][ks], aaddr[ks]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_lgkm = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+    }
+  };
+  // per_ks = fragment reads this phase issued per ks group (3: b+a0+a1, 2: a0+a1, 1: b, 0: none)
+  auto mma_quadrant = [&](int qm, int qn, const s16x8_t (&bf)[4], int per_ks) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (per_ks > 0) wait_lgkm(per_ks * (3 - ks));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) acc[qm * 2 + mm][qn] = mfma32(bf[ks], af[mm][ks], acc[qm * 2 + mm][qn]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#define VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  // ---- first output tile: offsets + the six prologue half-tiles (K-tile 0: A0 B0 B1 A1, K-tile 1: A0 B0)
+  int vt = blockIdx.x;
+  tile_origin(vt, m0, n0);
+  set_offsets(m0, n0);
+  int gk = 0;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
+  stage_half(0, 0, 0, 0, false);
+  stage_half(0, 0, 1, 0, false);
+  stage_half(0, 0, 1, 1, false);
+  stage_half(0, 0, 0, 1, false);
+  stage_half(1, 1, 0, 0, false);
+  stage_half(1, 1, 1, 0, false);
+  bool first = true;
+
+  while (true) {
+    const int vnext = vt + gridDim.x;
+    const bool has_next = vnext < ntiles;
+    int m0n = 0, n0n = 0;
+    if (has_next) tile_origin(vnext, m0n, n0n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (first) VMCNT8();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // prefetched K-tiles + this wave's epilogue traffic
+    first = false;
+    BAR();
+    if (wr == 1) BAR();  // second wave of every SIMD runs one barrier behind
+    // Steady part: K-tiles t+1, t+2 are full base-segment tiles of THIS output tile — straight-line fast staging, no
+    // branches.  Tail part (last <= 2 + LoRA-slab iterations): K tail, slab, and the next output tile's first K-tiles.
+    auto stage_fast = [&](int kt, unsigned ldst_buf, int opnd, int half) {
+      const unsigned soff = (unsigned)kt * (BK * 2);
+      const unsigned ldst = ldst_buf + (opnd ? A_BYTES : 0) + half * (2 * NT * 16);
+      dma(ldst, opnd ? vb[2 * half] : va[2 * half], opnd ? srdB : srdA, soff);
+      dma(ldst + NT * 16, opnd ? vb[2 * half + 1] : va[2 * half + 1], opnd ? srdB : srdA, soff);
+    };
+    auto flip = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        aaddr[ks] ^= BUF_BYTES;
+        baddr[ks] ^= BUF_BYTES;
+      }
+    };
+    const int nsteady = min(nfast, nsteps) - 2;  // iterations t < nsteady stage only fast tiles (t + 2 < nfast)
+    int t = 0;
+    for (; t < nsteady; ++t) {
+      const unsigned lb1 = lds_wave + ((gk + t + 1) & 1) * BUF_BYTES, lb2 = lds_wave + ((gk + t) & 1) * BUF_BYTES;
+      read_frags(IC<0>{}, IC<0>{}, &b0f);
+      stage_fast(t + 1, lb1, 1, 1);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 0, b0f, 3);
+      BAR();
+      read_frags(IC<-1>{}, IC<1>{}, &b1f);
+      stage_fast(t + 1, lb1, 0, 1);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 1, b1f, 1);
+      BAR();
+      read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
+      stage_fast(t + 2, lb2, 0, 0);
+      BAR();
+      mma_quadrant(1, 1, b1f, 2);
+      BAR();
+      stage_fast(t + 2, lb2, 1, 0);
+      VMCNT8();
+      BAR();
+      mma_quadrant(1, 0, b0f, 0);
+      flip();
+      BAR();
+    }
+    bool switched = false;  // offsets already describe the NEXT output tile
+    for (; t < nsteps; ++t) {
+      // K-tiles t+1 / t+2 past this output tile are K-tiles 0 / 1 of the next one (or dead)
+      const int t1 = t + 1, t2 = t + 2;
+      const bool n1 = t1 >= nsteps, n2 = t2 >= nsteps;
+      const int k1 = n1 ? t1 - nsteps : t1, k2 = n2 ? t2 - nsteps : t2;
+      const int buf1 = (gk + t1) & 1, buf2 = (gk + t2) & 1;
+      // phase 0
+      read_frags(IC<0>{}, IC<0>{}, &b0f);
+      stage_half(k1, buf1, 1, 1, n1 && !has_next);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 0, b0f, 3);
+      BAR();
+      // phase 1
+      read_frags(IC<-1>{}, IC<1>{}, &b1f);
+      stage_half(k1, buf1, 0, 1, n1 && !has_next);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 1, b1f, 1);
+      BAR();
+      // phase 2
+      read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
+      if (n2 && !switched) {  // every staging from here on belongs to the next output tile
+        if (has_next) set_offsets(m0n, n0n);
+        switched = true;
+      }
+      stage_half(k2, buf2, 0, 0, n2 && !has_next);
+      BAR();
+      mma_quadrant(1, 1, b1f, 2);
+      BAR();
+      // phase 3
+      stage_half(k2, buf2, 1, 0, n2 && !has_next);
+      VMCNT8();
+      BAR();
+      mma_quadrant(1, 0, b0f, 0);
+      flip();
+      BAR();
+    }
+    if (wr == 0) BAR();  // pair the extra barrier of the second group
+    gk += nsteps;
+
+    // ---------------- epilogue (tile m0, n0; wave block rows wr*128.., cols wc*64..) ----------------
+#ifdef AITK_ABL_NOEPI
+    if (p.K == 7)
+#endif
+    {
+      KArgsPtr q = kargs();
+      const int flags = q->flags;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));  // keep the epilogue's lane geometry out of the K loop's live set
+      char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
+      const int r_w = ln & 31, h = ln >> 5;       // write side: MFMA layout, lane owns row l31, 4 columns per (g, h)
+      const int rr = ln >> 2, c4 = ln & 3;        // read side: 16 rows x 4 lanes, lane owns 8 columns c4*8..
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wc * 64 + ni * 32 + c4 * 8;
+        const bool ncol = n < q->N;
+        float bias8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+        if ((flags & AITK_EPI_BIAS) && ncol) unpack8f(*reinterpret_cast<const uint4*>(q->bias + n), bias8);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          // acc block -> wave-private patch [32 rows][32 fp32], 16-B chunk (2g+h) swizzled by row&7
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4_t v4 = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(patch + r_w * 128 + (((2 * g + h) ^ (r_w & 7)) << 4)) = v4;
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same-wave LDS ops execute in order, no barrier needed
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int r = it * 16 + rr;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4) ^ (r & 7)) << 4));
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4 + 1) ^ (r & 7)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const int m = m0 + wr * 128 + mi * 32 + r;
+            if (m < q->M && ncol) {
+              bf16_t* crow = const_cast<bf16_t*>(seg_row8(q->C, q->ldc, q->c_seg_rows, q->c_seg_stride, m)) + n;
+              if (flags & AITK_EPI_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+              }
+              if (flags & AITK_EPI_BIAS_ROW) {
+                const float br = bf2f(q->bias[m]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += br;
+              }
+              if (flags & AITK_EPI_ADD_AUX) {
+                float a8[8];
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), a8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += a8[e];
+              }
+              if (flags & AITK_EPI_ACCUM) {
+                float c8[8];
+                unpack8f(*reinterpret_cast<const uint4*>(crow), c8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += c8[e];
+              }
+              if (flags & AITK_EPI_GELU) {
+                // u = bf16(pre-activation) is saved for backward; h = gelu_tanh(u) (torch evaluates GELU on the bf16 value)
+                *reinterpret_cast<uint4*>(q->aux_out + (long)m * q->ld_aux_out + n) = pack8f(v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(bfround(v[e]));
+              }
+              if (flags & AITK_EPI_DGELU) {
+                float u8[8];
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), u8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad_f(u8[e]);
+              }
+              if (flags & AITK_EPI_GATE_RES) {
+                // y = bf16(linear out) saved when asked (d_gate needs it); x_new = res + gate[b] * y
+                if (q->aux_out) *reinterpret_cast<uint4*>(q->aux_out + (long)m * q->ld_aux_out + n) = pack8f(v);
+                float r8[8], g8[8];
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), r8);
+                unpack8f(*reinterpret_cast<const uint4*>(q->gate + (long)(m / q->gate_rows) * q->ld_gate + n), g8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = r8[e] + g8[e] * bfround(v[e]);
+              }
+              *reinterpret_cast<uint4*>(crow) = pack8f(v);
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // patch reads retired before the next block overwrites it
+        }
+      }
+    }
+    if (!has_next) break;
+    vt = vnext;
+    m0 = m0n;
+    n0 = n0n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef VMCNT8
+#undef SROW
+#undef CC
+#undef BAR
+}
+
+// Called by aitk_gemm_nt (gemm.hip) for big bf16 problems.  Returns AITK_OK after launching, or 1 when the shape is
+// outside this kernel's contract (caller falls back to the 2-barrier kernels).
+extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
+  if (a->conv_mode || a->b_scale_mode) return 1;
+  if ((a->K % 16) || (a->K2 % 16) || (a->N % 8) || (a->ldc % 8)) return 1;
+  const int nsteps = (a->K + BK - 1) / BK + (a->K2 > 0 ? (a->K2 + BK - 1) / BK : 0);
+  if (nsteps < 2) return 1;
+  if ((a->flags & (AITK_EPI_ADD_AUX | AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && (a->ld_aux_in % 8)) return 1;
+  if ((a->flags & AITK_EPI_GELU) && (a->ld_aux_out % 8)) return 1;
+  if ((a->flags & AITK_EPI_GATE_RES) && ((a->ld_gate % 8) || (a->aux_out && (a->ld_aux_out % 8)))) return 1;
+  if ((a->flags & AITK_EPI_BIAS) && ((uintptr_t)a->bias & 15)) return 1;
+  if (((uintptr_t)a->aux_in | (uintptr_t)a->aux_out | (uintptr_t)a->gate | (uintptr_t)a->C) & 15) return 1;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EPI_OFF + 32768) != hipSuccess) {
+      n_cu = 0;
+      return 1;
+    }
+  }
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  return AITK_OK;
+}
