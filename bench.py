@@ -65,7 +65,7 @@ def gemm_roofline(step_fn, ops_mod):
         e0.record()
         r = orig(a, b, out, **kw)
         e1.record()
-        recs.append((e0, e1, 2.0 * M * N * (K + K2)))
+        recs.append((e0, e1, 2.0 * M * N * (K + K2), (M, N, K, K2, kw.get("flags", 0))))
         return r
 
     ops_mod.gemm_nt = timed
@@ -74,10 +74,18 @@ def gemm_roofline(step_fn, ops_mod):
         torch.cuda.synchronize()
     finally:
         ops_mod.gemm_nt = orig
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-    fl = sum(f for _, _, f in recs)
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+    fl = sum(f for _, _, f, _ in recs)
+    by_shape = {}
+    for e0, e1, f, key in recs:
+        d = by_shape.setdefault(key, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+        d[2] += f
+    census = sorted(({"M": k[0], "N": k[1], "K": k[2], "K2": k[3], "flags": k[4], "calls": v[0], "ms": round(v[1], 2),
+                      "tflops": round(v[2] / v[1] / 1e9, 1)} for k, v in by_shape.items()), key=lambda r: -r["ms"])
     return {"launches": len(recs), "gemm_ms_per_step": ms, "gemm_flop_per_step": fl, "avg_launch_us": 1e3 * ms / max(1, len(recs)),
-            "tflops": fl / ms / 1e9 if ms > 0 else 0.0}
+            "tflops": fl / ms / 1e9 if ms > 0 else 0.0, "census": census}
 
 
 def cpu_baseline():
@@ -187,7 +195,11 @@ def main():
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
     if rank == 0:
         if rf is not None:
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<1> (LoRA-fused bf16 GEMM, all launches of one step)",
+            if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
+                with open(os.environ["AITK_GEMM_CENSUS"], "w") as fh:
+                    json.dump(rf["census"], fh, indent=0)
+            out["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt: gemm_nt_8phase_kernel (big problems) + gemm_nt_kernel<1,128,128> "
+                                                         "(LoRA-fused bf16 GEMM, all launches of one step)",
                                "achieved": rf["tflops"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": rf["tflops"] / PEAK_BF16,
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
