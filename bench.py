@@ -203,6 +203,14 @@ def main():
                                "achieved": rf["tflops"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": rf["tflops"] / PEAK_BF16,
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
+            # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+            # WRITE_SIZE, profiles/r01_pmc_v2/summary.json) for the dominant shape 18432x3072x3072 (+r16 slab)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")
+            if os.path.exists(pmc):
+                g8 = json.load(open(pmc))["gemm_nt_8phase_kernel"]
+                out["roofline"]["traffic"] = g8["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = ("PMC, launch 18432x3072x3072+r16: memory-side bytes incl. Infinity-Cache hits; "
+                                                   f"algorithmic {g8['algorithmic_read_bytes'] + g8['algorithmic_write_bytes']} B")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     if world > 1:
