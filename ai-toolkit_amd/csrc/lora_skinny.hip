@@ -104,13 +104,110 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// lora_down, K % 32 == 0 (every shape of the hot path): v_mfma_f32_16x16x32_bf16 so one P fragment (16 ranks x 32 k) serves
+// TWO 16-row blocks of X — a third of the load instructions fetch the (L2-resident, WG-redundant) projection instead of half —
+// each lane's loads are 16 B of a 64-B row segment, and 8 k-steps (24+ loads per lane) are in flight before the first MFMA.
+// One workgroup = 32 rows, wave w contracts K-quarter w; partials combined through LDS in a fixed order.
+// RB = number of 16-wide rank blocks (R <= 16*RB <= 64).
+// ------------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * RB * 2 * 4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  const bf16_t* xrow[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+    xrow[blk] = seg_row2(p.X, p.ldx, p.x_seg_rows, p.x_seg_stride, min(m0 + blk * 16 + i16, p.M - 1)) + 8 * g;
+  const bf16_t* prow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 16 + i16, p.R - 1) * p.ldp + 8 * g;
+  f32x4_t acc[RB][2];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int ksteps = p.K / 32;
+  const int kbeg = (ksteps * wave) / 4, kend = (ksteps * (wave + 1)) / 4;
+  constexpr int U = RB <= 2 ? 8 : 4;  // k-steps in flight
+  int ks = kbeg;
+  for (; ks + U <= kend; ks += U) {
+    s16x8_t xa[U][2], pa[U][RB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (ks + u) * 32;
+      xa[u][0] = *reinterpret_cast<const s16x8_t*>(xrow[0] + k);
+      xa[u][1] = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) pa[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first MFMA waits on one
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);  // D rows = rank, cols = x row
+        acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
+      }
+  }
+  for (; ks < kend; ++ks) {
+    const int k = ks * 32;
+    const s16x8_t x0 = *reinterpret_cast<const s16x8_t*>(xrow[0] + k), x1 = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
+      acc[rb][0] = mfma16(pf, x0, acc[rb][0]);
+      acc[rb][1] = mfma16(pf, x1, acc[rb][1]);
+    }
+  }
+  // partials -> LDS [wave][rb][blk][reg][lane]; wave w then finishes the (rb, blk) pairs with (rb*2+blk) % 4 == w
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * RB + rb) * 2 + blk) * 4 + r) * 64 + lane] = acc[rb][blk][r];
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      if (((rb * 2 + blk) & 3) != wave) continue;
+      const int m = m0 + blk * 16 + i16;
+      float c = p.scale;
+      if (p.mult) c *= p.mult[min(m, p.M - 1) / p.rows_per_batch];
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
+        v[r] = s * c;
+      }
+      const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
+      if (m < p.M && rr < p.R) {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p.T + (long)m * p.ldt + rr) = o;
+      }
+    }
+}
+
 extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if (!a || a->M <= 0 || a->K <= 0 || a->R <= 0) return AITK_ERR_SHAPE;
   if ((a->K % 16) || (a->R % 4) || a->R > 64) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ldp % 8) || (a->ldt % 4)) return AITK_ERR_ALIGN;
   if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
   const int grid = (a->M + 31) / 32;
-  if (a->R <= 32)
+  if (a->K % 32 == 0) {
+    if (a->R <= 16) hipLaunchKernelGGL(lora_down16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 32) hipLaunchKernelGGL(lora_down16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 48) hipLaunchKernelGGL(lora_down16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(lora_down16_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  } else if (a->R <= 32)
     hipLaunchKernelGGL(lora_down_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else
     hipLaunchKernelGGL(lora_down_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
@@ -124,7 +221,7 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
 // ds_read_b64_tr_b16 (the contraction index is the tile row).  Chunk partials go to `partial`
 // [nchunks][R][L] fp32; aitk_lora_wgrad_finish adds them (deterministic order) into the gradient arena.
 // ------------------------------------------------------------------------------------------------------------
-#define WG_MC 256
+#define WG_MC 256  /* minimum rows per chunk (workspace sizing); big problems use 512 (fewer partials to reduce) */
 #define WG_LT 128
 #define WG_GPITCH 144  // elements (288 B): 4 consecutive rows land on disjoint bank octets for the tr reads
 #define WG_SPITCH 72   // elements (144 B), R <= 64
@@ -146,13 +243,13 @@ __device__ __forceinline__ s16x8_t load_frag_tr(const bf16_t* tile, int pitch, i
 }
 
 template <int RB16>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p) {
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, int mc) {
   __shared__ __attribute__((aligned(16))) bf16_t gt[64 * WG_GPITCH];
   __shared__ __attribute__((aligned(16))) bf16_t st[64 * WG_SPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l0 = blockIdx.x * WG_LT;
-  const int mbeg = blockIdx.y * WG_MC;
-  const int mend = min(p.M, mbeg + WG_MC);
+  const int mbeg = blockIdx.y * mc;
+  const int mend = min(p.M, mbeg + mc);
 
   f32x4_t acc[RB16][2];
 #pragma unroll
@@ -162,29 +259,45 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
-  for (int ms = mbeg; ms < mend; ms += 64) {
-    // stage G: 64 rows x 128 cols = 1024 16-B chunks, 4 per thread; rows beyond M / cols beyond L are zero
+  // Register-prefetched staging: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and written to
+  // LDS after them, so a workgroup overlaps its own HBM latency with its compute (before: load -> write -> sync -> compute).
+  const int chunks_per_row = p.R / 8;  // S: 64 rows x R cols = 64 * R/8 16-B chunks, <= 2 per thread
+  uint4 rg[4], rs[2];
+  auto load_regs = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + 256 * i;
       const int row = q >> 4, ch = q & 15;
       const int m = ms + row, col = l0 + ch * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < mend && col < p.L) v = *reinterpret_cast<const uint4*>(seg_row2(p.G, p.ldg, p.g_seg_rows, p.g_seg_stride, m) + col);
-      *reinterpret_cast<uint4*>(gt + row * WG_GPITCH + ch * 8) = v;
+      rg[i] = make_uint4(0, 0, 0, 0);  // rows beyond M / cols beyond L are zero
+      if (m < mend && col < p.L) rg[i] = *reinterpret_cast<const uint4*>(seg_row2(p.G, p.ldg, p.g_seg_rows, p.g_seg_stride, m) + col);
     }
-    // stage S: 64 rows x R cols (R/8 chunks per row)
-    {
-      const int chunks_per_row = p.R / 8;
-      for (int q = tid; q < 64 * chunks_per_row; q += 256) {
-        const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
-        const int m = ms + row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < mend) v = *reinterpret_cast<const uint4*>(p.S + (long)m * p.lds + ch * 8);
-        *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = v;
-      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
+      rs[i] = make_uint4(0, 0, 0, 0);
+      if (q < 64 * chunks_per_row && ms + row < mend) rs[i] = *reinterpret_cast<const uint4*>(p.S + (long)(ms + row) * p.lds + ch * 8);
     }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      *reinterpret_cast<uint4*>(gt + (q >> 4) * WG_GPITCH + (q & 15) * 8) = rg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
+      if (q < 64 * chunks_per_row) *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = rs[i];
+    }
+  };
+  load_regs(mbeg);
+  for (int ms = mbeg; ms < mend; ms += 64) {
+    write_lds();
     __syncthreads();
+    if (ms + 64 < mend) load_regs(ms + 64);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {  // two 32-row contraction steps
       s16x8_t bfr[2];
@@ -235,14 +348,15 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
   if (!a->partial || !a->out) return AITK_ERR_ARG;
-  const int nchunks = (a->M + WG_MC - 1) / WG_MC;
+  const int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
+  const int nchunks = (a->M + mc - 1) / mc;
   dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
   hipStream_t s = (hipStream_t)stream;
   switch (a->R / 16) {
-    case 1: hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, s, *a); break;
-    case 2: hipLaunchKernelGGL(lora_wgrad_kernel<2>, grid, dim3(256), 0, s, *a); break;
-    case 3: hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, s, *a); break;
-    default: hipLaunchKernelGGL(lora_wgrad_kernel<4>, grid, dim3(256), 0, s, *a); break;
+    case 1: hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, s, *a, mc); break;
+    case 2: hipLaunchKernelGGL(lora_wgrad_kernel<2>, grid, dim3(256), 0, s, *a, mc); break;
+    case 3: hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, s, *a, mc); break;
+    default: hipLaunchKernelGGL(lora_wgrad_kernel<4>, grid, dim3(256), 0, s, *a, mc); break;
   }
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;

@@ -37,6 +37,38 @@ def test_gemm_lora_fused(stage):
     _ok(g.gemm_case(512, 3072, 64, stage=stage))  # x_embedder shape (K = one step)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gemm_persistent_8phase(seed):
+    """gemm8.hip (stage_mode 4 forces it; default launches pick it for big problems): K tails and narrow LoRA slabs read
+    zeros through the buffer descriptor, several output tiles per workgroup with cross-tile prefetch (tiles > CUs), odd
+    K-tile counts, segmented rows, every epilogue through the LDS-transposed store path.  Two seeds = a small race screen."""
+    from ai_toolkit_amd import ops
+    from tools import gpu_check as g
+
+    orig = ops.gemm_nt
+
+    def forced(a, b, out, **kw):
+        kw.pop("stage_mode", None)
+        return orig(a, b, out, stage_mode=4, tile_mode=2, **kw)
+
+    ops.gemm_nt = forced
+    try:
+        _ok(g.gemm_case(512, 512, 128, stage=1, seed=seed))
+        _ok(g.gemm_case(300, 200, 192, r=16, stage=1, seed=seed))
+        _ok(g.gemm_case(700, 1000, 80, r=16, stage=1, seed=seed))            # K tail (80 = 64 + 16)
+        _ok(g.gemm_case(260, 520, 64, r=48, stage=1, seed=seed))             # one base K-tile + 48-wide slab
+        _ok(g.gemm_case(512, 768, 128, r=16, flags=ops.EPI_GELU, stage=1, seed=seed))
+        _ok(g.gemm_case(512, 768, 128, r=16, flags=ops.EPI_GATE_RES, stage=1, seed=seed))
+        _ok(g.gemm_case(512, 768, 128, r=48, flags=ops.EPI_ACCUM, stage=1, seed=seed))
+        _ok(g.gemm_case(600, 512, 128, r=16, seg=True, stage=1, seed=seed))
+        _ok(g.gemm_case(8192, 4096, 256, r=16, flags=ops.EPI_GELU, stage=1, seed=seed))        # 512 tiles: 2 per workgroup
+        _ok(g.gemm_case(6000, 5000, 128, r=32, flags=ops.EPI_DGELU | ops.EPI_ACCUM, stage=1, seed=seed))
+        _ok(g.gemm_case(9000, 3072, 192, stage=1, seed=seed))                # odd K-tile count across tile boundaries
+        _ok(g.gemm_case(1024, 3072, 12288, r=16, stage=1, seed=seed))
+    finally:
+        ops.gemm_nt = orig
+
+
 def test_lora_skinny_kernels():
     from tools import gpu_check2 as g
 
