@@ -42,12 +42,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                                 "bwd_tflops_alg": round(2.5 * fl / bw / 1e9, 1)}))
 else:
     res = {}
+    variants = [("fwd8_pingpong", {}), ("fwd4", {"AITK_ATTN_FWD4": "1"})]
+    variants += [(os.path.basename(l), {"AITK_LIB_PATH": l}) for l in sorted(glob.glob(os.path.join(ROOT, "ai-toolkit_amd", "libaitk_abl_attn*.so")))]
     for rep in range(2):
-        for lib in sorted(glob.glob(os.path.join(ROOT, "ai-toolkit_amd", "libaitk_abl_attn*.so"))):
-            env = dict(os.environ, AITK_LIB_PATH=lib)
+        for name, extra in variants:
+            env = dict(os.environ, **extra)
             r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True, timeout=200)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-            res[f"{os.path.basename(lib)}#{rep}"] = json.loads(line[0][7:]) if line else r.stderr[-300:]
-            print(os.path.basename(lib), rep, res[f"{os.path.basename(lib)}#{rep}"], flush=True)
+            res[f"{name}#{rep}"] = json.loads(line[0][7:]) if line else r.stderr[-300:]
+            print(name, rep, res[f"{name}#{rep}"], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "attn_ab.json"), "w"), indent=1)
