@@ -139,7 +139,7 @@ class NoisePackArgs(C.Structure):
 
 class MseArgs(C.Structure):
     _fields_ = [("pred", vp), ("target", vp), ("weight", vp), ("dpred", vp), ("partial", vp),
-                ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("_pad", i32)]
+                ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("feat", i32), ("mask", vp)]
 
 
 class AdamWArgs(C.Structure):

@@ -138,8 +138,17 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(AitkMseArgs p, int nch
     d[2] = bf2f(pv.y & 0xffff) - bf2f(tv.y & 0xffff); d[3] = bf2f(pv.y >> 16) - bf2f(tv.y >> 16);
     d[4] = bf2f(pv.z & 0xffff) - bf2f(tv.z & 0xffff); d[5] = bf2f(pv.z >> 16) - bf2f(tv.z >> 16);
     d[6] = bf2f(pv.w & 0xffff) - bf2f(tv.w & 0xffff); d[7] = bf2f(pv.w >> 16) - bf2f(tv.w >> 16);
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (p.mask) {  // 8 consecutive features of one token: patch positions 0,1,2,3,0,1,2,3
+      const long j = i - (long)b * p.n_per_sample;
+      const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(p.mask + ((long)b * (p.n_per_sample / p.feat) + j / p.feat) * 4);
+      mk[0] = m4[0]; mk[1] = m4[1]; mk[2] = m4[2]; mk[3] = m4[3];
+    }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc += d[e] * d[e];
+    for (int e = 0; e < 8; ++e) {
+      acc += mk[e & 3] * d[e] * d[e];
+      d[e] *= mk[e & 3];
+    }
     uint4 g;
     g.x = pack2bf(d[0] * gs, d[1] * gs); g.y = pack2bf(d[2] * gs, d[3] * gs);
     g.z = pack2bf(d[4] * gs, d[5] * gs); g.w = pack2bf(d[6] * gs, d[7] * gs);
@@ -174,6 +183,7 @@ extern "C" int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample) {
 extern "C" int aitk_mse_loss_grad(const AitkMseArgs* a, aitk_stream_t stream) {
   if (!a || a->B <= 0 || a->B > 64 || a->n_per_sample <= 0 || (a->n_per_sample % 8)) return AITK_ERR_SHAPE;
   if (!a->pred || !a->target || !a->dpred || !a->partial || !a->loss || !a->loss_per_sample) return AITK_ERR_ARG;
+  if (a->mask && (a->feat <= 0 || (a->feat % 8) || (a->n_per_sample % a->feat))) return AITK_ERR_ARG;
   const int nchunk = (int)((a->n_per_sample + LOSS_CHUNK - 1) / LOSS_CHUNK);
   hipLaunchKernelGGL(mse_partial_kernel, dim3(nchunk, a->B), dim3(256), 0, (hipStream_t)stream, *a, nchunk);
   AITK_LAUNCH_CHECK();

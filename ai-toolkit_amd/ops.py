@@ -319,8 +319,9 @@ def flow_noise_pack(latents, noise, t, noisy, target):
     _capi.check(_capi.lib().aitk_flow_noise_pack(C.byref(a), _capi.stream_ptr()), "aitk_flow_noise_pack")
 
 
-def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None):
-    """loss_b = mean((pred-target)^2), loss = mean_b(w_b loss_b); dpred = dloss/dpred (bf16)."""
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None):
+    """loss_b = mean(mask*(pred-target)^2), loss = mean_b(w_b loss_b); dpred = dloss/dpred (bf16).
+    mask: fp32 [B, tokens, 4] (per 2x2-patch position), pred [B, tokens, feat]."""
     a = _capi.MseArgs()
     B = pred.shape[0]
     n = pred[0].numel()
@@ -329,6 +330,9 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None):
     a.pred, a.target, a.weight, a.dpred, a.partial = _ptr(pred), _ptr(target), _ptr(weight), _ptr(dpred), _ptr(ws)
     a.loss_per_sample, a.loss = _ptr(loss_per_sample), _ptr(loss)
     a.n_per_sample, a.B = n, B
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * (n // pred.shape[-1]) * 4
+        a.mask, a.feat = _ptr(mask), pred.shape[-1]
     _capi.check(_capi.lib().aitk_mse_loss_grad(C.byref(a), _capi.stream_ptr()), "aitk_mse_loss_grad")
 
 

@@ -65,14 +65,25 @@ class _LoRATrainStepBase:
             w.wait()
         self._pending = []
 
-    def _loss_backward_update(self, pred, target, loss_weight):
+    @staticmethod
+    def pack_mask(mask):
+        """reference mask_multiplier [B,1,H,W] (or [B,1,F,H,W]) at latent resolution, already divided by its mean
+        (SDTrainer.py:1484-1504) -> fp32 [B, tokens, 4] in the packed 2x2-patch token order of the prediction."""
+        if mask.dim() == 4:
+            mask = mask[:, :, None]
+        B, _, Fr, Hh, W = mask.shape
+        m = mask.float().reshape(B, Fr, Hh // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
+        return m.reshape(B, Fr * (Hh // 2) * (W // 2), 4).contiguous()
+
+    def _loss_backward_update(self, pred, target, loss_weight, loss_mask=None):
         """MSE loss + explicit backward (caller holds `with network`), then all-reduce / clip / AdamW / EMA."""
         ops, model, net = self.ops, self.model, self.network
         B = pred.shape[0]
         dpred = torch.empty_like(pred)
         if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
             self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
-        ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight)
+        ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
+                          mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
         net.zero_grad_arena()
         model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
 
@@ -93,7 +104,7 @@ class _LoRATrainStepBase:
 
 class FluxLoRATrainStep(_LoRATrainStepBase):
     # ------------------------------------------------------------------ one step
-    def step(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None):
+    def step(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None):
         """latents [B,16,H,W] (scaled VAE latents), prompt_embeds [B,512,4096], pooled_embeds [B,768].
         Returns the device-resident loss tensor (no host sync)."""
         ops, model, net = self.ops, self.model, self.network
@@ -116,7 +127,7 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         guidance = torch.full((B,), float(self.guidance), device=dev)
         with net:
             pred = model.forward_native(noisy, prompt_embeds, pooled_embeds, timesteps / 1000, img_ids, txt_ids, guidance)
-            self._loss_backward_update(pred, target, loss_weight)
+            self._loss_backward_update(pred, target, loss_weight, loss_mask)
         return self._optimizer_step()
 
 
@@ -130,7 +141,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         kw.setdefault("schedule", FlowMatchTrainSchedule(shift=3.0, use_dynamic_shifting=False))
         super().__init__(model, network, ops, **kw)
 
-    def step(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None):
+    def step(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None):
         """latents [B,16,F,H,W] (normalised Wan-VAE latents), prompt_embeds [B,512,4096] (UMT5).  Returns the loss tensor."""
         ops, model, net = self.ops, self.model, self.network
         dt = model.dt
@@ -152,7 +163,9 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         grid = (Fr, Hh // 2, W // 2)
         with net:
             pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, prompt_embeds, grid)
-            self._loss_backward_update(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight)
+            if loss_mask is not None and loss_mask.dim() == 4:  # [B,1,H,W] -> repeated over frames (SDTrainer.py:955-958)
+                loss_mask = loss_mask[:, :, None].expand(-1, -1, Fr, -1, -1)
+            self._loss_backward_update(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight, loss_mask)
         return self._optimizer_step()
 
 

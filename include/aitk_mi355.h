@@ -230,11 +230,16 @@ typedef struct AitkNoisePackArgs {
 int aitk_flow_noise_pack(const AitkNoisePackArgs* args, aitk_stream_t stream);
 
 /* ---- MSE loss (SDTrainer.py:916, 987-990, 1013) and its gradient wrt pred (bf16).  weight[b] (may be NULL) is the
- * per-sample loss multiplier.  partial: aitk_mse_workspace_bytes() scratch. */
+ * per-sample loss multiplier (loss_multiplier / timestep weights, SDTrainer.py:932-944, 994).  mask (may be NULL) is the
+ * reference's mask_multiplier (SDTrainer.py:959, 1484-1504: [B,1,h,w] broadcast over channels, already divided by its mean) in
+ * the packed-token layout of pred: fp32 [B][n_per_sample / feat][4], element (token, feature f) uses entry f & 3 (the
+ * (ph, pw) position inside the 2x2 patch); feat = features per token (64).  loss_b = mean_j (mask_j (pred_j - target_j)^2).
+ * partial: aitk_mse_workspace_bytes() scratch. */
 typedef struct AitkMseArgs {
   const aitk_bf16* pred; const aitk_bf16* target; const float* weight;
   aitk_bf16* dpred; float* partial; float* loss_per_sample; float* loss;
-  int64_t n_per_sample; int32_t B, _pad;
+  int64_t n_per_sample; int32_t B, feat;
+  const float* mask;
 } AitkMseArgs;
 int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample);
 int aitk_mse_loss_grad(const AitkMseArgs* args, aitk_stream_t stream);

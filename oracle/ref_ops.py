@@ -272,12 +272,18 @@ def flow_noise_pack(latents, noise, t, noisy, target):
     target.copy_(pack(e - x0).to(target.dtype))
 
 
-def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None):
-    """mse(pred.float(), target.float()) -> mean over (C,H,W) -> * multiplier -> mean over batch (SDTrainer.py:916-1013)."""
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None):
+    """mse(pred.float(), target.float()) [* mask_multiplier] -> mean over (C,H,W) -> * multiplier -> mean over batch
+    (SDTrainer.py:916-1013); mask [B, tokens, 4] is the reference's [B,1,h,w] mask in the packed 2x2-patch layout."""
     B = pred.shape[0]
     d = pred.float().reshape(B, -1) - target.float().reshape(B, -1)
     n = d.shape[1]
-    lps = (d * d).mean(1)
+    mk = torch.ones_like(d)
+    if mask is not None:
+        feat = pred.shape[-1]
+        mk = mask.float().reshape(B, -1, 1, 4).expand(B, n // feat, feat // 4, 4).reshape(B, n)
+    lps = (mk * d * d).mean(1)
+    d = d * mk
     w = weight.float() if weight is not None else torch.ones(B, device=pred.device)
     loss_per_sample.copy_(lps)
     loss.copy_((lps * w).mean().reshape(1))

@@ -108,3 +108,25 @@ def test_step_kernels_vs_oracle_ops():
     _ok(g.t_noise_mse())
     _ok(g.t_adamw())
     _ok(g.t_shadows())
+
+
+def test_masked_mse_kernel_vs_oracle():
+    import torch
+
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(9)
+    B, T, F = 3, 520, 64
+    pred = torch.randn(B, T, F, generator=g).to(torch.bfloat16).cuda()
+    tgt = torch.randn(B, T, F, generator=g).to(torch.bfloat16).cuda()
+    mask = torch.rand(B, T, 4, generator=g).cuda()
+    w = torch.tensor([1.0, 0.25, 3.0]).cuda()
+    outs = []
+    for o_ in (ops, ref_ops):
+        dp = torch.empty_like(pred)
+        lps, loss = torch.zeros(B, device="cuda"), torch.zeros(1, device="cuda")
+        o_.mse_loss_grad(pred, tgt, dp, lps, loss, weight=w, mask=mask)
+        outs.append((dp.float(), lps, loss))
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-5)
+    assert (outs[0][0] - outs[1][0]).abs().max() <= 2 ** -8 * outs[1][0].abs().max()

@@ -69,3 +69,28 @@ def test_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
         lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
         step.step(lat, emb, pooled, noise=noise, timesteps=ts)
     assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
+
+
+def test_masked_and_weighted_loss_matches_reference_formula():
+    """mask_multiplier [B,1,h,w] (normalised by its mean, SDTrainer.py:1484-1504) * mse -> mean(1,2,3) -> * loss_multiplier ->
+    mean (SDTrainer.py:916-1013), in the packed-token layout the step uses; gradient vs autograd."""
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import flux_ref, ref_ops
+
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 16, 8, 12
+    pred4 = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    tgt4 = torch.randn(B, C, H, W, generator=g)
+    mask = torch.rand(B, 1, H, W, generator=g)
+    mask = mask / mask.mean()
+    w = torch.tensor([0.5, 2.0])
+    loss_ref = (((pred4.float() - tgt4.float()) ** 2) * mask).mean([1, 2, 3])
+    (loss_ref * w).mean().backward()
+    pred = flux_ref.pack_latents(pred4.detach())
+    tgt = flux_ref.pack_latents(tgt4)
+    dpred = torch.empty_like(pred)
+    lps, loss = torch.zeros(B), torch.zeros(1)
+    ref_ops.mse_loss_grad(pred, tgt, dpred, lps, loss, weight=w, mask=FluxLoRATrainStep.pack_mask(mask))
+    assert torch.allclose(lps, loss_ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(loss, (loss_ref.detach() * w).mean().reshape(1), rtol=1e-5)
+    assert torch.allclose(dpred, flux_ref.pack_latents(pred4.grad), rtol=1e-5, atol=1e-7)
