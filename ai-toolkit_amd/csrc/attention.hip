@@ -188,6 +188,10 @@ __device__ __forceinline__ void frag_tr_perm_st_issue(s16x4_t& lo, s16x4_t& hi, 
   const int row2 = row + 8;
   tr16_issue(hi, base + row2 * 32 + ((lh ^ ((row2 >> 3) & 1)) << 4));
 }
+template <int OFF>
+__device__ __forceinline__ void tr16_issue_off(s16x4_t& out, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF));
+}
 #define TR_PIN8(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
 __device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& hi) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -407,30 +411,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
     const lds_float* dtc = ltc + 64;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      f32x16_t s = zero16(), dp = zero16();
-      {
-        s16x8_t qa[8], da[8];
+      f32x16_t s, dp;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          qa[ks] = frag_rm_st(qtc, 32 * sub, 16 * ks, lane);
-          da[ks] = frag_rm_st(dotc, 32 * sub, 16 * ks, lane);
+      for (int hk = 0; hk < 2; ++hk) {  // two batches of 4 k-steps: 32 fragment registers instead of 64
+        s16x8_t qa[4], da[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qa[ks] = frag_rm_st(qtc, 32 * sub, 16 * (4 * hk + ks), lane);
+          da[ks] = frag_rm_st(dotc, 32 * sub, 16 * (4 * hk + ks), lane);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          s = mfma32(qa[ks], kf[ks], s);
-          dp = mfma32(da[ks], vf[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) {
+          // inline asm pins the register classes: S / dP accumulate in arch VGPRs (the softmax VALU reads them), the
+          // loop-invariant K / V fragments sit in AccVGPRs.  Left to the allocator (389 registers, 1 wave per SIMD) S / dP
+          // land in AccVGPRs time-shared with dK: 128 v_accvgpr_read/write per iteration.
+          if (hk == 0 && ks == 0) {  // first product of the chain: C = 0 (no zero-fill of the 32 accumulator registers)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(s) : "v"(qa[ks]), "a"(kf[0]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(dp) : "v"(da[ks]), "a"(vf[0]));
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(da[ks]), "a"(vf[4 * hk + ks]));
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      // MFMA results -> VALU reads: the hazard recogniser does not see inside the asm (18 wait states for a 16-pass result)
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s), "+v"(dp));
       // transposed operands of the dV / dK products: issued now so their LDS latency hides behind the softmax VALU
       s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];  // index = 4*kk + d
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          frag_tr_perm_st_issue(dlo[4 * kk + d], dhi[4 * kk + d], dotc, 32 * sub + 16 * kk, 32 * d, lane);
-          frag_tr_perm_st_issue(qlo[4 * kk + d], qhi[4 * kk + d], qtc, 32 * sub + 16 * kk, 32 * d, lane);
+      {
+        // lane (h, gq, i) reads rows 32 sub + 16 kk + 4h + (i>>2) (+8) of column block 2d + gq of the sub-tiled Q / dO tiles:
+        // (row>>3)&1 is 0 for the first and 1 for the second read, so two per-lane bases + immediates address all 32 reads
+        const int hq = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15, lh = (i & 3) >> 1;
+        const unsigned tlo = (unsigned)(size_t)qtc + gq * SUBP + (i & 1) * 8 + (4 * hq + (i >> 2)) * 32 + (lh << 4);
+        const unsigned thi = tlo + 8 * 32 + ((lh ^ 1) - lh) * 16;
+#define TRQ(KK, D)                                                                                   \
+  tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dlo[4 * KK + D], tlo);               \
+  tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dhi[4 * KK + D], thi);               \
+  tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qlo[4 * KK + D], tlo);                    \
+  tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qhi[4 * KK + D], thi);
+#define TRQ8() TRQ(0, 0) TRQ(0, 1) TRQ(0, 2) TRQ(0, 3) TRQ(1, 0) TRQ(1, 1) TRQ(1, 2) TRQ(1, 3)
+        if (sub == 0) {
+#define SUBI 0
+          TRQ8()
+#undef SUBI
+        } else {
+#define SUBI 1
+          TRQ8()
+#undef SUBI
         }
+#undef TRQ8
+#undef TRQ
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
