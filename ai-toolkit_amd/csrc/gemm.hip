@@ -308,29 +308,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
       if (s + 1 < nsteps) write_b8(s + 1, (s + 1) & 1);
       __syncthreads();
     }
-  } else {
-    // STAGE 2: three-buffer LDS-DMA ring, two K-steps in flight across a raw s_barrier, counted vmcnt (guide T3+T4):
-    //   wait(tile s landed: at most the PA+PB DMAs of tile s+1 may stay outstanding) -> barrier (every wave's piece of
-    //   tile s is visible AND every wave finished reading buffer (s-1)%3) -> refill that buffer with tile s+2 -> compute.
-    static_assert(PA + PB == 6 || PA + PB == 4 || PA + PB == 8, "vmcnt immediates below");
-    issue_glds(0, 0);
-    if (nsteps > 1) issue_glds(1, 1);
-    int cur = 0, nxt2 = 2;
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) {
-        if (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < nsteps) issue_glds(s + 2, nxt2);
-      compute(s, cur);
-      cur = cur == 2 ? 0 : cur + 1;
-      nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
-    }
   }
 
   // ---------------- epilogue ----------------
@@ -471,7 +448,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
-  // stage_mode: 0 VGPR-staged, 1 auto (8-phase persistent kernel when the problem is big, else LDS-DMA 2-barrier), 2 ring3,
+  // stage_mode: 0 VGPR-staged, 1 auto (8-phase persistent kernel when the problem is big, else LDS-DMA 2-barrier),
   //             4 force the 8-phase kernel, 5 force the 2-barrier LDS-DMA kernels (A/B reference)
   if ((a->stage_mode == 1 && big) || a->stage_mode == 4) {
     if (aitk_gemm8_try_launch(a, st) == AITK_OK) {
@@ -480,15 +457,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     }
   }
   if (a->stage_mode >= 4) tmp.stage_mode = 1;
-  if (a->stage_mode == 2) {
-    static bool attr3 = false;
-    if (!attr3) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2, 256, 128, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
-      attr3 = true;
-    }
-    const int tiles = ((a->M + 255) / 256) * ((a->N + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_kernel<2, 256, 128, 4, 2>), dim3(tiles), dim3(512), 147456, st, *a);
-  } else if (big) {
+  if (big) {
     const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     if (a->stage_mode == 1)
       hipLaunchKernelGGL((gemm_nt_kernel<1, 256, 256, 2, 4>), dim3(tiles), dim3(512), 131072, st, *a);

@@ -56,7 +56,8 @@ typedef struct AitkGemmArgs {
   const aitk_bf16* gate; int64_t ld_gate; int32_t gate_rows;
   int32_t M, N, K, K2;
   int32_t flags;
-  int32_t stage_mode; /* 0 = VGPR-staged, 1 = LDS-DMA (global_load_lds) */
+  int32_t stage_mode; /* 0 = VGPR-staged 2-barrier kernel, 1 = auto: persistent 8-phase LDS-DMA kernel for big problems, else
+                         2-barrier LDS-DMA kernel, 4 = force the 8-phase kernel, 5 = force the 2-barrier LDS-DMA kernels */
   int32_t tile_mode;  /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves) */
   /* implicit-GEMM 3x3 convolution (conv_mode = 1): A = NHWC input [B, conv_H, conv_W, conv_Cin], M = B*Ho*Wo,
    * K = 9*conv_Cin with k = (ky*3+kx)*Cin + cin, B = weight [Cout, K]; zero_page = >=16 B of zeros on the device */
