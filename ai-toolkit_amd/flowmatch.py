@@ -31,6 +31,15 @@ class FlowMatchTrainSchedule:
         self.base_image_seq_len, self.max_image_seq_len = base_image_seq_len, max_image_seq_len
         self.timesteps = None
         self.timestep_type = "linear"
+        # Bell-shaped mean-normalised timestep weights and the half-bell variant (custom_flowmatch_sampler.py:29-56)
+        n = 1000
+        x = torch.arange(n, dtype=torch.float32)
+        y = torch.exp(-2 * ((x - n / 2) / n) ** 2)
+        y = y - y.min()
+        self.linear_timesteps_weights = y * (n / y.sum())
+        w2 = y * (n / y.sum())
+        w2[n // 2:] = w2[n // 2:].max()
+        self.linear_timesteps_weights2 = w2
 
     def set_train_timesteps(self, num_timesteps, device, timestep_type="linear", latents=None, patch_size=1):
         self.timestep_type = timestep_type
@@ -62,10 +71,34 @@ class FlowMatchTrainSchedule:
             raise ValueError(f"Invalid timestep type: {timestep_type}")
         return self.timesteps
 
-    def sample_timesteps(self, batch_size, device, generator=None, min_idx=0, max_idx=None):
-        """'balanced': randint(min_idx, max_idx) into the table; flow-matching uses [0, num_train_timesteps - 1)
-        (jobs/process/BaseSDTrainProcess.py:1301-1323)."""
+    def sample_timesteps(self, batch_size, device, generator=None, min_idx=0, max_idx=None, content_or_style="balanced"):
+        """Timestep indices into the table (jobs/process/BaseSDTrainProcess.py:1248-1323):
+        'balanced' -> randint(min_idx, max_idx), flow-matching uses [0, num_train_timesteps - 1);
+        'content' / 'style' -> cubic sampling u^3 / 1 - u^3 of u ~ U(0,1), mapped to [min_idx, max_idx] and clamped (1275-1298)."""
         if max_idx is None:
             max_idx = self.num_train_timesteps - 1
-        idx = torch.randint(min_idx, max_idx, (batch_size,), device=device, generator=generator).long()
+        if content_or_style == "balanced":
+            if min_idx == max_idx:
+                idx = torch.full((batch_size,), min_idx, device=device).long()
+            else:
+                idx = torch.randint(min_idx, max_idx, (batch_size,), device=device, generator=generator).long()
+        elif content_or_style in ("content", "style"):
+            u = torch.rand((batch_size,), device=device, generator=generator)
+            n = self.num_train_timesteps
+            t = u ** 3 * n if content_or_style == "content" else (1 - u ** 3) * n
+            t = (t - 0) * (max_idx - min_idx) / ((n - 1) - 0) + min_idx  # toolkit/basic.py:7-8 value_map
+            idx = t.long().clamp(min_idx, max_idx)
+        else:
+            raise ValueError(f"Unknown content_or_style {content_or_style}")
         return self.timesteps[idx].float().contiguous(), idx
+
+    def get_weights_for_timesteps(self, timesteps, v2=False, timestep_type="linear"):
+        """Per-sample loss weights of `linear_timesteps` / `linear_timesteps2` training (custom_flowmatch_sampler.py:59-76,
+        applied at SDTrainer.py:925-944): bell-shaped weight of each timestep's INDEX in the current table.  The 'weighted'
+        type needs the reference's 1000-entry default_weighing_scheme data table, which is not carried here."""
+        if timestep_type == "weighted":
+            raise NotImplementedError("timestep_type='weighted' needs toolkit/timestep_weighing/default_weighing_scheme.py")
+        table = self.timesteps.to(timesteps.device)
+        idx = torch.stack([(table == t).nonzero()[0, 0] for t in timesteps]).cpu()
+        w = (self.linear_timesteps_weights2 if v2 else self.linear_timesteps_weights)[idx]
+        return w.flatten().to(timesteps.device)

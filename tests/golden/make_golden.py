@@ -114,6 +114,12 @@ def golden_flowmatch():
     noisy = torch.cat([s.add_noise(x0[i:i + 1], eps[i:i + 1], ts[i:i + 1]) for i in range(3)], 0)  # per-sample loop like
     out["noisy"] = noisy  # toolkit/stable_diffusion_model.py:1861-1875
     out["calc_shift"] = torch.tensor([calculate_shift(n) for n in (256, 1024, 4096, 3952)], dtype=torch.float64)
+    # bell-shaped timestep weights of the reference scheduler for a few table entries (linear table)
+    s.set_train_timesteps(1000, "cpu", "linear")
+    tw = s.timesteps[torch.tensor([0, 17, 499, 500, 730, 999])].clone()
+    out["tw_ts"] = tw
+    out["tw_v1"] = s.get_weights_for_timesteps(tw, v2=False, timestep_type="linear").clone()
+    out["tw_v2"] = s.get_weights_for_timesteps(tw, v2=True, timestep_type="linear").clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "flowmatch.safetensors"))
     print("flowmatch golden written")
 

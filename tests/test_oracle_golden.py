@@ -135,6 +135,26 @@ def test_flowmatch_schedule_matches_reference_scheduler():
     assert torch.allclose(flux_ref.unpack_latents(target, Hh, W), eps - x0, rtol=1e-6, atol=1e-6)
     cs = torch.tensor([calculate_shift(n) for n in (256, 1024, 4096, 3952)], dtype=torch.float64)
     assert torch.allclose(cs, t["calc_shift"])
+    # bell-shaped per-timestep loss weights (linear_timesteps / linear_timesteps2) of the reference scheduler
+    s.set_train_timesteps(1000, "cpu", "linear")
+    assert torch.allclose(s.get_weights_for_timesteps(t["tw_ts"], v2=False), t["tw_v1"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(s.get_weights_for_timesteps(t["tw_ts"], v2=True), t["tw_v2"], rtol=1e-6, atol=1e-7)
+
+
+def test_timestep_index_sampling_modes():
+    """content / style cubic sampling and the degenerate balanced case (BaseSDTrainProcess.py:1275-1318)."""
+    s = FlowMatchTrainSchedule()
+    s.set_train_timesteps(1000, "cpu", "linear")
+    g = torch.Generator().manual_seed(4)
+    u = torch.rand((64,), generator=torch.Generator().manual_seed(4))
+    ts, idx = s.sample_timesteps(64, "cpu", generator=g, content_or_style="content")
+    want = ((u ** 3 * 1000) * 998 / 999).long().clamp(0, 998)
+    assert torch.equal(idx, want) and torch.equal(ts, s.timesteps[want])
+    _, idx_s = s.sample_timesteps(64, "cpu", generator=torch.Generator().manual_seed(4), content_or_style="style")
+    assert torch.equal(idx_s, (((1 - u ** 3) * 1000) * 998 / 999).long().clamp(0, 998))
+    assert idx.float().mean() < idx_s.float().mean()  # content favours early table entries (high noise), style late ones
+    _, idx_b = s.sample_timesteps(5, "cpu", min_idx=7, max_idx=7)
+    assert idx_b.tolist() == [7] * 5
 
 
 def test_pack_unpack_roundtrip_and_ids():
