@@ -148,10 +148,10 @@ def test_timestep_index_sampling_modes():
     g = torch.Generator().manual_seed(4)
     u = torch.rand((64,), generator=torch.Generator().manual_seed(4))
     ts, idx = s.sample_timesteps(64, "cpu", generator=g, content_or_style="content")
-    want = ((u ** 3 * 1000) * 998 / 999).long().clamp(0, 998)
+    want = ((u ** 3 * 1000) * 999 / 999).long().clamp(0, 999)  # value_map(0..999 -> min_idx..max_idx) then clamp
     assert torch.equal(idx, want) and torch.equal(ts, s.timesteps[want])
     _, idx_s = s.sample_timesteps(64, "cpu", generator=torch.Generator().manual_seed(4), content_or_style="style")
-    assert torch.equal(idx_s, (((1 - u ** 3) * 1000) * 998 / 999).long().clamp(0, 998))
+    assert torch.equal(idx_s, (((1 - u ** 3) * 1000) * 999 / 999).long().clamp(0, 999))
     assert idx.float().mean() < idx_s.float().mean()  # content favours early table entries (high noise), style late ones
     _, idx_b = s.sample_timesteps(5, "cpu", min_idx=7, max_idx=7)
     assert idx_b.tolist() == [7] * 5
