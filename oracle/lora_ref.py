@@ -45,10 +45,55 @@ class RefLoRAModule(nn.Module):
         return org + lx.to(org.dtype)
 
 
+class RefDoRAModule(nn.Module):
+    """toolkit/models/DoRA.py:36-148 + the DoRA branch of toolkit/network_mixins.py:323-339:
+        out = org(x) + scale * m_b * up(down(x32)) + (magnitude / ||W + s*up@down||_row - 1) * F.linear(x32, W + s*up@down)
+    with s = multiplier.mean(), the row norm detached (DoRA paper §4.3), lora_down ~ N(0, 1/r), lora_up = 0,
+    magnitude initialised to the row norm of the base weight.  Parameter registration order (magnitude is created last but
+    nn.Module lists Parameters before sub-modules): magnitude, lora_up.weight, lora_down.weight."""
+
+    def __init__(self, lora_name, org_module, lora_dim, alpha, network):
+        super().__init__()
+        self.lora_name = lora_name
+        self.lora_dim = lora_dim
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self.scale = float(alpha) / lora_dim
+        self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
+        self.lora_up.weight.data = torch.zeros_like(self.lora_up.weight.data)
+        self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
+        self.lora_down.weight.data = torch.randn_like(self.lora_down.weight.data) * (1 / torch.sqrt(torch.tensor(lora_dim).float()))
+        self.org_module = [org_module]
+        self.network = [network]
+        w = org_module.weight.data.detach().float()
+        self.magnitude = nn.Parameter(torch.linalg.norm(w + self.lora_up.weight @ self.lora_down.weight, dim=1).detach().clone())
+
+    def apply_to(self):
+        self.org_forward = self.org_module[0].forward
+        self.org_module[0].forward = self.forward
+
+    def forward(self, x, *args, **kwargs):
+        net = self.network[0]
+        if not net.is_active or net.multiplier_is_zero():
+            return self.org_forward(x, *args, **kwargs)
+        org = self.org_forward(x, *args, **kwargs)
+        x32 = x.to(self.lora_down.weight.dtype)
+        lx = self.lora_up(self.lora_down(x32)) * self.scale
+        m = net.torch_multiplier
+        if lx.size(0) != m.size(0):
+            m = m.repeat_interleave(lx.size(0) // m.size(0))
+        lx = (lx * m.view(-1, *([1] * (lx.dim() - 1)))).to(org.dtype)
+        slw = (self.lora_up.weight @ self.lora_down.weight) * m.mean()
+        w = self.org_module[0].weight.data.detach().to(slw.dtype)
+        norm = torch.linalg.norm(w + slw, dim=1).detach()
+        dora = (self.magnitude / norm - 1).view(1, -1) * torch.nn.functional.linear(x32, w + slw)
+        return org + lx + dora.to(org.dtype)
+
+
 class RefLoRANetwork(nn.Module):
     """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
 
-    def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",)):
+    def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",),
+                 network_type="lora"):
         super().__init__()
         self.is_active = False
         self.torch_multiplier = torch.tensor([float(multiplier)])
@@ -63,7 +108,8 @@ class RefLoRANetwork(nn.Module):
                 lora_name = clean.replace(".", "$$")
                 if not any(b in clean for b in block_names):
                     continue
-                self.unet_loras.append(RefLoRAModule(lora_name, child, lora_dim, lora_dim, self))
+                cls = RefDoRAModule if network_type == "dora" else RefLoRAModule
+                self.unet_loras.append(cls(lora_name, child, lora_dim, lora_dim, self))
         for lo in self.unet_loras:
             self.add_module(lo.lora_name, lo)
 

@@ -124,6 +124,51 @@ def golden_flowmatch():
     print("flowmatch golden written")
 
 
+def golden_dora():
+    """Reference LoRASpecialNetwork(network_type='dora') on the tiny FLUX oracle: init draws, forward, every gradient
+    (magnitude / lora_up / lora_down) and the PEFT-format state dict it saves."""
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    torch.manual_seed(99)
+    net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=8, alpha=1.0, multiplier=1.0, train_text_encoder=False,
+                             train_unet=True, is_flux=True, target_lin_modules=["FluxTransformer2DModel"], transformer_only=True,
+                             network_type="dora")
+    out = {}
+    for m in net.unet_loras:
+        out[f"init/{m.lora_name}/down"] = m.lora_down.weight.detach().clone()
+        out[f"init/{m.lora_name}/magnitude"] = m.magnitude.detach().clone()
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+            m.magnitude.mul_(1 + 0.05 * torch.randn(m.magnitude.shape, generator=g))
+            out[f"set/{m.lora_name}/up"] = m.lora_up.weight.detach().clone()
+            out[f"set/{m.lora_name}/magnitude"] = m.magnitude.detach().clone()
+    net.force_to("cpu", torch.float32)
+    net._update_torch_multiplier()
+    net.apply_to(None, model, False, True)
+    net.is_active = True
+    pred = model(*tiny_inputs())
+    w = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+    (pred * w).sum().backward()
+    out["fwd/pred"] = pred.detach().clone()
+    out["fwd/w"] = w
+    for m in net.unet_loras:
+        out[f"grad/{m.lora_name}/down"] = m.lora_down.weight.grad.clone()
+        out[f"grad/{m.lora_name}/up"] = m.lora_up.weight.grad.clone()
+        out[f"grad/{m.lora_name}/magnitude"] = m.magnitude.grad.clone()
+    sd = net.get_state_dict(dtype=torch.float32)
+    for k, v in sd.items():
+        out["saved/" + k] = v.clone()
+    meta = {"names": json.dumps([m.lora_name for m in net.unet_loras]), "saved_keys": json.dumps(list(sd.keys())),
+            "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()])}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "dora_flux_tiny.safetensors"), meta)
+    print("dora golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors")
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -147,5 +192,6 @@ def golden_wan_lora_keys():
 
 if __name__ == "__main__":
     golden_lora()
+    golden_dora()
     golden_flowmatch()
     golden_wan_lora_keys()

@@ -165,3 +165,36 @@ def test_pack_unpack_roundtrip_and_ids():
     img_ids, txt_ids = flux_ref.make_ids(8, 6, 5)
     assert img_ids.shape == (12, 3) and txt_ids.shape == (5, 3)
     assert img_ids[4].tolist() == [0.0, 1.0, 1.0]
+
+
+def test_oracle_dora_matches_reference_dora_network():
+    """oracle/lora_ref.RefDoRAModule vs the reference's DoRAModule (tests/golden/dora_flux_tiny.safetensors, produced by
+    LoRASpecialNetwork(network_type='dora') under the import shims): init draws under the same seed, forward, all gradients
+    (magnitude / lora_up / lora_down) and saved keys."""
+    path = os.path.join(G, "dora_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    t = load_file(path)
+    model = oracle_model()
+    torch.manual_seed(99)
+    net = lora_ref.RefLoRANetwork(model, 8, network_type="dora")
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    assert [n for n, _ in net.unet_loras[0].named_parameters()] == meta["param_order"]
+    for m in net.unet_loras:
+        assert torch.equal(m.lora_down.weight, t[f"init/{m.lora_name}/down"]), m.lora_name
+        assert torch.allclose(m.magnitude, t[f"init/{m.lora_name}/magnitude"], rtol=1e-6), m.lora_name
+        with torch.no_grad():
+            m.lora_up.weight.copy_(t[f"set/{m.lora_name}/up"])
+            m.magnitude.copy_(t[f"set/{m.lora_name}/magnitude"])
+    net.apply_to()
+    with net:
+        pred = model(*tiny_inputs())
+        (pred * t["fwd/w"]).sum().backward()
+    assert torch.allclose(pred, t["fwd/pred"], rtol=1e-5, atol=1e-6)
+    for m in net.unet_loras:
+        for nm, p_ in (("down", m.lora_down.weight), ("up", m.lora_up.weight), ("magnitude", m.magnitude)):
+            assert torch.allclose(p_.grad, t[f"grad/{m.lora_name}/{nm}"], rtol=2e-4, atol=2e-6), (m.lora_name, nm)
+    sd = net.peft_state_dict(torch.float32)
+    assert sorted(sd.keys()) == sorted(meta["saved_keys"])
+    for k, v in sd.items():
+        assert torch.allclose(v, t[f"saved/{k}"]), k
