@@ -378,6 +378,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             dcat_o = self._new(Mj, d)
             du = self._new(Mj, 4 * d)
             # proj_out: adapter grads once, then the two column ranges of d[attn | mlp]
+            dy = self._dora_dz(blk.proj_out, dy, Mj)
             dT = self._lora_grads(blk.proj_out, dy, r["T_out"], r["cat"], M=Mj, rows_per_batch=S, B=B)
             self._lin_dgrad(blk.proj_out, dy, dT, dcat_o, M=Mj, w_rows=(0, d))
             self._lin_dgrad(blk.proj_out, dy, dT, du, M=Mj, w_rows=(d, 5 * d), flags=EPI_DGELU, aux_in=r["u"])

@@ -152,6 +152,12 @@ class FusedGraphBase(nn.Module):
                 mult, rpb = self._mult(rows_per_batch, B)
                 ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
             kw = dict(a2=T, b2=lo.sh_up)
+            if lo.magnitude is not None:  # DoRA: y = c * (x W^T + T B^T) + b; the linear output is kept for d magnitude
+                kw["col_scale"] = lo.c
+                if (flags & EPI_GATE_RES) and aux_out is None:
+                    aux_out = self._new(M, lin.out_features)
+                assert c_seg is None
+                lo.y_lin = aux_out if (flags & (EPI_GELU | EPI_GATE_RES)) else out
         else:
             T = None
         if lin.qweight is not None:
@@ -167,6 +173,7 @@ class FusedGraphBase(nn.Module):
             return None
         ops = self.ops
         lo = lin.lora
+        assert lo.magnitude is None or getattr(dy, "_dora_dz", False), "DoRA: pass dy through _dora_dz() first"
         dT = dT_out if dT_out is not None else self._new(M, lo.lora_dim)
         mult, rpb = self._mult(rows_per_batch, B)
         ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
@@ -174,6 +181,18 @@ class FusedGraphBase(nn.Module):
         if dT_out is None:
             ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
         return dT
+
+    def _dora_dz(self, lin, dy, M):
+        """DoRA layers: the gradient entering the (W, A, B) products is dz = c * dy, and d magnitude is accumulated from dy
+        and this step's linear output.  Plain LoRA layers: dy unchanged."""
+        if not self._lora_active(lin) or lin.lora.magnitude is None:
+            return dy
+        lo = lin.lora
+        dz = self._new(M, lin.out_features)
+        self.ops.dora_bwd(dy, lo.y_lin, lo.c, lin.bias, lo.magnitude.data, dz, lo.g_mag, M=M)
+        lo.y_lin = None
+        dz._dora_dz = True
+        return dz
 
     def _group_bwd(self, lins, dys, Ts, x_in, dx, *, M, rows_per_batch, B, first_flags=0):
         """Backward of several adapters+linears that read the same x_in: dx (+)= sum_j dy_j W_j + dT_j A_j, up-grads per
@@ -183,6 +202,7 @@ class FusedGraphBase(nn.Module):
             grp = None
         dTcat = self._new(M, grp["R"]) if grp is not None else None
         for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
+            dy = self._dora_dz(lin, dy, M)
             dT_out = None
             if grp is not None:
                 c0 = grp["col"][id(lin.lora)]
@@ -205,6 +225,7 @@ class FusedGraphBase(nn.Module):
         self.ops.gemm_nt(dy, wt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, **kw)
 
     def _lin_bwd(self, lin, dy, T, x_in, dx, *, M, rows_per_batch, B, flags=0, aux_in=None, x_seg=None, dx_seg=None):
+        dy = self._dora_dz(lin, dy, M)
         dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, x_seg=x_seg)
         self._lin_dgrad(lin, dy, dT, dx, M=M, flags=flags, aux_in=aux_in, dx_seg=dx_seg)
 
@@ -220,6 +241,9 @@ class FusedGraphBase(nn.Module):
             mult, rpb = self._mult(1, B)
             ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
             kw = dict(t=T, bl=lo.sh_up)
+            if lo.magnitude is not None:
+                kw["col_scale"] = lo.c
+                lo.y_lin = mod
         ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, **kw)
         return mod, T
 
@@ -229,6 +253,7 @@ class FusedGraphBase(nn.Module):
             return
         ops = self.ops
         lo = ada_lin.lora
+        dmod = self._dora_dz(ada_lin, dmod, B)
         dT = self._new(B, lo.lora_dim)
         mult, rpb = self._mult(1, B)
         ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)

@@ -56,6 +56,7 @@ class LoRAModule(nn.Module):
         self.register_buffer("alpha", torch.tensor(alpha))
         nn.init.kaiming_uniform_(self.lora_down.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_up.weight)
+        self.magnitude = None  # DoRAModule sets it
         self.multiplier = multiplier
         self.org_module = [org_module]  # list keeps it out of state_dict (reference lines 125-126)
         self.dropout, self.rank_dropout, self.module_dropout = dropout, rank_dropout, module_dropout
@@ -88,6 +89,43 @@ class LoRAModule(nn.Module):
         return self.lora_up.weight.shape[0]
 
 
+class DoRAModule(LoRAModule):
+    """toolkit/models/DoRA.py:36-106: same surface as LoRAModule plus `magnitude` [out] (initialised to the row norm of the
+    base weight), lora_up created first and zeroed, lora_down ~ N(0, 1/r) — same construction order, hence the same RNG
+    consumption as the reference.  The fused GEMM applies c = magnitude / ||W + s*up@down||_row as a column scale."""
+
+    def __init__(self, lora_name, org_module, multiplier=1.0, lora_dim=4, alpha=1, network=None, **kwargs):
+        nn.Module.__init__(self)
+        self.can_merge_in = False  # network_mixins.py:894-897: merge_in is a no-op for DoRA
+        self.network_ref = weakref.ref(network) if network is not None else (lambda: None)
+        self.is_checkpointing = False
+        self._multiplier = None
+        self.lora_name = lora_name
+        self.orig_module_ref = weakref.ref(org_module)
+        in_dim, out_dim = org_module.in_features, org_module.out_features
+        self.lora_dim = lora_dim
+        self.full_rank = False
+        if isinstance(alpha, torch.Tensor):
+            alpha = float(alpha.detach().float().item())
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        self._set_runtime_scale(float(alpha) / lora_dim)
+        self.lora_up = nn.Linear(lora_dim, out_dim, bias=False)
+        self.lora_up.weight.data = torch.zeros_like(self.lora_up.weight.data)
+        self.lora_down = nn.Linear(in_dim, lora_dim, bias=False)
+        self.lora_down.weight.data = torch.randn_like(self.lora_down.weight.data) * (1 / torch.sqrt(torch.tensor(lora_dim).float()))
+        w = org_module.weight.data.detach().float().cpu()
+        self.magnitude = nn.Parameter(torch.linalg.norm(w, dim=1).clone())  # lora_up = 0 at init: ||W + up@down|| = ||W||
+        self.multiplier = multiplier
+        self.org_module = [org_module]
+        self.dropout = self.rank_dropout = self.module_dropout = None
+        self.off_down = self.off_up = self.off_mag = -1
+        self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
+        self.g_down = self.g_up = self.g_mag = None
+        self.c = None       # fp32 [out]: magnitude / ||W + s*up@down||, refreshed after every optimizer step
+        self.w2 = None      # fp32 [out]: ||W_j||^2 of the frozen base weight
+        self.y_lin = None   # this step's linear output (c*z + b), kept for d magnitude
+
+
 class FusedLoRANetwork(nn.Module):
     """Drop-in for LoRASpecialNetwork on transformer (PEFT-format) models."""
 
@@ -96,6 +134,8 @@ class FusedLoRANetwork(nn.Module):
                  is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1"):
         super().__init__()
         assert peft_format and is_transformer, "kohya-format UNet naming is a later row (SURVEY.md §8f.3)"
+        assert network_type.lower() in ("lora", "dora"), "LoKr / full-rank adapters are not on the fused path"
+        module_class = DoRAModule if network_type.lower() == "dora" else LoRAModule  # toolkit/lora_special.py:403-405
         self.lora_dim = lora_dim
         self.network_type = network_type
         self.peft_format = True
@@ -135,7 +175,7 @@ class FusedLoRANetwork(nn.Module):
                 if lora_name in names:
                     continue
                 names.add(lora_name)
-                lora = LoRAModule(lora_name, child, multiplier, lora_dim, self.alpha, network=self)
+                lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self)
                 self.unet_loras.append(lora)
         for lora in self.unet_loras:
             self.add_module(lora.lora_name, lora)
@@ -161,6 +201,8 @@ class FusedLoRANetwork(nn.Module):
         # the skinny kernels handle up to 64 ranks per launch: larger groups (e.g. q,k,v at rank 32) stay ungrouped
         groups = [g for g in (groups or []) if sum(x.lora_dim for x in g) <= 64]
         n = sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in mods)
+        n_mat = n  # [0, n_mat): the matrices (shadowed in bf16); [n_mat, n): DoRA magnitude vectors (fp32 only)
+        n += sum(m.magnitude.numel() for m in mods if m.magnitude is not None)
         self.arena_p = torch.empty(n, dtype=torch.float32, device=device)
         self.arena_g = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_m = torch.zeros(n, dtype=torch.float32, device=device)
@@ -169,7 +211,7 @@ class FusedLoRANetwork(nn.Module):
         dt = torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
         self.shadow_dtype = dt
         # shadow arena: [0, n) direct copies at the fp32 arena's offsets, [n, 2n) transposed copies
-        self.arena_shadow = torch.empty(2 * n, dtype=dt, device=device)
+        self.arena_shadow = torch.empty(2 * n_mat, dtype=dt, device=device)
         group_of = {}
         for gi, grp in enumerate(groups or []):
             for m in grp:
@@ -196,15 +238,31 @@ class FusedLoRANetwork(nn.Module):
             gview = self.arena_g[off:off + cnt].view(rows, cols)
             lin.weight.grad = gview
             sh = self.arena_shadow[off:off + cnt].view(rows, cols)
-            shT = self.arena_shadow[n + off:n + off + cnt].view(cols, rows)
-            entries.append((off, off, n + off, rows, cols))
+            shT = self.arena_shadow[n_mat + off:n_mat + off + cnt].view(cols, rows)
+            entries.append((off, off, n_mat + off, rows, cols))
             if which == "down":
                 m.off_down, m.g_down, m.sh_down, m.sh_downT = off, gview, sh, shT
             else:
                 m.off_up, m.g_up, m.sh_up, m.sh_upT = off, gview, sh, shT
             off += cnt
+        assert off == n_mat
         for m in mods:
-            m.alpha = m.alpha.to(device)
+            if m.magnitude is None:
+                continue
+            cnt = m.magnitude.numel()
+            view = self.arena_p[off:off + cnt]
+            view.copy_(m.magnitude.data)
+            m.magnitude = nn.Parameter(view, requires_grad=True)
+            m.g_mag = self.arena_g[off:off + cnt]
+            m.magnitude.grad = m.g_mag
+            m.off_mag = off
+            m.c = torch.ones(cnt, dtype=torch.float32, device=device)
+            w = m.org_module[0].weight.data
+            m.w2 = w.float().pow(2).sum(1).to(device)
+            off += cnt
+        for m in mods:
+            if hasattr(m, "alpha"):
+                m.alpha = m.alpha.to(device)
             m._runtime_scale = m._runtime_scale.to(device)
             m.group = None
         self.groups = []
@@ -235,12 +293,38 @@ class FusedLoRANetwork(nn.Module):
         if self._shadow_table is None:
             self._shadow_table = ops.make_shadow_table(self._shadow_entries, self.arena_p.device)
         ops.refresh_shadows(self.arena_p, self.arena_shadow, self._shadow_table)
+        self.refresh_dora(ops)
+
+    def refresh_dora(self, ops):
+        """c = magnitude / ||W + s*up@down||_row for every DoRA module, from the current adapter state:
+        ||.||^2 = ||W||^2 + 2 s B.(W A^T) + s^2 B (A A^T) B^T — one skinny pass over each base weight (aitk_lora_down with the
+        weight as the streamed operand), an r x r Gram matrix (aitk_lora_wgrad) and a row kernel.  The norm is detached in the
+        reference (DoRA.py:139-147), so c is a constant of the step."""
+        mods = [m for m in self.get_all_modules() if m.magnitude is not None]
+        if not mods:
+            return
+        mult = self._multiplier
+        vals = [float(x) for x in mult] if isinstance(mult, (list, tuple)) else [float(mult)]
+        if max(vals) != min(vals):
+            raise NotImplementedError("DoRA with per-sample multipliers (slider training) is not on the fused path")
+        for m in mods:
+            lin = m.org_module[0]
+            if getattr(lin, "qweight", None) is not None:
+                raise NotImplementedError("DoRA over a weight-only fp8 base is not on the fused path")
+            dev, r = self.arena_p.device, m.lora_dim
+            tw = torch.empty(lin.out_features, r, dtype=self.shadow_dtype, device=dev)
+            ops.lora_down(lin.weight.data, m.sh_down, tw, scale=1.0, M=lin.out_features)
+            gram = torch.zeros(r, r, dtype=torch.float32, device=dev)
+            ops.lora_wgrad(m.sh_downT, m.sh_downT, gram, M=m.in_features)
+            ops.dora_colscale(m.w2, tw, m.lora_up.weight.data, gram, m.magnitude.data, m.scale * vals[0], m.c)
 
     def zero_grad_arena(self):
         self.arena_g.zero_()
         for m in self.get_all_modules():  # optimizer.zero_grad(set_to_none=True) may have dropped the views
             m.lora_down.weight.grad = m.g_down
             m.lora_up.weight.grad = m.g_up
+            if m.magnitude is not None:
+                m.magnitude.grad = m.g_mag
 
     # ------------------------------------------------------------------ multiplier / activation (network_mixins.py:791-853)
     @property
@@ -282,8 +366,11 @@ class FusedLoRANetwork(nn.Module):
     def prepare_optimizer_params(self, text_encoder_lr=None, unet_lr=None, default_lr=None):
         """One group with every adapter weight (toolkit/kohya_lora.py:1030-1074, unet branch)."""
         params = []
-        for m in self.unet_loras:
-            params.extend([m.lora_down.weight, m.lora_up.weight])
+        for m in self.unet_loras:  # named_parameters() order of the reference modules
+            if m.magnitude is not None:
+                params.extend([m.magnitude, m.lora_up.weight, m.lora_down.weight])
+            else:
+                params.extend([m.lora_down.weight, m.lora_up.weight])
         group = {"params": params}
         lr = unet_lr if unet_lr is not None else default_lr
         if lr is not None:
@@ -301,6 +388,11 @@ class FusedLoRANetwork(nn.Module):
                 if src is not None:
                     w = src[off:off + w.numel()].view_as(w)
                 sd[f"{base}.{which}.weight"] = w.clone().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
+            if m.magnitude is not None:
+                w = m.magnitude.detach()
+                if src is not None:
+                    w = src[m.off_mag:m.off_mag + w.numel()]
+                sd[f"{base}.magnitude"] = w.clone().to("cpu").to(dtype)
         if extra_state_dict is not None:
             for k, v in extra_state_dict.items():
                 sd[k] = v.detach().clone().to("cpu").to(dtype)
@@ -340,6 +432,9 @@ class FusedLoRANetwork(nn.Module):
                         w.copy_(v)
                         used.add(k)
                         hit = True
+                if k.endswith(".magnitude") and k[: -len(".magnitude")] in by_name and by_name[k[: -len(".magnitude")]].magnitude is not None:
+                    by_name[k[: -len(".magnitude")]].magnitude.copy_(v.to(self.arena_p.device, torch.float32))
+                    hit = True
                 if not hit:
                     extra[k] = v
         return extra if len(extra) else None
@@ -353,6 +448,8 @@ class FusedLoRANetwork(nn.Module):
         """W <- W + merge_weight * scale * (lora_up @ lora_down) for every wrapped Linear (and its transposed copy),
         as a rank-r GEMM with the accumulate epilogue: C += (c*B) A  — the MFMA form of ToolkitModuleMixin.merge_in."""
         ops = ops or self._ops
+        if self.network_type.lower() == "dora":
+            return  # toolkit/network_mixins.py:894-897
         self.refresh_shadows(ops)
         for m in self.get_all_modules():
             lin = m.org_module[0]

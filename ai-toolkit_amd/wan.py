@@ -393,6 +393,7 @@ class WanTransformer3DModel(FusedGraphBase):
             grp = None
         dTcat = self._new(Mt, grp["R"]) if grp is not None else None
         for lin, dy, T in zip(lins, dys, Ts):
+            dy = self._dora_dz(lin, dy, Mt)
             dT_out = None
             if grp is not None:
                 c0 = grp["col"][id(lin.lora)]

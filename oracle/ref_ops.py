@@ -41,7 +41,7 @@ def rows_per_block():
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0):
+            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0, col_scale=None):
     """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342).  b_scale: weight-only fp8 base,
     dequantised as (fp8 * scale) rounded to the activation dtype (quanto / torchao weight-only semantics)."""
     if M is None:
@@ -54,6 +54,8 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     v = A @ b.float().t()
     if a2 is not None:
         v = v + a2[:M].float() @ b2.float().t()
+    if col_scale is not None:  # DoRA: magnitude / ||W + dW||_row applied to the un-biased product
+        v = v * col_scale.float()[None, :]
     if bias is not None:
         v = v + (bias.float()[:, None] if flags & EPI_BIAS_ROW else bias.float())
     if flags & EPI_ADD_AUX:
@@ -245,12 +247,19 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
         dst[: B * n, : H * 128].copy_(src.grad.transpose(1, 2).reshape(B * n, H * 128).to(dst.dtype))
 
 
-def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
+def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scale=None):
     v = x.float() @ w.float().t()
-    if bias is not None:
-        v = v + bias.float()
-    if t is not None:
-        v = v + t.float() @ bl.float().t()
+    if col_scale is None:
+        if bias is not None:
+            v = v + bias.float()
+        if t is not None:
+            v = v + t.float() @ bl.float().t()
+    else:  # DoRA: c * (x W^T + T B^T) + b
+        if t is not None:
+            v = v + t.float() @ bl.float().t()
+        v = v * col_scale.float()[None, :]
+        if bias is not None:
+            v = v + bias.float()
     if accumulate:
         v = v + out.float()
     out.copy_(v.to(out.dtype))
@@ -404,3 +413,25 @@ def rms_full_bwd(g, x, weight, dx, *, S, cos=None, sin=None, eps=1e-6):
         _rms_full(xx, weight, S, cos, sin, eps, None).backward(g.float())
     dx.copy_(xx.grad.to(dx.dtype))
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------- DoRA
+def dora_colscale(w2, tw, up, gram, mag, s, c_out):
+    """c_j = magnitude_j / ||W_j + s * B_j A||  (toolkit/models/DoRA.py:126-148), from precomputed pieces:
+    ||.||^2 = ||W_j||^2 + 2 s B_j . (W A^T)_j + s^2 B_j (A A^T) B_j^T."""
+    upf = up.float()
+    n2 = w2.float() + 2.0 * s * (upf * tw.float()).sum(1) + (s * s) * ((upf @ gram.float()) * upf).sum(1)
+    c_out.copy_(mag.float() / torch.sqrt(n2))
+    return c_out
+
+
+def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
+    """y = c * z + b  (z = x W^T + T B^T):  dz = c * dy ;  d magnitude_j += sum_m dy_mj z_mj / ||.||_j = (sum dy*y - b_j sum dy) / mag_j."""
+    d = dy[:M].float()
+    yf = y[:M].float()
+    dz[:M].copy_((d * c.float()[None, :]).to(dz.dtype))
+    s1 = (d * yf).sum(0)
+    s0 = d.sum(0)
+    b = bias.float() if bias is not None else torch.zeros_like(s0)
+    dmag += (s1 - b * s0) / mag.float()
+    return dz

@@ -1,0 +1,120 @@
+"""DoRA through the fused graph (host logic on CPU, oracle kernel table): network_type='dora' must reproduce
+ (a) the reference's own DoRA network on the tiny FLUX model — golden vectors written by tests/golden/make_golden.py from
+     toolkit.lora_special.LoRASpecialNetwork(network_type='dora') — init draws, prediction, every gradient, saved file;
+ (b) autograd of the oracle DoRA module on a larger configuration, through a full train step with AdamW."""
+import json
+import os
+
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+from ai_toolkit_amd.lora import FusedLoRANetwork
+from ai_toolkit_amd.trainer import FluxLoRATrainStep
+from oracle import flux_ref, lora_ref, ref_ops, train_ref
+from tests.test_oracle_golden import TINY, oracle_model, tiny_inputs
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_fused_dora_matches_reference_golden(tmp_path):
+    path = os.path.join(G, "dora_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    t = load_file(path)
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=8, network_type="dora")
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    for m in net.unet_loras:
+        assert torch.equal(m.lora_down.weight, t[f"init/{m.lora_name}/down"]), m.lora_name  # same RNG consumption
+        assert torch.allclose(m.magnitude, t[f"init/{m.lora_name}/magnitude"], rtol=1e-6)
+        with torch.no_grad():
+            m.lora_up.weight.copy_(t[f"set/{m.lora_name}/up"])
+            m.magnitude.copy_(t[f"set/{m.lora_name}/magnitude"])
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    with net:
+        pred = nat.forward_native(*tiny_inputs())
+        assert torch.allclose(pred, t["fwd/pred"], rtol=2e-4, atol=2e-5), (pred - t["fwd/pred"]).abs().max()
+        net.zero_grad_arena()
+        nat.backward_native(t["fwd/w"])
+    for m in net.unet_loras:
+        for nm, p_ in (("down", m.lora_down.weight), ("up", m.lora_up.weight), ("magnitude", m.magnitude)):
+            ref_g = t[f"grad/{m.lora_name}/{nm}"]
+            err = ((p_.grad - ref_g).norm() / (ref_g.norm() + 1e-12)).item()
+            assert err < 5e-4, (m.lora_name, nm, err)
+    # saved file: same keys / values as the reference writes (order of keys inside a module differs: sorted compare)
+    f = tmp_path / "dora.safetensors"
+    net.save_weights(str(f), dtype=torch.float32, metadata={"name": "x"})
+    sd = load_file(str(f))
+    assert sorted(sd.keys()) == sorted(meta["saved_keys"])
+    for k, v in sd.items():
+        assert torch.allclose(v, t[f"saved/{k}"], rtol=1e-6), k
+    # optimizer parameter order of the reference module: magnitude, lora_up, lora_down
+    m0 = net.unet_loras[0]
+    first3 = net.prepare_optimizer_params()[0]["params"][:3]
+    assert first3[0] is m0.magnitude and first3[1] is m0.lora_up.weight and first3[2] is m0.lora_down.weight
+
+
+CFG = dict(in_channels=64, num_layers=1, num_single_layers=2, attention_head_dim=128, num_attention_heads=2,
+           joint_attention_dim=64, pooled_projection_dim=32)
+
+
+def test_dora_train_steps_match_oracle_autograd_adamw():
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+    nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(5)
+    ref_net = lora_ref.RefLoRANetwork(ref, 4, network_type="dora")
+    torch.manual_seed(5)
+    net = FusedLoRANetwork(nat, lora_dim=4, network_type="dora")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.equal(a.lora_down.weight, b.lora_down.weight)
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.05
+            a.lora_up.weight.copy_(up)
+            b.lora_up.weight.copy_(up)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    params = [p for m in ref_net.unet_loras for p in (m.magnitude, m.lora_up.weight, m.lora_down.weight)]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, eps=1e-6)
+    for it in range(3):
+        gi = torch.Generator().manual_seed(20 + it)
+        lat = torch.randn(2, 16, 8, 4, generator=gi)
+        emb = torch.randn(2, 6, 64, generator=gi)
+        pooled = torch.randn(2, 32, generator=gi)
+        noise = torch.randn(2, 16, 8, 4, generator=gi)
+        ts = torch.tensor([310.0, 845.0])
+        loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        tt = (ts / 1000).view(-1, 1, 1, 1)
+        noisy = flux_ref.pack_latents((1 - tt) * lat + tt * noise)
+        img_ids, txt_ids = flux_ref.make_ids(8, 4, 6)
+        opt.zero_grad()
+        with ref_net:
+            pred = ref(noisy, emb, pooled, ts / 1000, img_ids, txt_ids, torch.ones(2))
+            loss_ref = (pred - flux_ref.pack_latents(noise - lat)).pow(2).mean()
+            loss_ref.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        assert abs(loss.item() - loss_ref.item()) < 2e-4 * max(1.0, abs(loss_ref.item())), (it, loss.item(), loss_ref.item())
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert torch.allclose(a.magnitude, b.magnitude, rtol=2e-3, atol=2e-6), a.lora_name
+        assert torch.allclose(a.lora_up.weight, b.lora_up.weight, rtol=2e-3, atol=2e-6), a.lora_name
+        assert torch.allclose(a.lora_down.weight, b.lora_down.weight, rtol=2e-3, atol=2e-6), a.lora_name
