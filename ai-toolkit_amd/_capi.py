@@ -27,6 +27,7 @@ class GemmArgs(C.Structure):
         ("conv_pad_t", i32), ("conv_pad_l", i32), ("_pad3", i32),
         ("zero_page", vp),
         ("b_scale", vp), ("b_scale_mode", i32), ("_pad4", i32),
+        ("col_scale", vp),
     ]
 
 
@@ -129,6 +130,7 @@ class GemvArgs(C.Structure):
         ("T", vp), ("ldt", i64), ("Bl", vp), ("ldbl", i64),
         ("out", vp), ("ldo", i64),
         ("Bm", i32), ("N", i32), ("K", i32), ("R", i32), ("accumulate", i32), ("cols_per_group", i32),
+        ("col_scale", vp),
     ]
 
 
@@ -159,15 +161,25 @@ class RmsFullArgs(C.Structure):
                 ("eps", C.c_float), ("S", i32), ("M", i64), ("C", i32), ("_pad", i32)]
 
 
+class DoraColscaleArgs(C.Structure):
+    _fields_ = [("w2", vp), ("tw", vp), ("ldtw", i64), ("up", vp), ("gram", vp), ("mag", vp), ("c", vp),
+                ("s", C.c_float), ("N", i32), ("R", i32), ("_pad", i32)]
+
+
+class DoraBwdArgs(C.Structure):
+    _fields_ = [("dy", vp), ("ld_dy", i64), ("y", vp), ("ld_y", i64), ("c", vp), ("bias", vp), ("mag", vp),
+                ("dz", vp), ("ld_dz", i64), ("dmag", vp), ("partial", vp), ("M", i32), ("N", i32)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
 
 
-EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE = 1, 2, 4, 8, 16, 32, 64, 128
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
-            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs}
+            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs, 17: DoraColscaleArgs, 18: DoraBwdArgs}
 
 
 def lib():

@@ -328,6 +328,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
+        if (flags & AITK_EPI_COL_SCALE) {
+          const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.col_scale + nb);
+          v[0] *= cs[0]; v[1] *= cs[1]; v[2] *= cs[2]; v[3] *= cs[3];
+        }
         if (flags & AITK_EPI_BIAS) {
           uint2 bb = *reinterpret_cast<const uint2*>(p.bias + nb);
           v[0] += bf2f(bb.x & 0xffff); v[1] += bf2f(bb.x >> 16);
@@ -391,6 +395,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_BIAS | AITK_EPI_BIAS_ROW)) && !a->bias) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_ADD_AUX) && !a->aux_in) return AITK_ERR_ARG;
+  if ((a->flags & AITK_EPI_COL_SCALE) && (!a->col_scale || ((uintptr_t)a->col_scale & 15))) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GELU) && !a->aux_out) return AITK_ERR_ARG;  // GATE_RES: aux_out optional (only d_gate needs y)
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;

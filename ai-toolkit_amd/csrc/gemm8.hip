@@ -372,6 +372,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
         if ((flags & AITK_EPI_BIAS) && ncol) unpack8f(*reinterpret_cast<const uint4*>(q->bias + n), bias8);
+        float cs8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs8[e] = 1.f;
+        if ((flags & AITK_EPI_COL_SCALE) && ncol) {
+          const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(q->col_scale + n), c1 = *reinterpret_cast<const f32x4_t*>(q->col_scale + n + 4);
+          cs8[0] = c0[0]; cs8[1] = c0[1]; cs8[2] = c0[2]; cs8[3] = c0[3]; cs8[4] = c1[0]; cs8[5] = c1[1]; cs8[6] = c1[2]; cs8[7] = c1[3];
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           // acc block -> wave-private patch [32 rows][32 fp32], 16-B chunk (2g+h) swizzled by row&7
@@ -390,6 +397,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
             const int m = m0 + wr * 128 + mi * 32 + r;
             if (m < q->M && ncol) {
               bf16_t* crow = const_cast<bf16_t*>(seg_row8(q->C, q->ldc, q->c_seg_rows, q->c_seg_stride, m)) + n;
+              if (flags & AITK_EPI_COL_SCALE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= cs8[e];
+              }
               if (flags & AITK_EPI_BIAS) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];

@@ -84,6 +84,8 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 14: return (int)sizeof(AitkShadowDesc);
     case 15: return (int)sizeof(AitkGroupNormArgs);
     case 16: return (int)sizeof(AitkRmsFullArgs);
+    case 17: return (int)sizeof(AitkDoraColscaleArgs);
+    case 18: return (int)sizeof(AitkDoraBwdArgs);
     default: return -1;
   }
 }

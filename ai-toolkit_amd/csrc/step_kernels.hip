@@ -63,12 +63,13 @@ __global__ __launch_bounds__(256) void gemv_nt_kernel(AitkGemvArgs p) {
 #pragma unroll
       for (int k = 0; k < GEMV_MAXB; ++k)
         if (k == bb) v = acc[k];
-      if (p.bias) v += bf2f(p.bias[n]);
       if (p.R > 0) {
         float lv = 0.f;
         for (int r = 0; r < p.R; ++r) lv += bf2f(p.T[(long)bb * p.ldt + r]) * bf2f(p.Bl[(long)n * p.ldbl + r]);
         v += lv;
       }
+      if (p.col_scale) v *= p.col_scale[n];  // DoRA: c * (x W^T + T B^T) + b
+      if (p.bias) v += bf2f(p.bias[n]);
       bf16_t* o = p.out + (long)bb * p.ldo + n;
       if (p.accumulate) v += bf2f(*o);
       *o = f2bf(v);
@@ -305,6 +306,98 @@ extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, 
                                          aitk_stream_t stream) {
   if (!arena || !shadow || !table || ntensors <= 0) return AITK_ERR_ARG;
   hipLaunchKernelGGL(refresh_shadows_kernel, dim3(16, ntensors), dim3(256), 0, (hipStream_t)stream, arena, shadow, table);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ DoRA
+// c_j = magnitude_j / sqrt(||W_j||^2 + 2 s B_j.(W A^T)_j + s^2 B_j (A A^T) B_j^T); one thread per output channel (R <= 64)
+__global__ void dora_colscale_kernel(AitkDoraColscaleArgs p) {
+  __shared__ float g[64 * 64];
+  for (int i = threadIdx.x; i < p.R * p.R; i += blockDim.x) g[i] = p.gram[i];
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.N) return;
+  const float* b = p.up + (long)j * p.R;
+  float cross = 0.f, quad = 0.f;
+  for (int r = 0; r < p.R; ++r) {
+    const float br = b[r];
+    cross += br * bf2f(p.tw[(long)j * p.ldtw + r]);
+    float t = 0.f;
+    for (int q = 0; q < p.R; ++q) t += g[r * p.R + q] * b[q];
+    quad += br * t;
+  }
+  const float n2 = p.w2[j] + 2.0f * p.s * cross + p.s * p.s * quad;
+  p.c[j] = p.mag[j] / sqrtf(n2);
+}
+extern "C" int aitk_dora_colscale(const AitkDoraColscaleArgs* a, aitk_stream_t stream) {
+  if (!a || a->N <= 0 || a->R <= 0 || a->R > 64) return AITK_ERR_SHAPE;
+  if (!a->w2 || !a->tw || !a->up || !a->gram || !a->mag || !a->c) return AITK_ERR_ARG;
+  hipLaunchKernelGGL(dora_colscale_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// dz = c * dy; per-row-block partial column sums of dy and dy*y (deterministic two-stage reduction like aitk_gate_bwd)
+#define DORA_RPB 16
+__global__ __launch_bounds__(256) void dora_bwd_kernel(AitkDoraBwdArgs p) {
+  const int m0 = blockIdx.x * DORA_RPB;
+  const int nrows = min(DORA_RPB, p.M - m0);
+  for (int ch = threadIdx.x; ch < p.N / 8; ch += 256) {
+    const int c = ch * 8;
+    float cs[8], s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cs[e] = p.c[c + e];
+      s0[e] = s1[e] = 0.f;
+    }
+    for (int r = 0; r < nrows; ++r) {
+      const long m = m0 + r;
+      const uint4 dv = *reinterpret_cast<const uint4*>(p.dy + m * p.ld_dy + c);
+      const uint4 yv = *reinterpret_cast<const uint4*>(p.y + m * p.ld_y + c);
+      float d[8], y[8];
+      d[0] = bf2f(dv.x & 0xffff); d[1] = bf2f(dv.x >> 16); d[2] = bf2f(dv.y & 0xffff); d[3] = bf2f(dv.y >> 16);
+      d[4] = bf2f(dv.z & 0xffff); d[5] = bf2f(dv.z >> 16); d[6] = bf2f(dv.w & 0xffff); d[7] = bf2f(dv.w >> 16);
+      y[0] = bf2f(yv.x & 0xffff); y[1] = bf2f(yv.x >> 16); y[2] = bf2f(yv.y & 0xffff); y[3] = bf2f(yv.y >> 16);
+      y[4] = bf2f(yv.z & 0xffff); y[5] = bf2f(yv.z >> 16); y[6] = bf2f(yv.w & 0xffff); y[7] = bf2f(yv.w >> 16);
+      uint4 o;
+      o.x = pack2bf(d[0] * cs[0], d[1] * cs[1]); o.y = pack2bf(d[2] * cs[2], d[3] * cs[3]);
+      o.z = pack2bf(d[4] * cs[4], d[5] * cs[5]); o.w = pack2bf(d[6] * cs[6], d[7] * cs[7]);
+      *reinterpret_cast<uint4*>(p.dz + m * p.ld_dz + c) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s0[e] += d[e];
+        s1[e] += d[e] * y[e];
+      }
+    }
+    float* pp = p.partial + ((long)blockIdx.x * 2) * p.N + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      pp[e] = s0[e];
+      pp[p.N + e] = s1[e];
+    }
+  }
+}
+__global__ void dora_bwd_finish_kernel(AitkDoraBwdArgs p, int nchunk) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.N) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = 0; k < nchunk; ++k) {
+    s0 += p.partial[((long)k * 2) * p.N + j];
+    s1 += p.partial[((long)k * 2 + 1) * p.N + j];
+  }
+  const float b = p.bias ? bf2f(p.bias[j]) : 0.f;
+  p.dmag[j] += (s1 - b * s0) / p.mag[j];
+}
+extern "C" int aitk_dora_bwd(const AitkDoraBwdArgs* a, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->N <= 0 || (a->N % 8)) return AITK_ERR_SHAPE;
+  if ((a->ld_dy % 8) || (a->ld_y % 8) || (a->ld_dz % 8)) return AITK_ERR_ALIGN;
+  if (!a->dy || !a->y || !a->c || !a->mag || !a->dz || !a->dmag || !a->partial) return AITK_ERR_ARG;
+  const int nchunk = (a->M + DORA_RPB - 1) / DORA_RPB;
+  hipLaunchKernelGGL(dora_bwd_kernel, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dora_bwd_finish_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a, nchunk);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

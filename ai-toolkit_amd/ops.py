@@ -24,7 +24,8 @@ def _row_major(t, name):
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None,
-            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0):
+            gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0,
+            col_scale=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T + bias).
 
     a_seg / c_seg = (seg_rows, seg_stride_elems): logical row m lives at base + (m // seg_rows) * seg_stride
@@ -71,6 +72,10 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     if gate is not None:
         g.ld_gate = _row_major(gate, "gate")
         g.gate, g.gate_rows = _ptr(gate), gate_rows
+    if col_scale is not None:  # DoRA: product * col_scale[n] before the bias
+        assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == N
+        g.col_scale = _ptr(col_scale)
+        flags |= _capi.EPI_COL_SCALE
     g.M, g.N, g.K, g.flags = M, N, K, flags
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
     g.tile_mode = TILE_MODE if tile_mode is None else tile_mode
@@ -294,7 +299,7 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
     _capi.check(_capi.lib().aitk_attn_bwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_bwd")
 
 
-def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
+def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scale=None):
     """out[Bm,N] (+)= x[Bm,K] @ w[N,K]^T + bias + t[Bm,R] @ bl[N,R]^T   (Bm <= 8)."""
     a = _capi.GemvArgs()
     a.ldx, a.ldw, a.ldo = _row_major(x, "x"), _row_major(w, "w"), _row_major(out, "out")
@@ -305,6 +310,9 @@ def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False):
     if t is not None:
         a.T, a.ldt, a.Bl, a.ldbl, a.R = _ptr(t), _row_major(t, "t"), _ptr(bl), _row_major(bl, "bl"), t.shape[1]
     a.accumulate = int(accumulate)
+    if col_scale is not None:
+        assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == a.N
+        a.col_scale = _ptr(col_scale)
     _capi.check(_capi.lib().aitk_gemv_nt(C.byref(a), _capi.stream_ptr()), "aitk_gemv_nt")
     return out
 
@@ -462,3 +470,30 @@ def rms_full_bwd(g, x, weight, dx, *, S, cos=None, sin=None, eps=1e-6):
     a.g, a.ldg = _ptr(g), _row_major(g, "g")
     _capi.check(_capi.lib().aitk_rms_full_bwd(C.byref(a), _capi.stream_ptr()), "aitk_rms_full_bwd")
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------- DoRA
+def dora_colscale(w2, tw, up, gram, mag, s, c_out):
+    """c = magnitude / ||W + s*B A||_row from ||W||^2, tw = W A^T [N,R] (bf16), B fp32 [N,R], gram = A A^T fp32 [R,R]."""
+    a = _capi.DoraColscaleArgs()
+    N, R = up.shape
+    assert up.dtype == torch.float32 and up.is_contiguous() and gram.dtype == torch.float32 and gram.is_contiguous()
+    assert w2.dtype == torch.float32 and mag.dtype == torch.float32 and c_out.dtype == torch.float32 and tw.dtype == BF16
+    a.w2, a.tw, a.ldtw, a.up, a.gram, a.mag, a.c = _ptr(w2), _ptr(tw), tw.stride(0), _ptr(up), _ptr(gram), _ptr(mag), _ptr(c_out)
+    a.s, a.N, a.R = float(s), N, R
+    _capi.check(_capi.lib().aitk_dora_colscale(C.byref(a), _capi.stream_ptr()), "aitk_dora_colscale")
+    return c_out
+
+
+def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
+    """dz = c * dy;  dmag += (colsum(dy*y) - bias * colsum(dy)) / mag   (y = c*z + bias is this step's linear output)."""
+    a = _capi.DoraBwdArgs()
+    N = dz.shape[1]
+    a.dy, a.ld_dy, a.y, a.ld_y, a.dz, a.ld_dz = _ptr(dy), _row_major(dy, "dy"), _ptr(y), _row_major(y, "y"), _ptr(dz), _row_major(dz, "dz")
+    assert c.dtype == torch.float32 and mag.dtype == torch.float32 and dmag.dtype == torch.float32 and dmag.is_contiguous()
+    nchunk = (M + 15) // 16
+    part = workspace(2 * nchunk * N * 4, dz.device, "dora_bwd")
+    a.c, a.bias, a.mag, a.dmag, a.partial = _ptr(c), _ptr(bias), _ptr(mag), _ptr(dmag), _ptr(part)
+    a.M, a.N = M, N
+    _capi.check(_capi.lib().aitk_dora_bwd(C.byref(a), _capi.stream_ptr()), "aitk_dora_bwd")
+    return dz

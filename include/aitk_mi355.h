@@ -35,6 +35,7 @@ typedef uint16_t aitk_bf16;
 #define AITK_EPI_GATE_RES 16 /* aux_out = y; C = aux_in(residual) + gate[m / gate_rows][n] * y   */
 #define AITK_EPI_BIAS_ROW 32 /* + bias[m]  (transposed products, e.g. V^T = W_v x^T)             */
 #define AITK_EPI_ADD_AUX 64  /* + aux_in[m][n]  (residual add of ResnetBlock2D / VAE attention)  */
+#define AITK_EPI_COL_SCALE 128 /* product * col_scale[n] before the bias: DoRA magnitude / ||W + dW||_row (toolkit/models/DoRA.py:126-148) */
 
 /*
  * C[M,N] = epi( A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T + bias )       (bf16 in/out, fp32 accumulate)
@@ -67,6 +68,7 @@ typedef struct AitkGemmArgs {
   /* weight-only fp8 base operand (b_scale_mode != 0): B points to OCP e4m3 bytes [N, K] (ldb in bytes), dequantised to
    * bf16(fp8 * scale) on the way into LDS.  1: scale[n] per B row (forward); 2: scale[k] per contraction index (dgrad on W^T). */
   const float* b_scale; int32_t b_scale_mode; int32_t _pad4;
+  const float* col_scale; /* fp32 [N], AITK_EPI_COL_SCALE */
 } AitkGemmArgs;
 
 int aitk_abi_version(void);
@@ -217,6 +219,7 @@ typedef struct AitkGemvArgs {
   aitk_bf16* out; int64_t ldo;
   int32_t Bm, N, K, R;
   int32_t accumulate; int32_t cols_per_group; /* cols_per_group: set by the library */
+  const float* col_scale; /* may be NULL; DoRA: out = col_scale[n] * (X W^T + T Bl^T) + bias */
 } AitkGemvArgs;
 int aitk_gemv_nt(const AitkGemvArgs* args, aitk_stream_t stream);
 
@@ -299,6 +302,25 @@ typedef struct AitkRmsFullArgs {
 } AitkRmsFullArgs;
 int aitk_rms_full_fwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
 int aitk_rms_full_bwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
+
+/* ---- DoRA (toolkit/models/DoRA.py, network_mixins.py:323-339): y = c * (x W^T + s m x A^T B^T) + b with
+ * c_j = magnitude_j / ||W_j + s B_j A||, the norm detached.
+ * aitk_dora_colscale: c from ||W_j||^2 (w2), tw = W A^T [N,R] (aitk_lora_down with the weight as streamed operand), up = B fp32
+ *   [N,R] (arena view), gram = A A^T fp32 [R,R] (aitk_lora_wgrad), magnitude:  n^2 = w2 + 2 s B.tw + s^2 B gram B^T.
+ * aitk_dora_bwd: dz = c * dy (bf16) and magnitude.grad_j += (sum_m dy*y - bias_j sum_m dy) / magnitude_j with y = this step's
+ *   linear output; partial = 2 * ceil(M / aitk_rows_per_block()) * N floats of scratch. */
+typedef struct AitkDoraColscaleArgs {
+  const float* w2; const aitk_bf16* tw; int64_t ldtw; const float* up; const float* gram; const float* mag; float* c;
+  float s; int32_t N, R, _pad;
+} AitkDoraColscaleArgs;
+int aitk_dora_colscale(const AitkDoraColscaleArgs* args, aitk_stream_t stream);
+typedef struct AitkDoraBwdArgs {
+  const aitk_bf16* dy; int64_t ld_dy; const aitk_bf16* y; int64_t ld_y;
+  const float* c; const aitk_bf16* bias; const float* mag;
+  aitk_bf16* dz; int64_t ld_dz; float* dmag; float* partial;
+  int32_t M, N;
+} AitkDoraBwdArgs;
+int aitk_dora_bwd(const AitkDoraBwdArgs* args, aitk_stream_t stream);
 
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);

@@ -64,7 +64,7 @@ class RefDoRAModule(nn.Module):
         self.lora_down.weight.data = torch.randn_like(self.lora_down.weight.data) * (1 / torch.sqrt(torch.tensor(lora_dim).float()))
         self.org_module = [org_module]
         self.network = [network]
-        w = org_module.weight.data.detach().float()
+        w = org_module.weight.data.detach().float().to(self.lora_up.weight.device)
         self.magnitude = nn.Parameter(torch.linalg.norm(w + self.lora_up.weight @ self.lora_down.weight, dim=1).detach().clone())
 
     def apply_to(self):

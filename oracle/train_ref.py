@@ -17,7 +17,8 @@ class RefTrainStep:
     def __init__(self, model, net, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0,
                  ema_decay=0.0, guidance=1.0):
         self.model, self.net = model, net
-        self.params = [p for m in net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)]
+        self.params = [p for m in net.unet_loras for p in
+                       ((m.magnitude, m.lora_up.weight, m.lora_down.weight) if hasattr(m, "magnitude") else (m.lora_down.weight, m.lora_up.weight))]
         self.opt = torch.optim.AdamW(self.params, lr=lr, eps=eps, betas=betas, weight_decay=weight_decay)
         self.max_grad_norm, self.ema_decay, self.guidance = max_grad_norm, ema_decay, guidance
         self.ema = [p.detach().clone() for p in self.params] if ema_decay > 0 else None
