@@ -162,6 +162,14 @@ class FusedGraphBase(nn.Module):
             T = None
         if lin.qweight is not None:
             kw.update(b_scale=lin.wscale, b_scale_mode=1)
+        if "col_scale" in kw and (flags & EPI_ADD_AUX):
+            # DoRA needs the bare linear output for d magnitude and the residual-add epilogue does not store it: product first,
+            # residual in a second pass (Wan cross-attention out-projection only)
+            y = self._new(M, lin.out_features)
+            ops.gemm_nt(x, lin.weight, y, bias=lin.bias, flags=flags & ~EPI_ADD_AUX, a_seg=a_seg, M=M, **kw)
+            ops.ew(2, y, out, a=aux_in)
+            lin.lora.y_lin = y
+            return T
         ops.gemm_nt(x, lin.qweight if lin.qweight is not None else lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out,
                     aux_in=aux_in, gate=gate, gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
         return T

@@ -137,3 +137,47 @@ def test_wan_lora_state_dict_keys_and_original_format_round_trip():
     assert "diffusion_model.blocks.2.ffn.0.lora_A.weight" in orig
     back = convert.wan_lora_to_diffusers(orig)
     assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+
+
+def test_wan_dora_network_matches_oracle_autograd():
+    """network_type='dora' through the Wan graph (cross-attention k/v adapters take the weight-gradient-only path)."""
+    torch.manual_seed(0)
+    ref = wan_ref.WanTransformer3DModel(**CFG)
+    wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+    nat = WanTransformer3DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(3)
+    ref_net = lora_ref.RefLoRANetwork(ref, 8, target=("WanTransformer3DModel",), block_names=("blocks",), network_type="dora")
+    torch.manual_seed(3)
+    net = FusedLoRANetwork(nat, lora_dim=8, target_lin_modules=("WanTransformer3DModel",), transformer_block_names=["blocks"],
+                           base_model_version="wan_2.1", network_type="dora")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.equal(a.lora_down.weight, b.lora_down.weight)
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.05
+            mg = b.magnitude * (1 + 0.05 * torch.randn(b.magnitude.shape, generator=g))
+            for m in (a, b):
+                m.lora_up.weight.copy_(up)
+                m.magnitude.copy_(mg)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    lat, txt, t = inputs()
+    with ref_net:
+        pred_ref = ref(lat, t, txt)
+        w5 = torch.randn(pred_ref.shape, generator=torch.Generator().manual_seed(11))
+        (pred_ref * w5).sum().backward()
+    with net:
+        pred = nat.forward_native(nat.pack_tokens(lat), t, txt, (3, 4, 2))
+        assert torch.allclose(pred, nat.pack_tokens(pred_ref.detach()), rtol=2e-4, atol=2e-5)
+        net.zero_grad_arena()
+        nat.backward_native(nat.pack_tokens(w5))
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for x, y, nm in ((a.lora_down.weight.grad, b.lora_down.weight.grad, "down"), (a.lora_up.weight.grad, b.lora_up.weight.grad, "up"),
+                         (a.magnitude.grad, b.magnitude.grad, "magnitude")):
+            err = ((x - y).norm() / (y.norm() + 1e-12)).item()
+            assert err < 5e-4, (a.lora_name, nm, err)
