@@ -401,3 +401,44 @@ extern "C" int aitk_dora_bwd(const AitkDoraBwdArgs* a, aitk_stream_t stream) {
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------ fp8 weight dequantisation
+// out[r][k] = bf16(e4m3(q[r][k]) * scale) with scale indexed by the row (mode 1: q = W [out,in]) or by the column (mode 2:
+// q = W^T [in,out]) — the value a weight-only-quantised Linear multiplies with (optimum-quanto qfloat8 / torchao
+// Float8WeightOnly, toolkit/util/quantize.py:43-75).  Used to expand one layer's weight into a reusable bf16 scratch right
+// before its GEMM: 3 bytes of traffic per weight element, then the bf16 8-phase kernel runs at full speed.
+__global__ __launch_bounds__(256) void dequant_fp8_kernel(const uint8_t* q, long ldq, const float* scale, int mode, bf16_t* out, long ldo,
+                                                           int rows, int cols) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  const long total = (long)rows * cols;
+  if (i >= total) return;
+  const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+  const uint2 v = *reinterpret_cast<const uint2*>(q + (long)r * ldq + c);
+  float f[8];
+  f[0] = __builtin_amdgcn_cvt_f32_fp8(v.x, 0); f[1] = __builtin_amdgcn_cvt_f32_fp8(v.x, 1);
+  f[2] = __builtin_amdgcn_cvt_f32_fp8(v.x, 2); f[3] = __builtin_amdgcn_cvt_f32_fp8(v.x, 3);
+  f[4] = __builtin_amdgcn_cvt_f32_fp8(v.y, 0); f[5] = __builtin_amdgcn_cvt_f32_fp8(v.y, 1);
+  f[6] = __builtin_amdgcn_cvt_f32_fp8(v.y, 2); f[7] = __builtin_amdgcn_cvt_f32_fp8(v.y, 3);
+  if (mode == 1) {
+    const float sc = scale[r];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= sc;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= scale[c + e];
+  }
+  uint4 o;
+  o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+  *reinterpret_cast<uint4*>(out + (long)r * ldo + c) = o;
+}
+extern "C" int aitk_dequant_fp8(const uint8_t* q, int64_t ldq, const float* scale, int32_t mode, aitk_bf16* out, int64_t ldo,
+                                int32_t rows, int32_t cols, aitk_stream_t stream) {
+  if (!q || !scale || !out || rows <= 0 || cols <= 0 || (cols % 8) || (mode != 1 && mode != 2)) return AITK_ERR_ARG;
+  if ((ldq % 8) || (ldo % 8)) return AITK_ERR_ALIGN;
+  const long n = (long)rows * cols / 8;
+  hipLaunchKernelGGL(dequant_fp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q, (long)ldq, scale, mode, out,
+                     (long)ldo, rows, cols);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}

@@ -81,8 +81,9 @@ class FusedGraphBase(nn.Module):
     def quantize_base_fp8(self, release_bf16=False):
         """Weight-only fp8 (OCP e4m3, per-output-channel scale) for every token-GEMM Linear of the blocks — BASELINE config 5;
         the reference does this with optimum-quanto qfloat8 / torchao Float8WeightOnly (toolkit/util/quantize.py:43-75,
-        toolkit/stable_diffusion_model.py:794-801).  Activations and the LoRA adapter stay bf16 / fp32.  The GEMM dequantises
-        bf16(fp8 * scale) while staging, forward from `qweight` [out,in], dgrad from `qweight_t` [in,out].  adaLN / embedder
+        toolkit/stable_diffusion_model.py:794-801).  Activations and the LoRA adapter stay bf16 / fp32.  Each layer's weight is
+        expanded to bf16(fp8 * scale) into a shared scratch right before its GEMM (_dequant): forward from `qweight` [out,in], dgrad
+        from `qweight_t` [in,out]; aitk_gemm_nt can also consume the fp8 bytes directly (b_scale, slower).  adaLN / embedder
         projections (B rows, weight streaming) keep bf16 weights."""
         for lin in self._token_linears():
             w = lin.weight.data.float()
@@ -97,6 +98,18 @@ class FusedGraphBase(nn.Module):
         self._prepared = True
         self.is_quantized = True
         return self
+
+    def _dequant(self, q, scale, mode):
+        """Weight-only fp8 base: expand ONE layer's e4m3 weight into the shared bf16 scratch right before its GEMM (in-order on
+        the stream, so the scratch is reused by every layer).  +3 B/element of traffic (~10-40 us per layer) buys the full-speed
+        bf16 8-phase GEMM instead of a GEMM that dequantises in its load segment."""
+        n = q.shape[0] * q.shape[1]
+        buf = getattr(self, "_dq_scratch", None)
+        if buf is None or buf.numel() < n:
+            buf = self._dq_scratch = torch.empty(n, dtype=self.dt, device=q.device)
+        out = buf[:n].view(q.shape[0], q.shape[1])
+        self.ops.dequant_fp8(q, scale, mode, out)
+        return out
 
     def dequantized_weight(self, lin):
         return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)
@@ -160,17 +173,16 @@ class FusedGraphBase(nn.Module):
                 lo.y_lin = aux_out if (flags & (EPI_GELU | EPI_GATE_RES)) else out
         else:
             T = None
-        if lin.qweight is not None:
-            kw.update(b_scale=lin.wscale, b_scale_mode=1)
+        w = lin.weight if lin.qweight is None else self._dequant(lin.qweight, lin.wscale, 1)
         if "col_scale" in kw and (flags & EPI_ADD_AUX):
             # DoRA needs the bare linear output for d magnitude and the residual-add epilogue does not store it: product first,
             # residual in a second pass (Wan cross-attention out-projection only)
             y = self._new(M, lin.out_features)
-            ops.gemm_nt(x, lin.weight, y, bias=lin.bias, flags=flags & ~EPI_ADD_AUX, a_seg=a_seg, M=M, **kw)
+            ops.gemm_nt(x, w, y, bias=lin.bias, flags=flags & ~EPI_ADD_AUX, a_seg=a_seg, M=M, **kw)
             ops.ew(2, y, out, a=aux_in)
             lin.lora.y_lin = y
             return T
-        ops.gemm_nt(x, lin.qweight if lin.qweight is not None else lin.weight, out, bias=lin.bias, flags=flags, aux_out=aux_out,
+        ops.gemm_nt(x, w, out, bias=lin.bias, flags=flags, aux_out=aux_out,
                     aux_in=aux_in, gate=gate, gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
         return T
 
@@ -226,10 +238,11 @@ class FusedGraphBase(nn.Module):
         if dT is not None:
             shT = lin.lora.sh_downT
             kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
-        wt_full = lin.qweight_t if lin.qweight is not None else lin.weight_t
-        if lin.qweight is not None:
-            kw.update(b_scale=lin.wscale, b_scale_mode=2)
-        wt = wt_full if w_rows is None else wt_full[w_rows[0]:w_rows[1]]
+        if lin.qweight is not None:  # rows of W^T = input columns; scale runs along the contraction (out) axis
+            qt = lin.qweight_t if w_rows is None else lin.qweight_t[w_rows[0]:w_rows[1]]
+            wt = self._dequant(qt, lin.wscale, 2)
+        else:
+            wt = lin.weight_t if w_rows is None else lin.weight_t[w_rows[0]:w_rows[1]]
         self.ops.gemm_nt(dy, wt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, **kw)
 
     def _lin_bwd(self, lin, dy, T, x_in, dx, *, M, rows_per_batch, B, flags=0, aux_in=None, x_seg=None, dx_seg=None):

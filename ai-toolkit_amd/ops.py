@@ -497,3 +497,12 @@ def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
     a.M, a.N = M, N
     _capi.check(_capi.lib().aitk_dora_bwd(C.byref(a), _capi.stream_ptr()), "aitk_dora_bwd")
     return dz
+
+
+def dequant_fp8(q, scale, mode, out):
+    """out (bf16 [rows, cols]) = e4m3(q) * scale (per row: mode 1, per column: mode 2)."""
+    assert q.element_size() == 1 and q.dim() == 2 and q.stride(1) == 1 and out.dtype == BF16 and out.shape == q.shape and out.stride(1) == 1
+    assert scale.dtype == torch.float32 and scale.numel() == (q.shape[0] if mode == 1 else q.shape[1])
+    _capi.check(_capi.lib().aitk_dequant_fp8(_ptr(q), q.stride(0), _ptr(scale), mode, _ptr(out), out.stride(0), q.shape[0], q.shape[1],
+                                             _capi.stream_ptr()), "aitk_dequant_fp8")
+    return out

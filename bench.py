@@ -181,7 +181,7 @@ def main():
         "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else ""),
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (fp8 e4m3 base weights dequantised in the GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
+        "dtype": "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
         "config": {"workload": "FLUX.1-dev DiT LoRA r16, 1024x1024 (4096 img + 512 txt tokens), bf16, AdamW+EMA, clip 1.0",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
                    "lora_params": net.arena_p.numel(), "grad_checkpointing": False},

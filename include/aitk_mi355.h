@@ -303,6 +303,11 @@ typedef struct AitkRmsFullArgs {
 int aitk_rms_full_fwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
 int aitk_rms_full_bwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
 
+/* out[r][k] = bf16(e4m3(q[r][k]) * scale[mode == 1 ? r : k]): one layer's weight-only-fp8 base weight expanded into a reusable
+ * bf16 scratch right before its GEMM (toolkit/util/quantize.py:43-75 semantics: weight-only, bf16 arithmetic). */
+int aitk_dequant_fp8(const uint8_t* q, int64_t ldq, const float* scale, int32_t mode, aitk_bf16* out, int64_t ldo, int32_t rows,
+                     int32_t cols, aitk_stream_t stream);
+
 /* ---- DoRA (toolkit/models/DoRA.py, network_mixins.py:323-339): y = c * (x W^T + s m x A^T B^T) + b with
  * c_j = magnitude_j / ||W_j + s B_j A||, the norm detached.
  * aitk_dora_colscale: c from ||W_j||^2 (w2), tw = W A^T [N,R] (aitk_lora_down with the weight as streamed operand), up = B fp32

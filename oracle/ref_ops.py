@@ -435,3 +435,9 @@ def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
     b = bias.float() if bias is not None else torch.zeros_like(s0)
     dmag += (s1 - b * s0) / mag.float()
     return dz
+
+
+def dequant_fp8(q, scale, mode, out):
+    f = q.view(torch.float8_e4m3fn).float()
+    out.copy_((f * (scale[:, None] if mode == 1 else scale[None, :])).to(out.dtype))
+    return out
