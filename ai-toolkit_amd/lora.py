@@ -211,6 +211,7 @@ class FusedLoRANetwork(nn.Module):
         dt = torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
         self.shadow_dtype = dt
         # shadow arena: [0, n) direct copies at the fp32 arena's offsets, [n, 2n) transposed copies
+        self.n_mat = n_mat
         self.arena_shadow = torch.empty(2 * n_mat, dtype=dt, device=device)
         group_of = {}
         for gi, grp in enumerate(groups or []):

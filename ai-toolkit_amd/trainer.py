@@ -55,10 +55,11 @@ class _LoRATrainStepBase:
         import torch.distributed as dist
 
         g = self.network.arena_g
-        piece = g[self._split:] if which in ("single", "late") else g[: self._split]
-        if piece.numel() == 0:
-            return
-        self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        n_mat = getattr(self.network, "n_mat", g.numel())  # DoRA magnitude vectors sit at [n_mat, n): final only at the end
+        pieces = [g[self._split:n_mat]] if which in ("single", "late") else [g[: self._split], g[n_mat:]]
+        for piece in pieces:
+            if piece.numel():
+                self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _finish_allreduce(self):
         for w in self._pending:

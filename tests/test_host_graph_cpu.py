@@ -11,7 +11,7 @@ CFG = dict(in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim
            joint_attention_dim=64, pooled_projection_dim=32)
 
 
-def build_pair(rank=8, multiplier=1.0, seed=0, grouped=True):
+def build_pair(rank=8, multiplier=1.0, seed=0, grouped=True, network_type="lora"):
     torch.manual_seed(seed)
     ref = flux_ref.FluxTransformer2DModel(**CFG)
     flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
@@ -23,8 +23,8 @@ def build_pair(rank=8, multiplier=1.0, seed=0, grouped=True):
                 p.copy_(1 + 0.1 * torch.randn_like(p))
     nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
     missing, unexpected = nat.load_state_dict(ref.state_dict(), strict=True)
-    ref_net = lora_ref.RefLoRANetwork(ref, rank, multiplier)
-    net = FusedLoRANetwork(nat, lora_dim=rank, multiplier=multiplier)
+    ref_net = lora_ref.RefLoRANetwork(ref, rank, multiplier, network_type=network_type)
+    net = FusedLoRANetwork(nat, lora_dim=rank, multiplier=multiplier, network_type=network_type)
     assert [m.lora_name for m in net.unet_loras] == [m.lora_name for m in ref_net.unet_loras]
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():

@@ -44,11 +44,11 @@ def test_three_steps_match_oracle_optimizer_sequence():
             i += 1
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, network_type):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    ref, ref_net, nat, net = build_pair(rank=4)
+    ref, ref_net, nat, net = build_pair(rank=4, network_type=network_type)
     step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
     for k in range(2):
         lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
@@ -58,12 +58,14 @@ def _dp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
-    port = 29400 + os.getpid() % 500
-    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("network_type", ["lora", "dora"])
+def test_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path, network_type):
+    """DoRA adds the magnitude vectors at the tail of the gradient arena: they join the second all-reduce piece."""
+    port = 29400 + (os.getpid() + (7 if network_type == "dora" else 0)) % 500
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path), network_type), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert torch.equal(p0, p1), "ranks must hold bit-identical adapter weights"
-    ref, ref_net, nat, net = build_pair(rank=4)
+    ref, ref_net, nat, net = build_pair(rank=4, network_type=network_type)
     step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5)
     for k in range(2):
         lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
