@@ -21,13 +21,16 @@ class _LoRATrainStepBase:
 
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
-                 seed=None, schedule=None):
+                 seed=None, schedule=None, lr_scheduler=None):
         self.model, self.network, self.ops = model, network, ops
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.timestep_type, self.guidance = timestep_type, guidance
         self.schedule = schedule or FlowMatchTrainSchedule()
         self.step_num = 0
+        self.lr_scheduler = lr_scheduler  # LRSchedule or None (constant): stepped once per train-loop iteration
+        if lr_scheduler is not None:
+            self.lr = lr_scheduler.get_last_lr()[0]
         self.pg = process_group
         self.world = 1
         self._pending = []
@@ -48,7 +51,7 @@ class _LoRATrainStepBase:
             network.arena_ema = network.arena_p.clone()
         # arena split point: adapters at [split, n) get their final gradients first during backward
         self._split = model.grad_split_offset(network)
-        model.grad_ready_hook = self._on_grads_ready if self.world > 1 else None
+        model.grad_ready_hook = None  # set per backward pass (only the last micro-batch issues the all-reduce)
 
     # ------------------------------------------------------------------ DP
     def _on_grads_ready(self, which):
@@ -76,8 +79,26 @@ class _LoRATrainStepBase:
         m = mask.float().reshape(B, Fr, Hh // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
         return m.reshape(B, Fr * (Hh // 2) * (W // 2), 4).contiguous()
 
-    def _loss_backward_update(self, pred, target, loss_weight, loss_mask=None):
-        """MSE loss + explicit backward (caller holds `with network`), then all-reduce / clip / AdamW / EMA."""
+    def step_list(self, batches):
+        """The reference's `gradient_accumulation` batch list (SDTrainer.py:2243-2293): gradients are zeroed once, every
+        micro-batch (any bucket resolution) runs forward + backward into the same fp32 arena, the micro-batch losses are SUMMED
+        (no 1/len scaling, like the reference), then one clip / AdamW / EMA.  The DP all-reduce is issued only by the last
+        micro-batch's backward.  `batches` is a list of keyword dicts for `step`."""
+        self.network.zero_grad_arena()
+        total = None
+        for i, b in enumerate(batches):
+            loss = self._single(final=(i == len(batches) - 1), **b)
+            if len(batches) > 1:
+                total = loss.clone() if total is None else total.add_(loss)
+            else:
+                total = loss
+        self._optimizer_step()
+        if self.lr_scheduler is not None:  # SDTrainer.py:2298-2300
+            self.lr = self.lr_scheduler.step()
+        return total
+
+    def _loss_backward(self, pred, target, loss_weight, loss_mask=None, final=True):
+        """MSE loss + explicit backward accumulating into the gradient arena (caller holds `with network`)."""
         ops, model, net = self.ops, self.model, self.network
         B = pred.shape[0]
         dpred = torch.empty_like(pred)
@@ -85,8 +106,9 @@ class _LoRATrainStepBase:
             self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
                           mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
-        net.zero_grad_arena()
+        model.grad_ready_hook = self._on_grads_ready if (final and self.world > 1) else None
         model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
+        return self.loss
 
     def _optimizer_step(self):
         ops, net = self.ops, self.network
@@ -105,9 +127,18 @@ class _LoRATrainStepBase:
 
 class FluxLoRATrainStep(_LoRATrainStepBase):
     # ------------------------------------------------------------------ one step
-    def step(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None):
-        """latents [B,16,H,W] (scaled VAE latents), prompt_embeds [B,512,4096], pooled_embeds [B,768].
+    def step(self, latents, prompt_embeds, pooled_embeds, **kw):
+        """latents [B,16,H,W] (scaled VAE latents), prompt_embeds [B,512,4096], pooled_embeds [B,768]; keywords of `_single`.
         Returns the device-resident loss tensor (no host sync)."""
+        return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, **kw)])
+
+    def _single(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None,
+                preservation=None, preservation_multiplier=1.0, final=True):
+        """One micro-batch: noise / pack, forward, loss, backward.  `preservation=(prompt_embeds, pooled_embeds)` adds the
+        reference's diff-output / blank-prompt preservation term (SDTrainer.py:1229-1247, 2182-2220): the base model's
+        prediction on those embeds (adapter inactive, nothing saved) is the target of a second adapter-active pass on the same
+        noisy latents, `mse(pred, prior) * preservation_multiplier` joins the loss.  The two backward passes accumulate into
+        the same arena, which equals the reference's single backward of the summed loss."""
         ops, model, net = self.ops, self.model, self.network
         dt = model.dt
         B, Cc, Hh, W = latents.shape
@@ -126,10 +157,19 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         ops.flow_noise_pack(latents, noise, timesteps, noisy, target)
         img_ids, txt_ids = make_ids(Hh, W, prompt_embeds.shape[1], dev)
         guidance = torch.full((B,), float(self.guidance), device=dev)
+        prior = None
+        if preservation is not None:  # adapter inactive (outside `with net`): base-model prediction, no graph kept
+            prior = model.forward_native(noisy, preservation[0], preservation[1], timesteps / 1000, img_ids, txt_ids, guidance,
+                                         save_for_backward=False)
         with net:
             pred = model.forward_native(noisy, prompt_embeds, pooled_embeds, timesteps / 1000, img_ids, txt_ids, guidance)
-            self._loss_backward_update(pred, target, loss_weight, loss_mask)
-        return self._optimizer_step()
+            loss = self._loss_backward(pred, target, loss_weight, loss_mask, final=final and prior is None)
+            if prior is not None:
+                loss = loss.clone()
+                pres = model.forward_native(noisy, preservation[0], preservation[1], timesteps / 1000, img_ids, txt_ids, guidance)
+                w = torch.full((B,), float(preservation_multiplier), dtype=torch.float32, device=dev)
+                loss.add_(self._loss_backward(pres, prior, w, None, final=final))
+        return loss
 
 
 class WanLoRATrainStep(_LoRATrainStepBase):
@@ -142,8 +182,11 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         kw.setdefault("schedule", FlowMatchTrainSchedule(shift=3.0, use_dynamic_shifting=False))
         super().__init__(model, network, ops, **kw)
 
-    def step(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None):
+    def step(self, latents, prompt_embeds, **kw):
         """latents [B,16,F,H,W] (normalised Wan-VAE latents), prompt_embeds [B,512,4096] (UMT5).  Returns the loss tensor."""
+        return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, **kw)])
+
+    def _single(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None, final=True):
         ops, model, net = self.ops, self.model, self.network
         dt = model.dt
         B, Cc, Fr, Hh, W = latents.shape
@@ -166,8 +209,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
             pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, prompt_embeds, grid)
             if loss_mask is not None and loss_mask.dim() == 4:  # [B,1,H,W] -> repeated over frames (SDTrainer.py:955-958)
                 loss_mask = loss_mask[:, :, None].expand(-1, -1, Fr, -1, -1)
-            self._loss_backward_update(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight, loss_mask)
-        return self._optimizer_step()
+            return self._loss_backward(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight, loss_mask, final=final)
 
 
 def make_ids(Hh, W, n_txt, device):

@@ -96,3 +96,56 @@ def test_masked_and_weighted_loss_matches_reference_formula():
     assert torch.allclose(lps, loss_ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(loss, (loss_ref.detach() * w).mean().reshape(1), rtol=1e-5)
     assert torch.allclose(dpred, flux_ref.pack_latents(pred4.grad), rtol=1e-5, atol=1e-7)
+
+
+def _assert_adapters_match(net, ref_net, rtol=2e-3, atol=2e-6):
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for pa, pb in ((a.lora_down.weight, b.lora_down.weight), (a.lora_up.weight, b.lora_up.weight)):
+            assert torch.allclose(pa, pb, rtol=rtol, atol=atol), (a.lora_name, (pa - pb).abs().max())
+
+
+def test_batch_list_accumulation_over_two_bucket_resolutions_matches_oracle():
+    """`gradient_accumulation: 2` (SDTrainer.py:2243-2293): one zero_grad, two micro-batches of different bucket shapes,
+    summed losses, one clip + AdamW step."""
+    ref, ref_net, nat, net = build_pair(rank=4)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=0.5)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    for k in range(2):
+        b1, b2 = batch(2, seed=30 + k), batch(1, seed=40 + k, Hl=4, Wl=12, n_txt=6)
+        l_ref = oracle.step_list([dict(latents=b[0], prompt_embeds=b[1], pooled=b[2], noise=b[3], timesteps=b[4]) for b in (b1, b2)])
+        l = ours.step_list([dict(latents=b[0], prompt_embeds=b[1], pooled_embeds=b[2], noise=b[3], timesteps=b[4]) for b in (b1, b2)])
+        assert abs(l.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item()), (k, l.item(), l_ref.item())
+    _assert_adapters_match(net, ref_net)
+
+
+def test_output_preservation_pass_matches_oracle():
+    """diff_output_preservation / blank_prompt_preservation: prior = base model on the preservation embeds, second
+    adapter-active pass pulled towards it with weight `multiplier` (SDTrainer.py:1229-1247, 2182-2220)."""
+    ref, ref_net, nat, net = build_pair(rank=4)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=0.5)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    g = torch.Generator().manual_seed(77)
+    for k in range(2):
+        lat, emb, pooled, noise, ts = batch(2, seed=50 + k)
+        pres = (torch.randn(emb.shape, generator=g) * 0.5, torch.randn(pooled.shape, generator=g) * 0.5)
+        l_ref = oracle.step(lat, emb, pooled, noise, ts, preservation=pres, preservation_multiplier=0.7)
+        l = ours.step(lat, emb, pooled, noise=noise, timesteps=ts, preservation=pres, preservation_multiplier=0.7)
+        assert abs(l.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item()), (k, l.item(), l_ref.item())
+    _assert_adapters_match(net, ref_net)
+
+
+def test_lr_schedule_drives_the_fused_adamw_like_torch_scheduler():
+    from ai_toolkit_amd.lr_schedule import LRSchedule
+
+    ref, ref_net, nat, net = build_pair(rank=4)
+    kw = dict(lr=2e-3, weight_decay=0.01, max_grad_norm=0.5)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr_scheduler=lambda o: torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=3), **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, lr_scheduler=LRSchedule("cosine", 2e-3, total_iters=3), **kw)
+    for k in range(3):
+        lat, emb, pooled, noise, ts = batch(2, seed=60 + k)
+        oracle.step(lat, emb, pooled, noise, ts)
+        ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        assert ours.lr == pytest.approx(oracle.lr_scheduler.get_last_lr()[0], rel=1e-6, abs=1e-12)
+    _assert_adapters_match(net, ref_net)
