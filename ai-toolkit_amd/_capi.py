@@ -171,6 +171,13 @@ class DoraBwdArgs(C.Structure):
                 ("dz", vp), ("ld_dz", i64), ("dmag", vp), ("partial", vp), ("M", i32), ("N", i32)]
 
 
+class KronApplyArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("x_seg_stride", i64), ("A", vp), ("B", vp), ("out", vp), ("ldo", i64),
+                ("out_seg_stride", i64), ("x_seg_rows", i32), ("out_seg_rows", i32), ("M", i32), ("a_in", i32), ("b_in", i32),
+                ("a_out", i32), ("b_out", i32), ("transpose_out", i32), ("accumulate", i32), ("col0", i32), ("ncols", i32),
+                ("scale", C.c_float)]
+
+
 class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
 
@@ -179,7 +186,8 @@ EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AU
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
-            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs, 17: DoraColscaleArgs, 18: DoraBwdArgs}
+            12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs, 17: DoraColscaleArgs, 18: DoraBwdArgs,
+            19: KronApplyArgs}
 
 
 def lib():

@@ -86,6 +86,7 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 16: return (int)sizeof(AitkRmsFullArgs);
     case 17: return (int)sizeof(AitkDoraColscaleArgs);
     case 18: return (int)sizeof(AitkDoraBwdArgs);
+    case 19: return (int)sizeof(AitkKronApplyArgs);
     default: return -1;
   }
 }

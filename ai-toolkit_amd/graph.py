@@ -40,6 +40,9 @@ class _Holder(nn.Module):
     pass
 
 
+_KRON = object()  # marker travelling where the rank-r activation T / its gradient dT travel for LoRA layers
+
+
 class FusedGraphBase(nn.Module):
     """Sub-classes set: self.ops, self.dt (model dtype), and implement _token_linears() (every Linear that runs as a
     token GEMM and needs the transposed / fp8 copies)."""
@@ -158,6 +161,15 @@ class FusedGraphBase(nn.Module):
         launch) may be passed in."""
         ops = self.ops
         kw = {}
+        if self._lora_active(lin) and lin.lora.is_lokr:
+            # LoKr: the Kronecker delta is written into the destination first, the base GEMM then accumulates onto it BEFORE its
+            # activation / gate epilogue (ACCUM precedes GELU / GATE_RES in the epilogue order)
+            assert not (flags & EPI_ACCUM)
+            self._kron(lin.lora, x, out, M=M, x_seg=a_seg, out_seg=c_seg)
+            w = lin.weight if lin.qweight is None else self._dequant(lin.qweight, lin.wscale, 1)
+            ops.gemm_nt(x, w, out, bias=lin.bias, flags=flags | EPI_ACCUM, aux_out=aux_out, aux_in=aux_in, gate=gate,
+                        gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M)
+            return _KRON
         if self._lora_active(lin):
             lo = lin.lora
             if T is None:
@@ -186,11 +198,62 @@ class FusedGraphBase(nn.Module):
                     aux_in=aux_in, gate=gate, gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M, **kw)
         return T
 
+    # ------------------------------------------------------------------ LoKr (toolkit/models/lokr.py:331-399)
+    def _lokr_scale(self, lo):
+        """runtime scale * mean(network multiplier): the reference averages per-sample multipliers for LoKr (lokr.py:394-395)."""
+        mv = self.network._multiplier
+        vals = [float(v) for v in mv] if isinstance(mv, (list, tuple)) else [float(mv)]
+        return lo.scale * sum(vals) / len(vals)
+
+    def _kron(self, lo, x, out, *, M, x_seg=None, out_seg=None):
+        """out = scale * per-token lokr_w1 . X . lokr_w2^T  (the LoKr delta of one layer)."""
+        self.ops.kron_apply(x, lo.sh_up, lo.sh_down, out, a_in=lo.in_m, b_in=lo.in_n, a_out=lo.out_l, b_out=lo.out_k,
+                            scale=self._lokr_scale(lo), x_seg=x_seg, out_seg=out_seg, M=M)
+
+    def _lokr_grads(self, lo, dy, x_in, *, M, x_seg=None):
+        """Factor gradients into the fp32 arena (autograd of the reference's two einsums):
+          d lokr_w1[p,q] = sum_{m,o} dY[m,p,o] * (X_m w2^T)[q,o]        d lokr_w2[o,s] = sum_{m,q} (w1^T dY_m)[q,o] * X[m,q,s]
+        Both are skinny weight-gradient contractions over (token x factor-index) rows once the per-token intermediates are laid
+        out with the contracted index leading: aitk_kron_apply writes them (transposed where needed), aitk_lora_wgrad reduces."""
+        ops, sc = self.ops, self._lokr_scale(lo)
+        a_in, b_in, a_out, b_out = lo.in_m, lo.in_n, lo.out_l, lo.out_k
+        tmpT = self._new(M, b_out * a_in)   # [m, o, q] = (X_m w2^T)^T
+        ops.kron_apply(x_in, None, lo.sh_down, tmpT, a_in=a_in, b_in=b_in, a_out=a_in, b_out=b_out, transpose_out=True, x_seg=x_seg, M=M)
+        dyT = self._new(M, b_out * a_out)   # [m, o, p] = scale * dY_m^T
+        ops.kron_apply(dy, None, None, dyT, a_in=a_out, b_in=b_out, a_out=a_out, b_out=b_out, transpose_out=True, scale=sc, M=M)
+        self._skinny_tn(dyT.view(M * b_out, a_out), tmpT.view(M * b_out, a_in), lo.g_up, rows=M * b_out)
+        U = self._new(M, a_in * b_out)      # [m, q, o] = scale * (w1^T dY_m)
+        ops.kron_apply(dy, lo.sh_upT, None, U, a_in=a_out, b_in=b_out, a_out=a_in, b_out=b_out, scale=sc, M=M)
+        if x_in.stride(0) != a_in * b_in:   # column window of a wider buffer: gather the rows first
+            xc = self._new(M, a_in * b_in)
+            ops.kron_apply(x_in, None, None, xc, a_in=a_in, b_in=b_in, a_out=a_in, b_out=b_in, x_seg=x_seg, M=M)
+            x_in, x_seg = xc, None
+        rows = M if x_seg is None else x_seg[0]
+        xg = x_in[:rows].view(rows * a_in, b_in)
+        g_seg = None if x_seg is None else (x_seg[0] * a_in, x_seg[1])
+        self._skinny_tn(U.view(M * a_in, b_out), xg, lo.g_down, rows=M * a_in, g_seg=g_seg)
+
+    def _skinny_tn(self, s, g, out, *, rows, g_seg=None):
+        """out[R, L] (fp32) += s[rows, R]^T @ g[rows, L] through aitk_lora_wgrad (rank blocks of <= 64 columns, R % 16 == 0);
+        when R is not a multiple of 16 but L is (and L <= 64, unsegmented) the roles are swapped and the result written transposed."""
+        R, L = s.shape[1], g.shape[1]
+        if R % 16 == 0:
+            for c0 in range(0, R, 64):
+                c1 = min(R, c0 + 64)
+                self.ops.lora_wgrad(s[:, c0:c1], g, out[c0:c1], accumulate=True, g_seg=g_seg, M=rows)
+        elif L % 16 == 0 and L <= 64 and g_seg is None and R % 8 == 0:
+            self.ops.lora_wgrad(g, s, out, transpose_out=True, accumulate=True, M=rows)
+        else:
+            raise NotImplementedError(f"LoKr factor gradient {R}x{L}: needs a factor dimension that is a multiple of 16")
+
     def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
         """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None.
         With dT_out (a column slice of a group's dT buffer) the lora_down gradient is left to _group_wgrad."""
         if T is None:
             return None
+        if T is _KRON:
+            self._lokr_grads(lin.lora, dy, x_in, M=M, x_seg=x_seg)
+            return _KRON
         ops = self.ops
         lo = lin.lora
         assert lo.magnitude is None or getattr(dy, "_dora_dz", False), "DoRA: pass dy through _dora_dz() first"
@@ -235,6 +298,13 @@ class FusedGraphBase(nn.Module):
     def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
         """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""
         kw = {}
+        if dT is _KRON:  # dX_m = w1^T . dY_m . w2, written (or added) into dx ahead of the base dgrad GEMM
+            lo = lin.lora
+            c0, nc = (0, 0) if w_rows is None else (w_rows[0], w_rows[1] - w_rows[0])
+            self.ops.kron_apply(dy, lo.sh_upT, lo.sh_downT, dx, a_in=lo.out_l, b_in=lo.out_k, a_out=lo.in_m, b_out=lo.in_n,
+                                scale=self._lokr_scale(lo), accumulate=bool(flags & EPI_ACCUM), col0=c0, ncols=nc, out_seg=dx_seg, M=M)
+            flags |= EPI_ACCUM
+            dT = None
         if dT is not None:
             shT = lin.lora.sh_downT
             kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
@@ -256,6 +326,10 @@ class FusedGraphBase(nn.Module):
         mod = self._new(B, ada_lin.out_features)
         T = None
         kw = {}
+        if self._lora_active(ada_lin) and ada_lin.lora.is_lokr:
+            self._kron(ada_lin.lora, silu_temb, mod, M=B)
+            ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, accumulate=True)
+            return mod, _KRON
         if self._lora_active(ada_lin):
             lo = ada_lin.lora
             T = self._new(B, lo.lora_dim)
@@ -271,6 +345,9 @@ class FusedGraphBase(nn.Module):
     def _ada_bwd(self, ada_lin, dmod, T, silu_temb, B):
         """Only the adapter gradients: temb has no trainable ancestor, so no data gradient is propagated."""
         if T is None:
+            return
+        if T is _KRON:
+            self._lokr_grads(ada_lin.lora, dmod, silu_temb, M=B)
             return
         ops = self.ops
         lo = ada_lin.lora

@@ -30,6 +30,8 @@ LINEAR_MODULES = ["Linear", "LoRACompatibleLinear", "QLinear", "OstrisLinear"]  
 class LoRAModule(nn.Module):
     """State holder for one wrapped Linear.  The arithmetic is NOT here: the fused GEMM reads the bf16 shadows."""
 
+    is_lokr = False
+
     def __init__(self, lora_name, org_module, multiplier=1.0, lora_dim=4, alpha=1, dropout=None, rank_dropout=None,
                  module_dropout=None, network=None, use_bias=False, **kwargs):
         super().__init__()
@@ -126,16 +128,118 @@ class DoRAModule(LoRAModule):
         self.y_lin = None   # this step's linear output (c*z + b), kept for d magnitude
 
 
+def factorization(dimension: int, factor: int = -1):
+    """(m, n) with m * n == dimension, m <= n, m as close to `factor` as the divisors allow (factor -1: closest to sqrt) —
+    restates toolkit/models/lokr.py:22-59 (LyCORIS factorization)."""
+    if factor > 0 and dimension % factor == 0:
+        return factor, dimension // factor
+    if factor == -1:
+        factor = dimension
+    m, n = 1, dimension
+    length = m + n
+    while m < n:
+        new_m = m + 1
+        while dimension % new_m != 0:
+            new_m += 1
+        new_n = dimension // new_m
+        if new_m + new_n > length or new_m > factor:
+            break
+        m, n = new_m, new_n
+    if m > n:
+        n, m = m, n
+    return m, n
+
+
+class _ParamProxy:
+    """`.weight` view of a module-level nn.Parameter, so the arena builder can treat lokr_w2 / lokr_w1 like lora_down / lora_up."""
+
+    def __init__(self, module, name):
+        self._m, self._n = module, name
+
+    @property
+    def weight(self):
+        return getattr(self._m, self._n)
+
+    @weight.setter
+    def weight(self, value):
+        setattr(self._m, self._n, value)
+
+
+class LoKrModule(LoRAModule):
+    """toolkit/models/lokr.py:76-242 for a Linear with full factors (the reference's default `lokr_full_rank: true`,
+    toolkit/config_modules.py:204-209): delta W = kron(lokr_w1 [out_l, in_m], lokr_w2 [out_k, in_n]) * scale,
+    (out_l, out_k) = factorization(out), (in_m, in_n) = factorization(in); lokr_w2 = 0, lokr_w1 kaiming-uniform at init (one RNG
+    draw, like the reference); both factors full => alpha = lora_dim => scale 1.  The arithmetic is aitk_kron_apply (per-token
+    A . X . B^T, csrc/kron.hip) — kron(w1, w2) is never formed.  In the arena lokr_w2 takes the `down` slot, lokr_w1 the `up` slot."""
+
+    is_lokr = True
+
+    def __init__(self, lora_name, org_module, multiplier=1.0, lora_dim=4, alpha=1, network=None, factor=-1, **kwargs):
+        nn.Module.__init__(self)
+        self.can_merge_in = False  # merging kron(w1, w2) into the base weight is not on the fused path yet
+        self.network_ref = weakref.ref(network) if network is not None else (lambda: None)
+        self.is_checkpointing = False
+        self._multiplier = None
+        self.lora_name = lora_name
+        self.orig_module_ref = weakref.ref(org_module)
+        self.lora_dim = lora_dim
+        self.full_rank = False
+        in_dim, out_dim = org_module.in_features, org_module.out_features
+        self.in_m, self.in_n = factorization(in_dim, int(factor))
+        self.out_l, self.out_k = factorization(out_dim, int(factor))
+        if lora_dim < max(self.out_k, self.in_n) / 2:
+            raise NotImplementedError("low-rank lokr_w2 (lokr_full_rank: false) is not on the fused path")
+        if self.in_n % 8 or self.out_k % 8:
+            raise NotImplementedError(f"LoKr factor {self.out_k}x{self.in_n}: the kron kernel needs multiples of 8")
+        self.use_w1 = self.use_w2 = True
+        self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))
+        self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
+        if isinstance(alpha, torch.Tensor):
+            alpha = float(alpha.detach().float().item())
+        alpha = lora_dim if alpha is None or alpha == 0 else alpha
+        alpha = lora_dim  # both factors full: scale 1 (lokr.py:203-206)
+        self._set_runtime_scale(float(alpha) / lora_dim)
+        self.register_buffer("alpha", torch.tensor(alpha))
+        nn.init.constant_(self.lokr_w2, 0)
+        nn.init.kaiming_uniform_(self.lokr_w1, a=math.sqrt(5))
+        self.magnitude = None
+        self.multiplier = multiplier
+        self.org_module = [org_module]
+        self.dropout = self.rank_dropout = self.module_dropout = None
+        self._in, self._out = in_dim, out_dim
+        self.off_down = self.off_up = -1
+        self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
+        self.g_down = self.g_up = None
+
+    @property
+    def lora_down(self):
+        return _ParamProxy(self, "lokr_w2")
+
+    @property
+    def lora_up(self):
+        return _ParamProxy(self, "lokr_w1")
+
+    @property
+    def in_features(self):
+        return self._in
+
+    @property
+    def out_features(self):
+        return self._out
+
+
 class FusedLoRANetwork(nn.Module):
     """Drop-in for LoRASpecialNetwork on transformer (PEFT-format) models."""
 
     def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
                  transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
-                 is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1"):
+                 is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1):
         super().__init__()
         assert peft_format and is_transformer, "kohya-format UNet naming is a later row (SURVEY.md §8f.3)"
-        assert network_type.lower() in ("lora", "dora"), "LoKr / full-rank adapters are not on the fused path"
-        module_class = DoRAModule if network_type.lower() == "dora" else LoRAModule  # toolkit/lora_special.py:403-405
+        assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
+        # toolkit/lora_special.py:403-408
+        module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]
+        module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
         self.lora_dim = lora_dim
         self.network_type = network_type
         self.peft_format = True
@@ -175,7 +279,7 @@ class FusedLoRANetwork(nn.Module):
                 if lora_name in names:
                     continue
                 names.add(lora_name)
-                lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self)
+                lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self, **module_kwargs)
                 self.unet_loras.append(lora)
         for lora in self.unet_loras:
             self.add_module(lora.lora_name, lora)
@@ -370,6 +474,8 @@ class FusedLoRANetwork(nn.Module):
         for m in self.unet_loras:  # named_parameters() order of the reference modules
             if m.magnitude is not None:
                 params.extend([m.magnitude, m.lora_up.weight, m.lora_down.weight])
+            elif getattr(m, "is_lokr", False):
+                params.extend([m.lokr_w1, m.lokr_w2])
             else:
                 params.extend([m.lora_down.weight, m.lora_up.weight])
         group = {"params": params}
@@ -384,6 +490,13 @@ class FusedLoRANetwork(nn.Module):
         sd = OrderedDict()
         for m in self.get_all_modules():
             base = m.lora_name.replace("$$", ".")
+            if getattr(m, "is_lokr", False):  # <name>.lokr_w1 / .lokr_w2 / .alpha — LoKr keeps alpha (network_mixins.py:613-616)
+                for key, w, off in (("lokr_w1", m.lokr_w1.detach(), m.off_up), ("lokr_w2", m.lokr_w2.detach(), m.off_down)):
+                    if src is not None:
+                        w = src[off:off + w.numel()].view_as(w)
+                    sd[f"{base}.{key}"] = w.clone().to("cpu").to(dtype)
+                sd[f"{base}.alpha"] = m.alpha.detach().clone().to("cpu").to(dtype)
+                continue
             for which, lin, off in (("lora_A", m.lora_down, m.off_down), ("lora_B", m.lora_up, m.off_up)):
                 w = lin.weight.detach()
                 if src is not None:
@@ -421,8 +534,11 @@ class FusedLoRANetwork(nn.Module):
         with torch.no_grad():
             for k, v in sd.items():
                 hit = False
-                for which, attr in ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up")):
+                for which, attr in ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up"), (".lokr_w1", "lora_up"),
+                                    (".lokr_w2", "lora_down")):
                     if k.endswith(which) and k[: -len(which)] in by_name:
+                        if which.startswith(".lokr") != bool(getattr(by_name[k[: -len(which)]], "is_lokr", False)):
+                            continue
                         w = getattr(by_name[k[: -len(which)]], attr).weight
                         v = v.to(w.device, torch.float32)
                         if v.shape != w.shape:
@@ -436,6 +552,8 @@ class FusedLoRANetwork(nn.Module):
                 if k.endswith(".magnitude") and k[: -len(".magnitude")] in by_name and by_name[k[: -len(".magnitude")]].magnitude is not None:
                     by_name[k[: -len(".magnitude")]].magnitude.copy_(v.to(self.arena_p.device, torch.float32))
                     hit = True
+                if k.endswith(".alpha") and k[: -len(".alpha")] in by_name:
+                    hit = True  # constant buffer (LoKr files carry it)
                 if not hit:
                     extra[k] = v
         return extra if len(extra) else None
@@ -451,6 +569,8 @@ class FusedLoRANetwork(nn.Module):
         ops = ops or self._ops
         if self.network_type.lower() == "dora":
             return  # toolkit/network_mixins.py:894-897
+        if self.network_type.lower() == "lokr":
+            raise NotImplementedError("merging kron(lokr_w1, lokr_w2) into the base weights is not on the fused path yet")
         self.refresh_shadows(ops)
         for m in self.get_all_modules():
             lin = m.org_module[0]
@@ -475,17 +595,28 @@ class FusedLoRANetwork(nn.Module):
         """kaiming-uniform lora_down, zero lora_up (network_mixins.py reset_weights), e.g. after a merge-and-reset cycle."""
         with torch.no_grad():
             for m in self.get_all_modules():
+                if getattr(m, "is_lokr", False):
+                    nn.init.constant_(m.lokr_w2, 0)
+                    nn.init.kaiming_uniform_(m.lokr_w1, a=math.sqrt(5))
+                    continue
                 nn.init.kaiming_uniform_(m.lora_down.weight, a=math.sqrt(5))
                 nn.init.zeros_(m.lora_up.weight)
 
     # ------------------------------------------------------------------ optimizer state checkpoint (BaseSDTrainProcess.py:701-714)
+    @staticmethod
+    def _opt_order(m):
+        """(holder, arena offset) in the reference module's named_parameters() order."""
+        if getattr(m, "is_lokr", False):
+            return ((m.lora_up, m.off_up), (m.lora_down, m.off_down))  # lokr_w1, lokr_w2
+        return ((m.lora_down, m.off_down), (m.lora_up, m.off_up))
+
     def optimizer_state_dict(self, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01):
         """The fused AdamW state exported in torch.optim.AdamW.state_dict() layout (params in prepare_optimizer_params
         order), so `optimizer.pt` written here can be loaded by the reference's torch optimizer and vice versa."""
         state, ids = {}, []
         i = 0
         for m in self.unet_loras:
-            for lin, off in ((m.lora_down, m.off_down), (m.lora_up, m.off_up)):
+            for lin, off in self._opt_order(m):
                 n = lin.weight.numel()
                 state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.arena_m[off:off + n].view_as(lin.weight).clone().cpu(),
                             "exp_avg_sq": self.arena_v[off:off + n].view_as(lin.weight).clone().cpu()}
@@ -499,7 +630,7 @@ class FusedLoRANetwork(nn.Module):
         """Inverse of optimizer_state_dict; returns the step count."""
         i, step = 0, 0
         for m in self.unet_loras:
-            for lin, off in ((m.lora_down, m.off_down), (m.lora_up, m.off_up)):
+            for lin, off in self._opt_order(m):
                 n = lin.weight.numel()
                 st = sd["state"][i]
                 self.arena_m[off:off + n].copy_(st["exp_avg"].reshape(-1))

@@ -499,6 +499,31 @@ def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
     return dz
 
 
+def kron_apply(x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale=1.0, transpose_out=False, accumulate=False, col0=0, ncols=0,
+               x_seg=None, out_seg=None, M=None):
+    """LoKr per-token product: out[m] (viewed [a_out, b_out], or [b_out, a_out] when transpose_out) (+)=
+    scale * A[a_out,a_in] @ x[m].view(a_in, b_in) @ Bm[b_out,b_in]^T;  A / Bm None = identity.  Only columns
+    [col0, col0+ncols) of each output row are written (ncols 0: all) — `out` is then the destination window."""
+    a = _capi.KronApplyArgs()
+    a.ldx = _row_major(x, "x")
+    a.ldo = _row_major(out, "out")
+    assert x.shape[1] == a_in * b_in, (tuple(x.shape), a_in, b_in)
+    for mat, r, c in ((A, a_out, a_in), (Bm, b_out, b_in)):
+        if mat is not None:
+            assert mat.dtype == BF16 and mat.is_contiguous() and tuple(mat.shape) == (r, c), (tuple(mat.shape), r, c)
+    a.x, a.A, a.B, a.out = _ptr(x), _ptr(A), _ptr(Bm), _ptr(out)
+    if x_seg is not None:
+        a.x_seg_rows, a.x_seg_stride = x_seg
+    if out_seg is not None:
+        a.out_seg_rows, a.out_seg_stride = out_seg
+    a.M = x.shape[0] if M is None else M
+    a.a_in, a.b_in, a.a_out, a.b_out = a_in, b_in, a_out, b_out
+    assert out.shape[1] == (ncols if ncols else a_out * b_out)
+    a.transpose_out, a.accumulate, a.col0, a.ncols, a.scale = int(transpose_out), int(accumulate), col0, ncols, float(scale)
+    _capi.check(_capi.lib().aitk_kron_apply(C.byref(a), _capi.stream_ptr()), "aitk_kron_apply")
+    return out
+
+
 def dequant_fp8(q, scale, mode, out):
     """out (bf16 [rows, cols]) = e4m3(q) * scale (per row: mode 1, per column: mode 2)."""
     assert q.element_size() == 1 and q.dim() == 2 and q.stride(1) == 1 and out.dtype == BF16 and out.shape == q.shape and out.stride(1) == 1

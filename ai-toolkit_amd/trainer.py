@@ -33,6 +33,7 @@ class _LoRATrainStepBase:
             self.lr = lr_scheduler.get_last_lr()[0]
         self.pg = process_group
         self.world = 1
+        self.dp = process_group is not None  # a 1-rank group still walks the all-reduce path (RCCL smoke on one GPU)
         self._pending = []
         if process_group is not None:
             import torch.distributed as dist
@@ -106,7 +107,7 @@ class _LoRATrainStepBase:
             self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
                           mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
-        model.grad_ready_hook = self._on_grads_ready if (final and self.world > 1) else None
+        model.grad_ready_hook = self._on_grads_ready if (final and self.dp) else None
         model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
         return self.loss
 
@@ -114,7 +115,7 @@ class _LoRATrainStepBase:
         ops, net = self.ops, self.network
         self.step_num += 1
         grad_scale = 1.0
-        if self.world > 1:
+        if self.dp:
             self._finish_allreduce()
             grad_scale = 1.0 / self.world
         ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],

@@ -24,7 +24,7 @@ FLOP_PER_IMAGE = 163.6e12  # fwd 74.4 + bwd 89.2 TFLOP, no reco
 PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
 
 
-def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False):
+def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False, network_type="lora"):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -37,10 +37,15 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=Fa
             if mod.__class__.__name__ == "Linear":
                 mod.weight.copy_((torch.randn(mod.weight.shape, device=dev, generator=g) * 0.02).to(torch.bfloat16))
     torch.manual_seed(1234)
-    net = FusedLoRANetwork(model, lora_dim=rank)
+    if network_type == "lokr":  # full Kronecker factors (the reference's lokr_full_rank default), not the headline metric
+        net = FusedLoRANetwork(model, lora_dim=9999999999, alpha=9999999999, network_type="lokr")
+    else:
+        net = FusedLoRANetwork(model, lora_dim=rank, network_type=network_type)
     with torch.no_grad():  # "warm" adapter so dA != 0 from step 0
         for m in net.unet_loras:
-            m.lora_up.weight.normal_(0, 1e-3)
+            m.lora_up.weight.normal_(0, 1e-3)  # LoKr: lokr_w1 takes the `up` slot and is already non-zero; w2 below
+            if network_type == "lokr":
+                m.lokr_w2.normal_(0, 1e-3)
     net.apply_to()
     net.build_arena(dev, ema=ema, groups=model.lora_groups())
     net.refresh_shadows(ops)
@@ -125,6 +130,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AITK_BENCH_BATCH", "4")), help="per-GPU batch")
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--fp8-base", action="store_true", help="BASELINE config 5 variant (not the headline metric): fp8 e4m3 base weights")
+    ap.add_argument("--network", default="lora", choices=["lora", "dora", "lokr"], help="adapter type (headline metric: lora)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -137,16 +143,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("AITK_BENCH_FORCE_PG"):  # FORCE_PG: 1-rank RCCL group, exercises the collective path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
 
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
 
-    model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base)
+    model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base, network_type=args.network)
     step = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99,
                              timestep_type="linear", process_group=pg, seed=1000 + rank)
     B = args.batch
@@ -178,7 +185,8 @@ def main():
     final_loss = float(loss.item())
     ips = world * B * args.steps / dt
     out = {
-        "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else ""),
+        "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else "")
+                  + (f" [adapter: {args.network}]" if args.network != "lora" else ""),
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",

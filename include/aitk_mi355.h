@@ -308,6 +308,25 @@ int aitk_rms_full_bwd(const AitkRmsFullArgs* args, aitk_stream_t stream);
 int aitk_dequant_fp8(const uint8_t* q, int64_t ldq, const float* scale, int32_t mode, aitk_bf16* out, int64_t ldo, int32_t rows,
                      int32_t cols, aitk_stream_t stream);
 
+/* ---- LoKr (Kronecker adapter; reference toolkit/models/lokr.py:331-399 _call_forward_fast_linear, factor shapes 136-188).
+ * Per token m:   out_m[a_out x b_out] = scale * A[a_out x a_in] . X_m[a_in x b_in] . B[b_out x b_in]^T
+ * X_m = row m of x viewed (a_in, b_in) row-major (the reference's x.unflatten(-1, (in_m, in_n))), out row m viewed
+ * (a_out, b_out) row-major — (b_out, a_out) when transpose_out.  A / B are dense row-major bf16 with leading dimension a_in /
+ * b_in; NULL = identity (then a_out == a_in / b_out == b_in).  forward delta: A = lokr_w1, B = lokr_w2; data gradient: the
+ * transposed factors; one factor NULL: the intermediates of the factor gradients (ai-toolkit_amd/graph.py _lokr_grads).
+ * Only columns [col0, col0 + ncols) of each output row are written, to out + row + (j - col0) (ncols == 0: all); accumulate: +=.
+ * x / out rows may be segmented like AitkGemmArgs.A / .C.  b_in % 8 == b_out % 8 == 0; any a_in, a_out. */
+typedef struct AitkKronApplyArgs {
+  const aitk_bf16* x; int64_t ldx; int64_t x_seg_stride;
+  const aitk_bf16* A; const aitk_bf16* B;
+  aitk_bf16* out; int64_t ldo; int64_t out_seg_stride;
+  int32_t x_seg_rows, out_seg_rows;
+  int32_t M, a_in, b_in, a_out, b_out;
+  int32_t transpose_out, accumulate, col0, ncols;
+  float scale;
+} AitkKronApplyArgs;
+int aitk_kron_apply(const AitkKronApplyArgs* args, aitk_stream_t stream);
+
 /* ---- DoRA (toolkit/models/DoRA.py, network_mixins.py:323-339): y = c * (x W^T + s m x A^T B^T) + b with
  * c_j = magnitude_j / ||W_j + s B_j A||, the norm detached.
  * aitk_dora_colscale: c from ||W_j||^2 (w2), tw = W A^T [N,R] (aitk_lora_down with the weight as streamed operand), up = B fp32

@@ -89,11 +89,69 @@ class RefDoRAModule(nn.Module):
         return org + lx + dora.to(org.dtype)
 
 
+def factorization(dimension, factor=-1):
+    """toolkit/models/lokr.py:22-59."""
+    if factor > 0 and dimension % factor == 0:
+        return factor, dimension // factor
+    if factor == -1:
+        factor = dimension
+    m, n = 1, dimension
+    length = m + n
+    while m < n:
+        new_m = m + 1
+        while dimension % new_m != 0:
+            new_m += 1
+        new_n = dimension // new_m
+        if new_m + new_n > length or new_m > factor:
+            break
+        m, n = new_m, new_n
+    if m > n:
+        n, m = m, n
+    return m, n
+
+
+class RefLokrModule(nn.Module):
+    """toolkit/models/lokr.py:76-242 (Linear, both factors full) + the factorised forward 331-399:
+        X = x.unflatten(-1, (in_m, in_n)); tmp = einsum('...qs,os->...qo', X, w2); delta = einsum('...qo,pq->...po', tmp, w1*scale)
+        out = org(x) + delta.flatten(-2) * mean(multiplier), computed in the base output's dtype."""
+
+    def __init__(self, lora_name, org_module, lora_dim, alpha, network, factor=-1):
+        super().__init__()
+        self.lora_name = lora_name
+        self.lora_dim = lora_dim
+        self.in_m, self.in_n = factorization(org_module.in_features, factor)
+        self.out_l, self.out_k = factorization(org_module.out_features, factor)
+        assert lora_dim >= max(self.out_k, self.in_n) / 2, "oracle restates the full-factor case only"
+        self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))
+        self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
+        self.scale = 1.0  # alpha forced to lora_dim when both factors are full
+        self.register_buffer("alpha", torch.tensor(lora_dim))
+        nn.init.constant_(self.lokr_w2, 0)
+        nn.init.kaiming_uniform_(self.lokr_w1, a=math.sqrt(5))
+        self.org_module = [org_module]
+        self.network = [network]
+
+    def apply_to(self):
+        self.org_forward = self.org_module[0].forward
+        self.org_module[0].forward = self.forward
+
+    def forward(self, x, *args, **kwargs):
+        net = self.network[0]
+        if not net.is_active or net.multiplier_is_zero():
+            return self.org_forward(x, *args, **kwargs)
+        org = self.org_forward(x, *args, **kwargs)
+        dt = org.dtype
+        X = x.to(dt).unflatten(-1, (self.in_m, self.in_n))
+        tmp = torch.einsum("...qs,os->...qo", X, self.lokr_w2.to(dt))
+        delta = torch.einsum("...qo,pq->...po", tmp, self.lokr_w1.to(dt) * self.scale).flatten(-2, -1)
+        return (org + delta * net.torch_multiplier.mean().to(dt)).to(x.dtype)
+
+
 class RefLoRANetwork(nn.Module):
     """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
 
     def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",),
-                 network_type="lora"):
+                 network_type="lora", lokr_factor=-1):
         super().__init__()
         self.is_active = False
         self.torch_multiplier = torch.tensor([float(multiplier)])
@@ -107,6 +165,9 @@ class RefLoRANetwork(nn.Module):
                 clean = ".".join([x for x in ("transformer", name, child_name) if x])
                 lora_name = clean.replace(".", "$$")
                 if not any(b in clean for b in block_names):
+                    continue
+                if network_type == "lokr":
+                    self.unet_loras.append(RefLokrModule(lora_name, child, lora_dim, lora_dim, self, factor=lokr_factor))
                     continue
                 cls = RefDoRAModule if network_type == "dora" else RefLoRAModule
                 self.unet_loras.append(cls(lora_name, child, lora_dim, lora_dim, self))
@@ -129,8 +190,9 @@ class RefLoRANetwork(nn.Module):
     def peft_state_dict(self, dtype=torch.float16):
         """PEFT renaming of toolkit/network_mixins.py:607-624."""
         sd = OrderedDict()
+        lokr = any(isinstance(m, RefLokrModule) for m in self.unet_loras)
         for k, v in self.state_dict().items():
-            if k.endswith(".alpha"):
+            if k.endswith(".alpha") and not lokr:  # LoKr files keep alpha (network_mixins.py:613-616)
                 continue
             k = k.replace("lora_down", "lora_A").replace("lora_up", "lora_B").replace("$$", ".")
             sd[k] = v.detach().clone().to("cpu").to(dtype)

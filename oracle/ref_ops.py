@@ -441,3 +441,25 @@ def dequant_fp8(q, scale, mode, out):
     f = q.view(torch.float8_e4m3fn).float()
     out.copy_((f * (scale[:, None] if mode == 1 else scale[None, :])).to(out.dtype))
     return out
+
+
+def kron_apply(x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale=1.0, transpose_out=False, accumulate=False, col0=0, ncols=0,
+               x_seg=None, out_seg=None, M=None):
+    """LoKr per-token product (toolkit/models/lokr.py:331-399): X = x.unflatten(-1, (a_in, b_in));
+    tmp = einsum('mqs,os->mqo', X, Bm) rounded to the storage dtype; out = scale * einsum('mqo,pq->mpo', tmp, A)."""
+    if M is None:
+        M = x.shape[0]
+    X = _seg_view(x, x_seg, M).float().reshape(M, a_in, b_in)
+    tmp = X if Bm is None else torch.einsum("mqs,os->mqo", X, Bm.float())
+    if A is not None and Bm is not None:
+        tmp = tmp.to(out.dtype).float()  # the kernel keeps the intermediate in the storage dtype (as the reference does)
+    res = (tmp if A is None else torch.einsum("mqo,pq->mpo", tmp, A.float())) * scale
+    if transpose_out:
+        res = res.transpose(1, 2)
+    res = res.reshape(M, a_out * b_out)
+    if ncols:
+        res = res[:, col0:col0 + ncols]
+    if accumulate:
+        res = res + _seg_view(out, out_seg, M).float()
+    _seg_store(out, out_seg, M, res)
+    return out

@@ -169,6 +169,58 @@ def golden_dora():
     print("dora golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors")
 
 
+def golden_lokr():
+    """Reference LoRASpecialNetwork(network_type='lokr') (full factors, factor -1) on the tiny FLUX oracle: factor shapes, the
+    init it draws under the same seed, forward, every factor gradient and the saved state dict (keys + values, alpha kept)."""
+    from types import SimpleNamespace
+
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    torch.manual_seed(99)
+    big = 9999999999  # toolkit/config_modules.py:204-209 (lokr_full_rank)
+    net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=big, alpha=big, multiplier=1.0, train_text_encoder=False,
+                             train_unet=True, is_flux=True, target_lin_modules=["FluxTransformer2DModel"], transformer_only=True,
+                             network_type="lokr", network_config=SimpleNamespace(lokr_factor=-1, old_lokr_format=False))
+    out = {}
+    shapes = {}
+    for m in net.unet_loras:
+        out[f"init/{m.lora_name}/w1"] = m.lokr_w1.detach().clone()
+        assert float(m.lokr_w2.abs().max()) == 0.0
+        shapes[m.lora_name] = [list(m.lokr_w1.shape), list(m.lokr_w2.shape)]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lokr_w2.copy_(torch.randn(m.lokr_w2.shape, generator=g) * 0.05)
+            out[f"set/{m.lora_name}/w2"] = m.lokr_w2.detach().clone()
+    net.force_to("cpu", torch.float32)
+    net._update_torch_multiplier()
+    net.apply_to(None, model, False, True)
+    net.is_active = True
+    pred = model(*tiny_inputs())
+    w = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+    (pred * w).sum().backward()
+    out["fwd/pred"] = pred.detach().clone()
+    out["fwd/w"] = w
+    for m in net.unet_loras:
+        out[f"grad/{m.lora_name}/w1"] = m.lokr_w1.grad.clone()
+        out[f"grad/{m.lora_name}/w2"] = m.lokr_w2.grad.clone()
+    sd = net.get_state_dict(dtype=torch.float32)
+    for k, v in sd.items():
+        out["saved/" + k] = v.clone()
+    meta = {"names": json.dumps([m.lora_name for m in net.unet_loras]), "saved_keys": json.dumps(list(sd.keys())),
+            "shapes": json.dumps(shapes), "scale": json.dumps(net.unet_loras[0].scale),
+            "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()])}
+    from toolkit.models.lokr import factorization
+
+    dims = (64, 127, 128, 250, 256, 360, 512, 768, 1024, 1280, 1536, 3072, 8960, 9216, 12288, 15360, 18432)
+    meta["factorization"] = json.dumps({f"{d}:{f}": list(factorization(d, f)) for d in dims for f in (-1, 2, 4, 8, 16)})
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "lokr_flux_tiny.safetensors"), meta)
+    print("lokr golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale)
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -193,5 +245,6 @@ def golden_wan_lora_keys():
 if __name__ == "__main__":
     golden_lora()
     golden_dora()
+    golden_lokr()
     golden_flowmatch()
     golden_wan_lora_keys()

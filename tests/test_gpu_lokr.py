@@ -1,0 +1,181 @@
+"""LoKr on the MI355X through the C ABI: aitk_kron_apply (per-token A . X . B^T, every mode the graph uses) against the oracle's
+function of the same name, and one full LoKr train step against the fp32 autograd oracle (reference LoKr semantics are pinned
+on CPU in tests/test_lokr_cpu.py against vectors produced by the reference's LokrModule)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+SHAPES = [  # a_in, b_in, a_out, b_out, M
+    (48, 64, 48, 64, 1000),    # FLUX 3072 -> 3072
+    (48, 64, 96, 128, 777),    # 3072 -> 12288
+    (120, 128, 48, 64, 300),   # 15360 -> 3072 (single-block proj_out; a_in padded to 128)
+    (48, 64, 128, 144, 4),     # adaLN 3072 -> 18432 on B rows
+    (96, 128, 48, 64, 260),    # 12288 -> 3072
+    (128, 144, 48, 64, 9),     # 18432 features per row: longer than the register prefetch window (direct staging path)
+    (16, 16, 24, 32, 64),      # tiny-model shapes (pads in every dimension)
+    (32, 40, 16, 16, 130),
+    (80, 112, 32, 48, 200),    # Wan 8960 -> 1536
+]
+
+
+@pytest.mark.parametrize("a_in,b_in,a_out,b_out,M", SHAPES)
+def test_kron_apply_full_product_and_data_gradient_form(a_in, b_in, a_out, b_out, M):
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(a_in * 7 + b_out)
+    x = torch.randn(M, a_in * b_in, generator=g).to(BF).cuda()
+    A = (torch.randn(a_out, a_in, generator=g) / math.sqrt(a_in)).to(BF).cuda()
+    Bm = (torch.randn(b_out, b_in, generator=g) / math.sqrt(b_in)).to(BF).cuda()
+    kw = dict(a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_out)
+    out, ref = torch.empty(M, a_out * b_out, dtype=BF, device="cuda"), torch.empty(M, a_out * b_out, dtype=BF, device="cuda")
+    ops.kron_apply(x, A, Bm, out, scale=0.7, **kw)
+    ref_ops.kron_apply(x, A, Bm, ref, scale=0.7, **kw)
+    assert _rel(out, ref) < 4e-3, _rel(out, ref)
+    # equals F.linear(x, kron(A, B)) — the un-factorised definition (toolkit/models/lokr.py make_kron)
+    if a_in * b_in * a_out * b_out <= 3072 * 3072:
+        dense = x.float() @ torch.kron(A.float(), Bm.float()).t() * 0.7
+        assert _rel(out, dense) < 8e-3
+    # transposed output, accumulate, column window
+    outT, refT = torch.empty_like(out), torch.empty_like(ref)
+    ops.kron_apply(x, A, Bm, outT, transpose_out=True, **kw)
+    ref_ops.kron_apply(x, A, Bm, refT, transpose_out=True, **kw)
+    assert _rel(outT, refT) < 4e-3
+    base = torch.randn(M, a_out * b_out, generator=g).to(BF).cuda()
+    acc, acc_r = base.clone(), base.clone()
+    ops.kron_apply(x, A, Bm, acc, accumulate=True, **kw)
+    ref_ops.kron_apply(x, A, Bm, acc_r, accumulate=True, **kw)
+    assert _rel(acc, acc_r) < 4e-3
+    n = a_out * b_out
+    c0, nc = (n // 16) * 8, (n // 32) * 8
+    wide = torch.zeros(M, nc + 24, dtype=BF, device="cuda")
+    win, win_r = wide[:, 8:8 + nc], torch.zeros(M, nc, dtype=BF, device="cuda")
+    ops.kron_apply(x, A, Bm, win, col0=c0, ncols=nc, **kw)
+    ref_ops.kron_apply(x, A, Bm, win_r, col0=c0, ncols=nc, **kw)
+    assert _rel(win, win_r) < 4e-3 and float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + nc:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("a_in,b_in,a_out,b_out,M", SHAPES[:4] + SHAPES[5:7])
+def test_kron_apply_identity_factor_modes(a_in, b_in, a_out, b_out, M):
+    """the intermediates of the factor gradients: (I, B) transposed, (A, I), and the pure per-token transpose."""
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(b_in * 3 + a_out)
+    x = torch.randn(M, a_in * b_in, generator=g).to(BF).cuda()
+    A = (torch.randn(a_out, a_in, generator=g) / math.sqrt(a_in)).to(BF).cuda()
+    Bm = (torch.randn(b_out, b_in, generator=g) / math.sqrt(b_in)).to(BF).cuda()
+    for Aop, Bop, ao, bo, tr in ((None, Bm, a_in, b_out, True), (None, Bm, a_in, b_out, False), (A, None, a_out, b_in, False),
+                                 (A, None, a_out, b_in, True), (None, None, a_in, b_in, True), (None, None, a_in, b_in, False)):
+        out = torch.empty(M, ao * bo, dtype=BF, device="cuda")
+        ref = torch.empty_like(out)
+        kw = dict(a_in=a_in, b_in=b_in, a_out=ao, b_out=bo, transpose_out=tr, scale=1.3)
+        ops.kron_apply(x, Aop, Bop, out, **kw)
+        ref_ops.kron_apply(x, Aop, Bop, ref, **kw)
+        assert _rel(out, ref) < 4e-3, (Aop is None, Bop is None, tr, _rel(out, ref))
+    # identity x identity without scale is a bit-exact (transposing) copy
+    out = torch.empty(M, a_in * b_in, dtype=BF, device="cuda")
+    ops.kron_apply(x, None, None, out, a_in=a_in, b_in=b_in, a_out=a_in, b_out=b_in, transpose_out=True)
+    assert torch.equal(out.view(M, b_in, a_in), x.view(M, a_in, b_in).transpose(1, 2))
+
+
+def test_kron_apply_segmented_rows():
+    """rows of the image stream inside the joint [B, S, C] buffer (x_seg) and a segmented destination (out_seg)."""
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(1)
+    B, S, St, a_in, b_in, a_out, b_out = 3, 40, 8, 16, 16, 16, 16
+    C = a_in * b_in
+    joint = torch.randn(B, S, C, generator=g).to(BF).cuda()
+    A = (torch.randn(a_out, a_in, generator=g) / 4).to(BF).cuda()
+    Bm = (torch.randn(b_out, b_in, generator=g) / 4).to(BF).cuda()
+    Si = S - St
+    seg = (Si, S * C)
+    xv = joint.view(B * S, C)[St:St + Si]
+    dst, dst_r = torch.zeros(B, S, C, dtype=BF, device="cuda"), torch.zeros(B, S, C, dtype=BF, device="cuda")
+    kw = dict(a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_out, x_seg=seg, out_seg=seg, M=B * Si)
+    ops.kron_apply(xv, A, Bm, dst.view(B * S, C)[St:St + Si], **kw)
+    ref_ops.kron_apply(xv, A, Bm, dst_r.view(B * S, C)[St:St + Si], **kw)
+    assert _rel(dst, dst_r) < 4e-3 and float(dst[:, :St].abs().max()) == 0
+    want = torch.einsum("bmqo,pq->bmpo", torch.einsum("bmqs,os->bmqo", joint[:, St:].float().view(B, Si, a_in, b_in), Bm.float()), A.float())
+    assert _rel(dst[:, St:], want.reshape(B, Si, C)) < 8e-3
+
+
+def test_lokr_train_step_vs_fp32_oracle():
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import flux_ref, lora_ref, train_ref
+    from tests.test_gpu_e2e import CFG as CFG3
+
+    CFG = dict(CFG3, num_attention_heads=2)  # d = 256: every Kronecker factor of the model is a multiple of 8
+    dev, big = "cuda", 9999999999
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.03)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.to(BF).float())
+    ref = ref.to(dev)
+    nat = FluxTransformer2DModel(**CFG, dtype=BF, device=dev, ops=ops)
+    nat.load_state_dict({k: v.to(BF) for k, v in ref.state_dict().items()}, strict=True)
+    torch.manual_seed(5)
+    ref_net = lora_ref.RefLoRANetwork(ref, big, network_type="lokr").to(dev)
+    torch.manual_seed(5)
+    net = FusedLoRANetwork(nat, lora_dim=big, alpha=big, network_type="lokr")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.equal(a.lokr_w1, b.lokr_w1.cpu())
+            w2 = torch.randn(b.lokr_w2.shape, generator=g) * 0.03
+            b.lokr_w2.copy_(w2)
+            a.lokr_w2.copy_(w2)
+    ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena(dev, groups=nat.lora_groups())
+    net.refresh_shadows(ops)
+    nat.attach_network(net)
+    nat.prepare()
+    gb = torch.Generator().manual_seed(5)
+    Bn, Hl, Wl, n_txt = 2, 16, 12, 40
+    lat = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
+    emb = (torch.randn(Bn, n_txt, CFG["joint_attention_dim"], generator=gb) * 0.5).to(BF).to(dev)
+    pooled = (torch.randn(Bn, CFG["pooled_projection_dim"], generator=gb) * 0.5).to(BF).to(dev)
+    noise = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
+    ts = torch.tensor([700.0, 250.0], device=dev)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = {id(p): p.grad.clone() for p in oracle.params}
+    ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1.5e-3 * abs(loss32), (loss, loss32)
+    num = den = 0.0
+    worst = 0.0
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for pa, pb in ((a.lokr_w1, b.lokr_w1), (a.lokr_w2, b.lokr_w2)):
+            d2 = ((pa.grad - g32[id(pb)]) ** 2).sum().item()
+            n2 = (g32[id(pb)] ** 2).sum().item()
+            num, den = num + d2, den + n2
+            worst = max(worst, math.sqrt(d2 / (n2 + 1e-30)))
+    e = math.sqrt(num / den)
+    print(f"lokr loss ours {loss:.6f} fp32 {loss32:.6f}; factor-gradient rel err {e:.3e} (worst layer {worst:.3e})")
+    assert e < 2e-2, e
+    # a real update moves the loss and keeps the adapter finite
+    ours2 = FluxLoRATrainStep(nat, net, ops, lr=1e-3, max_grad_norm=1.0)
+    l0 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    l1 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert math.isfinite(l1) and l1 < l0, (l0, l1)

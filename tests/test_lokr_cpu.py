@@ -1,0 +1,149 @@
+"""LoKr (Kronecker adapter, reference toolkit/models/lokr.py): the oracle module against vectors produced by the reference's own
+LokrModule / LoRASpecialNetwork(network_type='lokr') (tests/golden/lokr_flux_tiny.safetensors), then the native network + host
+graph (oracle kernel table, fp32) against both, the saved-file surface, and a full train step against the autograd oracle."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+from ai_toolkit_amd.lora import FusedLoRANetwork, factorization
+from ai_toolkit_amd.trainer import FluxLoRATrainStep
+from oracle import lora_ref, ref_ops, train_ref
+from tests.test_oracle_golden import G, TINY, oracle_model, tiny_inputs
+from tests.test_train_step_cpu import batch
+
+BIG = 9999999999  # lokr_full_rank (toolkit/config_modules.py:204-209)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    path = os.path.join(G, "lokr_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    return load_file(path), meta
+
+
+def test_factorization_equals_the_reference_function(gold):
+    """toolkit/models/lokr.py:22-59 executed by make_golden.py over model dims and factors (its docstring table is not what
+    the code returns, e.g. 250 -> (10, 25))."""
+    table = gold[1]["factorization"]
+    assert len(table) == 85
+    for key, want in table.items():
+        d, f = (int(v) for v in key.split(":"))
+        assert list(factorization(d, f)) == want == list(lora_ref.factorization(d, f)), key
+    assert factorization(3072) == (48, 64) and factorization(12288) == (96, 128) and factorization(15360) == (120, 128)
+
+
+def test_oracle_lokr_matches_reference_lokr_network(gold):
+    t, meta = gold
+    model = oracle_model()
+    torch.manual_seed(99)
+    net = lora_ref.RefLoRANetwork(model, BIG, network_type="lokr")
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    assert [n for n, _ in net.unet_loras[0].named_parameters()] == meta["param_order"] and meta["scale"] == 1.0
+    for m in net.unet_loras:
+        assert [list(m.lokr_w1.shape), list(m.lokr_w2.shape)] == meta["shapes"][m.lora_name]
+        assert torch.equal(m.lokr_w1, t[f"init/{m.lora_name}/w1"]), m.lora_name  # same RNG consumption
+        assert float(m.lokr_w2.abs().max()) == 0.0
+        with torch.no_grad():
+            m.lokr_w2.copy_(t[f"set/{m.lora_name}/w2"])
+    net.apply_to()
+    with net:
+        pred = model(*tiny_inputs())
+        (pred * t["fwd/w"]).sum().backward()
+    assert torch.allclose(pred, t["fwd/pred"], rtol=1e-5, atol=1e-6)
+    for m in net.unet_loras:
+        assert torch.allclose(m.lokr_w1.grad, t[f"grad/{m.lora_name}/w1"], rtol=2e-4, atol=2e-6), m.lora_name
+        assert torch.allclose(m.lokr_w2.grad, t[f"grad/{m.lora_name}/w2"], rtol=2e-4, atol=2e-6), m.lora_name
+    sd = net.peft_state_dict(torch.float32)
+    assert list(sd.keys()) == meta["saved_keys"]
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+
+
+def native_pair():
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=BIG, alpha=BIG, network_type="lokr")
+    return ref, nat, net
+
+
+def test_native_lokr_network_and_host_graph_match_reference_vectors(gold, tmp_path):
+    t, meta = gold
+    ref, nat, net = native_pair()
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    for m in net.unet_loras:
+        assert [list(m.lokr_w1.shape), list(m.lokr_w2.shape)] == meta["shapes"][m.lora_name]
+        assert torch.equal(m.lokr_w1, t[f"init/{m.lora_name}/w1"]), m.lora_name
+        assert m.scale == 1.0
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lokr_w2.copy_(t[f"set/{m.lora_name}/w2"])
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    with net:
+        pred = nat.forward_native(*tiny_inputs())
+        assert torch.allclose(pred, t["fwd/pred"], rtol=1e-4, atol=1e-5)
+        net.zero_grad_arena()
+        nat.backward_native(t["fwd/w"].clone())
+    for m in net.unet_loras:
+        assert torch.allclose(m.lokr_w1.grad, t[f"grad/{m.lora_name}/w1"], rtol=3e-4, atol=1e-5), m.lora_name
+        assert torch.allclose(m.lokr_w2.grad, t[f"grad/{m.lora_name}/w2"], rtol=3e-4, atol=1e-5), m.lora_name
+    # saved file: the reference's keys and values (alpha kept for LoKr), loadable back
+    f = str(tmp_path / "lokr.safetensors")
+    net.save_weights(f, dtype=torch.float32)
+    sd = load_file(f)
+    assert sorted(sd.keys()) == sorted(meta["saved_keys"])
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+    before = net.arena_p.clone()
+    net.arena_p.zero_()
+    assert net.load_weights(f) is None
+    assert torch.equal(net.arena_p, before)
+    params = net.prepare_optimizer_params(default_lr=1e-4)[0]["params"]
+    assert params[0] is net.unet_loras[0].lokr_w1 and params[1] is net.unet_loras[0].lokr_w2
+
+
+def test_lokr_train_steps_match_autograd_oracle():
+    ref, nat, net = native_pair()
+    torch.manual_seed(99)
+    ref_net = lora_ref.RefLoRANetwork(ref, BIG, network_type="lokr")
+    g = torch.Generator().manual_seed(5)
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        with torch.no_grad():
+            b.lokr_w2.copy_(torch.randn(b.lokr_w2.shape, generator=g) * 0.05)
+    ref_net.apply_to()
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            a.lokr_w1.copy_(b.lokr_w1)
+            a.lokr_w2.copy_(b.lokr_w2)
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=0.5)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    CFGI = dict(joint=TINY["joint_attention_dim"], pooled=TINY["pooled_projection_dim"])
+    for k in range(2):
+        gg = torch.Generator().manual_seed(70 + k)
+        lat = torch.randn(2, 16, 8, 4, generator=gg)
+        emb = torch.randn(2, 6, CFGI["joint"], generator=gg) * 0.5
+        pooled = torch.randn(2, CFGI["pooled"], generator=gg) * 0.5
+        noise = torch.randn(2, 16, 8, 4, generator=gg)
+        ts = torch.tensor([700.0, 250.0])
+        l_ref = oracle.step(lat, emb, pooled, noise, ts)
+        l = ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        assert abs(l.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item()), (k, l.item(), l_ref.item())
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert torch.allclose(a.lokr_w1, b.lokr_w1, rtol=2e-3, atol=2e-6), a.lora_name
+        assert torch.allclose(a.lokr_w2, b.lokr_w2, rtol=2e-3, atol=2e-6), a.lora_name

@@ -181,3 +181,46 @@ def test_wan_dora_network_matches_oracle_autograd():
                          (a.magnitude.grad, b.magnitude.grad, "magnitude")):
             err = ((x - y).norm() / (y.norm() + 1e-12)).item()
             assert err < 5e-4, (a.lora_name, nm, err)
+
+
+def test_wan_lokr_network_matches_oracle_autograd():
+    """network_type='lokr' (full Kronecker factors) through the Wan graph, incl. the weight-gradient-only cross-attention k/v."""
+    torch.manual_seed(0)
+    cfg = dict(CFG, ffn_dim=384)  # factor pairs must be multiples of 8 on the kernel path: 384 -> (16, 24); real Wan: 8960 -> (80, 112)
+    ref = wan_ref.WanTransformer3DModel(**cfg)
+    wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+    nat = WanTransformer3DModel(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    big = 9999999999
+    torch.manual_seed(3)
+    ref_net = lora_ref.RefLoRANetwork(ref, big, target=("WanTransformer3DModel",), block_names=("blocks",), network_type="lokr")
+    torch.manual_seed(3)
+    net = FusedLoRANetwork(nat, lora_dim=big, target_lin_modules=("WanTransformer3DModel",), transformer_block_names=["blocks"],
+                           base_model_version="wan_2.1", network_type="lokr")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.equal(a.lokr_w1, b.lokr_w1)
+            w2 = torch.randn(b.lokr_w2.shape, generator=g) * 0.05
+            a.lokr_w2.copy_(w2)
+            b.lokr_w2.copy_(w2)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    lat, txt, t = inputs()
+    with ref_net:
+        pred_ref = ref(lat, t, txt)
+        w5 = torch.randn(pred_ref.shape, generator=torch.Generator().manual_seed(11))
+        (pred_ref * w5).sum().backward()
+    with net:
+        pred = nat.forward_native(nat.pack_tokens(lat), t, txt, (3, 4, 2))
+        assert torch.allclose(pred, nat.pack_tokens(pred_ref.detach()), rtol=2e-4, atol=2e-5)
+        net.zero_grad_arena()
+        nat.backward_native(nat.pack_tokens(w5))
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for x, y, nm in ((a.lokr_w1.grad, b.lokr_w1.grad, "w1"), (a.lokr_w2.grad, b.lokr_w2.grad, "w2")):
+            err = ((x - y).norm() / (y.norm() + 1e-12)).item()
+            assert err < 5e-4, (a.lora_name, nm, err)
