@@ -327,13 +327,22 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
     }
 }
 
-__global__ void lora_wgrad_finish_kernel(AitkLoraWgradArgs p, int nchunks) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four
+// partial sums are combined through LDS in a fixed order (deterministic; 4x shorter dependent-load chain than one thread per
+// output, which matters for the LoKr factor gradients whose row count M * factor runs into the millions).
+__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(AitkLoraWgradArgs p, int nchunks) {
+  __shared__ float red[256];
+  const int j = threadIdx.x & 63, k = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + j;
   const long total = (long)p.R * p.L;
-  if (idx >= total) return;
-  const int r = (int)(idx / p.L), l = (int)(idx - (long)r * p.L);
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += p.partial[(long)c * total + idx];
+  if (idx < total)
+    for (int c = k; c < nchunks; c += 4) s += p.partial[(long)c * total + idx];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (k != 0 || idx >= total) return;
+  s = (red[j] + red[64 + j]) + (red[128 + j] + red[192 + j]);
+  const int r = (int)(idx / p.L), l = (int)(idx - (long)r * p.L);
   float* o = p.out + (long)r * p.out_stride_r + (long)l * p.out_stride_l;
   *o = p.accumulate ? (*o + s) : s;
 }
@@ -348,7 +357,8 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
   if (!a->partial || !a->out) return AITK_ERR_ARG;
-  const int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
+  int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
+  if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;  // millions of rows (LoKr): at most 512 row chunks
   const int nchunks = (a->M + mc - 1) / mc;
   dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
   hipStream_t s = (hipStream_t)stream;
@@ -360,7 +370,7 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
   }
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;
-  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *a, nchunks);
+  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
