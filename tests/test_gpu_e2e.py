@@ -170,3 +170,43 @@ def test_ragged_bucket_shapes_match_oracle(hw):
     num = sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32))
     den = sum((b ** 2).sum().item() for b in g32)
     assert math.sqrt(num / den) < 2e-2, math.sqrt(num / den)
+
+
+def test_batch_list_accumulation_and_preservation_pass_on_device():
+    """SDTrainer.hook_train_loop variants through the C ABI: (1) a batch list accumulates in the fp32 arena — the same
+    micro-batch twice gives exactly twice the gradient (x + x is exact in fp32) and the summed loss; a second bucket shape adds
+    its own gradient; (2) the output-preservation pass against the fp32 oracle (prior with the adapter inactive, second pass
+    pulled towards it)."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import train_ref
+
+    ref, ref_net, nat, net = _build()
+    lat, emb, pooled, noise, ts = _batch(2)
+    kw = dict(lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    step = FluxLoRATrainStep(nat, net, ops, **kw)
+    b1 = dict(latents=lat, prompt_embeds=emb, pooled_embeds=pooled, noise=noise, timesteps=ts)
+    l1 = step.step(**b1).item()
+    g1 = net.arena_g.clone()
+    l2 = step.step_list([b1, b1]).item()
+    assert torch.equal(net.arena_g, 2 * g1) and abs(l2 - 2 * l1) <= 1e-6 * abs(l2)
+    lat3, emb3, pooled3, noise3, ts3 = _batch(1, Hl=8, Wl=20, n_txt=24, seed=9)
+    b3 = dict(latents=lat3, prompt_embeds=emb3, pooled_embeds=pooled3, noise=noise3, timesteps=ts3)
+    l3 = step.step(**b3).item()
+    g3 = net.arena_g.clone()
+    l13 = step.step_list([b1, b3]).item()
+    assert torch.allclose(net.arena_g, g1 + g3, rtol=1e-5, atol=1e-7) and abs(l13 - (l1 + l3)) <= 1e-5 * abs(l13)
+
+    # output preservation vs the fp32 autograd oracle
+    gp = torch.Generator().manual_seed(21)
+    pres = ((torch.randn(emb.shape, generator=gp) * 0.5).to(torch.bfloat16).cuda(), (torch.randn(pooled.shape, generator=gp) * 0.5).to(torch.bfloat16).cuda())
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    l_ref = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts, preservation=(pres[0].float(), pres[1].float()),
+                        preservation_multiplier=0.7).item()
+    g32 = torch.cat([p.grad.reshape(-1) for m in ref_net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)])
+    lp = step.step(**b1, preservation=pres, preservation_multiplier=0.7).item()
+    assert lp > l1 and abs(lp - l_ref) <= 2e-3 * abs(l_ref), (lp, l_ref, l1)
+    ours = torch.cat([p.grad.reshape(-1) for m in net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)])
+    err = ((ours - g32).norm() / g32.norm()).item()
+    print(f"preservation: loss {lp:.6f} fp32 {l_ref:.6f} (plain {l1:.6f}); adapter-gradient rel err {err:.3e}")
+    assert err < 2e-2, err
