@@ -102,3 +102,33 @@ class FlowMatchTrainSchedule:
         idx = torch.stack([(table == t).nonzero()[0, 0] for t in timesteps]).cpu()
         w = (self.linear_timesteps_weights2 if v2 else self.linear_timesteps_weights)[idx]
         return w.flatten().to(timesteps.device)
+
+
+def get_noise(latents, generator=None, *, noise_offset=0.0, noise_multiplier=1.0, random_noise_shift=0.0,
+              random_noise_multiplier=0.0, dynamic_noise_offset=False, dtype=None):
+    """The reference's noise for one batch, same draw order on the same device generator:
+      randn(latents.shape) in fp32 on the device                         toolkit/stable_diffusion_model.py:1803-1811
+      + noise_offset * randn(B, C, 1, 1)   (4-D latents only)            toolkit/train_tools.py:132-139
+      cast to the training dtype                                          jobs/process/BaseSDTrainProcess.py:1020-1027
+      + latents channel mean / 2           (dynamic_noise_offset)         BaseSDTrainProcess.py:1331-1335
+      * noise_multiplier                                                   1344-1351
+      + randn(B, C[, F], 1, 1) * random_noise_shift                        1378-1386
+      * exp(randn(B, C[, F], 1, 1) * random_noise_multiplier)              1388-1391
+    Tiny per-batch tensor plumbing on [B, C, h, w]; the mixing with the latents and the 2x2 packing are aitk_flow_noise_pack."""
+    dev = latents.device
+    dtype = dtype or latents.dtype
+    noise = torch.randn(latents.shape, device=dev, dtype=torch.float32, generator=generator)
+    if noise_offset is not None and abs(noise_offset) >= 0.000001:
+        if latents.dim() > 4:
+            raise ValueError("Applying noise offset not supported for video models at this time.")
+        noise = noise + noise_offset * torch.randn((noise.shape[0], noise.shape[1], 1, 1), device=dev, generator=generator)
+    noise = noise.to(dtype)
+    if dynamic_noise_offset:
+        noise = noise + latents.mean(dim=(2, 3), keepdim=True).to(dtype) / 2
+    s = (noise.shape[0], noise.shape[1], 1, 1) if noise.dim() == 4 else (noise.shape[0], noise.shape[1], noise.shape[2], 1, 1)
+    noise = noise * noise_multiplier
+    if random_noise_shift > 0.0:
+        noise = noise + torch.randn(s, device=dev, dtype=dtype, generator=generator) * random_noise_shift
+    if random_noise_multiplier > 0.0:
+        noise = noise * torch.exp(torch.randn(s, device=dev, dtype=dtype, generator=generator) * random_noise_multiplier)
+    return noise

@@ -13,7 +13,7 @@ run redundantly on every rank (bit-identical adapter weights across ranks).
 """
 import torch
 
-from .flowmatch import FlowMatchTrainSchedule
+from .flowmatch import FlowMatchTrainSchedule, get_noise
 
 
 class _LoRATrainStepBase:
@@ -21,13 +21,14 @@ class _LoRATrainStepBase:
 
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
-                 seed=None, schedule=None, lr_scheduler=None):
+                 seed=None, schedule=None, lr_scheduler=None, noise_options=None):
         self.model, self.network, self.ops = model, network, ops
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.timestep_type, self.guidance = timestep_type, guidance
         self.schedule = schedule or FlowMatchTrainSchedule()
         self.step_num = 0
+        self.noise_options = dict(noise_options or {})  # keywords of flowmatch.get_noise (noise_offset, noise_multiplier, ...)
         self.lr_scheduler = lr_scheduler  # LRSchedule or None (constant): stepped once per train-loop iteration
         if lr_scheduler is not None:
             self.lr = lr_scheduler.get_last_lr()[0]
@@ -149,8 +150,8 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         timesteps = timesteps.float().contiguous()
-        if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812)
-            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32, generator=self.gen)
+        if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812) + the noise options
+            noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
         noise = noise.to(dt).contiguous()
         n_tok = (Hh // 2) * (W // 2)
         noisy = torch.empty(B, n_tok, Cc * 4, dtype=dt, device=dev)
@@ -197,7 +198,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         timesteps = timesteps.float().contiguous()
         if noise is None:
-            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32, generator=self.gen)
+            noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
         # frame-major copies ([B*F, C, H, W]) so the 2x2 pack kernel emits tokens in (frame, row, col) order
         lat_f = latents.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
         noi_f = noise.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()

@@ -149,3 +149,26 @@ def test_lr_schedule_drives_the_fused_adamw_like_torch_scheduler():
         ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
         assert ours.lr == pytest.approx(oracle.lr_scheduler.get_last_lr()[0], rel=1e-6, abs=1e-12)
     _assert_adapters_match(net, ref_net)
+
+
+def test_get_noise_follows_the_reference_draw_order_and_options():
+    """BaseSDTrainProcess.get_noise + prepare_noise block (999-1034, 1325-1391) restated inline from the same generator."""
+    from ai_toolkit_amd.flowmatch import get_noise
+
+    lat = torch.randn(3, 16, 8, 6, generator=torch.Generator().manual_seed(1))
+    g1, g2 = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+    got = get_noise(lat, g1, noise_offset=0.05, noise_multiplier=1.1, random_noise_shift=0.02, random_noise_multiplier=0.03,
+                    dynamic_noise_offset=True)
+    n = torch.randn(lat.shape, generator=g2)
+    n = n + 0.05 * torch.randn((3, 16, 1, 1), generator=g2)
+    n = n + lat.mean(dim=(2, 3), keepdim=True) / 2
+    n = n * 1.1
+    n = n + torch.randn((3, 16, 1, 1), generator=g2) * 0.02
+    n = n * torch.exp(torch.randn((3, 16, 1, 1), generator=g2) * 0.03)
+    assert torch.equal(got, n)
+    # defaults: exactly randn (the headline path's RNG stream is unchanged)
+    assert torch.equal(get_noise(lat, torch.Generator().manual_seed(5)), torch.randn(lat.shape, generator=torch.Generator().manual_seed(5)))
+    with pytest.raises(ValueError):
+        get_noise(torch.zeros(1, 16, 3, 4, 4), noise_offset=0.1)
+    v = get_noise(torch.zeros(2, 16, 3, 4, 4), torch.Generator().manual_seed(2), random_noise_shift=0.5)
+    assert v.shape == (2, 16, 3, 4, 4)
