@@ -13,10 +13,16 @@ anchors it on the reference's own call sites / in-tree restatements:
   * timestep sinusoid ................ extensions_built_in/diffusion_models/chroma/src/layers.py:30-53
   * embedder composition ............. toolkit/models/flux.py:10-16
 
-PARITY UNPINNED for the base-model math: the reference holds no golden vector / known-answer test at this boundary
- and diffusers cannot be imported here.  Class and attribute names follow diffusers exactly so the
-reference's LoRASpecialNetwork attaches to it and produces the reference's state-dict keys (that part IS pinned,
-see tests/golden/make_golden.py).
+PARITY: the reference holds no golden vector / known-answer test at this boundary and diffusers cannot be
+imported here, but the block ARITHMETIC is pinned on the reference's own executable restatement of the FLUX blocks: the Chroma
+model's DoubleStreamBlock / SingleStreamBlock / LastLayer / EmbedND / timestep_embedding / MLPEmbedder are run by
+tests/golden/make_golden.py (golden_flux_blocks) on this file's weights mapped through the reference's diffusers<->BFL key map,
+and tests/test_flux_blocks_golden.py holds this file to those outputs (RoPE table and application, QK-RMSNorm, joint attention
+order, gate / residual / MLP arithmetic, single-block split and concat order, last layer with the [scale, shift] swap, timestep
+sinusoid and its MLP).  Still UNPINNED (diffusers-only conventions, anchored on the key map and call sites above): the chunk
+order of the adaLN projections, the sum of the timestep / guidance / pooled-text embedders, x_embedder / context_embedder.
+Class and attribute names follow diffusers exactly so the reference's LoRASpecialNetwork attaches to it and produces the
+reference's state-dict keys (pinned as well, see tests/golden/make_golden.py).
 """
 import math
 from typing import Tuple

@@ -221,6 +221,109 @@ def golden_lokr():
     print("lokr golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale)
 
 
+def golden_flux_blocks():
+    """FLUX block arithmetic pinned on the reference's OWN in-tree restatement of the BFL FLUX blocks — the Chroma model
+    (extensions_built_in/diffusion_models/chroma/src/layers.py: DoubleStreamBlock 471-607, SingleStreamBlock 610-681, LastLayer
+    684-720, QKNorm / RMSNorm 72-89, 417-427, EmbedND 13-27, timestep_embedding 30-53, MLPEmbedder 56-69; math.py: attention 13-31,
+    rope 34-43, apply_rope 46-51), executed here on the oracle's tiny model weights mapped through the reference's diffusers<->BFL
+    key map (scripts/convert_diffusers_to_comfy.py:67-285: q/k/v concatenated into qkv, norm_q/norm_k -> query_norm/key_norm,
+    to_out.0 -> proj, ff.net.0.proj / ff.net.2 -> mlp.0 / mlp.2, single: q,k,v,proj_mlp -> linear1, proj_out -> linear2,
+    norm_out.linear [scale, shift] -> adaLN_modulation [shift, scale]).  Chroma feeds the modulation vectors from outside
+    (ModulationOut(shift, scale, gate)); they are taken from the oracle's adaLN Linear chunked in that order."""
+    import importlib
+    import types
+
+    src = "/root/reference/extensions_built_in/diffusion_models/chroma/src"
+    pkg = types.ModuleType("chroma_src")
+    pkg.__path__ = [src]
+    sys.modules["chroma_src"] = pkg
+    L = importlib.import_module("chroma_src.layers")
+    M = importlib.import_module("chroma_src.math")
+    assert not M._HAS_FLASH
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    with torch.no_grad():  # non-trivial biases / norm scales so every term is exercised
+        gi = torch.Generator().manual_seed(77)
+        for n, p_ in model.named_parameters():
+            if n.endswith("bias"):
+                p_.copy_(torch.randn(p_.shape, generator=gi) * 0.05)
+            if "norm_" in n and n.endswith("weight"):
+                p_.copy_(1 + 0.2 * torch.randn(p_.shape, generator=gi))
+    d, H = 256, 2
+    g = torch.Generator().manual_seed(21)
+    B, Hl, Wl, n_txt = 2, 4, 6, 5
+    Si = (Hl // 2) * (Wl // 2)
+    img = torch.randn(B, Si, d, generator=g)
+    txt = torch.randn(B, n_txt, d, generator=g)
+    temb = torch.randn(B, d, generator=g)
+    img_ids, txt_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+    ids = torch.cat((txt_ids, img_ids), 0)[None].repeat(B, 1, 1)
+    out = {"in/img": img, "in/txt": txt, "in/temb": temb, "in/ids": ids[0]}
+    # the weights are regenerated by the test with the same three lines (seeded); a checksum guards the regeneration
+    out["w_checksum"] = torch.stack([v.double().abs().sum() for v in model.state_dict().values()]).float()
+
+    def cat(*ws):
+        return torch.cat([w.detach() for w in ws], 0)
+
+    with torch.no_grad():
+        pe = L.EmbedND(dim=128, theta=10000, axes_dim=[16, 56, 56])(ids)
+        out["ref/pe"] = pe.clone()
+        # ---- double block
+        blk = model.transformer_blocks[0]
+        ref = L.DoubleStreamBlock(d, H, mlp_ratio=4.0, qkv_bias=True)
+        a = blk.attn
+        sd = {"img_attn.qkv.weight": cat(a.to_q.weight, a.to_k.weight, a.to_v.weight), "img_attn.qkv.bias": cat(a.to_q.bias, a.to_k.bias, a.to_v.bias),
+              "img_attn.norm.query_norm.scale": a.norm_q.weight, "img_attn.norm.key_norm.scale": a.norm_k.weight,
+              "img_attn.proj.weight": a.to_out[0].weight, "img_attn.proj.bias": a.to_out[0].bias,
+              "img_mlp.0.weight": blk.ff.net[0].proj.weight, "img_mlp.0.bias": blk.ff.net[0].proj.bias,
+              "img_mlp.2.weight": blk.ff.net[2].weight, "img_mlp.2.bias": blk.ff.net[2].bias,
+              "txt_attn.qkv.weight": cat(a.add_q_proj.weight, a.add_k_proj.weight, a.add_v_proj.weight),
+              "txt_attn.qkv.bias": cat(a.add_q_proj.bias, a.add_k_proj.bias, a.add_v_proj.bias),
+              "txt_attn.norm.query_norm.scale": a.norm_added_q.weight, "txt_attn.norm.key_norm.scale": a.norm_added_k.weight,
+              "txt_attn.proj.weight": a.to_add_out.weight, "txt_attn.proj.bias": a.to_add_out.bias,
+              "txt_mlp.0.weight": blk.ff_context.net[0].proj.weight, "txt_mlp.0.bias": blk.ff_context.net[0].proj.bias,
+              "txt_mlp.2.weight": blk.ff_context.net[2].weight, "txt_mlp.2.bias": blk.ff_context.net[2].bias}
+        ref.load_state_dict({k: v.detach().clone() for k, v in sd.items()}, strict=True)
+
+        def mods(lin, n):
+            c = lin(torch.nn.functional.silu(temb))[:, None, :].chunk(n, dim=-1)
+            return [L.ModulationOut(*c[i:i + 3]) for i in range(0, n, 3)]
+
+        r_img, r_txt = ref(img=img, txt=txt, pe=pe, distill_vec=[mods(blk.norm1.linear, 6), mods(blk.norm1_context.linear, 6)], mask=None)
+        out["ref/double/img"], out["ref/double/txt"] = r_img.clone(), r_txt.clone()
+        # ---- single block on the concatenated stream
+        sb = model.single_transformer_blocks[0]
+        refs = L.SingleStreamBlock(d, H, mlp_ratio=4.0)
+        a = sb.attn
+        refs.load_state_dict({"linear1.weight": cat(a.to_q.weight, a.to_k.weight, a.to_v.weight, sb.proj_mlp.weight),
+                              "linear1.bias": cat(a.to_q.bias, a.to_k.bias, a.to_v.bias, sb.proj_mlp.bias),
+                              "linear2.weight": sb.proj_out.weight.detach().clone(), "linear2.bias": sb.proj_out.bias.detach().clone(),
+                              "norm.query_norm.scale": a.norm_q.weight.detach().clone(), "norm.key_norm.scale": a.norm_k.weight.detach().clone()},
+                             strict=True)
+        x = torch.cat((r_txt, r_img), 1)
+        r_x = refs(x, pe=pe, distill_vec=mods(sb.norm.linear, 3)[0], mask=None)
+        out["ref/single/x"] = r_x.clone()
+        # ---- last layer on the image tokens: BFL order [shift, scale] = diffusers norm_out.linear [scale, shift] swapped
+        last = L.LastLayer(d, 1, TINY["in_channels"])
+        last.load_state_dict({"linear.weight": model.proj_out.weight.detach().clone(), "linear.bias": model.proj_out.bias.detach().clone()})
+        scale, shift = model.norm_out.linear(torch.nn.functional.silu(temb)).chunk(2, dim=1)
+        out["ref/last"] = last(r_x[:, n_txt:], [shift[:, None], scale[:, None]]).clone()
+        # ---- conditioning embedders
+        tt = torch.tensor([0.3, 0.8])
+        out["in/t"] = tt
+        out["ref/t_sinusoid"] = L.timestep_embedding(tt, 256).clone()  # time_factor 1000: the model is called with timestep / 1000
+        emb = L.MLPEmbedder(256, d)
+        te = model.time_text_embed.timestep_embedder
+        emb.load_state_dict({"in_layer.weight": te.linear_1.weight.detach().clone(), "in_layer.bias": te.linear_1.bias.detach().clone(),
+                             "out_layer.weight": te.linear_2.weight.detach().clone(), "out_layer.bias": te.linear_2.bias.detach().clone()})
+        out["ref/t_mlp"] = emb(out["ref/t_sinusoid"]).clone()
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "flux_blocks_chroma.safetensors"),
+              {"cfg": json.dumps(TINY), "shape": json.dumps([B, Hl, Wl, n_txt])})
+    print("flux block golden (reference Chroma blocks) written:", {k: tuple(v.shape) for k, v in out.items() if k.startswith("ref/")})
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -246,5 +349,6 @@ if __name__ == "__main__":
     golden_lora()
     golden_dora()
     golden_lokr()
+    golden_flux_blocks()
     golden_flowmatch()
     golden_wan_lora_keys()
