@@ -6,7 +6,8 @@ restates the published architecture with diffusers' module / parameter names (ch
 The one piece that IS reference code is the attention processor, toolkit/models/wan21/wan_attn.py:12-103: q/k/v
 projections -> norm_q / norm_k (RMSNorm over the whole projection, "rms_norm_across_heads") -> split heads -> rotary
 embedding as a complex multiply on (2i, 2i+1) pairs in float64 (self-attention only) -> SDPA -> to_out; `Attention`
-below follows it line by line for the T2V case (no image-conditioning branch).
+below follows it line by line for the T2V case (no image-conditioning branch) and is PINNED to it: make_golden.py executes the
+reference processor on this module and tests/test_wan_cpu.py compares (self-attention with RoPE, text cross-attention).
 
 Model:
   patch_embedding Conv3d(16, D, k=s=(1,2,2)) -> tokens (f, h/2, w/2)

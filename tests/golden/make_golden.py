@@ -324,6 +324,39 @@ def golden_flux_blocks():
     print("flux block golden (reference Chroma blocks) written:", {k: tuple(v.shape) for k, v in out.items() if k.startswith("ref/")})
 
 
+def golden_wan_attn():
+    """The reference's Wan attention processor (toolkit/models/wan21/wan_attn.py:8-84: projection -> q/k norm -> heads -> complex
+    RoPE in float64 -> SDPA -> to_out) executed on the Wan oracle's Attention module (same attribute names as the diffusers
+    Attention it is written for), self-attention with rotary_emb and text cross-attention without."""
+    import importlib.util
+
+    from oracle import wan_ref
+
+    spec = importlib.util.spec_from_file_location("wan_attn_ref", "/root/reference/toolkit/models/wan21/wan_attn.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    proc = m.WanAttnProcessor2_0()
+    torch.manual_seed(31)
+    attn = wan_ref.Attention(256, 2, 128)
+    with torch.no_grad():
+        for p_ in attn.parameters():
+            p_.copy_(torch.randn(p_.shape) * 0.05)
+        attn.norm_q.weight.copy_(1 + 0.2 * torch.randn(256))
+        attn.norm_k.weight.copy_(1 + 0.2 * torch.randn(256))
+    attn.add_k_proj = None
+    g = torch.Generator().manual_seed(32)
+    Fr, Hh, W = 2, 3, 4
+    x = torch.randn(2, Fr * Hh * W, 256, generator=g)
+    enc = torch.randn(2, 7, 256, generator=g)
+    ang = wan_ref.wan_rope_freqs(Fr, Hh, W)
+    freqs = torch.polar(torch.ones_like(ang), ang)[None, None]  # complex128 [1, 1, S, 64] (WanRotaryPosEmbed output form)
+    with torch.no_grad():
+        out = {"x": x, "enc": enc, "self": proc(attn, x, None, None, freqs).clone(), "cross": proc(attn, x, enc, None, None).clone(),
+               "w_checksum": torch.stack([v.double().abs().sum() for v in attn.state_dict().values()]).float()}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "wan_attn.safetensors"), {"grid": json.dumps([Fr, Hh, W])})
+    print("wan attention golden written")
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -350,5 +383,6 @@ if __name__ == "__main__":
     golden_dora()
     golden_lokr()
     golden_flux_blocks()
+    golden_wan_attn()
     golden_flowmatch()
     golden_wan_lora_keys()

@@ -224,3 +224,31 @@ def test_wan_lokr_network_matches_oracle_autograd():
         for x, y, nm in ((a.lokr_w1.grad, b.lokr_w1.grad, "w1"), (a.lokr_w2.grad, b.lokr_w2.grad, "w2")):
             err = ((x - y).norm() / (y.norm() + 1e-12)).item()
             assert err < 5e-4, (a.lora_name, nm, err)
+
+
+def test_oracle_attention_equals_reference_wan_attention_processor():
+    """oracle/wan_ref.Attention against outputs of the reference's WanAttnProcessor2_0 (toolkit/models/wan21/wan_attn.py) executed by
+    tests/golden/make_golden.py on the same (seeded) module: self-attention with the float64 complex RoPE and text cross-attention."""
+    import json
+    import os
+
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "wan_attn.safetensors")
+    t = load_file(path)
+    with safe_open(path, "pt") as f:
+        Fr, Hh, W = json.loads(f.metadata()["grid"])
+    torch.manual_seed(31)
+    attn = wan_ref.Attention(256, 2, 128)
+    with torch.no_grad():
+        for p_ in attn.parameters():
+            p_.copy_(torch.randn(p_.shape) * 0.05)
+        attn.norm_q.weight.copy_(1 + 0.2 * torch.randn(256))
+        attn.norm_k.weight.copy_(1 + 0.2 * torch.randn(256))
+        chk = torch.stack([v.double().abs().sum() for v in attn.state_dict().values()]).float()
+        assert torch.allclose(chk, t["w_checksum"], rtol=1e-6)
+        got_self = attn(t["x"], None, wan_ref.wan_rope_freqs(Fr, Hh, W))
+        got_cross = attn(t["x"], t["enc"], None)
+    assert torch.allclose(got_self, t["self"], rtol=1e-5, atol=1e-6), (got_self - t["self"]).abs().max()
+    assert torch.allclose(got_cross, t["cross"], rtol=1e-5, atol=1e-6)
