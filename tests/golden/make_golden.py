@@ -357,6 +357,30 @@ def golden_wan_attn():
     print("wan attention golden written")
 
 
+def golden_optimizer_ema():
+    """The per-step tail of SDTrainer.hook_train_loop (2273-2293): clip_grad_norm_ -> torch.optim.AdamW(eps=1e-6) as built by
+    toolkit/optimizer.py:78-79 -> the reference's own toolkit/ema.py ExponentialMovingAverage.update(), run for 3 steps on a
+    small flat parameter; the fused aitk_adamw_ema_step must land on the same parameters and EMA shadow."""
+    from toolkit.ema import ExponentialMovingAverage
+
+    g = torch.Generator().manual_seed(41)
+    p = torch.nn.Parameter(torch.randn(4096, generator=g) * 0.1)
+    p0 = p.detach().clone()
+    opt = torch.optim.AdamW([p], lr=3e-3, eps=1e-6, weight_decay=0.01)
+    ema = ExponentialMovingAverage([p], decay=0.9)
+    grads = torch.randn(3, 4096, generator=g) * torch.tensor([0.02, 3.0, 0.5])[:, None]  # below / above / near the clip threshold
+    norms = []
+    for k in range(3):
+        p.grad = grads[k].clone()
+        norms.append(torch.nn.utils.clip_grad_norm_([p], 1.0).clone())
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        ema.update()
+    out = {"p0": p0, "grads": grads, "p3": p.detach().clone(), "ema3": ema.shadow_params[0].clone(), "norms": torch.stack(norms)}
+    save_file(out, os.path.join(HERE, "optimizer_ema.safetensors"))
+    print("optimizer + EMA golden written; grad norms", [round(float(n), 3) for n in norms])
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -384,5 +408,6 @@ if __name__ == "__main__":
     golden_lokr()
     golden_flux_blocks()
     golden_wan_attn()
+    golden_optimizer_ema()
     golden_flowmatch()
     golden_wan_lora_keys()

@@ -130,3 +130,23 @@ def test_masked_mse_kernel_vs_oracle():
         outs.append((dp.float(), lps, loss))
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-5)
     assert (outs[0][0] - outs[1][0]).abs().max() <= 2 ** -8 * outs[1][0].abs().max()
+
+
+def test_adamw_ema_kernel_vs_torch_adamw_and_reference_ema_golden():
+    """aitk_adamw_ema_step against the committed vectors of clip_grad_norm_ -> torch.optim.AdamW -> the reference's own
+    toolkit/ema.py ExponentialMovingAverage.update() (tests/golden/optimizer_ema.safetensors, three steps)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from ai_toolkit_amd import ops
+
+    t = load_file(os.path.join(os.path.dirname(__file__), "golden", "optimizer_ema.safetensors"))
+    p, ema = t["p0"].cuda(), t["p0"].cuda()
+    m, v, norm = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(1, device="cuda")
+    for k in range(3):
+        ops.adamw_ema_step(p, t["grads"][k].cuda().contiguous(), m, v, lr=3e-3, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.01,
+                           step=k + 1, max_norm=1.0, ema=ema, ema_decay=0.9, norm_out=norm)
+        assert abs(norm.item() - t["norms"][k].item()) <= 1e-5 * t["norms"][k].item()
+    assert torch.allclose(p.cpu(), t["p3"], rtol=2e-5, atol=2e-7), (p.cpu() - t["p3"]).abs().max()
+    assert torch.allclose(ema.cpu(), t["ema3"], rtol=2e-5, atol=2e-7), (ema.cpu() - t["ema3"]).abs().max()

@@ -198,3 +198,18 @@ def test_oracle_dora_matches_reference_dora_network():
     assert sorted(sd.keys()) == sorted(meta["saved_keys"])
     for k, v in sd.items():
         assert torch.allclose(v, t[f"saved/{k}"]), k
+
+
+def test_fused_optimizer_tail_matches_torch_adamw_and_reference_ema_class():
+    """clip_grad_norm_ -> torch.optim.AdamW(eps=1e-6, wd=0.01) -> the reference's toolkit/ema.py ExponentialMovingAverage.update(),
+    executed by make_golden.py for three steps (grad norm below / far above / above the clip threshold): the oracle's
+    adamw_ema_step (what the HIP kernel is tested against on the GPU) lands on the same parameters and EMA shadow."""
+    t = load_file(os.path.join(G, "optimizer_ema.safetensors"))
+    p, ema = t["p0"].clone(), t["p0"].clone()
+    m, v, norm = torch.zeros_like(p), torch.zeros_like(p), torch.zeros(1)
+    for k in range(3):
+        ref_ops.adamw_ema_step(p, t["grads"][k].clone(), m, v, lr=3e-3, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.01, step=k + 1,
+                               max_norm=1.0, ema=ema, ema_decay=0.9, norm_out=norm)
+        assert torch.allclose(norm[0], t["norms"][k], rtol=1e-5)
+    assert torch.allclose(p, t["p3"], rtol=1e-5, atol=1e-7), (p - t["p3"]).abs().max()
+    assert torch.allclose(ema, t["ema3"], rtol=1e-5, atol=1e-7), (ema - t["ema3"]).abs().max()
