@@ -128,6 +128,21 @@ class DoRAModule(LoRAModule):
         self.y_lin = None   # this step's linear output (c*z + b), kept for d magnitude
 
 
+def add_model_hash_to_meta(state_dict, meta):
+    """sshs_model_hash / sshs_legacy_hash of sd-webui-additional-networks, as the reference stamps every saved adapter
+    (toolkit/metadata.py:32-48, toolkit/train_tools.py:162-185): serialise the tensors with only the `ss_*` metadata, sha256 of
+    everything after the safetensors header, and the first 8 hex digits of sha256 over bytes [0x100000, 0x110000)."""
+    import hashlib
+
+    from safetensors.torch import save as st_save
+
+    blob = st_save(state_dict, {k: v for k, v in meta.items() if k.startswith("ss_")})
+    n = int.from_bytes(blob[:8], "little")
+    meta["sshs_model_hash"] = hashlib.sha256(blob[n + 8:]).hexdigest()
+    meta["sshs_legacy_hash"] = hashlib.sha256(blob[0x100000:0x110000]).hexdigest()[0:8]
+    return meta
+
+
 def factorization(dimension: int, factor: int = -1):
     """(m, n) with m * n == dimension, m <= n, m as close to `factor` as the divisors allow (factor -1: closest to sqrt) —
     restates toolkit/models/lokr.py:22-59 (LyCORIS factorization)."""
@@ -519,6 +534,7 @@ class FusedLoRANetwork(nn.Module):
         meta = OrderedDict()
         for k, v in (metadata or {}).items():  # every value JSON-stringified (toolkit/metadata.py:13-29)
             meta[k] = v if isinstance(v, str) else json.dumps(v)
+        meta = add_model_hash_to_meta(sd, meta)  # toolkit/network_mixins.py:655-663
         meta.setdefault("format", "pt")
         os.makedirs(os.path.dirname(os.path.abspath(file)), exist_ok=True)
         save_file(sd, file, meta)

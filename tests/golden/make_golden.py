@@ -381,6 +381,25 @@ def golden_optimizer_ema():
     print("optimizer + EMA golden written; grad norms", [round(float(n), 3) for n in norms])
 
 
+def golden_model_hash():
+    """sshs_model_hash / sshs_legacy_hash the reference stamps on saved adapters (toolkit/metadata.py:32-48), computed by its own
+    add_model_hash_to_meta on a small and on a > 1 MiB state dict (the legacy hash reads bytes at offset 0x100000)."""
+    import types
+    from collections import OrderedDict
+
+    sys.modules.setdefault("info", types.SimpleNamespace(software_meta={"name": "ai-toolkit"}))
+    from toolkit.metadata import add_model_hash_to_meta
+
+    g = torch.Generator().manual_seed(51)
+    res = {}
+    for tag, shape in (("small", (8, 16)), ("big", (600, 512))):
+        sd = OrderedDict((f"transformer.blocks.{i}.lora_A.weight", torch.randn(shape, generator=g).to(torch.float16)) for i in range(3))
+        meta = add_model_hash_to_meta(sd, OrderedDict(ss_output_name="x", ss_base_model_version="flux1", name="not hashed"))
+        res[tag] = {"shape": list(shape), "sshs_model_hash": meta["sshs_model_hash"], "sshs_legacy_hash": meta["sshs_legacy_hash"]}
+    json.dump(res, open(os.path.join(HERE, "model_hash.json"), "w"), indent=1)
+    print("model hash golden written", res)
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -409,5 +428,6 @@ if __name__ == "__main__":
     golden_flux_blocks()
     golden_wan_attn()
     golden_optimizer_ema()
+    golden_model_hash()
     golden_flowmatch()
     golden_wan_lora_keys()

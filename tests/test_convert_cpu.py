@@ -47,3 +47,22 @@ def test_wan_key_conversion_matches_reference_converter_golden():
     orig = convert.wan_lora_to_original(sd)
     assert list(orig) == gold["original"]
     assert list(convert.wan_lora_to_diffusers(orig)) == gold["diffusers"]
+
+
+def test_saved_file_hashes_equal_the_reference_add_model_hash_to_meta():
+    """sshs_model_hash / sshs_legacy_hash (toolkit/metadata.py:32-48) against values computed by the reference's own function."""
+    import json
+    import os
+    from collections import OrderedDict
+
+    import torch
+
+    from ai_toolkit_amd.lora import add_model_hash_to_meta
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_hash.json")))
+    g = torch.Generator().manual_seed(51)
+    for tag in ("small", "big"):
+        shape = tuple(gold[tag]["shape"])
+        sd = OrderedDict((f"transformer.blocks.{i}.lora_A.weight", torch.randn(shape, generator=g).to(torch.float16)) for i in range(3))
+        meta = add_model_hash_to_meta(sd, OrderedDict(ss_output_name="x", ss_base_model_version="flux1", name="not hashed"))
+        assert meta["sshs_model_hash"] == gold[tag]["sshs_model_hash"] and meta["sshs_legacy_hash"] == gold[tag]["sshs_legacy_hash"], tag
