@@ -42,3 +42,79 @@ def test_set_runtime_scale_updates_in_place():
     runtime_scale = module._runtime_scale
     module._set_runtime_scale(1.0)
     assert module._runtime_scale is runtime_scale and module.scale == 1.0 and module._runtime_scale.item() == 1.0
+
+
+# ---- third reference test (testing/test_lora_compile_scalars.py:94-150): a wrapped Linear executed by the fast path matches the eager
+# adapter (forward + both weight gradients, rtol 2e-2 / atol 5e-2) and a runtime scale update applies without rebuilding anything
+# (delta * 0.25 after scale 2 -> 0.5).  The reference compiles the module; here the "compiled" artefact is the fused kernel path.
+def one_linear_model(n, ops, dtype, device):
+    from ai_toolkit_amd.graph import FusedGraphBase, Linear, _Holder
+
+    class OneLinear(FusedGraphBase):
+        def __init__(self):
+            super().__init__()
+            self._init_graph(ops, dtype)
+            blk = _Holder()
+            blk.proj = Linear(n, n, bias=False, dtype=dtype, device=device)
+            self.transformer_blocks = torch.nn.ModuleList([blk])
+
+        def _token_linears(self):
+            return [self.transformer_blocks[0].proj]
+
+    return OneLinear()
+
+
+def run_fused_vs_eager(ops, dtype, device, n=256, M=192):
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+
+    torch.manual_seed(0)
+    model = one_linear_model(n, ops, dtype, device)
+    lin = model.transformer_blocks[0].proj
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(n, n) / n ** 0.5).to(dtype))
+    net = FusedLoRANetwork(model, lora_dim=4, target_lin_modules=("OneLinear",), peft_format=True)
+    mod = net.unet_loras[0]
+    mod._set_runtime_scale(2.0)  # the reference test's alpha 8 / rank 4 (PEFT-format networks force alpha = rank at construction)
+    with torch.no_grad():
+        mod.lora_up.weight.normal_()
+    net.apply_to()
+    net.build_arena(device)
+    net.refresh_shadows(ops)
+    model.attach_network(net)
+    model.prepare()
+    value = torch.randn(M, n).to(dtype).to(device)
+    W, A, Bu = lin.weight.float(), mod.lora_down.weight.float(), mod.lora_up.weight.float()
+
+    def eager(scale):  # toolkit/network_mixins.py:304-342 on one Linear
+        Ar, Br = A.detach().clone().requires_grad_(True), Bu.detach().clone().requires_grad_(True)
+        out = (value.float() @ W.t() + (value.float() @ Ar.t()) @ Br.t() * scale).to(dtype)
+        out.float().square().mean().backward()
+        return out, Ar.grad, Br.grad
+
+    def fused():
+        out = torch.empty(M, n, dtype=dtype, device=device)
+        with net:
+            T = model._lin_fwd(lin, value, out, M=M, rows_per_batch=M, B=1)
+            dy = (out.float() * (2.0 / out.numel())).to(dtype)
+            dx = torch.empty_like(value)
+            net.zero_grad_arena()
+            model._lin_bwd(lin, dy, T, value, dx, M=M, rows_per_batch=M, B=1)
+        return out
+
+    want, g_down, g_up = eager(2.0)
+    got = fused()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(mod.lora_down.weight.grad, g_down, rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(mod.lora_up.weight.grad, g_up, rtol=2e-2, atol=5e-2)
+    base = (value.float() @ W.t()).to(dtype)
+    original_delta = got.float() - base.float()
+    mod._set_runtime_scale(0.5)
+    updated = fused()
+    torch.testing.assert_close(updated.float() - base.float(), original_delta * 0.25, rtol=2e-2, atol=5e-2)
+    assert float(original_delta.abs().max()) > 0.5  # the adapter term is not lost in the tolerance
+
+
+def test_fused_linear_matches_eager_adapter_and_runtime_scale_updates_apply():
+    from oracle import ref_ops
+
+    run_fused_vs_eager(ref_ops, torch.float32, "cpu")

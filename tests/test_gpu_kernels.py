@@ -150,3 +150,11 @@ def test_adamw_ema_kernel_vs_torch_adamw_and_reference_ema_golden():
         assert abs(norm.item() - t["norms"][k].item()) <= 1e-5 * t["norms"][k].item()
     assert torch.allclose(p.cpu(), t["p3"], rtol=2e-5, atol=2e-7), (p.cpu() - t["p3"]).abs().max()
     assert torch.allclose(ema.cpu(), t["ema3"], rtol=2e-5, atol=2e-7), (ema.cpu() - t["ema3"]).abs().max()
+
+
+def test_fused_linear_matches_eager_adapter_and_runtime_scale_updates_apply_on_device():
+    """GPU leg of the reference's third adapter test (testing/test_lora_compile_scalars.py:94-150), through the C ABI in bf16."""
+    from ai_toolkit_amd import ops
+    from tests.test_adapter_scalars_cpu import run_fused_vs_eager
+
+    run_fused_vs_eager(ops, torch.bfloat16, "cuda")
