@@ -64,7 +64,7 @@ def one_linear_model(n, ops, dtype, device):
     return OneLinear()
 
 
-def run_fused_vs_eager(ops, dtype, device, n=256, M=192):
+def run_fused_vs_eager(ops, dtype, device, n=256, M=192, rank=4):
     from ai_toolkit_amd.lora import FusedLoRANetwork
 
     torch.manual_seed(0)
@@ -72,7 +72,7 @@ def run_fused_vs_eager(ops, dtype, device, n=256, M=192):
     lin = model.transformer_blocks[0].proj
     with torch.no_grad():
         lin.weight.copy_((torch.randn(n, n) / n ** 0.5).to(dtype))
-    net = FusedLoRANetwork(model, lora_dim=4, target_lin_modules=("OneLinear",), peft_format=True)
+    net = FusedLoRANetwork(model, lora_dim=rank, target_lin_modules=("OneLinear",), peft_format=True)
     mod = net.unet_loras[0]
     mod._set_runtime_scale(2.0)  # the reference test's alpha 8 / rank 4 (PEFT-format networks force alpha = rank at construction)
     with torch.no_grad():
