@@ -400,6 +400,31 @@ def golden_model_hash():
     print("model hash golden written", res)
 
 
+def golden_merge():
+    """Reference LoRASpecialNetwork.merge_in(0.7) (toolkit/network_mixins.py:370-462, 894-899) on the tiny FLUX oracle with the
+    warm adapter of golden_lora: the merged base weights of three wrapped Linears."""
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    torch.manual_seed(99)
+    net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=8, alpha=1.0, multiplier=1.0, train_text_encoder=False,
+                             train_unet=True, is_flux=True, target_lin_modules=["FluxTransformer2DModel"], transformer_only=True)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+    net.force_to("cpu", torch.float32)
+    net.apply_to(None, model, False, True)
+    net.merge_in(merge_weight=0.7)
+    assert net.is_merged_in
+    keys = ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.ff.net.0.proj.weight", "single_transformer_blocks.0.proj_out.weight"]
+    sd = model.state_dict()
+    save_file({k: sd[k][:24].clone().contiguous() for k in keys}, os.path.join(HERE, "merge_flux_tiny.safetensors"))  # first 24 rows
+    print("merge golden written")
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -429,5 +454,6 @@ if __name__ == "__main__":
     golden_wan_attn()
     golden_optimizer_ema()
     golden_model_hash()
+    golden_merge()
     golden_flowmatch()
     golden_wan_lora_keys()

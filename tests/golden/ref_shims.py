@@ -60,7 +60,8 @@ def install():
                  "lycoris.kohya", "lycoris.kohya.utils", "lycoris.wrapper", "lycoris.modules.lokr", "lycoris.modules.base",
                  "lycoris.functional", "lycoris.functional.general", "lycoris.logging", "oyaml", "dotenv", "cv2", "albumentations",
                  "kornia", "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "prodigyopt",
-                 "bitsandbytes", "peft", "safetensors_rust", "einops_exts", "k_diffusion", "lpips", "open_clip", "timm"):
+                 "bitsandbytes", "peft", "safetensors_rust", "einops_exts", "k_diffusion", "lpips", "open_clip", "timm",
+                 "optimum.quanto.quantize", "torchao.quantization.quant_api"):
         if name not in sys.modules:
             _auto(name)
     qp = _auto("torchao.quantization.quant_primitives")

@@ -213,3 +213,31 @@ def test_fused_optimizer_tail_matches_torch_adamw_and_reference_ema_class():
         assert torch.allclose(norm[0], t["norms"][k], rtol=1e-5)
     assert torch.allclose(p, t["p3"], rtol=1e-5, atol=1e-7), (p - t["p3"]).abs().max()
     assert torch.allclose(ema, t["ema3"], rtol=1e-5, atol=1e-7), (ema - t["ema3"]).abs().max()
+
+
+def test_merge_in_equals_reference_merge_in(gold):
+    """FusedLoRANetwork.merge_in(0.7) (rank-r accumulate GEMM on the base weight) against base weights merged by the reference's
+    own LoRASpecialNetwork.merge_in(0.7) (tests/golden/merge_flux_tiny.safetensors); merge_out restores the originals."""
+    t, meta = gold
+    want = load_file(os.path.join(G, "merge_flux_tiny.safetensors"))
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=8, alpha=1.0)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(t[f"warm/{m.lora_name}/up"])
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    nat.attach_network(net)
+    nat.prepare()
+    before = {k: nat.state_dict()[k].clone() for k in want}
+    net.merge_in(0.7, ops=ref_ops)
+    assert net.is_merged_in
+    for k, v in want.items():  # the golden keeps the first 24 rows of each merged weight
+        got = nat.state_dict()[k][:24]
+        assert torch.allclose(got, v, rtol=1e-5, atol=1e-6) and not torch.allclose(got, before[k][:24], atol=1e-4), (k, (got - v).abs().max())
+    net.merge_out(0.7, ops=ref_ops)
+    for k, v in before.items():
+        assert torch.allclose(nat.state_dict()[k], v, rtol=1e-5, atol=1e-6), k
