@@ -2,8 +2,11 @@
 
 The reference calls `self.vae.encode(images).latent_dist.sample()` then `scaling_factor * (latents - shift_factor)`
 (toolkit/stable_diffusion_model.py:2533-2575); the encoder arithmetic itself is diffusers' `AutoencoderKL`
-(un-vendored, `requirements_base.txt:3`) -> PARITY UNPINNED for this file: it restates the published architecture with
-diffusers' module / parameter names (so a diffusers VAE checkpoint loads by key):
+(un-vendored, `requirements_base.txt:3`); this file restates the published architecture with diffusers' module / parameter
+names (so a diffusers VAE checkpoint loads by key).  The encoder ARITHMETIC is pinned on the reference's own in-tree LDM-style
+Encoder of the same architecture (extensions_built_in/diffusion_models/flux2/src/autoencoder.py:36-233), executed by
+tests/golden/make_golden.py (golden_vae_encoder) on this file's weights mapped to its names; tests/test_vae_cpu.py compares the
+moments.  Unpinned: the DiagonalGaussian sample / clamp and the FLUX.1 scaling constants (diffusers config values).
 
   encoder.conv_in -> down_blocks[i].resnets[j] (GroupNorm32 -> SiLU -> conv3x3 -> GroupNorm32 -> SiLU -> conv3x3,
   1x1 conv_shortcut when channels change) -> downsamplers[0].conv (3x3 stride 2 on F.pad(x,(0,1,0,1))) ->

@@ -425,6 +425,56 @@ def golden_merge():
     print("merge golden written")
 
 
+def golden_vae_encoder():
+    """VAE encoder arithmetic pinned on the reference's in-tree LDM-style `Encoder`
+    (extensions_built_in/diffusion_models/flux2/src/autoencoder.py:36-233: ResnetBlock, Downsample with the (0,1,0,1) pad,
+    AttnBlock, mid block, norm_out -> swish -> conv_out), the architecture of the FLUX.1 AutoencoderKL encoder, executed on the
+    VAE oracle's weights mapped diffusers -> LDM names (down_blocks.i.resnets.j -> down.i.block.j, conv_shortcut -> nin_shortcut,
+    downsamplers.0.conv -> downsample.conv, mid_block.resnets.0/1 -> mid.block_1/2, attention Linear -> 1x1 conv,
+    conv_norm_out -> norm_out); its extra quant_conv is set to the identity (FLUX.1's VAE has none)."""
+    import importlib.util
+
+    from oracle import vae_ref
+
+    spec = importlib.util.spec_from_file_location("flux2_autoencoder_ref", "/root/reference/extensions_built_in/diffusion_models/flux2/src/autoencoder.py")
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["flux2_autoencoder_ref"] = m  # dataclasses resolve the module through sys.modules
+    spec.loader.exec_module(m)
+    chans, zc = (32, 64, 64), 4
+    torch.manual_seed(0)
+    mine = vae_ref.Encoder(3, zc, chans, 2, 32)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(61)
+        for n, p_ in mine.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.08 if p_.dim() > 1 else 0.05) + (1.0 if ("norm" in n and n.endswith("weight")) else 0.0))
+    ref = m.Encoder(resolution=32, in_channels=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=2, z_channels=zc)
+    sd = {}
+    for k, v in mine.state_dict().items():
+        k2 = k
+        for i in range(3):
+            for j in range(2):
+                k2 = k2.replace(f"down_blocks.{i}.resnets.{j}.", f"down.{i}.block.{j}.")
+            k2 = k2.replace(f"down_blocks.{i}.downsamplers.0.conv.", f"down.{i}.downsample.conv.")
+        k2 = k2.replace("mid_block.resnets.0.", "mid.block_1.").replace("mid_block.resnets.1.", "mid.block_2.")
+        k2 = k2.replace("mid_block.attentions.0.group_norm.", "mid.attn_1.norm.")
+        for a, b in (("to_q", "q"), ("to_k", "k"), ("to_v", "v"), ("to_out.0", "proj_out")):
+            k2 = k2.replace(f"mid_block.attentions.0.{a}.", f"mid.attn_1.{b}.")
+        k2 = k2.replace("conv_shortcut.", "nin_shortcut.").replace("conv_norm_out.", "norm_out.")
+        if "mid.attn_1." in k2 and k2.endswith("weight") and v.dim() == 2:
+            v = v[:, :, None, None]
+        sd[k2] = v.clone()
+    sd["quant_conv.weight"] = torch.eye(2 * zc)[:, :, None, None].clone()
+    sd["quant_conv.bias"] = torch.zeros(2 * zc)
+    ref.load_state_dict(sd, strict=True)
+    x = torch.randn(2, 3, 32, 24, generator=torch.Generator().manual_seed(62))
+    with torch.no_grad():
+        out = {"x": x, "moments": ref(x).clone(),
+               "w_checksum": torch.stack([v.double().abs().sum() for v in mine.state_dict().values()]).float()}
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "vae_encoder_ldm.safetensors"),
+              {"chans": json.dumps(list(chans)), "zc": json.dumps(zc)})
+    print("vae encoder golden written", tuple(out["moments"].shape))
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -455,5 +505,6 @@ if __name__ == "__main__":
     golden_optimizer_ema()
     golden_model_hash()
     golden_merge()
+    golden_vae_encoder()
     golden_flowmatch()
     golden_wan_lora_keys()

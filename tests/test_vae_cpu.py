@@ -51,3 +51,25 @@ def test_latent_cache_path_and_roundtrip(tmp_path):
     nvae.save_latent_cache(path, lat)
     assert list(load_file(path).keys()) == ["latent"]  # toolkit/dataloader_mixins.py:2076-2080
     assert torch.equal(nvae.load_latent_cache(path), lat)
+
+
+def test_oracle_encoder_equals_reference_ldm_encoder():
+    """oracle/vae_ref.Encoder (diffusers names) against the moments computed by the reference's in-tree LDM-style Encoder
+    (extensions_built_in/diffusion_models/flux2/src/autoencoder.py) executed by make_golden.py on the same seeded weights mapped to
+    its names: ResnetBlock, asymmetric-pad Downsample, single-head mid attention, norm_out -> SiLU -> conv_out."""
+    from safetensors import safe_open
+
+    path = os.path.join(os.path.dirname(__file__), "golden", "vae_encoder_ldm.safetensors")
+    t = load_file(path)
+    with safe_open(path, "pt") as f:
+        chans, zc = tuple(json.loads(f.metadata()["chans"])), json.loads(f.metadata()["zc"])
+    torch.manual_seed(0)
+    enc = vae_ref.Encoder(3, zc, chans, 2, 32)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(61)
+        for n, p_ in enc.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.08 if p_.dim() > 1 else 0.05) + (1.0 if ("norm" in n and n.endswith("weight")) else 0.0))
+        chk = torch.stack([v.double().abs().sum() for v in enc.state_dict().values()]).float()
+        assert torch.allclose(chk, t["w_checksum"], rtol=1e-6)
+        got = enc(t["x"])
+    assert torch.allclose(got, t["moments"], rtol=1e-4, atol=1e-5), (got - t["moments"]).abs().max()
