@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 bf = torch.bfloat16
 
 
-def _flux(num_layers, num_single, rank=16, warm=True, seed=1234):
+def _flux(num_layers, num_single, rank=16, warm=True, seed=1234, network_type="lora"):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -29,11 +29,14 @@ def _flux(num_layers, num_single, rank=16, warm=True, seed=1234):
                 mod.weight.copy_((torch.randn(mod.weight.shape, device=dev, generator=g) * 0.02).to(bf))
                 mod.bias.copy_((torch.randn(mod.bias.shape, device=dev, generator=g) * 0.01).to(bf))
     torch.manual_seed(seed)
-    net = FusedLoRANetwork(model, lora_dim=rank)
+    net = FusedLoRANetwork(model, lora_dim=rank, alpha=rank, network_type=network_type)
     if warm:
         with torch.no_grad():
             for m in net.unet_loras:
-                m.lora_up.weight.normal_(0, 2e-3)
+                if network_type == "lokr":
+                    m.lokr_w2.normal_(0, 2e-3)  # lokr_w1 is kaiming-initialised, lokr_w2 zero: warm w2 so every gradient is non-trivial
+                else:
+                    m.lora_up.weight.normal_(0, 2e-3)
     net.apply_to()
     net.build_arena(dev, groups=model.lora_groups())
     net.refresh_shadows(ops)
@@ -86,6 +89,45 @@ def test_full_width_two_blocks_vs_fp32_oracle():
     assert rel < 1.5e-2, rel
     worst = max(((a - b).norm() / (b.norm() + 1e-30)).item() for a, b in zip(mine, g32))
     assert worst < 0.08, worst
+
+
+def test_full_width_lokr_two_blocks_vs_fp32_oracle():
+    """LoKr at the real FLUX factor shapes (3072 -> 48x64, 12288 -> 96x128, 15360 -> 120x128, 18432 -> 128x144, 9216 -> 96x96)
+    through the whole graph: Kronecker delta ahead of the ACCUM-epilogue GEMMs (plain, GELU, gate-residual, segmented joint
+    buffers), the windowed data gradient of the single block's proj_out, factor gradients over millions of contraction rows."""
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import flux_ref, lora_ref, train_ref
+
+    big = 9999999999
+    model, net, ops = _flux(1, 1, rank=big, network_type="lokr")
+    m0 = net.unet_loras[0]
+    assert (m0.out_l, m0.in_m, m0.out_k, m0.in_n) == (128, 48, 144, 64), "norm1.linear 3072 -> 18432"
+    ref = flux_ref.FluxTransformer2DModel(num_layers=1, num_single_layers=1).cuda()
+    ref.load_state_dict({k: v.float() for k, v in model.state_dict().items()}, strict=True)
+    ref_net = lora_ref.RefLoRANetwork(ref, big, network_type="lokr").cuda()
+    ref_net.torch_multiplier = ref_net.torch_multiplier.cuda()
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert a.lora_name == b.lora_name
+            b.lokr_w1.copy_(a.lokr_w1)
+            b.lokr_w2.copy_(a.lokr_w2)
+    ref_net.apply_to()
+    lat, emb, pooled, noise, ts = _batch(1)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = [p.grad for p in oracle.params]
+    ours = FluxLoRATrainStep(model, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1e-3 * abs(loss32), (loss, loss32)
+    mine = []
+    for m in net.unet_loras:
+        mine += [m.lokr_w1.grad, m.lokr_w2.grad]
+    num = sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32))
+    den = sum((b ** 2).sum().item() for b in g32)
+    rel = math.sqrt(num / den)
+    worst = max(((a - b).norm() / (b.norm() + 1e-30)).item() for a, b in zip(mine, g32))
+    print(f"full-width LoKr 1+1 blocks: loss {loss:.6f} vs fp32 {loss32:.6f}; factor-grad rel err {rel:.3e} (worst {worst:.3e})")
+    assert rel < 2e-2 and worst < 0.1, (rel, worst)
 
 
 def test_full_model_determinism_zero_adapter_and_batch_independence():
