@@ -221,6 +221,7 @@ def lib():
     L.aitk_groupnorm_workspace_bytes.restype = C.c_int64
     L.aitk_groupnorm_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.aitk_softmax_rows.argtypes = [vp, i64, i32, i32, C.c_float, vp]
+    L.aitk_kron_merge.argtypes = [vp, i64, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.aitk_image_to_nhwc8.argtypes = [vp, vp, i32, i32, i32, vp]
     L.aitk_latent_sample.argtypes = [vp, i64, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]
     L.aitk_timestep_embed.argtypes = [vp, vp, i32, i32, C.c_float, vp]

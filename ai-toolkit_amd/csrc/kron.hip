@@ -214,7 +214,39 @@ __global__ __launch_bounds__(256) void kron_apply_kernel(AitkKronApplyArgs p) {
   }
 }
 
+// W[r][c] += alpha * A[r / b_rows][c / b_cols] * B[r % b_rows][c % b_cols]   (W bf16 [a_rows*b_rows, a_cols*b_cols], A / B fp32):
+// the LoKr delta kron(lokr_w1, lokr_w2) * scale merged into a base weight (toolkit/models/lokr.py:62-69, 261-309).
+__global__ __launch_bounds__(256) void kron_merge_kernel(bf16_t* W, long ldw, const float* A, const float* B, int a_rows, int a_cols,
+                                                          int b_rows, int b_cols, float alpha) {
+  const long cols8 = (long)a_cols * b_cols / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a_rows * b_rows * cols8) return;
+  const int r = (int)(i / cols8), c = (int)(i - (long)r * cols8) * 8;
+  const int p = r / b_rows, o = r - p * b_rows;
+  const int q = c / b_cols, s0 = c - q * b_cols;  // b_cols % 8 == 0: the 8 columns share one A entry
+  const float a = alpha * A[(long)p * a_cols + q];
+  uint4 v = *reinterpret_cast<uint4*>(W + (long)r * ldw + c);
+  const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = bf2f(e[j]) + a * B[(long)o * b_cols + s0 + j];
+  uint4 w;
+  w.x = pack2bf(f[0], f[1]); w.y = pack2bf(f[2], f[3]); w.z = pack2bf(f[4], f[5]); w.w = pack2bf(f[6], f[7]);
+  *reinterpret_cast<uint4*>(W + (long)r * ldw + c) = w;
+}
+
 }  // namespace
+
+extern "C" int aitk_kron_merge(aitk_bf16* W, int64_t ldw, const float* A, const float* B, int32_t a_rows, int32_t a_cols, int32_t b_rows,
+                               int32_t b_cols, float alpha, aitk_stream_t stream) {
+  if (!W || !A || !B || a_rows <= 0 || a_cols <= 0 || b_rows <= 0 || b_cols <= 0 || (b_cols % 8)) return AITK_ERR_SHAPE;
+  if ((ldw % 8) || ((uintptr_t)W & 15)) return AITK_ERR_ALIGN;
+  const long n = (long)a_rows * b_rows * ((long)a_cols * b_cols / 8);
+  hipLaunchKernelGGL(kron_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw, A, B, a_rows, a_cols,
+                     b_rows, b_cols, alpha);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
 
 extern "C" int aitk_kron_apply(const AitkKronApplyArgs* a, aitk_stream_t stream) {
   if (!a || a->M <= 0 || a->a_in <= 0 || a->b_in <= 0 || a->a_out <= 0 || a->b_out <= 0) return AITK_ERR_SHAPE;

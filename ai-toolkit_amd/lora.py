@@ -191,7 +191,7 @@ class LoKrModule(LoRAModule):
 
     def __init__(self, lora_name, org_module, multiplier=1.0, lora_dim=4, alpha=1, network=None, factor=-1, **kwargs):
         nn.Module.__init__(self)
-        self.can_merge_in = False  # merging kron(w1, w2) into the base weight is not on the fused path yet
+        self.can_merge_in = True
         self.network_ref = weakref.ref(network) if network is not None else (lambda: None)
         self.is_checkpointing = False
         self._multiplier = None
@@ -585,8 +585,17 @@ class FusedLoRANetwork(nn.Module):
         ops = ops or self._ops
         if self.network_type.lower() == "dora":
             return  # toolkit/network_mixins.py:894-897
-        if self.network_type.lower() == "lokr":
-            raise NotImplementedError("merging kron(lokr_w1, lokr_w2) into the base weights is not on the fused path yet")
+        if self.network_type.lower() == "lokr":  # toolkit/models/lokr.py:261-309: W += kron(w1, w2) * scale * merge_weight
+            for m in self.get_all_modules():
+                lin = m.org_module[0]
+                if getattr(lin, "qweight", None) is not None:
+                    raise NotImplementedError("LoKr merge into a weight-only fp8 base is not on the fused path")
+                a = float(merge_weight) * m.scale
+                ops.kron_merge(lin.weight.data, m.lokr_w1.data.contiguous(), m.lokr_w2.data.contiguous(), a)
+                if getattr(lin, "weight_t", None) is not None:
+                    ops.kron_merge(lin.weight_t, m.lokr_w1.data.t().contiguous(), m.lokr_w2.data.t().contiguous(), a)
+            self.is_merged_in = merge_weight > 0
+            return
         self.refresh_shadows(ops)
         for m in self.get_all_modules():
             lin = m.org_module[0]

@@ -524,6 +524,16 @@ def kron_apply(x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale=1.0, transpose_
     return out
 
 
+def kron_merge(W, A, Bm, alpha):
+    """W (bf16 [a_rows*b_rows, a_cols*b_cols]) += alpha * kron(A, Bm) with fp32 factors (LoKr merge_in)."""
+    assert W.dtype == BF16 and W.dim() == 2 and W.stride(1) == 1
+    assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and A.is_contiguous() and Bm.is_contiguous()
+    assert W.shape[0] == A.shape[0] * Bm.shape[0] and W.shape[1] == A.shape[1] * Bm.shape[1]
+    _capi.check(_capi.lib().aitk_kron_merge(_ptr(W), W.stride(0), _ptr(A), _ptr(Bm), A.shape[0], A.shape[1], Bm.shape[0], Bm.shape[1],
+                                            float(alpha), _capi.stream_ptr()), "aitk_kron_merge")
+    return W
+
+
 def dequant_fp8(q, scale, mode, out):
     """out (bf16 [rows, cols]) = e4m3(q) * scale (per row: mode 1, per column: mode 2)."""
     assert q.element_size() == 1 and q.dim() == 2 and q.stride(1) == 1 and out.dtype == BF16 and out.shape == q.shape and out.stride(1) == 1

@@ -326,6 +326,11 @@ typedef struct AitkKronApplyArgs {
   float scale;
 } AitkKronApplyArgs;
 int aitk_kron_apply(const AitkKronApplyArgs* args, aitk_stream_t stream);
+/* W[a_rows*b_rows, a_cols*b_cols] (bf16, leading dimension ldw) += alpha * kron(A[a_rows,a_cols], B[b_rows,b_cols]) (fp32 factors):
+ * LokrModule.merge_in (toolkit/models/lokr.py:261-309) on the base weight (A = lokr_w1, B = lokr_w2) or on its transposed copy
+ * (A = lokr_w1^T, B = lokr_w2^T).  b_cols % 8 == 0. */
+int aitk_kron_merge(aitk_bf16* W, int64_t ldw, const float* A, const float* B, int32_t a_rows, int32_t a_cols, int32_t b_rows,
+                    int32_t b_cols, float alpha, aitk_stream_t stream);
 
 /* ---- DoRA (toolkit/models/DoRA.py, network_mixins.py:323-339): y = c * (x W^T + s m x A^T B^T) + b with
  * c_j = magnitude_j / ||W_j + s B_j A||, the norm detached.

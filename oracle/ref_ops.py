@@ -463,3 +463,9 @@ def kron_apply(x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale=1.0, transpose_
         res = res + _seg_view(out, out_seg, M).float()
     _seg_store(out, out_seg, M, res)
     return out
+
+
+def kron_merge(W, A, Bm, alpha):
+    """LokrModule.merge_in (toolkit/models/lokr.py:261-309): weight + kron(w1, w2) * scale * merge_weight, cast back."""
+    W.copy_((W.float() + alpha * torch.kron(A.float(), Bm.float())).to(W.dtype))
+    return W

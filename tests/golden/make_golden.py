@@ -213,6 +213,13 @@ def golden_lokr():
     meta = {"names": json.dumps([m.lora_name for m in net.unet_loras]), "saved_keys": json.dumps(list(sd.keys())),
             "shapes": json.dumps(shapes), "scale": json.dumps(net.unet_loras[0].scale),
             "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()])}
+    # LokrModule.merge_in(0.7) (toolkit/models/lokr.py:261-309) into two base weights (first 24 rows kept)
+    for m in net.unet_loras:
+        if m.lora_name.endswith("transformer_blocks$$0$$attn$$to_q") or m.lora_name.endswith("single_transformer_blocks$$0$$proj_out"):
+            w_before = m.org_module[0].weight.detach().clone()
+            m.merge_in(0.7)
+            out[f"merged/{m.lora_name}"] = m.org_module[0].weight.detach()[:24].clone()
+            assert not torch.equal(w_before, m.org_module[0].weight)
     from toolkit.models.lokr import factorization
 
     dims = (64, 127, 128, 250, 256, 360, 512, 768, 1024, 1280, 1536, 3072, 8960, 9216, 12288, 15360, 18432)

@@ -179,3 +179,24 @@ def test_lokr_train_step_vs_fp32_oracle():
     l0 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
     l1 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
     assert math.isfinite(l1) and l1 < l0, (l0, l1)
+
+
+def test_kron_merge_kernel():
+    """aitk_kron_merge (LoKr merge_in) on the FLUX factor shapes, weight and transposed-copy orientation, vs torch.kron in fp32."""
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(3)
+    for (ar, ac, br, bc) in ((48, 48, 64, 64), (96, 48, 128, 64), (48, 120, 64, 128), (24, 16, 32, 16)):
+        W = (torch.randn(ar * br, ac * bc, generator=g) * 0.02).to(BF).cuda()
+        A = torch.randn(ar, ac, generator=g).cuda() * 0.1
+        Bm = torch.randn(br, bc, generator=g).cuda() * 0.1
+        want = ref_ops.kron_merge(W.clone(), A, Bm, 0.7)
+        got = ops.kron_merge(W.clone(), A, Bm, 0.7)
+        # same fp32 sum, different association (alpha * A first): at most one bf16 ulp apart
+        assert ((got.float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 1e-6).all(), (ar, ac, br, bc)
+        assert _rel(got, want) < 2e-3
+        # transposed copy: kron(A, B)^T = kron(A^T, B^T)
+        Wt = W.t().contiguous()
+        got_t = ops.kron_merge(Wt, A.t().contiguous(), Bm.t().contiguous(), 0.7)
+        assert torch.equal(got_t, got.t())  # both orientations round identically

@@ -147,3 +147,33 @@ def test_lokr_train_steps_match_autograd_oracle():
     for a, b in zip(net.unet_loras, ref_net.unet_loras):
         assert torch.allclose(a.lokr_w1, b.lokr_w1, rtol=2e-3, atol=2e-6), a.lora_name
         assert torch.allclose(a.lokr_w2, b.lokr_w2, rtol=2e-3, atol=2e-6), a.lora_name
+
+
+def test_lokr_merge_in_equals_reference_merge_in(gold):
+    """FusedLoRANetwork.merge_in(0.7) for LoKr (aitk_kron_merge: W += kron(w1, w2) * scale * merge_weight, on the weight and its
+    transposed copy) against base weights merged by the reference's LokrModule.merge_in(0.7); merge_out restores."""
+    t, meta = gold
+    ref, nat, net = native_pair()
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lokr_w2.copy_(t[f"set/{m.lora_name}/w2"])
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    keys = [k[len("merged/"):] for k in t if k.startswith("merged/")]
+    assert len(keys) == 3
+    mods = {m.lora_name: m for m in net.unet_loras}
+    before = {k: (mods[k].org_module[0].weight.detach().clone(), mods[k].org_module[0].weight_t.clone()) for k in keys}
+    net.merge_in(0.7, ops=ref_ops)
+    assert net.is_merged_in
+    for k in keys:
+        lin = mods[k].org_module[0]
+        assert torch.allclose(lin.weight[:24], t[f"merged/{k}"], rtol=1e-5, atol=1e-6), k
+        assert torch.allclose(lin.weight_t, lin.weight.t(), rtol=1e-5, atol=1e-6), k  # the dgrad copy is merged consistently
+        assert not torch.allclose(lin.weight, before[k][0], atol=1e-4)
+    net.merge_out(0.7, ops=ref_ops)
+    for k in keys:
+        lin = mods[k].org_module[0]
+        assert torch.allclose(lin.weight, before[k][0], rtol=1e-5, atol=1e-6) and torch.allclose(lin.weight_t, before[k][1], rtol=1e-5, atol=1e-6)
