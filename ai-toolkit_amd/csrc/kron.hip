@@ -20,7 +20,8 @@
 
 namespace {
 
-constexpr int KRON_MAXCH = 8;  // 16-byte chunks of the token row held in registers per thread (rows up to 16384 features)
+// KRON_MAXCH (template): 16-byte chunks of the token row held in registers per thread — 2 for rows up to 4096 features (the
+// common 3072-wide layers: fewer registers, one more resident workgroup per CU), 8 for rows up to 16384; longer rows are staged directly.
 
 __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, int seg_rows, long seg_stride, int m) {
   if (seg_rows > 0) {
@@ -53,6 +54,7 @@ __host__ __device__ inline KronLayout kron_layout(int a_in, int b_in, int a_out,
   return L;
 }
 
+template <int KRON_MAXCH>
 __global__ __launch_bounds__(256) void kron_apply_kernel(AitkKronApplyArgs p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,8 +271,8 @@ extern "C" int aitk_kron_apply(const AitkKronApplyArgs* a, aitk_stream_t stream)
     hipDeviceProp_t prop;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kron_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const void* f : {reinterpret_cast<const void*>(kron_apply_kernel<2>), reinterpret_cast<const void*>(kron_apply_kernel<8>)})
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
@@ -278,7 +280,10 @@ extern "C" int aitk_kron_apply(const AitkKronApplyArgs* a, aitk_stream_t stream)
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   long grid = (long)n_cu * per_cu;
   if (grid > a->M) grid = a->M;
-  hipLaunchKernelGGL(kron_apply_kernel, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, *a);
+  if (a->a_in * a->b_in <= 2 * 256 * 8)
+    hipLaunchKernelGGL(kron_apply_kernel<2>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(kron_apply_kernel<8>, dim3((unsigned)grid), dim3(256), lds_bytes, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
