@@ -11,7 +11,7 @@ from ai_toolkit_amd import ops  # noqa: E402
 
 dev = "cuda"
 bf = torch.bfloat16
-M, N, K = 18432, 3072, 3072
+M, N, K = int(os.environ.get("AITK_PMC_M", "18432")), 3072, 3072  # 18432 = batch 4, 32256 = batch 7
 a = torch.randn(M, K, device=dev).to(bf)
 b = (torch.randn(N, K, device=dev) * 0.02).to(bf)
 a2 = torch.randn(M, 16, device=dev).to(bf)
