@@ -152,7 +152,7 @@ class FusedGraphBase(nn.Module):
         out = {}
         for l in lins:
             c0 = grp["col"][id(l.lora)]
-            out[id(l)] = Tcat[:, c0:c0 + l.lora.lora_dim]
+            out[id(l)] = Tcat[:, c0:c0 + l.lora.rank_pad]
         return out
 
     def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
@@ -173,7 +173,7 @@ class FusedGraphBase(nn.Module):
         if self._lora_active(lin):
             lo = lin.lora
             if T is None:
-                T = self._new(M, lo.lora_dim)
+                T = self._new(M, lo.rank_pad)
                 mult, rpb = self._mult(rows_per_batch, B)
                 ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
             kw = dict(a2=T, b2=lo.sh_up)
@@ -257,7 +257,7 @@ class FusedGraphBase(nn.Module):
         ops = self.ops
         lo = lin.lora
         assert lo.magnitude is None or getattr(dy, "_dora_dz", False), "DoRA: pass dy through _dora_dz() first"
-        dT = dT_out if dT_out is not None else self._new(M, lo.lora_dim)
+        dT = dT_out if dT_out is not None else self._new(M, lo.rank_pad)
         mult, rpb = self._mult(rows_per_batch, B)
         ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
         ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M)
@@ -289,7 +289,7 @@ class FusedGraphBase(nn.Module):
             dT_out = None
             if grp is not None:
                 c0 = grp["col"][id(lin.lora)]
-                dT_out = dTcat[:, c0:c0 + lin.lora.lora_dim]
+                dT_out = dTcat[:, c0:c0 + lin.lora.rank_pad]
             dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dT_out)
             self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
         if grp is not None:
@@ -332,7 +332,7 @@ class FusedGraphBase(nn.Module):
             return mod, _KRON
         if self._lora_active(ada_lin):
             lo = ada_lin.lora
-            T = self._new(B, lo.lora_dim)
+            T = self._new(B, lo.rank_pad)
             mult, rpb = self._mult(1, B)
             ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
             kw = dict(t=T, bl=lo.sh_up)
@@ -352,7 +352,7 @@ class FusedGraphBase(nn.Module):
         ops = self.ops
         lo = ada_lin.lora
         dmod = self._dora_dz(ada_lin, dmod, B)
-        dT = self._new(B, lo.lora_dim)
+        dT = self._new(B, lo.rank_pad)
         mult, rpb = self._mult(1, B)
         ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
         ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B)

@@ -318,11 +318,24 @@ class FusedLoRANetwork(nn.Module):
         launch produces all their lora_down gradients (the activation is streamed once instead of 3-4 times)."""
         mods = self.get_all_modules()
         # the skinny kernels handle up to 64 ranks per launch: larger groups (e.g. q,k,v at rank 32) stay ungrouped
-        groups = [g for g in (groups or []) if sum(x.lora_dim for x in g) <= 64]
-        n = sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in mods)
+        # Ranks are padded to a multiple of 16 inside the arenas (the MFMA K-slab and the skinny kernels work on 16-wide rank
+        # blocks): lora_down lives in the first r rows of a [rank_pad, in] block, lora_up in the first r columns of an
+        # [out, rank_pad] block.  The padding is zero at creation and stays exactly zero: its gradients are products with zero
+        # rows / columns and AdamW maps (p, g, m, v) = 0 to 0.  The nn.Parameters are the logical [r, in] / [out, r] views.
+        for m in mods:
+            m.rank_pad = (1 << 30) if m.is_lokr else (m.lora_dim + 15) // 16 * 16  # LoKr: no rank slab (never grouped)
+
+        def block_shape(m, which):
+            w = (m.lora_down if which == "down" else m.lora_up).weight
+            if m.is_lokr:
+                return tuple(w.shape)
+            return (m.rank_pad, w.shape[1]) if which == "down" else (w.shape[0], m.rank_pad)
+
+        groups = [g for g in (groups or []) if sum(x.rank_pad for x in g) <= 64]
+        n = sum(block_shape(m, "down")[0] * block_shape(m, "down")[1] + block_shape(m, "up")[0] * block_shape(m, "up")[1] for m in mods)
         n_mat = n  # [0, n_mat): the matrices (shadowed in bf16); [n_mat, n): DoRA magnitude vectors (fp32 only)
         n += sum(m.magnitude.numel() for m in mods if m.magnitude is not None)
-        self.arena_p = torch.empty(n, dtype=torch.float32, device=device)
+        self.arena_p = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_g = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_m = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_v = torch.zeros(n, dtype=torch.float32, device=device)
@@ -350,20 +363,21 @@ class FusedLoRANetwork(nn.Module):
         for m, which in order:
             lin = m.lora_down if which == "down" else m.lora_up
             w = lin.weight.data
-            rows, cols = w.shape
+            rows, cols = block_shape(m, which)
             cnt = rows * cols
-            view = self.arena_p[off:off + cnt].view(rows, cols)
+            block = self.arena_p[off:off + cnt].view(rows, cols)
+            view = block[: w.shape[0], : w.shape[1]]  # logical matrix: leading rows (down) / leading columns (up) of the block
             view.copy_(w)
             lin.weight = nn.Parameter(view, requires_grad=True)
-            gview = self.arena_g[off:off + cnt].view(rows, cols)
-            lin.weight.grad = gview
+            gblock = self.arena_g[off:off + cnt].view(rows, cols)
+            lin.weight.grad = gblock[: w.shape[0], : w.shape[1]]
             sh = self.arena_shadow[off:off + cnt].view(rows, cols)
             shT = self.arena_shadow[n_mat + off:n_mat + off + cnt].view(cols, rows)
             entries.append((off, off, n_mat + off, rows, cols))
             if which == "down":
-                m.off_down, m.g_down, m.sh_down, m.sh_downT = off, gview, sh, shT
+                m.off_down, m.g_down, m.sh_down, m.sh_downT, m.blk_down = off, gblock, sh, shT, (rows, cols)
             else:
-                m.off_up, m.g_up, m.sh_up, m.sh_upT = off, gview, sh, shT
+                m.off_up, m.g_up, m.sh_up, m.sh_upT, m.blk_up = off, gblock, sh, shT, (rows, cols)
             off += cnt
         assert off == n_mat
         for m in mods:
@@ -388,14 +402,14 @@ class FusedLoRANetwork(nn.Module):
         self.groups = []
         for grp in groups or []:
             first = grp[0]
-            rtot = sum(x.lora_dim for x in grp)
+            rtot = sum(x.rank_pad for x in grp)
             cin = first.in_features
             assert all(x.in_features == cin and x.scale == first.scale for x in grp)
             o0 = first.off_down
-            assert [x.off_down for x in grp] == [o0 + sum(y.lora_dim for y in grp[:i]) * cin for i in range(len(grp))]
+            assert [x.off_down for x in grp] == [o0 + sum(y.rank_pad for y in grp[:i]) * cin for i in range(len(grp))]
             g = {"mods": grp, "R": rtot, "sh_down": self.arena_shadow[o0:o0 + rtot * cin].view(rtot, cin),
                  "g_down": self.arena_g[o0:o0 + rtot * cin].view(rtot, cin), "scale": first.scale,
-                 "col": {id(x): sum(y.lora_dim for y in grp[:i]) for i, x in enumerate(grp)}}
+                 "col": {id(x): sum(y.rank_pad for y in grp[:i]) for i, x in enumerate(grp)}}
             for x in grp:
                 x.group = g
             self.groups.append(g)
@@ -406,6 +420,16 @@ class FusedLoRANetwork(nn.Module):
         self._arena_built = True
         self._update_torch_multiplier()
         return self
+
+    def arena_view(self, arena, m, which, padded=False):
+        """The [rows, cols] matrix of module m inside a flat arena (arena_p / _g / _m / _v / _ema): the padded block, or the
+        logical (unpadded) view of it."""
+        off, (rows, cols) = (m.off_down, m.blk_down) if which == "down" else (m.off_up, m.blk_up)
+        block = arena[off:off + rows * cols].view(rows, cols)
+        if padded:
+            return block
+        w = (m.lora_down if which == "down" else m.lora_up).weight
+        return block[: w.shape[0], : w.shape[1]]
 
     def refresh_shadows(self, ops):
         """bf16 copies (both orientations) of every adapter matrix; call after each optimizer step / weight load."""
@@ -431,18 +455,18 @@ class FusedLoRANetwork(nn.Module):
             lin = m.org_module[0]
             if getattr(lin, "qweight", None) is not None:
                 raise NotImplementedError("DoRA over a weight-only fp8 base is not on the fused path")
-            dev, r = self.arena_p.device, m.lora_dim
+            dev, r = self.arena_p.device, m.rank_pad
             tw = torch.empty(lin.out_features, r, dtype=self.shadow_dtype, device=dev)
             ops.lora_down(lin.weight.data, m.sh_down, tw, scale=1.0, M=lin.out_features)
             gram = torch.zeros(r, r, dtype=torch.float32, device=dev)
             ops.lora_wgrad(m.sh_downT, m.sh_downT, gram, M=m.in_features)
-            ops.dora_colscale(m.w2, tw, m.lora_up.weight.data, gram, m.magnitude.data, m.scale * vals[0], m.c)
+            ops.dora_colscale(m.w2, tw, self.arena_view(self.arena_p, m, "up", padded=True), gram, m.magnitude.data, m.scale * vals[0], m.c)
 
     def zero_grad_arena(self):
         self.arena_g.zero_()
         for m in self.get_all_modules():  # optimizer.zero_grad(set_to_none=True) may have dropped the views
-            m.lora_down.weight.grad = m.g_down
-            m.lora_up.weight.grad = m.g_up
+            m.lora_down.weight.grad = self.arena_view(self.arena_g, m, "down")
+            m.lora_up.weight.grad = self.arena_view(self.arena_g, m, "up")
             if m.magnitude is not None:
                 m.magnitude.grad = m.g_mag
 
@@ -506,17 +530,17 @@ class FusedLoRANetwork(nn.Module):
         for m in self.get_all_modules():
             base = m.lora_name.replace("$$", ".")
             if getattr(m, "is_lokr", False):  # <name>.lokr_w1 / .lokr_w2 / .alpha — LoKr keeps alpha (network_mixins.py:613-616)
-                for key, w, off in (("lokr_w1", m.lokr_w1.detach(), m.off_up), ("lokr_w2", m.lokr_w2.detach(), m.off_down)):
+                for key, w, which in (("lokr_w1", m.lokr_w1.detach(), "up"), ("lokr_w2", m.lokr_w2.detach(), "down")):
                     if src is not None:
-                        w = src[off:off + w.numel()].view_as(w)
-                    sd[f"{base}.{key}"] = w.clone().to("cpu").to(dtype)
+                        w = self.arena_view(src, m, which)
+                    sd[f"{base}.{key}"] = w.clone().contiguous().to("cpu").to(dtype)
                 sd[f"{base}.alpha"] = m.alpha.detach().clone().to("cpu").to(dtype)
                 continue
-            for which, lin, off in (("lora_A", m.lora_down, m.off_down), ("lora_B", m.lora_up, m.off_up)):
+            for key, lin, which in (("lora_A", m.lora_down, "down"), ("lora_B", m.lora_up, "up")):
                 w = lin.weight.detach()
                 if src is not None:
-                    w = src[off:off + w.numel()].view_as(w)
-                sd[f"{base}.{which}.weight"] = w.clone().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
+                    w = self.arena_view(src, m, which)
+                sd[f"{base}.{key}.weight"] = w.clone().contiguous().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
             if m.magnitude is not None:
                 w = m.magnitude.detach()
                 if src is not None:
@@ -603,9 +627,6 @@ class FusedLoRANetwork(nn.Module):
                 continue
             bs = torch.empty_like(m.sh_up)
             ops.ew(3, m.sh_up, bs, alpha=float(merge_weight) * m.scale)
-            r = m.lora_dim
-            if r % 8:
-                raise NotImplementedError("merge needs rank % 8 == 0")
             ops.gemm_nt(bs, m.sh_downT, lin.weight.data, flags=2)          # [out,in] += (cB)[out,r] . A^T[in,r]^T
             if getattr(lin, "weight_t", None) is not None:
                 ops.gemm_nt(m.sh_downT, bs, lin.weight_t, flags=2)         # [in,out] += A^T[in,r] . (cB)[out,r]^T
@@ -632,8 +653,8 @@ class FusedLoRANetwork(nn.Module):
     def _opt_order(m):
         """(holder, arena offset) in the reference module's named_parameters() order."""
         if getattr(m, "is_lokr", False):
-            return ((m.lora_up, m.off_up), (m.lora_down, m.off_down))  # lokr_w1, lokr_w2
-        return ((m.lora_down, m.off_down), (m.lora_up, m.off_up))
+            return ((m.lora_up, "up"), (m.lora_down, "down"))  # lokr_w1, lokr_w2
+        return ((m.lora_down, "down"), (m.lora_up, "up"))
 
     def optimizer_state_dict(self, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01):
         """The fused AdamW state exported in torch.optim.AdamW.state_dict() layout (params in prepare_optimizer_params
@@ -641,10 +662,9 @@ class FusedLoRANetwork(nn.Module):
         state, ids = {}, []
         i = 0
         for m in self.unet_loras:
-            for lin, off in self._opt_order(m):
-                n = lin.weight.numel()
-                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.arena_m[off:off + n].view_as(lin.weight).clone().cpu(),
-                            "exp_avg_sq": self.arena_v[off:off + n].view_as(lin.weight).clone().cpu()}
+            for lin, which in self._opt_order(m):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.arena_view(self.arena_m, m, which).clone().contiguous().cpu(),
+                            "exp_avg_sq": self.arena_view(self.arena_v, m, which).clone().contiguous().cpu()}
                 ids.append(i)
                 i += 1
         group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
@@ -655,11 +675,10 @@ class FusedLoRANetwork(nn.Module):
         """Inverse of optimizer_state_dict; returns the step count."""
         i, step = 0, 0
         for m in self.unet_loras:
-            for lin, off in self._opt_order(m):
-                n = lin.weight.numel()
+            for lin, which in self._opt_order(m):
                 st = sd["state"][i]
-                self.arena_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
-                self.arena_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self.arena_view(self.arena_m, m, which).copy_(st["exp_avg"])
+                self.arena_view(self.arena_v, m, which).copy_(st["exp_avg_sq"])
                 step = int(float(st["step"]))
                 i += 1
         return step

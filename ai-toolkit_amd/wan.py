@@ -397,7 +397,7 @@ class WanTransformer3DModel(FusedGraphBase):
             dT_out = None
             if grp is not None:
                 c0 = grp["col"][id(lin.lora)]
-                dT_out = dTcat[:, c0:c0 + lin.lora.lora_dim]
+                dT_out = dTcat[:, c0:c0 + lin.lora.rank_pad]
             self._lora_grads(lin, dy, T, enc, M=Mt, rows_per_batch=St, B=B, dT_out=dT_out)
         if grp is not None:
             self.ops.lora_wgrad(dTcat, enc, grp["g_down"], accumulate=True, M=Mt)

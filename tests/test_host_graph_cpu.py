@@ -120,7 +120,7 @@ def test_merge_in_equals_active_adapter_and_merge_out_restores():
     assert net.is_merged_in and not torch.equal(w0, nat.transformer_blocks[0].attn.to_q.weight)
     with net:  # merged => adapters are skipped (toolkit/network_mixins.py:285-287)
         got = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)
-    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-6 * float(want.abs().max()))  # fp32 summation-order noise on O(70) outputs
     lin = nat.transformer_blocks[0].attn.to_q
     assert torch.allclose(lin.weight_t, lin.weight.t(), rtol=0, atol=1e-6)
     net.merge_out(1.0, ops=ref_ops)
@@ -139,7 +139,11 @@ def test_optimizer_state_exports_as_torch_adamw_state_dict():
     assert float(st["step"]) == 7 and torch.equal(st["exp_avg"], net.arena_m[m0.off_down:m0.off_down + m0.lora_down.weight.numel()].view_as(m0.lora_down.weight))
     m_copy = net.arena_m.clone()
     net.arena_m.zero_()
-    assert net.load_optimizer_state_dict(opt.state_dict()) == 7 and torch.equal(net.arena_m, m_copy)
+    assert net.load_optimizer_state_dict(opt.state_dict()) == 7
+    for m in net.unet_loras:  # rank 4 lives in 16-wide padded blocks: every logical matrix is restored (the padding carries no state)
+        for which in ("down", "up"):
+            assert torch.equal(net.arena_view(net.arena_m, m, which), net.arena_view(m_copy, m, which)), (m.lora_name, which)
+    assert m0.rank_pad == 16 and m0.blk_down == (16, m0.in_features) and m0.blk_up == (m0.out_features, 16)
 
 
 def test_attached_network_stays_out_of_base_state_dict():

@@ -39,7 +39,7 @@ def test_three_steps_match_oracle_optimizer_sequence():
         for pa, pb in ((a.lora_down.weight, b.lora_down.weight), (a.lora_up.weight, b.lora_up.weight)):
             assert torch.allclose(pa, pb, rtol=2e-3, atol=2e-6), (a.lora_name, (pa - pb).abs().max())
             e = oracle.ema[i]
-            mine = net.arena_ema[(a.off_down if pa is a.lora_down.weight else a.off_up):][: pa.numel()].view_as(pa)
+            mine = net.arena_view(net.arena_ema, a, "down" if pa is a.lora_down.weight else "up")
             assert torch.allclose(mine, e, rtol=2e-3, atol=2e-6)
             i += 1
 
