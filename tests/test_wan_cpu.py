@@ -252,3 +252,49 @@ def test_oracle_attention_equals_reference_wan_attention_processor():
         got_cross = attn(t["x"], t["enc"], None)
     assert torch.allclose(got_self, t["self"], rtol=1e-5, atol=1e-6), (got_self - t["self"]).abs().max()
     assert torch.allclose(got_cross, t["cross"], rtol=1e-5, atol=1e-6)
+
+
+def _wan_dp_worker(rank, world, port, out):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    ref, ref_net, nat, net = build_pair(rank=4)
+    step = WanLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
+    for k in range(2):  # every step = a batch list of two micro-batches (gradient accumulation): the all-reduce is issued once
+        micro = []
+        for j in range(2):
+            lat, txt, t = inputs(B=2, seed=60 + 2 * k + j)
+            noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(80 + 2 * k + j))
+            sl = slice(rank, rank + 1)  # disjoint shard of each micro-batch
+            micro.append(dict(latents=lat[sl], prompt_embeds=txt[sl], noise=noise[sl], timesteps=t[sl]))
+        step.step_list(micro)
+    torch.save(net.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_wan_dp2_gloo_with_accumulation_equals_single_rank(tmp_path):
+    """Wan step, 2 ranks x 2 accumulated micro-batches (all-reduce pieces 'late' / 'early' issued by the last backward only)
+    == one rank on the concatenated micro-batches; ranks end bit-identical."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    port = 29100 + os.getpid() % 400
+    mp.spawn(_wan_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1)
+    ref, ref_net, nat, net = build_pair(rank=4)
+    step = WanLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5)
+    for k in range(2):
+        micro = []
+        for j in range(2):
+            lat, txt, t = inputs(B=2, seed=60 + 2 * k + j)
+            noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(80 + 2 * k + j))
+            micro.append(dict(latents=lat, prompt_embeds=txt, noise=noise, timesteps=t))
+        step.step_list(micro)
+    # DP(2) averages rank gradients of per-rank means over 1 sample = the mean over the 2-sample micro-batch
+    assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
