@@ -34,17 +34,28 @@ __global__ __launch_bounds__(256) void gemv_nt_kernel(AitkGemvArgs p) {
     float acc[GEMV_MAXB];
 #pragma unroll
     for (int bb = 0; bb < GEMV_MAXB; ++bb) acc[bb] = 0.f;
-    for (int c = sub; c < kch; c += 16) {
-      const uint4 wv = *reinterpret_cast<const uint4*>(wrow + c * 8);
-      float w[8];
-      w[0] = bf2f(wv.x & 0xffff); w[1] = bf2f(wv.x >> 16); w[2] = bf2f(wv.y & 0xffff); w[3] = bf2f(wv.y >> 16);
-      w[4] = bf2f(wv.z & 0xffff); w[5] = bf2f(wv.z >> 16); w[6] = bf2f(wv.w & 0xffff); w[7] = bf2f(wv.w >> 16);
+    for (int c0 = sub; c0 < kch; c0 += 64) {  // four 16-B weight loads in flight per lane before the first FMA
+      uint4 wq[4];
 #pragma unroll
-      for (int bb = 0; bb < GEMV_MAXB; ++bb) {
-        if (bb < p.Bm) {
-          const uint4 xv = *reinterpret_cast<const uint4*>(xs + (long)bb * p.K + c * 8);
-          acc[bb] += w[0] * bf2f(xv.x & 0xffff) + w[1] * bf2f(xv.x >> 16) + w[2] * bf2f(xv.y & 0xffff) + w[3] * bf2f(xv.y >> 16) +
-                     w[4] * bf2f(xv.z & 0xffff) + w[5] * bf2f(xv.z >> 16) + w[6] * bf2f(xv.w & 0xffff) + w[7] * bf2f(xv.w >> 16);
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        wq[u] = c < kch ? *reinterpret_cast<const uint4*>(wrow + c * 8) : uint4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        if (c >= kch) break;
+        const uint4 wv = wq[u];
+        float w[8];
+        w[0] = bf2f(wv.x & 0xffff); w[1] = bf2f(wv.x >> 16); w[2] = bf2f(wv.y & 0xffff); w[3] = bf2f(wv.y >> 16);
+        w[4] = bf2f(wv.z & 0xffff); w[5] = bf2f(wv.z >> 16); w[6] = bf2f(wv.w & 0xffff); w[7] = bf2f(wv.w >> 16);
+#pragma unroll
+        for (int bb = 0; bb < GEMV_MAXB; ++bb) {
+          if (bb < p.Bm) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(xs + (long)bb * p.K + c * 8);
+            acc[bb] += w[0] * bf2f(xv.x & 0xffff) + w[1] * bf2f(xv.x >> 16) + w[2] * bf2f(xv.y & 0xffff) + w[3] * bf2f(xv.y >> 16) +
+                       w[4] * bf2f(xv.z & 0xffff) + w[5] * bf2f(xv.z >> 16) + w[6] * bf2f(xv.w & 0xffff) + w[7] * bf2f(xv.w >> 16);
+          }
         }
       }
     }
@@ -84,7 +95,7 @@ extern "C" int aitk_gemv_nt(const AitkGemvArgs* a, aitk_stream_t stream) {
   const size_t lds = (size_t)a->Bm * a->K * 2;
   if (lds > 64 * 1024) return AITK_ERR_SHAPE;
   AitkGemvArgs args = *a;
-  args.cols_per_group = 4;
+  args.cols_per_group = 1;  // 16 columns per workgroup: N / 16 workgroups (> 4 per CU for the adaLN projections) keep enough loads in flight
   const int ncol = 16 * args.cols_per_group;
   hipLaunchKernelGGL(gemv_nt_kernel, dim3((a->N + ncol - 1) / ncol), dim3(256), lds, (hipStream_t)stream, args);
   AITK_LAUNCH_CHECK();
