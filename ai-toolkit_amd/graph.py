@@ -40,6 +40,19 @@ class _Holder(nn.Module):
     pass
 
 
+@torch.no_grad()
+def quantize_linear_fp8(lin, w):
+    """lin.qweight / qweight_t / wscale from a [out, in] weight: OCP e4m3 bytes with one fp32 scale per output channel
+    (amax / 448) — used at load time (quantize_base_fp8) and when an adapter is merged into a quantised base
+    (toolkit/network_mixins.py:452-459: merged weights are re-quantised so the model stays quantised)."""
+    w = w.float()
+    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    lin.qweight = q.view(torch.uint8).contiguous()
+    lin.qweight_t = q.view(torch.uint8).t().contiguous()
+    lin.wscale = scale
+
+
 _KRON = object()  # marker travelling where the rank-r activation T / its gradient dT travel for LoRA layers
 
 
@@ -89,12 +102,7 @@ class FusedGraphBase(nn.Module):
         from `qweight_t` [in,out]; aitk_gemm_nt can also consume the fp8 bytes directly (b_scale, slower).  adaLN / embedder
         projections (B rows, weight streaming) keep bf16 weights."""
         for lin in self._token_linears():
-            w = lin.weight.data.float()
-            scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
-            q = (w / scale[:, None]).to(torch.float8_e4m3fn)
-            lin.qweight = q.view(torch.uint8).contiguous()
-            lin.qweight_t = q.view(torch.uint8).t().contiguous()
-            lin.wscale = scale
+            quantize_linear_fp8(lin, lin.weight.data)
             lin.weight_t = None
             if release_bf16:
                 lin.weight.data = torch.empty(0, dtype=lin.weight.dtype, device=lin.weight.device)

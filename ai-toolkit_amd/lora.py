@@ -627,6 +627,15 @@ class FusedLoRANetwork(nn.Module):
                 continue
             bs = torch.empty_like(m.sh_up)
             ops.ew(3, m.sh_up, bs, alpha=float(merge_weight) * m.scale)
+            if getattr(lin, "qweight", None) is not None:
+                # weight-only fp8 base: dequantise, add the delta, re-quantise (toolkit/network_mixins.py:452-459) — the model
+                # stays quantised across merge / reset cycles; the scale per output channel is recomputed from the merged row
+                from .graph import quantize_linear_fp8
+
+                w = (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(m.sh_up.dtype)
+                ops.gemm_nt(bs, m.sh_downT, w, flags=2)
+                quantize_linear_fp8(lin, w)
+                continue
             ops.gemm_nt(bs, m.sh_downT, lin.weight.data, flags=2)          # [out,in] += (cB)[out,r] . A^T[in,r]^T
             if getattr(lin, "weight_t", None) is not None:
                 ops.gemm_nt(m.sh_downT, bs, lin.weight_t, flags=2)         # [in,out] += A^T[in,r] . (cB)[out,r]^T

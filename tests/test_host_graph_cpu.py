@@ -171,3 +171,26 @@ def test_fp8_weight_only_base_matches_oracle_with_dequantised_weights():
     for a, b in zip(net.unet_loras, ref_net.unet_loras):
         err = (a.lora_down.weight.grad - b.lora_down.weight.grad).norm() / (b.lora_down.weight.grad.norm() + 1e-12)
         assert err < 2e-4, (a.lora_name, err.item())
+
+
+def test_merge_into_weight_only_fp8_base_requantises():
+    """toolkit/network_mixins.py:452-459: merging into a quantised base dequantises, adds scale * up @ down and re-quantises, so
+    the model stays quantised across merge / reset cycles."""
+    ref, ref_net, nat, net = build_pair(rank=4)
+    nat.quantize_base_fp8()
+    lin = nat.transformer_blocks[0].attn.to_q
+    m = lin.lora
+    deq = lambda: lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]  # noqa: E731
+    w0 = deq()
+    delta = 0.7 * m.scale * (m.lora_up.weight.detach() @ m.lora_down.weight.detach())
+    net.merge_in(0.7, ops=ref_ops)
+    assert net.is_merged_in and lin.qweight.dtype == torch.uint8 and lin.weight_t is None
+    w1 = deq()
+    step = (w0 + delta).abs().amax(dim=1, keepdim=True) / 448.0 * 32  # e4m3: 3 mantissa bits -> spacing <= amax / 14 at the top binade
+    assert ((w1 - (w0 + delta)).abs() <= 0.5 * step + 1e-7).all()
+    assert torch.allclose(lin.qweight_t, lin.qweight.t()) and not torch.equal(w1, w0)
+    # exactly what a fresh quantisation of the merged weight gives
+    q_ref = ((w0 + delta) / lin.wscale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(lin.qweight, q_ref)
+    net.merge_out(0.7, ops=ref_ops)
+    assert ((deq() - w0).abs() <= step).all()  # two roundings away from the original at most
