@@ -19,8 +19,9 @@ model's DoubleStreamBlock / SingleStreamBlock / LastLayer / EmbedND / timestep_e
 tests/golden/make_golden.py (golden_flux_blocks) on this file's weights mapped through the reference's diffusers<->BFL key map,
 and tests/test_flux_blocks_golden.py holds this file to those outputs (RoPE table and application, QK-RMSNorm, joint attention
 order, gate / residual / MLP arithmetic, single-block split and concat order, last layer with the [scale, shift] swap, timestep
-sinusoid and its MLP).  Still UNPINNED (diffusers-only conventions, anchored on the key map and call sites above): the chunk
-order of the adaLN projections, the sum of the timestep / guidance / pooled-text embedders, x_embedder / context_embedder.
+sinusoid and its MLP, and the timestep + pooled-text embedder sum through the reference's guidance_embed_bypass_forward,
+toolkit/models/flux.py:8-14).  Still UNPINNED (diffusers-only conventions, anchored on the key map and call sites above): the chunk
+order of the adaLN projections, the guidance-embedder term, x_embedder / context_embedder.
 Class and attribute names follow diffusers exactly so the reference's LoRASpecialNetwork attaches to it and produces the
 reference's state-dict keys (pinned as well, see tests/golden/make_golden.py).
 """
@@ -71,6 +72,12 @@ class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
         self.timestep_embedder = TimestepEmbedding(256, embedding_dim)
         self.guidance_embedder = TimestepEmbedding(256, embedding_dim)
         self.text_embedder = PixArtAlphaTextProjection(pooled_projection_dim, embedding_dim)
+
+    @staticmethod
+    def time_proj(t):
+        """diffusers `Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0)` — the attribute the reference's
+        guidance_embed_bypass_forward calls (toolkit/models/flux.py:9)."""
+        return get_timestep_embedding(t, 256)
 
     def forward(self, timestep, guidance, pooled_projection):
         t_emb = self.timestep_embedder(get_timestep_embedding(timestep).to(pooled_projection.dtype))

@@ -326,6 +326,17 @@ def golden_flux_blocks():
         emb.load_state_dict({"in_layer.weight": te.linear_1.weight.detach().clone(), "in_layer.bias": te.linear_1.bias.detach().clone(),
                              "out_layer.weight": te.linear_2.weight.detach().clone(), "out_layer.bias": te.linear_2.bias.detach().clone()})
         out["ref/t_mlp"] = emb(out["ref/t_sinusoid"]).clone()
+        # embedder composition: the reference's guidance_embed_bypass_forward (toolkit/models/flux.py:8-14) executed on the
+        # oracle's time_text_embed module = timestep_embedder(time_proj(t)) + text_embedder(pooled)  (no guidance term)
+        import importlib.util as _ilu
+
+        spec = _ilu.spec_from_file_location("flux_bypass_ref", "/root/reference/toolkit/models/flux.py")
+        fb = _ilu.module_from_spec(spec)
+        spec.loader.exec_module(fb)
+        pooled = torch.randn(2, TINY["pooled_projection_dim"], generator=g)
+        t1000 = tt * 1000  # the transformer multiplies its timestep / 1000 input by 1000 before time_text_embed
+        out["in/pooled"] = pooled
+        out["ref/cond_no_guidance"] = fb.guidance_embed_bypass_forward(model.time_text_embed, t1000, None, pooled).clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "flux_blocks_chroma.safetensors"),
               {"cfg": json.dumps(TINY), "shape": json.dumps([B, Hl, Wl, n_txt])})
     print("flux block golden (reference Chroma blocks) written:", {k: tuple(v.shape) for k, v in out.items() if k.startswith("ref/")})

@@ -62,6 +62,12 @@ def test_oracle_blocks_equal_reference_chroma_blocks():
         sinus = flux_ref.get_timestep_embedding(t["in/t"] * 1000, 256)
         assert torch.allclose(sinus, t["ref/t_sinusoid"], rtol=1e-5, atol=1e-6)
         assert torch.allclose(model.time_text_embed.timestep_embedder(t["ref/t_sinusoid"]), t["ref/t_mlp"], rtol=1e-5, atol=1e-6)
+        # embedder sum: the reference's guidance-bypass forward (toolkit/models/flux.py:8-14) = oracle forward minus the guidance term
+        tte = model.time_text_embed
+        t1000, guid = t["in/t"] * 1000, torch.tensor([3.5, 1.0]) * 1000
+        full = tte(t1000, guid, t["in/pooled"])
+        g_term = tte.guidance_embedder(flux_ref.get_timestep_embedding(guid, 256))
+        assert torch.allclose(full - g_term, t["ref/cond_no_guidance"], rtol=1e-5, atol=1e-5)
 
 
 def test_native_host_graph_blocks_equal_reference_chroma_blocks():
