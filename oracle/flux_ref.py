@@ -20,8 +20,10 @@ tests/golden/make_golden.py (golden_flux_blocks) on this file's weights mapped t
 and tests/test_flux_blocks_golden.py holds this file to those outputs (RoPE table and application, QK-RMSNorm, joint attention
 order, gate / residual / MLP arithmetic, single-block split and concat order, last layer with the [scale, shift] swap, timestep
 sinusoid and its MLP, and the timestep + pooled-text embedder sum through the reference's guidance_embed_bypass_forward,
-toolkit/models/flux.py:8-14).  Still UNPINNED (diffusers-only conventions, anchored on the key map and call sites above): the chunk
-order of the adaLN projections, the guidance-embedder term, x_embedder / context_embedder.
+toolkit/models/flux.py:8-14).  Not executable-pinned (diffusers-only glue): the chunk order of the adaLN projections — (shift, scale,
+gate) x 2, the order in which the reference's distribute_modulations (chroma/src/layers.py:92-176) fills `img_mod.lin` /
+`txt_mod.lin` / `modulation.lin`, which the key map sends to norm1.linear / norm1_context.linear / norm.linear unchanged —
+the guidance-embedder term (same form as the pinned timestep embedder) and the plain x_embedder / context_embedder Linears.
 Class and attribute names follow diffusers exactly so the reference's LoRASpecialNetwork attaches to it and produces the
 reference's state-dict keys (pinned as well, see tests/golden/make_golden.py).
 """
