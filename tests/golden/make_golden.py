@@ -493,6 +493,32 @@ def golden_vae_encoder():
     print("vae encoder golden written", tuple(out["moments"].shape))
 
 
+def golden_latent_cache_paths():
+    """`_latent_cache/<stem>_<hash>.safetensors` names computed by the reference's own FileItemDTO mixin methods
+    (toolkit/dataloader_mixins.py:1779-1842 get_latent_info_dict / get_latent_path) for a few crop plans / flips."""
+    import types
+
+    sys.modules.setdefault("info", types.SimpleNamespace(software_meta={"name": "ai-toolkit"}))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    import toolkit.dataloader_mixins as dm
+
+    cases = []
+    for path, geo, flips, lsv in (("/data/set/cat 01.JPG", (1536, 1024, 0, 0, 1536, 1024), (False, False), "flux1"),
+                                  ("/data/x/img.png", (1024, 1540, 0, 2, 1024, 1536), (True, False), "flux1"),
+                                  ("/data/x/a.b.webp", (832, 1250, 0, 17, 832, 1216), (False, True), "sdxl"),
+                                  ("rel/dir/q.jpeg", (1216, 832, 0, 0, 1216, 832), (True, True), "wan21")):
+        it = types.SimpleNamespace(path=path, scale_to_width=geo[0], scale_to_height=geo[1], crop_x=geo[2], crop_y=geo[3],
+                                   crop_width=geo[4], crop_height=geo[5], latent_space_version=lsv, latent_version=1,
+                                   flip_x=flips[0], flip_y=flips[1], is_video=False, is_audio_model=False, _latent_path=None,
+                                   dataset_config=types.SimpleNamespace(cache_tensors_to_disk=False, auto_frame_count=False, num_frames=1))
+        it.get_latent_info_dict = types.MethodType(dm.LatentCachingFileItemDTOMixin.get_latent_info_dict, it)
+        out_path = dm.LatentCachingFileItemDTOMixin.get_latent_path(it)
+        cases.append({"path": path, "geometry": list(geo), "flip_x": flips[0], "flip_y": flips[1], "latent_space_version": lsv,
+                      "latent_path": out_path, "info": it.get_latent_info_dict()})
+    json.dump(cases, open(os.path.join(HERE, "latent_cache_paths.json"), "w"), indent=1)
+    print("latent cache path golden written:", [os.path.basename(c["latent_path"]) for c in cases])
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -524,5 +550,6 @@ if __name__ == "__main__":
     golden_model_hash()
     golden_merge()
     golden_vae_encoder()
+    golden_latent_cache_paths()
     golden_flowmatch()
     golden_wan_lora_keys()

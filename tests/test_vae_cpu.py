@@ -73,3 +73,15 @@ def test_oracle_encoder_equals_reference_ldm_encoder():
         assert torch.allclose(chk, t["w_checksum"], rtol=1e-6)
         got = enc(t["x"])
     assert torch.allclose(got, t["moments"], rtol=1e-4, atol=1e-5), (got - t["moments"]).abs().max()
+
+
+def test_latent_cache_paths_equal_reference_file_item_methods():
+    """`_latent_cache` file names against the reference's own FileItemDTO.get_latent_info_dict / get_latent_path
+    (toolkit/dataloader_mixins.py:1779-1842), executed by make_golden.py: an existing cache made by the reference is found."""
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "latent_cache_paths.json")))
+    assert len(cases) == 4
+    for c in cases:
+        plan = bk.CropPlan(*c["geometry"])
+        info = nvae.latent_info_dict(c["path"], plan, c["latent_space_version"], flip_x=c["flip_x"], flip_y=c["flip_y"])
+        assert dict(info) == c["info"] and list(info) == list(c["info"]), c["path"]
+        assert nvae.latent_cache_path(c["path"], info) == c["latent_path"], c["path"]
