@@ -27,6 +27,22 @@ class TrainBatch:
     pooled_embeds: torch.Tensor  # [B, P]
 
 
+def text_embedding_cache_path(image_path: str, caption: str, text_embedding_space_version: str, text_embedding_version: int = 1) -> str:
+    """`_t_e_cache/<stem>_<hash>.safetensors` of the reference's text-embedding cache (toolkit/dataloader_mixins.py:2120-2163):
+    md5 of the JSON of (caption, text_embedding_space_version, text_embedding_version), urlsafe-base64 without padding —
+    the plain-caption case (no control image / first-frame conditioning keys)."""
+    import base64
+    import hashlib
+    import json
+    from collections import OrderedDict
+
+    info = OrderedDict([("caption", caption), ("text_embedding_space_version", text_embedding_space_version),
+                        ("text_embedding_version", text_embedding_version)])
+    h = base64.urlsafe_b64encode(hashlib.md5(json.dumps(info, sort_keys=True).encode("utf-8")).digest()).decode("ascii").replace("=", "")
+    stem = os.path.splitext(os.path.basename(image_path))[0]
+    return os.path.join(os.path.dirname(image_path), "_t_e_cache", f"{stem}_{h}.safetensors")
+
+
 def save_prompt_embeds(path: str, text_embed: torch.Tensor, pooled_embed: Optional[torch.Tensor] = None,
                        attention_mask: Optional[torch.Tensor] = None):
     from safetensors.torch import save_file

@@ -515,8 +515,27 @@ def golden_latent_cache_paths():
         out_path = dm.LatentCachingFileItemDTOMixin.get_latent_path(it)
         cases.append({"path": path, "geometry": list(geo), "flip_x": flips[0], "flip_y": flips[1], "latent_space_version": lsv,
                       "latent_path": out_path, "info": it.get_latent_info_dict()})
-    json.dump(cases, open(os.path.join(HERE, "latent_cache_paths.json"), "w"), indent=1)
-    print("latent cache path golden written:", [os.path.basename(c["latent_path"]) for c in cases])
+    # text-embedding cache names (2120-2163) for plain captions, and a PromptEmbeds file written by the reference's own
+    # PromptEmbeds.save (toolkit/prompt_utils.py:119-141)
+    te = []
+    for path, caption, space in (("/data/set/cat 01.JPG", "a photo of a cat, [trigger]", "flux1"), ("/d/x.png", "", "wan21"),
+                                 ("rel/q.jpeg", "ünïcode caption \u2603", "flux1")):
+        it = types.SimpleNamespace(path=path, caption=caption, text_embedding_space_version=space, text_embedding_version=1,
+                                   encode_control_in_text_embeddings=False, control_path=None, is_video=False,
+                                   dataset_config=types.SimpleNamespace(do_i2v=False), _text_embedding_path=None)
+        it.get_text_embedding_info_dict = types.MethodType(dm.TextEmbeddingFileItemDTOMixin.get_text_embedding_info_dict, it)
+        it._build_text_embedding_path = types.MethodType(dm.TextEmbeddingFileItemDTOMixin._build_text_embedding_path, it)
+        te.append({"path": path, "caption": caption, "space": space, "te_path": dm.TextEmbeddingFileItemDTOMixin.get_text_embedding_path(it)})
+    from toolkit.prompt_utils import PromptEmbeds
+
+    g = torch.Generator().manual_seed(71)
+    pe = PromptEmbeds(None)
+    pe.text_embeds = torch.randn(1, 6, 8, generator=g).to(torch.bfloat16)
+    pe.pooled_embeds = torch.randn(1, 4, generator=g).to(torch.bfloat16)
+    pe.attention_mask = None
+    pe.save(os.path.join(HERE, "prompt_embeds_ref.safetensors"))
+    json.dump({"latent": cases, "text": te}, open(os.path.join(HERE, "latent_cache_paths.json"), "w"), indent=1)
+    print("cache path golden written:", [os.path.basename(c["latent_path"]) for c in cases], [os.path.basename(c["te_path"]) for c in te])
 
 
 def golden_wan_lora_keys():

@@ -78,10 +78,26 @@ def test_oracle_encoder_equals_reference_ldm_encoder():
 def test_latent_cache_paths_equal_reference_file_item_methods():
     """`_latent_cache` file names against the reference's own FileItemDTO.get_latent_info_dict / get_latent_path
     (toolkit/dataloader_mixins.py:1779-1842), executed by make_golden.py: an existing cache made by the reference is found."""
-    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "latent_cache_paths.json")))
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "latent_cache_paths.json")))
+    cases = gold["latent"]
     assert len(cases) == 4
     for c in cases:
         plan = bk.CropPlan(*c["geometry"])
         info = nvae.latent_info_dict(c["path"], plan, c["latent_space_version"], flip_x=c["flip_x"], flip_y=c["flip_y"])
         assert dict(info) == c["info"] and list(info) == list(c["info"]), c["path"]
         assert nvae.latent_cache_path(c["path"], info) == c["latent_path"], c["path"]
+
+
+def test_text_embedding_cache_names_and_prompt_embeds_file_equal_reference():
+    """`_t_e_cache` names against the reference's get_text_embedding_path, and a file written by the reference's own
+    PromptEmbeds.save read back by load_prompt_embeds (toolkit/prompt_utils.py:119-190)."""
+    from ai_toolkit_amd import batches
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "latent_cache_paths.json")))
+    assert len(gold["text"]) == 3
+    for c in gold["text"]:
+        assert batches.text_embedding_cache_path(c["path"], c["caption"], c["space"]) == c["te_path"], c["path"]
+    text, pooled, mask = batches.load_prompt_embeds(os.path.join(os.path.dirname(__file__), "golden", "prompt_embeds_ref.safetensors"))
+    g = torch.Generator().manual_seed(71)
+    assert torch.equal(text, torch.randn(1, 6, 8, generator=g).to(torch.bfloat16))
+    assert torch.equal(pooled, torch.randn(1, 4, generator=g).to(torch.bfloat16)) and mask is None
