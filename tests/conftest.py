@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (multi-process gloo rendezvous of the DP tests)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

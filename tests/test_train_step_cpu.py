@@ -46,7 +46,9 @@ def test_three_steps_match_oracle_optimizer_sequence():
 
 def _dp_worker(rank, world, port, out, network_type):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.set_num_threads(2)
     ref, ref_net, nat, net = build_pair(rank=4, network_type=network_type)
     step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
@@ -61,7 +63,9 @@ def _dp_worker(rank, world, port, out, network_type):
 @pytest.mark.parametrize("network_type", ["lora", "dora"])
 def test_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path, network_type):
     """DoRA adds the magnitude vectors at the tail of the gradient arena: they join the second all-reduce piece."""
-    port = 29400 + (os.getpid() + (7 if network_type == "dora" else 0)) % 500
+    from tests.conftest import free_port
+
+    port = free_port()
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path), network_type), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert torch.equal(p0, p1), "ranks must hold bit-identical adapter weights"

@@ -260,7 +260,9 @@ def _wan_dp_worker(rank, world, port, out):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.set_num_threads(2)
     ref, ref_net, nat, net = build_pair(rank=4)
     step = WanLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
@@ -283,7 +285,9 @@ def test_wan_dp2_gloo_with_accumulation_equals_single_rank(tmp_path):
 
     import torch.multiprocessing as mp
 
-    port = 29100 + os.getpid() % 400
+    from tests.conftest import free_port
+
+    port = free_port()
     mp.spawn(_wan_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert torch.equal(p0, p1)
