@@ -67,6 +67,14 @@ class FlowMatchTrainSchedule:
             else:
                 sigmas = self.shift * sigmas / (1 + (self.shift - 1) * sigmas)
             self.timesteps = (torch.from_numpy(sigmas).to(dtype=torch.float32, device=device)) * n
+        elif timestep_type == "lognorm_blend":
+            # custom_flowmatch_sampler.py:194-217: 75 % log-normal(0, 0.333) samples scaled into (0, 1000], 25 % linear, sorted, int
+            alpha = 0.75
+            t1 = torch.distributions.LogNormal(loc=0, scale=0.333).sample((int(num_timesteps * alpha),)).to(device)
+            t1 = (1 - t1 / t1.max()) * 1000
+            t2 = torch.linspace(1000, 1, int(num_timesteps * (1 - alpha)), device=device)
+            ts, _ = torch.sort(torch.cat((t1, t2)), descending=True)
+            self.timesteps = ts.to(torch.int).to(device=device)
         else:
             raise ValueError(f"Invalid timestep type: {timestep_type}")
         return self.timesteps

@@ -106,6 +106,8 @@ def golden_flowmatch():
     out = {"linear": s.set_train_timesteps(1000, "cpu", "linear").clone()}
     torch.manual_seed(123)
     out["sigmoid_seed123"] = s.set_train_timesteps(1000, "cpu", "sigmoid").clone()
+    torch.manual_seed(321)
+    out["lognorm_blend_seed321"] = s.set_train_timesteps(1000, "cpu", "lognorm_blend").clone()
     g = torch.Generator().manual_seed(5)
     x0 = torch.randn(3, 16, 8, 8, generator=g)
     eps = torch.randn(3, 16, 8, 8, generator=g)

@@ -126,6 +126,8 @@ def test_flowmatch_schedule_matches_reference_scheduler():
     assert torch.equal(s.set_train_timesteps(1000, "cpu", "linear"), t["linear"])
     torch.manual_seed(123)
     assert torch.equal(s.set_train_timesteps(1000, "cpu", "sigmoid"), t["sigmoid_seed123"])
+    torch.manual_seed(321)
+    assert torch.equal(s.set_train_timesteps(1000, "cpu", "lognorm_blend"), t["lognorm_blend_seed321"])
     x0, eps, ts = t["x0"], t["eps"], t["ts"]
     B, Cc, Hh, W = x0.shape
     noisy = torch.empty(B, Hh * W // 4, Cc * 4)
