@@ -540,6 +540,36 @@ def golden_latent_cache_paths():
     print("cache path golden written:", [os.path.basename(c["latent_path"]) for c in cases], [os.path.basename(c["te_path"]) for c in te])
 
 
+def golden_kohya_to_peft():
+    """The reference's scripts/convert_lora_to_peft_format.py (a CLI script) run on a kohya-format file holding the FLUX adapter
+    names of golden_lora (alpha = rank, as ai-toolkit writes): the PEFT keys it produces, in order."""
+    import subprocess
+    import tempfile
+
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+
+    src = os.path.join(HERE, "lora_flux_tiny.safetensors")
+    with safe_open(src, "pt") as f:
+        names = json.loads(f.metadata()["names"])
+    g = torch.Generator().manual_seed(81)
+    kohya = {}
+    for n in names:  # transformer$$transformer_blocks$$0$$attn$$to_q -> lora_transformer_transformer_blocks_0_attn_to_q
+        base = "lora_" + n.replace("$$", "_")
+        kohya[base + ".lora_down.weight"] = torch.randn(8, 4, generator=g)
+        kohya[base + ".lora_up.weight"] = torch.randn(4, 8, generator=g)
+        kohya[base + ".alpha"] = torch.tensor(8.0)
+    with tempfile.TemporaryDirectory() as td:
+        a, b = os.path.join(td, "kohya.safetensors"), os.path.join(td, "peft.safetensors")
+        save_file(kohya, a)
+        subprocess.check_call([sys.executable, "/root/reference/scripts/convert_lora_to_peft_format.py", a, b], stdout=subprocess.DEVNULL)
+        out = load_file(b)
+    json.dump({"kohya_keys": list(kohya), "peft_keys": sorted(out)}, open(os.path.join(HERE, "kohya_to_peft_keys.json"), "w"), indent=0)
+    chk = {k: float(v.double().sum()) for k, v in out.items()}
+    json.dump(chk, open(os.path.join(HERE, "kohya_to_peft_sums.json"), "w"), indent=0)
+    print("kohya -> peft golden written:", len(out), "tensors")
+
+
 def golden_wan_lora_keys():
     """Key names written by the reference's Wan adapter converter (toolkit/models/wan21/wan_lora_convert.py)."""
     import importlib.util
@@ -572,5 +602,6 @@ if __name__ == "__main__":
     golden_merge()
     golden_vae_encoder()
     golden_latent_cache_paths()
+    golden_kohya_to_peft()
     golden_flowmatch()
     golden_wan_lora_keys()

@@ -66,3 +66,30 @@ def test_saved_file_hashes_equal_the_reference_add_model_hash_to_meta():
         sd = OrderedDict((f"transformer.blocks.{i}.lora_A.weight", torch.randn(shape, generator=g).to(torch.float16)) for i in range(3))
         meta = add_model_hash_to_meta(sd, OrderedDict(ss_output_name="x", ss_base_model_version="flux1", name="not hashed"))
         assert meta["sshs_model_hash"] == gold[tag]["sshs_model_hash"] and meta["sshs_legacy_hash"] == gold[tag]["sshs_legacy_hash"], tag
+
+
+def test_kohya_to_peft_agrees_with_the_reference_script_where_the_script_is_well_formed():
+    """scripts/convert_lora_to_peft_format.py (executed by make_golden.py on a kohya-format file with the FLUX adapter names,
+    alpha = rank) rewrites names with string replacements ("currently only works with flux as support is not quite there yet"): for the
+    attention / proj_mlp / proj_out / single-block norm.linear adapters it yields real module paths and the converter here — which
+    resolves names against the module tree — gives exactly those keys and values; for ff / ff_context / norm1(_context).linear its
+    replacements produce names that are not module paths (`ff.net_0.proj`, `ff.context.net.0.proj`, `norm1_linear`), which the
+    module-tree lookup gets right."""
+    d = os.path.dirname(__file__)
+    gold = json.load(open(os.path.join(d, "golden", "kohya_to_peft_keys.json")))
+    sums = json.load(open(os.path.join(d, "golden", "kohya_to_peft_sums.json")))
+    g = torch.Generator().manual_seed(81)
+    kohya = {}
+    for k in gold["kohya_keys"]:
+        kohya[k] = torch.tensor(8.0) if k.endswith(".alpha") else (torch.randn(8, 4, generator=g) if "lora_down" in k else torch.randn(4, 8, generator=g))
+    model = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu")
+    paths = [n for n, m in model.named_modules() if m.__class__.__name__ == "Linear"]
+    mine = convert.kohya_to_peft(convert.scale_for_alpha(kohya), paths)
+    ref_keys = set(gold["peft_keys"])
+    well_formed = {k for k in ref_keys if k.rsplit(".lora_", 1)[0][len("transformer."):] in paths}
+    assert len(well_formed) == 28 and well_formed <= set(mine)           # 14 adapters: q/k/v/out/add_*/to_add_out, single q/k/v/proj_mlp/proj_out/norm.linear
+    for k in well_formed:
+        assert abs(float(mine[k].double().sum()) - sums[k]) < 1e-9, k
+    bad = sorted(k for k in ref_keys - well_formed)
+    assert all(("ff." in k or "norm1" in k) for k in bad) and len(bad) == 12
+    assert len(mine) == 40 and all(k.rsplit(".lora_", 1)[0][len("transformer."):] in paths for k in mine)
