@@ -64,5 +64,5 @@ for _ in range(n):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print("EAGER", json.dumps({"per_gpu_batch": B, "ms_per_step": round(dt * 1e3, 1), "images_per_s": round(B / dt, 3), "loss": float(loss),
+print("EAGER", json.dumps({"per_gpu_batch": B, "ms_per_step": round(dt * 1e3, 1), "images_per_s": round(B / dt, 3), "loss": float(loss.detach()),
                            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
