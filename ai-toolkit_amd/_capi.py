@@ -37,14 +37,15 @@ class LoraDownArgs(C.Structure):
         ("P", vp), ("ldp", i64),
         ("T", vp), ("ldt", i64),
         ("mult", vp), ("scale", C.c_float), ("rows_per_batch", i32),
-        ("M", i32), ("K", i32), ("R", i32), ("_pad1", i32),
+        ("M", i32), ("K", i32), ("R", i32), ("split_rp", i32),
+        ("P_lo", vp),
     ]
 
 
 class LoraWgradArgs(C.Structure):
     _fields_ = [
         ("S", vp), ("lds", i64),
-        ("G", vp), ("ldg", i64), ("g_seg_rows", i32), ("_pad0", i32), ("g_seg_stride", i64),
+        ("G", vp), ("ldg", i64), ("g_seg_rows", i32), ("split_rp", i32), ("g_seg_stride", i64),
         ("partial", vp),
         ("out", vp), ("out_stride_r", i64), ("out_stride_l", i64),
         ("accumulate", i32),
@@ -179,7 +180,7 @@ class KronApplyArgs(C.Structure):
 
 
 class ShadowDesc(C.Structure):
-    _fields_ = [("src_off", i64), ("dst_off", i64), ("dstT_off", i64), ("rows", i32), ("cols", i32)]
+    _fields_ = [("src_off", i64), ("d0", i64), ("d1", i64), ("d2", i64), ("rows", i32), ("cols", i32), ("kind", i32), ("_pad", i32)]
 
 
 EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE = 1, 2, 4, 8, 16, 32, 64, 128

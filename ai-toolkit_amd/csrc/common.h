@@ -38,6 +38,9 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+// the two halves of a packed bf16x2 word back as fp32 (exact)
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 // D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[i=l&31][k=8*(l>>5)..+8] and B[k=8*(l>>5)..+8][j=l&31];
 // lane l receives D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31] in register r (guide: cdna_hip_programming.md §3).

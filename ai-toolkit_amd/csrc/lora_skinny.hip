@@ -9,6 +9,13 @@
 //        dB[n][r] = sum_m dY[m][n] * T[m][r]     (S = T,  G = dY, transposed output strides)
 //        = what autograd produces for lora_down.weight / lora_up.weight in the reference.
 //
+// Split precision (the adapter branch of the reference is fp32: toolkit/network_mixins.py:309, BaseSDTrainProcess.py:1982-1983):
+// every fp32 adapter matrix is shadowed as hi = bf16(w), lo = bf16(w - hi) (|w - hi - lo| <= 2^-17 |w|).  lora_down contracts
+// X against BOTH (P and P_lo accumulate into the same fp32 accumulator), and with split_rp > 0 writes the fp32 result as a
+// bf16 pair in the K-slab layout the GEMM consumes: per rank block of split_rp columns [T_hi | T_lo | T_hi] (3*split_rp
+// columns), to be multiplied with [B_hi | B_hi | B_lo] — T_hi*B_hi + T_lo*B_hi + T_hi*B_lo, the lo*lo term (2^-18) dropped.
+// lora_wgrad reads S from the same layout (hi and lo into one accumulator).  The extra MFMAs ride under the X / dY stream.
+//
 // Both are HBM-bound (they stream X / dY once); MFMA is used only because the contraction is matmul-shaped.
 // The contraction of wgrad runs over the ROW index of row-major tiles, so both operands are consumed through
 // ds_read_b64_tr_b16 (hardware transpose read; lane mapping verified by aitk_probe_tr16).
@@ -21,6 +28,26 @@ __device__ __forceinline__ const bf16_t* seg_row2(const bf16_t* base, long ld, i
     return base + (long)s * seg_stride + (long)(m - s * seg_rows) * ld;
   }
   return base + (long)m * ld;
+}
+
+// four consecutive ranks rr..rr+3 of row m: plain bf16, or the [hi | lo | hi] K-slab triple of the rank block (split_rp > 0)
+__device__ __forceinline__ void store_t4(const AitkLoraDownArgs& p, int m, int rr, const float v[4]) {
+  uint2 hi;
+  hi.x = pack2bf(v[0], v[1]);
+  hi.y = pack2bf(v[2], v[3]);
+  bf16_t* row = p.T + (long)m * p.ldt;
+  if (p.split_rp <= 0) {
+    *reinterpret_cast<uint2*>(row + rr) = hi;
+    return;
+  }
+  const int blk = rr / p.split_rp, j = rr - blk * p.split_rp;
+  row += (long)blk * 3 * p.split_rp + j;
+  uint2 lo;
+  lo.x = pack2bf(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x));
+  lo.y = pack2bf(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y));
+  *reinterpret_cast<uint2*>(row) = hi;
+  *reinterpret_cast<uint2*>(row + p.split_rp) = lo;
+  *reinterpret_cast<uint2*>(row + 2 * p.split_rp) = hi;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -38,6 +65,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
   const bf16_t* prow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 32 + l31, p.R - 1) * p.ldp;
+  const long lo_off = p.P_lo ? (p.P_lo - p.P) : 0;  // same row pitch, element offset between the hi and lo matrices
 
   f32x16_t acc[RB];
 #pragma unroll
@@ -63,6 +91,14 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma32(pa[u][rb], xa[u], acc[rb]);  // D rows = r, cols = m
+    if (lo_off) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = (ks + u) * 16 + 8 * h;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma32(*reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + k), xa[u], acc[rb]);
+      }
+    }
   }
   for (; ks < kend; ++ks) {
     const int k = ks * 16 + 8 * h;
@@ -71,6 +107,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
     for (int rb = 0; rb < RB; ++rb) {
       s16x8_t pa = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
       acc[rb] = mfma32(pa, xa, acc[rb]);
+      if (lo_off) acc[rb] = mfma32(*reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + k), xa, acc[rb]);
     }
   }
   // partials -> LDS [wave][rb][reg][lane]
@@ -95,12 +132,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
       v[e] = s * c;
     }
     const int rr = rb * 32 + 8 * wave + 4 * h;  // rank index of v[0]
-    if (m < p.M && rr < p.R) {
-      uint2 o;
-      o.x = pack2bf(v[0], v[1]);
-      o.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(p.T + (long)m * p.ldt + rr) = o;
-    }
+    if (m < p.M && rr < p.R) store_t4(p, m, rr, v);
   }
 }
 
@@ -124,6 +156,7 @@ __global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
   const bf16_t* prow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 16 + i16, p.R - 1) * p.ldp + 8 * g;
+  const long lo_off = p.P_lo ? (p.P_lo - p.P) : 0;
   f32x4_t acc[RB][2];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -144,6 +177,28 @@ __global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
       for (int rb = 0; rb < RB; ++rb) pa[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
     }
     __builtin_amdgcn_sched_barrier(0);  // all loads of the batch are issued before the first MFMA waits on one
+    if (lo_off) {  // the lo halves of the (L2-resident) projection: loaded behind the X loads, contracted with the same X fragments
+      s16x8_t pl[U][RB];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) pl[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + (ks + u) * 32);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);
+          acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          acc[rb][0] = mfma16(pl[u][rb], xa[u][0], acc[rb][0]);
+          acc[rb][1] = mfma16(pl[u][rb], xa[u][1], acc[rb][1]);
+        }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -160,6 +215,11 @@ __global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
       const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
       acc[rb][0] = mfma16(pf, x0, acc[rb][0]);
       acc[rb][1] = mfma16(pf, x1, acc[rb][1]);
+      if (lo_off) {
+        const s16x8_t pl = *reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + k);
+        acc[rb][0] = mfma16(pl, x0, acc[rb][0]);
+        acc[rb][1] = mfma16(pl, x1, acc[rb][1]);
+      }
     }
   }
   // partials -> LDS [wave][rb][blk][reg][lane]; wave w then finishes the (rb, blk) pairs with (rb*2+blk) % 4 == w
@@ -187,12 +247,7 @@ __global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
         v[r] = s * c;
       }
       const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
-      if (m < p.M && rr < p.R) {
-        uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p.T + (long)m * p.ldt + rr) = o;
-      }
+      if (m < p.M && rr < p.R) store_t4(p, m, rr, v);
     }
 }
 
@@ -201,6 +256,7 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if ((a->K % 16) || (a->R % 4) || a->R > 64) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ldp % 8) || (a->ldt % 4)) return AITK_ERR_ALIGN;
   if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->R % a->split_rp)))) return AITK_ERR_ARG;
   const int grid = (a->M + 31) / 32;
   if (a->K % 32 == 0) {
     if (a->R <= 16) hipLaunchKernelGGL(lora_down16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
@@ -245,9 +301,10 @@ __device__ __forceinline__ s16x8_t load_frag_tr(const bf16_t* tile, int pitch, i
 template <int RB16>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, int mc) {
   __shared__ __attribute__((aligned(16))) bf16_t gt[64 * WG_GPITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t st[64 * WG_SPITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t st[2 * 64 * WG_SPITCH];  // [hi | lo] tiles of S (lo used when split_rp > 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l0 = blockIdx.x * WG_LT;
+  const bool split = p.split_rp > 0;
   const int mbeg = blockIdx.y * mc;
   const int mend = min(p.M, mbeg + mc);
 
@@ -262,7 +319,7 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
   // Register-prefetched staging: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and written to
   // LDS after them, so a workgroup overlaps its own HBM latency with its compute (before: load -> write -> sync -> compute).
   const int chunks_per_row = p.R / 8;  // S: 64 rows x R cols = 64 * R/8 16-B chunks, <= 2 per thread
-  uint4 rg[4], rs[2];
+  uint4 rg[4], rs[2], rl[2];
   auto load_regs = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -277,7 +334,17 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
       const int q = tid + 256 * i;
       const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
       rs[i] = make_uint4(0, 0, 0, 0);
-      if (q < 64 * chunks_per_row && ms + row < mend) rs[i] = *reinterpret_cast<const uint4*>(p.S + (long)(ms + row) * p.lds + ch * 8);
+      rl[i] = make_uint4(0, 0, 0, 0);
+      if (q < 64 * chunks_per_row && ms + row < mend) {
+        if (!split) {
+          rs[i] = *reinterpret_cast<const uint4*>(p.S + (long)(ms + row) * p.lds + ch * 8);
+        } else {  // rank r of the [hi | lo | hi] slab layout: column (r / rp) * 3 rp + r % rp, lo one rp further (rp % 8 == 0)
+          const int r = ch * 8, blk = r / p.split_rp;
+          const bf16_t* src = p.S + (long)(ms + row) * p.lds + (long)blk * 3 * p.split_rp + (r - blk * p.split_rp);
+          rs[i] = *reinterpret_cast<const uint4*>(src);
+          rl[i] = *reinterpret_cast<const uint4*>(src + p.split_rp);
+        }
+      }
     }
   };
   auto write_lds = [&]() {
@@ -290,7 +357,10 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
     for (int i = 0; i < 2; ++i) {
       const int q = tid + 256 * i;
       const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
-      if (q < 64 * chunks_per_row) *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = rs[i];
+      if (q < 64 * chunks_per_row) {
+        *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = rs[i];
+        if (split) *reinterpret_cast<uint4*>(st + 64 * WG_SPITCH + row * WG_SPITCH + ch * 8) = rl[i];
+      }
     }
   };
   load_regs(mbeg);
@@ -308,6 +378,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
         s16x8_t af = load_frag_tr(st, WG_SPITCH, kk * 32, rb * 16, lane);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma16(af, bfr[cb], acc[rb][cb]);  // D[i=r][j=l]
+        if (split) {
+          s16x8_t al = load_frag_tr(st + 64 * WG_SPITCH, WG_SPITCH, kk * 32, rb * 16, lane);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma16(al, bfr[cb], acc[rb][cb]);
+        }
       }
     }
     __syncthreads();
@@ -357,6 +432,7 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
   if (!a->partial || !a->out) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->R % a->split_rp)))) return AITK_ERR_ARG;
   int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
   if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;  // millions of rows (LoKr): at most 512 row chunks
   const int nchunks = (a->M + mc - 1) / mc;

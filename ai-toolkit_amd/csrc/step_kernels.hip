@@ -300,17 +300,38 @@ extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 shadows
-// For every LoRA matrix in the fp32 arena (row-major [rows, cols]) write bf16 copies in both orientations; the
-// forward K-slab / lora_down read the direct one, the backward dT / dgrad K-slab read the transposed one.
+// For every adapter matrix in the fp32 arena (row-major [rows, cols]) write its bf16 shadows in the layouts the skinny kernels
+// and the GEMM K-slab read (AitkShadowDesc in the header): hi = bf16(w), lo = bf16(w - hi) — the split representation that keeps
+// the adapter branch at fp32-class precision (|w - hi - lo| <= 2^-17 |w|) on bf16 MFMA.
 __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena, bf16_t* shadow, const AitkShadowDesc* table) {
   const AitkShadowDesc d = table[blockIdx.y];
   const long n = (long)d.rows * d.cols;
   const float* src = arena + d.src_off;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const bf16_t v = f2bf(src[i]);
-    shadow[d.dst_off + i] = v;
+    const float w = src[i];
+    const bf16_t hi = f2bf(w);
     const long r = i / d.cols, c = i - r * d.cols;
-    shadow[d.dstT_off + c * d.rows + r] = v;
+    if (d.kind == 0) {
+      shadow[d.d0 + i] = hi;
+      shadow[d.d1 + c * d.rows + r] = hi;
+      continue;
+    }
+    const bf16_t lo = f2bf(w - bf2f(hi));
+    if (d.kind == 1) {  // A [rank, in]
+      shadow[d.d0 + i] = hi;
+      shadow[d.d1 + i] = lo;
+      bf16_t* t3 = shadow + d.d2 + c * 3 * d.rows + r;
+      t3[0] = hi;
+      t3[d.rows] = hi;
+      t3[2 * d.rows] = lo;
+    } else {  // B [out, rank]
+      bf16_t* d3 = shadow + d.d0 + r * 3 * d.cols + c;
+      d3[0] = hi;
+      d3[d.cols] = hi;
+      d3[2 * d.cols] = lo;
+      shadow[d.d1 + c * d.rows + r] = hi;
+      shadow[d.d2 + c * d.rows + r] = lo;
+    }
   }
 }
 extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,

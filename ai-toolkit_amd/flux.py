@@ -147,8 +147,17 @@ class FluxTransformer2DModel(FusedGraphBase):
         return network.arena_p.numel()
 
     def rope_tables(self, img_ids, txt_ids):
-        """FluxPosEmbed in float64 on the host, cached per (shape) bucket; fp32 [S, 128] cos/sin on device."""
-        key = (tuple(img_ids.shape), tuple(txt_ids.shape), float(img_ids.sum()), float(img_ids[-1].sum()))
+        """FluxPosEmbed in float64 on the host, cached per bucket; fp32 [S, 128] cos/sin on device.  The cache key is the
+        position grid itself: `_aitk_grid` = (h2, w2, n_txt) stamped on img_ids by make_ids / the plug-in (no device sync), or —
+        for ids built elsewhere — the bytes of the ids (one device-to-host copy).  Transposed buckets (96x168 vs 168x96 latents)
+        therefore never share a table."""
+        grid = getattr(img_ids, "_aitk_grid", None)
+        if grid is not None and (grid[0] * grid[1], grid[2]) == (img_ids.shape[0], txt_ids.shape[0]):
+            key = ("grid",) + tuple(int(g) for g in grid)
+        else:
+            key = ("ids", tuple(img_ids.shape), tuple(txt_ids.shape),
+                   img_ids.detach().to("cpu", torch.float32).contiguous().numpy().tobytes(),
+                   txt_ids.detach().to("cpu", torch.float32).contiguous().numpy().tobytes())
         hit = self._rope_cache.get(key)
         if hit is not None:
             return hit
@@ -482,5 +491,11 @@ class _FluxGraphFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx_, dpred):
+        net = ctx_.model.network
+        mods = net.get_all_modules()
+        if mods and mods[0].lora_down.weight.grad is None:
+            # the trainer's optimizer.zero_grad(set_to_none=True) (SDTrainer.py:2249, 2288) dropped the .grad views: "none" means
+            # zero, so the arena they alias is cleared and the views are re-attached before this backward accumulates into it
+            net.zero_grad_arena()
         ctx_.model.backward_native(dpred)
         return None, None, None

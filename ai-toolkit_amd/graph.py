@@ -154,13 +154,14 @@ class FusedGraphBase(nn.Module):
         grp = getattr(lins[0].lora, "group", None)
         if grp is None or [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             return {}
-        Tcat = self._new(M, grp["R"])
+        Tcat = self._new(M, 3 * grp["R"])  # per adapter [T_hi | T_lo | T_hi] (split precision, see aitk_lora_down)
         mult, rpb = self._mult(rows_per_batch, B)
-        self.ops.lora_down(x, grp["sh_down"], Tcat, scale=grp["scale"], mult=mult, rows_per_batch=rpb, M=M)
+        self.ops.lora_down(x, grp["sh_down"], Tcat, scale=grp["scale"], mult=mult, rows_per_batch=rpb, M=M,
+                           p_lo=grp["sh_down_lo"], split=grp["rp"])
         out = {}
         for l in lins:
-            c0 = grp["col"][id(l.lora)]
-            out[id(l)] = Tcat[:, c0:c0 + l.lora.rank_pad]
+            c0 = 3 * grp["col"][id(l.lora)]
+            out[id(l)] = Tcat[:, c0:c0 + 3 * l.lora.rank_pad]
         return out
 
     def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
@@ -181,10 +182,11 @@ class FusedGraphBase(nn.Module):
         if self._lora_active(lin):
             lo = lin.lora
             if T is None:
-                T = self._new(M, lo.rank_pad)
+                T = self._new(M, 3 * lo.rank_pad)
                 mult, rpb = self._mult(rows_per_batch, B)
-                ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M)
-            kw = dict(a2=T, b2=lo.sh_up)
+                ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M,
+                              p_lo=lo.sh_down_lo, split=lo.rank_pad)
+            kw = dict(a2=T, b2=lo.sh_up3)  # [T_hi | T_lo | T_hi] . [B_hi | B_hi | B_lo]^T: the fp32 adapter product to 2^-17
             if lo.magnitude is not None:  # DoRA: y = c * (x W^T + T B^T) + b; the linear output is kept for d magnitude
                 kw["col_scale"] = lo.c
                 if (flags & EPI_GATE_RES) and aux_out is None:
@@ -255,7 +257,7 @@ class FusedGraphBase(nn.Module):
             raise NotImplementedError(f"LoKr factor gradient {R}x{L}: needs a factor dimension that is a multiple of 16")
 
     def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
-        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) (bf16 [M, r]) or None.
+        """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) ([M, 3r] split slab layout) or None.
         With dT_out (a column slice of a group's dT buffer) the lora_down gradient is left to _group_wgrad."""
         if T is None:
             return None
@@ -265,12 +267,13 @@ class FusedGraphBase(nn.Module):
         ops = self.ops
         lo = lin.lora
         assert lo.magnitude is None or getattr(dy, "_dora_dz", False), "DoRA: pass dy through _dora_dz() first"
-        dT = dT_out if dT_out is not None else self._new(M, lo.rank_pad)
+        rp = lo.rank_pad
+        dT = dT_out if dT_out is not None else self._new(M, 3 * rp)
         mult, rpb = self._mult(rows_per_batch, B)
-        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M)
-        ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M)
+        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp)
+        ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
         if dT_out is None:
-            ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M)
+            ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
         return dT
 
     def _dora_dz(self, lin, dy, M):
@@ -291,17 +294,17 @@ class FusedGraphBase(nn.Module):
         grp = getattr(lins[0].lora, "group", None) if all(t is not None for t in Ts) else None
         if grp is not None and [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             grp = None
-        dTcat = self._new(M, grp["R"]) if grp is not None else None
+        dTcat = self._new(M, 3 * grp["R"]) if grp is not None else None
         for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
             dy = self._dora_dz(lin, dy, M)
             dT_out = None
             if grp is not None:
-                c0 = grp["col"][id(lin.lora)]
-                dT_out = dTcat[:, c0:c0 + lin.lora.rank_pad]
+                c0 = 3 * grp["col"][id(lin.lora)]
+                dT_out = dTcat[:, c0:c0 + 3 * lin.lora.rank_pad]
             dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dT_out)
             self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
         if grp is not None:
-            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M)
+            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
 
     def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
         """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""
@@ -314,7 +317,7 @@ class FusedGraphBase(nn.Module):
             flags |= EPI_ACCUM
             dT = None
         if dT is not None:
-            shT = lin.lora.sh_downT
+            shT = lin.lora.sh_downT3  # [in, 3r] = [A^T_hi | A^T_hi | A^T_lo] against dT = [hi | lo | hi]
             kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
         if lin.qweight is not None:  # rows of W^T = input columns; scale runs along the contraction (out) axis
             qt = lin.qweight_t if w_rows is None else lin.qweight_t[w_rows[0]:w_rows[1]]
@@ -340,10 +343,11 @@ class FusedGraphBase(nn.Module):
             return mod, _KRON
         if self._lora_active(ada_lin):
             lo = ada_lin.lora
-            T = self._new(B, lo.rank_pad)
+            T = self._new(B, 3 * lo.rank_pad)
             mult, rpb = self._mult(1, B)
-            ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
-            kw = dict(t=T, bl=lo.sh_up)
+            ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_down_lo,
+                          split=lo.rank_pad)
+            kw = dict(t=T, bl=lo.sh_up3)
             if lo.magnitude is not None:
                 kw["col_scale"] = lo.c
                 lo.y_lin = mod
@@ -360,8 +364,9 @@ class FusedGraphBase(nn.Module):
         ops = self.ops
         lo = ada_lin.lora
         dmod = self._dora_dz(ada_lin, dmod, B)
-        dT = self._new(B, lo.rank_pad)
+        rp = lo.rank_pad
+        dT = self._new(B, 3 * rp)
         mult, rpb = self._mult(1, B)
-        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B)
-        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B)
-        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B)
+        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_upT_lo, split=rp)
+        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B, split=rp)
+        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B, split=rp)

@@ -66,7 +66,7 @@ class LoRAModule(nn.Module):
             raise NotImplementedError("dropout variants are not on the fused path (reference default: None)")
         # arena bookkeeping (filled by FusedLoRANetwork._build_arena)
         self.off_down = self.off_up = -1
-        self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
+        self.sh_down = self.sh_down_lo = self.sh_downT3 = self.sh_up3 = self.sh_upT = self.sh_upT_lo = None  # build_arena
         self.g_down = self.g_up = None
 
     def _set_runtime_scale(self, value):
@@ -121,7 +121,7 @@ class DoRAModule(LoRAModule):
         self.org_module = [org_module]
         self.dropout = self.rank_dropout = self.module_dropout = None
         self.off_down = self.off_up = self.off_mag = -1
-        self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
+        self.sh_down = self.sh_down_lo = self.sh_downT3 = self.sh_up3 = self.sh_upT = self.sh_upT_lo = None
         self.g_down = self.g_up = self.g_mag = None
         self.c = None       # fp32 [out]: magnitude / ||W + s*up@down||, refreshed after every optimizer step
         self.w2 = None      # fp32 [out]: ||W_j||^2 of the frozen base weight
@@ -248,8 +248,11 @@ class FusedLoRANetwork(nn.Module):
 
     def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
                  transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
-                 is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1):
+                 is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1,
+                 base_model=None):
         super().__init__()
+        # the reference holds a weak reference to the model plug-in for the save / load key-conversion hooks (lora_special.py:373-375)
+        self.base_model_ref = weakref.ref(base_model) if base_model is not None else None
         assert peft_format and is_transformer, "kohya-format UNet naming is a later row (SURVEY.md §8f.3)"
         assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
         # toolkit/lora_special.py:403-408
@@ -309,7 +312,7 @@ class FusedLoRANetwork(nn.Module):
         for lora in self.get_all_modules():
             lora.apply_to()
 
-    def build_arena(self, device, ema: bool = False, groups=None):
+    def build_arena(self, device, ema: bool = False, groups=None, shadow_dtype=None):
         """Move every adapter matrix into flat fp32 arenas on `device` (reference: network.force_to(device, fp32),
         jobs/process/BaseSDTrainProcess.py:1982-1983) and create grad / Adam / EMA / bf16-shadow arenas.
 
@@ -340,11 +343,9 @@ class FusedLoRANetwork(nn.Module):
         self.arena_m = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_v = torch.zeros(n, dtype=torch.float32, device=device)
         self.arena_ema = None
-        dt = torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32
+        dt = shadow_dtype or (torch.bfloat16 if torch.device(device).type == "cuda" else torch.float32)
         self.shadow_dtype = dt
-        # shadow arena: [0, n) direct copies at the fp32 arena's offsets, [n, 2n) transposed copies
         self.n_mat = n_mat
-        self.arena_shadow = torch.empty(2 * n_mat, dtype=dt, device=device)
         group_of = {}
         for gi, grp in enumerate(groups or []):
             for m in grp:
@@ -358,6 +359,40 @@ class FusedLoRANetwork(nn.Module):
             elif gi not in done_groups:
                 done_groups.add(gi)
                 order += [(x, "down") for x in groups[gi]] + [(x, "up") for x in groups[gi]]
+        # bf16 shadow arena in the layouts the kernels read (AitkShadowDesc, include/aitk_mi355.h).  The reference keeps the
+        # adapter in fp32 (network_mixins.py:309, BaseSDTrainProcess.py:1982-1983); bf16 MFMA reaches that precision through the
+        # split hi = bf16(w), lo = bf16(w - hi):
+        #   lora_down A [rp, in]:  hi / lo [rp, in]   (P, P_lo of the forward lora_down; a same-input group's matrices adjacent)
+        #                          [in, 3rp] = [A^T_hi | A^T_hi | A^T_lo]   (B2 of the data-gradient K-slab)
+        #   lora_up   B [out, rp]: [out, 3rp] = [B_hi | B_hi | B_lo]          (B2 of the forward K-slab)
+        #                          hi / lo transposed [rp, out]               (P, P_lo of the backward lora_down)
+        #   LoKr factors: plain bf16, direct + transposed (the Kronecker kernel's operands).
+        sizes = {"hi": 0, "lo": 0, "t3": 0, "u3": 0, "uth": 0, "utl": 0}
+        for m, which in order:
+            rows, cols = block_shape(m, which)
+            cnt = rows * cols
+            if m.is_lokr:
+                sizes["hi"] += cnt
+                sizes["t3"] += cnt
+            elif which == "down":
+                sizes["hi"] += cnt
+                sizes["lo"] += cnt
+                sizes["t3"] += 3 * cnt
+            else:
+                sizes["u3"] += 3 * cnt
+                sizes["uth"] += cnt
+                sizes["utl"] += cnt
+        cur, tot = {}, 0
+        for k in ("hi", "lo", "t3", "u3", "uth", "utl"):
+            cur[k] = tot
+            tot += (sizes[k] + 63) // 64 * 64  # regions start 128-byte aligned
+        self.arena_shadow = torch.zeros(max(tot, 1), dtype=dt, device=device)
+
+        def take(region, cnt, shape):
+            o = cur[region]
+            cur[region] += cnt
+            return o, self.arena_shadow[o:o + cnt].view(*shape)
+
         entries = []
         off = 0
         for m, which in order:
@@ -371,13 +406,28 @@ class FusedLoRANetwork(nn.Module):
             lin.weight = nn.Parameter(view, requires_grad=True)
             gblock = self.arena_g[off:off + cnt].view(rows, cols)
             lin.weight.grad = gblock[: w.shape[0], : w.shape[1]]
-            sh = self.arena_shadow[off:off + cnt].view(rows, cols)
-            shT = self.arena_shadow[n_mat + off:n_mat + off + cnt].view(cols, rows)
-            entries.append((off, off, n_mat + off, rows, cols))
-            if which == "down":
-                m.off_down, m.g_down, m.sh_down, m.sh_downT, m.blk_down = off, gblock, sh, shT, (rows, cols)
+            if m.is_lokr:
+                d0, sh = take("hi", cnt, (rows, cols))
+                d1, shT = take("t3", cnt, (cols, rows))
+                entries.append((off, rows, cols, 0, d0, d1, 0))
+                if which == "down":
+                    m.off_down, m.g_down, m.sh_down, m.sh_downT, m.blk_down = off, gblock, sh, shT, (rows, cols)
+                else:
+                    m.off_up, m.g_up, m.sh_up, m.sh_upT, m.blk_up = off, gblock, sh, shT, (rows, cols)
+            elif which == "down":
+                d0, hi = take("hi", cnt, (rows, cols))
+                d1, lo = take("lo", cnt, (rows, cols))
+                d2, t3 = take("t3", 3 * cnt, (cols, 3 * rows))
+                entries.append((off, rows, cols, 1, d0, d1, d2))
+                m.off_down, m.g_down, m.blk_down = off, gblock, (rows, cols)
+                m.sh_down, m.sh_down_lo, m.sh_downT3, m._sh_down_off = hi, lo, t3, (d0, d1)
             else:
-                m.off_up, m.g_up, m.sh_up, m.sh_upT, m.blk_up = off, gblock, sh, shT, (rows, cols)
+                d0, u3 = take("u3", 3 * cnt, (rows, 3 * cols))
+                d1, th = take("uth", cnt, (cols, rows))
+                d2, tl = take("utl", cnt, (cols, rows))
+                entries.append((off, rows, cols, 2, d0, d1, d2))
+                m.off_up, m.g_up, m.blk_up = off, gblock, (rows, cols)
+                m.sh_up3, m.sh_upT, m.sh_upT_lo = u3, th, tl
             off += cnt
         assert off == n_mat
         for m in mods:
@@ -407,7 +457,11 @@ class FusedLoRANetwork(nn.Module):
             assert all(x.in_features == cin and x.scale == first.scale for x in grp)
             o0 = first.off_down
             assert [x.off_down for x in grp] == [o0 + sum(y.rank_pad for y in grp[:i]) * cin for i in range(len(grp))]
-            g = {"mods": grp, "R": rtot, "sh_down": self.arena_shadow[o0:o0 + rtot * cin].view(rtot, cin),
+            assert all(x.rank_pad == first.rank_pad for x in grp), "a same-input group shares one rank"
+            h0, l0 = first._sh_down_off
+            assert [x._sh_down_off[0] for x in grp] == [h0 + i * first.rank_pad * cin for i in range(len(grp))]
+            g = {"mods": grp, "R": rtot, "rp": first.rank_pad, "sh_down": self.arena_shadow[h0:h0 + rtot * cin].view(rtot, cin),
+                 "sh_down_lo": self.arena_shadow[l0:l0 + rtot * cin].view(rtot, cin),
                  "g_down": self.arena_g[o0:o0 + rtot * cin].view(rtot, cin), "scale": first.scale,
                  "col": {id(x): sum(y.rank_pad for y in grp[:i]) for i, x in enumerate(grp)}}
             for x in grp:
@@ -432,7 +486,8 @@ class FusedLoRANetwork(nn.Module):
         return block[: w.shape[0], : w.shape[1]]
 
     def refresh_shadows(self, ops):
-        """bf16 copies (both orientations) of every adapter matrix; call after each optimizer step / weight load."""
+        """bf16 shadows (split hi + lo, every layout the kernels read) of every adapter matrix; call after each optimizer step /
+        weight load."""
         self._ops = ops
         if self._shadow_table is None:
             self._shadow_table = ops.make_shadow_table(self._shadow_entries, self.arena_p.device)
@@ -457,18 +512,34 @@ class FusedLoRANetwork(nn.Module):
                 raise NotImplementedError("DoRA over a weight-only fp8 base is not on the fused path")
             dev, r = self.arena_p.device, m.rank_pad
             tw = torch.empty(lin.out_features, r, dtype=self.shadow_dtype, device=dev)
-            ops.lora_down(lin.weight.data, m.sh_down, tw, scale=1.0, M=lin.out_features)
+            ops.lora_down(lin.weight.data, m.sh_down, tw, scale=1.0, M=lin.out_features, p_lo=m.sh_down_lo)
             gram = torch.zeros(r, r, dtype=torch.float32, device=dev)
-            ops.lora_wgrad(m.sh_downT, m.sh_downT, gram, M=m.in_features)
+            at = m.sh_downT3[:, :r]  # A^T_hi [in, r] (row stride 3r)
+            ops.lora_wgrad(at, at, gram, M=m.in_features)
             ops.dora_colscale(m.w2, tw, self.arena_view(self.arena_p, m, "up", padded=True), gram, m.magnitude.data, m.scale * vals[0], m.c)
+
+    def attach_grad_views(self):
+        """Every Parameter's .grad is a view of the flat gradient arena; optimizer.zero_grad(set_to_none=True) — what the reference's
+        trainer calls after each step (SDTrainer.py:2288) — drops them, so they are re-attached before gradients are written."""
+        for m in self.get_all_modules():
+            if m.lora_down.weight.grad is None:
+                m.lora_down.weight.grad = self.arena_view(self.arena_g, m, "down")
+            if m.lora_up.weight.grad is None:
+                m.lora_up.weight.grad = self.arena_view(self.arena_g, m, "up")
+            if m.magnitude is not None and m.magnitude.grad is None:
+                m.magnitude.grad = m.g_mag
 
     def zero_grad_arena(self):
         self.arena_g.zero_()
-        for m in self.get_all_modules():  # optimizer.zero_grad(set_to_none=True) may have dropped the views
-            m.lora_down.weight.grad = self.arena_view(self.arena_g, m, "down")
-            m.lora_up.weight.grad = self.arena_view(self.arena_g, m, "up")
-            if m.magnitude is not None:
-                m.magnitude.grad = m.g_mag
+        self._arena_dirty = False
+        self.attach_grad_views()
+
+    def zero_grad(self, set_to_none: bool = True):
+        """nn.Module.zero_grad of the adapter: the arena is zeroed in one memset; the .grad views stay attached."""
+        if getattr(self, "_arena_built", False):
+            self.zero_grad_arena()
+        else:
+            super().zero_grad(set_to_none)
 
     # ------------------------------------------------------------------ multiplier / activation (network_mixins.py:791-853)
     @property
@@ -524,6 +595,10 @@ class FusedLoRANetwork(nn.Module):
         return [group]
 
     # ------------------------------------------------------------------ state-dict I/O (network_mixins.py:581-789)
+    def _base_model(self):
+        ref = getattr(self, "base_model_ref", None)
+        return ref() if ref is not None else None
+
     def get_state_dict(self, extra_state_dict=None, dtype=torch.float16, use_ema=False):
         src = self.arena_ema if (use_ema and self.arena_ema is not None) else None
         sd = OrderedDict()
@@ -549,6 +624,9 @@ class FusedLoRANetwork(nn.Module):
         if extra_state_dict is not None:
             for k, v in extra_state_dict.items():
                 sd[k] = v.detach().clone().to("cpu").to(dtype)
+        base_model = self._base_model()
+        if base_model is not None:  # model-specific key names, e.g. Wan: diffusion_model.blocks.N.self_attn.q... (network_mixins.py:637-638)
+            sd = base_model.convert_lora_weights_before_save(sd)
         return sd
 
     def save_weights(self, file, dtype=torch.float16, metadata=None, extra_state_dict=None, use_ema=False):
@@ -559,18 +637,33 @@ class FusedLoRANetwork(nn.Module):
         for k, v in (metadata or {}).items():  # every value JSON-stringified (toolkit/metadata.py:13-29)
             meta[k] = v if isinstance(v, str) else json.dumps(v)
         meta = add_model_hash_to_meta(sd, meta)  # toolkit/network_mixins.py:655-663
+        base_model = self._base_model()
+        if base_model is not None and hasattr(base_model, "save_lora"):  # network_mixins.py:657-660
+            base_model.save_lora(sd, file, meta)
+            return
         meta.setdefault("format", "pt")
         os.makedirs(os.path.dirname(os.path.abspath(file)), exist_ok=True)
         save_file(sd, file, meta)
 
     def load_weights(self, file):
-        """Accepts the PEFT keys this class writes; rank grow/shrink by zero-pad / truncate (network_mixins.py:737-775)."""
+        """Accepts the PEFT keys this class writes (after the base model's convert_lora_weights_before_load hook, like the
+        reference: network_mixins.py:674-688); rank grow/shrink by zero-pad / truncate (737-775).  Returns the keys that matched
+        no adapter (the reference's `extra_dict`), or None; a file that matches NO adapter at all raises, because training would
+        otherwise silently continue from the fresh initialisation."""
         from safetensors.torch import load_file
 
-        sd = file if isinstance(file, dict) else load_file(file)
+        base_model = self._base_model()
+        if isinstance(file, dict):
+            sd = file
+        elif base_model is not None and hasattr(base_model, "load_lora"):
+            sd = base_model.load_lora(file)
+        else:
+            sd = load_file(file)
+        if base_model is not None:
+            sd = base_model.convert_lora_weights_before_load(sd)
         extra = OrderedDict()
         by_name = {m.lora_name.replace("$$", "."): m for m in self.get_all_modules()}
-        used = set()
+        n_hit = 0
         with torch.no_grad():
             for k, v in sd.items():
                 hit = False
@@ -587,15 +680,23 @@ class FusedLoRANetwork(nn.Module):
                             new[:r0, :r1] = v[:r0, :r1]
                             v = new
                         w.copy_(v)
-                        used.add(k)
                         hit = True
-                if k.endswith(".magnitude") and k[: -len(".magnitude")] in by_name and by_name[k[: -len(".magnitude")]].magnitude is not None:
-                    by_name[k[: -len(".magnitude")]].magnitude.copy_(v.to(self.arena_p.device, torch.float32))
+                        n_hit += 1
+                mk = k[: -len(".magnitude")] if k.endswith(".magnitude") else None
+                if mk is not None and mk in by_name and by_name[mk].magnitude is not None:
+                    mag = by_name[mk].magnitude
+                    mag.copy_(v.to(mag.device, torch.float32))
                     hit = True
+                    n_hit += 1
                 if k.endswith(".alpha") and k[: -len(".alpha")] in by_name:
                     hit = True  # constant buffer (LoKr files carry it)
                 if not hit:
                     extra[k] = v
+        if n_hit == 0 and len(sd) > 0:
+            raise ValueError(f"load_weights: none of the {len(sd)} keys matches an adapter of this network "
+                             f"(first key: {next(iter(sd))!r}); wrong key format or missing base_model conversion hook")
+        if getattr(self, "_arena_built", False) and getattr(self, "_ops", None) is not None:
+            self.refresh_shadows(self._ops)  # the kernels read the shadows (and DoRA's column scale), not the fp32 arena
         return extra if len(extra) else None
 
     def set_multiplier(self, multiplier):
@@ -605,10 +706,11 @@ class FusedLoRANetwork(nn.Module):
     @torch.no_grad()
     def merge_in(self, merge_weight=1.0, ops=None):
         """W <- W + merge_weight * scale * (lora_up @ lora_down) for every wrapped Linear (and its transposed copy),
-        as a rank-r GEMM with the accumulate epilogue: C += (c*B) A  — the MFMA form of ToolkitModuleMixin.merge_in."""
-        ops = ops or self._ops
+        as a rank-r GEMM with the accumulate epilogue: C += (c*B) A  — the MFMA form of ToolkitModuleMixin.merge_in.  The product
+        uses the split shadows (B_hi A_hi + B_hi A_lo + B_lo A_hi), i.e. the fp32 product of the reference to 2^-17."""
         if self.network_type.lower() == "dora":
             return  # toolkit/network_mixins.py:894-897
+        ops = ops or self._ops
         if self.network_type.lower() == "lokr":  # toolkit/models/lokr.py:261-309: W += kron(w1, w2) * scale * merge_weight
             for m in self.get_all_modules():
                 lin = m.org_module[0]
@@ -625,69 +727,83 @@ class FusedLoRANetwork(nn.Module):
             lin = m.org_module[0]
             if not m.can_merge_in:
                 continue
-            bs = torch.empty_like(m.sh_up)
-            ops.ew(3, m.sh_up, bs, alpha=float(merge_weight) * m.scale)
+            if not bool(m.lora_up.weight.any()) or not bool(m.lora_down.weight.any()):
+                continue  # a zero delta merges to identity: skipped (matters on quantised bases; network_mixins.py:381-389)
+            rp = m.rank_pad
+            bs = torch.empty_like(m.sh_up3)  # (c B) as [B_hi | B_hi | B_lo]
+            ops.ew(3, m.sh_up3, bs, alpha=float(merge_weight) * m.scale)
+            t3 = m.sh_downT3
+            at = torch.cat((t3[:, :rp], t3[:, 2 * rp:], t3[:, rp:2 * rp]), dim=1).contiguous()  # [A^T_hi | A^T_lo | A^T_hi]
             if getattr(lin, "qweight", None) is not None:
                 # weight-only fp8 base: dequantise, add the delta, re-quantise (toolkit/network_mixins.py:452-459) — the model
                 # stays quantised across merge / reset cycles; the scale per output channel is recomputed from the merged row
                 from .graph import quantize_linear_fp8
 
-                w = (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(m.sh_up.dtype)
-                ops.gemm_nt(bs, m.sh_downT, w, flags=2)
+                w = (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(bs.dtype)
+                ops.gemm_nt(bs, at, w, flags=2)
                 quantize_linear_fp8(lin, w)
                 continue
-            ops.gemm_nt(bs, m.sh_downT, lin.weight.data, flags=2)          # [out,in] += (cB)[out,r] . A^T[in,r]^T
+            ops.gemm_nt(bs, at, lin.weight.data, flags=2)          # [out,in] += (cB)[out,3r] . A^T[in,3r]^T
             if getattr(lin, "weight_t", None) is not None:
-                ops.gemm_nt(m.sh_downT, bs, lin.weight_t, flags=2)         # [in,out] += A^T[in,r] . (cB)[out,r]^T
+                ops.gemm_nt(at, bs, lin.weight_t, flags=2)         # [in,out] += A^T[in,3r] . (cB)[out,3r]^T
         self.is_merged_in = merge_weight > 0
 
     @torch.no_grad()
     def merge_out(self, merge_weight=1.0, ops=None):
+        if not self.is_merged_in:
+            return  # toolkit/network_mixins.py:900-902: nothing was merged, nothing to subtract
         self.merge_in(-abs(merge_weight), ops=ops)
         self.is_merged_in = False
 
     def reset_weights(self):
-        """kaiming-uniform lora_down, zero lora_up (network_mixins.py reset_weights), e.g. after a merge-and-reset cycle."""
+        """The reference zeroes every `lora_up` and leaves lora_down as trained (toolkit/network_mixins.py:464-471, 890-892), e.g.
+        after a merge-and-reset cycle; LoKr modules have no lora_up key and are left untouched by that loop."""
         with torch.no_grad():
             for m in self.get_all_modules():
                 if getattr(m, "is_lokr", False):
-                    nn.init.constant_(m.lokr_w2, 0)
-                    nn.init.kaiming_uniform_(m.lokr_w1, a=math.sqrt(5))
                     continue
-                nn.init.kaiming_uniform_(m.lora_down.weight, a=math.sqrt(5))
                 nn.init.zeros_(m.lora_up.weight)
+        if getattr(self, "_arena_built", False) and getattr(self, "_ops", None) is not None:
+            self.refresh_shadows(self._ops)
 
     # ------------------------------------------------------------------ optimizer state checkpoint (BaseSDTrainProcess.py:701-714)
-    @staticmethod
-    def _opt_order(m):
-        """(holder, arena offset) in the reference module's named_parameters() order."""
-        if getattr(m, "is_lokr", False):
-            return ((m.lora_up, "up"), (m.lora_down, "down"))  # lokr_w1, lokr_w2
-        return ((m.lora_down, "down"), (m.lora_up, "up"))
+    def _opt_slices(self, arena):
+        """Views of a flat arena (arena_m / arena_v / ...) for every trainable tensor, in prepare_optimizer_params() order —
+        i.e. the reference modules' named_parameters() order: LoRA (lora_down, lora_up); DoRA (magnitude, lora_up, lora_down);
+        LoKr (lokr_w1, lokr_w2)."""
+        out = []
+        for m in self.unet_loras:
+            if m.magnitude is not None:
+                out.append(arena[m.off_mag:m.off_mag + m.magnitude.numel()])
+                out += [self.arena_view(arena, m, "up"), self.arena_view(arena, m, "down")]
+            elif getattr(m, "is_lokr", False):
+                out += [self.arena_view(arena, m, "up"), self.arena_view(arena, m, "down")]  # lokr_w1, lokr_w2
+            else:
+                out += [self.arena_view(arena, m, "down"), self.arena_view(arena, m, "up")]
+        return out
 
     def optimizer_state_dict(self, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01):
         """The fused AdamW state exported in torch.optim.AdamW.state_dict() layout (params in prepare_optimizer_params
         order), so `optimizer.pt` written here can be loaded by the reference's torch optimizer and vice versa."""
-        state, ids = {}, []
-        i = 0
-        for m in self.unet_loras:
-            for lin, which in self._opt_order(m):
-                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.arena_view(self.arena_m, m, which).clone().contiguous().cpu(),
-                            "exp_avg_sq": self.arena_view(self.arena_v, m, which).clone().contiguous().cpu()}
-                ids.append(i)
-                i += 1
+        state = {}
+        for i, (mv, vv) in enumerate(zip(self._opt_slices(self.arena_m), self._opt_slices(self.arena_v))):
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": mv.clone().contiguous().cpu(),
+                        "exp_avg_sq": vv.clone().contiguous().cpu()}
         group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
-                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": ids}
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, sd):
         """Inverse of optimizer_state_dict; returns the step count."""
-        i, step = 0, 0
-        for m in self.unet_loras:
-            for lin, which in self._opt_order(m):
-                st = sd["state"][i]
-                self.arena_view(self.arena_m, m, which).copy_(st["exp_avg"])
-                self.arena_view(self.arena_v, m, which).copy_(st["exp_avg_sq"])
-                step = int(float(st["step"]))
-                i += 1
+        step = 0
+        ms, vs = self._opt_slices(self.arena_m), self._opt_slices(self.arena_v)
+        if len(sd["state"]) != len(ms):
+            raise ValueError(f"optimizer state has {len(sd['state'])} tensors, the network has {len(ms)} trainable tensors")
+        for i, (mv, vv) in enumerate(zip(ms, vs)):
+            st = sd["state"][i]
+            if tuple(st["exp_avg"].shape) != tuple(mv.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} does not match parameter {tuple(mv.shape)}")
+            mv.copy_(st["exp_avg"])
+            vv.copy_(st["exp_avg_sq"])
+            step = int(float(st["step"]))
         return step

@@ -102,15 +102,20 @@ def rows_per_block():
     return _capi.lib().aitk_rows_per_block()
 
 
-def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None):
-    """out[M,R] = bf16(scale * mult[m // rows_per_batch] * (x[M,K] @ pmat[R,K]^T))."""
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0):
+    """out = scale * mult[m // rows_per_batch] * (x[M,K] @ (pmat + p_lo)[R,K]^T): [M,R] bf16, or — split = rank-block width —
+    the [M,3R] K-slab layout [hi | lo | hi] per rank block (AitkLoraDownArgs in the header)."""
     a = _capi.LoraDownArgs()
     a.ldx = _row_major(x, "x")
     a.ldp = _row_major(pmat, "pmat")
     a.ldt = _row_major(out, "out")
     R, K = pmat.shape
-    assert x.shape[1] == K and out.shape[1] == R
+    assert x.shape[1] == K and out.shape[1] == (3 * R if split else R)
     a.X, a.P, a.T = _ptr(x), _ptr(pmat), _ptr(out)
+    if p_lo is not None:
+        assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == a.ldp
+        a.P_lo = _ptr(p_lo)
+    a.split_rp = int(split)
     if x_seg is not None:
         a.x_seg_rows, a.x_seg_stride = x_seg
     if mult is not None:
@@ -122,12 +127,14 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     return out
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None):
-    """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad)."""
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0):
+    """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad).
+    split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo."""
     a = _capi.LoraWgradArgs()
     a.lds = _row_major(s, "s")
     a.ldg = _row_major(g, "g")
-    R, L = s.shape[1], g.shape[1]
+    R, L = (s.shape[1] // 3 if split else s.shape[1]), g.shape[1]
+    a.split_rp = int(split)
     M = s.shape[0] if M is None else M
     assert out.dtype == torch.float32 and out.is_contiguous()
     if transpose_out:
@@ -362,10 +369,10 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
 
 
 def make_shadow_table(entries, device):
-    """entries: list of (src_off, dst_off, dstT_off, rows, cols) -> device table for refresh_shadows."""
+    """entries: list of (src_off, rows, cols, kind, d0, d1, d2) (AitkShadowDesc) -> device table for refresh_shadows."""
     arr = (_capi.ShadowDesc * len(entries))()
-    for i, (so, do, dto, r, c) in enumerate(entries):
-        arr[i].src_off, arr[i].dst_off, arr[i].dstT_off, arr[i].rows, arr[i].cols = so, do, dto, r, c
+    for i, (so, r, c, kind, d0, d1, d2) in enumerate(entries):
+        arr[i].src_off, arr[i].rows, arr[i].cols, arr[i].kind, arr[i].d0, arr[i].d1, arr[i].d2 = so, r, c, kind, d0, d1, d2
     raw = bytes(arr)
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return t, len(entries)

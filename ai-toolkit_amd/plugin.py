@@ -120,6 +120,7 @@ class Flux1MI355Model(_PluginBase):
             img_ids[..., 1] = img_ids[..., 1] + torch.arange(h // 2)[:, None]
             img_ids[..., 2] = img_ids[..., 2] + torch.arange(w // 2)[None, :]
             img_ids = img_ids.reshape(-1, 3).to(dev)
+            img_ids._aitk_grid = (h // 2, w // 2, text.shape[1])
             txt_ids = torch.zeros(text.shape[1], 3, device=dev)
             if isinstance(guidance_embedding_scale, list):
                 guidance = torch.tensor(guidance_embedding_scale, device=dev, dtype=torch.float32)

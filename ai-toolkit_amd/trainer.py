@@ -36,6 +36,8 @@ class _LoRATrainStepBase:
         self.world = 1
         self.dp = process_group is not None  # a 1-rank group still walks the all-reduce path (RCCL smoke on one GPU)
         self._pending = []
+        self.collect_dp_timing = False  # bench.py: events around the all-reduce wait (what of the collective is NOT hidden)
+        self.dp_wait_events = []
         if process_group is not None:
             import torch.distributed as dist
 
@@ -117,7 +119,13 @@ class _LoRATrainStepBase:
         self.step_num += 1
         grad_scale = 1.0
         if self.dp:
+            if self.collect_dp_timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()  # on the launch stream, behind the last backward kernel
             self._finish_allreduce()
+            if self.collect_dp_timing:
+                e1.record()  # behind the stream-wait on the collective: e1 - e0 = exposed all-reduce time
+                self.dp_wait_events.append((e0, e1))
             grad_scale = 1.0 / self.world
         ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
@@ -220,4 +228,6 @@ def make_ids(Hh, W, n_txt, device):
     img_ids = torch.zeros(h2, w2, 3)
     img_ids[..., 1] = img_ids[..., 1] + torch.arange(h2)[:, None]
     img_ids[..., 2] = img_ids[..., 2] + torch.arange(w2)[None, :]
-    return img_ids.reshape(h2 * w2, 3).to(device), torch.zeros(n_txt, 3, device=device)
+    img_ids = img_ids.reshape(h2 * w2, 3).to(device)
+    img_ids._aitk_grid = (h2, w2, n_txt)  # RoPE-table cache key of the fused graph (no device sync per step)
+    return img_ids, torch.zeros(n_txt, 3, device=device)

@@ -391,13 +391,13 @@ class WanTransformer3DModel(FusedGraphBase):
         grp = getattr(lins[0].lora, "group", None) if all(t is not None for t in Ts) else None
         if grp is not None and [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             grp = None
-        dTcat = self._new(Mt, grp["R"]) if grp is not None else None
+        dTcat = self._new(Mt, 3 * grp["R"]) if grp is not None else None  # split slab layout per adapter (aitk_lora_down)
         for lin, dy, T in zip(lins, dys, Ts):
             dy = self._dora_dz(lin, dy, Mt)
             dT_out = None
             if grp is not None:
-                c0 = grp["col"][id(lin.lora)]
-                dT_out = dTcat[:, c0:c0 + lin.lora.rank_pad]
+                c0 = 3 * grp["col"][id(lin.lora)]
+                dT_out = dTcat[:, c0:c0 + 3 * lin.lora.rank_pad]
             self._lora_grads(lin, dy, T, enc, M=Mt, rows_per_batch=St, B=B, dT_out=dT_out)
         if grp is not None:
-            self.ops.lora_wgrad(dTcat, enc, grp["g_down"], accumulate=True, M=Mt)
+            self.ops.lora_wgrad(dTcat, enc, grp["g_down"], accumulate=True, M=Mt, split=grp["rp"])

@@ -122,6 +122,96 @@ def cpu_baseline():
                       "fwd+bwd+AdamW incl. embedders/head each; extrapolated x19/x38"}
 
 
+BUCKETS = [(1024, 1024), (832, 1216), (1216, 832), (896, 1152), (1152, 896)]  # BASELINE.md §2 bucket mix (W x H pixels)
+
+
+def _pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+def make_batch(dev, B, width=1024, height=1024, seed=42):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    lat = torch.randn(B, 16, height // 8, width // 8, device=dev, generator=gen).to(torch.bfloat16)
+    emb = (torch.randn(B, 512, 4096, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    pooled = (torch.randn(B, 768, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    return lat, emb, pooled
+
+
+def timed_steps(fn, n, sync):
+    """n calls of fn bracketed by `sync` (barrier + device sync) on both sides; per-step GPU durations from events recorded at
+    the step boundaries on the launch stream (no host sync inside the region)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    sync()
+    t0 = time.perf_counter()
+    evs[0].record()
+    out = None
+    for i in range(n):
+        out = fn()
+        evs[i + 1].record()
+    sync()
+    dt = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(n)]
+    return dt, per, out
+
+
+def gpu_comparator(dev, rank, steps=3):
+    """The reference-equivalent PyTorch-ROCm EAGER step on this GPU, in this run: the oracle's plain-PyTorch FLUX.1-dev (bf16,
+    F.scaled_dot_product_attention) + the oracle restatement of the reference LoRA modules (fp32 adapter on an fp32 activation copy,
+    toolkit/network_mixins.py:304-342) + autograd + clip_grad_norm_ + torch.optim.AdamW; B = 1, no gradient checkpointing (the
+    reference's default recomputes every block and would be slower still)."""
+    from oracle import flux_ref, lora_ref
+
+    torch.manual_seed(0)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            model = flux_ref.FluxTransformer2DModel()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.Linear):
+                m.weight.normal_(0, 0.02)
+                if m.bias is not None:
+                    m.bias.zero_()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    net = lora_ref.RefLoRANetwork(model, rank).to(dev)
+    net.torch_multiplier = net.torch_multiplier.to(dev)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.normal_(0, 1e-3)
+    net.apply_to()
+    params = [p for m in net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)]
+    opt = torch.optim.AdamW(params, lr=1e-4, eps=1e-6, weight_decay=0.01)
+    lat, emb, pooled = make_batch(dev, 1)
+    img_ids, txt_ids = flux_ref.make_ids(128, 128, 512, dev)
+    guid = torch.ones(1, device=dev)
+
+    def step():
+        noise = torch.randn_like(lat)
+        t = torch.rand(1, device=dev)
+        noisy = ((1 - t.view(1, 1, 1, 1)) * lat.float() + t.view(1, 1, 1, 1) * noise.float()).to(torch.bfloat16)
+        opt.zero_grad(set_to_none=True)
+        with net:
+            pred = flux_ref.unpack_latents(model(flux_ref.pack_latents(noisy), emb, pooled, t, img_ids, txt_ids, guid), 128, 128)
+            loss = torch.nn.functional.mse_loss(pred.float(), (noise.float() - lat.float()))
+            loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+
+    step()
+    dt, per, _ = timed_steps(step, steps, torch.cuda.synchronize)
+    return {"value": steps / dt, "unit": "images/s", "kind": "PyTorch-ROCm eager, same GPU (oracle modules: bf16 base, fp32 LoRA, autograd, "
+            "clip_grad_norm_, torch AdamW; no gradient checkpointing)", "per_gpu_batch": 1, "steps": steps, "ms_per_step": 1e3 * dt / steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +225,7 @@ def main():
     ap.add_argument("--network", default="lora", choices=["lora", "dora", "lokr"], help="adapter type (headline metric: lora)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,10 +253,7 @@ def main():
     if B <= 0:
         avail_gib = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30  # free + what this process holds
         B = 7 if (avail_gib >= 252 and not args.fp8_base and args.network == "lora") else 4
-    gen = torch.Generator(device=dev).manual_seed(42 + rank)
-    lat = torch.randn(B, 16, 128, 128, device=dev, generator=gen).to(torch.bfloat16)
-    emb = (torch.randn(B, 512, 4096, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
-    pooled = (torch.randn(B, 768, device=dev, generator=gen) * 0.1).to(torch.bfloat16)
+    lat, emb, pooled = make_batch(dev, B, seed=42 + rank)
 
     def one():
         return step.step(lat, emb, pooled)
@@ -177,35 +265,73 @@ def main():
 
     for _ in range(args.warmup):
         one()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one()
-    barrier()
-    dt = time.perf_counter() - t0
+    step.collect_dp_timing = world > 1 or pg is not None
+    dt, per_step_ms, loss = timed_steps(one, args.steps, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
     ips = world * B * args.steps / dt
+    workload = (f"FLUX.1-dev DiT {args.network.upper() if args.network != 'lora' else 'LoRA'} r{args.rank}, 1024x1024 (4096 img + 512 txt "
+                "tokens), bf16" + (" activations over a weight-only fp8 e4m3 base" if args.fp8_base else "") + ", AdamW+EMA, clip 1.0")
     out = {
         "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else "")
                   + (f" [adapter: {args.network}]" if args.network != "lora" else ""),
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
-        "config": {"workload": "FLUX.1-dev DiT LoRA r16, 1024x1024 (4096 img + 512 txt tokens), bf16, AdamW+EMA, clip 1.0",
+        "config": {"workload": workload,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
-                   "lora_params": net.arena_p.numel(), "grad_checkpointing": False},
+                   "lora_params": net.arena_p.numel(), "grad_checkpointing": False,
+                   "adapter_precision": "fp32 master + split bf16 (hi+lo) shadows on MFMA"},
         "final_loss": final_loss,
+        "step_ms": {"median": _pct(per_step_ms, 0.5), "p10": _pct(per_step_ms, 0.1), "p90": _pct(per_step_ms, 0.9), "n": len(per_step_ms),
+                    "note": "GPU time between step boundaries (events on the launch stream), rank 0"},
         "step_mfma_frac": FLOP_PER_IMAGE * (ips / world) / (PEAK_BF16 * 1e12),
     }
+    if step.collect_dp_timing and step.dp_wait_events:
+        waits = [a.elapsed_time(b) for a, b in step.dp_wait_events]
+        out["allreduce_ms_exposed"] = {"median": _pct(waits, 0.5), "p90": _pct(waits, 0.9), "n": len(waits),
+                                       "note": "launch-stream time between the end of backward and the optimizer kernel, i.e. the part "
+                                               "of the gradient all-reduce not hidden behind the double-block backward (rank 0)"}
+    step.collect_dp_timing = False
     rf = None
     if not args.no_roofline:
         rf = gemm_roofline(one, ops)  # every rank runs the instrumented step (it contains the gradient all-reduce)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
+
+    extras = world == 1 and not args.no_extras and not args.fp8_base and args.network == "lora"
+    if extras:
+        # ---- batch sweep (single bucket): the headline B plus 1 and 4 (SURVEY.md §8d asked for B in {1, 2, 4})
+        del lat, emb, pooled
+        sweep = {str(B): {"images_per_s": ips, "ms_per_step": 1e3 * dt / args.steps}}
+        for b2 in (1, 4):
+            if b2 == B:
+                continue
+            l2, e2, p2 = make_batch(dev, b2, seed=43)
+            fn = lambda: step.step(l2, e2, p2)  # noqa: E731
+            fn()
+            d2, _, _ = timed_steps(fn, 3, barrier)
+            sweep[str(b2)] = {"images_per_s": b2 * 3 / d2, "ms_per_step": 1e3 * d2 / 3}
+            del l2, e2, p2
+        out["batch_sweep"] = sweep
+        # ---- bucketed run (BASELINE.json configs[2] "1024x1024 buckets"): the five resolutions of BASELINE.md §2 cycled so the
+        # sequence length changes every step (toolkit/config_modules.py:1095-1113, toolkit/data_loader.py:718, 749-756)
+        torch.cuda.empty_cache()
+        bb = min(B, 4)
+        batches = [make_batch(dev, bb, w, h, seed=50 + i) for i, (w, h) in enumerate(BUCKETS)]
+        for bt in batches:  # first touch of every shape (allocator, RoPE tables) outside the timed region
+            step.step(*bt)
+        order = [batches[i % len(batches)] for i in range(2 * len(batches))]
+        it = iter(order)
+        db, per_b, _ = timed_steps(lambda: step.step(*next(it)), len(order), barrier)
+        out["bucketed"] = {"images_per_s": bb * len(order) / db, "per_gpu_batch": bb, "steps": len(order),
+                           "buckets": [f"{w}x{h}" for w, h in BUCKETS], "ms_per_step_by_bucket": {f"{w}x{h}": round((per_b[i] + per_b[i + 5]) / 2, 2)
+                                                                                                 for i, (w, h) in enumerate(BUCKETS)},
+                           "single_bucket_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s")}
+        del batches, order
     if rank == 0:
         if rf is not None:
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
@@ -217,17 +343,32 @@ def main():
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-            # WRITE_SIZE, profiles/r01_pmc_v2/summary.json) for the dominant shape 18432x3072x3072 (+r16 slab)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")
-            if os.path.exists(pmc):
+            # WRITE_SIZE) for the dominant shape (B * 4608) x 3072 x 3072 (+ LoRA slab): newest round first
+            for pmc in (os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")):
+                if not os.path.exists(pmc):
+                    continue
                 by_m = json.load(open(pmc)).get("gemm_nt_8phase_kernel_by_M", {})
-                g8 = by_m.get(str(B * 4608))  # the most frequent launch of a step: (B * 4608) x 3072 x 3072 (+r16 slab)
+                g8 = by_m.get(str(B * 4608))  # the most frequent launch of a step
                 if g8 is not None:
                     out["roofline"]["traffic"] = g8["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = (f"PMC, launch {B * 4608}x3072x3072+r16: memory-side bytes incl. Infinity-Cache hits; "
-                                                       f"algorithmic {g8['algorithmic_bytes']} B")
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+                    out["roofline"]["traffic_note"] = (f"PMC ({os.path.basename(os.path.dirname(pmc))}), launch {B * 4608}x3072x3072+LoRA slab: "
+                                                       f"memory-side bytes incl. Infinity-Cache hits; algorithmic {g8['algorithmic_bytes']} B")
+                    break
+    if extras:
+        # ---- same-GPU eager comparator, measured in this run (our step state released first: the eager path needs ~78 GiB at B = 1)
+        del step, model, net, one
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            out["gpu_comparator"] = gpu_comparator(dev, args.rank)
+        except Exception as ex:  # the comparator must never cost the headline line
+            out["gpu_comparator"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 1
+#define AITK_ABI_VERSION 2
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -77,17 +77,25 @@ int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
 
 
 /*
- * T[M,R] = bf16( scale * mult[m / rows_per_batch] * (X[M,K] P[R,K]^T) )     R <= 64, R % 4 == 0, K % 16 == 0
+ * T[M,R] = scale * mult[m / rows_per_batch] * (X[M,K] (P + P_lo)[R,K]^T)     R <= 64, R % 4 == 0, K % 16 == 0
  * forward : P = lora_down.weight            -> T   (reference: toolkit/network_mixins.py:197-239, 309-321)
  * backward: X = dY, P = lora_up.weight^T    -> dT  (autograd of the same lines)
  * mult may be NULL (multiplier 1); X rows may be segmented like AitkGemmArgs.A.
+ * Split precision — the reference keeps the adapter in fp32 (network_mixins.py:309, BaseSDTrainProcess.py:1982-1983):
+ *   P_lo (may be NULL): bf16(w - bf16(w)) of the fp32 matrix whose bf16 rounding is P (same ldp); both are contracted into
+ *     one fp32 accumulator, so X (P + P_lo)^T carries 16 mantissa bits of the fp32 weight.
+ *   split_rp == 0: T is [M, R] bf16 (one rounding).
+ *   split_rp  > 0 (R % split_rp == 0, split_rp % 4 == 0): T is [M, 3R]; rank block b (split_rp ranks) is written as
+ *     [hi | lo | hi] at columns 3*b*split_rp, hi = bf16(t), lo = bf16(t - hi) — the K-slab A2 of aitk_gemm_nt, to be paired
+ *     with B2 = [B_hi | B_hi | B_lo] (aitk_lora_refresh_shadows), and the S operand of aitk_lora_wgrad(split_rp).
  */
 typedef struct AitkLoraDownArgs {
   const aitk_bf16* X; int64_t ldx; int32_t x_seg_rows; int32_t _pad0; int64_t x_seg_stride;
   const aitk_bf16* P; int64_t ldp;
   aitk_bf16* T; int64_t ldt;
   const float* mult; float scale; int32_t rows_per_batch;
-  int32_t M, K, R, _pad1;
+  int32_t M, K, R, split_rp;
+  const aitk_bf16* P_lo;
 } AitkLoraDownArgs;
 int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
 
@@ -96,10 +104,12 @@ int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
  *   lora_down.weight.grad [R,K]: S = dT, G = X,  strides (K, 1)
  *   lora_up.weight.grad   [N,R]: S = T,  G = dY, strides (1, R)
  * `partial` is caller-provided scratch of aitk_lora_wgrad_workspace_bytes(M,R,L) bytes.
+ * split_rp > 0 (split_rp % 8 == 0): S is the [M, 3R] slab layout aitk_lora_down(split_rp) writes; rank r is read as
+ *   hi + lo from columns (r / rp) * 3 rp + r % rp (+ rp), both contracted into the same fp32 accumulator.
  */
 typedef struct AitkLoraWgradArgs {
   const aitk_bf16* S; int64_t lds;
-  const aitk_bf16* G; int64_t ldg; int32_t g_seg_rows; int32_t _pad0; int64_t g_seg_stride;
+  const aitk_bf16* G; int64_t ldg; int32_t g_seg_rows; int32_t split_rp; int64_t g_seg_stride;
   float* partial;
   float* out; int64_t out_stride_r; int64_t out_stride_l;
   int32_t accumulate;
@@ -260,8 +270,14 @@ typedef struct AitkAdamWArgs {
 int64_t aitk_adamw_workspace_bytes(int64_t n);
 int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
 
-/* bf16 shadows (direct + transposed) of every LoRA matrix of the fp32 arena, refreshed after each optimizer step */
-typedef struct AitkShadowDesc { int64_t src_off; int64_t dst_off; int64_t dstT_off; int32_t rows, cols; } AitkShadowDesc;
+/* bf16 shadows of every adapter matrix of the fp32 arena (row-major [rows, cols] at src_off), refreshed after each optimizer
+ * step.  hi = bf16(w), lo = bf16(w - hi).  Offsets are elements into `shadow`.
+ *   kind 0 (plain; LoKr factors): d0 = hi [rows, cols], d1 = hi transposed [cols, rows].
+ *   kind 1 (lora_down A [r, in]):  d0 = hi [r, in], d1 = lo [r, in] (P / P_lo of the forward aitk_lora_down),
+ *                                  d2 = [in, 3r] rows = [A^T_hi | A^T_hi | A^T_lo] (B2 of the dgrad K-slab).
+ *   kind 2 (lora_up B [out, r]):   d0 = [out, 3r] rows = [B_hi | B_hi | B_lo] (B2 of the forward K-slab),
+ *                                  d1 = hi transposed [r, out], d2 = lo transposed [r, out] (P / P_lo of the backward aitk_lora_down). */
+typedef struct AitkShadowDesc { int64_t src_off; int64_t d0; int64_t d1; int64_t d2; int32_t rows, cols, kind, _pad; } AitkShadowDesc;
 int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                               aitk_stream_t stream);
 

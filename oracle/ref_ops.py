@@ -80,21 +80,41 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     return out
 
 
-def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None):
-    """lora_down(x.float()) * scale * multiplier (toolkit/network_mixins.py:197-239, 309-318)."""
+def _split_cols(R, rp):
+    """column indices of (hi, lo, hi-again) for the [M, 3R] K-slab layout: rank block b at columns 3*b*rp."""
+    r = torch.arange(R)
+    base = (r // rp) * 3 * rp + r % rp
+    return base, base + rp, base + 2 * rp
+
+
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0):
+    """lora_down(x.float()) * scale * multiplier (toolkit/network_mixins.py:197-239, 309-318).  p_lo: second half of a split
+    (hi + lo) projection; split: write the fp32 result as the [hi | lo | hi] bf16-pair slab layout (hi = round(t), lo = round(t - hi))."""
     if M is None:
         M = x.shape[0]
-    v = _seg_view(x, x_seg, M).float() @ pmat.float().t() * scale
+    P = pmat.float() if p_lo is None else pmat.float() + p_lo.float()
+    v = _seg_view(x, x_seg, M).float() @ P.t() * scale
     if mult is not None:
         v = v * mult.repeat_interleave(rows_per_batch)[:M, None]
-    out[:M].copy_(v.to(out.dtype))
+    if not split:
+        out[:M].copy_(v.to(out.dtype))
+        return out
+    hi = v.to(out.dtype)
+    lo = (v - hi.float()).to(out.dtype)
+    c_hi, c_lo, c_hi2 = _split_cols(pmat.shape[0], split)
+    out[:M, c_hi] = hi
+    out[:M, c_lo] = lo
+    out[:M, c_hi2] = hi
     return out
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None):
-    """autograd of lora_down / lora_up weights."""
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0):
+    """autograd of lora_down / lora_up weights (split: s is the slab layout, read as hi + lo)."""
     if M is None:
         M = s.shape[0]
+    if split:
+        c_hi, c_lo, _ = _split_cols(s.shape[1] // 3, split)
+        s = s[:M, c_hi].float() + s[:M, c_lo].float()
     v = s[:M].float().t() @ _seg_view(g, g_seg, M).float()
     if transpose_out:
         v = v.t()
@@ -325,11 +345,24 @@ def make_shadow_table(entries, device):
 
 
 def refresh_shadows(arena, shadow, table):
+    """hi = round(w), lo = round(w - hi) in the layouts of AitkShadowDesc (include/aitk_mi355.h)."""
     entries, _ = table
-    for so, do, dto, r, c in entries:
+    for so, r, c, kind, d0, d1, d2 in entries:
         w = arena[so:so + r * c].view(r, c)
-        shadow[do:do + r * c].view(r, c).copy_(w.to(shadow.dtype))
-        shadow[dto:dto + r * c].view(c, r).copy_(w.t().to(shadow.dtype))
+        hi = w.to(shadow.dtype)
+        if kind == 0:
+            shadow[d0:d0 + r * c].view(r, c).copy_(hi)
+            shadow[d1:d1 + r * c].view(c, r).copy_(hi.t())
+            continue
+        lo = (w - hi.float()).to(shadow.dtype)
+        if kind == 1:  # A [rank, in]
+            shadow[d0:d0 + r * c].view(r, c).copy_(hi)
+            shadow[d1:d1 + r * c].view(r, c).copy_(lo)
+            shadow[d2:d2 + 3 * r * c].view(c, 3 * r).copy_(torch.cat((hi.t(), hi.t(), lo.t()), dim=1))
+        else:  # B [out, rank]
+            shadow[d0:d0 + 3 * r * c].view(r, 3 * c).copy_(torch.cat((hi, hi, lo), dim=1))
+            shadow[d1:d1 + r * c].view(c, r).copy_(hi.t())
+            shadow[d2:d2 + r * c].view(c, r).copy_(lo.t())
 
 
 # ---------------------------------------------------------------------------------------------------------- VAE encoder

@@ -1,0 +1,275 @@
+"""Regression tests for the round-1 review findings (host logic on CPU, oracle kernel table) and for the split-precision
+(hi + lo bf16) adapter branch that reproduces the reference's fp32 adapter arithmetic (toolkit/network_mixins.py:309-321)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+from ai_toolkit_amd.lora import FusedLoRANetwork
+from ai_toolkit_amd.plugin import Flux1MI355Model, Wan21MI355Model
+from ai_toolkit_amd.trainer import make_ids
+from oracle import flux_ref, ref_ops
+from tests.test_host_graph_cpu import CFG, build_pair
+
+
+def _ids_inputs(Hl, Wl, B=1, n_txt=6, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    n_img = (Hl // 2) * (Wl // 2)
+    hidden = torch.randn(B, n_img, 64, generator=g)
+    enc = torch.randn(B, n_txt, CFG["joint_attention_dim"], generator=g)
+    pooled = torch.randn(B, CFG["pooled_projection_dim"], generator=g)
+    return hidden, enc, pooled, torch.tensor([0.4][:B]), torch.ones(B), n_txt
+
+
+def test_rope_tables_of_transposed_buckets_do_not_collide():
+    """HxW then WxH (768x1344 vs 1344x768 buckets): same token count, same id sums — the tables must differ and each
+    prediction must match the oracle (the round-1 cache key was symmetric in h and w)."""
+    ref, ref_net, nat, net = build_pair(rank=4)
+    for Hl, Wl in ((12, 4), (4, 12), (12, 4)):
+        hidden, enc, pooled, t, guid, n_txt = _ids_inputs(Hl, Wl)
+        img_ids, txt_ids = make_ids(Hl, Wl, n_txt, "cpu")
+        assert img_ids._aitk_grid == (Hl // 2, Wl // 2, n_txt)
+        ref_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+        with net, ref_net:
+            want = ref(hidden, enc, pooled, t, ref_ids[0], ref_ids[1], guid)
+            got = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (Hl, Wl, (got - want).abs().max())
+    assert len(nat._rope_cache) == 2
+    # ids built elsewhere (no stamp): keyed on their values
+    ids_a, ids_b = flux_ref.make_ids(12, 4, 6), flux_ref.make_ids(4, 12, 6)
+    ca, _ = nat.rope_tables(*ids_a)
+    cb, _ = nat.rope_tables(*ids_b)
+    assert not torch.equal(ca, cb) and len(nat._rope_cache) == 4
+
+
+def test_dora_optimizer_state_round_trips_through_torch_adamw():
+    """prepare_optimizer_params emits [magnitude, lora_up, lora_down] per DoRA module (the reference module's named_parameters
+    order); the exported optimizer.pt must carry the same tensors in the same order, magnitude moments included."""
+    ref, ref_net, nat, net = build_pair(rank=4, network_type="dora")
+    net.arena_m.normal_()
+    net.arena_v.uniform_()
+    params = net.prepare_optimizer_params()[0]["params"]
+    sd = net.optimizer_state_dict(step=5, lr=1e-4)
+    assert len(sd["state"]) == len(params) == 3 * len(net.unet_loras)
+    opt = torch.optim.AdamW(params, lr=1e-4, eps=1e-6)
+    opt.load_state_dict(sd)  # shapes line up parameter by parameter, or torch raises / mis-assigns
+    m0 = net.unet_loras[0]
+    assert torch.equal(opt.state[m0.magnitude]["exp_avg"], net.arena_m[m0.off_mag:m0.off_mag + m0.magnitude.numel()])
+    assert torch.equal(opt.state[m0.lora_up.weight]["exp_avg_sq"], net.arena_view(net.arena_v, m0, "up"))
+    m_copy, v_copy = net.arena_m.clone(), net.arena_v.clone()
+    net.arena_m.zero_()
+    net.arena_v.zero_()
+    assert net.load_optimizer_state_dict(opt.state_dict()) == 5
+    for m in net.unet_loras:
+        for which in ("down", "up"):
+            assert torch.equal(net.arena_view(net.arena_m, m, which), net.arena_view(m_copy, m, which))
+        sl = slice(m.off_mag, m.off_mag + m.magnitude.numel())
+        assert torch.equal(net.arena_m[sl], m_copy[sl]) and torch.equal(net.arena_v[sl], v_copy[sl])
+    bad = {"state": {0: sd["state"][0]}, "param_groups": sd["param_groups"]}
+    with pytest.raises(ValueError):
+        net.load_optimizer_state_dict(bad)
+
+
+def test_wan_adapter_files_use_the_reference_key_names_and_reload(tmp_path):
+    """network.get_state_dict / load_weights go through the base model's convert_lora_weights_before_save / _load hooks like
+    the reference (toolkit/network_mixins.py:637-638, 687-688): Wan files carry diffusion_model.blocks.N.self_attn.q... keys."""
+    from safetensors.torch import load_file
+    from tests.test_wan_cpu import CFG as WCFG
+    from ai_toolkit_amd.wan import WanTransformer3DModel
+    from oracle import wan_ref
+
+    torch.manual_seed(0)
+    ref = wan_ref.WanTransformer3DModel(**WCFG)
+    wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+    nat = WanTransformer3DModel(**WCFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    plug = Wan21MI355Model("cpu", model=nat, dtype=torch.float32)
+    net = FusedLoRANetwork(nat, lora_dim=4, target_lin_modules=("WanTransformer3DModel",), transformer_block_names=["blocks"],
+                           base_model_version="wan_2.1", base_model=plug)
+    assert net.base_model_ref() is plug
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.normal_(0, 0.02)
+    net.apply_to()
+    net.build_arena("cpu")
+    net.refresh_shadows(ref_ops)
+    f = tmp_path / "wan.safetensors"
+    net.save_weights(str(f), dtype=torch.float32)
+    sd = load_file(str(f))
+    assert all(k.startswith("diffusion_model.blocks.") for k in sd), list(sd)[:3]
+    assert "diffusion_model.blocks.0.self_attn.q.lora_A.weight" in sd and "diffusion_model.blocks.2.ffn.2.lora_B.weight" in sd
+    want = {m.lora_name: (m.lora_down.weight.detach().clone(), m.lora_up.weight.detach().clone()) for m in net.unet_loras}
+    with torch.no_grad():
+        net.arena_p.zero_()
+    assert net.load_weights(str(f)) is None  # every key matched an adapter
+    for m in net.unet_loras:
+        assert torch.equal(m.lora_down.weight, want[m.lora_name][0]) and torch.equal(m.lora_up.weight, want[m.lora_name][1])
+    # shadows were refreshed by load_weights (the kernels read them, not the fp32 arena)
+    m0 = net.unet_loras[0]
+    assert torch.equal(m0.sh_down[: m0.lora_dim], m0.lora_down.weight.detach())
+    # a file in a foreign key format matches nothing: loud error instead of silently training from scratch
+    with pytest.raises(ValueError):
+        net.load_weights({"lora_unet_foo.lora_down.weight": torch.zeros(4, 4)})
+    # without the hook-holding base model the same file does not match (diffusers names expected) -> also loud
+    net2 = FusedLoRANetwork(nat, lora_dim=4, target_lin_modules=("WanTransformer3DModel",), transformer_block_names=["blocks"])
+    with pytest.raises(ValueError):
+        net2.load_weights(str(f))
+
+
+def test_merge_out_without_merge_is_a_no_op_and_dora_merge_needs_no_ops():
+    ref, ref_net, nat, net = build_pair(rank=4)
+    lin = nat.transformer_blocks[0].attn.to_q
+    w0 = lin.weight.detach().clone()
+    net.merge_out(1.0, ops=ref_ops)  # reference: returns early when not is_merged_in (network_mixins.py:900-902)
+    assert torch.equal(lin.weight, w0) and not net.is_merged_in
+    net.merge_in(0.5, ops=ref_ops)
+    m = lin.lora
+    want = w0 + 0.5 * m.scale * (m.lora_up.weight.detach() @ m.lora_down.weight.detach())
+    assert torch.allclose(lin.weight, want, rtol=0, atol=1e-6) and net.is_merged_in
+    net.merge_out(0.5, ops=ref_ops)
+    assert torch.allclose(lin.weight, w0, rtol=0, atol=1e-6) and not net.is_merged_in
+    # reset_weights: the reference zeroes lora_up only (network_mixins.py:464-471)
+    down0 = m.lora_down.weight.detach().clone()
+    net.reset_weights()
+    assert torch.equal(m.lora_down.weight, down0) and float(m.lora_up.weight.detach().abs().max()) == 0.0
+    assert float(m.sh_up3.abs().max()) == 0.0  # shadows follow
+    # DoRA: merge_in is a no-op that must not need a kernel table (never refreshed network)
+    torch.manual_seed(1)
+    nat2 = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    dnet = FusedLoRANetwork(nat2, lora_dim=4, network_type="dora")
+    dnet.merge_in(1.0)
+    assert not dnet.is_merged_in
+
+
+def test_plugin_path_two_steps_with_torch_adamw_and_set_to_none():
+    """The reference trainer: optimizer.zero_grad() ... loss.backward() ... optimizer.step(); optimizer.zero_grad(set_to_none=True)
+    (SDTrainer.py:2249-2288).  set_to_none drops the .grad views of the arena: the autograd bridge must re-attach them and must
+    not accumulate into a stale arena, so two consecutive steps follow the oracle network under the same optimizer."""
+    ref, ref_net, nat, net = build_pair(rank=4)
+    plug = Flux1MI355Model("cpu", model=nat, dtype=torch.float32)
+    opt = torch.optim.AdamW(net.prepare_optimizer_params(default_lr=1e-3)[0]["params"], lr=1e-3, eps=1e-6)
+    ref_params = [p for m in ref_net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)]
+    opt_ref = torch.optim.AdamW(ref_params, lr=1e-3, eps=1e-6)
+    g = torch.Generator().manual_seed(5)
+    B, Hl, Wl, n_txt = 2, 8, 4, 6
+    for step in range(2):
+        lat = torch.randn(B, 16, Hl, Wl, generator=g)
+        pe = SimpleNamespace(text_embeds=torch.randn(B, n_txt, CFG["joint_attention_dim"], generator=g) * 0.5,
+                             pooled_embeds=torch.randn(B, CFG["pooled_projection_dim"], generator=g) * 0.5)
+        ts = torch.tensor([700.0, 250.0])
+        target = torch.randn(B, 16, Hl, Wl, generator=g)
+        img_ids, txt_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+        opt_ref.zero_grad()
+        with ref_net:
+            p_ref = flux_ref.unpack_latents(ref(flux_ref.pack_latents(lat), pe.text_embeds, pe.pooled_embeds, ts / 1000, img_ids,
+                                                txt_ids, torch.full((B,), 1.0)), Hl, Wl)
+            torch.nn.functional.mse_loss(p_ref, target).backward()
+        opt_ref.step()
+        opt_ref.zero_grad(set_to_none=True)
+        opt.zero_grad()
+        with net:
+            pred = plug.get_noise_prediction(lat, ts, pe, guidance_embedding_scale=1.0, bypass_guidance_embedding=False)
+            torch.nn.functional.mse_loss(pred, target).backward()
+        m0 = net.unet_loras[0]
+        assert m0.lora_up.weight.grad is not None and m0.lora_up.weight.grad.data_ptr() == net.arena_view(net.arena_g, m0, "up").data_ptr()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        assert m0.lora_up.weight.grad is None
+        net.refresh_shadows(ref_ops)  # what the reference's weights-changed hook would trigger
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.allclose(a.lora_up.weight, b.lora_up.weight, rtol=2e-3, atol=1e-5), (step, a.lora_name)
+            assert torch.allclose(a.lora_down.weight, b.lora_down.weight, rtol=2e-3, atol=1e-5), (step, a.lora_name)
+    # nn.Module.zero_grad on the network keeps the views and clears the arena
+    net.arena_g.fill_(1.0)
+    net.zero_grad()
+    assert float(net.arena_g.abs().max()) == 0.0 and net.unet_loras[0].lora_up.weight.grad is not None
+
+
+# ---------------------------------------------------------------------------------------------------- split precision
+def _bf16_pair(rank=16, seed=0):
+    """tiny FLUX pair whose adapter shadows are bf16 (as on the GPU) while the oracle kernel table does the arithmetic."""
+    torch.manual_seed(seed)
+    ref, ref_net, nat, net = build_pair(rank=rank)
+    return ref, ref_net, nat, net
+
+
+def test_split_shadow_layouts_and_precision():
+    ref, ref_net, nat, net = build_pair(rank=8)
+    net.build_arena("cpu", groups=nat.lora_groups(), shadow_dtype=torch.bfloat16)
+    net.refresh_shadows(ref_ops)
+    m = nat.transformer_blocks[0].attn.to_q.lora
+    rp = m.rank_pad
+    A = net.arena_view(net.arena_p, m, "down", padded=True)
+    Bm = net.arena_view(net.arena_p, m, "up", padded=True)
+    assert m.sh_down.dtype == torch.bfloat16 and m.sh_down.shape == (rp, m.in_features) and m.sh_down_lo.shape == m.sh_down.shape
+    assert torch.equal(m.sh_down, A.to(torch.bfloat16))
+    assert torch.equal(m.sh_down_lo, (A - m.sh_down.float()).to(torch.bfloat16))
+    assert float((A - m.sh_down.float() - m.sh_down_lo.float()).abs().max()) <= 2.0 ** -16 * float(A.abs().max())
+    assert m.sh_downT3.shape == (m.in_features, 3 * rp)
+    assert torch.equal(m.sh_downT3[:, :rp], m.sh_down.t()) and torch.equal(m.sh_downT3[:, rp:2 * rp], m.sh_down.t())
+    assert torch.equal(m.sh_downT3[:, 2 * rp:], m.sh_down_lo.t())
+    assert m.sh_up3.shape == (m.out_features, 3 * rp)
+    hi = Bm.to(torch.bfloat16)
+    assert torch.equal(m.sh_up3[:, :rp], hi) and torch.equal(m.sh_up3[:, rp:2 * rp], hi)
+    assert torch.equal(m.sh_up3[:, 2 * rp:], (Bm - hi.float()).to(torch.bfloat16))
+    assert torch.equal(m.sh_upT, hi.t()) and torch.equal(m.sh_upT_lo, m.sh_up3[:, 2 * rp:].t())
+    # a same-input group: the hi / lo matrices of q, k, v are adjacent, in the order of the gradient arena
+    grp = m.group
+    assert grp["sh_down"].shape == (3 * rp, m.in_features) and torch.equal(grp["sh_down"][:rp], m.sh_down)
+    k = nat.transformer_blocks[0].attn.to_k.lora
+    assert torch.equal(grp["sh_down_lo"][rp:2 * rp], k.sh_down_lo)
+
+
+def test_split_adapter_branch_reaches_fp32_class_precision_on_bf16_operands():
+    """One wrapped Linear in isolation, bf16 activations (the reference also feeds bf16 activations to its fp32 adapter):
+    LoRA output, dT, dA, dB from the [hi | lo | hi] x [hi | hi | lo] slabs are within 1e-4 of fp32 adapter arithmetic — the
+    north-star tolerance for LoRA deltas is 1e-3 — while single-bf16 shadows (round 1) sit at ~3e-3."""
+    torch.manual_seed(0)
+    M, K, N, r = 256, 192, 128, 16
+    bf = torch.bfloat16
+    x = torch.randn(M, K).to(bf)
+    dy = torch.randn(M, N).to(bf)
+    A = torch.empty(r, K).uniform_(-1, 1) / K ** 0.5
+    Bm = torch.randn(N, r) * 0.05
+
+    def split(w):
+        hi = w.to(bf)
+        return hi, (w - hi.float()).to(bf)
+
+    A_hi, A_lo = split(A)
+    B_hi, B_lo = split(Bm)
+    # fp32 adapter on bf16 activations = the reference's arithmetic
+    T_ref = x.float() @ A.t()
+    y_ref = T_ref @ Bm.t()
+    dT_ref = dy.float() @ Bm
+    dA_ref = dT_ref.t() @ x.float()
+    dB_ref = dy.float().t() @ T_ref
+    dx_ref = dT_ref @ A
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+
+    # --- split path through the kernel table's contracts
+    T3 = torch.empty(M, 3 * r, dtype=bf)
+    ref_ops.lora_down(x, A_hi, T3, p_lo=A_lo, split=r)
+    y = torch.zeros(M, N, dtype=torch.float32)
+    y = T3.float() @ torch.cat((B_hi, B_hi, B_lo), 1).float().t()
+    dT3 = torch.empty(M, 3 * r, dtype=bf)
+    ref_ops.lora_down(dy, B_hi.t().contiguous(), dT3, p_lo=B_lo.t().contiguous(), split=r)
+    dA = torch.zeros(r, K)
+    ref_ops.lora_wgrad(dT3, x, dA, split=r)
+    dB = torch.zeros(N, r)
+    ref_ops.lora_wgrad(T3, dy, dB, transpose_out=True, split=r)
+    dx = dT3.float() @ torch.cat((A_hi.t(), A_hi.t(), A_lo.t()), 1).float().t()
+    errs_split = dict(y=rel(y, y_ref), dA=rel(dA, dA_ref), dB=rel(dB, dB_ref), dx=rel(dx, dx_ref))
+    # --- round-1 arithmetic: one bf16 rounding of A, T, B, dT
+    T1 = (x.float() @ A_hi.float().t()).to(bf)
+    y1 = T1.float() @ B_hi.float().t()
+    dT1 = (dy.float() @ B_hi.float()).to(bf)
+    errs_bf16 = dict(y=rel(y1, y_ref), dA=rel(dT1.float().t() @ x.float(), dA_ref), dB=rel(dy.float().t() @ T1.float(), dB_ref),
+                     dx=rel(dT1.float() @ A_hi.float(), dx_ref))
+    for k, v in errs_split.items():
+        assert v < 1e-4, (k, v)
+        assert errs_bf16[k] > 1e-3 > 10 * v, (k, errs_bf16[k], v)

@@ -85,6 +85,33 @@ def test_lora_skinny_kernels():
     _ok(g.t_lora_wgrad(2, 16, 18432, transpose=True))
 
 
+def test_split_precision_skinny_kernels():
+    """hi + lo shadows, [hi | lo | hi] slab layout: the adapter branch carries fp32-class precision on bf16 MFMA (the reference's
+    adapter is fp32, toolkit/network_mixins.py:309)."""
+    from tools import gpu_check2 as g
+
+    _ok(g.t_lora_down_split(4608, 3072, 16, 16))
+    _ok(g.t_lora_down_split(1000, 3072, 64, 16, mult=True))      # a q,k,v,proj_mlp group: four rank blocks of 16
+    _ok(g.t_lora_down_split(600, 1024, 32, 32, seg=True))         # rank 32
+    _ok(g.t_lora_down_split(512, 1040, 16, 16))                   # K % 32 != 0: 32x32x16 fallback kernel
+    _ok(g.t_lora_down_split(2, 18432, 16, 16))
+    _ok(g.t_lora_wgrad_split(4608, 16, 16, 3072))
+    _ok(g.t_lora_wgrad_split(1000, 64, 16, 3072))
+    _ok(g.t_lora_wgrad_split(700, 32, 32, 1024, transpose=True, accumulate=True))
+    _ok(g.t_lora_wgrad_split(2, 16, 16, 18432, transpose=True))
+
+
+def test_adapter_branch_matches_fp32_adapter_arithmetic():
+    """North-star tolerance on LoRA quantities is 1e-3 relative; the split branch delivers ~1e-5 on the fp32 gradient outputs
+    (single-bf16 shadows, the round-1 arithmetic: ~3e-3)."""
+    from tools import gpu_check2 as g
+
+    r = g.t_adapter_branch(4608, 3072, 3072, 16)
+    _ok(r)
+    assert r["dA_single_bf16"] > 1e-3 and r["dB_single_bf16"] > 1e-3, r
+    _ok(g.t_adapter_branch(2048, 3072, 12288, 32))
+
+
 def test_norm_and_elementwise_kernels():
     from tools import gpu_check2 as g
 

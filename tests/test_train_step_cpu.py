@@ -102,7 +102,7 @@ def test_masked_and_weighted_loss_matches_reference_formula():
     assert torch.allclose(dpred, flux_ref.pack_latents(pred4.grad), rtol=1e-5, atol=1e-7)
 
 
-def _assert_adapters_match(net, ref_net, rtol=2e-3, atol=2e-6):
+def _assert_adapters_match(net, ref_net, rtol=2e-3, atol=1e-5):  # atol = 1% of one lr step: fp32 summation-order noise on near-zero gradients under AdamW
     for a, b in zip(net.unet_loras, ref_net.unet_loras):
         for pa, pb in ((a.lora_down.weight, b.lora_down.weight), (a.lora_up.weight, b.lora_up.weight)):
             assert torch.allclose(pa, pb, rtol=rtol, atol=atol), (a.lora_name, (pa - pb).abs().max())

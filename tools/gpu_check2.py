@@ -61,6 +61,115 @@ def t_lora_down(M, K, Rk, mult=False, seg=False):
     return {"rel_err": e, "ok": e < 5e-3}
 
 
+def t_lora_down_split(M, K, Rk, rp, mult=False, seg=False):
+    """P = hi + lo contracted into one accumulator, result written as the [hi | lo | hi] slab layout per rank block of rp."""
+    from oracle import ref_ops
+
+    x = R(M, K, seed=1).to(bf).to(dev)
+    p32 = R(Rk, K, s=0.05, seed=2).to(dev)
+    p_hi = p32.to(bf)
+    p_lo = (p32 - p_hi.float()).to(bf)
+    out = torch.full((M, 3 * Rk), float("nan"), dtype=bf, device=dev)
+    want = torch.empty_like(out)
+    kw = {}
+    ref32 = x.float() @ p32.t() * 0.5
+    if mult:
+        m = torch.tensor([0.7, -1.3], device=dev)
+        kw = dict(mult=m, rows_per_batch=M // 2)
+        ref32 = ref32 * m.repeat_interleave(M // 2)[:, None]
+    if seg:
+        half = M // 2
+        buf = torch.zeros(2, half + 3, K, dtype=bf, device=dev)
+        buf[:, 1:1 + half] = x.view(2, half, K)
+        ops.lora_down(buf[0, 1:], p_hi, out, scale=0.5, x_seg=(half, (half + 3) * K), M=M, p_lo=p_lo, split=rp, **kw)
+    else:
+        ops.lora_down(x, p_hi, out, scale=0.5, p_lo=p_lo, split=rp, **kw)
+    ref_ops.lora_down(x, p_hi, want, scale=0.5, p_lo=p_lo, split=rp, **kw)
+    torch.cuda.synchronize()
+    c_hi, c_lo, c_hi2 = ref_ops._split_cols(Rk, rp)
+    c_hi, c_lo, c_hi2 = c_hi.to(dev), c_lo.to(dev), c_hi2.to(dev)
+    rec = out[:, c_hi].float() + out[:, c_lo].float()
+    e32 = rel(rec, ref32)                       # the pair carries the fp32 value
+    e_hi = rel(out[:, c_hi], want[:, c_hi])     # layout + rounding agree with the oracle
+    same_hi2 = bool(torch.equal(out[:, c_hi], out[:, c_hi2]))
+    return {"rel_err_fp32": e32, "rel_err_hi": e_hi, "hi_twice": same_hi2, "ok": e32 < 3e-5 and e_hi < 2e-3 and same_hi2}
+
+
+def t_lora_wgrad_split(M, Rk, rp, L, transpose=False, accumulate=False):
+    s32 = R(M, Rk, seed=3).to(dev)
+    g = R(M, L, seed=4).to(bf).to(dev)
+    hi = s32.to(bf)
+    lo = (s32 - hi.float()).to(bf)
+    from oracle import ref_ops
+
+    c_hi, c_lo, c_hi2 = (c.to(dev) for c in ref_ops._split_cols(Rk, rp))
+    s3 = torch.zeros(M, 3 * Rk, dtype=bf, device=dev)
+    s3[:, c_hi], s3[:, c_lo], s3[:, c_hi2] = hi, lo, hi
+    ref = (hi.float() + lo.float()).t() @ g.float()
+    ref32 = s32.t() @ g.float()
+    if transpose:
+        out = torch.full((L, Rk), 2.0 if accumulate else float("nan"), device=dev)
+        ref, ref32 = ref.t(), ref32.t()
+    else:
+        out = torch.full((Rk, L), 2.0 if accumulate else float("nan"), device=dev)
+    if accumulate:
+        ref, ref32 = ref + 2.0, ref32 + 2.0
+    ops.lora_wgrad(s3, g, out, transpose_out=transpose, accumulate=accumulate, split=rp)
+    torch.cuda.synchronize()
+    e, e32 = rel(out, ref), rel(out, ref32)
+    return {"rel_err": e, "rel_err_fp32": e32, "ok": e < 1e-4 and e32 < 1e-4}
+
+
+def t_adapter_branch(M=4608, K=3072, N=3072, r=16):
+    """One wrapped Linear's adapter branch through the real kernels (refresh_shadows -> lora_down -> K-slab GEMM -> lora_down on dY
+    -> both lora_wgrad -> dgrad K-slab) against fp32 adapter arithmetic on the same bf16 activations — the reference's arithmetic
+    (toolkit/network_mixins.py:309-321).  North-star tolerance on LoRA quantities: 1e-3; measured here ~1e-5 (fp32 outputs)."""
+    from ai_toolkit_amd import _capi  # noqa: F401
+
+    x = R(M, K, seed=1).to(bf).to(dev)
+    dy = R(M, N, seed=2).to(bf).to(dev)
+    A = (R(r, K, seed=3) / K ** 0.5).to(dev)
+    Bm = R(N, r, s=0.05, seed=4).to(dev)
+    nA, nB = r * K, N * r
+    arena = torch.cat((A.reshape(-1), Bm.reshape(-1)))
+    off = {"hi": 0, "lo": nA, "t3": 2 * nA, "u3": 5 * nA, "uth": 5 * nA + 3 * nB, "utl": 5 * nA + 4 * nB}
+    shadow = torch.zeros(5 * (nA + nB), dtype=bf, device=dev)
+    entries = [(0, r, K, 1, off["hi"], off["lo"], off["t3"]), (nA, N, r, 2, off["u3"], off["uth"], off["utl"])]
+    ops.refresh_shadows(arena, shadow, ops.make_shadow_table(entries, dev))
+    A_hi, A_lo = shadow[off["hi"]:off["hi"] + nA].view(r, K), shadow[off["lo"]:off["lo"] + nA].view(r, K)
+    At3 = shadow[off["t3"]:off["t3"] + 3 * nA].view(K, 3 * r)
+    B3 = shadow[off["u3"]:off["u3"] + 3 * nB].view(N, 3 * r)
+    Bt_hi, Bt_lo = shadow[off["uth"]:off["uth"] + nB].view(r, N), shadow[off["utl"]:off["utl"] + nB].view(r, N)
+    T3 = torch.empty(M, 3 * r, dtype=bf, device=dev)
+    ops.lora_down(x, A_hi, T3, p_lo=A_lo, split=r)
+    zero_w = torch.zeros(N, K, dtype=bf, device=dev)
+    y = torch.empty(M, N, dtype=bf, device=dev)
+    ops.gemm_nt(x, zero_w, y, a2=T3, b2=B3)
+    dT3 = torch.empty(M, 3 * r, dtype=bf, device=dev)
+    ops.lora_down(dy, Bt_hi, dT3, p_lo=Bt_lo, split=r)
+    dA = torch.zeros(r, K, device=dev)
+    dB = torch.zeros(N, r, device=dev)
+    ops.lora_wgrad(dT3, x, dA, split=r)
+    ops.lora_wgrad(T3, dy, dB, transpose_out=True, split=r)
+    zero_wt = torch.zeros(K, N, dtype=bf, device=dev)
+    dx = torch.empty(M, K, dtype=bf, device=dev)
+    ops.gemm_nt(dy, zero_wt, dx, a2=dT3, b2=At3)
+    torch.cuda.synchronize()
+    xf, dyf = x.float(), dy.float()
+    T_ref = xf @ A.t()
+    y_ref = T_ref @ Bm.t()
+    dT_ref = dyf @ Bm
+    dA_ref, dB_ref, dx_ref = dT_ref.t() @ xf, dyf.t() @ T_ref, dT_ref @ A
+    # round-1 arithmetic for comparison: one bf16 rounding of A, T, B, dT
+    T1 = (xf @ A.to(bf).float().t()).to(bf).float()
+    dT1 = (dyf @ Bm.to(bf).float()).to(bf).float()
+    out = {"dA": rel(dA, dA_ref), "dB": rel(dB, dB_ref), "y_vs_bf16_of_fp32": rel(y, y_ref.to(bf)), "dx_vs_bf16_of_fp32": rel(dx, dx_ref.to(bf)),
+           "dA_single_bf16": rel(dT1.t() @ xf, dA_ref), "dB_single_bf16": rel(dyf.t() @ T1, dB_ref),
+           "y_single_bf16_vs_bf16_of_fp32": rel((T1 @ Bm.to(bf).float().t()).to(bf), y_ref.to(bf))}
+    out["ok"] = out["dA"] < 1e-4 and out["dB"] < 1e-4 and out["y_vs_bf16_of_fp32"] < 1e-3 and out["dx_vs_bf16_of_fp32"] < 1e-3
+    return out
+
+
 def t_lora_wgrad(M, Rk, L, transpose=False, accumulate=False):
     s = R(M, Rk, seed=3).to(bf).to(dev)
     g = R(M, L, seed=4).to(bf).to(dev)
@@ -335,6 +444,10 @@ def main():
         rec("lora_wgrad_r48_acc", lambda: t_lora_wgrad(700, 48, 1024, accumulate=True))
         rec("lora_wgrad_r64", lambda: t_lora_wgrad(300, 64, 520))
         rec("lora_wgrad_smallM", lambda: t_lora_wgrad(2, 16, 18432, transpose=True))
+        rec("lora_down_split_r16", lambda: t_lora_down_split(4608, 3072, 16, 16))
+        rec("lora_down_split_group64", lambda: t_lora_down_split(1000, 3072, 64, 16, mult=True))
+        rec("lora_wgrad_split_r16", lambda: t_lora_wgrad_split(4608, 16, 16, 3072))
+        rec("adapter_branch_split", lambda: t_adapter_branch())
     if want("norm"):
         rec("ln_mod_2x200x3072", lambda: t_ln_mod(2, 200, 3072))
         rec("ln_mod_1x37x1536", lambda: t_ln_mod(1, 37, 1536))

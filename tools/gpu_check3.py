@@ -97,14 +97,23 @@ def t_adamw():
 
 def t_shadows():
     entries = []
-    off = 0
-    shapes = [(16, 3072), (3072, 16), (16, 96), (40, 16)]
-    for r, c in shapes:
-        entries.append((off, 2 * off, 2 * off + r * c, r, c))
-        off += r * c
+    off = soff = 0
+    shapes = [(16, 3072, 1), (3072, 16, 2), (16, 96, 1), (40, 16, 2), (48, 64, 0), (24, 8, 0)]  # (rows, cols, AitkShadowDesc kind)
+    for r, c, kind in shapes:
+        n = r * c
+        if kind == 0:
+            entries.append((off, r, c, 0, soff, soff + n, 0))
+            soff += 2 * n
+        elif kind == 1:
+            entries.append((off, r, c, 1, soff, soff + n, soff + 2 * n))
+            soff += 5 * n
+        else:
+            entries.append((off, r, c, 2, soff, soff + 3 * n, soff + 4 * n))
+            soff += 5 * n
+        off += n
     arena = R(off, seed=15).to(dev)
-    s1 = torch.zeros(2 * off, dtype=bf, device=dev)
-    s2 = torch.zeros(2 * off, dtype=bf, device=dev)
+    s1 = torch.zeros(soff, dtype=bf, device=dev)
+    s2 = torch.zeros(soff, dtype=bf, device=dev)
     ops.refresh_shadows(arena, s1, ops.make_shadow_table(entries, dev))
     ref_ops.refresh_shadows(arena, s2, ref_ops.make_shadow_table(entries, dev))
     torch.cuda.synchronize()
