@@ -336,14 +336,11 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, in
       rs[i] = make_uint4(0, 0, 0, 0);
       rl[i] = make_uint4(0, 0, 0, 0);
       if (q < 64 * chunks_per_row && ms + row < mend) {
-        if (!split) {
-          rs[i] = *reinterpret_cast<const uint4*>(p.S + (long)(ms + row) * p.lds + ch * 8);
-        } else {  // rank r of the [hi | lo | hi] slab layout: column (r / rp) * 3 rp + r % rp, lo one rp further (rp % 8 == 0)
-          const int r = ch * 8, blk = r / p.split_rp;
-          const bf16_t* src = p.S + (long)(ms + row) * p.lds + (long)blk * 3 * p.split_rp + (r - blk * p.split_rp);
-          rs[i] = *reinterpret_cast<const uint4*>(src);
-          rl[i] = *reinterpret_cast<const uint4*>(src + p.split_rp);
-        }
+        // split: rank r of the [hi | lo | hi] slab layout sits at column (r / rp) * 3 rp + r % rp, lo one rp further (rp % 8 == 0)
+        const int r = ch * 8, blk = split ? r / p.split_rp : 0;
+        const bf16_t* src = p.S + (long)(ms + row) * p.lds + r + 2 * blk * p.split_rp;
+        rs[i] = *reinterpret_cast<const uint4*>(src);
+        if (split) rl[i] = *reinterpret_cast<const uint4*>(src + p.split_rp);
       }
     }
   };

@@ -74,7 +74,7 @@ def _rel(a, b):
 def test_native_library_loaded_and_fails_loudly_without_it(monkeypatch):
     from ai_toolkit_amd import _capi
 
-    assert _capi.lib().aitk_abi_version() == 1
+    assert _capi.lib().aitk_abi_version() == 2
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libaitk.so")
     with pytest.raises(RuntimeError):
@@ -142,8 +142,12 @@ def test_three_training_steps_track_oracle():
         num += ((d_ours - d_ref) ** 2).sum().item()
         den += (d_ref ** 2).sum().item()
     rel = math.sqrt(num / den)
-    print("LoRA delta rel err after 3 AdamW steps:", rel)
-    assert rel < 0.15, rel  # sign flips of near-zero gradient entries dominate; see DESIGN.md "parity"
+    print("LoRA parameter-delta rel err after 3 AdamW steps (vs fp32 oracle):", rel)
+    # The bound on LoRA deltas is stated and asserted in tests/test_gpu_parity_r2.py::test_three_adamw_steps_lora_delta_four_way
+    # (effective dW = B'A' - BA against the fp32 oracle, the reference's bf16 arithmetic and the rounding-matched oracle); here
+    # only the sanity envelope of the raw parameter deltas: AdamW's first steps are ~lr*sign(g), so entries whose gradient is
+    # below the bf16 noise flip sign in any bf16 implementation (the reference's own arithmetic measures the same).
+    assert rel < 0.08, rel
     assert net.arena_ema is not None and torch.isfinite(net.arena_ema).all()
 
 
@@ -210,3 +214,42 @@ def test_batch_list_accumulation_and_preservation_pass_on_device():
     err = ((ours - g32).norm() / g32.norm()).item()
     print(f"preservation: loss {lp:.6f} fp32 {l_ref:.6f} (plain {l1:.6f}); adapter-gradient rel err {err:.3e}")
     assert err < 2e-2, err
+
+
+def test_lora_merge_in_equals_active_adapter_and_merge_out_restores():
+    """ToolkitModuleMixin.merge_in / merge_out (toolkit/network_mixins.py:370-462, 894-906) on the device: the rank-r accumulate GEMM
+    on the weight and on its transposed copy.  Merged-weight forward (adapters skipped, 285-287) == adapter-active forward up to the
+    bf16 rounding of the merged weights; merge_out returns every weight to within one bf16 rounding of the original."""
+    from ai_toolkit_amd import ops
+
+    ref, ref_net, nat, net = _build()
+    lat, emb, pooled, noise, ts = _batch(2)
+    from ai_toolkit_amd.trainer import make_ids
+    from oracle import flux_ref
+
+    packed = flux_ref.pack_latents(lat)
+    img_ids, txt_ids = make_ids(lat.shape[2], lat.shape[3], emb.shape[1], "cuda")
+    guid = torch.ones(2, device="cuda")
+    args = (packed, emb, pooled, ts / 1000, img_ids, txt_ids, guid)
+    base = nat.forward_native(*args, save_for_backward=False).clone()
+    with net:
+        want = nat.forward_native(*args, save_for_backward=False).clone()
+    lin = nat.transformer_blocks[0].attn.to_q
+    w0, wt0 = lin.weight.detach().clone(), lin.weight_t.clone()
+    net.merge_in(1.0, ops=ops)
+    assert net.is_merged_in
+    m = lin.lora
+    exp = (w0.float() + m.scale * (m.lora_up.weight.detach() @ m.lora_down.weight.detach())).to(torch.bfloat16)
+    assert _rel(lin.weight, exp) < 1e-3 and (lin.weight.float() - exp.float()).abs().max() <= 2 * 2.0 ** -8 * exp.float().abs().max()
+    assert torch.equal(lin.weight_t, lin.weight.t()), "transposed copy (dgrad operand) must receive the same merge"
+    with net:  # merged: the adapter branch is skipped
+        got = nat.forward_native(*args, save_for_backward=False).clone()
+    e_merge, e_base = _rel(got, want), _rel(base, want)
+    print(f"merge_in: merged-vs-active rel err {e_merge:.3e} (base-vs-active {e_base:.3e})")
+    assert e_merge < 1e-2 and e_merge < 0.2 * e_base, (e_merge, e_base)
+    net.merge_out(1.0, ops=ops)
+    assert not net.is_merged_in
+    ulp = 2.0 ** -7 * w0.float().abs().clamp_min(1e-3)
+    assert ((lin.weight.float() - w0.float()).abs() <= ulp).all() and ((lin.weight_t.float() - wt0.float()).abs() <= ulp.t()).all()
+    again = nat.forward_native(*args, save_for_backward=False)
+    assert _rel(again, base) < 5e-3
