@@ -110,7 +110,7 @@ class QkvPostArgs(C.Structure):
 
 class EwArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("a", vp), ("lda", i64), ("y", vp), ("ldy", i64),
-                ("rows", i32), ("C", i32), ("op", i32), ("alpha", C.c_float)]
+                ("rows", i32), ("C", i32), ("op", i32), ("alpha", C.c_float), ("a_rows_per_batch", i32), ("_pad", i32)]
 
 
 class AttnArgs(C.Structure):
@@ -154,7 +154,18 @@ class AdamWArgs(C.Structure):
 
 class GroupNormArgs(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("y", vp), ("ldy", i64), ("gamma", vp), ("beta", vp), ("partial", vp), ("stats", vp),
-                ("eps", C.c_float), ("silu", i32), ("B", i32), ("HW", i32), ("C", i32), ("G", i32)]
+                ("eps", C.c_float), ("silu", i32), ("B", i32), ("HW", i32), ("C", i32), ("G", i32), ("stats_out", vp)]
+
+
+class GroupNormBwdArgs(C.Structure):
+    _fields_ = [("dy", vp), ("ld_dy", i64), ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("stats", vp),
+                ("dres", vp), ("ld_dres", i64), ("dx", vp), ("ld_dx", i64), ("partial", vp), ("red", vp),
+                ("silu", i32), ("B", i32), ("HW", i32), ("C", i32), ("G", i32), ("_pad", i32)]
+
+
+class DdpmNoiseArgs(C.Structure):
+    _fields_ = [("latents", vp), ("noise", vp), ("a", vp), ("s", vp), ("noisy", vp), ("target", vp),
+                ("B", i32), ("C", i32), ("HW", i32), ("Cp", i32), ("mode", i32), ("_pad", i32)]
 
 
 class RmsFullArgs(C.Structure):
@@ -188,7 +199,7 @@ EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AU
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
             12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs, 17: DoraColscaleArgs, 18: DoraBwdArgs,
-            19: KronApplyArgs}
+            19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs}
 
 
 def lib():
@@ -227,6 +238,12 @@ def lib():
     L.aitk_latent_sample.argtypes = [vp, i64, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]
     L.aitk_timestep_embed.argtypes = [vp, vp, i32, i32, C.c_float, vp]
     L.aitk_copy2d.argtypes = [vp, i64, vp, i64, i64, i64, vp]
+    L.aitk_groupnorm_bwd_workspace_bytes.restype = C.c_int64
+    L.aitk_groupnorm_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.aitk_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, vp]
+    L.aitk_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
+    L.aitk_resample2x.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.aitk_copy_heads.argtypes = [vp, i64, vp, i64, i64, i32, i32, i32, vp]
     _lib = L
     return L
 

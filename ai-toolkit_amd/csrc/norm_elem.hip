@@ -514,7 +514,8 @@ extern "C" int aitk_rms_full_bwd(const AitkRmsFullArgs* a, aitk_stream_t stream)
 // ---------------------------------------------------------------- small element-wise ops on [rows, C] bf16
 // op 0: y = silu(x)                      (AdaLayerNorm*: linear(silu(temb)))
 // op 1: y = x                            (copy / cast helper)
-// op 2: y = a + x                        (sum of embedder outputs)
+// op 2: y = a + x                        (sum of embedder outputs; a_rows_per_batch > 0: a row = m / a_rows_per_batch — the
+//                                         ResnetBlock2D time-embedding add h + temb_proj[b] broadcast over the pixels of a sample)
 // op 3: y = alpha * x                    (scaled lora_up for merge_in / merge_out)
 __global__ void ew_kernel(AitkEwArgs p) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -524,7 +525,7 @@ __global__ void ew_kernel(AitkEwArgs p) {
   const int c = (int)(i - r * p.C);
   float x[8], o[8], a8[8];
   unpack8(*reinterpret_cast<const uint4*>(p.x + r * p.ldx + c), x);
-  if (p.op == 2) unpack8(*reinterpret_cast<const uint4*>(p.a + r * p.lda + c), a8);
+  if (p.op == 2) unpack8(*reinterpret_cast<const uint4*>(p.a + (p.a_rows_per_batch > 0 ? r / p.a_rows_per_batch : r) * p.lda + c), a8);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     if (p.op == 0) o[e] = x[e] / (1.0f + expf(-x[e]));

@@ -87,6 +87,8 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 17: return (int)sizeof(AitkDoraColscaleArgs);
     case 18: return (int)sizeof(AitkDoraBwdArgs);
     case 19: return (int)sizeof(AitkKronApplyArgs);
+    case 20: return (int)sizeof(AitkGroupNormBwdArgs);
+    case 21: return (int)sizeof(AitkDdpmNoiseArgs);
     default: return -1;
   }
 }

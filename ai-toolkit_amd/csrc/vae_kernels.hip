@@ -60,6 +60,10 @@ __global__ void gn_finish_kernel(AitkGroupNormArgs p, int nchunk) {
   const double var = fmax(q / n - mean * mean, 0.0);
   p.stats[2 * idx] = (float)mean;
   p.stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  if (p.stats_out) {  // kept by the caller for aitk_groupnorm_bwd
+    p.stats_out[2 * idx] = p.stats[2 * idx];
+    p.stats_out[2 * idx + 1] = p.stats[2 * idx + 1];
+  }
 }
 // y = (x - mean) * rstd * gamma + beta, optionally SiLU
 __global__ __launch_bounds__(256) void gn_apply_kernel(AitkGroupNormArgs p) {

@@ -244,60 +244,72 @@ class LoKrModule(LoRAModule):
 
 
 class FusedLoRANetwork(nn.Module):
-    """Drop-in for LoRASpecialNetwork on transformer (PEFT-format) models."""
+    """Drop-in for LoRASpecialNetwork: transformer models in PEFT format (FLUX, Wan: `transformer.<path>.lora_A/B.weight`, alpha
+    forced to the rank) and UNet models (SD1.5 / SDXL) in kohya format (`lora_unet_<path_with_underscores>.lora_down/up.weight` +
+    `.alpha`; Linear and 1x1-Conv2d children of every Transformer2DModel, toolkit/kohya_lora.py:750, lora_special.py:463-502)."""
 
     def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
                  transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
                  is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1,
-                 base_model=None):
+                 base_model=None, conv_lora_dim=None):
         super().__init__()
         # the reference holds a weak reference to the model plug-in for the save / load key-conversion hooks (lora_special.py:373-375)
         self.base_model_ref = weakref.ref(base_model) if base_model is not None else None
-        assert peft_format and is_transformer, "kohya-format UNet naming is a later row (SURVEY.md §8f.3)"
         assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
+        if conv_lora_dim:
+            raise NotImplementedError("conv-LoRA on 3x3 convolutions (network.conv) is not on the fused path; 1x1 convolutions are")
         # toolkit/lora_special.py:403-408
         module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]
         module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
         self.lora_dim = lora_dim
         self.network_type = network_type
-        self.peft_format = True
-        self.is_transformer = True
+        # transformer models are always PEFT format (lora_special.py:418-422); UNet models keep the kohya format
+        self.peft_format = bool(peft_format or is_transformer)
+        self.is_transformer = bool(is_transformer)
+        if not self.peft_format and network_type.lower() != "lora":
+            raise NotImplementedError("kohya-format (UNet) networks: plain LoRA only on the fused path")
         self.is_lorm = False
         self.is_active = False
         self.is_merged_in = False
         self.base_model_version = base_model_version
-        # PEFT format: alpha forced to rank => scale 1 (toolkit/lora_special.py:428-433)
-        self.alpha = lora_dim
+        # PEFT format: alpha forced to rank => scale 1 (toolkit/lora_special.py:428-433); kohya format: alpha as configured
+        self.alpha = lora_dim if self.peft_format else alpha
         self._multiplier = 1.0
         self.torch_multiplier = None
         self.unet_loras: List[LoRAModule] = []
         self.text_encoder_loras: List[LoRAModule] = []
         ignore_if_contains = ignore_if_contains or []
-        prefix = "transformer"
+        if self.is_transformer:
+            prefix = "transformer" if self.peft_format else "lora_transformer"
+        else:
+            prefix = "unet" if self.peft_format else "lora_unet"  # lora_special.py:286-288, 463-469
         names = set()
         for name, module in unet.named_modules():
             if module.__class__.__name__ not in target_lin_modules:
                 continue
             for child_name, child in module.named_modules():
-                if child.__class__.__name__ not in LINEAR_MODULES:
+                is_linear = child.__class__.__name__ in LINEAR_MODULES
+                is_conv1x1 = bool(getattr(child, "is_conv1x1", False))  # Conv2d with kernel (1, 1): lora_special.py:487-488, 585-587
+                if not (is_linear or is_conv1x1):
                     continue
                 clean = ".".join([x for x in (prefix, name, child_name) if x])
-                lora_name = clean.replace(".", "$$")
+                lora_name = clean.replace(".", "$$") if self.peft_format else clean.replace(".", "_")
                 if any(w in clean for w in ignore_if_contains):
                     continue
-                if transformer_only:
+                if transformer_only and self.is_transformer:
                     blocks = transformer_block_names
                     if blocks is not None:
                         if not any(b in clean for b in blocks):
                             continue
                     elif "transformer_blocks" not in lora_name:
                         continue
-                if only_if_contains is not None and not any(w in clean for w in only_if_contains):
+                if only_if_contains is not None and not any(w in clean for w in only_if_contains) and not any(w in lora_name for w in only_if_contains):
                     continue
                 if lora_name in names:
                     continue
                 names.add(lora_name)
                 lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self, **module_kwargs)
+                lora.is_conv1x1 = is_conv1x1  # saved / loaded as Conv2d weights [r, in, 1, 1] / [out, r, 1, 1] like the reference's
                 self.unet_loras.append(lora)
         for lora in self.unet_loras:
             self.add_module(lora.lora_name, lora)
@@ -602,6 +614,24 @@ class FusedLoRANetwork(nn.Module):
     def get_state_dict(self, extra_state_dict=None, dtype=torch.float16, use_ema=False):
         src = self.arena_ema if (use_ema and self.arena_ema is not None) else None
         sd = OrderedDict()
+        if not self.peft_format:
+            # kohya format = the network's own state_dict (toolkit/network_mixins.py:590-598): per module `.alpha` (buffer), then
+            # `.lora_down.weight`, `.lora_up.weight`; 1x1-conv adapters keep their Conv2d shapes
+            for m in self.get_all_modules():
+                sd[f"{m.lora_name}.alpha"] = m.alpha.detach().clone().to("cpu").to(dtype)
+                for key, lin, which in (("lora_down", m.lora_down, "down"), ("lora_up", m.lora_up, "up")):
+                    w = lin.weight.detach() if src is None else self.arena_view(src, m, which)
+                    w = w.clone().contiguous()
+                    if getattr(m, "is_conv1x1", False):
+                        w = w[:, :, None, None]
+                    sd[f"{m.lora_name}.{key}.weight"] = w.to("cpu").to(dtype)
+            if extra_state_dict is not None:
+                for k, v in extra_state_dict.items():
+                    sd[k] = v.detach().clone().to("cpu").to(dtype)
+            base_model = self._base_model()
+            if base_model is not None:
+                sd = base_model.convert_lora_weights_before_save(sd)
+            return sd
         for m in self.get_all_modules():
             base = m.lora_name.replace("$$", ".")
             if getattr(m, "is_lokr", False):  # <name>.lokr_w1 / .lokr_w2 / .alpha — LoKr keeps alpha (network_mixins.py:613-616)
@@ -664,11 +694,15 @@ class FusedLoRANetwork(nn.Module):
         extra = OrderedDict()
         by_name = {m.lora_name.replace("$$", "."): m for m in self.get_all_modules()}
         n_hit = 0
+        suffixes = ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up"), (".lokr_w1", "lora_up"), (".lokr_w2", "lora_down"))
+        if not self.peft_format:  # kohya keys
+            suffixes = ((".lora_down.weight", "lora_down"), (".lora_up.weight", "lora_up"))
         with torch.no_grad():
             for k, v in sd.items():
                 hit = False
-                for which, attr in ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up"), (".lokr_w1", "lora_up"),
-                                    (".lokr_w2", "lora_down")):
+                if v.dim() == 4 and v.shape[2:] == (1, 1):
+                    v = v[:, :, 0, 0]  # 1x1-conv adapter weights
+                for which, attr in suffixes:
                     if k.endswith(which) and k[: -len(which)] in by_name:
                         if which.startswith(".lokr") != bool(getattr(by_name[k[: -len(which)]], "is_lokr", False)):
                             continue
@@ -689,7 +723,9 @@ class FusedLoRANetwork(nn.Module):
                     hit = True
                     n_hit += 1
                 if k.endswith(".alpha") and k[: -len(".alpha")] in by_name:
-                    hit = True  # constant buffer (LoKr files carry it)
+                    hit = True  # constant buffer (LoKr / kohya files carry it; the scale was fixed at construction like the reference's)
+                    if not self.peft_format:
+                        by_name[k[: -len(".alpha")]].alpha.copy_(v.to(by_name[k[: -len(".alpha")]].alpha))
                 if not hit:
                     extra[k] = v
         if n_hit == 0 and len(sd) > 0:

@@ -250,10 +250,12 @@ def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
     _capi.check(_capi.lib().aitk_qkv_post_bwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_bwd")
 
 
-def ew(op, x, y, a=None, alpha=1.0):
-    """op 0: y = silu(x); 1: y = x; 2: y = a + x; 3: y = alpha * x   ([rows, C] bf16 views)."""
+def ew(op, x, y, a=None, alpha=1.0, a_rows_per_batch=0):
+    """op 0: y = silu(x); 1: y = x; 2: y = a + x (a_rows_per_batch > 0: row m // a_rows_per_batch of `a`); 3: y = alpha * x
+    ([rows, C] bf16 views)."""
     g = _capi.EwArgs()
     g.alpha = float(alpha)
+    g.a_rows_per_batch = int(a_rows_per_batch)
     g.x, g.ldx, g.y, g.ldy = _ptr(x), _row_major(x, "x"), _ptr(y), _row_major(y, "y")
     if a is not None:
         g.a, g.lda = _ptr(a), _row_major(a, "a")
@@ -422,9 +424,12 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     return out
 
 
-def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False):
-    """out = GroupNorm_G(x [B*HW, C]) * gamma + beta (+ SiLU)."""
+def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False, stats_out=None):
+    """out = GroupNorm_G(x [B*HW, C]) * gamma + beta (+ SiLU); stats_out fp32 [B, G, 2] (mean, rstd) for groupnorm_bwd."""
     a = _capi.GroupNormArgs()
+    if stats_out is not None:
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.numel() == 2 * B * G
+        a.stats_out = _ptr(stats_out)
     Cc = x.shape[1]
     a.x, a.ldx, a.y, a.ldy = _ptr(x), _row_major(x, "x"), _ptr(out), _row_major(out, "out")
     a.gamma, a.beta = _ptr(gamma), _ptr(beta)
@@ -548,3 +553,85 @@ def dequant_fp8(q, scale, mode, out):
     _capi.check(_capi.lib().aitk_dequant_fp8(_ptr(q), q.stride(0), _ptr(scale), mode, _ptr(out), out.stride(0), q.shape[0], q.shape[1],
                                              _capi.stream_ptr()), "aitk_dequant_fp8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------- UNet (SD1.5 / SDXL)
+def groupnorm_bwd(dy, x, gamma, beta, stats, dx, *, B, HW, G=32, silu=False, dres=None):
+    """dx = backward of act(GroupNorm_G(x) * gamma + beta) (+ dres); stats = the forward's stats_out."""
+    a = _capi.GroupNormBwdArgs()
+    Cc = x.shape[1]
+    a.dy, a.ld_dy, a.x, a.ldx, a.dx, a.ld_dx = _ptr(dy), _row_major(dy, "dy"), _ptr(x), _row_major(x, "x"), _ptr(dx), _row_major(dx, "dx")
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == 2 * B * G
+    a.gamma, a.beta, a.stats = _ptr(gamma), _ptr(beta), _ptr(stats)
+    if dres is not None:
+        a.dres, a.ld_dres = _ptr(dres), _row_major(dres, "dres")
+    ws = workspace(_capi.lib().aitk_groupnorm_bwd_workspace_bytes(B, HW, Cc, G), x.device, "groupnorm_bwd")
+    a.partial = _ptr(ws)
+    a.silu, a.B, a.HW, a.C, a.G = int(silu), B, HW, Cc, G
+    _capi.check(_capi.lib().aitk_groupnorm_bwd(C.byref(a), _capi.stream_ptr()), "aitk_groupnorm_bwd")
+    return dx
+
+
+def geglu_fwd(hg, out):
+    """out[M, F] = hg[:, :F] * gelu_erf(hg[:, F:])  (diffusers GEGLU)."""
+    M, F2 = hg.shape
+    assert out.shape == (M, F2 // 2)
+    _capi.check(_capi.lib().aitk_geglu_fwd(_ptr(hg), _row_major(hg, "hg"), _ptr(out), _row_major(out, "out"), M, F2 // 2, _capi.stream_ptr()),
+                "aitk_geglu_fwd")
+    return out
+
+
+def geglu_bwd(dy, hg, dhg):
+    M, F2 = hg.shape
+    assert dy.shape == (M, F2 // 2) and dhg.shape == hg.shape
+    _capi.check(_capi.lib().aitk_geglu_bwd(_ptr(dy), _row_major(dy, "dy"), _ptr(hg), _row_major(hg, "hg"), _ptr(dhg), _row_major(dhg, "dhg"),
+                                           M, F2 // 2, _capi.stream_ptr()), "aitk_geglu_bwd")
+    return dhg
+
+
+def resample2x(src, dst, *, B, H, W, mode):
+    """contiguous NHWC [B*H*W, C] -> mode 0 nearest up [B*2H*2W, C]; 1: 2x2 sum [B*(H/2)*(W/2), C]; 2: zero insertion [B*2H*2W, C]."""
+    Cc = src.shape[1]
+    assert src.is_contiguous() and dst.is_contiguous() and src.dtype == BF16 and dst.dtype == BF16 and src.shape[0] == B * H * W
+    assert dst.shape == ((B * (H // 2) * (W // 2), Cc) if mode == 1 else (B * 4 * H * W, Cc))
+    _capi.check(_capi.lib().aitk_resample2x(_ptr(src), _ptr(dst), B, H, W, Cc, mode, _capi.stream_ptr()), "aitk_resample2x")
+    return dst
+
+
+def copy_heads(src, dst, *, H, d_src, d_dst):
+    """dst[m, h*d_dst + j] = src[m, h*d_src + j] (j < d_src) else 0, j < d_dst."""
+    M = src.shape[0]
+    assert dst.shape[0] == M and src.shape[1] >= H * d_src and dst.shape[1] >= H * d_dst
+    _capi.check(_capi.lib().aitk_copy_heads(_ptr(src), _row_major(src, "src"), _ptr(dst), _row_major(dst, "dst"), M, H, d_src, d_dst,
+                                            _capi.stream_ptr()), "aitk_copy_heads")
+    return dst
+
+
+def ddpm_noise_nhwc(latents, noise, a, s, noisy, target, *, v_prediction=False):
+    """latents / noise NCHW [B,C,h,w] bf16; a, s fp32 [B]; noisy [B*h*w, Cp] (zero-padded channels), target [B*h*w, C]."""
+    g = _capi.DdpmNoiseArgs()
+    B, Cc, h, w = latents.shape
+    assert latents.is_contiguous() and noise.is_contiguous() and noisy.is_contiguous() and target.is_contiguous()
+    assert latents.dtype == BF16 and noise.dtype == BF16 and a.dtype == torch.float32 and s.dtype == torch.float32
+    assert noisy.shape[0] == B * h * w and target.shape == (B * h * w, Cc)
+    g.latents, g.noise, g.a, g.s, g.noisy, g.target = _ptr(latents), _ptr(noise), _ptr(a), _ptr(s), _ptr(noisy), _ptr(target)
+    g.B, g.C, g.HW, g.Cp, g.mode = B, Cc, h * w, noisy.shape[1], int(v_prediction)
+    _capi.check(_capi.lib().aitk_ddpm_noise_nhwc(C.byref(g), _capi.stream_ptr()), "aitk_ddpm_noise_nhwc")
+
+
+def attn_small_fwd(q, k, v, o, lse, *, B, H, S, D, scale, Skv=0):
+    """generic attention (head_dim D > 128): q, o [B*S, >= H*D]; k, v [B*Skv, >= H*D]; lse [B,H,S] natural log."""
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
+    a.D = D
+    _capi.check(_capi.lib().aitk_attn_small_fwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_small_fwd")
+    return o
+
+
+def attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, D, scale, Skv=0):
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
+    a.D = D
+    a.dO, a.lddo = _ptr(do), _row_major(do, "do")
+    a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
+    a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")
+    a.delta = _ptr(workspace(B * H * S * 4, q.device, "attn_delta"))
+    _capi.check(_capi.lib().aitk_attn_small_bwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_small_bwd")

@@ -222,6 +222,57 @@ class WanLoRATrainStep(_LoRATrainStepBase):
             return self._loss_backward(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight, loss_mask, final=final)
 
 
+class UNetLoRATrainStep(_LoRATrainStepBase):
+    """SD1.5 / SDXL LoRA step (BASELINE configs 1-2).  Per step the reference runs: DDPM timesteps + add_noise
+    (jobs/process/BaseSDTrainProcess.py:1301-1323, toolkit/stable_diffusion_model.py:1854-1876), the UNet on (noisy latents, timestep,
+    CLIP states[, pooled text + time_ids for SDXL: 1824-1852, 1985-1990]) (2049-2055 / 2260-2265), target = eps (SDTrainer.py:650) or the
+    velocity (623-625), MSE with optional min-SNR weighting (1005-1011), backward, clip, AdamW."""
+
+    def __init__(self, model, network, ops, *, min_snr_gamma=None, snr_gamma=None, **kw):
+        from .ddpm import DDPMTrainSchedule
+
+        sched = kw.pop("schedule", None) or DDPMTrainSchedule()
+        super().__init__(model, network, ops, schedule=sched, **kw)
+        self.min_snr_gamma, self.snr_gamma = min_snr_gamma, snr_gamma
+        self.is_xl = model.config["addition_embed_type"] == "text_time"
+
+    def step(self, latents, prompt_embeds, pooled_embeds=None, **kw):
+        """latents [B,4,h,w] (scaled VAE latents), prompt_embeds [B,77,768|2048], pooled_embeds [B,1280] (SDXL)."""
+        return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, **kw)])
+
+    def _single(self, latents, prompt_embeds, pooled_embeds=None, *, noise=None, timesteps=None, loss_weight=None, time_ids=None,
+                final=True):
+        ops, model, net = self.ops, self.model, self.network
+        dt = model.dt
+        B, Cc, Hh, W = latents.shape
+        dev = latents.device
+        latents = latents.to(dt).contiguous()
+        if timesteps is None:
+            timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
+        timesteps = timesteps.to(dev).long()
+        if noise is None:
+            noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
+        noise = noise.to(dt).contiguous()
+        a, s = self.schedule.noise_coefficients(timesteps, dt)
+        noisy = torch.empty(B * Hh * W, 8, dtype=dt, device=dev)
+        target = torch.empty(B * Hh * W, Cc, dtype=dt, device=dev)
+        ops.ddpm_noise_nhwc(latents, noise, a, s, noisy, target, v_prediction=self.schedule.prediction_type == "v_prediction")
+        added = None
+        if self.is_xl:
+            if time_ids is None:  # StableDiffusion.get_time_ids_from_latents: (H, W, 0, 0, H, W) in pixels
+                time_ids = torch.tensor([[Hh * 8, W * 8, 0, 0, Hh * 8, W * 8]], dtype=dt, device=dev).repeat(B, 1)
+            added = dict(text_embeds=pooled_embeds, time_ids=time_ids)
+        w = loss_weight
+        gamma = self.min_snr_gamma if (self.min_snr_gamma is not None and self.min_snr_gamma > 1e-6) else None
+        fixed = self.snr_gamma is not None and self.snr_gamma > 1e-6
+        if fixed or gamma is not None:  # SDTrainer.py:1003-1011: snr_gamma (fixed) takes precedence over min_snr_gamma
+            sw = self.schedule.snr_weights(timesteps, self.snr_gamma if fixed else gamma, fixed=fixed)
+            w = sw if w is None else w * sw
+        with net:
+            pred = model.forward_native(noisy, timesteps.float(), prompt_embeds, added, B=B, H=Hh, W=W)
+            return self._loss_backward(pred.view(B, Hh * W, Cc), target.view(B, Hh * W, Cc), w, None, final=final)
+
+
 def make_ids(Hh, W, n_txt, device):
     """img_ids (0,row,col) for the 2x2-packed grid, txt_ids zeros (toolkit/stable_diffusion_model.py:2165-2170)."""
     h2, w2 = Hh // 2, W // 2

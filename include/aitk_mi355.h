@@ -192,6 +192,7 @@ typedef struct AitkEwArgs {
   const aitk_bf16* a; int64_t lda;
   aitk_bf16* y; int64_t ldy;
   int32_t rows, C, op; float alpha;
+  int32_t a_rows_per_batch; int32_t _pad; /* op 2: > 0 broadcasts row (m / a_rows_per_batch) of `a` (ResnetBlock2D time-embedding add) */
 } AitkEwArgs;
 int aitk_ew(const AitkEwArgs* args, aitk_stream_t stream);
 /* out[b] = [cos(t*tscale*f_i) | sin(...)], f_i = 10000^(-i/(dim/2))   (diffusers Timesteps, flip_sin_to_cos) */
@@ -292,6 +293,7 @@ typedef struct AitkGroupNormArgs {
   float* partial; float* stats; /* stats: set by the library (inside partial) */
   float eps; int32_t silu;
   int32_t B, HW, C, G;
+  float* stats_out; /* may be NULL: fp32 [B][G][2] (mean, rstd) kept by the caller for aitk_groupnorm_bwd */
 } AitkGroupNormArgs;
 int64_t aitk_groupnorm_workspace_bytes(int32_t B, int32_t HW, int32_t C, int32_t G);
 int aitk_groupnorm(const AitkGroupNormArgs* args, aitk_stream_t stream);
@@ -366,6 +368,51 @@ typedef struct AitkDoraBwdArgs {
   int32_t M, N;
 } AitkDoraBwdArgs;
 int aitk_dora_bwd(const AitkDoraBwdArgs* args, aitk_stream_t stream);
+
+/* ---- UNet2DConditionModel side kernels (SD1.5 / SDXL; NHWC bf16 activations [B*H*W, C]).  Replace the diffusers UNet body reached
+ * from toolkit/stable_diffusion_model.py:2049-2055 (SDXL) / 2260-2265 (SD1.5) and its autograd backward.
+ * GroupNorm(+SiLU) backward: dx = d/dx act(GroupNorm(x) * gamma + beta) . dy (+ dres); gamma / beta frozen.  stats = the forward's
+ * stats_out; partial = aitk_groupnorm_bwd_workspace_bytes scratch. */
+typedef struct AitkGroupNormBwdArgs {
+  const aitk_bf16* dy; int64_t ld_dy;
+  const aitk_bf16* x; int64_t ldx;
+  const aitk_bf16* gamma; const aitk_bf16* beta;
+  const float* stats;
+  const aitk_bf16* dres; int64_t ld_dres; /* may be NULL */
+  aitk_bf16* dx; int64_t ld_dx;
+  float* partial; float* red; /* red: set by the library (inside partial) */
+  int32_t silu; int32_t B, HW, C, G, _pad;
+} AitkGroupNormBwdArgs;
+int64_t aitk_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C, int32_t G);
+int aitk_groupnorm_bwd(const AitkGroupNormBwdArgs* args, aitk_stream_t stream);
+/* diffusers GEGLU (FeedForward of BasicTransformerBlock): hg [M, 2F] = [hidden | gate]; out = hidden * gelu_erf(gate); backward writes
+ * d[hidden | gate] */
+int aitk_geglu_fwd(const aitk_bf16* hg, int64_t ld_hg, aitk_bf16* out, int64_t ld_out, int64_t M, int32_t F, aitk_stream_t stream);
+int aitk_geglu_bwd(const aitk_bf16* dy, int64_t ld_dy, const aitk_bf16* hg, int64_t ld_hg, aitk_bf16* dhg, int64_t ld_dhg, int64_t M,
+                   int32_t F, aitk_stream_t stream);
+/* 2x resampling of a contiguous NHWC tensor, (H, W) = SOURCE size.  mode 0: nearest up (Upsample2D forward) -> [B,2H,2W,C];
+ * mode 1: 2x2 sum (its backward) -> [B,H/2,W/2,C]; mode 2: zero insertion -> [B,2H,2W,C] (data gradient of a stride-2 conv as a stride-1
+ * conv with the rotated filter). */
+int aitk_resample2x(const aitk_bf16* src, aitk_bf16* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, aitk_stream_t stream);
+/* per-head column copy with zero fill: dst[m][h*d_dst + j] = j < d_src ? src[m][h*d_src + j] : 0 (j < d_dst) — pads head_dim 40 / 64 / 80 to
+ * the flash kernels' 128 (exact: zero columns change neither q.k nor softmax) and drops the padding again. */
+int aitk_copy_heads(const aitk_bf16* src, int64_t ld_src, aitk_bf16* dst, int64_t ld_dst, int64_t M, int32_t H, int32_t d_src, int32_t d_dst,
+                    aitk_stream_t stream);
+/* generic attention for head_dim > 128 (SD1.5: 160 at its two coarsest levels, <= 256 tokens at 512^2) — same AitkAttnArgs, D = head_dim (any
+ * multiple of 8 up to 256), heads at column h*D, S and Skv <= 8192; LSE = natural-log log-sum-exp of the scaled scores.  Plain fp32
+ * formulation, deterministic; aitk_attn_fwd / aitk_attn_bwd (head_dim 128, MFMA) stay the path for everything that fits them. */
+int aitk_attn_small_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
+int aitk_attn_small_bwd(const AitkAttnArgs* args, aitk_stream_t stream);
+/* DDPMScheduler.add_noise (toolkit/stable_diffusion_model.py:1854-1876) into the NHWC conv_in operand + the loss target:
+ * noisy [B*HW, Cp] (channels >= C zero), target [B*HW, C] = eps (mode 0, SDTrainer.py:650) or velocity (mode 1, 623-625);
+ * a[b] = sqrt(alphas_cumprod[t_b]), s[b] = sqrt(1 - alphas_cumprod[t_b]) as fp32 values already rounded to the latent dtype. */
+typedef struct AitkDdpmNoiseArgs {
+  const aitk_bf16* latents; const aitk_bf16* noise; /* NCHW [B, C, HW] */
+  const float* a; const float* s;
+  aitk_bf16* noisy; aitk_bf16* target;
+  int32_t B, C, HW, Cp, mode, _pad;
+} AitkDdpmNoiseArgs;
+int aitk_ddpm_noise_nhwc(const AitkDdpmNoiseArgs* args, aitk_stream_t stream);
 
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);

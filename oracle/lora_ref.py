@@ -18,8 +18,12 @@ class RefLoRAModule(nn.Module):
         super().__init__()
         self.lora_name = lora_name
         self.lora_dim = lora_dim
-        self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
-        self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
+        if isinstance(org_module, nn.Conv2d):  # toolkit/lora_special.py:95-104 (UNet: 1x1 proj_in / proj_out of SD1.5)
+            self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, org_module.kernel_size, org_module.stride, org_module.padding, bias=False)
+            self.lora_up = nn.Conv2d(lora_dim, org_module.out_channels, (1, 1), (1, 1), bias=False)
+        else:
+            self.lora_down = nn.Linear(org_module.in_features, lora_dim, bias=False)
+            self.lora_up = nn.Linear(lora_dim, org_module.out_features, bias=False)
         alpha = lora_dim if alpha is None or alpha == 0 else alpha
         self.scale = float(alpha) / lora_dim
         self.register_buffer("alpha", torch.tensor(alpha))
@@ -151,7 +155,9 @@ class RefLoRANetwork(nn.Module):
     """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
 
     def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",),
-                 network_type="lora", lokr_factor=-1):
+                 network_type="lora", lokr_factor=-1, kohya_unet=False, alpha=None):
+        """kohya_unet: the UNet branch of toolkit/lora_special.py:457-647 — prefix lora_unet, dots -> underscores, Linear and 1x1
+        Conv2d children of every `target` module (Transformer2DModel), no block filter, alpha as configured (scale = alpha / rank)."""
         super().__init__()
         self.is_active = False
         self.torch_multiplier = torch.tensor([float(multiplier)])
@@ -160,6 +166,12 @@ class RefLoRANetwork(nn.Module):
             if module.__class__.__name__ not in target:
                 continue
             for child_name, child in module.named_modules():
+                if kohya_unet:
+                    if not (child.__class__.__name__ == "Linear" or (child.__class__.__name__ == "Conv2d" and child.kernel_size == (1, 1))):
+                        continue
+                    lora_name = ".".join([x for x in ("lora_unet", name, child_name) if x]).replace(".", "_")
+                    self.unet_loras.append(RefLoRAModule(lora_name, child, lora_dim, lora_dim if alpha is None else alpha, self))
+                    continue
                 if child.__class__.__name__ != "Linear":
                     continue
                 clean = ".".join([x for x in ("transformer", name, child_name) if x])

@@ -211,14 +211,17 @@ def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
         graw[: B * S_src, :HD].copy_(x.grad.reshape(B * S_src, HD).to(graw.dtype))
 
 
-def ew(op, x, y, a=None, alpha=1.0):
+def ew(op, x, y, a=None, alpha=1.0, a_rows_per_batch=0):
     xf = x.float()
     if op == 0:
         v = F.silu(xf)
     elif op == 1:
         v = xf
     elif op == 2:
-        v = a.float() + xf
+        af = a.float()
+        if a_rows_per_batch:  # row m // rpb of `a`: ResnetBlock2D's hidden + time_emb_proj(...)[:, :, None, None]
+            af = af.repeat_interleave(a_rows_per_batch, 0)[: xf.shape[0]]
+        v = af + xf
     else:
         v = alpha * xf
     y.copy_(v.to(y.dtype))
@@ -386,14 +389,97 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     return out
 
 
-def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False):
+def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False, stats_out=None):
     Cc = x.shape[1]
     xi = x.float().view(B, HW, Cc).transpose(1, 2)
     y = F.group_norm(xi, G, gamma.float(), beta.float(), eps)
     if silu:
         y = F.silu(y)
     out.copy_(y.transpose(1, 2).reshape(B * HW, Cc).to(out.dtype))
+    if stats_out is not None:
+        xg = xi.reshape(B, G, -1).double()
+        mean = xg.mean(-1)
+        var = (xg * xg).mean(-1) - mean * mean
+        stats_out.view(B, G, 2).copy_(torch.stack((mean, 1.0 / torch.sqrt(var.clamp_min(0) + eps)), -1).float())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------- UNet (SD1.5 / SDXL)
+def groupnorm_bwd(dy, x, gamma, beta, stats, dx, *, B, HW, G=32, silu=False, dres=None):
+    """autograd of act(nn.GroupNorm(x)) wrt x with the forward's (mean, rstd) (diffusers ResnetBlock2D / Transformer2DModel norms)."""
+    Cc = x.shape[1]
+    st = stats.view(B, G, 2)
+    xg = x.float().view(B, HW, G, Cc // G)
+    xh = (xg - st[:, None, :, 0:1]) * st[:, None, :, 1:2]
+    ga, be = gamma.float().view(1, 1, G, -1), beta.float().view(1, 1, G, -1)
+    dz = dy.float().view(B, HW, G, Cc // G)
+    if silu:
+        z = xh * ga + be
+        sg = torch.sigmoid(z)
+        dz = dz * sg * (1 + z * (1 - sg))
+    dxh = dz * ga
+    m1 = dxh.mean(dim=(1, 3), keepdim=True)
+    m2 = (dxh * xh).mean(dim=(1, 3), keepdim=True)
+    v = st[:, None, :, 1:2] * (dxh - m1 - xh * m2)
+    v = v.reshape(B * HW, Cc)
+    if dres is not None:
+        v = v + dres.float()
+    dx.copy_(v.to(dx.dtype))
+    return dx
+
+
+def geglu_fwd(hg, out):
+    """diffusers GEGLU: hidden * F.gelu(gate) (exact erf GELU)."""
+    Fd = hg.shape[1] // 2
+    out.copy_((hg[:, :Fd].float() * F.gelu(hg[:, Fd:].float())).to(out.dtype))
+    return out
+
+
+def geglu_bwd(dy, hg, dhg):
+    Fd = hg.shape[1] // 2
+    h, g = hg[:, :Fd].float(), hg[:, Fd:].float()
+    d = dy.float()
+    cdf = 0.5 * (1 + torch.erf(g * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * g * g) * 0.3989422804014327
+    dhg[:, :Fd].copy_((d * g * cdf).to(dhg.dtype))
+    dhg[:, Fd:].copy_((d * h * (cdf + g * pdf)).to(dhg.dtype))
+    return dhg
+
+
+def resample2x(src, dst, *, B, H, W, mode):
+    """mode 0: F.interpolate(scale_factor=2, mode='nearest') (Upsample2D); 1: its adjoint (2x2 sum); 2: zero insertion."""
+    Cc = src.shape[1]
+    x = src.float().view(B, H, W, Cc)
+    if mode == 0:
+        y = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    elif mode == 1:
+        y = x.view(B, H // 2, 2, W // 2, 2, Cc).sum(dim=(2, 4))
+    else:
+        y = torch.zeros(B, 2 * H, 2 * W, Cc, dtype=torch.float32, device=src.device)
+        y[:, ::2, ::2] = x
+    dst.copy_(y.reshape(dst.shape).to(dst.dtype))
+    return dst
+
+
+def copy_heads(src, dst, *, H, d_src, d_dst):
+    M = src.shape[0]
+    d = min(d_src, d_dst)
+    out = torch.zeros(M, H, d_dst, dtype=dst.dtype, device=dst.device)
+    out[:, :, :d] = src[:, : H * d_src].reshape(M, H, d_src)[:, :, :d]
+    dst[:, : H * d_dst].copy_(out.reshape(M, H * d_dst))
+    return dst
+
+
+def ddpm_noise_nhwc(latents, noise, a, s, noisy, target, *, v_prediction=False):
+    """DDPMScheduler.add_noise / get_velocity in the latent dtype (products and the sum each rounded), written NHWC."""
+    B, Cc, h, w = latents.shape
+    dt = latents.dtype
+    av, sv = a.to(dt).view(B, 1, 1, 1), s.to(dt).view(B, 1, 1, 1)
+    nz = av * latents + sv * noise
+    tg = (av * noise - sv * latents) if v_prediction else noise
+    noisy.zero_()
+    noisy[:, :Cc].copy_(nz.permute(0, 2, 3, 1).reshape(B * h * w, Cc))
+    target.copy_(tg.permute(0, 2, 3, 1).reshape(B * h * w, Cc))
 
 
 def softmax_rows(x, scale):
@@ -502,3 +588,30 @@ def kron_merge(W, A, Bm, alpha):
     """LokrModule.merge_in (toolkit/models/lokr.py:261-309): weight + kron(w1, w2) * scale * merge_weight, cast back."""
     W.copy_((W.float() + alpha * torch.kron(A.float(), Bm.float())).to(W.dtype))
     return W
+
+
+
+def _heads_d(t, B, S, H, D):
+    return t[: B * S, : H * D].reshape(B, S, H, D).transpose(1, 2).float()
+
+
+def attn_small_fwd(q, k, v, o, lse, *, B, H, S, D, scale, Skv=0):
+    """F.scaled_dot_product_attention for any head_dim (diffusers AttnProcessor2_0 of the UNet attention blocks)."""
+    Skv = Skv or S
+    qf, kf, vf = _heads_d(q, B, S, H, D), _heads_d(k, B, Skv, H, D), _heads_d(v, B, Skv, H, D)
+    sc = (qf @ kf.transpose(-1, -2)) * scale
+    lse.copy_(torch.logsumexp(sc, -1))
+    o[: B * S, : H * D].copy_((sc.softmax(-1) @ vf).transpose(1, 2).reshape(B * S, H * D).to(o.dtype))
+    return o
+
+
+def attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, D, scale, Skv=0):
+    Skv = Skv or S
+    qf = _heads_d(q, B, S, H, D).requires_grad_(True)
+    kf = _heads_d(k, B, Skv, H, D).requires_grad_(True)
+    vf = _heads_d(v, B, Skv, H, D).requires_grad_(True)
+    with torch.enable_grad():
+        out = ((qf @ kf.transpose(-1, -2)) * scale).softmax(-1) @ vf
+        out.backward(_heads_d(do, B, S, H, D))
+    for dst, src, n in ((dq, qf, S), (dk, kf, Skv), (dv, vf, Skv)):
+        dst[: B * n, : H * D].copy_(src.grad.transpose(1, 2).reshape(B * n, H * D).to(dst.dtype))

@@ -77,3 +77,44 @@ class RefTrainStep:
                 loss = loss + torch.nn.functional.mse_loss(pres, prior) * preservation_multiplier
             loss.backward()
         return loss.detach()
+
+
+class RefUNetTrainStep:
+    """SD1.5 / SDXL step of the reference in plain PyTorch + autograd: DDPM add_noise in the latent dtype
+    (toolkit/stable_diffusion_model.py:1854-1876), UNet call (2049-2055 / 2260-2265; SDXL time_ids 1824-1852), target = noise
+    (SDTrainer.py:650) or velocity (623-625), mse(pred.float(), target.float()).mean([1,2,3]) (916, 987-990), min-SNR / fixed-SNR
+    weights (1003-1011, toolkit/train_tools.py:720-749), mean (1013), clip_grad_norm_, torch.optim.AdamW(eps=1e-6)."""
+
+    def __init__(self, model, net, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6, max_grad_norm=1.0, min_snr_gamma=None,
+                 snr_gamma=None, prediction_type="epsilon"):
+        from . import unet_ref
+
+        self.model, self.net, self.U = model, net, unet_ref
+        self.params = [p for m in net.unet_loras for p in (m.lora_down.weight, m.lora_up.weight)]
+        self.opt = torch.optim.AdamW(self.params, lr=lr, eps=eps, betas=betas, weight_decay=weight_decay)
+        self.max_grad_norm, self.min_snr_gamma, self.snr_gamma, self.prediction_type = max_grad_norm, min_snr_gamma, snr_gamma, prediction_type
+        self.acp = unet_ref.ddpm_alphas_cumprod()
+        self.is_xl = model.config["addition_embed_type"] == "text_time"
+
+    def step(self, latents, prompt_embeds, pooled, noise, timesteps, dtype=torch.float32):
+        U = self.U
+        self.opt.zero_grad()
+        lat, noi = latents.to(dtype), noise.to(dtype)
+        noisy = U.ddpm_add_noise(lat, noi, timesteps, self.acp)
+        target = U.ddpm_velocity(lat, noi, timesteps, self.acp) if self.prediction_type == "v_prediction" else noi
+        added = None
+        if self.is_xl:
+            added = dict(text_embeds=pooled.to(dtype), time_ids=U.time_ids_from_latents(lat))
+        with self.net:
+            pred = self.model(noisy, timesteps.float(), prompt_embeds.to(dtype), added)
+            loss = torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3])
+            if self.snr_gamma is not None and self.snr_gamma > 1e-6:
+                loss = loss * U.min_snr_weight(timesteps, self.acp, self.snr_gamma, fixed=True)
+            elif self.min_snr_gamma is not None and self.min_snr_gamma > 1e-6:
+                loss = loss * U.min_snr_weight(timesteps, self.acp, self.min_snr_gamma)
+            loss = loss.mean()
+            loss.backward()
+        if self.max_grad_norm > 0:
+            torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
+        self.opt.step()
+        return loss.detach()

@@ -174,9 +174,9 @@ class Upsample2D(nn.Module):
 
 
 class _DownBlock(nn.Module):
-    def __init__(self, cin, cout, layers, add_down, attn=None, temb=1280):
+    def __init__(self, cin, cout, layers, add_down, attn=None, temb=1280, groups=32):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb) for i in range(layers)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
         if attn is not None:
             self.attentions = nn.ModuleList([Transformer2DModel(in_channels=cout, **attn) for _ in range(layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
@@ -203,9 +203,9 @@ class DownBlock2D(_DownBlock):
 
 
 class UNetMidBlock2DCrossAttn(nn.Module):
-    def __init__(self, ch, attn, temb=1280):
+    def __init__(self, ch, attn, temb=1280, groups=32):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb), ResnetBlock2D(ch, ch, temb)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb, groups), ResnetBlock2D(ch, ch, temb, groups)])
         self.attentions = nn.ModuleList([Transformer2DModel(in_channels=ch, **attn)])
 
     def forward(self, x, temb, context):
@@ -215,13 +215,13 @@ class UNetMidBlock2DCrossAttn(nn.Module):
 
 
 class _UpBlock(nn.Module):
-    def __init__(self, cin, cout, prev, layers, add_up, attn=None, temb=1280):
+    def __init__(self, cin, cout, prev, layers, add_up, attn=None, temb=1280, groups=32):
         super().__init__()
         res = []
         for i in range(layers):
             skip = cin if i == layers - 1 else cout
             rin = prev if i == 0 else cout
-            res.append(ResnetBlock2D(rin + skip, cout, temb))
+            res.append(ResnetBlock2D(rin + skip, cout, temb, groups))
         self.resnets = nn.ModuleList(res)
         if attn is not None:
             self.attentions = nn.ModuleList([Transformer2DModel(in_channels=cout, **attn) for _ in range(layers)])
@@ -277,9 +277,8 @@ class UNet2DConditionModel(nn.Module):
             in_ch, out_ch = out_ch, block_out_channels[i]
             cls = CrossAttnDownBlock2D if t == "CrossAttnDownBlock2D" else DownBlock2D
             downs.append(cls(in_ch, out_ch, layers_per_block, add_down=i != n - 1, attn=attn_kw(i) if t == "CrossAttnDownBlock2D" else None,
-                             temb=temb))
-        self.down_blocks = nn.ModuleList(downs)
-        self.mid_block = UNetMidBlock2DCrossAttn(block_out_channels[-1], attn_kw(n - 1), temb)
+                             temb=temb, groups=norm_num_groups))
+        mid = UNetMidBlock2DCrossAttn(block_out_channels[-1], attn_kw(n - 1), temb, norm_num_groups)
         rev = list(reversed(block_out_channels))
         ups = []
         out_ch = rev[0]
@@ -287,8 +286,12 @@ class UNet2DConditionModel(nn.Module):
             prev, out_ch, in_ch = out_ch, rev[i], rev[min(i + 1, n - 1)]
             cls = CrossAttnUpBlock2D if t == "CrossAttnUpBlock2D" else UpBlock2D
             ups.append(cls(in_ch, out_ch, prev, layers_per_block + 1, add_up=i != n - 1,
-                           attn=attn_kw(n - 1 - i) if t == "CrossAttnUpBlock2D" else None, temb=temb))
+                           attn=attn_kw(n - 1 - i) if t == "CrossAttnUpBlock2D" else None, temb=temb,
+                           groups=norm_num_groups))
+        # diffusers registers down_blocks and up_blocks (empty ModuleLists) before mid_block: named_modules() order = adapter order
+        self.down_blocks = nn.ModuleList(downs)
         self.up_blocks = nn.ModuleList(ups)
+        self.mid_block = mid
         self.conv_norm_out = nn.GroupNorm(norm_num_groups, c0, eps=1e-5)
         self.conv_out = nn.Conv2d(c0, out_channels, 3, padding=1)
 
