@@ -56,6 +56,101 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=Fa
     return model, net, ops
 
 
+def build_unet(dev, kind="sdxl", rank=8):
+    """BASELINE config 2 (SDXL UNet LoRA r8) / config 1 architecture (SD1.5) with synthetic weights: W ~ N(0, 1/fan_in)."""
+    import math
+
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.unet import SD15_CONFIG, SDXL_CONFIG, UNet2DConditionModel
+
+    model = UNet2DConditionModel(**(SDXL_CONFIG if kind == "sdxl" else SD15_CONFIG), dtype=torch.bfloat16, device=dev, ops=ops)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for m in model.modules():
+            w = getattr(m, "weight", None)
+            if w is not None and w.dim() >= 2:
+                w.copy_((torch.randn(w.shape, device=dev, generator=g) / math.sqrt(w[0].numel())).to(torch.bfloat16))
+    torch.manual_seed(1234)
+    net = FusedLoRANetwork(model, lora_dim=rank, alpha=rank, target_lin_modules=("Transformer2DModel",), is_transformer=False,
+                           peft_format=False, transformer_only=False, base_model_version="sdxl" if kind == "sdxl" else "sd1")
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.normal_(0, 1e-3)
+    net.apply_to()
+    net.build_arena(dev, ema=True, groups=model.lora_groups())
+    net.refresh_shadows(ops)
+    model.attach_network(net)
+    model.prepare()
+    return model, net, ops
+
+
+def bench_unet(args, dev):
+    """Secondary line (not the headline metric): train images/sec of the UNet LoRA step — BASELINE config 2 (SDXL r8 @1024^2) or the
+    SD1.5 architecture at 512^2 — with the MFMA throughput of its GEMM + implicit-GEMM-conv launches measured by events in one extra step."""
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+
+    kind = args.model
+    model, net, ops = build_unet(dev, kind, rank=args.rank if args.rank != 16 else (8 if kind == "sdxl" else 4))
+    step = UNetLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, seed=1000)
+    B = args.batch if args.batch > 0 else (4 if kind == "sdxl" else 8)
+    side = 128 if kind == "sdxl" else 64
+    gen = torch.Generator(device=dev).manual_seed(42)
+    lat = torch.randn(B, 4, side, side, device=dev, generator=gen).to(torch.bfloat16)
+    ctx = (torch.randn(B, 77, model.config["cross_attention_dim"], device=dev, generator=gen) * 0.5).to(torch.bfloat16)
+    pooled = (torch.randn(B, 1280, device=dev, generator=gen) * 0.5).to(torch.bfloat16) if kind == "sdxl" else None
+
+    def one():
+        return step.step(lat, ctx, pooled)
+
+    for _ in range(args.warmup):
+        one()
+    dt, per, loss = timed_steps(one, args.steps, torch.cuda.synchronize)
+    recs = []
+    og, oc = ops.gemm_nt, ops.conv3x3
+
+    def tg(a, b, out, **kw):
+        M = kw.get("M") or a.shape[0]
+        K2 = kw["a2"].shape[1] if kw.get("a2") is not None else 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = og(a, b, out, **kw)
+        e1.record()
+        recs.append((e0, e1, 2.0 * M * b.shape[0] * (b.shape[1] + K2)))
+        return r
+
+    def tc(x, w, out, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = oc(x, w, out, **kw)
+        e1.record()
+        recs.append((e0, e1, 2.0 * out.shape[0] * w.shape[0] * w.shape[1]))
+        return r
+
+    ops.gemm_nt, ops.conv3x3 = tg, tc
+    try:
+        one()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt, ops.conv3x3 = og, oc
+    ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+    fl = sum(f for _, _, f in recs)
+    name = "SDXL UNet LoRA r8 @1024^2" if kind == "sdxl" else "SD1.5 UNet LoRA r4 @512^2"
+    out = {"metric": f"train images/sec, {name}", "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic (random-init architecture, N(0,1) latents, 0.5*N(0,1) text states)",
+           "config": {"workload": f"{name}, eps-prediction DDPM, 77 text tokens, bf16, AdamW+EMA, clip 1.0 (BASELINE config {2 if kind == 'sdxl' else 1} "
+                                  "architecture; not the headline metric)", "per_gpu_batch": B, "adapters": len(net.unet_loras),
+                      "lora_params": net.arena_p.numel(), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+           "final_loss": float(loss.item()),
+           "step_ms": {"median": _pct(per, 0.5), "p10": _pct(per, 0.1), "p90": _pct(per, 0.9), "n": len(per)},
+           "roofline": {"bound": "mfma", "kernel": "aitk_gemm_nt (LoRA-fused token GEMMs + implicit-GEMM 3x3 convolutions, all launches of one step)",
+                        "achieved": fl / ms / 1e9 if ms > 0 else 0.0, "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": (fl / ms / 1e9) / PEAK_BF16 if ms > 0 else 0.0,
+                        "traffic": None, "launches_per_step": len(recs), "gemm_conv_ms_per_step": ms, "gemm_conv_tflop_per_step": fl / 1e12}}
+    print(json.dumps(out), flush=True)
+
+
 def gemm_roofline(step_fn, ops_mod):
     """One extra instrumented step: HIP events (torch's current stream = the stream every kernel is launched on) around
     each launch of the dominant kernel (gemm_nt); algorithmic FLOPs = 2 M N (K + K2) per launch."""
@@ -223,6 +318,8 @@ def main():
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--fp8-base", action="store_true", help="BASELINE config 5 variant (not the headline metric): fp8 e4m3 base weights")
     ap.add_argument("--network", default="lora", choices=["lora", "dora", "lokr"], help="adapter type (headline metric: lora)")
+    ap.add_argument("--model", default="flux", choices=["flux", "sdxl", "sd15"], help="flux = the headline metric; sdxl / sd15 = the UNet path "
+                    "(BASELINE configs 2 / 1 architectures), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
@@ -243,6 +340,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
+
+    if args.model != "flux":
+        bench_unet(args, dev)
+        return
 
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
 

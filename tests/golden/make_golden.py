@@ -591,7 +591,71 @@ def golden_wan_lora_keys():
     print("wan lora keys golden written")
 
 
+def golden_unet_lora():
+    """Reference LoRASpecialNetwork on the UNet oracle trees (kohya format, the SD1.5 / SDXL branch of toolkit/lora_special.py:457-647):
+    tiny SD1.5-like (1x1-conv proj_in / proj_out adapters) and SDXL-like models -> adapter names, init draws under manual_seed(99),
+    one forward + every adapter gradient through the reference's own LoRAModule.forward, and the state dict it saves; plus the adapter
+    name lists of the FULL SD1.5 (192) and SDXL (722) trees (built on the meta device) as count + sha256."""
+    import hashlib
+
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, TINY_SDXL, _inputs
+
+    out, meta = {}, {}
+    for tag, cfg, is_xl in (("sd15", TINY_SD15, False), ("sdxl", TINY_SDXL, True)):
+        torch.manual_seed(0)
+        model = unet_ref.UNet2DConditionModel(**cfg)
+        unet_ref.init_synthetic_(model, seed=11)
+        torch.manual_seed(99)
+        net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=4, alpha=2.0, multiplier=1.0, train_text_encoder=False,
+                                 train_unet=True, is_sdxl=is_xl)
+        names = [m.lora_name for m in net.unet_loras]
+        for m in net.unet_loras:
+            out[f"{tag}/init/{m.lora_name}/down"] = m.lora_down.weight.detach().clone()
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in net.unet_loras:
+                m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+                out[f"{tag}/warm/{m.lora_name}/up"] = m.lora_up.weight.detach().clone()
+        net.force_to("cpu", torch.float32)
+        net._update_torch_multiplier()
+        net.apply_to(None, model, False, True)
+        lat, ts, ctx, added = _inputs(cfg)
+        with net:
+            pred = model(lat, ts, ctx, added)
+            wgt = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+            (pred * wgt).sum().backward()
+        out[f"{tag}/pred"], out[f"{tag}/wgt"] = pred.detach().clone(), wgt
+        for m in net.unet_loras:
+            out[f"{tag}/grad/{m.lora_name}/down"] = m.lora_down.weight.grad.detach().clone()
+            out[f"{tag}/grad/{m.lora_name}/up"] = m.lora_up.weight.grad.detach().clone()
+        sd = net.get_state_dict(dtype=torch.float32)
+        for k, v in sd.items():
+            out[f"{tag}/saved/{k}"] = v.clone()
+        meta[tag] = {"names": names, "saved_keys": list(sd.keys()), "scale": net.unet_loras[0].scale, "peft_format": bool(net.peft_format)}
+        print(f"unet lora golden [{tag}]:", len(names), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale)
+    for tag, cfg, is_xl in (("sd15_full", unet_ref.SD15, False), ("sdxl_full", unet_ref.SDXL, True)):
+        with torch.device("meta"):
+            model = unet_ref.UNet2DConditionModel(**cfg)
+        net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=4, alpha=4.0, multiplier=1.0, train_text_encoder=False,
+                                 train_unet=True, is_sdxl=is_xl)
+        names = [m.lora_name for m in net.unet_loras]
+        shapes = [[list(m.lora_down.weight.shape), list(m.lora_up.weight.shape)] for m in net.unet_loras]
+        meta[tag] = {"count": len(names), "names_sha256": hashlib.sha256("\n".join(names).encode()).hexdigest(), "first": names[:3], "last": names[-3:],
+                     "shapes_sha256": hashlib.sha256(json.dumps(shapes).encode()).hexdigest(),
+                     "params": int(sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in net.unet_loras))}
+        print(f"unet lora golden [{tag}]:", meta[tag]["count"], "adapters,", meta[tag]["params"], "parameters")
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_lora_tiny.safetensors"), {"meta": json.dumps(meta)})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # python make_golden.py golden_unet_lora ...: regenerate selected fixtures only
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        raise SystemExit(0)
+    golden_unet_lora()
     golden_lora()
     golden_dora()
     golden_lokr()
