@@ -14,6 +14,21 @@ import numpy as np
 import torch
 
 
+_WEIGHING = None
+
+
+def default_weighing_scheme():
+    global _WEIGHING
+    if _WEIGHING is None:
+        import json
+        import os
+
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "flowmatch_default_weighing_scheme.json")) as fh:
+            _WEIGHING = json.load(fh)["weights"]
+        assert len(_WEIGHING) == 1000
+    return _WEIGHING
+
+
 def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.16):
     m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
     b = base_shift - m * base_seq_len
@@ -102,12 +117,13 @@ class FlowMatchTrainSchedule:
 
     def get_weights_for_timesteps(self, timesteps, v2=False, timestep_type="linear"):
         """Per-sample loss weights of `linear_timesteps` / `linear_timesteps2` training (custom_flowmatch_sampler.py:59-76,
-        applied at SDTrainer.py:925-944): bell-shaped weight of each timestep's INDEX in the current table.  The 'weighted'
-        type needs the reference's 1000-entry default_weighing_scheme data table, which is not carried here."""
-        if timestep_type == "weighted":
-            raise NotImplementedError("timestep_type='weighted' needs toolkit/timestep_weighing/default_weighing_scheme.py")
+        applied at SDTrainer.py:925-944): bell-shaped weight of each timestep's INDEX in the current table.  'weighted' looks the
+        index up in the reference's empirical 1000-entry default_weighing_scheme (data/flowmatch_default_weighing_scheme.json,
+        imported verbatim by tools/import_reference_tables.py) and returns it in the timesteps' dtype like the reference."""
         table = self.timesteps.to(timesteps.device)
         idx = torch.stack([(table == t).nonzero()[0, 0] for t in timesteps]).cpu()
+        if timestep_type == "weighted":
+            return torch.tensor([default_weighing_scheme()[int(i)] for i in idx], device=timesteps.device, dtype=timesteps.dtype)
         w = (self.linear_timesteps_weights2 if v2 else self.linear_timesteps_weights)[idx]
         return w.flatten().to(timesteps.device)
 

@@ -21,11 +21,14 @@ class _LoRATrainStepBase:
 
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
-                 seed=None, schedule=None, lr_scheduler=None, noise_options=None):
+                 seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False):
         self.model, self.network, self.ops = model, network, ops
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.timestep_type, self.guidance = timestep_type, guidance
+        # SDTrainer.py:923-944: linear_timesteps / linear_timesteps2 / timestep_type 'weighted' multiply the per-sample loss by
+        # the scheduler's weight of each sampled timestep
+        self.linear_timesteps, self.linear_timesteps2 = bool(linear_timesteps), bool(linear_timesteps2)
         self.schedule = schedule or FlowMatchTrainSchedule()
         self.step_num = 0
         self.noise_options = dict(noise_options or {})  # keywords of flowmatch.get_noise (noise_offset, noise_multiplier, ...)
@@ -67,6 +70,13 @@ class _LoRATrainStepBase:
         for piece in pieces:
             if piece.numel():
                 self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _timestep_loss_weight(self, timesteps, loss_weight):
+        """per-sample loss weights of the flow-matching timestep weighting (None when off), folded into `loss_weight`."""
+        if not (self.linear_timesteps or self.linear_timesteps2 or self.timestep_type == "weighted"):
+            return loss_weight
+        tw = self.schedule.get_weights_for_timesteps(timesteps, v2=self.linear_timesteps2, timestep_type=self.timestep_type).float()
+        return tw if loss_weight is None else loss_weight * tw
 
     def _finish_allreduce(self):
         for w in self._pending:
@@ -157,6 +167,7 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
+        loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
         timesteps = timesteps.float().contiguous()
         if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812) + the noise options
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
@@ -204,6 +215,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
+        loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
         timesteps = timesteps.float().contiguous()
         if noise is None:
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)

@@ -68,19 +68,24 @@ class Conv3x3(nn.Module):
 
     kernel_size = (3, 3)
 
-    def __init__(self, cin, cout, stride, dtype, device, cin_pad=None):
+    def __init__(self, cin, cout, stride, dtype, device, cin_pad=None, cout_pad=None):
         super().__init__()
         self.in_channels, self.out_channels, self.stride = cin, cout, stride
         self.cin_pad = cin_pad or cin  # conv_in: 4 latent channels zero-padded to 8 (the kernel's 16-byte channel chunks)
+        self.cout_pad = cout_pad or cout  # conv_out: 4 output channels zero-padded to 8 (so its data gradient reads 16-byte chunks)
         self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout, dtype=dtype, device=device), requires_grad=False)
-        self.wk = self.wd = None
+        self.wk = self.wd = self.bias_k = None
 
     @torch.no_grad()
     def prepare(self, need_dgrad=True):
         w = self.weight.data
         if self.cin_pad != self.in_channels:
             w = torch.cat((w, torch.zeros(w.shape[0], self.cin_pad - self.in_channels, 3, 3, dtype=w.dtype, device=w.device)), 1)
+        self.bias_k = self.bias.data
+        if self.cout_pad != self.out_channels:
+            w = torch.cat((w, torch.zeros(self.cout_pad - self.out_channels, w.shape[1], 3, 3, dtype=w.dtype, device=w.device)), 0)
+            self.bias_k = torch.cat((self.bias.data, torch.zeros(self.cout_pad - self.out_channels, dtype=w.dtype, device=w.device))).contiguous()
         self.wk = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
         if need_dgrad:
             self.wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], 9 * w.shape[0]).contiguous()
@@ -273,7 +278,7 @@ class UNet2DConditionModel(FusedGraphBase):
         self.up_blocks = nn.ModuleList(ups)
         self.mid_block = mid
         self.conv_norm_out = _Norm(c0, 1e-5, dtype, device, G)
-        self.conv_out = Conv3x3(c0, out_channels, 1, dtype, device)
+        self.conv_out = Conv3x3(c0, out_channels, 1, dtype, device, cout_pad=8)
         self._init_graph(ops, dtype)
         self.tape = None
 
@@ -319,8 +324,8 @@ class UNet2DConditionModel(FusedGraphBase):
         ops = self.ops
         s = conv.stride
         Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
-        y = self._new(B * Ho * Wo, conv.out_channels)
-        ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias, flags=EPI_ADD_AUX if res is not None else 0, aux_in=res)
+        y = self._new(B * Ho * Wo, conv.cout_pad)
+        ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=EPI_ADD_AUX if res is not None else 0, aux_in=res)
         if tape.needs(x, res):
             need_x = tape.needs(x)
 
@@ -331,7 +336,7 @@ class UNet2DConditionModel(FusedGraphBase):
                     return
                 g = dy if dy.is_contiguous() else self._contig(dy)
                 if s == 2:  # zero insertion to the input grid (even H, W: pad 1 / stride 2 maps 2Ho x 2Wo back to H x W)
-                    z = self._new(B * 4 * Ho * Wo, conv.out_channels)
+                    z = self._new(B * 4 * Ho * Wo, conv.cout_pad)
                     ops.resample2x(g, z, B=B, H=Ho, W=Wo, mode=2)
                     g = z
                 dx = self._new(B * H * W, conv.cin_pad)
@@ -645,16 +650,22 @@ class UNet2DConditionModel(FusedGraphBase):
                 x = self._upsample(x, blk.upsamplers[0].conv, B, h, w, tape)
                 h, w = 2 * h, 2 * w
         x = self._gn(x, self.conv_norm_out, B, h * w, True, tape)
-        pred, _, _ = self._conv(x, self.conv_out, B, h, w, tape=tape)
+        pred8, _, _ = self._conv(x, self.conv_out, B, h, w, tape=tape)  # [M, 8]: the 4 prediction channels + zero padding
+        Co = cfg["out_channels"]
+        pred = self._new(pred8.shape[0], Co)
+        ops.copy_rows(pred, pred8[:, :Co])
         self.tape = tape if tape.enabled else None
-        self._pred = pred
+        self._pred = pred8
         return pred
 
     def backward_native(self, dpred):
         """dpred NHWC [B*H*W, out_channels]: accumulates every adapter gradient into network.arena_g; frees the tape."""
         tape = self.tape
         assert tape is not None, "forward_native(save_for_backward=True) inside `with network:` must run first"
-        tape.backward(self._pred, dpred.to(self.dt).reshape(self._pred.shape).contiguous())
+        Co = self.config["out_channels"]
+        d8 = torch.zeros(self._pred.shape, dtype=self.dt, device=self._pred.device)
+        self.ops.copy_rows(d8[:, :Co], dpred.to(self.dt).reshape(-1, Co).contiguous())
+        tape.backward(self._pred, d8)
         self.tape = self._pred = None
         if self.grad_ready_hook is not None:
             self.grad_ready_hook("single")

@@ -122,6 +122,9 @@ def golden_flowmatch():
     out["tw_ts"] = tw
     out["tw_v1"] = s.get_weights_for_timesteps(tw, v2=False, timestep_type="linear").clone()
     out["tw_v2"] = s.get_weights_for_timesteps(tw, v2=True, timestep_type="linear").clone()
+    s.set_train_timesteps(1000, "cpu", "weighted")  # timestep_type 'weighted': the linear table + the empirical per-index weights
+    out["tw_weighted_table"] = s.timesteps.clone()
+    out["tw_weighted"] = s.get_weights_for_timesteps(tw, timestep_type="weighted").clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "flowmatch.safetensors"))
     print("flowmatch golden written")
 

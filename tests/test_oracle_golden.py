@@ -141,6 +141,10 @@ def test_flowmatch_schedule_matches_reference_scheduler():
     s.set_train_timesteps(1000, "cpu", "linear")
     assert torch.allclose(s.get_weights_for_timesteps(t["tw_ts"], v2=False), t["tw_v1"], rtol=1e-6, atol=1e-7)
     assert torch.allclose(s.get_weights_for_timesteps(t["tw_ts"], v2=True), t["tw_v2"], rtol=1e-6, atol=1e-7)
+    # timestep_type 'weighted' (custom_flowmatch_sampler.py:65-70, 116): linear table, empirical per-index weights
+    assert torch.equal(s.set_train_timesteps(1000, "cpu", "weighted"), t["tw_weighted_table"])
+    w = s.get_weights_for_timesteps(t["tw_ts"], timestep_type="weighted")
+    assert w.dtype == t["tw_weighted"].dtype and torch.equal(w, t["tw_weighted"])
 
 
 def test_timestep_index_sampling_modes():

@@ -176,3 +176,24 @@ def test_get_noise_follows_the_reference_draw_order_and_options():
         get_noise(torch.zeros(1, 16, 3, 4, 4), noise_offset=0.1)
     v = get_noise(torch.zeros(2, 16, 3, 4, 4), torch.Generator().manual_seed(2), random_noise_shift=0.5)
     assert v.shape == (2, 16, 3, 4, 4)
+
+
+def test_weighted_timestep_type_scales_the_per_sample_loss_like_the_reference():
+    """timestep_type 'weighted' (SDTrainer.py:923-944): loss_b *= default_weighing_scheme[index of t_b]; equals a plain step with
+    the same weights passed explicitly, and differs from the unweighted step."""
+    from ai_toolkit_amd.flowmatch import default_weighing_scheme
+
+    ref, ref_net, nat, net = build_pair(rank=4)
+    lat, emb, pooled, noise, _ = batch(2, seed=5)
+    kw = dict(lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    a = FluxLoRATrainStep(nat, net, ref_ops, timestep_type="weighted", **kw)
+    a.schedule.set_train_timesteps(1000, "cpu", "weighted")
+    ts = a.schedule.timesteps[torch.tensor([100, 700])].clone()
+    la = a.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    ga = net.arena_g.clone()
+    w = torch.tensor([default_weighing_scheme()[100], default_weighing_scheme()[700]])
+    b = FluxLoRATrainStep(nat, net, ref_ops, timestep_type="linear", **kw)
+    lb = b.step(lat, emb, pooled, noise=noise, timesteps=ts, loss_weight=w).item()
+    assert la == lb and torch.equal(ga, net.arena_g)
+    lc = b.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(lc - la) > 1e-3 * abs(la) and len(default_weighing_scheme()) == 1000

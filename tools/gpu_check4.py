@@ -172,16 +172,19 @@ def t_conv(B=2, H=32, W=24, Cin=64, Cout=96, stride=1, res=False, dgrad=False):
 
     from ai_toolkit_amd.unet import Conv3x3
 
-    conv = Conv3x3(Cin, Cout, stride, bf, dev)
+    conv = Conv3x3(Cin, Cout, stride, bf, dev, cout_pad=max(Cout, 8))
     with torch.no_grad():
         conv.weight.copy_((R(Cout, Cin, 3, 3, seed=1) / math.sqrt(9 * Cin)).to(bf))
         conv.bias.copy_((R(Cout, seed=2) * 0.1).to(bf))
     conv.prepare()
     x = R(B * H * W, Cin, seed=3).to(bf).to(dev)
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty(B * Ho * Wo, Cout, dtype=bf, device=dev)
+    Cp = conv.cout_pad
+    y = torch.empty(B * Ho * Wo, Cp, dtype=bf, device=dev)
     aux = R(B * Ho * Wo, Cout, seed=4).to(bf).to(dev) if res else None
-    ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=stride, Ho=Ho, Wo=Wo, bias=conv.bias, flags=ops.EPI_ADD_AUX if res else 0, aux_in=aux)
+    ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=stride, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=ops.EPI_ADD_AUX if res else 0, aux_in=aux)
+    pad_zero = Cp == Cout or float(y[:, Cout:].abs().max()) == 0.0
+    y = y[:, :Cout]
     xi = x.float().view(B, H, W, Cin).permute(0, 3, 1, 2).requires_grad_(True)
     yr = F.conv2d(xi, conv.weight.float(), conv.bias.float(), stride=stride, padding=1)
     yref = yr.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout) + (aux.float() if res else 0)
@@ -189,6 +192,9 @@ def t_conv(B=2, H=32, W=24, Cin=64, Cout=96, stride=1, res=False, dgrad=False):
     if dgrad:
         dy = R(B * Ho * Wo, Cout, seed=5).to(bf).to(dev)
         g = dy
+        if Cp != Cout:  # conv_out: the data gradient reads the zero-padded [M, 8] gradient
+            g = torch.zeros(B * Ho * Wo, Cp, dtype=bf, device=dev)
+            g[:, :Cout] = dy
         if stride == 2:
             g = torch.empty(B * 4 * Ho * Wo, Cout, dtype=bf, device=dev)
             ops.resample2x(dy, g, B=B, H=Ho, W=Wo, mode=2)
@@ -197,7 +203,7 @@ def t_conv(B=2, H=32, W=24, Cin=64, Cout=96, stride=1, res=False, dgrad=False):
         yr.backward(dy.float().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2))
         r["dgrad"] = rel(dx, xi.grad.permute(0, 2, 3, 1).reshape(B * H * W, Cin))
     torch.cuda.synchronize()
-    r["ok"] = r["fwd"] < 3e-3 and r.get("dgrad", 0.0) < 3e-3
+    r["ok"] = r["fwd"] < 3e-3 and r.get("dgrad", 0.0) < 3e-3 and pad_zero
     return r
 
 
