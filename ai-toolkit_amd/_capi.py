@@ -39,6 +39,7 @@ class LoraDownArgs(C.Structure):
         ("mult", vp), ("scale", C.c_float), ("rows_per_batch", i32),
         ("M", i32), ("K", i32), ("R", i32), ("split_rp", i32),
         ("P_lo", vp),
+        ("tmask", vp), ("tmask_rows_per_batch", i32), ("_pad1", i32),
     ]
 
 

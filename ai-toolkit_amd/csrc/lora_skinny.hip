@@ -31,7 +31,13 @@ __device__ __forceinline__ const bf16_t* seg_row2(const bf16_t* base, long ld, i
 }
 
 // four consecutive ranks rr..rr+3 of row m: plain bf16, or the [hi | lo | hi] K-slab triple of the rank block (split_rp > 0)
-__device__ __forceinline__ void store_t4(const AitkLoraDownArgs& p, int m, int rr, const float v[4]) {
+__device__ __forceinline__ void store_t4(const AitkLoraDownArgs& p, int m, int rr, const float vin[4]) {
+  float v[4] = {vin[0], vin[1], vin[2], vin[3]};
+  if (p.tmask) {  // dropout / rank-dropout mask (already scaled by 1 / keep-probability) on the rank-space activation
+    const float* tm = p.tmask + (long)(p.tmask_rows_per_batch > 0 ? m / p.tmask_rows_per_batch : m) * p.R + rr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= tm[e];
+  }
   uint2 hi;
   hi.x = pack2bf(v[0], v[1]);
   hi.y = pack2bf(v[2], v[3]);

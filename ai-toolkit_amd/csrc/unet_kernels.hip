@@ -70,16 +70,23 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(AitkGroupNormBwdArg
     for (int e = 0; e < 8; ++e) { pp[e] = s1[e]; pp[p.C + e] = s2[e]; }
   }
 }
-__global__ void gn_bwd_finish_kernel(AitkGroupNormBwdArgs p, int nchunk) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * p.G) return;
+__global__ __launch_bounds__(64) void gn_bwd_finish_kernel(AitkGroupNormBwdArgs p, int nchunk) {  // one wave per (b, g)
+  const int idx = blockIdx.x;
   const int b = idx / p.G, g = idx - b * p.G;
   const int cg = p.C / p.G;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    const float* pp = p.partial + (((long)b * nchunk + k) * 2) * p.C + g * cg;
-    for (int c = 0; c < cg; ++c) { s1 += pp[c]; s2 += pp[p.C + c]; }
+  for (int i = threadIdx.x; i < nchunk * cg; i += 64) {
+    const int k = i / cg, c = i - k * cg;
+    const float* pp = p.partial + (((long)b * nchunk + k) * 2) * p.C + g * cg + c;
+    s1 += pp[0];
+    s2 += pp[p.C];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (threadIdx.x != 0) return;
   const double n = (double)p.HW * cg;
   p.red[2 * idx] = (float)(s1 / n);
   p.red[2 * idx + 1] = (float)(s2 / n);
@@ -121,7 +128,7 @@ extern "C" int aitk_groupnorm_bwd(const AitkGroupNormBwdArgs* a, aitk_stream_t s
   args.red = a->partial + (long)a->B * nchunk * 2 * a->C;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, a->B), dim3(256), 0, s, args);
   AITK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((a->B * a->G + 63) / 64), dim3(64), 0, s, args, nchunk);
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(a->B * a->G), dim3(64), 0, s, args, nchunk);
   AITK_LAUNCH_CHECK();
   const long total = (long)a->B * a->HW * (a->C / 8);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, args);

@@ -151,6 +151,8 @@ class FusedGraphBase(nn.Module):
         group is not laid out adjacently / inactive)."""
         if not all(self._lora_active(l) for l in lins):
             return {}
+        if self.network.training and self.network.has_dropout:
+            return {}  # dropout decisions are per adapter: each layer draws its own mask in _lin_fwd
         grp = getattr(lins[0].lora, "group", None)
         if grp is None or [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             return {}
@@ -179,13 +181,17 @@ class FusedGraphBase(nn.Module):
             ops.gemm_nt(x, w, out, bias=lin.bias, flags=flags | EPI_ACCUM, aux_out=aux_out, aux_in=aux_in, gate=gate,
                         gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M)
             return _KRON
-        if self._lora_active(lin):
+        plan = self.network.dropout_plan(lin.lora, M=M, rows_per_batch=rows_per_batch, B=B) if (T is None and self._lora_active(lin) and not lin.lora.is_lokr) else None
+        if self._lora_active(lin) and plan != "skip":
             lo = lin.lora
             if T is None:
                 T = self._new(M, 3 * lo.rank_pad)
                 mult, rpb = self._mult(rows_per_batch, B)
+                tm, tm_rpb = plan if plan is not None else (None, 0)
                 ops.lora_down(x, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, x_seg=a_seg, M=M,
-                              p_lo=lo.sh_down_lo, split=lo.rank_pad)
+                              p_lo=lo.sh_down_lo, split=lo.rank_pad, tmask=tm, tmask_rows_per_batch=tm_rpb)
+                if plan is not None:
+                    T._tmask = plan  # the gradient of the masked activation takes the same mask (_lora_grads)
             kw = dict(a2=T, b2=lo.sh_up3)  # [T_hi | T_lo | T_hi] . [B_hi | B_hi | B_lo]^T: the fp32 adapter product to 2^-17
             if lo.magnitude is not None:  # DoRA: y = c * (x W^T + T B^T) + b; the linear output is kept for d magnitude
                 kw["col_scale"] = lo.c
@@ -270,7 +276,9 @@ class FusedGraphBase(nn.Module):
         rp = lo.rank_pad
         dT = dT_out if dT_out is not None else self._new(M, 3 * rp)
         mult, rpb = self._mult(rows_per_batch, B)
-        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp)
+        tm, tm_rpb = getattr(T, "_tmask", (None, 0))
+        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
+                      tmask_rows_per_batch=tm_rpb)
         ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
         if dT_out is None:
             ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
@@ -341,12 +349,16 @@ class FusedGraphBase(nn.Module):
             self._kron(ada_lin.lora, silu_temb, mod, M=B)
             ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, accumulate=True)
             return mod, _KRON
-        if self._lora_active(ada_lin):
+        plan = self.network.dropout_plan(ada_lin.lora, M=B, rows_per_batch=1, B=B) if self._lora_active(ada_lin) else None
+        if self._lora_active(ada_lin) and plan != "skip":
             lo = ada_lin.lora
             T = self._new(B, 3 * lo.rank_pad)
             mult, rpb = self._mult(1, B)
+            tm, tm_rpb = plan if plan is not None else (None, 0)
             ops.lora_down(silu_temb, lo.sh_down, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_down_lo,
-                          split=lo.rank_pad)
+                          split=lo.rank_pad, tmask=tm, tmask_rows_per_batch=tm_rpb)
+            if plan is not None:
+                T._tmask = plan
             kw = dict(t=T, bl=lo.sh_up3)
             if lo.magnitude is not None:
                 kw["col_scale"] = lo.c
@@ -367,6 +379,8 @@ class FusedGraphBase(nn.Module):
         rp = lo.rank_pad
         dT = self._new(B, 3 * rp)
         mult, rpb = self._mult(1, B)
-        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_upT_lo, split=rp)
+        tm, tm_rpb = getattr(T, "_tmask", (None, 0))
+        ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
+                      tmask_rows_per_batch=tm_rpb)
         ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B, split=rp)
         ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B, split=rp)

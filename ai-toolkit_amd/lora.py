@@ -61,9 +61,9 @@ class LoRAModule(nn.Module):
         self.magnitude = None  # DoRAModule sets it
         self.multiplier = multiplier
         self.org_module = [org_module]  # list keeps it out of state_dict (reference lines 125-126)
+        # dropout on lx = lora_down(x), rank_dropout (per sample, per rank, rescaled by 1 / (1 - p)) and module_dropout
+        # (toolkit/network_mixins.py:198-228): executed as a multiplier on the rank-space activation inside aitk_lora_down
         self.dropout, self.rank_dropout, self.module_dropout = dropout, rank_dropout, module_dropout
-        if dropout or rank_dropout or module_dropout:
-            raise NotImplementedError("dropout variants are not on the fused path (reference default: None)")
         # arena bookkeeping (filled by FusedLoRANetwork._build_arena)
         self.off_down = self.off_up = -1
         self.sh_down = self.sh_down_lo = self.sh_downT3 = self.sh_up3 = self.sh_upT = self.sh_upT_lo = None  # build_arena
@@ -251,8 +251,14 @@ class FusedLoRANetwork(nn.Module):
     def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
                  transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
                  is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1,
-                 base_model=None, conv_lora_dim=None):
+                 base_model=None, conv_lora_dim=None, dropout=None, rank_dropout=None, module_dropout=None):
         super().__init__()
+        self.dropout, self.rank_dropout, self.module_dropout = dropout, rank_dropout, module_dropout
+        if (dropout or rank_dropout or module_dropout) and network_type.lower() != "lora":
+            raise NotImplementedError("dropout variants: plain LoRA modules only on the fused path")
+        # draws the random numbers of the dropout masks: (lora_name, kind, shape, device) -> uniform [0, 1) tensor; the default is
+        # torch.rand on the adapter device like the reference (network_mixins.py:200, 220); tests inject a keyed provider
+        self.mask_provider = lambda name, kind, shape, device: torch.rand(shape, device="cpu" if kind == "module" else device)
         # the reference holds a weak reference to the model plug-in for the save / load key-conversion hooks (lora_special.py:373-375)
         self.base_model_ref = weakref.ref(base_model) if base_model is not None else None
         assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
@@ -308,6 +314,8 @@ class FusedLoRANetwork(nn.Module):
                 if lora_name in names:
                     continue
                 names.add(lora_name)
+                if network_type.lower() == "lora":
+                    module_kwargs = dict(dropout=dropout, rank_dropout=rank_dropout, module_dropout=module_dropout)
                 lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self, **module_kwargs)
                 lora.is_conv1x1 = is_conv1x1  # saved / loaded as Conv2d weights [r, in, 1, 1] / [out, r, 1, 1] like the reference's
                 self.unet_loras.append(lora)
@@ -529,6 +537,36 @@ class FusedLoRANetwork(nn.Module):
             at = m.sh_downT3[:, :r]  # A^T_hi [in, r] (row stride 3r)
             ops.lora_wgrad(at, at, gram, M=m.in_features)
             ops.dora_colscale(m.w2, tw, self.arena_view(self.arena_p, m, "up", padded=True), gram, m.magnitude.data, m.scale * vals[0], m.c)
+
+    @property
+    def has_dropout(self):
+        return bool(self.dropout or self.rank_dropout or self.module_dropout)
+
+    def dropout_plan(self, m, *, M, rows_per_batch, B):
+        """Dropout decisions of one adapter for one forward, in the reference's order (toolkit/network_mixins.py:198-228; only in
+        training mode): returns None (no dropout), "skip" (module_dropout fired: the adapter contributes nothing this call) or
+        (tmask fp32 [rows, rank_pad], tmask_rows_per_batch) — the multiplier aitk_lora_down applies to lx (and to its gradient):
+        neuron dropout keep / (1 - p) per element, rank dropout keep / (1 - p) per (sample, rank)."""
+        if not (self.training and self.has_dropout):
+            return None
+        dev = self.arena_p.device
+        if m.module_dropout and float(self.mask_provider(m.lora_name, "module", (1,), dev)) < m.module_dropout:
+            return "skip"
+        mask, rpb = None, 0
+        if m.dropout:
+            keep = (self.mask_provider(m.lora_name, "dropout", (M, m.lora_dim), dev) >= m.dropout).float() / (1.0 - m.dropout)
+            mask = keep
+        if m.rank_dropout and m.rank_dropout > 0:
+            keep = (self.mask_provider(m.lora_name, "rank", (B, m.lora_dim), dev) > m.rank_dropout).float() / (1.0 - m.rank_dropout)
+            if mask is None:
+                mask, rpb = keep, rows_per_batch
+            else:
+                mask = mask * keep.repeat_interleave(rows_per_batch, 0)[:M]
+        if mask is None:
+            return None
+        full = torch.zeros(mask.shape[0], m.rank_pad, dtype=torch.float32, device=dev)
+        full[:, : m.lora_dim] = mask.to(dev)
+        return full.contiguous(), rpb
 
     def attach_grad_views(self):
         """Every Parameter's .grad is a view of the flat gradient arena; optimizer.zero_grad(set_to_none=True) — what the reference's

@@ -102,7 +102,8 @@ def rows_per_block():
     return _capi.lib().aitk_rows_per_block()
 
 
-def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0):
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0, tmask=None,
+              tmask_rows_per_batch=0):
     """out = scale * mult[m // rows_per_batch] * (x[M,K] @ (pmat + p_lo)[R,K]^T): [M,R] bf16, or — split = rank-block width —
     the [M,3R] K-slab layout [hi | lo | hi] per rank block (AitkLoraDownArgs in the header)."""
     a = _capi.LoraDownArgs()
@@ -116,6 +117,9 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
         assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == a.ldp
         a.P_lo = _ptr(p_lo)
     a.split_rp = int(split)
+    if tmask is not None:  # dropout / rank_dropout multipliers on T, fp32 [rows, R]
+        assert tmask.dtype == torch.float32 and tmask.is_contiguous() and tmask.shape[1] == R
+        a.tmask, a.tmask_rows_per_batch = _ptr(tmask), int(tmask_rows_per_batch)
     if x_seg is not None:
         a.x_seg_rows, a.x_seg_stride = x_seg
     if mult is not None:

@@ -96,6 +96,10 @@ typedef struct AitkLoraDownArgs {
   const float* mult; float scale; int32_t rows_per_batch;
   int32_t M, K, R, split_rp;
   const aitk_bf16* P_lo;
+  /* dropout on the rank-space activation (toolkit/network_mixins.py:212-228): fp32 [rows, R] multipliers (0 or 1 / keep-probability)
+   * applied to T before rounding; row = m / tmask_rows_per_batch (rank_dropout: one mask row per sample) or m (neuron dropout, 0).
+   * The backward call (X = dY, P = lora_up^T) takes the SAME mask: d(T * mask)/dT = mask.  May be NULL. */
+  const float* tmask; int32_t tmask_rows_per_batch; int32_t _pad1;
 } AitkLoraDownArgs;
 int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
 

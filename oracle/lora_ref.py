@@ -41,7 +41,25 @@ class RefLoRAModule(nn.Module):
         if not net.is_active or net.multiplier_is_zero():
             return self.org_forward(x, *args, **kwargs)
         org = self.org_forward(x, *args, **kwargs)
-        lx = self.lora_up(self.lora_down(x.to(self.lora_down.weight.dtype))) * self.scale
+        # dropout variants of ToolkitModuleMixin._call_forward (toolkit/network_mixins.py:198-228), training mode only; the uniform
+        # draws come from network.mask_provider(lora_name, kind, shape, device) (default torch.rand, like the reference)
+        prov = getattr(net, "mask_provider", None) if (self.training and getattr(net, "dropout_cfg", None)) else None
+        cfg = getattr(net, "dropout_cfg", None) or {}
+        if prov is not None and cfg.get("module_dropout") and float(prov(self.lora_name, "module", (1,), x.device)) < cfg["module_dropout"]:
+            return org
+        lx = self.lora_down(x.to(self.lora_down.weight.dtype))
+        scale = self.scale
+        if prov is not None and cfg.get("dropout"):
+            flat = lx.reshape(-1, self.lora_dim)
+            keep = (prov(self.lora_name, "dropout", tuple(flat.shape), x.device) >= cfg["dropout"]).to(lx.dtype) / (1.0 - cfg["dropout"])
+            lx = (flat * keep).reshape(lx.shape)
+        if prov is not None and cfg.get("rank_dropout"):
+            mask = (prov(self.lora_name, "rank", (lx.size(0), self.lora_dim), x.device) > cfg["rank_dropout"]).to(lx.dtype)
+            if lx.dim() == 3:
+                mask = mask.unsqueeze(1)
+            lx = lx * mask
+            scale = scale * (1.0 / (1.0 - cfg["rank_dropout"]))
+        lx = self.lora_up(lx) * scale
         m = net.torch_multiplier
         if lx.size(0) != m.size(0):
             m = m.repeat_interleave(lx.size(0) // m.size(0))

@@ -87,7 +87,8 @@ def _split_cols(R, rp):
     return base, base + rp, base + 2 * rp
 
 
-def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0):
+def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0, tmask=None,
+              tmask_rows_per_batch=0):
     """lora_down(x.float()) * scale * multiplier (toolkit/network_mixins.py:197-239, 309-318).  p_lo: second half of a split
     (hi + lo) projection; split: write the fp32 result as the [hi | lo | hi] bf16-pair slab layout (hi = round(t), lo = round(t - hi))."""
     if M is None:
@@ -96,6 +97,8 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     v = _seg_view(x, x_seg, M).float() @ P.t() * scale
     if mult is not None:
         v = v * mult.repeat_interleave(rows_per_batch)[:M, None]
+    if tmask is not None:  # dropout / rank_dropout on lx = lora_down(x) (toolkit/network_mixins.py:212-228), pre-scaled by 1 / keep
+        v = v * (tmask.repeat_interleave(tmask_rows_per_batch, 0)[:M] if tmask_rows_per_batch else tmask[:M])
     if not split:
         out[:M].copy_(v.to(out.dtype))
         return out

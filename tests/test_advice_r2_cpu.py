@@ -273,3 +273,72 @@ def test_split_adapter_branch_reaches_fp32_class_precision_on_bf16_operands():
     for k, v in errs_split.items():
         assert v < 1e-4, (k, v)
         assert errs_bf16[k] > 1e-3 > 10 * v, (k, errs_bf16[k], v)
+
+
+# ---------------------------------------------------------------------------------------------------- dropout variants
+def test_lora_dropout_rank_dropout_and_module_dropout_match_the_oracle():
+    """toolkit/network_mixins.py:198-228 in training mode: neuron dropout on lx = lora_down(x), rank_dropout (one keep mask per
+    sample and rank, output rescaled by 1 / (1 - p)) and module_dropout (the adapter is skipped for this call) — executed as a
+    multiplier inside aitk_lora_down on the rank-space activation and on its gradient.  Both sides draw their uniforms from the same
+    keyed provider (the reference draws torch.rand in module-call order, which no two graphs share)."""
+    import hashlib
+
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep  # noqa: F401
+
+    def provider(name, kind, shape, device):
+        seed = int(hashlib.sha256(f"{name}/{kind}".encode()).hexdigest()[:8], 16)
+        return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+    nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    from oracle import lora_ref
+
+    cfg = dict(dropout=0.1, rank_dropout=0.25, module_dropout=0.2)
+    ref_net = lora_ref.RefLoRANetwork(ref, 8)
+    ref_net.dropout_cfg, ref_net.mask_provider = cfg, provider
+    net = FusedLoRANetwork(nat, lora_dim=8, **cfg)
+    net.mask_provider = provider
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            b.lora_up.weight.copy_(torch.randn(b.lora_up.weight.shape, generator=g) * 0.05)
+            a.lora_down.weight.copy_(b.lora_down.weight)
+            a.lora_up.weight.copy_(b.lora_up.weight)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    from tests.test_host_graph_cpu import inputs
+
+    hidden, enc, pooled, t, img_ids, txt_ids, guid = inputs()
+    skipped = [m.lora_name for m in net.unet_loras if float(provider(m.lora_name, "module", (1,), "cpu")) < 0.2]
+    assert 0 < len(skipped) < len(net.unet_loras)
+    for mode in ("train", "eval"):
+        getattr(ref_net, mode)()
+        getattr(net, mode)()
+        for p in ref_net.parameters():
+            p.grad = None
+        with ref_net:
+            pred_ref = ref(hidden, enc, pooled, t, img_ids, txt_ids, guid)
+            pred_ref.square().sum().backward()
+        with net:
+            pred = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid)
+            assert torch.allclose(pred, pred_ref, rtol=1e-4, atol=1e-5), (mode, (pred - pred_ref).abs().max())
+            net.zero_grad_arena()
+            nat.backward_native((2 * pred).detach())
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            if mode == "train" and a.lora_name in skipped:
+                assert float(a.lora_up.weight.grad.abs().max()) == 0.0 and b.lora_up.weight.grad is None
+                continue
+            for x, y in ((a.lora_down.weight.grad, b.lora_down.weight.grad), (a.lora_up.weight.grad, b.lora_up.weight.grad)):
+                assert ((x - y).norm() / (y.norm() + 1e-12)).item() < 3e-4, (mode, a.lora_name)
+    if True:  # train-mode prediction differs from eval-mode prediction (the masks are live)
+        net.train()
+        with net:
+            p_train = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid, save_for_backward=False)
+        assert not torch.allclose(p_train, pred, rtol=1e-3, atol=1e-4)

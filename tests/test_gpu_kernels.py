@@ -99,6 +99,8 @@ def test_split_precision_skinny_kernels():
     _ok(g.t_lora_wgrad_split(1000, 64, 16, 3072))
     _ok(g.t_lora_wgrad_split(700, 32, 32, 1024, transpose=True, accumulate=True))
     _ok(g.t_lora_wgrad_split(2, 16, 16, 18432, transpose=True))
+    _ok(g.t_lora_down_mask(1000, 3072, 16, per_sample=True))     # rank_dropout: one mask row per sample
+    _ok(g.t_lora_down_mask(1000, 3072, 16, per_sample=False))    # neuron dropout: one mask row per token
 
 
 def test_adapter_branch_matches_fp32_adapter_arithmetic():

@@ -95,6 +95,27 @@ def t_lora_down_split(M, K, Rk, rp, mult=False, seg=False):
     return {"rel_err_fp32": e32, "rel_err_hi": e_hi, "hi_twice": same_hi2, "ok": e32 < 3e-5 and e_hi < 2e-3 and same_hi2}
 
 
+def t_lora_down_mask(M=1000, K=3072, Rk=16, per_sample=True):
+    """dropout / rank_dropout multipliers on the rank-space activation (tmask), with the split output layout."""
+    from oracle import ref_ops
+
+    x = R(M, K, seed=1).to(bf).to(dev)
+    p32 = R(Rk, K, s=0.05, seed=2).to(dev)
+    p_hi = p32.to(bf)
+    p_lo = (p32 - p_hi.float()).to(bf)
+    nb = 4
+    g = torch.Generator().manual_seed(9)
+    tm = ((torch.rand(nb if per_sample else M, Rk, generator=g) > 0.3).float() / 0.7).to(dev)
+    kw = dict(tmask=tm, tmask_rows_per_batch=M // nb if per_sample else 0)
+    out, want = torch.empty(M, 3 * Rk, dtype=bf, device=dev), torch.empty(M, 3 * Rk, dtype=bf, device=dev)
+    ops.lora_down(x, p_hi, out, scale=0.5, p_lo=p_lo, split=Rk, **kw)
+    ref_ops.lora_down(x, p_hi, want, scale=0.5, p_lo=p_lo, split=Rk, **kw)
+    torch.cuda.synchronize()
+    e = rel(out[:, :Rk], want[:, :Rk])
+    zeros = bool(((want[:, :Rk] == 0) == (out[:, :Rk] == 0)).all())
+    return {"rel_err": e, "same_zero_pattern": zeros, "ok": e < 2e-3 and zeros}
+
+
 def t_lora_wgrad_split(M, Rk, rp, L, transpose=False, accumulate=False):
     s32 = R(M, Rk, seed=3).to(dev)
     g = R(M, L, seed=4).to(bf).to(dev)
