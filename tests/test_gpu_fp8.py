@@ -55,13 +55,22 @@ def test_fp8_base_train_step_vs_oracle_with_dequantised_weights():
     from oracle import train_ref
     from tests.test_gpu_e2e import _batch, _build
 
+    import numpy as np
+
+    from oracle import fp8_ref
+
     ref, ref_net, nat, net = _build(rank=32)
+    orig = {n: lin.weight.detach().float().cpu().numpy() for n, lin in nat.named_modules() if lin.__class__.__name__ == "Linear"}
     nat.quantize_base_fp8()
     with torch.no_grad():
         mods = dict(ref.named_modules())
         for n, lin in nat.named_modules():
             if getattr(lin, "qweight", None) is not None:
-                mods[n].weight.copy_(nat.dequantized_weight(lin).float())
+                # the oracle's weights come from the independent numpy restatement of the quantiser (oracle/fp8_ref.py) applied to the
+                # ORIGINAL weights — not from the product's own dequantisation — and the product's codes / scales must equal it
+                codes, scale = fp8_ref.quantize_per_channel(orig[n])
+                assert np.array_equal(lin.qweight.cpu().numpy(), codes) and np.array_equal(lin.wscale.cpu().numpy(), scale), n
+                mods[n].weight.copy_(torch.from_numpy(fp8_ref.dequantize(codes, scale)).to(torch.bfloat16).float())
     lat, emb, pooled, noise, ts = _batch(2)
     oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
     loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()

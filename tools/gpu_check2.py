@@ -357,7 +357,7 @@ def t_attn(B, H, S, bwd=True, ldmul=3):
     lse_ref = torch.logsumexp(sc, -1) / math.log(2)
     e_l = (lse - lse_ref).abs().max().item()
     res = {"o": e_o, "lse_maxabs": e_l}
-    ok = e_o < 1e-2 and e_l < 2e-2
+    ok = e_o < 3e-3 and e_l < 1e-4  # measured 2.2e-3 (one bf16 rounding of O on top of the bf16 P operand) / 2e-6
     if bwd:
         do = R(B * S, HD, seed=31).to(bf).to(dev)
         oref.backward(heads(do))
@@ -367,7 +367,7 @@ def t_attn(B, H, S, bwd=True, ldmul=3):
         res["dq"] = rel(heads(dqkv[:, :HD]), qf.grad)
         res["dk"] = rel(heads(dqkv[:, HD:2 * HD]), kf.grad)
         res["dv"] = rel(heads(dqkv[:, 2 * HD:]), vf.grad)
-        ok = ok and max(res["dq"], res["dk"], res["dv"]) < 2e-2
+        ok = ok and max(res["dq"], res["dk"], res["dv"]) < 3.5e-3  # measured 2.3-2.4e-3 at every size (bf16 P, dS operands + output rounding)
     res["ok"] = ok
     return res
 
