@@ -14,8 +14,9 @@ bf = torch.bfloat16
 M, N, K = int(os.environ.get("AITK_PMC_M", "18432")), 3072, 3072  # 18432 = batch 4, 32256 = batch 7
 a = torch.randn(M, K, device=dev).to(bf)
 b = (torch.randn(N, K, device=dev) * 0.02).to(bf)
-a2 = torch.randn(M, 16, device=dev).to(bf)
-b2 = torch.randn(N, 16, device=dev).to(bf)
+R2 = int(os.environ.get("AITK_PMC_K2", "48"))  # LoRA K-slab: 48 = rank 16 in the split [hi | lo | hi] layout (round 2), 16 = round 1
+a2 = torch.randn(M, R2, device=dev).to(bf)
+b2 = torch.randn(N, R2, device=dev).to(bf)
 bias = torch.randn(N, device=dev).to(bf)
 out = torch.empty(M, N, dtype=bf, device=dev)
 for _ in range(4):
