@@ -39,6 +39,7 @@ class _LoRATrainStepBase:
         self.world = 1
         self.dp = process_group is not None  # a 1-rank group still walks the all-reduce path (RCCL smoke on one GPU)
         self._pending = []
+        self._graphs, self._graph_pool = {}, None
         self.collect_dp_timing = False  # bench.py: events around the all-reduce wait (what of the collective is NOT hidden)
         self.dp_wait_events = []
         if process_group is not None:
@@ -93,6 +94,64 @@ class _LoRATrainStepBase:
         m = mask.float().reshape(B, Fr, Hh // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
         return m.reshape(B, Fr * (Hh // 2) * (W // 2), 4).contiguous()
 
+    # ------------------------------------------------------------------ hipGraph replay of the launch sequence
+    # A micro-batch is split into `_prepare` (host work: timestep sampling, noise draw, table look-ups, loss weights -> a dict of
+    # device tensors) and `_run` (nothing but kernel launches on the current stream: noise mix, forward, loss, backward).  `_run`
+    # of one bucket shape is captured once into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed with the prepared tensors
+    # copied into its static inputs: ~5 000 launches per step leave the Python host path, which is what bounds the small-batch
+    # and UNet steps (the reference's default batch size is 1).  All graphs share one memory pool (they replay one at a time), so
+    # the activations of every bucket shape alias the same HBM.  Clip / AdamW / EMA and the DP all-reduce stay outside the graph.
+    def _graph_key(self, prepared):
+        return tuple((k, tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else (k, repr(v)) for k, v in sorted(prepared.items()))
+
+    def capture(self, **batch):
+        """Capture the launch sequence of this batch's bucket shape; returns the graph entry (also cached by shape)."""
+        return self._capture_prepared(self._prepare(**batch))
+
+    def _capture_prepared(self, prepared):
+        key = self._graph_key(prepared)
+        if key in self._graphs:
+            return self._graphs[key]
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in prepared.items()}
+        # warm-up on a side stream (workspaces, function attributes, RoPE tables are created here, not under capture)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.network.zero_grad_arena()
+            self._run(static, final=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()  # the warm-up's activations go back to the driver: the graph pool takes their place
+        g = torch.cuda.CUDAGraph()
+        self.network.zero_grad_arena()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            self._run(static, final=False)
+        if self._graph_pool is None:
+            self._graph_pool = g.pool()
+        ent = {"graph": g, "static": static}
+        self._graphs[key] = ent
+        return ent
+
+    def step_graphed(self, **batch):
+        """`step` through the captured graph of the batch's bucket shape (captured on first use)."""
+        prepared = self._prepare(**batch)
+        ent = self._graphs.get(self._graph_key(prepared)) or self._capture_prepared(prepared)
+        for k, v in prepared.items():
+            if torch.is_tensor(v):
+                ent["static"][k].copy_(v)
+        self.network.zero_grad_arena()
+        ent["graph"].replay()
+        if self.dp:  # replay finishes every gradient at once: both pieces go out back to back (not overlapped with backward)
+            self._on_grads_ready("single")
+            self._on_grads_ready("double")
+        self._optimizer_step()
+        if self.lr_scheduler is not None:
+            self.lr = self.lr_scheduler.step()
+        return self.loss
+
+    def _single(self, final=True, **batch):
+        return self._run(self._prepare(**batch), final=final)
+
     def step_list(self, batches):
         """The reference's `gradient_accumulation` batch list (SDTrainer.py:2243-2293): gradients are zeroed once, every
         micro-batch (any bucket resolution) runs forward + backward into the same fp32 arena, the micro-batch losses are SUMMED
@@ -119,7 +178,7 @@ class _LoRATrainStepBase:
         if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
             self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
-                          mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
+                          mask=loss_mask)
         model.grad_ready_hook = self._on_grads_ready if (final and self.dp) else None
         model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
         return self.loss
@@ -152,44 +211,55 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         Returns the device-resident loss tensor (no host sync)."""
         return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, **kw)])
 
-    def _single(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None,
-                preservation=None, preservation_multiplier=1.0, final=True):
-        """One micro-batch: noise / pack, forward, loss, backward.  `preservation=(prompt_embeds, pooled_embeds)` adds the
-        reference's diff-output / blank-prompt preservation term (SDTrainer.py:1229-1247, 2182-2220): the base model's
-        prediction on those embeds (adapter inactive, nothing saved) is the target of a second adapter-active pass on the same
-        noisy latents, `mse(pred, prior) * preservation_multiplier` joins the loss.  The two backward passes accumulate into
-        the same arena, which equals the reference's single backward of the summed loss."""
-        ops, model, net = self.ops, self.model, self.network
-        dt = model.dt
-        B, Cc, Hh, W = latents.shape
+    def _prepare(self, latents, prompt_embeds, pooled_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None,
+                 preservation=None, preservation_multiplier=1.0):
+        """Host side of one micro-batch: timestep / noise draws and loss weights -> device tensors for `_run`."""
+        dt = self.model.dt
+        B = latents.shape[0]
         dev = latents.device
         latents = latents.to(dt).contiguous()
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
-        timesteps = timesteps.float().contiguous()
         if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812) + the noise options
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
-        noise = noise.to(dt).contiguous()
+        p = dict(latents=latents, noise=noise.to(dt).contiguous(), timesteps=timesteps.float().contiguous(),
+                 prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, loss_weight=loss_weight,
+                 loss_mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
+        if preservation is not None:
+            p.update(pres_embeds=preservation[0], pres_pooled=preservation[1],
+                     pres_weight=torch.full((B,), float(preservation_multiplier), dtype=torch.float32, device=dev))
+        return p
+
+    def _run(self, p, final=True):
+        """Device side of one micro-batch: noise / pack, forward, loss, backward — kernel launches only (capturable).  With
+        `pres_embeds` / `pres_pooled` it adds the reference's diff-output / blank-prompt preservation term (SDTrainer.py:1229-1247,
+        2182-2220): the base model's prediction on those embeds (adapter inactive, nothing saved) is the target of a second
+        adapter-active pass on the same noisy latents, `mse(pred, prior) * preservation_multiplier` joins the loss.  The two
+        backward passes accumulate into the same arena, which equals the reference's single backward of the summed loss."""
+        ops, model, net = self.ops, self.model, self.network
+        latents, timesteps = p["latents"], p["timesteps"]
+        dt = model.dt
+        B, Cc, Hh, W = latents.shape
+        dev = latents.device
         n_tok = (Hh // 2) * (W // 2)
         noisy = torch.empty(B, n_tok, Cc * 4, dtype=dt, device=dev)
         target = torch.empty_like(noisy)
-        ops.flow_noise_pack(latents, noise, timesteps, noisy, target)
-        img_ids, txt_ids = make_ids(Hh, W, prompt_embeds.shape[1], dev)
+        ops.flow_noise_pack(latents, p["noise"], timesteps, noisy, target)
+        img_ids, txt_ids = make_ids(Hh, W, p["prompt_embeds"].shape[1], dev)
         guidance = torch.full((B,), float(self.guidance), device=dev)
         prior = None
-        if preservation is not None:  # adapter inactive (outside `with net`): base-model prediction, no graph kept
-            prior = model.forward_native(noisy, preservation[0], preservation[1], timesteps / 1000, img_ids, txt_ids, guidance,
+        if p.get("pres_embeds") is not None:  # adapter inactive (outside `with net`): base-model prediction, no graph kept
+            prior = model.forward_native(noisy, p["pres_embeds"], p["pres_pooled"], timesteps / 1000, img_ids, txt_ids, guidance,
                                          save_for_backward=False)
         with net:
-            pred = model.forward_native(noisy, prompt_embeds, pooled_embeds, timesteps / 1000, img_ids, txt_ids, guidance)
-            loss = self._loss_backward(pred, target, loss_weight, loss_mask, final=final and prior is None)
+            pred = model.forward_native(noisy, p["prompt_embeds"], p["pooled_embeds"], timesteps / 1000, img_ids, txt_ids, guidance)
+            loss = self._loss_backward(pred, target, p.get("loss_weight"), p.get("loss_mask"), final=final and prior is None)
             if prior is not None:
                 loss = loss.clone()
-                pres = model.forward_native(noisy, preservation[0], preservation[1], timesteps / 1000, img_ids, txt_ids, guidance)
-                w = torch.full((B,), float(preservation_multiplier), dtype=torch.float32, device=dev)
-                loss.add_(self._loss_backward(pres, prior, w, None, final=final))
+                pres = model.forward_native(noisy, p["pres_embeds"], p["pres_pooled"], timesteps / 1000, img_ids, txt_ids, guidance)
+                loss.add_(self._loss_backward(pres, prior, p["pres_weight"], None, final=final))
         return loss
 
 
@@ -207,31 +277,40 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         """latents [B,16,F,H,W] (normalised Wan-VAE latents), prompt_embeds [B,512,4096] (UMT5).  Returns the loss tensor."""
         return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, **kw)])
 
-    def _single(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None, final=True):
-        ops, model, net = self.ops, self.model, self.network
-        dt = model.dt
+    def _prepare(self, latents, prompt_embeds, *, noise=None, timesteps=None, loss_weight=None, loss_mask=None):
+        dt = self.model.dt
         B, Cc, Fr, Hh, W = latents.shape
         dev = latents.device
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
-        timesteps = timesteps.float().contiguous()
         if noise is None:
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
+        if loss_mask is not None:
+            if loss_mask.dim() == 4:  # [B,1,H,W] -> repeated over frames (SDTrainer.py:955-958)
+                loss_mask = loss_mask[:, :, None].expand(-1, -1, Fr, -1, -1)
+            loss_mask = self.pack_mask(loss_mask)
+        return dict(latents=latents, noise=noise, timesteps=timesteps.float().contiguous(), prompt_embeds=prompt_embeds,
+                    loss_weight=loss_weight, loss_mask=loss_mask)
+
+    def _run(self, p, final=True):
+        ops, model, net = self.ops, self.model, self.network
+        latents, timesteps = p["latents"], p["timesteps"]
+        dt = model.dt
+        B, Cc, Fr, Hh, W = latents.shape
+        dev = latents.device
         # frame-major copies ([B*F, C, H, W]) so the 2x2 pack kernel emits tokens in (frame, row, col) order
         lat_f = latents.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
-        noi_f = noise.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
+        noi_f = p["noise"].to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, Cc, Hh, W).contiguous()
         n_tok = (Hh // 2) * (W // 2)
         noisy = torch.empty(B * Fr, n_tok, Cc * 4, dtype=dt, device=dev)
         target = torch.empty_like(noisy)
         ops.flow_noise_pack(lat_f, noi_f, timesteps.repeat_interleave(Fr).contiguous(), noisy, target)
         grid = (Fr, Hh // 2, W // 2)
         with net:
-            pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, prompt_embeds, grid)
-            if loss_mask is not None and loss_mask.dim() == 4:  # [B,1,H,W] -> repeated over frames (SDTrainer.py:955-958)
-                loss_mask = loss_mask[:, :, None].expand(-1, -1, Fr, -1, -1)
-            return self._loss_backward(pred, target.view(B, Fr * n_tok, Cc * 4), loss_weight, loss_mask, final=final)
+            pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, p["prompt_embeds"], grid)
+            return self._loss_backward(pred, target.view(B, Fr * n_tok, Cc * 4), p.get("loss_weight"), p.get("loss_mask"), final=final)
 
 
 class UNetLoRATrainStep(_LoRATrainStepBase):
@@ -252,10 +331,8 @@ class UNetLoRATrainStep(_LoRATrainStepBase):
         """latents [B,4,h,w] (scaled VAE latents), prompt_embeds [B,77,768|2048], pooled_embeds [B,1280] (SDXL)."""
         return self.step_list([dict(latents=latents, prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, **kw)])
 
-    def _single(self, latents, prompt_embeds, pooled_embeds=None, *, noise=None, timesteps=None, loss_weight=None, time_ids=None,
-                final=True):
-        ops, model, net = self.ops, self.model, self.network
-        dt = model.dt
+    def _prepare(self, latents, prompt_embeds, pooled_embeds=None, *, noise=None, timesteps=None, loss_weight=None, time_ids=None):
+        dt = self.model.dt
         B, Cc, Hh, W = latents.shape
         dev = latents.device
         latents = latents.to(dt).contiguous()
@@ -264,29 +341,51 @@ class UNetLoRATrainStep(_LoRATrainStepBase):
         timesteps = timesteps.to(dev).long()
         if noise is None:
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
-        noise = noise.to(dt).contiguous()
         a, s = self.schedule.noise_coefficients(timesteps, dt)
-        noisy = torch.empty(B * Hh * W, 8, dtype=dt, device=dev)
-        target = torch.empty(B * Hh * W, Cc, dtype=dt, device=dev)
-        ops.ddpm_noise_nhwc(latents, noise, a, s, noisy, target, v_prediction=self.schedule.prediction_type == "v_prediction")
-        added = None
+        p = dict(latents=latents, noise=noise.to(dt).contiguous(), t_float=timesteps.float(), alpha=a, sigma=s,
+                 prompt_embeds=prompt_embeds)
         if self.is_xl:
             if time_ids is None:  # StableDiffusion.get_time_ids_from_latents: (H, W, 0, 0, H, W) in pixels
                 time_ids = torch.tensor([[Hh * 8, W * 8, 0, 0, Hh * 8, W * 8]], dtype=dt, device=dev).repeat(B, 1)
-            added = dict(text_embeds=pooled_embeds, time_ids=time_ids)
+            p.update(pooled_embeds=pooled_embeds, time_ids=time_ids)
         w = loss_weight
         gamma = self.min_snr_gamma if (self.min_snr_gamma is not None and self.min_snr_gamma > 1e-6) else None
         fixed = self.snr_gamma is not None and self.snr_gamma > 1e-6
         if fixed or gamma is not None:  # SDTrainer.py:1003-1011: snr_gamma (fixed) takes precedence over min_snr_gamma
             sw = self.schedule.snr_weights(timesteps, self.snr_gamma if fixed else gamma, fixed=fixed)
             w = sw if w is None else w * sw
+        p["loss_weight"] = w
+        return p
+
+    def _run(self, p, final=True):
+        ops, model, net = self.ops, self.model, self.network
+        latents = p["latents"]
+        dt = model.dt
+        B, Cc, Hh, W = latents.shape
+        dev = latents.device
+        noisy = torch.empty(B * Hh * W, 8, dtype=dt, device=dev)
+        target = torch.empty(B * Hh * W, Cc, dtype=dt, device=dev)
+        ops.ddpm_noise_nhwc(latents, p["noise"], p["alpha"], p["sigma"], noisy, target,
+                            v_prediction=self.schedule.prediction_type == "v_prediction")
+        added = dict(text_embeds=p["pooled_embeds"], time_ids=p["time_ids"]) if self.is_xl else None
         with net:
-            pred = model.forward_native(noisy, timesteps.float(), prompt_embeds, added, B=B, H=Hh, W=W)
-            return self._loss_backward(pred.view(B, Hh * W, Cc), target.view(B, Hh * W, Cc), w, None, final=final)
+            pred = model.forward_native(noisy, p["t_float"], p["prompt_embeds"], added, B=B, H=Hh, W=W)
+            return self._loss_backward(pred.view(B, Hh * W, Cc), target.view(B, Hh * W, Cc), p.get("loss_weight"), None, final=final)
+
+
+_IDS_CACHE = {}
 
 
 def make_ids(Hh, W, n_txt, device):
-    """img_ids (0,row,col) for the 2x2-packed grid, txt_ids zeros (toolkit/stable_diffusion_model.py:2165-2170)."""
+    """img_ids (0,row,col) for the 2x2-packed grid, txt_ids zeros (toolkit/stable_diffusion_model.py:2165-2170); cached per bucket
+    (the host-to-device copy must not happen under graph capture)."""
+    key = (Hh, W, n_txt, str(device))
+    if key not in _IDS_CACHE:
+        _IDS_CACHE[key] = _make_ids(Hh, W, n_txt, device)
+    return _IDS_CACHE[key]
+
+
+def _make_ids(Hh, W, n_txt, device):
     h2, w2 = Hh // 2, W // 2
     img_ids = torch.zeros(h2, w2, 3)
     img_ids[..., 1] = img_ids[..., 1] + torch.arange(h2)[:, None]

@@ -106,7 +106,24 @@ def bench_unet(args, dev):
 
     for _ in range(args.warmup):
         one()
-    dt, per, loss = timed_steps(one, args.steps, torch.cuda.synchronize)
+    dt_eager, per, loss = timed_steps(one, args.steps, torch.cuda.synchronize)
+    dt, mode = dt_eager, "eager launches"
+    graph = None
+    if not args.no_graph:
+        # the same step with forward + loss + backward replayed as one hipGraph (trainer.step_graphed): the UNet step is ~5 400 small
+        # launches and host-bound when launched from Python one by one
+        try:
+            def one_g():
+                return step.step_graphed(latents=lat, prompt_embeds=ctx, pooled_embeds=pooled)
+
+            for _ in range(max(args.warmup, 2)):
+                one_g()
+            dt_g, per_g, loss_g = timed_steps(one_g, args.steps, torch.cuda.synchronize)
+            graph = {"images_per_s": B * args.steps / dt_g, "ms_per_step": 1e3 * dt_g / args.steps}
+            if dt_g < dt:
+                dt, per, loss, mode = dt_g, per_g, loss_g, "hipGraph replay (forward + loss + backward), optimizer eager"
+        except Exception as ex:
+            graph = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     recs = []
     og, oc = ops.gemm_nt, ops.conv3x3
 
@@ -142,7 +159,9 @@ def bench_unet(args, dev):
            "dtype": "bf16", "data": "synthetic (random-init architecture, N(0,1) latents, 0.5*N(0,1) text states)",
            "config": {"workload": f"{name}, eps-prediction DDPM, 77 text tokens, bf16, AdamW+EMA, clip 1.0 (BASELINE config {2 if kind == 'sdxl' else 1} "
                                   "architecture; not the headline metric)", "per_gpu_batch": B, "adapters": len(net.unet_loras),
-                      "lora_params": net.arena_p.numel(), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+                      "lora_params": net.arena_p.numel(), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                      "launch_mode": mode},
+           "launch_modes": {"eager": {"images_per_s": B * args.steps / dt_eager, "ms_per_step": 1e3 * dt_eager / args.steps}, "graph": graph},
            "final_loss": float(loss.item()),
            "step_ms": {"median": _pct(per, 0.5), "p10": _pct(per, 0.1), "p90": _pct(per, 0.9), "n": len(per)},
            "roofline": {"bound": "mfma", "kernel": "aitk_gemm_nt (LoRA-fused token GEMMs + implicit-GEMM 3x3 convolutions, all launches of one step)",
@@ -322,6 +341,7 @@ def main():
                     "(BASELINE configs 2 / 1 architectures), single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
 
@@ -418,6 +438,23 @@ def main():
             sweep[str(b2)] = {"images_per_s": b2 * 3 / d2, "ms_per_step": 1e3 * d2 / 3}
             del l2, e2, p2
         out["batch_sweep"] = sweep
+        # ---- hipGraph replay of the same step (trainer.step_graphed): the ~5 000 launches of forward + backward leave the Python
+        # host path.  Measured at B = 1, the reference's default batch size, where the eager launch sequence is closest to host-bound.
+        try:
+            torch.cuda.empty_cache()
+            l2, e2, p2 = make_batch(dev, 1, seed=43)
+            fn = lambda: step.step_graphed(latents=l2, prompt_embeds=e2, pooled_embeds=p2)  # noqa: E731
+            fn()
+            fn()
+            d2, _, _ = timed_steps(fn, 5, barrier)
+            out["graph_replay"] = {"per_gpu_batch": 1, "images_per_s": 5 / d2, "ms_per_step": 1e3 * d2 / 5,
+                                   "eager_images_per_s": sweep["1"]["images_per_s"] if "1" in sweep else None,
+                                   "note": "forward + loss + backward replayed as one hipGraph per bucket shape; clip/AdamW/EMA launched eagerly"}
+            step._graphs.clear()
+            step._graph_pool = None
+            del l2, e2, p2, fn
+        except Exception as ex:  # never cost the headline line
+            out["graph_replay"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         # ---- bucketed run (BASELINE.json configs[2] "1024x1024 buckets"): the five resolutions of BASELINE.md §2 cycled so the
         # sequence length changes every step (toolkit/config_modules.py:1095-1113, toolkit/data_loader.py:718, 749-756)
         torch.cuda.empty_cache()

@@ -69,7 +69,15 @@ def test_fp8_base_train_step_vs_oracle_with_dequantised_weights():
                 # the oracle's weights come from the independent numpy restatement of the quantiser (oracle/fp8_ref.py) applied to the
                 # ORIGINAL weights — not from the product's own dequantisation — and the product's codes / scales must equal it
                 codes, scale = fp8_ref.quantize_per_channel(orig[n])
-                assert np.array_equal(lin.qweight.cpu().numpy(), codes) and np.array_equal(lin.wscale.cpu().numpy(), scale), n
+                # device `absmax / 448.0` is a multiply by the rounded reciprocal (torch's scalar division on the GPU), numpy divides:
+                # scales agree to 1 ulp, and a quotient that sits on a rounding boundary may land on the neighbouring code
+                got_c, got_s = lin.qweight.cpu().numpy(), lin.wscale.cpu().numpy()
+                assert np.allclose(got_s, scale, rtol=2.5e-7, atol=0), n
+                bad = got_c != codes
+                assert bad.mean() <= 1e-3, (n, bad.mean())
+                if bad.any():
+                    a, b = fp8_ref.e4m3fn_decode(got_c[bad]), fp8_ref.e4m3fn_decode(codes[bad])
+                    assert np.all(np.abs(a - b) <= 0.126 * np.maximum(np.abs(a), np.abs(b))), n  # adjacent grid points (step <= 1/8 of the value)
                 mods[n].weight.copy_(torch.from_numpy(fp8_ref.dequantize(codes, scale)).to(torch.bfloat16).float())
     lat, emb, pooled, noise, ts = _batch(2)
     oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
