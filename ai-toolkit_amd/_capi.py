@@ -192,7 +192,7 @@ class KronApplyArgs(C.Structure):
 
 
 class ShadowDesc(C.Structure):
-    _fields_ = [("src_off", i64), ("d0", i64), ("d1", i64), ("d2", i64), ("rows", i32), ("cols", i32), ("kind", i32), ("_pad", i32)]
+    _fields_ = [("src_off", i64), ("d0", i64), ("d1", i64), ("d2", i64), ("rows", i32), ("cols", i32), ("kind", i32), ("aux", i32)]
 
 
 EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE = 1, 2, 4, 8, 16, 32, 64, 128
@@ -231,6 +231,7 @@ def lib():
     L.aitk_adamw_workspace_bytes.restype = C.c_int64
     L.aitk_adamw_workspace_bytes.argtypes = [i64]
     L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]
+    L.aitk_lokr_lowrank_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.aitk_groupnorm_workspace_bytes.restype = C.c_int64
     L.aitk_groupnorm_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.aitk_softmax_rows.argtypes = [vp, i64, i32, i32, C.c_float, vp]

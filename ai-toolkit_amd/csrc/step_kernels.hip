@@ -307,6 +307,20 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena
   const AitkShadowDesc d = table[blockIdx.y];
   const long n = (long)d.rows * d.cols;
   const float* src = arena + d.src_off;
+  if (d.kind == 3) {  // low-rank LoKr factor: W2 = a [rows, r] @ b [r, cols] composed in fp32 (b follows a in the arena)
+    const int r = d.aux;
+    const float* a = src;
+    const float* b = src + (long)d.rows * r;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      const long ro = i / d.cols, c = i - ro * d.cols;
+      float acc = 0.f;
+      for (int k = 0; k < r; ++k) acc = fmaf(a[ro * r + k], b[(long)k * d.cols + c], acc);
+      const bf16_t hi = f2bf(acc);
+      shadow[d.d0 + i] = hi;
+      shadow[d.d1 + c * d.rows + ro] = hi;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float w = src[i];
     const bf16_t hi = f2bf(w);
@@ -342,6 +356,36 @@ extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, 
   return AITK_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ low-rank LoKr factor gradients
+// W2 = a [O, r] @ b [r, I] (toolkit/models/lokr.py:184-197): from the gradient dW [O, I] of the composed factor,
+// ga (+)= dW b^T, gb (+)= a^T dW.  O, I <= a few hundred, r <= 64: one workgroup, fp32 VALU, fixed summation order.
+__global__ __launch_bounds__(256) void lokr_lowrank_grad_kernel(const float* dW, const float* a, const float* b, float* ga, float* gb,
+                                                                int O, int I, int r, int accumulate) {
+  const int na = O * r, nb = r * I;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < na + nb; e += gridDim.x * 256) {
+    float acc = 0.f;
+    if (e < na) {
+      const int o = e / r, k = e - o * r;
+      for (int i = 0; i < I; ++i) acc = fmaf(dW[(long)o * I + i], b[(long)k * I + i], acc);
+      ga[e] = accumulate ? ga[e] + acc : acc;
+    } else {
+      const int f = e - na;
+      const int k = f / I, i = f - k * I;
+      for (int o = 0; o < O; ++o) acc = fmaf(a[(long)o * r + k], dW[(long)o * I + i], acc);
+      gb[f] = accumulate ? gb[f] + acc : acc;
+    }
+  }
+}
+extern "C" int aitk_lokr_lowrank_grad(const float* dW, const float* a, const float* b, float* ga, float* gb, int32_t O, int32_t I,
+                                      int32_t r, int32_t accumulate, aitk_stream_t stream) {
+  if (!dW || !a || !b || !ga || !gb) return AITK_ERR_ARG;
+  if (O <= 0 || I <= 0 || r <= 0) return AITK_ERR_SHAPE;
+  const int n = O * r + r * I;
+  hipLaunchKernelGGL(lokr_lowrank_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dW, a, b, ga, gb, O, I, r, accumulate);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ DoRA
 // c_j = magnitude_j / sqrt(||W_j||^2 + 2 s B_j.(W A^T)_j + s^2 B_j (A A^T) B_j^T); one thread per output channel (R <= 64)

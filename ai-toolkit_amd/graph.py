@@ -46,7 +46,10 @@ def quantize_linear_fp8(lin, w):
     (amax / 448) — used at load time (quantize_base_fp8) and when an adapter is merged into a quantised base
     (toolkit/network_mixins.py:452-459: merged weights are re-quantised so the model stays quantised)."""
     w = w.float()
-    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0).contiguous()
+    amax = w.abs().amax(dim=1).clamp_min(1e-12)
+    # tensor / tensor: an IEEE division on every device (a Python-scalar divisor becomes a multiply by the rounded reciprocal on the
+    # GPU, 1 ulp off on about half the rows, which moves exact ties of bf16 weights to the neighbouring code)
+    scale = (amax / torch.full_like(amax, 448.0)).contiguous()
     q = (w / scale[:, None]).to(torch.float8_e4m3fn)
     lin.qweight = q.view(torch.uint8).contiguous()
     lin.qweight_t = q.view(torch.uint8).t().contiguous()
@@ -247,18 +250,22 @@ class FusedGraphBase(nn.Module):
         rows = M if x_seg is None else x_seg[0]
         xg = x_in[:rows].view(rows * a_in, b_in)
         g_seg = None if x_seg is None else (x_seg[0] * a_in, x_seg[1])
-        self._skinny_tn(U.view(M * a_in, b_out), xg, lo.g_down, rows=M * a_in, g_seg=g_seg)
+        if lo.use_w2:
+            self._skinny_tn(U.view(M * a_in, b_out), xg, lo.g_down, rows=M * a_in, g_seg=g_seg)
+        else:  # low-rank W2 = a @ b: gradient of the composed factor into its scratch, then d a = dW2 b^T, d b = a^T dW2 into the arena
+            self._skinny_tn(U.view(M * a_in, b_out), xg, lo.g_down, rows=M * a_in, g_seg=g_seg, accumulate=False)
+            ops.lokr_lowrank_grad(lo.g_down, lo.lokr_w2_a.data, lo.lokr_w2_b.data, lo.g_w2a, lo.g_w2b, accumulate=True)
 
-    def _skinny_tn(self, s, g, out, *, rows, g_seg=None):
+    def _skinny_tn(self, s, g, out, *, rows, g_seg=None, accumulate=True):
         """out[R, L] (fp32) += s[rows, R]^T @ g[rows, L] through aitk_lora_wgrad (rank blocks of <= 64 columns, R % 16 == 0);
         when R is not a multiple of 16 but L is (and L <= 64, unsegmented) the roles are swapped and the result written transposed."""
         R, L = s.shape[1], g.shape[1]
         if R % 16 == 0:
             for c0 in range(0, R, 64):
                 c1 = min(R, c0 + 64)
-                self.ops.lora_wgrad(s[:, c0:c1], g, out[c0:c1], accumulate=True, g_seg=g_seg, M=rows)
+                self.ops.lora_wgrad(s[:, c0:c1], g, out[c0:c1], accumulate=accumulate, g_seg=g_seg, M=rows)
         elif L % 16 == 0 and L <= 64 and g_seg is None and R % 8 == 0:
-            self.ops.lora_wgrad(g, s, out, transpose_out=True, accumulate=True, M=rows)
+            self.ops.lora_wgrad(g, s, out, transpose_out=True, accumulate=accumulate, M=rows)
         else:
             raise NotImplementedError(f"LoKr factor gradient {R}x{L}: needs a factor dimension that is a multiple of 16")
 

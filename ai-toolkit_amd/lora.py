@@ -181,11 +181,15 @@ class _ParamProxy:
 
 
 class LoKrModule(LoRAModule):
-    """toolkit/models/lokr.py:76-242 for a Linear with full factors (the reference's default `lokr_full_rank: true`,
-    toolkit/config_modules.py:204-209): delta W = kron(lokr_w1 [out_l, in_m], lokr_w2 [out_k, in_n]) * scale,
-    (out_l, out_k) = factorization(out), (in_m, in_n) = factorization(in); lokr_w2 = 0, lokr_w1 kaiming-uniform at init (one RNG
-    draw, like the reference); both factors full => alpha = lora_dim => scale 1.  The arithmetic is aitk_kron_apply (per-token
-    A . X . B^T, csrc/kron.hip) — kron(w1, w2) is never formed.  In the arena lokr_w2 takes the `down` slot, lokr_w1 the `up` slot."""
+    """toolkit/models/lokr.py:76-242 for a Linear: delta W = kron(lokr_w1 [out_l, in_m], W2 [out_k, in_n]) * scale,
+    (out_l, out_k) = factorization(out), (in_m, in_n) = factorization(in).
+      * lora_dim >= max(out_k, in_n) / 2 (the reference's default `lokr_full_rank: true`, toolkit/config_modules.py:204-209):
+        W2 = lokr_w2, full; lokr_w2 = 0, lokr_w1 kaiming-uniform at init (one RNG draw); alpha = lora_dim => scale 1.
+      * otherwise (lokr.py:184-197): W2 = lokr_w2_a [out_k, r] @ lokr_w2_b [r, in_n]; lokr_w2_a kaiming-uniform (drawn first), lokr_w2_b = 0,
+        then lokr_w1; scale = alpha / r.  The kernels read the composed W2 from the bf16 shadows (shadow kind 3 composes a @ b in fp32);
+        the pair's gradients come from the gradient of the composed factor (aitk_lokr_lowrank_grad).
+    The arithmetic is aitk_kron_apply (per-token A . X . B^T, csrc/kron.hip) — kron(w1, W2) is never formed.  In the arena W2 (or the
+    pair a | b, back to back) takes the `down` slot, lokr_w1 the `up` slot."""
 
     is_lokr = True
 
@@ -202,20 +206,28 @@ class LoKrModule(LoRAModule):
         in_dim, out_dim = org_module.in_features, org_module.out_features
         self.in_m, self.in_n = factorization(in_dim, int(factor))
         self.out_l, self.out_k = factorization(out_dim, int(factor))
-        if lora_dim < max(self.out_k, self.in_n) / 2:
-            raise NotImplementedError("low-rank lokr_w2 (lokr_full_rank: false) is not on the fused path")
         if self.in_n % 8 or self.out_k % 8:
             raise NotImplementedError(f"LoKr factor {self.out_k}x{self.in_n}: the kron kernel needs multiples of 8")
-        self.use_w1 = self.use_w2 = True
+        self.use_w1 = True
+        self.use_w2 = lora_dim >= max(self.out_k, self.in_n) / 2
         self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))
-        self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
+        if self.use_w2:
+            self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
+        else:
+            self.lokr_w2_a = nn.Parameter(torch.empty(self.out_k, lora_dim))
+            self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, self.in_n))
         if isinstance(alpha, torch.Tensor):
             alpha = float(alpha.detach().float().item())
         alpha = lora_dim if alpha is None or alpha == 0 else alpha
-        alpha = lora_dim  # both factors full: scale 1 (lokr.py:203-206)
+        if self.use_w2:
+            alpha = lora_dim  # both factors full: scale 1 (lokr.py:203-206)
         self._set_runtime_scale(float(alpha) / lora_dim)
         self.register_buffer("alpha", torch.tensor(alpha))
-        nn.init.constant_(self.lokr_w2, 0)
+        if self.use_w2:
+            nn.init.constant_(self.lokr_w2, 0)
+        else:
+            nn.init.kaiming_uniform_(self.lokr_w2_a, a=math.sqrt(5))
+            nn.init.constant_(self.lokr_w2_b, 0)
         nn.init.kaiming_uniform_(self.lokr_w1, a=math.sqrt(5))
         self.magnitude = None
         self.multiplier = multiplier
@@ -225,9 +237,22 @@ class LoKrModule(LoRAModule):
         self.off_down = self.off_up = -1
         self.sh_down = self.sh_downT = self.sh_up = self.sh_upT = None
         self.g_down = self.g_up = None
+        self.g_w2a = self.g_w2b = None
+
+    def factor_params(self):
+        """(key, parameter) in the reference module's named_parameters() order."""
+        if self.use_w2:
+            return [("lokr_w1", self.lokr_w1), ("lokr_w2", self.lokr_w2)]
+        return [("lokr_w1", self.lokr_w1), ("lokr_w2_a", self.lokr_w2_a), ("lokr_w2_b", self.lokr_w2_b)]
+
+    def composed_w2(self):
+        """fp32 W2 (load-time utility for merge_in; the step reads the composed bf16 shadow instead)."""
+        return self.lokr_w2.data if self.use_w2 else (self.lokr_w2_a.data @ self.lokr_w2_b.data)
 
     @property
     def lora_down(self):
+        if not self.use_w2:
+            raise AttributeError("low-rank LoKr has no single `down` matrix: use factor_params()")
         return _ParamProxy(self, "lokr_w2")
 
     @property
@@ -349,6 +374,8 @@ class FusedLoRANetwork(nn.Module):
             m.rank_pad = (1 << 30) if m.is_lokr else (m.lora_dim + 15) // 16 * 16  # LoKr: no rank slab (never grouped)
 
         def block_shape(m, which):
+            if m.is_lokr and which == "down" and not m.use_w2:  # the pair a [out_k, r] | b [r, in_n], back to back
+                return (1, m.out_k * m.lora_dim + m.lora_dim * m.in_n)
             w = (m.lora_down if which == "down" else m.lora_up).weight
             if m.is_lokr:
                 return tuple(w.shape)
@@ -392,8 +419,9 @@ class FusedLoRANetwork(nn.Module):
             rows, cols = block_shape(m, which)
             cnt = rows * cols
             if m.is_lokr:
-                sizes["hi"] += cnt
-                sizes["t3"] += cnt
+                scnt = m.out_k * m.in_n if which == "down" else cnt  # the shadow of `down` is always the (composed) W2
+                sizes["hi"] += scnt
+                sizes["t3"] += scnt
             elif which == "down":
                 sizes["hi"] += cnt
                 sizes["lo"] += cnt
@@ -416,10 +444,28 @@ class FusedLoRANetwork(nn.Module):
         entries = []
         off = 0
         for m, which in order:
-            lin = m.lora_down if which == "down" else m.lora_up
-            w = lin.weight.data
             rows, cols = block_shape(m, which)
             cnt = rows * cols
+            if m.is_lokr and which == "down" and not m.use_w2:
+                r, na = m.lora_dim, m.out_k * m.lora_dim
+                for name, o, shape in (("lokr_w2_a", off, (m.out_k, r)), ("lokr_w2_b", off + na, (r, m.in_n))):
+                    view = self.arena_p[o:o + shape[0] * shape[1]].view(*shape)
+                    view.copy_(getattr(m, name).data)
+                    par = nn.Parameter(view, requires_grad=True)
+                    par.grad = self.arena_g[o:o + shape[0] * shape[1]].view(*shape)
+                    setattr(m, name, par)
+                m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
+                scnt = m.out_k * m.in_n
+                d0, sh = take("hi", scnt, (m.out_k, m.in_n))
+                d1, shT = take("t3", scnt, (m.in_n, m.out_k))
+                entries.append((off, m.out_k, m.in_n, 3, d0, d1, 0, r))
+                # gradient of the composed factor: scratch outside the arenas (never seen by the optimizer)
+                m.g_down = torch.zeros(m.out_k, m.in_n, dtype=torch.float32, device=device)
+                m.off_down, m.sh_down, m.sh_downT, m.blk_down = off, sh, shT, (1, cnt)
+                off += cnt
+                continue
+            lin = m.lora_down if which == "down" else m.lora_up
+            w = lin.weight.data
             block = self.arena_p[off:off + cnt].view(rows, cols)
             view = block[: w.shape[0], : w.shape[1]]  # logical matrix: leading rows (down) / leading columns (up) of the block
             view.copy_(w)
@@ -498,6 +544,11 @@ class FusedLoRANetwork(nn.Module):
     def arena_view(self, arena, m, which, padded=False):
         """The [rows, cols] matrix of module m inside a flat arena (arena_p / _g / _m / _v / _ema): the padded block, or the
         logical (unpadded) view of it."""
+        if which in ("w2_a", "w2_b"):  # low-rank LoKr pair inside the `down` slot
+            na = m.out_k * m.lora_dim
+            if which == "w2_a":
+                return arena[m.off_down:m.off_down + na].view(m.out_k, m.lora_dim)
+            return arena[m.off_down + na:m.off_down + na + m.lora_dim * m.in_n].view(m.lora_dim, m.in_n)
         off, (rows, cols) = (m.off_down, m.blk_down) if which == "down" else (m.off_up, m.blk_up)
         block = arena[off:off + rows * cols].view(rows, cols)
         if padded:
@@ -572,6 +623,12 @@ class FusedLoRANetwork(nn.Module):
         """Every Parameter's .grad is a view of the flat gradient arena; optimizer.zero_grad(set_to_none=True) — what the reference's
         trainer calls after each step (SDTrainer.py:2288) — drops them, so they are re-attached before gradients are written."""
         for m in self.get_all_modules():
+            if m.is_lokr and not m.use_w2:  # low-rank LoKr: the pair a | b shares the `down` slot
+                for par, which in ((m.lokr_w2_a, "w2_a"), (m.lokr_w2_b, "w2_b"), (m.lokr_w1, "up")):
+                    if par.grad is None:
+                        par.grad = self.arena_view(self.arena_g, m, which)
+                m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
+                continue
             if m.lora_down.weight.grad is None:
                 m.lora_down.weight.grad = self.arena_view(self.arena_g, m, "down")
             if m.lora_up.weight.grad is None:
@@ -635,7 +692,7 @@ class FusedLoRANetwork(nn.Module):
             if m.magnitude is not None:
                 params.extend([m.magnitude, m.lora_up.weight, m.lora_down.weight])
             elif getattr(m, "is_lokr", False):
-                params.extend([m.lokr_w1, m.lokr_w2])
+                params.extend(p for _, p in m.factor_params())
             else:
                 params.extend([m.lora_down.weight, m.lora_up.weight])
         group = {"params": params}
@@ -673,9 +730,10 @@ class FusedLoRANetwork(nn.Module):
         for m in self.get_all_modules():
             base = m.lora_name.replace("$$", ".")
             if getattr(m, "is_lokr", False):  # <name>.lokr_w1 / .lokr_w2 / .alpha — LoKr keeps alpha (network_mixins.py:613-616)
-                for key, w, which in (("lokr_w1", m.lokr_w1.detach(), "up"), ("lokr_w2", m.lokr_w2.detach(), "down")):
-                    if src is not None:
-                        w = self.arena_view(src, m, which)
+                # the reference's state_dict order: parameters (lokr_w1, lokr_w2 | lokr_w2_a, lokr_w2_b), then the alpha buffer
+                where = {"lokr_w1": "up", "lokr_w2": "down", "lokr_w2_a": "w2_a", "lokr_w2_b": "w2_b"}
+                for key, par in m.factor_params():
+                    w = par.detach() if src is None else self.arena_view(src, m, where[key])
                     sd[f"{base}.{key}"] = w.clone().contiguous().to("cpu").to(dtype)
                 sd[f"{base}.alpha"] = m.alpha.detach().clone().to("cpu").to(dtype)
                 continue
@@ -732,7 +790,8 @@ class FusedLoRANetwork(nn.Module):
         extra = OrderedDict()
         by_name = {m.lora_name.replace("$$", "."): m for m in self.get_all_modules()}
         n_hit = 0
-        suffixes = ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up"), (".lokr_w1", "lora_up"), (".lokr_w2", "lora_down"))
+        suffixes = ((".lora_A.weight", "lora_down"), (".lora_B.weight", "lora_up"), (".lokr_w1", "lokr_w1"), (".lokr_w2", "lokr_w2"),
+                    (".lokr_w2_a", "lokr_w2_a"), (".lokr_w2_b", "lokr_w2_b"))
         if not self.peft_format:  # kohya keys
             suffixes = ((".lora_down.weight", "lora_down"), (".lora_up.weight", "lora_up"))
         with torch.no_grad():
@@ -742,9 +801,15 @@ class FusedLoRANetwork(nn.Module):
                     v = v[:, :, 0, 0]  # 1x1-conv adapter weights
                 for which, attr in suffixes:
                     if k.endswith(which) and k[: -len(which)] in by_name:
-                        if which.startswith(".lokr") != bool(getattr(by_name[k[: -len(which)]], "is_lokr", False)):
+                        mod = by_name[k[: -len(which)]]
+                        if which.startswith(".lokr") != bool(getattr(mod, "is_lokr", False)):
                             continue
-                        w = getattr(by_name[k[: -len(which)]], attr).weight
+                        if which.startswith(".lokr"):
+                            w = getattr(mod, attr, None)  # a full-rank file does not load into a low-rank module and vice versa
+                            if w is None:
+                                continue
+                        else:
+                            w = getattr(mod, attr).weight
                         v = v.to(w.device, torch.float32)
                         if v.shape != w.shape:
                             new = torch.zeros_like(w)
@@ -791,9 +856,10 @@ class FusedLoRANetwork(nn.Module):
                 if getattr(lin, "qweight", None) is not None:
                     raise NotImplementedError("LoKr merge into a weight-only fp8 base is not on the fused path")
                 a = float(merge_weight) * m.scale
-                ops.kron_merge(lin.weight.data, m.lokr_w1.data.contiguous(), m.lokr_w2.data.contiguous(), a)
+                w2 = m.composed_w2()
+                ops.kron_merge(lin.weight.data, m.lokr_w1.data.contiguous(), w2.contiguous(), a)
                 if getattr(lin, "weight_t", None) is not None:
-                    ops.kron_merge(lin.weight_t, m.lokr_w1.data.t().contiguous(), m.lokr_w2.data.t().contiguous(), a)
+                    ops.kron_merge(lin.weight_t, m.lokr_w1.data.t().contiguous(), w2.t().contiguous(), a)
             self.is_merged_in = merge_weight > 0
             return
         self.refresh_shadows(ops)
@@ -850,8 +916,8 @@ class FusedLoRANetwork(nn.Module):
             if m.magnitude is not None:
                 out.append(arena[m.off_mag:m.off_mag + m.magnitude.numel()])
                 out += [self.arena_view(arena, m, "up"), self.arena_view(arena, m, "down")]
-            elif getattr(m, "is_lokr", False):
-                out += [self.arena_view(arena, m, "up"), self.arena_view(arena, m, "down")]  # lokr_w1, lokr_w2
+            elif getattr(m, "is_lokr", False):  # lokr_w1, lokr_w2 | lokr_w2_a, lokr_w2_b
+                out += [self.arena_view(arena, m, w) for w in (("up", "down") if m.use_w2 else ("up", "w2_a", "w2_b"))]
             else:
                 out += [self.arena_view(arena, m, "down"), self.arena_view(arena, m, "up")]
         return out

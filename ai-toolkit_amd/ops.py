@@ -375,13 +375,26 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
 
 
 def make_shadow_table(entries, device):
-    """entries: list of (src_off, rows, cols, kind, d0, d1, d2) (AitkShadowDesc) -> device table for refresh_shadows."""
+    """entries: list of (src_off, rows, cols, kind, d0, d1, d2[, aux]) (AitkShadowDesc) -> device table for refresh_shadows."""
     arr = (_capi.ShadowDesc * len(entries))()
-    for i, (so, r, c, kind, d0, d1, d2) in enumerate(entries):
+    for i, (so, r, c, kind, d0, d1, d2, *aux) in enumerate(entries):
         arr[i].src_off, arr[i].rows, arr[i].cols, arr[i].kind, arr[i].d0, arr[i].d1, arr[i].d2 = so, r, c, kind, d0, d1, d2
+        arr[i].aux = aux[0] if aux else 0
     raw = bytes(arr)
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return t, len(entries)
+
+
+def lokr_lowrank_grad(dw, a, b, ga, gb, *, accumulate=True):
+    """ga [O, r] (+)= dw [O, I] @ b[r, I]^T, gb [r, I] (+)= a[O, r]^T @ dw: gradients of the low-rank LoKr pair from the gradient of
+    their product (all fp32, contiguous)."""
+    O, I = dw.shape
+    r = a.shape[1]
+    for t in (dw, a, b, ga, gb):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    assert tuple(a.shape) == (O, r) == tuple(ga.shape) and tuple(b.shape) == (r, I) == tuple(gb.shape)
+    _capi.check(_capi.lib().aitk_lokr_lowrank_grad(_ptr(dw), _ptr(a), _ptr(b), _ptr(ga), _ptr(gb), O, I, r, int(accumulate),
+                                                   _capi.stream_ptr()), "aitk_lokr_lowrank_grad")
 
 
 def refresh_shadows(arena, shadow, table):

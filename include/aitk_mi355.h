@@ -281,10 +281,17 @@ int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
  *   kind 1 (lora_down A [r, in]):  d0 = hi [r, in], d1 = lo [r, in] (P / P_lo of the forward aitk_lora_down),
  *                                  d2 = [in, 3r] rows = [A^T_hi | A^T_hi | A^T_lo] (B2 of the dgrad K-slab).
  *   kind 2 (lora_up B [out, r]):   d0 = [out, 3r] rows = [B_hi | B_hi | B_lo] (B2 of the forward K-slab),
- *                                  d1 = hi transposed [r, out], d2 = lo transposed [r, out] (P / P_lo of the backward aitk_lora_down). */
-typedef struct AitkShadowDesc { int64_t src_off; int64_t d0; int64_t d1; int64_t d2; int32_t rows, cols, kind, _pad; } AitkShadowDesc;
+ *                                  d1 = hi transposed [r, out], d2 = lo transposed [r, out] (P / P_lo of the backward aitk_lora_down).
+ *   kind 3 (low-rank LoKr factor, toolkit/models/lokr.py:184-197): the arena holds a [rows, aux] followed by b [aux, cols];
+ *                                  d0 = bf16(a @ b) [rows, cols] composed in fp32, d1 = its transpose [cols, rows]. */
+typedef struct AitkShadowDesc { int64_t src_off; int64_t d0; int64_t d1; int64_t d2; int32_t rows, cols, kind, aux; } AitkShadowDesc;
 int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                               aitk_stream_t stream);
+
+/* Low-rank LoKr: gradients of the pair lokr_w2_a [O, r], lokr_w2_b [r, I] from the gradient dW [O, I] of their product
+ * (autograd of `lokr_w2_a @ lokr_w2_b`, toolkit/models/lokr.py:236-241, 331-339): ga (+)= dW b^T, gb (+)= a^T dW; all fp32. */
+int aitk_lokr_lowrank_grad(const float* dW, const float* a, const float* b, float* ga, float* gb, int32_t O, int32_t I, int32_t r,
+                           int32_t accumulate, aitk_stream_t stream);
 
 
 /* ---- VAE encoder side kernels (NHWC bf16): GroupNorm(G groups, eps, gamma/beta [C]) with optional SiLU over

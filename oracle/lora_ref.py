@@ -133,9 +133,12 @@ def factorization(dimension, factor=-1):
 
 
 class RefLokrModule(nn.Module):
-    """toolkit/models/lokr.py:76-242 (Linear, both factors full) + the factorised forward 331-399:
+    """toolkit/models/lokr.py:76-242 (Linear) + the factorised forward 331-399:
         X = x.unflatten(-1, (in_m, in_n)); tmp = einsum('...qs,os->...qo', X, w2); delta = einsum('...qo,pq->...po', tmp, w1*scale)
-        out = org(x) + delta.flatten(-2) * mean(multiplier), computed in the base output's dtype."""
+        out = org(x) + delta.flatten(-2) * mean(multiplier), computed in the base output's dtype.
+    lora_dim >= max(out_k, in_n) / 2: full lokr_w2 (= 0 at init), alpha forced to lora_dim (scale 1).  Otherwise (184-197) the
+    low-rank pair lokr_w2_a [out_k, r] (kaiming-uniform, drawn BEFORE w1) @ lokr_w2_b [r, in_n] (= 0), scale = alpha / r, and the
+    forward folds the rank through first: tmp = (X w2_b^T) w2_a^T."""
 
     def __init__(self, lora_name, org_module, lora_dim, alpha, network, factor=-1):
         super().__init__()
@@ -143,12 +146,19 @@ class RefLokrModule(nn.Module):
         self.lora_dim = lora_dim
         self.in_m, self.in_n = factorization(org_module.in_features, factor)
         self.out_l, self.out_k = factorization(org_module.out_features, factor)
-        assert lora_dim >= max(self.out_k, self.in_n) / 2, "oracle restates the full-factor case only"
+        self.use_w2 = lora_dim >= max(self.out_k, self.in_n) / 2
         self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))
-        self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
-        self.scale = 1.0  # alpha forced to lora_dim when both factors are full
-        self.register_buffer("alpha", torch.tensor(lora_dim))
-        nn.init.constant_(self.lokr_w2, 0)
+        if self.use_w2:
+            self.lokr_w2 = nn.Parameter(torch.empty(self.out_k, self.in_n))
+            alpha = lora_dim  # both factors full: scale 1 (lokr.py:203-206)
+            nn.init.constant_(self.lokr_w2, 0)
+        else:
+            self.lokr_w2_a = nn.Parameter(torch.empty(self.out_k, lora_dim))
+            self.lokr_w2_b = nn.Parameter(torch.empty(lora_dim, self.in_n))
+            nn.init.kaiming_uniform_(self.lokr_w2_a, a=math.sqrt(5))
+            nn.init.constant_(self.lokr_w2_b, 0)
+        self.scale = float(alpha) / lora_dim
+        self.register_buffer("alpha", torch.tensor(alpha))
         nn.init.kaiming_uniform_(self.lokr_w1, a=math.sqrt(5))
         self.org_module = [org_module]
         self.network = [network]
@@ -164,7 +174,11 @@ class RefLokrModule(nn.Module):
         org = self.org_forward(x, *args, **kwargs)
         dt = org.dtype
         X = x.to(dt).unflatten(-1, (self.in_m, self.in_n))
-        tmp = torch.einsum("...qs,os->...qo", X, self.lokr_w2.to(dt))
+        if self.use_w2:
+            tmp = torch.einsum("...qs,os->...qo", X, self.lokr_w2.to(dt))
+        else:
+            tmp = torch.einsum("...qs,rs->...qr", X, self.lokr_w2_b.to(dt))
+            tmp = torch.einsum("...qr,or->...qo", tmp, self.lokr_w2_a.to(dt))
         delta = torch.einsum("...qo,pq->...po", tmp, self.lokr_w1.to(dt) * self.scale).flatten(-2, -1)
         return (org + delta * net.torch_multiplier.mean().to(dt)).to(x.dtype)
 
@@ -197,6 +211,7 @@ class RefLoRANetwork(nn.Module):
                 if not any(b in clean for b in block_names):
                     continue
                 if network_type == "lokr":
+                    # PEFT-format transformer networks carry no alpha: alpha = rank (lora_special.py:428-433)
                     self.unet_loras.append(RefLokrModule(lora_name, child, lora_dim, lora_dim, self, factor=lokr_factor))
                     continue
                 cls = RefDoRAModule if network_type == "dora" else RefLoRAModule

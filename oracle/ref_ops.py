@@ -350,10 +350,26 @@ def make_shadow_table(entries, device):
     return entries, len(entries)
 
 
+def lokr_lowrank_grad(dw, a, b, ga, gb, *, accumulate=True):
+    da, db = dw @ b.t(), a.t() @ dw
+    if accumulate:
+        ga.add_(da)
+        gb.add_(db)
+    else:
+        ga.copy_(da)
+        gb.copy_(db)
+
+
 def refresh_shadows(arena, shadow, table):
     """hi = round(w), lo = round(w - hi) in the layouts of AitkShadowDesc (include/aitk_mi355.h)."""
     entries, _ = table
-    for so, r, c, kind, d0, d1, d2 in entries:
+    for so, r, c, kind, d0, d1, d2, *aux in entries:
+        if kind == 3:  # low-rank LoKr factor composed in fp32
+            k = aux[0]
+            w = arena[so:so + r * k].view(r, k) @ arena[so + r * k:so + r * k + k * c].view(k, c)
+            shadow[d0:d0 + r * c].view(r, c).copy_(w.to(shadow.dtype))
+            shadow[d1:d1 + r * c].view(c, r).copy_(w.to(shadow.dtype).t())
+            continue
         w = arena[so:so + r * c].view(r, c)
         hi = w.to(shadow.dtype)
         if kind == 0:

@@ -22,7 +22,7 @@ class RefTrainStep:
         self.model, self.net = model, net
         self.params = [p for m in net.unet_loras for p in
                        ((m.magnitude, m.lora_up.weight, m.lora_down.weight) if hasattr(m, "magnitude") else
-                        (m.lokr_w1, m.lokr_w2) if hasattr(m, "lokr_w1") else (m.lora_down.weight, m.lora_up.weight))]
+                        tuple(m.parameters()) if hasattr(m, "lokr_w1") else (m.lora_down.weight, m.lora_up.weight))]
         self.opt = torch.optim.AdamW(self.params, lr=lr, eps=eps, betas=betas, weight_decay=weight_decay)
         self.max_grad_norm, self.ema_decay, self.guidance = max_grad_norm, ema_decay, guidance
         self.ema = [p.detach().clone() for p in self.params] if ema_decay > 0 else None

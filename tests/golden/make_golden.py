@@ -233,6 +233,63 @@ def golden_lokr():
     print("lokr golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale)
 
 
+def golden_lokr_lowrank():
+    """Reference LoRASpecialNetwork(network_type='lokr', lora_dim=4, alpha=2) on the tiny FLUX oracle: every layer has
+    max(out_k, in_n) / 2 > 4, so lokr_w2 is the low-rank pair lokr_w2_a [out_k, 4] @ lokr_w2_b [4, in_n] (toolkit/models/lokr.py:184-197),
+    scale = alpha / lora_dim = 0.5.  Shapes, the init drawn under the same seed (w2_a then w1; w2_b = 0), forward, every factor gradient,
+    the saved state dict and merge_in."""
+    from types import SimpleNamespace
+
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    torch.manual_seed(0)
+    model = flux_ref.FluxTransformer2DModel(**TINY)
+    flux_ref.init_synthetic_(model, seed=1234, std=0.05)
+    torch.manual_seed(99)
+    net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=4, alpha=2, multiplier=1.0, train_text_encoder=False,
+                             train_unet=True, is_flux=True, target_lin_modules=["FluxTransformer2DModel"], transformer_only=True,
+                             network_type="lokr", network_config=SimpleNamespace(lokr_factor=-1, old_lokr_format=False))
+    out = {}
+    shapes = {}
+    for m in net.unet_loras:
+        assert not m.use_w2 and m.use_w1
+        out[f"init/{m.lora_name}/w1"] = m.lokr_w1.detach().clone()
+        out[f"init/{m.lora_name}/w2_a"] = m.lokr_w2_a.detach().clone()
+        assert float(m.lokr_w2_b.abs().max()) == 0.0
+        shapes[m.lora_name] = [list(m.lokr_w1.shape), list(m.lokr_w2_a.shape), list(m.lokr_w2_b.shape)]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lokr_w2_b.copy_(torch.randn(m.lokr_w2_b.shape, generator=g) * 0.2)
+            out[f"set/{m.lora_name}/w2_b"] = m.lokr_w2_b.detach().clone()
+    net.force_to("cpu", torch.float32)
+    net._update_torch_multiplier()
+    net.apply_to(None, model, False, True)
+    net.is_active = True
+    pred = model(*tiny_inputs())
+    w = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+    (pred * w).sum().backward()
+    out["fwd/pred"] = pred.detach().clone()
+    out["fwd/w"] = w
+    for m in net.unet_loras:
+        out[f"grad/{m.lora_name}/w1"] = m.lokr_w1.grad.clone()
+        out[f"grad/{m.lora_name}/w2_a"] = m.lokr_w2_a.grad.clone()
+        out[f"grad/{m.lora_name}/w2_b"] = m.lokr_w2_b.grad.clone()
+    sd = net.get_state_dict(dtype=torch.float32)
+    for k, v in sd.items():
+        out["saved/" + k] = v.clone()
+    meta = {"names": json.dumps([m.lora_name for m in net.unet_loras]), "saved_keys": json.dumps(list(sd.keys())),
+            "shapes": json.dumps(shapes), "scale": json.dumps(net.unet_loras[0].scale),
+            "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()])}
+    for m in net.unet_loras:
+        if m.lora_name.endswith("transformer_blocks$$0$$attn$$to_q") or m.lora_name.endswith("single_transformer_blocks$$0$$proj_out"):
+            m.merge_in(0.7)
+            out[f"merged/{m.lora_name}"] = m.org_module[0].weight.detach()[:24].clone()
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "lokr_lowrank_flux_tiny.safetensors"), meta)
+    print("lokr low-rank golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors; scale", net.unet_loras[0].scale,
+          "; params", meta["param_order"])
+
+
 def golden_flux_blocks():
     """FLUX block arithmetic pinned on the reference's OWN in-tree restatement of the BFL FLUX blocks — the Chroma model
     (extensions_built_in/diffusion_models/chroma/src/layers.py: DoubleStreamBlock 471-607, SingleStreamBlock 610-681, LastLayer
@@ -662,6 +719,7 @@ if __name__ == "__main__":
     golden_lora()
     golden_dora()
     golden_lokr()
+    golden_lokr_lowrank()
     golden_flux_blocks()
     golden_wan_attn()
     golden_optimizer_ema()

@@ -200,3 +200,101 @@ def test_kron_merge_kernel():
         Wt = W.t().contiguous()
         got_t = ops.kron_merge(Wt, A.t().contiguous(), Bm.t().contiguous(), 0.7)
         assert torch.equal(got_t, got.t())  # both orientations round identically
+
+
+def test_lowrank_lokr_compose_and_pair_gradient_kernels():
+    """shadow kind 3 (W2 = a @ b composed in fp32 -> bf16, both orientations) and aitk_lokr_lowrank_grad against fp32 torch."""
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(3)
+    for O, I, r in ((64, 64, 16), (128, 96, 4), (24, 40, 8)):
+        a = torch.randn(O, r, generator=g).cuda()
+        b = torch.randn(r, I, generator=g).cuda()
+        arena = torch.cat((torch.zeros(7), a.flatten().cpu(), b.flatten().cpu())).cuda()
+        entries = [(7, O, I, 3, 0, O * I, 0, r)]
+        sh = torch.zeros(2 * O * I, dtype=BF, device="cuda")
+        sh_ref = torch.zeros_like(sh)
+        ops.refresh_shadows(arena, sh, ops.make_shadow_table(entries, "cuda"))
+        ref_ops.refresh_shadows(arena, sh_ref, ref_ops.make_shadow_table(entries, "cuda"))
+        torch.cuda.synchronize()
+        # fp32 summation order differs (fma chain vs torch matmul): identical up to one bf16 rounding of a value that sat on a boundary
+        assert _rel(sh.float(), sh_ref.float()) < 2e-3
+        assert torch.equal(sh[:O * I].view(O, I).t(), sh[O * I:].view(I, O))
+        dw = torch.randn(O, I, generator=g).cuda()
+        ga0, gb0 = torch.randn(O, r, generator=g).cuda(), torch.randn(r, I, generator=g).cuda()
+        for acc in (False, True):
+            ga, gb = ga0.clone(), gb0.clone()
+            ops.lokr_lowrank_grad(dw, a, b, ga, gb, accumulate=acc)
+            ra, rb = ga0.clone(), gb0.clone()
+            ref_ops.lokr_lowrank_grad(dw, a, b, ra, rb, accumulate=acc)
+            torch.cuda.synchronize()
+            assert torch.allclose(ga, ra, rtol=1e-4, atol=1e-4) and torch.allclose(gb, rb, rtol=1e-4, atol=1e-4), (O, I, r, acc)
+
+
+def test_lowrank_lokr_train_step_vs_fp32_oracle():
+    """`lokr_full_rank: false` (lora_dim 4 < max(out_k, in_n) / 2 for every layer): loss and the gradients of lokr_w1, lokr_w2_a, lokr_w2_b."""
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import flux_ref, lora_ref, train_ref
+    from tests.test_gpu_e2e import CFG as CFG3
+
+    CFG = dict(CFG3, num_attention_heads=2)
+    dev, r = "cuda", 4
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.03)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.to(BF).float())
+    ref = ref.to(dev)
+    nat = FluxTransformer2DModel(**CFG, dtype=BF, device=dev, ops=ops)
+    nat.load_state_dict({k: v.to(BF) for k, v in ref.state_dict().items()}, strict=True)
+    torch.manual_seed(5)
+    ref_net = lora_ref.RefLoRANetwork(ref, r, network_type="lokr").to(dev)
+    torch.manual_seed(5)
+    net = FusedLoRANetwork(nat, lora_dim=r, alpha=r, network_type="lokr")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert not a.use_w2 and torch.equal(a.lokr_w1, b.lokr_w1.cpu()) and torch.equal(a.lokr_w2_a, b.lokr_w2_a.cpu())
+            wb = torch.randn(b.lokr_w2_b.shape, generator=g) * 0.1
+            b.lokr_w2_b.copy_(wb)
+            a.lokr_w2_b.copy_(wb)
+    ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena(dev, groups=nat.lora_groups())
+    net.refresh_shadows(ops)
+    nat.attach_network(net)
+    nat.prepare()
+    gb = torch.Generator().manual_seed(5)
+    Bn, Hl, Wl, n_txt = 2, 16, 12, 40
+    lat = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
+    emb = (torch.randn(Bn, n_txt, CFG["joint_attention_dim"], generator=gb) * 0.5).to(BF).to(dev)
+    pooled = (torch.randn(Bn, CFG["pooled_projection_dim"], generator=gb) * 0.5).to(BF).to(dev)
+    noise = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
+    ts = torch.tensor([700.0, 250.0], device=dev)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = {id(p): p.grad.clone() for p in oracle.params}
+    ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1.5e-3 * abs(loss32), (loss, loss32)
+    num = den = 0.0
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for k in ("lokr_w1", "lokr_w2_a", "lokr_w2_b"):
+            gr = g32[id(getattr(b, k))]
+            num += ((getattr(a, k).grad - gr) ** 2).sum().item()
+            den += (gr ** 2).sum().item()
+    e = math.sqrt(num / den)
+    print(f"low-rank lokr loss ours {loss:.6f} fp32 {loss32:.6f}; factor-gradient rel err {e:.3e}")
+    assert e < 2e-2, e
+    ours2 = FluxLoRATrainStep(nat, net, ops, lr=1e-3, max_grad_norm=1.0)
+    l0 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    l1 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert math.isfinite(l1) and l1 < l0, (l0, l1)

@@ -1,0 +1,177 @@
+"""Low-rank LoKr (`lokr_full_rank: false`; reference toolkit/models/lokr.py:184-197, 331-399): lokr_w2 = lokr_w2_a [out_k, r] @ lokr_w2_b [r, in_n].
+Oracle module and the fused network + host graph (oracle kernel table, fp32) against vectors produced by the reference's own
+LoRASpecialNetwork(network_type='lokr', lora_dim=4) (tests/golden/lokr_lowrank_flux_tiny.safetensors): shapes, init draws, forward,
+the three factor gradients, saved keys/values, merge_in; then two AdamW steps against the autograd oracle."""
+import json
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.flux import FluxTransformer2DModel
+from ai_toolkit_amd.lora import FusedLoRANetwork
+from ai_toolkit_amd.trainer import FluxLoRATrainStep
+from oracle import lora_ref, ref_ops, train_ref
+from tests.test_oracle_golden import G, TINY, oracle_model, tiny_inputs
+
+R = 4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    path = os.path.join(G, "lokr_lowrank_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    return load_file(path), meta
+
+
+def test_oracle_lowrank_lokr_matches_reference_network(gold):
+    t, meta = gold
+    model = oracle_model()
+    torch.manual_seed(99)
+    net = lora_ref.RefLoRANetwork(model, R, network_type="lokr")
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    assert [n for n, _ in net.unet_loras[0].named_parameters()] == meta["param_order"] == ["lokr_w1", "lokr_w2_a", "lokr_w2_b"]
+    for m in net.unet_loras:
+        assert not m.use_w2 and m.scale == meta["scale"]
+        assert [list(m.lokr_w1.shape), list(m.lokr_w2_a.shape), list(m.lokr_w2_b.shape)] == meta["shapes"][m.lora_name]
+        assert torch.equal(m.lokr_w1, t[f"init/{m.lora_name}/w1"]) and torch.equal(m.lokr_w2_a, t[f"init/{m.lora_name}/w2_a"]), m.lora_name
+        assert float(m.lokr_w2_b.abs().max()) == 0.0
+        with torch.no_grad():
+            m.lokr_w2_b.copy_(t[f"set/{m.lora_name}/w2_b"])
+    net.apply_to()
+    with net:
+        pred = model(*tiny_inputs())
+        (pred * t["fwd/w"]).sum().backward()
+    assert torch.allclose(pred, t["fwd/pred"], rtol=1e-5, atol=1e-6)
+    for m in net.unet_loras:
+        for k in ("w1", "w2_a", "w2_b"):
+            assert torch.allclose(getattr(m, f"lokr_{k}").grad, t[f"grad/{m.lora_name}/{k}"], rtol=2e-4, atol=2e-6), (m.lora_name, k)
+    sd = net.peft_state_dict(torch.float32)
+    assert list(sd.keys()) == meta["saved_keys"]
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+
+
+def native_pair():
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=R, alpha=2, network_type="lokr")
+    return ref, nat, net
+
+
+def _ready(net, nat, t=None):
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    if t is not None:
+        with torch.no_grad():
+            for m in net.unet_loras:
+                m.lokr_w2_b.copy_(t[f"set/{m.lora_name}/w2_b"])
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+
+
+def test_native_lowrank_lokr_network_and_host_graph_match_reference_vectors(gold, tmp_path):
+    t, meta = gold
+    ref, nat, net = native_pair()
+    assert [m.lora_name for m in net.unet_loras] == meta["names"]
+    for m in net.unet_loras:
+        assert [list(m.lokr_w1.shape), list(m.lokr_w2_a.shape), list(m.lokr_w2_b.shape)] == meta["shapes"][m.lora_name]
+        assert torch.equal(m.lokr_w1, t[f"init/{m.lora_name}/w1"]) and torch.equal(m.lokr_w2_a, t[f"init/{m.lora_name}/w2_a"]), m.lora_name
+        assert m.scale == meta["scale"]  # PEFT-format networks carry alpha = rank
+    _ready(net, nat, t)
+    m0 = net.unet_loras[0]
+    assert m0.lokr_w2_a.data_ptr() == net.arena_p.data_ptr() + 4 * m0.off_down  # the pair lives in the flat arena, a | b back to back
+    assert m0.lokr_w2_b.data_ptr() == m0.lokr_w2_a.data_ptr() + 4 * m0.lokr_w2_a.numel()
+    assert torch.allclose(m0.sh_down.float(), m0.lokr_w2_a @ m0.lokr_w2_b, atol=1e-6) and torch.equal(m0.sh_downT, m0.sh_down.t())
+    with net:
+        pred = nat.forward_native(*tiny_inputs())
+        assert torch.allclose(pred, t["fwd/pred"], rtol=1e-4, atol=1e-5)
+        net.zero_grad_arena()
+        nat.backward_native(t["fwd/w"].clone())
+    for m in net.unet_loras:
+        for k in ("w1", "w2_a", "w2_b"):
+            assert torch.allclose(getattr(m, f"lokr_{k}").grad, t[f"grad/{m.lora_name}/{k}"], rtol=3e-4, atol=1e-5), (m.lora_name, k)
+    f = str(tmp_path / "lokr_lr.safetensors")
+    net.save_weights(f, dtype=torch.float32)
+    sd = load_file(f)
+    assert sorted(sd.keys()) == sorted(meta["saved_keys"])
+    for k, v in sd.items():
+        assert torch.equal(v, t[f"saved/{k}"]), k
+    assert list(net.get_state_dict(dtype=torch.float32).keys()) == meta["saved_keys"]
+    before, shadow = net.arena_p.clone(), net.arena_shadow.clone()
+    net.arena_p.zero_()
+    assert net.load_weights(f) is None
+    assert torch.equal(net.arena_p, before) and torch.equal(net.arena_shadow, shadow)
+    params = net.prepare_optimizer_params(default_lr=1e-4)[0]["params"]
+    assert params[0] is m0.lokr_w1 and params[1] is m0.lokr_w2_a and params[2] is m0.lokr_w2_b
+    osd = net.optimizer_state_dict(3, 1e-4)
+    assert [tuple(osd["state"][i]["exp_avg"].shape) for i in range(3)] == [tuple(p.shape) for p in params[:3]]
+
+
+def test_lowrank_lokr_train_steps_match_autograd_oracle():
+    ref, nat, net = native_pair()
+    torch.manual_seed(99)
+    ref_net = lora_ref.RefLoRANetwork(ref, R, network_type="lokr")
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for b in ref_net.unet_loras:
+            b.lokr_w2_b.copy_(torch.randn(b.lokr_w2_b.shape, generator=g) * 0.2)
+    ref_net.apply_to()
+    _ready(net, nat)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            a.lokr_w1.copy_(b.lokr_w1)
+            a.lokr_w2_a.copy_(b.lokr_w2_a)
+            a.lokr_w2_b.copy_(b.lokr_w2_b)
+    net.refresh_shadows(ref_ops)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=0.5)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    for k in range(2):
+        gg = torch.Generator().manual_seed(70 + k)
+        lat = torch.randn(2, 16, 8, 4, generator=gg)
+        emb = torch.randn(2, 6, TINY["joint_attention_dim"], generator=gg) * 0.5
+        pooled = torch.randn(2, TINY["pooled_projection_dim"], generator=gg) * 0.5
+        noise = torch.randn(2, 16, 8, 4, generator=gg)
+        ts = torch.tensor([700.0, 250.0])
+        l_ref = oracle.step(lat, emb, pooled, noise, ts)
+        l = ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        assert abs(l.item() - l_ref.item()) <= 1e-4 * abs(l_ref.item()), (k, l.item(), l_ref.item())
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for k in ("lokr_w1", "lokr_w2_a", "lokr_w2_b"):
+            assert torch.allclose(getattr(a, k), getattr(b, k), rtol=2e-3, atol=2e-6), (a.lora_name, k)
+
+
+def test_lowrank_lokr_merge_in_equals_reference_merge_in(gold):
+    t, meta = gold
+    ref, nat, net = native_pair()
+    _ready(net, nat, t)
+    nat.prepare()
+    keys = [k[len("merged/"):] for k in t if k.startswith("merged/")]
+    assert len(keys) >= 2
+    mods = {m.lora_name: m for m in net.unet_loras}
+    before = {k: mods[k].org_module[0].weight.detach().clone() for k in keys}
+    net.merge_in(0.7, ops=ref_ops)
+    for k in keys:
+        lin = mods[k].org_module[0]
+        assert torch.allclose(lin.weight[:24], t[f"merged/{k}"], rtol=1e-5, atol=1e-6), k
+        assert torch.allclose(lin.weight_t, lin.weight.t(), rtol=1e-5, atol=1e-6), k
+    net.merge_out(0.7, ops=ref_ops)
+    for k in keys:
+        assert torch.allclose(mods[k].org_module[0].weight, before[k], rtol=1e-5, atol=1e-6)
+
+
+def test_full_and_lowrank_files_do_not_cross_load(tmp_path):
+    """a full-factor file carries `.lokr_w2`, a low-rank module has no such tensor: the keys come back as unmatched extras."""
+    _, nat, net = native_pair()
+    _ready(net, nat)
+    m0 = net.unet_loras[0]
+    base = m0.lora_name.replace("$$", ".")
+    extra = net.load_weights({f"{base}.lokr_w1": m0.lokr_w1.detach().clone(), f"{base}.lokr_w2": torch.zeros(m0.out_k, m0.in_n)})
+    assert list(extra.keys()) == [f"{base}.lokr_w2"]
