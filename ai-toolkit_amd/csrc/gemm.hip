@@ -14,6 +14,7 @@
 // Staging: STAGE=0 global->VGPR->LDS with the global loads issued before the MFMA phase (T14);
 //          STAGE=1 global_load_lds_dwordx4 (LDS-DMA, lane-linear destination, swizzle on the source address).
 // blockIdx -> tile: bijective XCD remap + grouped (8 row-tiles) ordering for per-XCD L2 reuse (T1).
+#include <cstdlib>
 #include "common.h"
 #include "aitk_args.h"
 
@@ -386,9 +387,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
 
 // gemm8.hip: persistent 8-phase kernel for big bf16 problems (returns 1 when the shape is outside its contract)
 extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st);
+extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, hipStream_t st);
 
-extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int gemm_check(const AitkGemmArgs* a);
+// smallest number of 256x256 output tiles for which the persistent 8-phase kernel (one workgroup per CU) is chosen over the 128x128
+// kernel (two workgroups per CU); AITK_BIG_TILES_MIN overrides it for A/B measurements
+static long big_tiles_min() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("AITK_BIG_TILES_MIN");
+    v = (e && atol(e) > 0) ? atol(e) : 192;
+  }
+  return v;
+}
+
+// Two independent problems C_i = epi(A_i B_i^T + A2_i B2_i^T + ...) with the same N, K, K2 and epilogue flags (e.g. the image- and
+// text-stream projections of a FLUX double block: different weights, adapters and row counts).  When together they fill the chip
+// they run as ONE persistent 8-phase launch whose tile list is the concatenation of both, so the small problem's tiles fill the
+// last, partly empty tile round of the big one; otherwise (or outside the 8-phase contract) the two are launched back to back.
+extern "C" int aitk_gemm_nt_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, aitk_stream_t stream_) {
+  int rc = gemm_check(a);
+  if (rc) return rc;
+  rc = gemm_check(b);
+  if (rc) return rc;
+  const bool same = a->N == b->N && a->K == b->K && a->K2 == b->K2 && a->flags == b->flags;
+  const bool plain = !a->conv_mode && !b->conv_mode && !a->b_scale_mode && !b->b_scale_mode && a->tile_mode == 0 && b->tile_mode == 0 &&
+                     a->stage_mode == 1 && b->stage_mode == 1;
+  const long t256 = (long)((a->M + 255) / 256 + (b->M + 255) / 256) * ((a->N + 255) / 256);
+  if (same && plain && a->N >= 512 && t256 >= big_tiles_min() && aitk_gemm8_try_launch_grouped(a, b, (hipStream_t)stream_) == AITK_OK) {
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
+  rc = aitk_gemm_nt(a, stream_);
+  return rc ? rc : aitk_gemm_nt(b, stream_);
+}
+
+static int gemm_check(const AitkGemmArgs* a) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return AITK_ERR_SHAPE;
   if ((a->K % 8) || (a->K2 % 8) || (a->N % 4)) return AITK_ERR_SHAPE;
   if ((a->lda % 8) || (a->ldb % 8) || (a->ldc % 4)) return AITK_ERR_ALIGN;
@@ -401,6 +435,13 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
   if (((uintptr_t)a->A | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
   if ((uintptr_t)a->B & (a->b_scale_mode ? 7 : 15)) return AITK_ERR_ALIGN;
+  return AITK_OK;
+}
+
+extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int chk = gemm_check(a);
+  if (chk) return chk;
   hipStream_t st = stream;
   if (a->conv_mode) {
     if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != 9 * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
@@ -445,7 +486,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   int big = a->tile_mode == 2 ? 1 : 0;
   if (a->tile_mode == 0) {
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    big = (a->M >= 1024 && a->N >= 512 && t256 >= 192) ? 1 : 0;
+    big = (a->M >= 1024 && a->N >= 512 && t256 >= big_tiles_min()) ? 1 : 0;
   }
   static bool attr_set = false;
   if (!attr_set) {

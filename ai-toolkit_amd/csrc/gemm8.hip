@@ -70,13 +70,20 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
   return o;
 }
 
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
+// GR: two problems in one launch (aitk_gemm_nt_grouped): same N, K, K2 and epilogue flags, different operands / M.  The tile list
+// is problem 0's tiles followed by problem 1's; a workgroup switches operand bases (buffer descriptors, row clamp, slab pointers)
+// when the tile it is STAGING changes problem, and epilogue arguments when the tile it is COMPUTING does.
+static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguous in the kernarg segment");
+template <bool GR>
+__device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int l31 = lane & 31, h = lane >> 5;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int ntiles = tiles_m * tiles_n;
+  const int nt1 = tiles_m * tiles_n;
+  const int tiles_m2 = GR ? (p2.M + BM - 1) / BM : 0;
+  const int ntiles = nt1 + tiles_m2 * tiles_n;
   const int nk1 = (p.K + BK - 1) / BK;
   const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
   const int nsteps = nk1 + nk2;   // >= 2 (launcher)
@@ -95,34 +102,60 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
 #else
   typedef const AitkGemmArgs* KArgsPtr;
 #endif
-  auto kargs = [&]() -> KArgsPtr {
+  auto kargs = [&](int prob = 0) -> KArgsPtr {
 #if defined(__HIP_DEVICE_COMPILE__)
     KArgsPtr q = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // constant address space: scalar loads
     asm volatile("" : "+s"(q));
-    return q;
+    return GR ? q + prob : q;
 #else
-    return &p;
+    return prob ? &p2 : &p;
 #endif
   };
   unsigned va[4], vb[4];  // byte offsets of this thread's chunk (K-tile 0) in A / B for the tile being STAGED
   int om0 = 0, on0 = 0;   // origin of that tile (the K-tail / LoRA-slab path recomputes its row offsets from it)
   int m0 = 0, n0 = 0;
-  auto tile_origin = [&](int v, int& tm0, int& tn0) {
-    const int lid = xcd_remap(v, ntiles);
+  int sM = p.M;   // row count of the problem being STAGED (row clamp of the A operand)
+  int sprob = 0;  // ... and its index (slab pointers)
+  auto tile_origin = [&](int v, int& tm0, int& tn0, int& prob) {
+    int lid = xcd_remap(v, ntiles);
+    int tmx = tiles_m;
+    prob = 0;
+    if (GR && lid >= nt1) {
+      lid -= nt1;
+      tmx = tiles_m2;
+      prob = 1;
+    }
     const int GROUP = 8;
     const int group_sz = GROUP * tiles_n;
     const int gid = lid / group_sz;
     const int first_m = gid * GROUP;
-    const int gm = min(tiles_m - first_m, GROUP);
+    const int gm = min(tmx - first_m, GROUP);
     tm0 = (first_m + (lid % group_sz) % gm) * BM;
     tn0 = ((lid % group_sz) / gm) * BN;
   };
-  auto a_row = [&](int i, int srow) { return min(om0 + (i & 1) * 128 + (i >> 1) * 64 + srow, p.M - 1); };
+  auto a_row = [&](int i, int srow) { return min(om0 + (i & 1) * 128 + (i >> 1) * 64 + srow, sM - 1); };
   auto b_row = [&](int i, int srow) { return min(on0 + ((srow >> 5) + 2 * (i & 1)) * 64 + (i >> 1) * 32 + (srow & 31), p.N - 1); };
-  auto set_offsets = [&](int tm0, int tn0) {
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  auto make_srd = [&](const void* ptr) {
+    const unsigned long long a = (unsigned long long)ptr;
+    v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+    r.z = (int)0x80000000u;
+    r.w = 0x00020000;
+    return r;
+  };
+  v4i srdA = make_srd(p.A), srdB = make_srd(p.B);
+  auto set_offsets = [&](int tm0, int tn0, int prob) {
     om0 = tm0;
     on0 = tn0;
-    KArgsPtr q = kargs();
+    KArgsPtr q = kargs(prob);
+    if (GR) {
+      sprob = prob;
+      sM = q->M;
+      srdA = make_srd(q->A);
+      srdB = make_srd(q->B);
+    }
     const int t_ = opaque_tid();
     const int srow = SROW(t_), cc = CC(t_);
 #pragma unroll
@@ -135,17 +168,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
   // Raw buffer descriptors (stride 0, 2 GiB window): LDS-DMA through buffer_load ... lds takes base (SGPRs) + 32-bit lane
   // offset (VGPR) + K offset (SGPR), and a lane whose offset is outside the window reads ZEROS — K tails, the narrow LoRA
   // slab and dead tiles need no zero page and no per-lane 64-bit pointers.
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  auto make_srd = [&](const void* ptr) {
-    const unsigned long long a = (unsigned long long)ptr;
-    v4i r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-    r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
-    r.z = (int)0x80000000u;
-    r.w = 0x00020000;
-    return r;
-  };
-  const v4i srdA = make_srd(p.A), srdB = make_srd(p.B);
   const unsigned OOB = 0x80000000u;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
@@ -178,10 +200,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
     for (int ii = 0; ii < 2; ++ii) {
       const int i = 2 * half + ii;
       unsigned voff;
-      if (second) voff = opnd ? ((unsigned)((long)b_row(i, srow) * p.ldb2) + cc * 8) * 2 : ((unsigned)((long)a_row(i, srow) * p.lda2) + cc * 8) * 2;
+      KArgsPtr qs = kargs(sprob);  // slab operands of the problem being staged
+      if (second) voff = opnd ? ((unsigned)((long)b_row(i, srow) * qs->ldb2) + cc * 8) * 2 : ((unsigned)((long)a_row(i, srow) * qs->lda2) + cc * 8) * 2;
       else voff = opnd ? vb[i] : va[i];
       if (!kvalid) voff = OOB;
-      if (second) dma(ldst + ii * (NT * 16), voff, make_srd(opnd ? (const void*)p.B2 : (const void*)p.A2), (unsigned)k0 * 2);
+      if (second) dma(ldst + ii * (NT * 16), voff, make_srd(opnd ? (const void*)qs->B2 : (const void*)qs->A2), (unsigned)k0 * 2);
       else dma(ldst + ii * (NT * 16), voff, opnd ? srdB : srdA, (unsigned)k0 * 2);
     }
   };
@@ -240,8 +263,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
 
   // ---- first output tile: offsets + the six prologue half-tiles (K-tile 0: A0 B0 B1 A1, K-tile 1: A0 B0)
   int vt = blockIdx.x;
-  tile_origin(vt, m0, n0);
-  set_offsets(m0, n0);
+  int cprob = 0;  // problem of the tile being COMPUTED (epilogue arguments)
+  tile_origin(vt, m0, n0, cprob);
+  set_offsets(m0, n0, cprob);
   int gk = 0;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
   stage_half(0, 0, 0, 0, false);
   stage_half(0, 0, 1, 0, false);
@@ -254,8 +278,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
   while (true) {
     const int vnext = vt + gridDim.x;
     const bool has_next = vnext < ntiles;
-    int m0n = 0, n0n = 0;
-    if (has_next) tile_origin(vnext, m0n, n0n);
+    int m0n = 0, n0n = 0, probn = 0;
+    if (has_next) tile_origin(vnext, m0n, n0n, probn);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
       // phase 2
       read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
       if (n2 && !switched) {  // every staging from here on belongs to the next output tile
-        if (has_next) set_offsets(m0n, n0n);
+        if (has_next) set_offsets(m0n, n0n, probn);
         switched = true;
       }
       stage_half(k2, buf2, 0, 0, n2 && !has_next);
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
     if (p.K == 7)
 #endif
     {
-      KArgsPtr q = kargs();
+      KArgsPtr q = kargs(cprob);
       const int flags = q->flags;
       int ln = lane;
       asm volatile("" : "+v"(ln));  // keep the epilogue's lane geometry out of the K loop's live set
@@ -454,6 +478,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
     vt = vnext;
     m0 = m0n;
     n0 = n0n;
+    cprob = probn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef VMCNT8
@@ -462,9 +487,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) {
 #undef BAR
 }
 
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) { gemm8_body<false>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true>(p, p2); }
+
 // Called by aitk_gemm_nt (gemm.hip) for big bf16 problems.  Returns AITK_OK after launching, or 1 when the shape is
 // outside this kernel's contract (caller falls back to the 2-barrier kernels).
-extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
+static int gemm8_contract(const AitkGemmArgs* a) {
   if (a->conv_mode || a->b_scale_mode) return 1;
   if ((a->K % 16) || (a->K2 % 16) || (a->N % 8) || (a->ldc % 8)) return 1;
   const int nsteps = (a->K + BK - 1) / BK + (a->K2 > 0 ? (a->K2 + BK - 1) / BK : 0);
@@ -474,20 +502,43 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if ((a->flags & AITK_EPI_GATE_RES) && ((a->ld_gate % 8) || (a->aux_out && (a->ld_aux_out % 8)))) return 1;
   if ((a->flags & AITK_EPI_BIAS) && ((uintptr_t)a->bias & 15)) return 1;
   if (((uintptr_t)a->aux_in | (uintptr_t)a->aux_out | (uintptr_t)a->gate | (uintptr_t)a->C) & 15) return 1;
+  return 0;
+}
+static int gemm8_cus() {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EPI_OFF + 32768) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EPI_OFF + 32768) != hipSuccess) {
       n_cu = 0;
-      return 1;
+      return 0;
     }
   }
+  return n_cu;
+}
+extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
+  if (gemm8_contract(a)) return 1;
+  const int n_cu = gemm8_cus();
+  if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
   hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  return AITK_OK;
+}
+// Two problems with equal N, K, K2 and flags in one persistent launch (aitk_gemm_nt_grouped); 1 = outside the contract.
+extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, hipStream_t st) {
+  if (gemm8_contract(a) || gemm8_contract(b)) return 1;
+  if (a->N != b->N || a->K != b->K || a->K2 != b->K2 || a->flags != b->flags) return 1;
+  const int n_cu = gemm8_cus();
+  if (!n_cu) return 1;
+  const int tn = (a->N + BN - 1) / BN;
+  const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   return AITK_OK;
 }

@@ -15,6 +15,7 @@ lora_wgrad straight into the flat fp32 gradient arena, all activations kept resi
 `ops` is the kernel table: ai_toolkit_amd.ops on MI355X.  Tests inject oracle/ref_ops.py (same signatures, plain
 torch) to check this host logic against autograd of the oracle on CPU; the product never does.
 """
+import functools
 import math
 from typing import Dict, List, Optional
 
@@ -255,7 +256,8 @@ class FluxTransformer2DModel(FusedGraphBase):
                        ("txt", x_txt, Mt, St, 0, blk.norm1_context,
                         (blk.attn.add_q_proj, blk.attn.add_k_proj, blk.attn.add_v_proj),
                         (blk.attn.norm_added_q, blk.attn.norm_added_k)))
-            for name, x, M, Ss, s_off, norm1, qkv_lins, qk_norms in streams:
+
+            def qkv_stream(name, x, M, Ss, s_off, norm1, qkv_lins, qk_norms):
                 r = {}
                 mod, r["T_mod"] = self._ada_fwd(norm1.linear, silu_temb, B)
                 r["mod"] = mod
@@ -272,11 +274,13 @@ class FluxTransformer2DModel(FusedGraphBase):
                 ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=Ss, S_dst=S, s_off=s_off)
                 r.update(x=x, mean1=mean, rstd1=rstd, xn=xn, qkv_raw=qkv_raw)
                 rec[name] = r
+
+            # image and text stream are independent up to the joint attention: their launches are merged, equal-shape GEMMs grouped
+            self._paired([functools.partial(qkv_stream, *st) for st in streams])
             ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], o_j, lse, B=B, H=H, S=S, scale=scale)
             rec.update(qkv_j=qkv_j, o_j=o_j, lse=lse)
             outs = {}
-            for name, M, Ss, s_off, out_lin, ff in (("img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
-                                                     ("txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)):
+            def mlp_stream(name, M, Ss, s_off, out_lin, ff):
                 r = rec[name]
                 mod, x = r["mod"], r["x"]
                 seg = (Ss, S * d)
@@ -297,6 +301,9 @@ class FluxTransformer2DModel(FusedGraphBase):
                                            aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss)
                 r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=hbuf, y_ff=y_ff)
                 outs[name] = x2
+
+            self._paired([functools.partial(mlp_stream, "img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
+                          functools.partial(mlp_stream, "txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)])
             x_img, x_txt = outs["img"], outs["txt"]
             if ctx is not None:
                 ctx["dbl"].append(rec)
@@ -428,8 +435,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             do_j = self._new(Mj, d)
             grads = {"img": dx_img, "txt": dx_txt}
             dmods, dx1s = {}, {}
-            for name, M, Ss, s_off, out_lin, ff in (("img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
-                                                     ("txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)):
+            def mlp_stream_bwd(name, M, Ss, s_off, out_lin, ff):
                 r = rec[name]
                 mod = r["mod"]
                 dx2 = grads[name]
@@ -448,15 +454,15 @@ class FluxTransformer2DModel(FusedGraphBase):
                 self._lin_bwd(out_lin, dy, r["T_o"], rec["o_j"][s_off:], do_j[s_off:], M=M, rows_per_batch=Ss, B=B,
                               x_seg=seg, dx_seg=seg)
                 dmods[name], dx1s[name] = dmod, dx1
+
+            self._paired([functools.partial(mlp_stream_bwd, "img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
+                          functools.partial(mlp_stream_bwd, "txt", Mt, St, 0, blk.attn.to_add_out, blk.ff_context)])
             qkv_j = rec["qkv_j"]
             dqkv_j = self._new(Mj, 3 * d)
             ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], rec["o_j"], rec["lse"], do_j,
                          dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_j[:, 2 * d:], B=B, H=H, S=S, scale=scale)
             new_grads = {}
-            for name, M, Ss, s_off, norm1, qkv_lins, qk_norms in (
-                    ("img", Mi, Si, St, blk.norm1, (blk.attn.to_q, blk.attn.to_k, blk.attn.to_v), (blk.attn.norm_q, blk.attn.norm_k)),
-                    ("txt", Mt, St, 0, blk.norm1_context, (blk.attn.add_q_proj, blk.attn.add_k_proj, blk.attn.add_v_proj),
-                     (blk.attn.norm_added_q, blk.attn.norm_added_k))):
+            def qkv_stream_bwd(name, M, Ss, s_off, norm1, qkv_lins, qk_norms):
                 r = rec[name]
                 mod, dmod = r["mod"], dmods[name]
                 qkv_raw = r["qkv_raw"]
@@ -473,6 +479,12 @@ class FluxTransformer2DModel(FusedGraphBase):
                                dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
                 self._ada_bwd(norm1.linear, dmod, r["T_mod"], silu_temb, B)
                 new_grads[name] = dx0
+
+            self._paired([functools.partial(qkv_stream_bwd, "img", Mi, Si, St, blk.norm1, (blk.attn.to_q, blk.attn.to_k, blk.attn.to_v),
+                                            (blk.attn.norm_q, blk.attn.norm_k)),
+                          functools.partial(qkv_stream_bwd, "txt", Mt, St, 0, blk.norm1_context,
+                                            (blk.attn.add_q_proj, blk.attn.add_k_proj, blk.attn.add_v_proj),
+                                            (blk.attn.norm_added_q, blk.attn.norm_added_k))])
             dx_img, dx_txt = new_grads["img"], new_grads["txt"]
             rec.clear()
         if self.grad_ready_hook is not None:

@@ -7,6 +7,8 @@ GEMM), the same-input group launches, and the small-batch (GEMV) modulation proj
 model's op graph.  `ops` is the kernel table: ai_toolkit_amd.ops on MI355X; tests inject oracle/ref_ops.py (same
 signatures, plain torch) to check the host logic against autograd of the oracle on CPU; the product never does.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -127,6 +129,24 @@ class FusedGraphBase(nn.Module):
 
     def dequantized_weight(self, lin):
         return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)
+
+    # ------------------------------------------------------------------ paired launches of two independent streams
+    pair_streams = os.environ.get("AITK_PAIR_STREAMS", "1") != "0"
+
+    def _paired(self, bodies):
+        """Run two independent op sequences (callables; e.g. the image and the text stream of a double block).  On the MI355X table
+        their kernel launches are recorded and merged so that GEMMs of equal shape go out as one grouped persistent launch
+        (ops.replay_paired); each sequence keeps its own order.  The fp8 base shares ONE dequantisation scratch between layers,
+        which would be overwritten under the merged order: sequential there."""
+        if not self.pair_streams or getattr(self, "is_quantized", False) or len(bodies) != 2 or not hasattr(self.ops, "recording"):
+            return [b() for b in bodies]
+        outs, recs = [], []
+        for b in bodies:
+            with self.ops.recording() as launches:
+                outs.append(b())
+            recs.append(launches)
+        self.ops.replay_paired(*recs)
+        return outs
 
     # ------------------------------------------------------------------ helpers
     def _new(self, *shape, dtype=None):

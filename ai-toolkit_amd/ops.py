@@ -17,6 +17,77 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+# ---------------------------------------------------------------------------------------------------------- launch plumbing
+# Every wrapper ends in _call(name, *args): the C entry point is invoked on the current stream — or, while `recording()`, appended to
+# a launch list.  Two launch lists of independent work (the image and the text stream of a FLUX double block) are merged by
+# `replay_paired`: each list keeps its own order, and whenever both are about to launch a GEMM the two go out as ONE
+# aitk_gemm_nt_grouped call (one persistent 8-phase launch when they are compatible, back-to-back launches otherwise).
+_REC = None
+_gemm_hook = None  # bench.py: fn(e0, e1, flops, shapes) called with events around every aitk_gemm_nt / aitk_gemm_nt_grouped launch
+
+
+def _gemm_shape(ref):
+    g = ref._obj
+    return (g.M, g.N, g.K, g.K2, g.flags)
+
+
+def _emit(name, args):
+    if name == "_keepalive":
+        return
+    timed = _gemm_hook is not None and name in ("aitk_gemm_nt", "aitk_gemm_nt_grouped")
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _capi.check(getattr(_capi.lib(), name)(*args, _capi.stream_ptr()), name)
+    if timed:
+        e1.record()
+        shapes = tuple(_gemm_shape(a) for a in args)
+        _gemm_hook(e0, e1, sum(2.0 * m * n * (k + k2) for m, n, k, k2, _ in shapes), shapes if len(shapes) > 1 else shapes[0])
+
+
+def _call(name, *args):
+    if _REC is not None:
+        _REC.append((name, args))
+        return
+    _emit(name, args)
+
+
+class recording:
+    """`with ops.recording() as launches:` — wrappers called inside enqueue nothing; `launches` is handed to replay_paired."""
+
+    def __enter__(self):
+        global _REC
+        assert _REC is None, "recording() does not nest"
+        self.launches = _REC = []
+        return self.launches
+
+    def __exit__(self, *exc):
+        global _REC
+        _REC = None
+        return False
+
+
+def replay_paired(a, b):
+    """Launch two recorded lists of mutually independent work; GEMMs that meet are grouped."""
+    i = j = 0
+    while i < len(a) or j < len(b):
+        while i < len(a) and a[i][0] != "aitk_gemm_nt":
+            _emit(*a[i])
+            i += 1
+        while j < len(b) and b[j][0] != "aitk_gemm_nt":
+            _emit(*b[j])
+            j += 1
+        if i < len(a) and j < len(b):
+            _emit("aitk_gemm_nt_grouped", (a[i][1][0], b[j][1][0]))
+            i, j = i + 1, j + 1
+        elif i < len(a):
+            _emit(*a[i])
+            i += 1
+        elif j < len(b):
+            _emit(*b[j])
+            j += 1
+
+
 def _row_major(t, name):
     assert t.dtype == BF16, f"{name}: expected bf16, got {t.dtype}"
     assert t.dim() == 2 and t.stride(1) == 1, f"{name}: need 2-D row-major view, got {tuple(t.shape)} strides {t.stride()}"
@@ -79,7 +150,7 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     g.M, g.N, g.K, g.flags = M, N, K, flags
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
     g.tile_mode = TILE_MODE if tile_mode is None else tile_mode
-    _capi.check(_capi.lib().aitk_gemm_nt(C.byref(g), _capi.stream_ptr()), "aitk_gemm_nt")
+    _call("aitk_gemm_nt", C.byref(g))
     return out
 
 
@@ -93,6 +164,8 @@ def workspace(nbytes, device, tag="ws"):
     n = (nbytes + 3) // 4
     t = _ws.get(key)
     if t is None or t.numel() < n:
+        if t is not None and _REC is not None:
+            _REC.append(("_keepalive", (t,)))  # recorded launches may still point into the buffer being replaced
         t = torch.empty(max(n, 1), dtype=torch.float32, device=device)
         _ws[key] = t
     return t
@@ -127,7 +200,7 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
         a.mult, a.rows_per_batch = _ptr(mult), rows_per_batch
     a.scale = float(scale)
     a.M, a.K, a.R = (x.shape[0] if M is None else M), K, R
-    _capi.check(_capi.lib().aitk_lora_down(C.byref(a), _capi.stream_ptr()), "aitk_lora_down")
+    _call("aitk_lora_down", C.byref(a))
     return out
 
 
@@ -154,7 +227,7 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
     a.S, a.G, a.partial, a.out = _ptr(s), _ptr(g), _ptr(ws), _ptr(out)
     a.accumulate = int(accumulate)
     a.M, a.R, a.L = M, R, L
-    _capi.check(_capi.lib().aitk_lora_wgrad(C.byref(a), _capi.stream_ptr()), "aitk_lora_wgrad")
+    _call("aitk_lora_wgrad", C.byref(a))
     return out
 
 
@@ -169,7 +242,7 @@ def ln_mod_fwd(x, shift, scale, out, *, rows_per_batch, mean=None, rstd=None, ep
     a.mean, a.rstd = _ptr(mean), _ptr(rstd)
     a.eps, a.rows_per_batch = eps, rows_per_batch
     a.M, a.C = x.shape
-    _capi.check(_capi.lib().aitk_ln_mod_fwd(C.byref(a), _capi.stream_ptr()), "aitk_ln_mod_fwd")
+    _call("aitk_ln_mod_fwd", C.byref(a))
     return out
 
 
@@ -180,7 +253,7 @@ def colsum_finish(partial, nchunk, B, V, Cc, out0, out1=None):
     if out1 is not None:
         assert _row_major(out1, "out1") == a.ld_out
     a.B, a.nchunk, a.V, a.C = B, nchunk, V, Cc
-    _capi.check(_capi.lib().aitk_colsum_finish(C.byref(a), _capi.stream_ptr()), "aitk_colsum_finish")
+    _call("aitk_colsum_finish", C.byref(a))
 
 
 def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, dscale=None):
@@ -198,7 +271,7 @@ def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, d
         part = workspace(B * nchunk * 2 * Cc * 4, x.device, "colsum")
         a.partial = _ptr(part)
     a.S, a.B, a.C = S, B, Cc
-    _capi.check(_capi.lib().aitk_ln_mod_bwd(C.byref(a), _capi.stream_ptr()), "aitk_ln_mod_bwd")
+    _call("aitk_ln_mod_bwd", C.byref(a))
     if dshift is not None:
         colsum_finish(part, nchunk, B, 2, Cc, dshift, dscale)
     return dx
@@ -214,12 +287,12 @@ def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
     if y is None:
         assert dgate is None
         a.ld_y = 8
-        _capi.check(_capi.lib().aitk_gate_bwd(C.byref(a), _capi.stream_ptr()), "aitk_gate_bwd")
+        _call("aitk_gate_bwd", C.byref(a))
         return dy
     nchunk = (S + rows_per_block() - 1) // rows_per_block()
     part = workspace(B * nchunk * Cc * 4, dx.device, "colsum")
     a.y, a.ld_y, a.partial = _ptr(y), _row_major(y, "y"), _ptr(part)
-    _capi.check(_capi.lib().aitk_gate_bwd(C.byref(a), _capi.stream_ptr()), "aitk_gate_bwd")
+    _call("aitk_gate_bwd", C.byref(a))
     colsum_finish(part, nchunk, B, 1, Cc, dgate)
     return dy
 
@@ -245,13 +318,13 @@ def _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps):
 def qkv_post_fwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
     """jobs: dicts {src [B*S_src, >=H*128], dst [B*S_dst, >=H*128], weight [128] or None (= plain copy)}."""
     a = _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps)
-    _capi.check(_capi.lib().aitk_qkv_post_fwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_fwd")
+    _call("aitk_qkv_post_fwd", C.byref(a))
 
 
 def qkv_post_bwd(jobs, cos, sin, *, B, H, S_src, S_dst, s_off, eps=1e-6):
     """jobs: {src: raw-side grad (written), dst: joint-side grad (read), weight, raw: forward input}."""
     a = _qkv_args(jobs, cos, sin, B, H, S_src, S_dst, s_off, eps)
-    _capi.check(_capi.lib().aitk_qkv_post_bwd(C.byref(a), _capi.stream_ptr()), "aitk_qkv_post_bwd")
+    _call("aitk_qkv_post_bwd", C.byref(a))
 
 
 def ew(op, x, y, a=None, alpha=1.0, a_rows_per_batch=0):
@@ -265,14 +338,14 @@ def ew(op, x, y, a=None, alpha=1.0, a_rows_per_batch=0):
         g.a, g.lda = _ptr(a), _row_major(a, "a")
     g.rows, g.C = x.shape
     g.op = op
-    _capi.check(_capi.lib().aitk_ew(C.byref(g), _capi.stream_ptr()), "aitk_ew")
+    _call("aitk_ew", C.byref(g))
     return y
 
 
 def timestep_embed(t, out, tscale=1.0):
     assert t.dtype == torch.float32 and out.dtype == BF16 and out.is_contiguous()
     B, dim = out.shape
-    _capi.check(_capi.lib().aitk_timestep_embed(_ptr(t), _ptr(out), B, dim, float(tscale), _capi.stream_ptr()), "aitk_timestep_embed")
+    _call("aitk_timestep_embed", _ptr(t), _ptr(out), B, dim, float(tscale))
     return out
 
 
@@ -280,8 +353,8 @@ def copy_rows(dst, src):
     """dst[:, :] = src[:, :] for 2-D views with unit inner stride (strided rows) via hipMemcpy2DAsync."""
     assert dst.shape == src.shape and dst.dtype == src.dtype and dst.stride(1) == 1 and src.stride(1) == 1
     es = dst.element_size()
-    _capi.check(_capi.lib().aitk_copy2d(_ptr(dst), dst.stride(0) * es, _ptr(src), src.stride(0) * es,
-                                        dst.shape[1] * es, dst.shape[0], _capi.stream_ptr()), "aitk_copy2d")
+    _call("aitk_copy2d", _ptr(dst), dst.stride(0) * es, _ptr(src), src.stride(0) * es,
+                                        dst.shape[1] * es, dst.shape[0])
     return dst
 
 
@@ -298,7 +371,7 @@ def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0):
 def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0):
     """q,o: [B*S, >=H*128]; k,v: [B*Skv, >=H*128] bf16 views (row stride = token stride); lse [B,H,S] fp32."""
     a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
-    _capi.check(_capi.lib().aitk_attn_fwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_fwd")
+    _call("aitk_attn_fwd", C.byref(a))
     return o
 
 
@@ -309,7 +382,7 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
     a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")
     delta = workspace(B * H * S * 4, q.device, "attn_delta")
     a.delta = _ptr(delta)
-    _capi.check(_capi.lib().aitk_attn_bwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_bwd")
+    _call("aitk_attn_bwd", C.byref(a))
 
 
 def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scale=None):
@@ -326,7 +399,7 @@ def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scal
     if col_scale is not None:
         assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == a.N
         a.col_scale = _ptr(col_scale)
-    _capi.check(_capi.lib().aitk_gemv_nt(C.byref(a), _capi.stream_ptr()), "aitk_gemv_nt")
+    _call("aitk_gemv_nt", C.byref(a))
     return out
 
 
@@ -337,7 +410,7 @@ def flow_noise_pack(latents, noise, t, noisy, target):
     assert latents.dtype == BF16 and noise.dtype == BF16 and t.dtype == torch.float32
     a.latents, a.noise, a.t, a.noisy, a.target = _ptr(latents), _ptr(noise), _ptr(t), _ptr(noisy), _ptr(target)
     a.B, a.C, a.H, a.W = latents.shape
-    _capi.check(_capi.lib().aitk_flow_noise_pack(C.byref(a), _capi.stream_ptr()), "aitk_flow_noise_pack")
+    _call("aitk_flow_noise_pack", C.byref(a))
 
 
 def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None):
@@ -354,7 +427,7 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=
     if mask is not None:
         assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * (n // pred.shape[-1]) * 4
         a.mask, a.feat = _ptr(mask), pred.shape[-1]
-    _capi.check(_capi.lib().aitk_mse_loss_grad(C.byref(a), _capi.stream_ptr()), "aitk_mse_loss_grad")
+    _call("aitk_mse_loss_grad", C.byref(a))
 
 
 def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
@@ -371,7 +444,7 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     a.bias_correction1 = 1.0 - beta1 ** step
     a.bias_correction2_sqrt = (1.0 - beta2 ** step) ** 0.5
     a.max_norm, a.ema_decay, a.grad_scale = max_norm, ema_decay, grad_scale
-    _capi.check(_capi.lib().aitk_adamw_ema_step(C.byref(a), _capi.stream_ptr()), "aitk_adamw_ema_step")
+    _call("aitk_adamw_ema_step", C.byref(a))
 
 
 def make_shadow_table(entries, device):
@@ -393,14 +466,12 @@ def lokr_lowrank_grad(dw, a, b, ga, gb, *, accumulate=True):
     for t in (dw, a, b, ga, gb):
         assert t.dtype == torch.float32 and t.is_contiguous()
     assert tuple(a.shape) == (O, r) == tuple(ga.shape) and tuple(b.shape) == (r, I) == tuple(gb.shape)
-    _capi.check(_capi.lib().aitk_lokr_lowrank_grad(_ptr(dw), _ptr(a), _ptr(b), _ptr(ga), _ptr(gb), O, I, r, int(accumulate),
-                                                   _capi.stream_ptr()), "aitk_lokr_lowrank_grad")
+    _call("aitk_lokr_lowrank_grad", _ptr(dw), _ptr(a), _ptr(b), _ptr(ga), _ptr(gb), O, I, r, int(accumulate))
 
 
 def refresh_shadows(arena, shadow, table):
     tab, n = table
-    _capi.check(_capi.lib().aitk_lora_refresh_shadows(_ptr(arena), _ptr(shadow), _ptr(tab), n, _capi.stream_ptr()),
-                "aitk_lora_refresh_shadows")
+    _call("aitk_lora_refresh_shadows", _ptr(arena), _ptr(shadow), _ptr(tab), n)
 
 
 # ---------------------------------------------------------------------------------------------------------- VAE encoder
@@ -437,7 +508,7 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     g.conv_mode, g.conv_H, g.conv_W, g.conv_Cin = 1, H, W, Cin
     g.conv_Wo, g.conv_HoWo, g.conv_stride, g.conv_pad_t, g.conv_pad_l = Wo, Ho * Wo, stride, pad_t, pad_l
     g.zero_page = _ptr(_zero_page(x.device))
-    _capi.check(_capi.lib().aitk_gemm_nt(C.byref(g), _capi.stream_ptr()), "aitk_gemm_nt(conv)")
+    _call("aitk_gemm_nt", C.byref(g))
     return out
 
 
@@ -453,28 +524,28 @@ def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False, stats_o
     ws = workspace(_capi.lib().aitk_groupnorm_workspace_bytes(B, HW, Cc, G), x.device, "groupnorm")
     a.partial = _ptr(ws)
     a.eps, a.silu, a.B, a.HW, a.C, a.G = eps, int(silu), B, HW, Cc, G
-    _capi.check(_capi.lib().aitk_groupnorm(C.byref(a), _capi.stream_ptr()), "aitk_groupnorm")
+    _call("aitk_groupnorm", C.byref(a))
     return out
 
 
 def softmax_rows(x, scale):
     ld = _row_major(x, "x")
-    _capi.check(_capi.lib().aitk_softmax_rows(_ptr(x), ld, x.shape[0], x.shape[1], float(scale), _capi.stream_ptr()), "aitk_softmax_rows")
+    _call("aitk_softmax_rows", _ptr(x), ld, x.shape[0], x.shape[1], float(scale))
     return x
 
 
 def image_to_nhwc8(img, out):
     B, Cc, H, W = img.shape
     assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and out.shape == (B * H * W, 8)
-    _capi.check(_capi.lib().aitk_image_to_nhwc8(_ptr(img), _ptr(out), B, H, W, _capi.stream_ptr()), "aitk_image_to_nhwc8")
+    _call("aitk_image_to_nhwc8", _ptr(img), _ptr(out), B, H, W)
     return out
 
 
 def latent_sample(moments, eps, out, *, scale, shift):
     B, L, h, w = out.shape
     assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == out.shape and out.is_contiguous()
-    _capi.check(_capi.lib().aitk_latent_sample(_ptr(moments), _row_major(moments, "moments"), _ptr(eps), _ptr(out), B, L, h * w,
-                                               float(scale), float(shift), _capi.stream_ptr()), "aitk_latent_sample")
+    _call("aitk_latent_sample", _ptr(moments), _row_major(moments, "moments"), _ptr(eps), _ptr(out), B, L, h * w,
+                                               float(scale), float(shift))
     return out
 
 
@@ -490,14 +561,14 @@ def _rms_full_args(x, weight, y, cos, sin, S, eps):
 def rms_full_fwd(x, weight, y, *, S, cos=None, sin=None, eps=1e-6):
     """y = rope(RMSNorm_C(x) * weight): norm across all heads of a token (C = H*128), rope on (2i,2i+1) pairs per head."""
     a = _rms_full_args(x, weight, y, cos, sin, S, eps)
-    _capi.check(_capi.lib().aitk_rms_full_fwd(C.byref(a), _capi.stream_ptr()), "aitk_rms_full_fwd")
+    _call("aitk_rms_full_fwd", C.byref(a))
     return y
 
 
 def rms_full_bwd(g, x, weight, dx, *, S, cos=None, sin=None, eps=1e-6):
     a = _rms_full_args(x, weight, dx, cos, sin, S, eps)
     a.g, a.ldg = _ptr(g), _row_major(g, "g")
-    _capi.check(_capi.lib().aitk_rms_full_bwd(C.byref(a), _capi.stream_ptr()), "aitk_rms_full_bwd")
+    _call("aitk_rms_full_bwd", C.byref(a))
     return dx
 
 
@@ -510,7 +581,7 @@ def dora_colscale(w2, tw, up, gram, mag, s, c_out):
     assert w2.dtype == torch.float32 and mag.dtype == torch.float32 and c_out.dtype == torch.float32 and tw.dtype == BF16
     a.w2, a.tw, a.ldtw, a.up, a.gram, a.mag, a.c = _ptr(w2), _ptr(tw), tw.stride(0), _ptr(up), _ptr(gram), _ptr(mag), _ptr(c_out)
     a.s, a.N, a.R = float(s), N, R
-    _capi.check(_capi.lib().aitk_dora_colscale(C.byref(a), _capi.stream_ptr()), "aitk_dora_colscale")
+    _call("aitk_dora_colscale", C.byref(a))
     return c_out
 
 
@@ -524,7 +595,7 @@ def dora_bwd(dy, y, c, bias, mag, dz, dmag, *, M):
     part = workspace(2 * nchunk * N * 4, dz.device, "dora_bwd")
     a.c, a.bias, a.mag, a.dmag, a.partial = _ptr(c), _ptr(bias), _ptr(mag), _ptr(dmag), _ptr(part)
     a.M, a.N = M, N
-    _capi.check(_capi.lib().aitk_dora_bwd(C.byref(a), _capi.stream_ptr()), "aitk_dora_bwd")
+    _call("aitk_dora_bwd", C.byref(a))
     return dz
 
 
@@ -549,7 +620,7 @@ def kron_apply(x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale=1.0, transpose_
     a.a_in, a.b_in, a.a_out, a.b_out = a_in, b_in, a_out, b_out
     assert out.shape[1] == (ncols if ncols else a_out * b_out)
     a.transpose_out, a.accumulate, a.col0, a.ncols, a.scale = int(transpose_out), int(accumulate), col0, ncols, float(scale)
-    _capi.check(_capi.lib().aitk_kron_apply(C.byref(a), _capi.stream_ptr()), "aitk_kron_apply")
+    _call("aitk_kron_apply", C.byref(a))
     return out
 
 
@@ -558,8 +629,8 @@ def kron_merge(W, A, Bm, alpha):
     assert W.dtype == BF16 and W.dim() == 2 and W.stride(1) == 1
     assert A.dtype == torch.float32 and Bm.dtype == torch.float32 and A.is_contiguous() and Bm.is_contiguous()
     assert W.shape[0] == A.shape[0] * Bm.shape[0] and W.shape[1] == A.shape[1] * Bm.shape[1]
-    _capi.check(_capi.lib().aitk_kron_merge(_ptr(W), W.stride(0), _ptr(A), _ptr(Bm), A.shape[0], A.shape[1], Bm.shape[0], Bm.shape[1],
-                                            float(alpha), _capi.stream_ptr()), "aitk_kron_merge")
+    _call("aitk_kron_merge", _ptr(W), W.stride(0), _ptr(A), _ptr(Bm), A.shape[0], A.shape[1], Bm.shape[0], Bm.shape[1],
+                                            float(alpha))
     return W
 
 
@@ -567,8 +638,7 @@ def dequant_fp8(q, scale, mode, out):
     """out (bf16 [rows, cols]) = e4m3(q) * scale (per row: mode 1, per column: mode 2)."""
     assert q.element_size() == 1 and q.dim() == 2 and q.stride(1) == 1 and out.dtype == BF16 and out.shape == q.shape and out.stride(1) == 1
     assert scale.dtype == torch.float32 and scale.numel() == (q.shape[0] if mode == 1 else q.shape[1])
-    _capi.check(_capi.lib().aitk_dequant_fp8(_ptr(q), q.stride(0), _ptr(scale), mode, _ptr(out), out.stride(0), q.shape[0], q.shape[1],
-                                             _capi.stream_ptr()), "aitk_dequant_fp8")
+    _call("aitk_dequant_fp8", _ptr(q), q.stride(0), _ptr(scale), mode, _ptr(out), out.stride(0), q.shape[0], q.shape[1])
     return out
 
 
@@ -585,7 +655,7 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, dx, *, B, HW, G=32, silu=False, dre
     ws = workspace(_capi.lib().aitk_groupnorm_bwd_workspace_bytes(B, HW, Cc, G), x.device, "groupnorm_bwd")
     a.partial = _ptr(ws)
     a.silu, a.B, a.HW, a.C, a.G = int(silu), B, HW, Cc, G
-    _capi.check(_capi.lib().aitk_groupnorm_bwd(C.byref(a), _capi.stream_ptr()), "aitk_groupnorm_bwd")
+    _call("aitk_groupnorm_bwd", C.byref(a))
     return dx
 
 
@@ -593,16 +663,15 @@ def geglu_fwd(hg, out):
     """out[M, F] = hg[:, :F] * gelu_erf(hg[:, F:])  (diffusers GEGLU)."""
     M, F2 = hg.shape
     assert out.shape == (M, F2 // 2)
-    _capi.check(_capi.lib().aitk_geglu_fwd(_ptr(hg), _row_major(hg, "hg"), _ptr(out), _row_major(out, "out"), M, F2 // 2, _capi.stream_ptr()),
-                "aitk_geglu_fwd")
+    _call("aitk_geglu_fwd", _ptr(hg), _row_major(hg, "hg"), _ptr(out), _row_major(out, "out"), M, F2 // 2)
     return out
 
 
 def geglu_bwd(dy, hg, dhg):
     M, F2 = hg.shape
     assert dy.shape == (M, F2 // 2) and dhg.shape == hg.shape
-    _capi.check(_capi.lib().aitk_geglu_bwd(_ptr(dy), _row_major(dy, "dy"), _ptr(hg), _row_major(hg, "hg"), _ptr(dhg), _row_major(dhg, "dhg"),
-                                           M, F2 // 2, _capi.stream_ptr()), "aitk_geglu_bwd")
+    _call("aitk_geglu_bwd", _ptr(dy), _row_major(dy, "dy"), _ptr(hg), _row_major(hg, "hg"), _ptr(dhg), _row_major(dhg, "dhg"),
+                                           M, F2 // 2)
     return dhg
 
 
@@ -611,7 +680,7 @@ def resample2x(src, dst, *, B, H, W, mode):
     Cc = src.shape[1]
     assert src.is_contiguous() and dst.is_contiguous() and src.dtype == BF16 and dst.dtype == BF16 and src.shape[0] == B * H * W
     assert dst.shape == ((B * (H // 2) * (W // 2), Cc) if mode == 1 else (B * 4 * H * W, Cc))
-    _capi.check(_capi.lib().aitk_resample2x(_ptr(src), _ptr(dst), B, H, W, Cc, mode, _capi.stream_ptr()), "aitk_resample2x")
+    _call("aitk_resample2x", _ptr(src), _ptr(dst), B, H, W, Cc, mode)
     return dst
 
 
@@ -619,8 +688,7 @@ def copy_heads(src, dst, *, H, d_src, d_dst):
     """dst[m, h*d_dst + j] = src[m, h*d_src + j] (j < d_src) else 0, j < d_dst."""
     M = src.shape[0]
     assert dst.shape[0] == M and src.shape[1] >= H * d_src and dst.shape[1] >= H * d_dst
-    _capi.check(_capi.lib().aitk_copy_heads(_ptr(src), _row_major(src, "src"), _ptr(dst), _row_major(dst, "dst"), M, H, d_src, d_dst,
-                                            _capi.stream_ptr()), "aitk_copy_heads")
+    _call("aitk_copy_heads", _ptr(src), _row_major(src, "src"), _ptr(dst), _row_major(dst, "dst"), M, H, d_src, d_dst)
     return dst
 
 
@@ -633,14 +701,14 @@ def ddpm_noise_nhwc(latents, noise, a, s, noisy, target, *, v_prediction=False):
     assert noisy.shape[0] == B * h * w and target.shape == (B * h * w, Cc)
     g.latents, g.noise, g.a, g.s, g.noisy, g.target = _ptr(latents), _ptr(noise), _ptr(a), _ptr(s), _ptr(noisy), _ptr(target)
     g.B, g.C, g.HW, g.Cp, g.mode = B, Cc, h * w, noisy.shape[1], int(v_prediction)
-    _capi.check(_capi.lib().aitk_ddpm_noise_nhwc(C.byref(g), _capi.stream_ptr()), "aitk_ddpm_noise_nhwc")
+    _call("aitk_ddpm_noise_nhwc", C.byref(g))
 
 
 def attn_small_fwd(q, k, v, o, lse, *, B, H, S, D, scale, Skv=0):
     """generic attention (head_dim D > 128): q, o [B*S, >= H*D]; k, v [B*Skv, >= H*D]; lse [B,H,S] natural log."""
     a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
     a.D = D
-    _capi.check(_capi.lib().aitk_attn_small_fwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_small_fwd")
+    _call("aitk_attn_small_fwd", C.byref(a))
     return o
 
 
@@ -651,4 +719,4 @@ def attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, D, scale, Skv=0)
     a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
     a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")
     a.delta = _ptr(workspace(B * H * S * 4, q.device, "attn_delta"))
-    _capi.check(_capi.lib().aitk_attn_small_bwd(C.byref(a), _capi.stream_ptr()), "aitk_attn_small_bwd")
+    _call("aitk_attn_small_bwd", C.byref(a))

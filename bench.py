@@ -125,32 +125,12 @@ def bench_unet(args, dev):
         except Exception as ex:
             graph = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     recs = []
-    og, oc = ops.gemm_nt, ops.conv3x3
-
-    def tg(a, b, out, **kw):
-        M = kw.get("M") or a.shape[0]
-        K2 = kw["a2"].shape[1] if kw.get("a2") is not None else 0
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = og(a, b, out, **kw)
-        e1.record()
-        recs.append((e0, e1, 2.0 * M * b.shape[0] * (b.shape[1] + K2)))
-        return r
-
-    def tc(x, w, out, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = oc(x, w, out, **kw)
-        e1.record()
-        recs.append((e0, e1, 2.0 * out.shape[0] * w.shape[0] * w.shape[1]))
-        return r
-
-    ops.gemm_nt, ops.conv3x3 = tg, tc
+    ops._gemm_hook = lambda e0, e1, flops, shapes: recs.append((e0, e1, flops))
     try:
         one()
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.conv3x3 = og, oc
+        ops._gemm_hook = None
     ms = sum(a.elapsed_time(b) for a, b, _ in recs)
     fl = sum(f for _, _, f in recs)
     name = "SDXL UNet LoRA r8 @1024^2" if kind == "sdxl" else "SD1.5 UNet LoRA r4 @512^2"
@@ -172,27 +152,19 @@ def bench_unet(args, dev):
 
 def gemm_roofline(step_fn, ops_mod):
     """One extra instrumented step: HIP events (torch's current stream = the stream every kernel is launched on) around
-    each launch of the dominant kernel (gemm_nt); algorithmic FLOPs = 2 M N (K + K2) per launch."""
+    each launch of the dominant kernel (aitk_gemm_nt / aitk_gemm_nt_grouped, hooked where ops.py invokes the C entry point);
+    algorithmic FLOPs = 2 M N (K + K2) per problem."""
     recs = []
-    orig = ops_mod.gemm_nt
 
-    def timed(a, b, out, **kw):
-        M = kw.get("M") or a.shape[0]
-        N, K = b.shape
-        K2 = kw["a2"].shape[1] if kw.get("a2") is not None else 0
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(a, b, out, **kw)
-        e1.record()
-        recs.append((e0, e1, 2.0 * M * N * (K + K2), (M, N, K, K2, kw.get("flags", 0))))
-        return r
+    def hook(e0, e1, flops, shapes):
+        recs.append((e0, e1, flops, shapes))
 
-    ops_mod.gemm_nt = timed
+    ops_mod._gemm_hook = hook
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        ops_mod.gemm_nt = orig
+        ops_mod._gemm_hook = None
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
     fl = sum(f for _, _, f, _ in recs)
     by_shape = {}
@@ -201,8 +173,12 @@ def gemm_roofline(step_fn, ops_mod):
         d[0] += 1
         d[1] += e0.elapsed_time(e1)
         d[2] += f
-    census = sorted(({"M": k[0], "N": k[1], "K": k[2], "K2": k[3], "flags": k[4], "calls": v[0], "ms": round(v[1], 2),
-                      "tflops": round(v[2] / v[1] / 1e9, 1)} for k, v in by_shape.items()), key=lambda r: -r["ms"])
+    def label(k):  # one problem (M, N, K, K2, flags) or a grouped pair of them
+        probs = k if isinstance(k[0], tuple) else (k,)
+        return {"M": "+".join(str(q[0]) for q in probs), "N": probs[0][1], "K": probs[0][2], "K2": probs[0][3], "flags": probs[0][4]}
+
+    census = sorted((dict(label(k), calls=v[0], ms=round(v[1], 2), tflops=round(v[2] / v[1] / 1e9, 1)) for k, v in by_shape.items()),
+                    key=lambda r: -r["ms"])
     return {"launches": len(recs), "gemm_ms_per_step": ms, "gemm_flop_per_step": fl, "avg_launch_us": 1e3 * ms / max(1, len(recs)),
             "tflops": fl / ms / 1e9 if ms > 0 else 0.0, "census": census}
 

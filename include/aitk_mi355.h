@@ -74,6 +74,11 @@ typedef struct AitkGemmArgs {
 int aitk_abi_version(void);
 int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */
 int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
+/* Two independent problems in one call (e.g. the image- and text-stream projections of a FLUX double block:
+ * transformer_blocks.N.attn.to_q / add_q_proj — different weights, adapters and row counts).  With equal N, K, K2 and flags, and big
+ * enough together, they run as ONE persistent launch whose tile list is the concatenation of both (the small problem fills the big
+ * one's partly empty last tile round); otherwise they are launched back to back.  Results are bitwise those of two aitk_gemm_nt calls. */
+int aitk_gemm_nt_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, aitk_stream_t stream);
 
 
 /*
