@@ -391,12 +391,14 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
 
 static int gemm_check(const AitkGemmArgs* a);
 // smallest number of 256x256 output tiles for which the persistent 8-phase kernel (one workgroup per CU) is chosen over the 128x128
-// kernel (two workgroups per CU); AITK_BIG_TILES_MIN overrides it for A/B measurements
+// kernel (two workgroups per CU); AITK_BIG_TILES_MIN overrides it for A/B measurements.  128 = half the chip: measured on the SDXL
+// step (its 8192 x 1280 token GEMMs are 160 tiles) 579 -> 688 TFLOP/s over all GEMM + conv launches against the old value 192, and
+// +1.6 % on the FLUX step without stream pairing (text-stream GEMMs, 168 tiles); 96 is no better (profiles/r02_notes_grouped_gemm.md)
 static long big_tiles_min() {
   static long v = -1;
   if (v < 0) {
     const char* e = getenv("AITK_BIG_TILES_MIN");
-    v = (e && atol(e) > 0) ? atol(e) : 192;
+    v = (e && atol(e) > 0) ? atol(e) : 128;
   }
   return v;
 }

@@ -19,6 +19,7 @@
 // Both are HBM-bound (they stream X / dY once); MFMA is used only because the contraction is matmul-shaped.
 // The contraction of wgrad runs over the ROW index of row-major tiles, so both operands are consumed through
 // ds_read_b64_tr_b16 (hardware transpose read; lane mapping verified by aitk_probe_tr16).
+#include <cstdlib>
 #include "common.h"
 #include "aitk_args.h"
 
@@ -149,8 +150,11 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // One workgroup = 32 rows, wave w contracts K-quarter w; partials combined through LDS in a fixed order.
 // RB = number of 16-wide rank blocks (R <= 16*RB <= 64).
 // ------------------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
+// U = k-steps (of 32) whose loads are in flight before the first MFMA.  RB = 1 (one rank-16 adapter, 95 % of the launches of a FLUX
+// step) runs with U = 6: 116 VGPRs -> 4 waves per SIMD -> all 1008 workgroups of a 32256-row launch are resident at once (U = 8 needs
+// 132 VGPRs -> 3 per SIMD -> 768 slots -> a second, one-third-full round).
+template <int RB, int U>
+__global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p) {
   __shared__ __attribute__((aligned(16))) float red[4 * RB * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -170,7 +174,6 @@ __global__ __launch_bounds__(256) void lora_down16_kernel(AitkLoraDownArgs p) {
     for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int ksteps = p.K / 32;
   const int kbeg = (ksteps * wave) / 4, kend = (ksteps * (wave + 1)) / 4;
-  constexpr int U = RB <= 2 ? 8 : 4;  // k-steps in flight
   int ks = kbeg;
   for (; ks + U <= kend; ks += U) {
     s16x8_t xa[U][2], pa[U][RB];
@@ -265,10 +268,16 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->R % a->split_rp)))) return AITK_ERR_ARG;
   const int grid = (a->M + 31) / 32;
   if (a->K % 32 == 0) {
-    if (a->R <= 16) hipLaunchKernelGGL(lora_down16_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->R <= 32) hipLaunchKernelGGL(lora_down16_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->R <= 48) hipLaunchKernelGGL(lora_down16_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL(lora_down16_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    static int u1 = 0;  // AITK_LORA_DOWN_U=8 selects the 3-waves-per-SIMD variant (A/B measurements)
+    if (!u1) {
+      const char* e = getenv("AITK_LORA_DOWN_U");
+      u1 = (e && atoi(e) == 8) ? 8 : 6;
+    }
+    if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 32) hipLaunchKernelGGL((lora_down16_kernel<2, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 48) hipLaunchKernelGGL((lora_down16_kernel<3, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((lora_down16_kernel<4, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   } else if (a->R <= 32)
     hipLaunchKernelGGL(lora_down_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else

@@ -14,7 +14,13 @@ STAGE_MODE = int(os.environ.get("AITK_GEMM_STAGE", "1"))  # 1 = LDS-DMA staging 
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    if t is None:
+        return C.c_void_p(0)
+    if _REC is not None:
+        # deferred launch: the tensor must outlive the recording — a temporary freed inside one stream's body could otherwise be
+        # handed by the allocator to the OTHER stream's body, whose kernels may run first in the merged order
+        _REC.append(("_keepalive", (t,)))
+    return C.c_void_p(t.data_ptr())
 
 
 # ---------------------------------------------------------------------------------------------------------- launch plumbing
@@ -68,7 +74,11 @@ class recording:
 
 
 def replay_paired(a, b):
-    """Launch two recorded lists of mutually independent work; GEMMs that meet are grouped."""
+    """Launch two recorded lists of mutually independent work; GEMMs that meet are grouped.  `_keepalive` entries hold every tensor a
+    recorded launch points to until the caller drops the lists, i.e. until everything has been enqueued on the stream."""
+    a_all, b_all = a, b
+    a = [e for e in a_all if e[0] != "_keepalive"]
+    b = [e for e in b_all if e[0] != "_keepalive"]
     i = j = 0
     while i < len(a) or j < len(b):
         while i < len(a) and a[i][0] != "aitk_gemm_nt":

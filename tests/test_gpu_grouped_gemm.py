@@ -45,7 +45,7 @@ def test_grouped_launch_is_bitwise_two_single_launches(M1, M2, N, K, r, gate):
             kw["aux_out"].fill_(float("nan"))
         with ops.recording() as rec:
             ops.gemm_nt(x, w, o, **kw)
-        assert len(rec) == 1 and rec[0][0] == "aitk_gemm_nt"
+        assert [e[0] for e in rec if e[0] != "_keepalive"] == ["aitk_gemm_nt"]
         recs.append(rec)
         got.append(o)
     ops.replay_paired(*recs)
