@@ -396,7 +396,13 @@ def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
 
 
 def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scale=None):
-    """out[Bm,N] (+)= x[Bm,K] @ w[N,K]^T + bias + t[Bm,R] @ bl[N,R]^T   (Bm <= 8)."""
+    """out[Bm,N] (+)= x[Bm,K] @ w[N,K]^T + bias + t[Bm,R] @ bl[N,R]^T.  The kernel takes Bm <= 8 rows per launch (weight streaming);
+    more rows go out in chunks of 8."""
+    if x.shape[0] > 8:
+        for r0 in range(0, x.shape[0], 8):
+            gemv_nt(x[r0:r0 + 8], w, out[r0:r0 + 8], bias=bias, t=None if t is None else t[r0:r0 + 8], bl=bl, accumulate=accumulate,
+                    col_scale=col_scale)
+        return out
     a = _capi.GemvArgs()
     a.ldx, a.ldw, a.ldo = _row_major(x, "x"), _row_major(w, "w"), _row_major(out, "out")
     a.X, a.W, a.out, a.bias = _ptr(x), _ptr(w), _ptr(out), _ptr(bias)

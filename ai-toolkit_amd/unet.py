@@ -587,7 +587,7 @@ class UNet2DConditionModel(FusedGraphBase):
         return y
 
     def _embed(self, proj_in, emb):
-        """TimestepEmbedding: linear_2(silu(linear_1(x)))  (small-batch projections, B <= 8 rows)."""
+        """TimestepEmbedding: linear_2(silu(linear_1(x)))  (small-batch projections: weight-streaming GEMV, 8 rows per launch)."""
         ops = self.ops
         B = proj_in.shape[0]
         h1 = self._new(B, emb.linear_1.out_features)
@@ -604,8 +604,6 @@ class UNet2DConditionModel(FusedGraphBase):
         ops, dt, cfg = self.ops, self.dt, self.config
         if not self._prepared:
             self.prepare()
-        if B > 8:
-            raise NotImplementedError("per-GPU batch > 8: the time-embedding projections use the small-batch GEMV (split the batch)")
         tape = _Tape(ops, save_for_backward and self.network is not None and self.network.is_active)
         c0 = cfg["block_out_channels"][0]
         # ---- time embedding (no trainable ancestor)

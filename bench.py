@@ -305,8 +305,8 @@ def gpu_comparator(dev, rank, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AITK_BENCH_BATCH", "0")),
                     help="per-GPU batch; 0 = 7 when the GPU has >= 252 GiB free (244 GiB peak; 7 x 4608 rows = 126 row tiles make the "
                          "N=3072 GEMMs 5.9 tile rounds on 256 CUs instead of 3.4 at batch 4), else 4 (157 GiB)")
