@@ -94,7 +94,9 @@ def bench_unet(args, dev):
     kind = args.model
     model, net, ops = build_unet(dev, kind, rank=args.rank if args.rank != 16 else (8 if kind == "sdxl" else 4))
     step = UNetLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, seed=1000)
-    B = args.batch if args.batch > 0 else 8  # the time-embedding projections take <= 8 rows per launch
+    # batch sweep on one MI355X (profiles/r02_bench_unet_*.json): SDXL 28.4 / 31.7 / 31.1 img/s at B = 8 / 12 / 16 (12 x 1024 tokens = 240 tiles
+    # of 256^2 at the 32x32 level: 94 % of one tile round); SD1.5 105 / 139 / 159 img/s at B = 8 / 16 / 32
+    B = args.batch if args.batch > 0 else (12 if kind == "sdxl" else 32)
     side = 128 if kind == "sdxl" else 64
     gen = torch.Generator(device=dev).manual_seed(42)
     lat = torch.randn(B, 4, side, side, device=dev, generator=gen).to(torch.bfloat16)
