@@ -453,7 +453,8 @@ def main():
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
                 with open(os.environ["AITK_GEMM_CENSUS"], "w") as fh:
                     json.dump(rf["census"], fh, indent=0)
-            out["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt: gemm_nt_8phase_kernel (big problems) + gemm_nt_kernel<1,128,128> "
+            out["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt / aitk_gemm_nt_grouped: gemm_nt_8phase_kernel, gemm_nt_8phase_grouped_kernel "
+                                                         "(image+text stream of the double blocks in one launch), gemm_nt_kernel<1,128,128> "
                                                          "(LoRA-fused bf16 GEMM, all launches of one step)",
                                "achieved": rf["tflops"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": rf["tflops"] / PEAK_BF16,
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
