@@ -203,6 +203,10 @@ __device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& h
 // Online softmax with deferred rescale (guide T13, threshold 2^8): O/l are only rescaled when the running max grows by
 // more than 8 in the log2 domain; P is then bounded by 2^8 instead of 1, exact in fp32 accumulation.
 #define ATTN_DEFER_THR 8.0f
+// KS = 16-wide contraction steps of Q K^T that carry data, DB = 32-wide output column blocks of P V that carry data: heads narrower than
+// the 128-column layout (UNet head_dim 40 / 64 / 80, stored zero-padded — AitkAttnArgs.Dv) skip the all-zero steps and blocks.  The
+// tiles keep their 128-column layouts; the skipped output columns are written as zeros, exactly what the padded computation yields.
+template <int KS, int DB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (row-major, swizzled) at b*FBUF, V tile (sub-tiled) at +16384
@@ -217,16 +221,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
 
-  s16x8_t qf[8];
+  s16x8_t qf[KS];
   {
     const int qr = min(q0 + l31, S - 1);
     const bf16_t* qp = Qb + (long)qr * p.ldq + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const s16x8_t*>(qp + 16 * ks);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const s16x8_t*>(qp + 16 * ks);
   }
-  f32x16_t o[4];
+  f32x16_t o[DB];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) o[d] = zero16();
+  for (int d = 0; d < DB; ++d) o[d] = zero16();
   float m_run = -INFINITY, l_run = 0.f;  // m_run in the scaled log2 domain
   const float c2 = p.scale * 1.4426950408889634f;
 
@@ -249,13 +253,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int j = 0; j < 2; ++j) {
       s[j] = zero16();
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        s16x8_t kfr[4];
+      for (int hh = 0; hh < (KS + 3) / 4; ++hh) {
+        constexpr int NU = 4;
+        s16x8_t kfr[NU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) kfr[u] = frag_rm_sw(ktc, 32 * j, 16 * (4 * hh + u), lane);
+        for (int u = 0; u < NU; ++u)
+          if (4 * hh + u < KS) kfr[u] = frag_rm_sw(ktc, 32 * j, 16 * (4 * hh + u), lane);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s[j] = mfma32(kfr[u], qf[4 * hh + u], s[j]);
+        for (int u = 0; u < NU; ++u)
+          if (4 * hh + u < KS) s[j] = mfma32(kfr[u], qf[4 * hh + u], s[j]);
       }
     }
     const int kv0 = t * 64;
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
       m_run = m_new;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int kk = 0; kk < 4; ++kk) {
       const s16x8_t pf = pack_acc8(s[kk >> 1], 8 * (kk & 1));
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = mfma32(frag_tr_perm_st(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
+      for (int d = 0; d < DB; ++d) o[d] = mfma32(frag_tr_perm_st(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
     }
     __syncthreads();
   }
@@ -309,9 +316,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        uint2 u;
-        u.x = pack2bf(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
-        u.y = pack2bf(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+        uint2 u = make_uint2(0u, 0u);
+        if (d < DB) {
+          u.x = pack2bf(o[d < DB ? d : 0][4 * g + 0] * inv, o[d < DB ? d : 0][4 * g + 1] * inv);
+          u.y = pack2bf(o[d < DB ? d : 0][4 * g + 2] * inv, o[d < DB ? d : 0][4 * g + 3] * inv);
+        }
         *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * h) = u;
       }
     if (h == 0) p.LSE[((long)b * p.H + hd) * S + q] = m_run + log2f(l_tot);
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AitkAttnArgs p) {
 // loops over query tiles of 32 rows staged (Q, dO, L2, delta) in LDS.
 // S[q][kv] = Q K^T (lane owns one kv column), P = exp2(S c2 - L2[q]), dP = dO V^T, dS = P (dP - delta[q]);
 // dV += P^T dO, dK += scale * dS^T Q  (Q/dO consumed via tr16 with the permuted order of the packed P / dS registers).
+template <int KS, int DB>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const sm = (lds_char*)smem;  // buffer b: Q tile (sub-tiled) at b*2*ST, dO tile at +ST; stats at 4*ST + b*512
@@ -364,20 +374,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const float* Lb = p.LSE + ((long)b * p.H + hd) * S;
   const float* Db = p.delta + ((long)b * p.H + hd) * S;
 
-  s16x8_t kf[8], vf[8];
+  s16x8_t kf[KS], vf[KS];
   {
     const int kr = min(kvw + l31, Skv - 1);
     const bf16_t* kp = Kb + (long)kr * p.ldk + 8 * h;
     const bf16_t* vp = Vb + (long)kr * p.ldv + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       kf[ks] = *reinterpret_cast<const s16x8_t*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const s16x8_t*>(vp + 16 * ks);
     }
   }
-  f32x16_t dk[4], dv[4];
+  f32x16_t dk[DB], dv[DB];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) {
+  for (int d = 0; d < DB; ++d) {
     dk[d] = zero16();
     dv[d] = zero16();
   }
@@ -413,16 +423,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
     for (int sub = 0; sub < 2; ++sub) {
       f32x16_t s, dp;
 #pragma unroll
-      for (int hk = 0; hk < 2; ++hk) {  // two batches of 4 k-steps: 32 fragment registers instead of 64
+      for (int hk = 0; hk < (KS + 3) / 4; ++hk) {  // batches of 4 k-steps: 32 fragment registers instead of 64
         s16x8_t qa[4], da[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+          if (4 * hk + ks >= KS) continue;
           qa[ks] = frag_rm_st(qtc, 32 * sub, 16 * (4 * hk + ks), lane);
           da[ks] = frag_rm_st(dotc, 32 * sub, 16 * (4 * hk + ks), lane);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+          if (4 * hk + ks >= KS) continue;
           // inline asm pins the register classes: S / dP accumulate in arch VGPRs (the softmax VALU reads them), the
           // loop-invariant K / V fragments sit in AccVGPRs.  Left to the allocator (389 registers, 1 wave per SIMD) S / dP
           // land in AccVGPRs time-shared with dK: 128 v_accvgpr_read/write per iteration.
@@ -446,11 +458,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         const int hq = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15, lh = (i & 3) >> 1;
         const unsigned tlo = (unsigned)(size_t)qtc + gq * SUBP + (i & 1) * 8 + (4 * hq + (i >> 2)) * 32 + (lh << 4);
         const unsigned thi = tlo + 8 * 32 + ((lh ^ 1) - lh) * 16;
-#define TRQ(KK, D)                                                                                   \
-  tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dlo[4 * KK + D], tlo);               \
-  tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dhi[4 * KK + D], thi);               \
-  tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qlo[4 * KK + D], tlo);                    \
-  tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qhi[4 * KK + D], thi);
+#define TRQ(KK, D)                                                                                     \
+  if constexpr (D < DB) {                                                                              \
+    tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dlo[4 * KK + D], tlo);               \
+    tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dhi[4 * KK + D], thi);               \
+    tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qlo[4 * KK + D], tlo);                    \
+    tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qhi[4 * KK + D], thi);                    \
+  }
 #define TRQ8() TRQ(0, 0) TRQ(0, 1) TRQ(0, 2) TRQ(0, 3) TRQ(1, 0) TRQ(1, 1) TRQ(1, 2) TRQ(1, 3)
         if (sub == 0) {
 #define SUBI 0
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         const s16x8_t pf = pack_acc8(s, 8 * kk);
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < DB; ++d) {
           dv[d] = mfma32(pf, join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);
           dk[d] = mfma32(df, join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);
         }
@@ -505,8 +519,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
       const int kv = kvw + crow(r, h);
       if (kv < Skv) {
         const long off = ((long)b * Skv + kv);
-        p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = f2bf(dk[d][r] * p.scale);
-        p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = f2bf(dv[d][r]);
+        p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = d < DB ? f2bf(dk[d < DB ? d : 0][r] * p.scale) : (bf16_t)0;
+        p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = d < DB ? f2bf(dv[d < DB ? d : 0][r]) : (bf16_t)0;
       }
     }
 }
@@ -515,6 +529,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 // grid (ceil(S/128), H, B); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
 // loops over KV tiles of 64 rows (K, V row-major in LDS).  S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP^T - delta[q]);
 // dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q]  (K through tr16, dS^T straight from registers).
+template <int KS, int DB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (sub-tiled: b128 + tr16 reads) at b*DBUF, V tile (row-major) after it
@@ -530,21 +545,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
   const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
   const int qr = min(q0 + l31, S - 1);
-  s16x8_t qf[8], gf[8];
+  s16x8_t qf[KS], gf[KS];
   {
     const bf16_t* qp = Qb + (long)qr * p.ldq + 8 * h;
     const bf16_t* gp = dOb + (long)qr * p.lddo + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       qf[ks] = *reinterpret_cast<const s16x8_t*>(qp + 16 * ks);
       gf[ks] = *reinterpret_cast<const s16x8_t*>(gp + 16 * ks);
     }
   }
   const float L2 = p.LSE[((long)b * p.H + hd) * S + qr];
   const float dl = p.delta[((long)b * p.H + hd) * S + qr];
-  f32x16_t dq[4];
+  f32x16_t dq[DB];
 #pragma unroll
-  for (int d = 0; d < 4; ++d) dq[d] = zero16();
+  for (int d = 0; d < DB; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (Skv + 63) / 64;
   glds_subtile64(sm, Kb, p.ldk, 0, Skv, wave, lane);
@@ -563,16 +578,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
     for (int j = 0; j < 2; ++j) {
       f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
+      for (int hh = 0; hh < (KS + 1) / 2; ++hh) {
         s16x8_t kfr[2], vfr[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+          if (2 * hh + u >= KS) continue;
           kfr[u] = frag_rm_st(ktc, 32 * j, 16 * (2 * hh + u), lane);
           vfr[u] = frag_rm_sw(vtc, 32 * j, 16 * (2 * hh + u), lane);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+          if (2 * hh + u >= KS) continue;
           s = mfma32(kfr[u], qf[2 * hh + u], s);
           dp = mfma32(vfr[u], gf[2 * hh + u], dp);
         }
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
       for (int kk = 0; kk < 2; ++kk) {
         const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma32(frag_tr_perm_st(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+        for (int d = 0; d < DB; ++d) dq[d] = mfma32(frag_tr_perm_st(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
       }
     }
     __syncthreads();
@@ -599,9 +616,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        uint2 u;
-        u.x = pack2bf(dq[d][4 * g + 0] * p.scale, dq[d][4 * g + 1] * p.scale);
-        u.y = pack2bf(dq[d][4 * g + 2] * p.scale, dq[d][4 * g + 3] * p.scale);
+        uint2 u = make_uint2(0u, 0u);
+        if (d < DB) {
+          u.x = pack2bf(dq[d < DB ? d : 0][4 * g + 0] * p.scale, dq[d < DB ? d : 0][4 * g + 1] * p.scale);
+          u.y = pack2bf(dq[d < DB ? d : 0][4 * g + 2] * p.scale, dq[d < DB ? d : 0][4 * g + 3] * p.scale);
+        }
         *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * h) = u;
       }
   }
@@ -609,22 +628,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
 
 static int attn_check(const AitkAttnArgs* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->S <= 0 || a->D != 128) return AITK_ERR_SHAPE;
+  if (a->Dv < 0 || a->Dv > 128) return AITK_ERR_SHAPE;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8)) return AITK_ERR_ALIGN;
   return AITK_OK;
+}
+
+// (KS, DB) instantiation for a valid head width Dv inside the 128-column layout: KS = ceil(Dv / 16), DB = ceil(Dv / 32)
+// 0: 128 (8, 4)   1: <= 96 (6, 3)   2: <= 80 (5, 3)   3: <= 64 (4, 2)   4: <= 48 (3, 2)
+static int attn_variant(int Dv) {
+  if (Dv <= 0 || Dv > 96) return 0;
+  if (Dv > 80) return 1;
+  if (Dv > 64) return 2;
+  if (Dv > 48) return 3;
+  return 4;
+}
+
+template <int KS, int DB>
+static void launch_fwd(const AitkAttnArgs* a, hipStream_t s) {
+  const size_t lds = 2 * (16384 + SUBTILE_BYTES);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  hipLaunchKernelGGL((attn_fwd_kernel<KS, DB>), grid, dim3(256), lds, s, *a);
+}
+
+template <int KS, int DB>
+static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
+  const int Skv = a->Skv > 0 ? a->Skv : a->S;
+  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
+  const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
+  const size_t lds2 = 2 * (16384 + SUBTILE_BYTES);
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KS, DB>), grid_kv, dim3(256), lds1, s, *a);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), lds2, s, *a);
 }
 
 extern "C" int aitk_attn_fwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   int rc = attn_check(a);
   if (rc) return rc;
   if (!a->Q || !a->K || !a->V || !a->O || !a->LSE) return AITK_ERR_ARG;
-  const size_t lds = 2 * (16384 + SUBTILE_BYTES);
-  static bool fattr = false;
-  if (!fattr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    fattr = true;
+  hipStream_t s = (hipStream_t)stream;
+  switch (attn_variant(a->Dv)) {
+    case 1: launch_fwd<6, 3>(a, s); break;
+    case 2: launch_fwd<5, 3>(a, s); break;
+    case 3: launch_fwd<4, 2>(a, s); break;
+    case 4: launch_fwd<3, 2>(a, s); break;
+    default: launch_fwd<8, 4>(a, s); break;
   }
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
@@ -638,24 +697,13 @@ extern "C" int aitk_attn_bwd(const AitkAttnArgs* a, aitk_stream_t stream) {
   const long npairs = (long)a->B * a->S * a->H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((npairs + 15) / 16)), dim3(256), 0, s, *a);
   AITK_LAUNCH_CHECK();
-  const int Skv = a->Skv > 0 ? a->Skv : a->S;
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
-  dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
-  const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    attr_set = true;
+  switch (attn_variant(a->Dv)) {
+    case 1: launch_bwd<6, 3>(a, s); break;
+    case 2: launch_bwd<5, 3>(a, s); break;
+    case 3: launch_bwd<4, 2>(a, s); break;
+    case 4: launch_bwd<3, 2>(a, s); break;
+    default: launch_bwd<8, 4>(a, s); break;
   }
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid_kv, dim3(256), lds1, s, *a);
-  AITK_LAUNCH_CHECK();
-  const size_t lds2 = 2 * (16384 + SUBTILE_BYTES);
-  static bool qattr = false;
-  if (!qattr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    qattr = true;
-  }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), lds2, s, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

@@ -368,9 +368,10 @@ def copy_rows(dst, src):
     return dst
 
 
-def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0):
+def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0, dv=0):
     a = _capi.AttnArgs()
     a.Skv = Skv
+    a.Dv = dv  # valid head width inside the 128-column layout (0 = 128)
     a.Q, a.K, a.V, a.O, a.LSE = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
     a.ldq, a.ldk, a.ldv, a.ldo = _row_major(q, "q"), _row_major(k, "k"), _row_major(v, "v"), _row_major(o, "o")
     assert lse.dtype == torch.float32 and lse.numel() == B * H * S
@@ -378,15 +379,16 @@ def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0):
     return a
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0):
-    """q,o: [B*S, >=H*128]; k,v: [B*Skv, >=H*128] bf16 views (row stride = token stride); lse [B,H,S] fp32."""
-    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0):
+    """q,o: [B*S, >=H*128]; k,v: [B*Skv, >=H*128] bf16 views (row stride = token stride); lse [B,H,S] fp32.  dv: heads narrower than
+    128 are stored zero-padded to 128 columns; the kernels then skip the all-zero parts (exactly the padded result)."""
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dv)
     _call("aitk_attn_fwd", C.byref(a))
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
-    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv)
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0):
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dvalid)
     a.dO, a.lddo = _ptr(do), _row_major(do, "do")
     a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
     a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")

@@ -439,7 +439,7 @@ class UNet2DConditionModel(FusedGraphBase):
             else:
                 qp, kp, vp = q, k, v
             op_ = self._new(Mq, H * PAD_D)
-            ops.attn_fwd(qp, kp, vp, op_, lse, B=B, H=H, S=Sq, scale=scale, Skv=kvn)
+            ops.attn_fwd(qp, kp, vp, op_, lse, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dv=d if d != PAD_D else 0)
             if d != PAD_D:
                 o = self._new(Mq, dim)
                 ops.copy_heads(op_, o, H=H, d_src=PAD_D, d_dst=d)
@@ -466,7 +466,7 @@ class UNet2DConditionModel(FusedGraphBase):
                 else:
                     dop = do
                 dqp, dkp, dvp = self._new(Mq, H * PAD_D), self._new(Mk, H * PAD_D), self._new(Mk, H * PAD_D)
-                ops.attn_bwd(qp, kp, vp, op_, lse, dop, dqp, dkp, dvp, B=B, H=H, S=Sq, scale=scale, Skv=kvn)
+                ops.attn_bwd(qp, kp, vp, op_, lse, dop, dqp, dkp, dvp, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dvalid=d if d != PAD_D else 0)
                 if d != PAD_D:
                     dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
                     for s_, d_ in ((dqp, dq), (dkp, dk), (dvp, dv)):

@@ -223,6 +223,8 @@ typedef struct AitkAttnArgs {
   aitk_bf16* dQ; aitk_bf16* dK; aitk_bf16* dV; int64_t lddq, lddk, lddv;
   float* delta;
   float scale; int32_t B, H, S, D, Skv; /* Skv: key/value rows per batch (0 = S); cross-attention has Skv != S */
+  int32_t Dv, _r0; /* Dv: valid head width inside the 128-column layout (0 = 128): UNet heads of 40 / 64 / 80 are stored zero-padded; the
+                      all-zero contraction steps and output blocks are skipped, the padded output columns are written as zeros */
 } AitkAttnArgs;
 int aitk_attn_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
 int aitk_attn_bwd(const AitkAttnArgs* args, aitk_stream_t stream);

@@ -249,7 +249,7 @@ def _heads(t, B, S, H):
     return t[: B * S, : H * 128].reshape(B, S, H, 128).transpose(1, 2).float()
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0):
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0):
     """F.scaled_dot_product_attention (toolkit/models/flux_sage_attn.py:76; chroma/src/math.py:27; cross-attention:
     toolkit/models/wan21/wan_attn.py:67-75)."""
     Skv = Skv or S
@@ -261,7 +261,7 @@ def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0):
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0):
     Skv = Skv or S
     qf = _heads(q, B, S, H).requires_grad_(True)
     kf = _heads(k, B, Skv, H).requires_grad_(True)

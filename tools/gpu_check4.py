@@ -134,7 +134,9 @@ def t_attn_small(B=2, H=8, S=256, D=160, Skv=0):
 
 
 def t_attn_padded(B=2, H=10, S=1000, D=64, Skv=77):
-    """head_dim 64 / 40 / 80 through the head_dim-128 flash kernels by zero padding == attention at the true head_dim."""
+    """head_dim 64 / 40 / 80 through the head_dim-128 flash kernels by zero padding == attention at the true head_dim; run twice: with the
+    full 128-wide kernels and with the `dv` variants that skip the all-zero contraction steps / output blocks — the two must agree bit for
+    bit on the valid columns (same MFMA sequence on the non-zero data) and both leave exact zeros in the padded columns."""
     kv = Skv or S
     q = R(B * S, H * D, s=0.5, seed=1).to(bf).to(dev)
     k = R(B * kv, H * D, s=0.5, seed=2).to(bf).to(dev)
@@ -144,11 +146,17 @@ def t_attn_padded(B=2, H=10, S=1000, D=64, Skv=77):
     pads = [torch.empty(t.shape[0], H * 128, dtype=bf, device=dev) for t in (q, k, v, do)]
     for s_, d_ in zip((q, k, v, do), pads):
         ops.copy_heads(s_, d_, H=H, d_src=D, d_dst=128)
-    op_ = torch.empty(B * S, H * 128, dtype=bf, device=dev)
-    lse = torch.empty(B, H, S, device=dev)
-    ops.attn_fwd(pads[0], pads[1], pads[2], op_, lse, B=B, H=H, S=S, scale=sc, Skv=Skv)
-    gp = [torch.empty_like(pads[0]), torch.empty_like(pads[1]), torch.empty_like(pads[2])]
-    ops.attn_bwd(pads[0], pads[1], pads[2], op_, lse, pads[3], *gp, B=B, H=H, S=S, scale=sc, Skv=Skv)
+    runs = {}
+    for dvv in (0, D):
+        op_ = torch.full((B * S, H * 128), float("nan"), dtype=bf, device=dev)
+        lse = torch.empty(B, H, S, device=dev)
+        ops.attn_fwd(pads[0], pads[1], pads[2], op_, lse, B=B, H=H, S=S, scale=sc, Skv=Skv, dv=dvv)
+        gp = [torch.full_like(pads[0], float("nan")), torch.full_like(pads[1], float("nan")), torch.full_like(pads[2], float("nan"))]
+        ops.attn_bwd(pads[0], pads[1], pads[2], op_, lse, pads[3], *gp, B=B, H=H, S=S, scale=sc, Skv=Skv, dvalid=dvv)
+        runs[dvv] = (op_, lse, gp)
+    torch.cuda.synchronize()
+    op_, lse, gp = runs[D]
+    same = all(torch.equal(a, b) for a, b in zip([runs[0][0], runs[0][1]] + runs[0][2], [op_, lse] + gp))
     o = torch.empty_like(q)
     ops.copy_heads(op_, o, H=H, d_src=128, d_dst=D)
     g = [torch.empty_like(t) for t in (q, k, v)]
@@ -159,9 +167,10 @@ def t_attn_padded(B=2, H=10, S=1000, D=64, Skv=77):
     g2 = [torch.empty_like(t) for t in (q, k, v)]
     ref_ops.attn_small_bwd(q, k, v, o2, l2, do, *g2, B=B, H=H, S=S, D=D, scale=sc, Skv=Skv)
     torch.cuda.synchronize()
-    padz = float(op_.view(B * S, H, 128)[:, :, D:].abs().max())
-    r = {"o": rel(o, o2), "dq": rel(g[0], g2[0]), "dk": rel(g[1], g2[1]), "dv": rel(g[2], g2[2]), "pad_cols_max": padz}
-    r["ok"] = r["o"] < 4e-3 and max(r["dq"], r["dk"], r["dv"]) < 1.5e-2 and padz == 0.0
+    padz = max(float(t.view(t.shape[0], H, 128)[:, :, D:].float().abs().max()) for t in [op_] + gp)
+    r = {"o": rel(o, o2), "dq": rel(g[0], g2[0]), "dk": rel(g[1], g2[1]), "dv": rel(g[2], g2[2]), "pad_cols_max": padz,
+         "dv_variant_bitwise_equal_to_full": same}
+    r["ok"] = r["o"] < 4e-3 and max(r["dq"], r["dk"], r["dv"]) < 1.5e-2 and padz == 0.0 and same
     return r
 
 
