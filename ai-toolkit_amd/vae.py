@@ -58,7 +58,9 @@ class _Holder(nn.Module):
 
 class AutoencoderKLEncoder(nn.Module):
     def __init__(self, latent_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2, groups=32,
-                 scaling_factor=0.3611, shift_factor=0.1159, dtype=torch.bfloat16, device=None, ops=None):
+                 scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False, dtype=torch.bfloat16, device=None, ops=None):
+        """Defaults = FLUX.1's VAE.  SD1.5 / SDXL: latent_channels=4, scaling_factor=0.18215 / 0.13025, shift_factor=0.0,
+        use_quant_conv=True (the 1x1 `quant_conv` on the moments that those AutoencoderKL configs carry)."""
         super().__init__()
         self.ops, self.dt, self.groups = ops, dtype, groups
         self.scaling_factor, self.shift_factor, self.latent_channels = scaling_factor, shift_factor, latent_channels
@@ -89,6 +91,7 @@ class AutoencoderKLEncoder(nn.Module):
         enc.conv_norm_out = _Norm(c, dtype, device)
         enc.conv_out = _Conv(c, 2 * latent_channels, 3, dtype, device)
         self.encoder = enc
+        self.quant_conv = _Conv(2 * latent_channels, 2 * latent_channels, 1, dtype, device) if use_quant_conv else None
         self._prepared = False
 
     def prepare(self):
@@ -170,6 +173,10 @@ class AutoencoderKLEncoder(nn.Module):
         ops.groupnorm(x, enc.conv_norm_out.weight, enc.conv_norm_out.bias, x, B=B, HW=H * W, G=self.groups, silu=True)
         mom = self._new(B * H * W, enc.conv_out.weight.shape[0])
         ops.conv3x3(x, enc.conv_out.wk, mom, B=B, H=H, W=W, bias=enc.conv_out.bias)
+        if self.quant_conv is not None:  # AutoencoderKL.encode: moments = quant_conv(encoder(x))
+            mq = self._new(B * H * W, mom.shape[1])
+            ops.gemm_nt(mom, self.quant_conv.wk, mq, bias=self.quant_conv.bias)
+            mom = mq
         return mom, (H, W)
 
     @torch.no_grad()

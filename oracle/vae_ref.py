@@ -118,14 +118,17 @@ class AutoencoderKLEncoder(nn.Module):
     """`vae.encode(x).latent_dist` with FLUX.1's config by default (scaling 0.3611, shift 0.1159, no quant_conv)."""
 
     def __init__(self, latent_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2, groups=32,
-                 scaling_factor=0.3611, shift_factor=0.1159):
+                 scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False):
         super().__init__()
         self.encoder = Encoder(3, latent_channels, block_out_channels, layers_per_block, groups)
+        # SD1.5 / SDXL AutoencoderKL: moments = quant_conv(encoder(x)), a 1x1 convolution (FLUX.1's VAE has none)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1) if use_quant_conv else None
         self.scaling_factor, self.shift_factor = scaling_factor, shift_factor
         self.latent_channels = latent_channels
 
     def moments(self, images):
-        return self.encoder(images)
+        m = self.encoder(images)
+        return m if self.quant_conv is None else self.quant_conv(m)
 
     def encode_images(self, images, eps):
         """toolkit/stable_diffusion_model.py:2567-2573 with the Gaussian sample made explicit (eps ~ N(0,1), NCHW)."""

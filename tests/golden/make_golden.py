@@ -290,6 +290,20 @@ def golden_lokr_lowrank():
           "; params", meta["param_order"])
 
 
+def golden_unet_keymap_keys():
+    """Parameter names of the diffusers UNet2DConditionModel (SD1.5: 686, SDXL: 1680) and of the AutoencoderKL encoder (+ quant_conv) as the
+    reference's own LDM<->diffusers key maps list them (toolkit/keymaps/stable_diffusion_sd1.json / _sdxl.json, `ldm_diffusers_keymap` values with
+    the `unet_` / `vae_` prefix of toolkit/saving.py stripped): the un-vendored diffusers classes' module structure, pinned on an in-tree artefact."""
+    out = {}
+    for tag, f in (("sd1", "stable_diffusion_sd1.json"), ("sdxl", "stable_diffusion_sdxl.json")):
+        km = json.load(open(os.path.join(os.environ.get("AITK_REFERENCE", "/root/reference"), "toolkit", "keymaps", f)))["ldm_diffusers_keymap"]
+        out[tag] = sorted(v[len("unet_"):] for v in km.values() if v.startswith("unet_"))
+        out[tag + "_vae_encoder"] = sorted(v[len("vae_"):] for v in km.values() if v.startswith("vae_encoder") or v.startswith("vae_quant_conv"))
+    assert out["sd1_vae_encoder"] == out["sdxl_vae_encoder"]
+    json.dump(out, open(os.path.join(HERE, "unet_keymap_keys.json"), "w"))
+    print("unet keymap keys:", {k: len(v) for k, v in out.items()})
+
+
 def golden_flux_blocks():
     """FLUX block arithmetic pinned on the reference's OWN in-tree restatement of the BFL FLUX blocks — the Chroma model
     (extensions_built_in/diffusion_models/chroma/src/layers.py: DoubleStreamBlock 471-607, SingleStreamBlock 610-681, LastLayer
@@ -716,6 +730,7 @@ if __name__ == "__main__":
             globals()[fn]()
         raise SystemExit(0)
     golden_unet_lora()
+    golden_unet_keymap_keys()
     golden_lora()
     golden_dora()
     golden_lokr()

@@ -124,3 +124,25 @@ def test_full_size_adapter_inventory_equals_the_reference(tag, cfg, count):
         shapes.append([d, u])
     assert hashlib.sha256(json.dumps(shapes).encode()).hexdigest() == m["shapes_sha256"]
     assert sum(x.lora_down.weight.numel() + x.lora_up.weight.numel() for x in net.unet_loras) == m["params"]
+
+
+def test_unet_parameter_names_equal_the_reference_keymaps():
+    """The diffusers UNet2DConditionModel is not vendored, but the reference's LDM<->diffusers key maps (toolkit/keymaps/stable_diffusion_sd1.json,
+    stable_diffusion_sdxl.json) list every one of its parameter names: 686 for SD1.5, 1680 for SDXL.  Oracle and fused model must carry exactly
+    those state-dict keys (tests/golden/unet_keymap_keys.json, written by make_golden.golden_unet_keymap_keys from the reference tree)."""
+    import json
+    import os
+
+    import torch
+
+    from ai_toolkit_amd.unet import SD15_CONFIG, SDXL_CONFIG, UNet2DConditionModel
+    from oracle import ref_ops, unet_ref
+
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "unet_keymap_keys.json")))
+    assert (len(keys["sd1"]), len(keys["sdxl"])) == (686, 1680)
+    for tag, ocfg, ncfg in (("sd1", unet_ref.SD15, SD15_CONFIG), ("sdxl", unet_ref.SDXL, SDXL_CONFIG)):
+        with torch.device("meta"):
+            ref = unet_ref.UNet2DConditionModel(**ocfg)
+        nat = UNet2DConditionModel(**ncfg, dtype=torch.float32, device="meta", ops=ref_ops)
+        assert sorted(ref.state_dict().keys()) == keys[tag], tag
+        assert sorted(nat.state_dict().keys()) == keys[tag], tag

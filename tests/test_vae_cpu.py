@@ -41,6 +41,33 @@ def test_encoder_graph_matches_oracle_fp32():
     assert torch.allclose(mom, m_ref, rtol=1e-4, atol=1e-5)
 
 
+def test_sd_vae_variant_with_quant_conv_and_the_reference_keymap_names():
+    """SD1.5 / SDXL AutoencoderKL: 4 latent channels, a 1x1 quant_conv on the moments, no shift.  Host graph vs oracle, and the parameter
+    names of the full-width encoder (+ quant_conv) against the list the reference's own key maps carry (toolkit/keymaps/
+    stable_diffusion_sd1.json / _sdxl.json via tests/golden/unet_keymap_keys.json)."""
+    torch.manual_seed(0)
+    cfg = dict(CFG, scaling_factor=0.13025, shift_factor=0.0, use_quant_conv=True)
+    ref = vae_ref.AutoencoderKLEncoder(**cfg)
+    vae_ref.init_synthetic_(ref)
+    nat = nvae.AutoencoderKLEncoder(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    nat.prepare()
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(2, 3, 32, 24, generator=g) * 2 - 1
+    eps = torch.randn(2, 4, 8, 6, generator=g)
+    want, got = ref.encode_images(img, eps), nat.encode_images(img, eps=eps)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+    no_q = vae_ref.AutoencoderKLEncoder(**dict(cfg, use_quant_conv=False))
+    no_q.load_state_dict({k: v for k, v in ref.state_dict().items() if not k.startswith("quant_conv")})
+    assert not torch.allclose(no_q.encode_images(img, eps), want, atol=1e-3)  # the 1x1 convolution is not a no-op
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "unet_keymap_keys.json")))
+    with torch.device("meta"):
+        full = vae_ref.AutoencoderKLEncoder(latent_channels=4, use_quant_conv=True)
+    full_nat = nvae.AutoencoderKLEncoder(latent_channels=4, use_quant_conv=True, dtype=torch.float32, device="meta", ops=ref_ops)
+    assert sorted(full.state_dict().keys()) == keys["sd1_vae_encoder"] == keys["sdxl_vae_encoder"] == sorted(full_nat.state_dict().keys())
+    assert len(keys["sd1_vae_encoder"]) == 108
+
+
 def test_latent_cache_path_and_roundtrip(tmp_path):
     plan = bk.plan_crop(2048, 1365, resolution=1024, bucket_tolerance=64)
     info = nvae.latent_info_dict("/data/set/cat 01.JPG", plan, latent_space_version="flux1")
