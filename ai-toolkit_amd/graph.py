@@ -120,9 +120,11 @@ class FusedGraphBase(nn.Module):
         the stream, so the scratch is reused by every layer).  +3 B/element of traffic (~10-40 us per layer) buys the full-speed
         bf16 8-phase GEMM instead of a GEMM that dequantises in its load segment."""
         n = q.shape[0] * q.shape[1]
-        buf = getattr(self, "_dq_scratch", None)
+        slot = getattr(self, "_dq_slot", 0)  # 0: sequential launches; 1 / 2: the two merged streams of _paired
+        pool = self.__dict__.setdefault("_dq_scratch", {})
+        buf = pool.get(slot)
         if buf is None or buf.numel() < n:
-            buf = self._dq_scratch = torch.empty(n, dtype=self.dt, device=q.device)
+            buf = pool[slot] = torch.empty(n, dtype=self.dt, device=q.device)
         out = buf[:n].view(q.shape[0], q.shape[1])
         self.ops.dequant_fp8(q, scale, mode, out)
         return out
@@ -136,15 +138,19 @@ class FusedGraphBase(nn.Module):
     def _paired(self, bodies):
         """Run two independent op sequences (callables; e.g. the image and the text stream of a double block).  On the MI355X table
         their kernel launches are recorded and merged so that GEMMs of equal shape go out as one grouped persistent launch
-        (ops.replay_paired); each sequence keeps its own order.  The fp8 base shares ONE dequantisation scratch between layers,
-        which would be overwritten under the merged order: sequential there."""
-        if not self.pair_streams or getattr(self, "is_quantized", False) or len(bodies) != 2 or not hasattr(self.ops, "recording"):
+        (ops.replay_paired); each sequence keeps its own order.  The fp8 base expands each layer's weight into a bf16 scratch right
+        before its GEMM: under the merged order the two sequences must not share that scratch, so each gets its own (_dq_slot)."""
+        if not self.pair_streams or len(bodies) != 2 or not hasattr(self.ops, "recording"):
             return [b() for b in bodies]
         outs, recs = [], []
-        for b in bodies:
-            with self.ops.recording() as launches:
-                outs.append(b())
-            recs.append(launches)
+        try:
+            for i, b in enumerate(bodies):
+                self._dq_slot = i + 1
+                with self.ops.recording() as launches:
+                    outs.append(b())
+                recs.append(launches)
+        finally:
+            self._dq_slot = 0
         self.ops.replay_paired(*recs)
         return outs
 

@@ -351,7 +351,9 @@ def main():
     B = args.batch
     if B <= 0:
         avail_gib = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30  # free + what this process holds
-        B = 7 if (avail_gib >= 252 and not args.fp8_base and args.network == "lora") else 4
+        # bf16 base: 245 GiB peak at B = 7; the fp8 base holds 23.8 GB less (weights as bytes, bf16 copies released): 7 fits from 232 GiB
+        need = 232 if args.fp8_base else 252
+        B = 7 if (avail_gib >= need and args.network == "lora") else 4
     lat, emb, pooled = make_batch(dev, B, seed=42 + rank)
 
     def one():

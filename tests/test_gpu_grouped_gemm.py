@@ -91,3 +91,25 @@ def test_flux_step_with_merged_stream_launches_is_bitwise_the_sequential_graph()
         ga = net_a.arena_g.clone()
         lb = sb.step(lat, emb, pooled, noise=noise, timesteps=ts).clone()
         assert torch.equal(la, lb) and torch.equal(ga, net_b.arena_g) and torch.equal(net_a.arena_p, net_b.arena_p), k
+
+
+def test_fp8_base_step_with_merged_stream_launches_is_bitwise_the_sequential_graph():
+    """weight-only fp8 base: each layer's weight is expanded into a bf16 scratch right before its GEMM; the two merged streams use
+    separate scratch buffers (graph._dq_slot), so the merged order must still give the sequential result bit for bit."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from tests.test_gpu_e2e import _batch, _build
+
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    _, _, nat_a, net_a = _build(rank=32)
+    _, _, nat_b, net_b = _build(rank=32)
+    nat_a.quantize_base_fp8()
+    nat_b.quantize_base_fp8()
+    nat_a.pair_streams, nat_b.pair_streams = True, False
+    sa, sb = FluxLoRATrainStep(nat_a, net_a, ops, **kw), FluxLoRATrainStep(nat_b, net_b, ops, **kw)
+    for k in range(2):
+        lat, emb, pooled, noise, ts = _batch(2, seed=95 + k)
+        la = sa.step(lat, emb, pooled, noise=noise, timesteps=ts).clone()
+        ga = net_a.arena_g.clone()
+        lb = sb.step(lat, emb, pooled, noise=noise, timesteps=ts).clone()
+        assert torch.equal(la, lb) and torch.equal(ga, net_b.arena_g) and torch.equal(net_a.arena_p, net_b.arena_p), k
