@@ -63,3 +63,21 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libaitk_mi355.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _capi.lib()
+
+
+def test_round2_entry_points_validate_their_arguments_before_launching():
+    """Every new C entry point returns an AITK_ERR_* code on bad arguments (no GPU is touched on these paths)."""
+    lib = _capi.lib()
+    a, b = _capi.GemmArgs(), _capi.GemmArgs()
+    assert lib.aitk_gemm_nt_grouped(ctypes.byref(a), ctypes.byref(b), None) == -1      # empty problems: AITK_ERR_SHAPE
+    assert lib.aitk_gemm_nt_grouped(None, ctypes.byref(b), None) == -1
+    at = _capi.AttnArgs()
+    at.B, at.H, at.S, at.D, at.Dv = 1, 2, 64, 128, 200                                 # valid width beyond the 128-column layout
+    assert lib.aitk_attn_fwd(ctypes.byref(at), None) == -1
+    at.Dv = 64
+    at.ldq = at.ldk = at.ldv = at.ldo = 256
+    assert lib.aitk_attn_fwd(ctypes.byref(at), None) == -3                             # null operands: AITK_ERR_ARG
+    assert lib.aitk_lokr_lowrank_grad(None, None, None, None, None, 8, 8, 4, 1, None) == -3
+    sd = _capi.ShadowDesc()
+    assert ctypes.sizeof(sd) == 48 and hasattr(sd, "aux")                              # kind 3 (composed low-rank LoKr factor) carries its rank here
+    assert lib.aitk_lora_refresh_shadows(None, None, None, 1, None) == -3

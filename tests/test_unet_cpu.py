@@ -210,3 +210,54 @@ def test_ddpm_schedule_tables():
     assert torch.allclose(s.snr_weights(ts, 5.0, fixed=True), unet_ref.min_snr_weight(ts, s.alphas_cumprod, 5.0, fixed=True))
     a, sg = s.noise_coefficients(ts, torch.bfloat16)
     assert a.dtype == torch.float32 and torch.equal(a, (s.alphas_cumprod.to(torch.bfloat16)[ts] ** 0.5).float())
+
+
+def _unet_dp_worker(rank, world, port, out):
+    import datetime
+    import os
+
+    import torch.distributed as dist
+
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    torch.set_num_threads(2)
+    ref, ref_net, nat, net = build_pair(TINY_SDXL)
+    step = UNetLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, min_snr_gamma=5.0, process_group=dist.group.WORLD)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _dp_batch(4, seed=40 + k)
+        sl = slice(rank * 2, rank * 2 + 2)  # disjoint shard of the bucket batch
+        step.step(lat[sl], ctx[sl], pooled[sl], noise=noise[sl], timesteps=ts[sl])
+    torch.save(net.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _dp_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    cfg = TINY_SDXL
+    lat = torch.randn(B, 4, 16, 8, generator=g)
+    ctx = torch.randn(B, 7, cfg["cross_attention_dim"], generator=g)
+    pooled = torch.randn(B, cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"], generator=g)
+    noise = torch.randn(B, 4, 16, 8, generator=g)
+    ts = torch.tensor([10, 500, 998, 250][:B])
+    return lat, ctx, pooled, noise, ts
+
+
+def test_unet_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
+    """SURVEY.md §8e for the UNet step: two ranks on disjoint halves of the batch, one all-reduce(mean) of the flat gradient arena
+    (up-block adapters first), then clip / AdamW redundantly == one rank on the whole batch; ranks end bit-identical."""
+    import torch.multiprocessing as mp
+
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+    from tests.conftest import free_port
+
+    mp.spawn(_unet_dp_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1), "ranks must hold bit-identical adapter weights"
+    ref, ref_net, nat, net = build_pair(TINY_SDXL)
+    step = UNetLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, min_snr_gamma=5.0)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _dp_batch(4, seed=40 + k)
+        step.step(lat, ctx, pooled, noise=noise, timesteps=ts)
+    assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
