@@ -149,7 +149,33 @@ def bench_unet(args, dev):
            "roofline": {"bound": "mfma", "kernel": "aitk_gemm_nt (LoRA-fused token GEMMs + implicit-GEMM 3x3 convolutions, all launches of one step)",
                         "achieved": fl / ms / 1e9 if ms > 0 else 0.0, "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": (fl / ms / 1e9) / PEAK_BF16 if ms > 0 else 0.0,
                         "traffic": None, "launches_per_step": len(recs), "gemm_conv_ms_per_step": ms, "gemm_conv_tflop_per_step": fl / 1e12}}
+    if kind == "sd15" and not args.no_cpu_baseline:
+        # BASELINE configs[0] is the reference's own CPU-runnable case: SD1.5 UNet LoRA r4 @512^2, fp32, batch 1.  The oracle runs exactly
+        # that, full size (859.5 M parameters, 192 adapters), on this host's cores: one warm-up step + one timed step.
+        out["cpu_baseline"] = cpu_baseline_sd15()
     print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_sd15():
+    from oracle import lora_ref, train_ref, unet_ref
+
+    torch.manual_seed(0)
+    m = unet_ref.UNet2DConditionModel(**unet_ref.SD15)
+    unet_ref.init_synthetic_(m, seed=11)
+    net = lora_ref.RefLoRANetwork(m, 4, target=("Transformer2DModel",), kohya_unet=True, alpha=4.0)
+    net.apply_to()
+    st = train_ref.RefUNetTrainStep(m, net, lr=1e-4)
+    g = torch.Generator().manual_seed(1)
+    lat, noise = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
+    ctx = torch.randn(1, 77, 768, generator=g) * 0.5
+    ts = torch.tensor([500])
+    st.step(lat, ctx, None, noise, ts)
+    t0 = time.time()
+    st.step(lat, ctx, None, noise, ts)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"full-size SD1.5 UNet (859.5 M parameters, 192 LoRA r4 adapters), 512^2, B=1, fp32, one complete step "
+                      f"(fwd + bwd + clip + AdamW) in {dt:.1f} s after one warm-up step"}
 
 
 def gemm_roofline(step_fn, ops_mod):
