@@ -647,11 +647,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
           dp = mfma32(vfr[u], gf[2 * hh + u], dp);
         }
       }
+      {
+        const f32x2_t c2v = {c2, c2}, lv = {-L2, -L2}, dlv = {dl, dl};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pr = ABL_EXP2(fmaf(s[r], c2, -L2));
-        if (tail && t * 64 + 32 * j + crow(r, h) >= Skv) pr = 0.f;
-        dp[r] = pr * (dp[r] - dl);
+        for (int r = 0; r < 16; r += 2) {  // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): this kernel is vector-issue bound
+                                           // (profiles/r02_notes_attention_ablation.md); backward 4.29 -> 4.12 ms same-box at B = 4
+          f32x2_t a = {s[r], s[r + 1]};
+          a = __builtin_elementwise_fma(a, c2v, lv);
+          a[0] = ABL_EXP2(a[0]);
+          a[1] = ABL_EXP2(a[1]);
+          if (tail) {
+            if (t * 64 + 32 * j + crow(r, h) >= Skv) a[0] = 0.f;
+            if (t * 64 + 32 * j + crow(r + 1, h) >= Skv) a[1] = 0.f;
+          }
+          f32x2_t d = {dp[r], dp[r + 1]};
+          d = a * (d - dlv);
+          dp[r] = d[0];
+          dp[r + 1] = d[1];
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
