@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 template <int KS, int DB>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (sub-tiled: b128 + tr16 reads) at b*DBUF, V tile (row-major) after it
-  constexpr int DBUF = SUBTILE_BYTES + 16384;
+  lds_char* const sm = (lds_char*)smem;  // buffer b: K tile (sub-tiled: b128 + tr16 reads) at b*DBUF, V tile (sub-tiled: b128 reads) after it
+  constexpr int DBUF = 2 * SUBTILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
@@ -615,8 +615,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   for (int d = 0; d < DB; ++d) dq[d] = zero16();
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (Skv + 63) / 64;
+  // Per-lane parts of every LDS fragment address, computed once: inside the tile loop an address is (tile base + lane part), one add per
+  // distinct lane part, plus a compile-time offset that goes into the instruction's immediate field.  (Left to the address helpers the
+  // swizzle arithmetic was redone for each of the 64 fragment reads of a tile: 72 v_add per tile in a kernel that is vector-issue bound.)
+  typedef const __attribute__((address_space(3))) s16x8_t* lds_v8;
+  const int gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
+  const unsigned ln_rm = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) << 4);                                     // frag_rm_st (K and V, sub-tiled)
+  const unsigned ln_tr_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);          // frag_tr_perm_st, rows with bit 3 clear
+  const unsigned ln_tr_hi = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2) + 8) * 32 + ((lh ^ 1) << 4);  // ... and the rows 8 further
   glds_subtile64(sm, Kb, p.ldk, 0, Skv, wave, lane);
-  glds_tile<64>(sm + SUBTILE_BYTES, Vb, p.ldv, 0, Skv, wave, lane);
+  glds_subtile64(sm + SUBTILE_BYTES, Vb, p.ldv, 0, Skv, wave, lane);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
@@ -624,53 +632,74 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
     const lds_char* vtc = ktc + SUBTILE_BYTES;
     if (t + 1 < ntiles) {
       glds_subtile64(sm + (cur ^ 1) * DBUF, Kb, p.ldk, (t + 1) * 64, Skv, wave, lane);
-      glds_tile<64>(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
+      glds_subtile64(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
     }
+    const lds_char* k_rm = ktc + ln_rm;
+    const lds_char* v_rm = vtc + ln_rm;
+    const lds_char* k_lo = ktc + ln_tr_lo;
+    const lds_char* k_hi = ktc + ln_tr_hi;
     const bool tail = t * 64 + 64 > Skv;
+    {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f32x16_t s = zero16(), dp = zero16();
+      for (int j = 0; j < 2; ++j) {
+        f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
-      for (int hh = 0; hh < (KS + 1) / 2; ++hh) {
-        s16x8_t kfr[2], vfr[2];
+        for (int hh = 0; hh < (KS + 1) / 2; ++hh) {
+          s16x8_t kfr[2], vfr[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (2 * hh + u >= KS) continue;
-          kfr[u] = frag_rm_st(ktc, 32 * j, 16 * (2 * hh + u), lane);
-          vfr[u] = frag_rm_sw(vtc, 32 * j, 16 * (2 * hh + u), lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (2 * hh + u >= KS) continue;
-          s = mfma32(kfr[u], qf[2 * hh + u], s);
-          dp = mfma32(vfr[u], gf[2 * hh + u], dp);
-        }
-      }
-      {
-        const f32x2_t c2v = {c2, c2}, lv = {-L2, -L2}, dlv = {dl, dl};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {  // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): this kernel is vector-issue bound
-                                           // (profiles/r02_notes_attention_ablation.md); backward 4.29 -> 4.12 ms same-box at B = 4
-          f32x2_t a = {s[r], s[r + 1]};
-          a = __builtin_elementwise_fma(a, c2v, lv);
-          a[0] = ABL_EXP2(a[0]);
-          a[1] = ABL_EXP2(a[1]);
-          if (tail) {
-            if (t * 64 + 32 * j + crow(r, h) >= Skv) a[0] = 0.f;
-            if (t * 64 + 32 * j + crow(r + 1, h) >= Skv) a[1] = 0.f;
+          for (int u = 0; u < 2; ++u) {
+            if (2 * hh + u >= KS) continue;
+#if defined(AITK_ABL_NOLDS)
+            kfr[u] = frag_rm_st(ktc, 32 * j, 16 * (2 * hh + u), lane);
+            vfr[u] = frag_rm_st(vtc, 32 * j, 16 * (2 * hh + u), lane);
+#else
+            kfr[u] = *reinterpret_cast<lds_v8>(k_rm + (2 * hh + u) * SUBP + 32 * j * 32);
+            vfr[u] = *reinterpret_cast<lds_v8>(v_rm + (2 * hh + u) * SUBP + 32 * j * 32);
+#endif
           }
-          f32x2_t d = {dp[r], dp[r + 1]};
-          d = a * (d - dlv);
-          dp[r] = d[0];
-          dp[r + 1] = d[1];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (2 * hh + u >= KS) continue;
+            s = mfma32(kfr[u], qf[2 * hh + u], s);
+            dp = mfma32(vfr[u], gf[2 * hh + u], dp);
+          }
         }
-      }
+        {
+          const f32x2_t c2v = {c2, c2}, lv = {-L2, -L2}, dlv = {dl, dl};
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const s16x8_t df = pack_acc8(dp, 8 * kk);
+          for (int r = 0; r < 16; r += 2) {  // register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): this kernel is vector-issue bound
+                                             // (profiles/r02_notes_attention_ablation.md); backward 4.29 -> 4.12 ms same-box at B = 4
+            f32x2_t a = {s[r], s[r + 1]};
+            a = __builtin_elementwise_fma(a, c2v, lv);
+            a[0] = ABL_EXP2(a[0]);
+            a[1] = ABL_EXP2(a[1]);
+            if (tail) {
+              if (t * 64 + 32 * j + crow(r, h) >= Skv) a[0] = 0.f;
+              if (t * 64 + 32 * j + crow(r + 1, h) >= Skv) a[1] = 0.f;
+            }
+            f32x2_t d = {dp[r], dp[r + 1]};
+            d = a * (d - dlv);
+            dp[r] = d[0];
+            dp[r + 1] = d[1];
+          }
+        }
 #pragma unroll
-        for (int d = 0; d < DB; ++d) dq[d] = mfma32(ABL_TR(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+        for (int kk = 0; kk < 2; ++kk) {
+          const s16x8_t df = pack_acc8(dp, 8 * kk);
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+#if defined(AITK_ABL_NOLDS) || defined(AITK_ABL_ATTN_B128)
+            dq[d] = mfma32(ABL_TR(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
+#else
+            // rows kb + 4h + (i>>2) (+8) of column block 2d + gq: kb = 32j + 16kk is a multiple of 16, so the first read sits in a row
+            // with bit 3 clear (lane part ln_tr_lo), the second 8 rows further (ln_tr_hi)
+            const s16x4_t lo = tr16l(k_lo + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
+            const s16x4_t hi = tr16l(k_hi + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
+            dq[d] = mfma32(join_lohi(lo, hi), df, dq[d]);
+#endif
+          }
+        }
       }
     }
     __syncthreads();
@@ -727,7 +756,7 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
   const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
-  const size_t lds2 = 2 * (16384 + SUBTILE_BYTES);
+  const size_t lds2 = 4 * SUBTILE_BYTES;
   static bool attr = false;
   if (!attr) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
