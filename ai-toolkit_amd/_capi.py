@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
         ("M", i32), ("N", i32), ("K", i32), ("K2", i32),
         ("flags", i32), ("stage_mode", i32), ("tile_mode", i32), ("conv_mode", i32),
         ("conv_H", i32), ("conv_W", i32), ("conv_Cin", i32), ("conv_Wo", i32), ("conv_HoWo", i32), ("conv_stride", i32),
-        ("conv_pad_t", i32), ("conv_pad_l", i32), ("_pad3", i32),
+        ("conv_pad_t", i32), ("conv_pad_l", i32), ("conv_t3d", i32),
         ("zero_page", vp),
         ("b_scale", vp), ("b_scale_mode", i32), ("_pad4", i32),
         ("col_scale", vp),
@@ -239,6 +239,8 @@ def lib():
     L.aitk_kron_merge.argtypes = [vp, i64, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.aitk_image_to_nhwc8.argtypes = [vp, vp, i32, i32, i32, vp]
     L.aitk_latent_sample.argtypes = [vp, i64, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]
+    L.aitk_latent_sample_affine.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.aitk_rmsnorm_rows.argtypes = [vp, i64, vp, i64, vp, i64, i32, C.c_float, i32, vp]
     L.aitk_timestep_embed.argtypes = [vp, vp, i32, i32, C.c_float, vp]
     L.aitk_copy2d.argtypes = [vp, i64, vp, i64, i64, i64, vp]
     L.aitk_groupnorm_bwd_workspace_bytes.restype = C.c_int64

@@ -39,6 +39,9 @@ __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* base, long ld, in
 // output pixel (b, oy, ox), the 16-B chunk at k = tap*Cin + cin is fetched from input pixel (oy*stride+ky-pad_t,
 // ox*stride+kx-pad_l), out-of-image chunks come from a zero page.  Replaces nn.Conv2d inside the VAE encoder the reference
 // runs at toolkit/stable_diffusion_model.py:2567 (diffusers AutoencoderKL).
+// conv_t3d != 0 (kt | tstride << 8 | ks << 16): the batch index is a FRAME and K also runs over kt temporal taps, k = ((dt*ks + ky)*ks +
+// kx)*Cin + cin, read from input frame b*tstride + dt — the causal 3-D convolutions of the Wan2.1 video VAE (AutoencoderKLWan, reached
+// from toolkit/models/wan21/wan21.py:659).  No bounds check in time: the caller's buffer starts with the causal zero frames.
 template <int STAGE, int BM, int BN, int WM, int WN, bool CONV = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
   constexpr int NT = 64 * WM * WN;           // threads
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
       const int oy = rem / p.conv_Wo, ox = rem - oy * p.conv_Wo;
       iy0[i] = oy * p.conv_stride - p.conv_pad_t;
       ix0[i] = ox * p.conv_stride - p.conv_pad_l;
-      pa[i] = (((long)b * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
+      const int fr = p.conv_t3d ? b * ((p.conv_t3d >> 8) & 255) : b;  // first input frame of output frame b
+      pa[i] = (((long)fr * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
       ao[i] = 0;
       ao2[i] = 0;
     } else {
@@ -215,10 +219,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     if constexpr (CONV) {
       const int kc = k0 + cc * 8;
       const bool kin = kc < p.K;
-      const int tap = kin ? kc / p.conv_Cin : 0;
-      const int cin = kc - tap * p.conv_Cin;
-      const int ky = tap / 3, kx = tap - 3 * ky;
-      const long toff = ((long)ky * p.conv_W + kx) * p.conv_Cin + cin;
+      const int tap3 = kin ? kc / p.conv_Cin : 0;
+      const int cin = kc - tap3 * p.conv_Cin;
+      const int ks = p.conv_t3d ? (p.conv_t3d >> 16) & 255 : 3;  // spatial kernel size (3, or 1 for the (3,1,1) time convolution)
+      const int dt = tap3 / (ks * ks), tap = tap3 - dt * ks * ks;  // temporal tap (always 0 for a 2-D convolution)
+      const int ky = tap / ks, kx = tap - ks * ky;
+      const long toff = ((long)(dt * p.conv_H + ky) * p.conv_W + kx) * p.conv_Cin + cin;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const bool ok = kin && (unsigned)(iy0[i] + ky) < (unsigned)p.conv_H && (unsigned)(ix0[i] + kx) < (unsigned)p.conv_W;
@@ -446,8 +452,11 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if (chk) return chk;
   hipStream_t st = stream;
   if (a->conv_mode) {
-    if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != 9 * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
-        a->conv_stride <= 0 || a->conv_Wo <= 0 || a->conv_HoWo <= 0)
+    const int c_kt = a->conv_t3d ? (a->conv_t3d & 255) : 1, c_ts = a->conv_t3d ? ((a->conv_t3d >> 8) & 255) : 1;
+    const int c_ks = a->conv_t3d ? ((a->conv_t3d >> 16) & 255) : 3;
+    if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != c_kt * c_ks * c_ks * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
+        a->conv_stride <= 0 || a->conv_Wo <= 0 || a->conv_HoWo <= 0 || c_kt < 1 || c_kt > 3 || c_ts < 1 || c_ts > 2 || (c_ks != 1 && c_ks != 3) ||
+        (a->conv_t3d >> 24))
       return AITK_ERR_ARG;
     static bool cattr = false;
     if (!cattr) {

@@ -212,3 +212,86 @@ extern "C" int aitk_latent_sample(const aitk_bf16* moments, int64_t ldm, const f
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
+
+// ---------------------------------------------------------------- Wan2.1 video VAE (AutoencoderKLWan encoder, ai-toolkit_amd/wan_vae.py)
+// the same sample with the per-channel affine of Wan21.encode_images (toolkit/models/wan21/wan21.py:661-670)
+__global__ void latent_sample_affine_kernel(const bf16_t* mom, long ldm, const float* eps, bf16_t* out, int B, int L, int hw,
+                                            const float* ch_shift, const float* ch_scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * L * hw;
+  if (idx >= total) return;
+  const int r = (int)(idx % hw);
+  const int c = (int)((idx / hw) % L);
+  const int b = (int)(idx / ((long)hw * L));
+  const bf16_t* mrow = mom + ((long)b * hw + r) * ldm;
+  const float mean = bf2f(mrow[c]);
+  const float logvar = fminf(fmaxf(bf2f(mrow[L + c]), -30.0f), 20.0f);
+  const float z = mean + expf(0.5f * logvar) * eps[idx];
+  out[idx] = f2bf(ch_scale[c] * (z - ch_shift[c]));
+}
+extern "C" int aitk_latent_sample_affine(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L,
+                                         int32_t hw, const float* ch_shift, const float* ch_scale, aitk_stream_t stream) {
+  if (!moments || !eps || !out || !ch_shift || !ch_scale || B <= 0 || L <= 0 || hw <= 0) return AITK_ERR_SHAPE;
+  const long total = (long)B * L * hw;
+  hipLaunchKernelGGL(latent_sample_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, moments,
+                     (long)ldm, eps, out, B, L, hw, ch_shift, ch_scale);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// WanRMS_norm over the channel axis of NHWC rows: y = x / max(||x||, eps) * sqrt(C) * gamma (+ SiLU).  HBM-bound (4 B / element):
+// G lanes per row (16 B each; G = 16 / 32 / 64 for C <= 128 / 256 / more), up to four 16-B chunks per lane, group reduction by
+// shuffles.  Rows are independent, so x and y may alias.
+template <int G, int NJ>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const bf16_t* x, long ldx, bf16_t* y, long ldy, const bf16_t* gamma, long M,
+                                                          int C, float eps, int silu) {
+  constexpr int RPB = 256 / G;
+  const long row = (long)blockIdx.x * RPB + threadIdx.x / G;
+  const int l = threadIdx.x % G;
+  if (row >= M) return;  // whole lane groups leave together (the shuffles below stay inside a group)
+  float v[NJ][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (l + j * G) * 8;
+    if (c < C) {
+      unpack8v(*reinterpret_cast<const uint4*>(x + row * ldx + c), v[j]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[j][e] * v[j][e];
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const float k = sqrtf((float)C) / fmaxf(sqrtf(ss), eps);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (l + j * G) * 8;
+    if (c < C) {
+      float g[8], o[8];
+      unpack8v(*reinterpret_cast<const uint4*>(gamma + c), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = v[j][e] * k * g[e];
+        o[e] = silu ? t / (1.0f + __expf(-t)) : t;
+      }
+      *reinterpret_cast<uint4*>(y + row * ldy + c) = pack8v(o);
+    }
+  }
+}
+extern "C" int aitk_rmsnorm_rows(const aitk_bf16* x, int64_t ldx, aitk_bf16* y, int64_t ldy, const aitk_bf16* gamma, int64_t M, int32_t C,
+                                 float eps, int32_t silu, aitk_stream_t stream) {
+  if (!x || !y || !gamma || M <= 0 || C <= 0 || (C % 8) || C > 2048 || (ldx % 8) || (ldy % 8)) return AITK_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 128) {
+    hipLaunchKernelGGL((rmsnorm_rows_kernel<16, 1>), dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma,
+                       (long)M, C, eps, silu);
+  } else if (C <= 256) {
+    hipLaunchKernelGGL((rmsnorm_rows_kernel<32, 1>), dim3((unsigned)((M + 7) / 8)), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma,
+                       (long)M, C, eps, silu);
+  } else {
+    hipLaunchKernelGGL((rmsnorm_rows_kernel<64, 4>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, (long)ldx, y, (long)ldy, gamma,
+                       (long)M, C, eps, silu);
+  }
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}

@@ -530,6 +530,54 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     return out
 
 
+def conv3d(x, w, out, *, T, H, W, kt=3, ks=3, tstride=1, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
+    """Implicit-GEMM 3-D convolution on frames of NHWC rows (Wan2.1 video VAE): x [>= ((T-1)*tstride + kt)*H*W, Cin] whose frame
+    t*tstride + dt feeds temporal tap dt of output frame t (a causal convolution passes a buffer that starts with its kt-1 zero frames),
+    w [Cout, kt*ks*ks*Cin] with k = ((dt*ks + ky)*ks + kx)*Cin + cin, out [T*Ho*Wo, Cout]."""
+    g = _capi.GemmArgs()
+    Cin = x.shape[1]
+    Ho = H if Ho is None else Ho
+    Wo = W if Wo is None else Wo
+    assert x.is_contiguous() and x.dtype == BF16 and x.shape[0] >= ((T - 1) * tstride + kt) * H * W
+    g.lda, g.ldb, g.ldc = Cin, _row_major(w, "w"), _row_major(out, "out")
+    N, K = w.shape
+    assert K == kt * ks * ks * Cin and out.shape == (T * Ho * Wo, N)
+    g.A, g.B, g.C = _ptr(x), _ptr(w), _ptr(out)
+    if bias is not None:
+        flags |= EPI_BIAS
+        g.bias = _ptr(bias)
+    if aux_in is not None:
+        g.aux_in, g.ld_aux_in = _ptr(aux_in), _row_major(aux_in, "aux_in")
+    g.M, g.N, g.K, g.flags = T * Ho * Wo, N, K, flags
+    g.stage_mode, g.tile_mode = 1, TILE_MODE
+    g.conv_mode, g.conv_H, g.conv_W, g.conv_Cin = 1, H, W, Cin
+    g.conv_Wo, g.conv_HoWo, g.conv_stride, g.conv_pad_t, g.conv_pad_l = Wo, Ho * Wo, stride, pad_t, pad_l
+    g.conv_t3d = kt | (tstride << 8) | (ks << 16)
+    g.zero_page = _ptr(_zero_page(x.device))
+    _call("aitk_gemm_nt", C.byref(g))
+    return out
+
+
+def rmsnorm_rows(x, gamma, out, *, eps=1e-12, silu=False):
+    """out = x / max(||x||_2, eps) * sqrt(C) * gamma (+ SiLU) per row of x [M, C] (WanRMS_norm on NHWC rows); out may be x."""
+    assert x.dtype == BF16 and out.dtype == BF16 and gamma.dtype == BF16 and gamma.is_contiguous() and gamma.numel() == x.shape[1]
+    _call("aitk_rmsnorm_rows", _ptr(x), _row_major(x, "x"), _ptr(out), _row_major(out, "out"), _ptr(gamma), x.shape[0], x.shape[1],
+          float(eps), int(silu))
+    return out
+
+
+def latent_sample_affine(moments, eps, out, *, ch_shift, ch_scale):
+    """out [B, L, ...] = ch_scale[c] * (mean + exp(0.5 clamp(logvar)) * eps - ch_shift[c]); moments rows ordered like out's trailing dims."""
+    B, L = out.shape[0], out.shape[1]
+    hw = out[0, 0].numel()
+    assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == out.shape and out.is_contiguous()
+    for t in (ch_shift, ch_scale):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == L
+    _call("aitk_latent_sample_affine", _ptr(moments), _row_major(moments, "moments"), _ptr(eps), _ptr(out), B, L, hw, _ptr(ch_shift),
+          _ptr(ch_scale))
+    return out
+
+
 def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False, stats_out=None):
     """out = GroupNorm_G(x [B*HW, C]) * gamma + beta (+ SiLU); stats_out fp32 [B, G, 2] (mean, rstd) for groupnorm_bwd."""
     a = _capi.GroupNormArgs()

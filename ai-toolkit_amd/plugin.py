@@ -158,6 +158,13 @@ class Wan21MI355Model(_PluginBase):
         return self.model(hidden_states=latent_model_input, timestep=timestep, encoder_hidden_states=text,
                           return_dict=False, **kwargs)[0]
 
+    def encode_images(self, image_list, device=None, dtype=None):
+        """list of [C,H,W] images / [T,C,H,W] clips in [-1, 1] -> normalised video latents [B,16,T',H/8,W/8] through the native
+        AutoencoderKLWan encoder (toolkit/models/wan21/wan21.py:618-672)."""
+        if self.vae is None:
+            raise RuntimeError("no VAE encoder attached (latents are expected to be cached)")
+        return self.vae.encode_images([im.to(self.device_torch) for im in image_list])
+
     def convert_lora_weights_before_save(self, state_dict):
         return wan_lora_to_original(state_dict)
 

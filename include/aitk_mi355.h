@@ -61,9 +61,13 @@ typedef struct AitkGemmArgs {
                          2-barrier LDS-DMA kernel, 4 = force the 8-phase kernel, 5 = force the 2-barrier LDS-DMA kernels */
   int32_t tile_mode;  /* 0 = auto, 1 = 128x128 (4 waves), 2 = 256x256 (8 waves) */
   /* implicit-GEMM 3x3 convolution (conv_mode = 1): A = NHWC input [B, conv_H, conv_W, conv_Cin], M = B*Ho*Wo,
-   * K = 9*conv_Cin with k = (ky*3+kx)*Cin + cin, B = weight [Cout, K]; zero_page = >=16 B of zeros on the device */
+   * K = 9*conv_Cin with k = (ky*3+kx)*Cin + cin, B = weight [Cout, K]; zero_page = >=16 B of zeros on the device.
+   * conv_t3d != 0 selects the 3-D form used by the Wan2.1 video VAE (toolkit/models/wan21/wan21.py:659): conv_t3d = kt | tstride << 8 |
+   * ks << 16 (kt = 1..3 temporal taps, tstride = 1..2, ks = 3 or 1 spatial kernel size); the batch index is then a frame, K =
+   * kt*ks*ks*conv_Cin with k = ((dt*ks + ky)*ks + kx)*Cin + cin, and tap dt of output frame t reads input frame t*tstride + dt of A
+   * (A starts with the zero frames of a causal convolution: there is no bounds check in time). */
   int32_t conv_mode;
-  int32_t conv_H, conv_W, conv_Cin, conv_Wo, conv_HoWo, conv_stride, conv_pad_t, conv_pad_l, _pad3;
+  int32_t conv_H, conv_W, conv_Cin, conv_Wo, conv_HoWo, conv_stride, conv_pad_t, conv_pad_l, conv_t3d;
   const aitk_bf16* zero_page;
   /* weight-only fp8 base operand (b_scale_mode != 0): B points to OCP e4m3 bytes [N, K] (ldb in bytes), dequantised to
    * bf16(fp8 * scale) on the way into LDS.  1: scale[n] per B row (forward); 2: scale[k] per contraction index (dgrad on W^T). */
@@ -323,6 +327,15 @@ int aitk_image_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t H, 
  * (toolkit/stable_diffusion_model.py:2567-2573) */
 int aitk_latent_sample(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L, int32_t hw,
                        float scale, float shift, aitk_stream_t stream);
+/* the same with a per-channel affine, out = ch_scale[c] * (z - ch_shift[c]) (ch_* fp32 [L] on the device): Wan21.encode_images'
+ * `(latents - latents_mean) * (1 / latents_std)` (toolkit/models/wan21/wan21.py:661-670); with hw = T'*h*w the output is [B, L, T', h, w] */
+int aitk_latent_sample_affine(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L, int32_t hw,
+                              const float* ch_shift, const float* ch_scale, aitk_stream_t stream);
+/* WanRMS_norm over the channel axis of NHWC rows (+ optional SiLU): y = x / max(||x||_2, eps) * sqrt(C) * gamma[c]
+ * (F.normalize(x, dim=1) * scale * gamma of diffusers' AutoencoderKLWan, reached from toolkit/models/wan21/wan21.py:659).
+ * x, y [M, C] bf16 (may alias), gamma bf16 [C], C % 8 == 0, C <= 2048. */
+int aitk_rmsnorm_rows(const aitk_bf16* x, int64_t ldx, aitk_bf16* y, int64_t ldy, const aitk_bf16* gamma, int64_t M, int32_t C,
+                      float eps, int32_t silu, aitk_stream_t stream);
 
 
 /* ---- RMSNorm across heads (weight [C], C = H*128) + optional rotary embedding, one row per token (Wan2.1 q/k path,

@@ -423,6 +423,47 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     return out
 
 
+def conv3d(x, w, out, *, T, H, W, kt=3, ks=3, tstride=1, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
+    """nn.Conv3d on frames of NHWC rows (diffusers AutoencoderKLWan's WanCausalConv3d / time_conv, reached from
+    toolkit/models/wan21/wan21.py:659): the caller's buffer carries the causal front padding, frame t*tstride + dt feeds tap dt."""
+    Cin = x.shape[1]
+    Ho = H if Ho is None else Ho
+    Wo = W if Wo is None else Wo
+    Tin = (T - 1) * tstride + kt
+    xi = x[:Tin * H * W].float().view(1, Tin, H, W, Cin).permute(0, 4, 1, 2, 3)
+    wk = w.float().view(w.shape[0], kt, ks, ks, Cin).permute(0, 4, 1, 2, 3)
+    pad_b = max((Ho - 1) * stride + ks - H - pad_t, 0)
+    pad_r = max((Wo - 1) * stride + ks - W - pad_l, 0)
+    xi = F.pad(xi, (pad_l, pad_r, pad_t, pad_b, 0, 0))
+    y = F.conv3d(xi, wk, None, stride=(tstride, stride, stride))[:, :, :T, :Ho, :Wo]
+    v = y[0].permute(1, 2, 3, 0).reshape(T * Ho * Wo, -1)
+    if bias is not None:
+        v = v + bias.float()
+    if flags & EPI_ADD_AUX:
+        v = v + aux_in.float()
+    out.copy_(v.to(out.dtype))
+    return out
+
+
+def rmsnorm_rows(x, gamma, out, *, eps=1e-12, silu=False):
+    """WanRMS_norm: F.normalize(x, dim=channel) * sqrt(C) * gamma (+ SiLU)."""
+    v = F.normalize(x.float(), dim=1, eps=eps) * (x.shape[1] ** 0.5) * gamma.float()
+    out.copy_((F.silu(v) if silu else v).to(out.dtype))
+    return out
+
+
+def latent_sample_affine(moments, eps, out, *, ch_shift, ch_scale):
+    """DiagonalGaussianDistribution.sample + (z - latents_mean) * (1 / latents_std) (toolkit/models/wan21/wan21.py:659-670)."""
+    B, L = out.shape[0], out.shape[1]
+    hw = out[0, 0].numel()
+    m = moments.float().view(B, hw, -1)
+    mean, logvar = m[..., :L], m[..., L:2 * L].clamp(-30.0, 20.0)
+    z = mean + torch.exp(0.5 * logvar) * eps.reshape(B, L, hw).transpose(1, 2)
+    z = (z - ch_shift.float()) * ch_scale.float()
+    out.copy_(z.transpose(1, 2).reshape(out.shape).to(out.dtype))
+    return out
+
+
 def groupnorm(x, gamma, beta, out, *, B, HW, G=32, eps=1e-6, silu=False, stats_out=None):
     Cc = x.shape[1]
     xi = x.float().view(B, HW, Cc).transpose(1, 2)

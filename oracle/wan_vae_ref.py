@@ -1,0 +1,234 @@
+"""ORACLE (test infrastructure): Wan2.1 video VAE *encoder* (`AutoencoderKLWan`) + latent sampling / normalisation, plain PyTorch.
+
+The reference calls `self.vae.encode(images).latent_dist.sample()` and then `(latents - latents_mean) * (1 / latents_std)` per channel
+(toolkit/models/wan21/wan21.py:618-672; image-list normalisation 636-646: [C,H,W] -> one frame, [T,C,H,W] -> [C,T,H,W]).  The encoder
+arithmetic is diffusers' `AutoencoderKLWan` (un-vendored, `requirements_base.txt:3`, commit c9438378; it is the port of Wan2.1's
+`wan/modules/vae.py`), which is NOT in this image: this file restates the published algorithm from the module structure — **parity
+unpinned** for the block arithmetic and for the parameter names (diffusers' names as published: `encoder.conv_in`,
+`encoder.down_blocks.N.{norm1,conv1,norm2,conv2,conv_shortcut}` / `.resample.1` / `.time_conv`, `encoder.mid_block.{resnets,attentions}`,
+`encoder.norm_out`, `encoder.conv_out`, `quant_conv`).  What IS pinned: the input handling and the per-channel latent normalisation are
+the reference's own lines above (tests/test_wan_vae_cpu.py restates them next to the call).
+
+The restatement keeps the published CHUNKED evaluation literally — first frame alone, then 4 frames at a time, every causal convolution
+carrying a 2-frame feature cache, the temporal down-sampler passing the first chunk through without its time convolution — so that the
+whole-sequence formulation of the product path (ai-toolkit_amd/wan_vae.py) is checked against the algorithm as published and not against
+itself.
+
+  encoder(base 96, mult 1/2/4/4, 2 residual blocks per level, spatial /2 after levels 0-2, temporal /2 after levels 1-2):
+  conv_in 3->96 (causal 3x3x3) -> [ResidualBlock(RMS_norm, SiLU, causal conv) x2, Resample] x3 -> ResidualBlock x2 ->
+  mid (ResidualBlock, per-frame single-head attention, ResidualBlock) -> RMS_norm -> SiLU -> conv_out 384 -> 32; quant_conv 1x1x1;
+  DiagonalGaussian(mean, clamp(logvar, -30, 20)).sample().
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+CACHE_T = 2
+
+LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497,
+                0.2503, -0.2921]
+LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251,
+               1.9160]
+
+
+class WanCausalConv3d(nn.Conv3d):
+    """zero padding: symmetric in space, 2*pad_t frames in FRONT in time; a feature cache replaces (part of) the front padding."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0):
+        super().__init__(cin, cout, kernel_size, stride, padding)
+        self._padding = (self.padding[2], self.padding[2], self.padding[1], self.padding[1], 2 * self.padding[0], 0)
+        self.padding = (0, 0, 0)
+
+    def forward(self, x, cache_x=None):
+        padding = list(self._padding)
+        if cache_x is not None and self._padding[4] > 0:
+            x = torch.cat([cache_x, x], dim=2)
+            padding[4] -= cache_x.shape[2]
+        return super().forward(F.pad(x, padding))
+
+
+class WanRMS_norm(nn.Module):
+    """F.normalize over the channel axis * sqrt(C) * gamma (channel-first; gamma [C,1,1,1] for video, [C,1,1] for images)."""
+
+    def __init__(self, dim, images=True):
+        super().__init__()
+        self.scale = dim ** 0.5
+        self.gamma = nn.Parameter(torch.ones((dim, 1, 1) if images else (dim, 1, 1, 1)))
+
+    def forward(self, x):
+        return F.normalize(x, dim=1) * self.scale * self.gamma
+
+
+def _cached_conv(conv, x, feat_cache, feat_idx):
+    """the cache protocol every 3x3x3 convolution of the encoder follows"""
+    if feat_cache is None:
+        return conv(x)
+    idx = feat_idx[0]
+    cache_x = x[:, :, -CACHE_T:].clone()
+    if cache_x.shape[2] < 2 and feat_cache[idx] is not None:
+        cache_x = torch.cat([feat_cache[idx][:, :, -1:], cache_x], dim=2)
+    y = conv(x, feat_cache[idx])
+    feat_cache[idx] = cache_x
+    feat_idx[0] += 1
+    return y
+
+
+class WanResidualBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = WanRMS_norm(cin, images=False)
+        self.conv1 = WanCausalConv3d(cin, cout, 3, padding=1)
+        self.norm2 = WanRMS_norm(cout, images=False)
+        self.conv2 = WanCausalConv3d(cout, cout, 3, padding=1)
+        self.conv_shortcut = WanCausalConv3d(cin, cout, 1) if cin != cout else nn.Identity()
+
+    def forward(self, x, feat_cache=None, feat_idx=None):
+        h = self.conv_shortcut(x)
+        x = _cached_conv(self.conv1, F.silu(self.norm1(x)), feat_cache, feat_idx)
+        x = _cached_conv(self.conv2, F.silu(self.norm2(x)), feat_cache, feat_idx)
+        return x + h
+
+
+class WanResample(nn.Module):
+    def __init__(self, dim, mode):
+        super().__init__()
+        assert mode in ("downsample2d", "downsample3d")
+        self.mode = mode
+        self.resample = nn.Sequential(nn.ZeroPad2d((0, 1, 0, 1)), nn.Conv2d(dim, dim, 3, stride=(2, 2)))
+        if mode == "downsample3d":
+            self.time_conv = WanCausalConv3d(dim, dim, (3, 1, 1), stride=(2, 1, 1), padding=(0, 0, 0))
+
+    def forward(self, x, feat_cache=None, feat_idx=None):
+        b, c, t, h, w = x.shape
+        x = self.resample(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
+        x = x.view(b, t, x.size(1), x.size(2), x.size(3)).permute(0, 2, 1, 3, 4)
+        if self.mode == "downsample3d" and feat_cache is not None:
+            idx = feat_idx[0]
+            if feat_cache[idx] is None:  # first chunk (one frame): passed through, no time convolution
+                feat_cache[idx] = x.clone()
+            else:
+                cache_x = x[:, :, -1:].clone()
+                x = self.time_conv(torch.cat([feat_cache[idx][:, :, -1:], x], 2))
+                feat_cache[idx] = cache_x
+            feat_idx[0] += 1
+        return x
+
+
+class WanAttentionBlock(nn.Module):
+    """single-head attention over the h*w positions of each frame"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = WanRMS_norm(dim)
+        self.to_qkv = nn.Conv2d(dim, dim * 3, 1)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+    def forward(self, x):
+        identity = x
+        b, c, t, h, w = x.shape
+        x = self.norm(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w))
+        qkv = self.to_qkv(x).reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2).contiguous()
+        q, k, v = qkv.chunk(3, dim=-1)
+        x = F.scaled_dot_product_attention(q, k, v)
+        x = x.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, w)
+        x = self.proj(x)
+        return x.view(b, t, c, h, w).permute(0, 2, 1, 3, 4) + identity
+
+
+class WanMidBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.resnets = nn.ModuleList([WanResidualBlock(dim, dim), WanResidualBlock(dim, dim)])
+        self.attentions = nn.ModuleList([WanAttentionBlock(dim)])
+
+    def forward(self, x, feat_cache=None, feat_idx=None):
+        x = self.resnets[0](x, feat_cache, feat_idx)
+        x = self.attentions[0](x)
+        return self.resnets[1](x, feat_cache, feat_idx)
+
+
+class WanEncoder3d(nn.Module):
+    def __init__(self, dim=96, z_dim=32, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)):
+        super().__init__()
+        dims = [dim * u for u in (1,) + tuple(dim_mult)]
+        self.conv_in = WanCausalConv3d(3, dims[0], 3, padding=1)
+        blocks = []
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                blocks.append(WanResidualBlock(cin, cout))
+                cin = cout
+            if i != len(dim_mult) - 1:
+                blocks.append(WanResample(cout, "downsample3d" if temperal_downsample[i] else "downsample2d"))
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = WanMidBlock(dims[-1])
+        self.norm_out = WanRMS_norm(dims[-1], images=False)
+        self.conv_out = WanCausalConv3d(dims[-1], z_dim, 3, padding=1)
+
+    def forward(self, x, feat_cache=None, feat_idx=None):
+        x = _cached_conv(self.conv_in, x, feat_cache, feat_idx)
+        for blk in self.down_blocks:
+            x = blk(x, feat_cache, feat_idx)
+        x = self.mid_block(x, feat_cache, feat_idx)
+        return _cached_conv(self.conv_out, F.silu(self.norm_out(x)), feat_cache, feat_idx)
+
+
+class AutoencoderKLWanEncoder(nn.Module):
+    def __init__(self, base_dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
+                 latents_mean=None, latents_std=None):
+        super().__init__()
+        self.z_dim = z_dim
+        self.encoder = WanEncoder3d(base_dim, z_dim * 2, dim_mult, num_res_blocks, temperal_downsample)
+        self.quant_conv = WanCausalConv3d(z_dim * 2, z_dim * 2, 1)
+        self.latents_mean = list(LATENTS_MEAN[:z_dim] if latents_mean is None else latents_mean)
+        self.latents_std = list(LATENTS_STD[:z_dim] if latents_std is None else latents_std)
+
+    def _n_cached_convs(self):
+        return sum(1 for m in self.encoder.modules() if isinstance(m, WanCausalConv3d))
+
+    def moments(self, x):
+        """x [B,3,T,H,W] -> [B, 2*z_dim, 1 + (T-1)//4, H/8, W/8]; the published chunk loop (frames past 1 + 4k are dropped)."""
+        T = x.shape[2]
+        feat_cache = [None] * self._n_cached_convs()
+        out = None
+        for i in range(1 + (T - 1) // 4):
+            chunk = x[:, :, :1] if i == 0 else x[:, :, 1 + 4 * (i - 1):1 + 4 * i]
+            o = self.encoder(chunk, feat_cache, [0])
+            out = o if out is None else torch.cat([out, o], 2)
+        return self.quant_conv(out)
+
+    @torch.no_grad()
+    def encode_images(self, image_list, eps=None, generator=None):
+        """toolkit/models/wan21/wan21.py:618-672 on a list of [C,H,W] images or [T,C,H,W] clips -> [B, z_dim, T', H/8, W/8]."""
+        norm = []
+        for im in image_list:
+            if im.ndim == 3:
+                norm.append(im.unsqueeze(1))
+            elif im.ndim == 4:
+                norm.append(im.permute(1, 0, 2, 3))
+            else:
+                raise ValueError(f"Invalid image shape: {im.shape}")
+        images = torch.stack(norm)
+        mom = self.moments(images)
+        mean, logvar = mom.chunk(2, dim=1)
+        std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+        if eps is None:
+            eps = torch.randn(mean.shape, generator=generator, dtype=mean.dtype)
+        z = mean + std * eps.to(mean.dtype)
+        lm = torch.tensor(self.latents_mean).view(1, self.z_dim, 1, 1, 1).to(z.device, z.dtype)
+        ls = 1.0 / torch.tensor(self.latents_std).view(1, self.z_dim, 1, 1, 1).to(z.device, z.dtype)
+        return (z - lm) * ls
+
+
+def init_synthetic_(m, seed=0):
+    """random-init weights that keep activations O(1) (fan-in scaled convolutions, gamma near 1, small biases)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith("bias"):
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            else:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * fan_in ** -0.5)
+    return m

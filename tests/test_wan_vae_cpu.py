@@ -1,0 +1,106 @@
+"""Wan2.1 video-VAE encoder host graph (whole-clip causal formulation, implicit-GEMM 3-D convolution layout, temporal down-sampler,
+per-frame mid attention, per-channel latent normalisation) driven by the oracle's torch kernels in fp32 vs the CHUNKED restatement of the
+published algorithm (oracle/wan_vae_ref.py), and the reference's own input handling / normalisation lines."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd import wan_vae as nwv
+from oracle import ref_ops, wan_vae_ref
+
+CFG = dict(base_dim=32, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=1, temperal_downsample=(False, True, True))
+
+
+def build(cfg=CFG, dtype=torch.float32, device="cpu", ops=ref_ops, seed=0):
+    ref = wan_vae_ref.AutoencoderKLWanEncoder(**cfg)
+    wan_vae_ref.init_synthetic_(ref, seed)
+    nat = nwv.AutoencoderKLWanEncoder(**cfg, dtype=dtype, device=device, ops=ops)
+    nat.load_state_dict({k: v.to(dtype) for k, v in ref.state_dict().items()}, strict=True)
+    nat.prepare()
+    return ref, nat
+
+
+@pytest.mark.parametrize("T", [1, 5, 9, 11])
+def test_whole_clip_graph_equals_the_chunked_algorithm(T):
+    ref, nat = build()
+    g = torch.Generator().manual_seed(T)
+    clip = torch.rand(T, 3, 32, 32, generator=g) * 2 - 1            # [T,C,H,W], as the reference's dataloader hands a clip over
+    with torch.no_grad():
+        want = ref.moments(clip.permute(1, 0, 2, 3).unsqueeze(0))   # [1, 8, T', 4, 4]
+    mom, (Tl, h, w) = nat.moments(clip)
+    assert (Tl, h, w) == (1 + (T - 1) // 4, 4, 4) and tuple(want.shape) == (1, 8, Tl, h, w)
+    got = mom.view(Tl, h, w, 8).permute(3, 0, 1, 2).unsqueeze(0)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+
+
+def test_encode_images_matches_the_reference_lines():
+    """Wan21.encode_images (toolkit/models/wan21/wan21.py:636-670) restated on the oracle VAE next to our entry point: clip list ->
+    [B,C,T,H,W] -> encode -> sample -> (z - mean) * (1 / std)."""
+    ref, nat = build(seed=3)
+    g = torch.Generator().manual_seed(7)
+    clips = [torch.rand(5, 3, 32, 48, generator=g) * 2 - 1 for _ in range(2)]
+    eps = torch.randn(2, 4, 2, 4, 6, generator=g)
+    # --- the reference's lines, on the oracle module
+    images = torch.stack([im.permute(1, 0, 2, 3) for im in clips])
+    with torch.no_grad():
+        mean, logvar = ref.moments(images).chunk(2, dim=1)
+    latents = mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps
+    latents_mean = torch.tensor(ref.latents_mean).view(1, 4, 1, 1, 1)
+    latents_std = 1.0 / torch.tensor(ref.latents_std).view(1, 4, 1, 1, 1)
+    want = (latents - latents_mean) * latents_std
+    assert torch.allclose(ref.encode_images(clips, eps), want)
+    got = nat.encode_images(clips, eps=eps)
+    assert got.shape == want.shape == (2, 4, 2, 4, 6)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+    # single images: [C,H,W] -> one frame
+    ims = [c[0] for c in clips]
+    e1 = torch.randn(2, 4, 1, 4, 6, generator=g)
+    assert torch.allclose(nat.encode_images(ims, eps=e1), ref.encode_images(ims, e1), rtol=1e-4, atol=1e-5)
+
+
+def test_argument_errors_and_published_config():
+    _, nat = build()
+    with pytest.raises(NotImplementedError):
+        nat.moments(torch.zeros(1, 3, 30, 32))
+    with pytest.raises(ValueError):
+        nat.encode_images([torch.zeros(3, 32)])
+    with pytest.raises(ValueError):
+        nat.encode_images([torch.zeros(1, 3, 32, 32), torch.zeros(5, 3, 32, 32)])
+    # full-width configuration: 2 x 16 moments, published normalisation constants, the module names of the published encoder
+    full = nwv.AutoencoderKLWanEncoder(dtype=torch.float32, device="meta")
+    keys = set(full.state_dict().keys())
+    for k in ("encoder.conv_in.weight", "encoder.down_blocks.0.norm1.gamma", "encoder.down_blocks.2.resample.1.weight",
+              "encoder.down_blocks.3.conv_shortcut.weight", "encoder.down_blocks.5.time_conv.weight", "encoder.down_blocks.8.time_conv.bias",
+              "encoder.down_blocks.10.conv2.weight", "encoder.mid_block.attentions.0.to_qkv.weight", "encoder.mid_block.resnets.1.norm2.gamma",
+              "encoder.norm_out.gamma", "encoder.conv_out.weight", "quant_conv.weight"):
+        assert k in keys, k
+    assert keys == set(wan_vae_ref.AutoencoderKLWanEncoder().state_dict().keys())
+    sd = full.state_dict()
+    assert tuple(sd["encoder.conv_in.weight"].shape) == (96, 3, 3, 3, 3) and tuple(sd["encoder.conv_out.weight"].shape) == (32, 384, 3, 3, 3)
+    assert tuple(sd["encoder.down_blocks.5.time_conv.weight"].shape) == (192, 192, 3, 1, 1)
+    assert len(full.latents_mean) == len(full.latents_std) == 16 and full.latents_std[0] == 2.8184
+
+
+def test_conv3d_table_entry_is_a_causal_conv3d():
+    """the oracle table's conv3d (what the HIP kernel is compared with on the GPU) against F.conv3d with explicit causal padding"""
+    g = torch.Generator().manual_seed(0)
+    T, H, W, Cin, Cout = 5, 5, 6, 8, 16
+    x = torch.randn(T, H, W, Cin, generator=g)
+    w5 = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    want = F.conv3d(F.pad(x.permute(3, 0, 1, 2).unsqueeze(0), (1, 1, 1, 1, 2, 0)), w5, bias)[0].permute(1, 2, 3, 0).reshape(T * H * W, Cout)
+    buf = torch.zeros((T + 2) * H * W, Cin)
+    buf[2 * H * W:] = x.reshape(T * H * W, Cin)
+    wk = w5.permute(0, 2, 3, 4, 1).reshape(Cout, 27 * Cin)
+    out = torch.empty(T * H * W, Cout)
+    ref_ops.conv3d(buf, wk, out, T=T, H=H, W=W, bias=bias)
+    assert torch.allclose(out, want, rtol=1e-5, atol=1e-5)
+    # (3,1,1) stride-2 time convolution
+    wt = torch.randn(Cin, Cin, 3, 1, 1, generator=g)
+    n = 2
+    want_t = F.conv3d(x[:2 * n + 1].permute(3, 0, 1, 2).unsqueeze(0), wt, None, stride=(2, 1, 1))[0].permute(1, 2, 3, 0).reshape(n * H * W, Cin)
+    out_t = torch.empty(n * H * W, Cin)
+    ref_ops.conv3d(x.reshape(T * H * W, Cin)[: (2 * n + 1) * H * W].contiguous(), wt.reshape(Cin, Cin, 3).permute(0, 2, 1).reshape(Cin, 3 * Cin),
+                   out_t, T=n, H=H, W=W, kt=3, ks=1, tstride=2, pad_t=0, pad_l=0)
+    assert torch.allclose(out_t, want_t, rtol=1e-5, atol=1e-5)
