@@ -380,6 +380,10 @@ def main():
         # bf16 base: 245 GiB peak at B = 7; the fp8 base holds 23.8 GB less (weights as bytes, bf16 copies released): 7 fits from 232 GiB
         need = 232 if args.fp8_base else 252
         B = 7 if (avail_gib >= need and args.network == "lora") else 4
+        if world > 1:  # every rank must step the same shard size (global batch = B * world): take the smallest choice
+            bt = torch.tensor([B], device=dev, dtype=torch.int64)
+            torch.distributed.all_reduce(bt, op=torch.distributed.ReduceOp.MIN)
+            B = int(bt.item())
     lat, emb, pooled = make_batch(dev, B, seed=42 + rank)
 
     def one():
@@ -476,6 +480,35 @@ def main():
                                                                                                  for i, (w, h) in enumerate(BUCKETS)},
                            "single_bucket_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s")}
         del batches, order
+        # ---- uncached-latent mode (north_star "VAE latent encode" inside the hot loop; jobs/process/BaseSDTrainProcess.py:1133 calls
+        # sd.encode_images when the batch carries no cached latents): the FLUX.1 AutoencoderKL encoder runs on the batch's images in
+        # front of every step, same batch size as the bucketed leg
+        try:
+            from ai_toolkit_amd import vae as nvae
+
+            torch.cuda.empty_cache()
+            enc = nvae.AutoencoderKLEncoder(dtype=torch.bfloat16, device=dev, ops=ops)
+            gv = torch.Generator(device=dev).manual_seed(7)
+            with torch.no_grad():
+                for name, prm in enc.named_parameters():
+                    if name.endswith("weight") and prm.dim() > 1:
+                        prm.copy_((torch.randn(prm.shape, device=dev, generator=gv) * prm[0].numel() ** -0.5).to(prm.dtype))
+            enc.prepare()
+            imgs = torch.rand(bb, 3, 1024, 1024, device=dev, generator=gv) * 2 - 1
+            _, e2, p2 = make_batch(dev, bb, seed=44)
+
+            def fn_vae():
+                lat2 = torch.cat([enc.encode_images(imgs[i:i + 1], generator=gv) for i in range(bb)])
+                return step.step(lat2, e2, p2)
+
+            fn_vae()
+            dv, _, _ = timed_steps(fn_vae, 3, barrier)
+            out["uncached_latents"] = {"images_per_s": bb * 3 / dv, "ms_per_step": 1e3 * dv / 3, "per_gpu_batch": bb,
+                                       "cached_latents_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s"),
+                                       "note": "FLUX.1 VAE encoder (1024x1024 -> 16x128x128, one image per launch sequence) + train step"}
+            del enc, imgs, e2, p2, fn_vae
+        except Exception as ex:  # never cost the headline line
+            out["uncached_latents"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     if rank == 0:
         if rf is not None:
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
