@@ -195,7 +195,7 @@ class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("d0", i64), ("d1", i64), ("d2", i64), ("rows", i32), ("cols", i32), ("kind", i32), ("aux", i32)]
 
 
-EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE, EPI_SPLIT_SLAB = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
@@ -248,6 +248,7 @@ def lib():
     L.aitk_geglu_fwd.argtypes = [vp, i64, vp, i64, i64, i32, vp]
     L.aitk_geglu_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
     L.aitk_resample2x.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.aitk_pad_nhwc.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.aitk_copy_heads.argtypes = [vp, i64, vp, i64, i64, i32, i32, i32, vp]
     _lib = L
     return L

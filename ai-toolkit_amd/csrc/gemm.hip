@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
       const int fr = p.conv_t3d ? b * ((p.conv_t3d >> 8) & 255) : b;  // first input frame of output frame b
       pa[i] = (((long)fr * p.conv_H + iy0[i]) * p.conv_W + ix0[i]) * p.conv_Cin;  // may lie outside; only used when valid
       ao[i] = 0;
-      ao2[i] = 0;
+      ao2[i] = p.K2 > 0 ? (unsigned)((long)ra * p.lda2) : 0u;  // LoRA K-slab of a convolution adapter: plain rows of A2 [M, K2]
     } else {
       pa[i] = 0;
       ao[i] = (unsigned)(seg_row(p.A, p.lda, p.a_seg_rows, p.a_seg_stride, ra) - p.A);
@@ -216,7 +216,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
     char* sa = smem + buf * BUF_BYTES;
     char* sb = sa + A_BYTES;
     // destination = wave-uniform base + lane*16 (LDS-DMA is lane-linear)
-    if constexpr (CONV) {
+    if (CONV && second) {  // K-slab steps of a convolution with an adapter: A2 is an ordinary row-major matrix
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const bf16_t* a = kvalid_chunk ? p.A2 + ao2[i] + kk : g_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a,
+                                         (__attribute__((address_space(3))) void*)(sa + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      }
+    } else if constexpr (CONV) {
       const int kc = k0 + cc * 8;
       const bool kin = kc < p.K;
       const int tap3 = kin ? kc / p.conv_Cin : 0;
@@ -333,6 +340,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
         const int nb = n0 + wc * (32 * NI) + ni * 32 + 8 * g + 4 * h;
         if (nb >= p.N) continue;
         float v[4];
+        if (flags & AITK_EPI_SPLIT_SLAB) {
+          // N = 32 = [P_hi ; P_lo] (16 + 16 rows of B): t = A P_hi^T + A P_lo^T in fp32 — columns n and n + 16 sit in register groups g
+          // and g + 2 of the same lane — written as the K-slab triple [hi | lo | hi] (48 columns) like aitk_lora_down(split_rp = 16)
+          if (g >= 2) continue;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e] + acc[mi][ni][4 * (g + 2) + e];
+          if (flags & AITK_EPI_COL_SCALE) {
+            const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(p.col_scale + nb);
+            v[0] *= cs[0]; v[1] *= cs[1]; v[2] *= cs[2]; v[3] *= cs[3];
+          }
+          uint2 hi, lo;
+          hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+          lo.x = pack2bf(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x));
+          lo.y = pack2bf(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y));
+          *reinterpret_cast<uint2*>(crow + nb) = hi;
+          *reinterpret_cast<uint2*>(crow + 16 + nb) = lo;
+          *reinterpret_cast<uint2*>(crow + 32 + nb) = hi;
+          continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e];
         if (flags & AITK_EPI_COL_SCALE) {
@@ -441,6 +467,9 @@ static int gemm_check(const AitkGemmArgs* a) {
   if ((a->flags & AITK_EPI_GELU) && !a->aux_out) return AITK_ERR_ARG;  // GATE_RES: aux_out optional (only d_gate needs y)
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
+  if (a->flags & AITK_EPI_SPLIT_SLAB) {  // [P_hi ; P_lo] product -> [hi | lo | hi] slab: rank block 16 only, no other epilogue but the column scale
+    if (a->N != 32 || a->ldc < 48 || a->c_seg_rows != 0 || (a->flags & ~(AITK_EPI_SPLIT_SLAB | AITK_EPI_COL_SCALE))) return AITK_ERR_ARG;
+  }
   if (((uintptr_t)a->A | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
   if ((uintptr_t)a->B & (a->b_scale_mode ? 7 : 15)) return AITK_ERR_ALIGN;
   return AITK_OK;
@@ -454,7 +483,7 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
   if (a->conv_mode) {
     const int c_kt = a->conv_t3d ? (a->conv_t3d & 255) : 1, c_ts = a->conv_t3d ? ((a->conv_t3d >> 8) & 255) : 1;
     const int c_ks = a->conv_t3d ? ((a->conv_t3d >> 16) & 255) : 3;
-    if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != c_kt * c_ks * c_ks * a->conv_Cin || a->K2 != 0 || a->a_seg_rows != 0 ||
+    if (!a->zero_page || a->conv_Cin <= 0 || (a->conv_Cin % 8) || a->K != c_kt * c_ks * c_ks * a->conv_Cin || a->a_seg_rows != 0 ||
         a->conv_stride <= 0 || a->conv_Wo <= 0 || a->conv_HoWo <= 0 || c_kt < 1 || c_kt > 3 || c_ts < 1 || c_ts > 2 || (c_ks != 1 && c_ks != 3) ||
         (a->conv_t3d >> 24))
       return AITK_ERR_ARG;

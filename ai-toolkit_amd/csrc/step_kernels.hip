@@ -321,6 +321,25 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena
     }
     return;
   }
+  if (d.kind == 4) {  // lora_down of a 3x3-conv adapter: Conv2d weight [rank, Cin, 3, 3] (columns c = cin*9 + tap), Cin = aux
+    const int cin_n = d.aux;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      const float w = src[i];
+      const bf16_t hi = f2bf(w);
+      const bf16_t lo = f2bf(w - bf2f(hi));
+      const long r = i / d.cols, c = i - r * d.cols;
+      const long cin = c / 9, tap = c - cin * 9;
+      // d0: [2 rank, 9 Cin] = [A_hi ; A_lo], tap-major columns — B operand of the implicit-GEMM lora_down (AITK_EPI_SPLIT_SLAB)
+      shadow[d.d0 + r * d.cols + tap * cin_n + cin] = hi;
+      shadow[d.d0 + (d.rows + r) * d.cols + tap * cin_n + cin] = lo;
+      // d1: [Cin, 9 * 3 rank]: data-gradient filter over the dT slab image [hi | lo | hi] = rotated taps, [A_hi | A_hi | A_lo] per tap
+      bf16_t* t3 = shadow + d.d1 + cin * (27 * d.rows) + (8 - tap) * 3 * d.rows + r;
+      t3[0] = hi;
+      t3[d.rows] = hi;
+      t3[2 * d.rows] = lo;
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float w = src[i];
     const bf16_t hi = f2bf(w);

@@ -239,6 +239,34 @@ extern "C" int aitk_resample2x(const aitk_bf16* src, aitk_bf16* dst, int32_t B, 
   return AITK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ one-pixel zero border
+// dst [B, H+2, W+2, C] = src [B, H, W, C] framed by zeros.  Weight gradient of a 3x3-conv adapter's lora_down (toolkit/lora_special.py:95-104):
+// with BOTH the layer input and the rank-space gradient on the framed grid, tap (ky, kx) of dA is the plain skinny contraction
+// sum_j dT[j]^T x[j + (ky-1)(W+2) + (kx-1)] over the flat pixel index (wrapped pairs always meet a zero), i.e. nine aitk_lora_wgrad launches.
+__global__ __launch_bounds__(256) void pad_nhwc_kernel(const bf16_t* src, bf16_t* dst, int B, int H, int W, int C) {
+  const int nch = C / 8;
+  const int Hp = H + 2, Wp = W + 2;
+  const long total = (long)B * Hp * Wp * nch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    long pix = i / nch;
+    const int ox = (int)(pix % Wp);
+    pix /= Wp;
+    const int oy = (int)(pix % Hp);
+    const int b = (int)(pix / Hp);
+    uint4 o = make_uint4(0, 0, 0, 0);
+    if (oy >= 1 && oy <= H && ox >= 1 && ox <= W) o = *reinterpret_cast<const uint4*>(src + (((long)b * H + oy - 1) * W + ox - 1) * C + ch * 8);
+    *reinterpret_cast<uint4*>(dst + i * 8) = o;
+  }
+}
+extern "C" int aitk_pad_nhwc(const aitk_bf16* src, aitk_bf16* dst, int32_t B, int32_t H, int32_t W, int32_t C, aitk_stream_t stream) {
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return AITK_ERR_SHAPE;
+  const long total = (long)B * (H + 2) * (W + 2) * (C / 8);
+  hipLaunchKernelGGL(pad_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, H, W, C);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ head-dim padding
 // dst[m][h * d_dst + j] = j < d_src ? src[m][h * d_src + j] : 0   for j < d_dst   (d_src, d_dst multiples of 8).  d_src < d_dst pads the
 // heads of q / k / v / dO to the flash kernel's head_dim 128 (zero columns change neither q.k nor the softmax, and give zero output /

@@ -214,9 +214,11 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     return out
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0):
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
     """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad).
-    split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo."""
+    split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo.
+    out_strides = (stride_r, stride_l): element (r, l) goes to out.flatten()[r*stride_r + l*stride_l] (`out` = fp32 view starting at the
+    first element; one tap of a conv adapter's [r, Cin, 3, 3] gradient: strides (9 Cin, 9))."""
     a = _capi.LoraWgradArgs()
     a.lds = _row_major(s, "s")
     a.ldg = _row_major(g, "g")
@@ -224,7 +226,10 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
     a.split_rp = int(split)
     M = s.shape[0] if M is None else M
     assert out.dtype == torch.float32 and out.is_contiguous()
-    if transpose_out:
+    if out_strides is not None:
+        a.out_stride_r, a.out_stride_l = out_strides
+        assert out.numel() > (R - 1) * out_strides[0] + (L - 1) * out_strides[1]
+    elif transpose_out:
         assert tuple(out.shape) == (L, R)
         a.out_stride_r, a.out_stride_l = 1, R
     else:
@@ -505,8 +510,12 @@ def _zero_page(device):
     return z
 
 
-def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
-    """Implicit-GEMM 3x3 convolution on NHWC: x [B*H*W, Cin], w [Cout, 9*Cin] (k = (ky*3+kx)*Cin + cin), out [B*Ho*Wo, Cout]."""
+def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None, a2=None, b2=None,
+            split_slab=False, col_scale=None):
+    """Implicit-GEMM 3x3 convolution on NHWC: x [B*H*W, Cin], w [Cout, 9*Cin] (k = (ky*3+kx)*Cin + cin), out [B*Ho*Wo, Cout].
+    a2 [M, K2] / b2 [Cout, K2]: LoRA K-slab added to the product (the lora_up of a conv adapter, fused like a Linear's).
+    split_slab: w = [A_hi ; A_lo] (32 rows) and out is the [M, 48] slab [hi | lo | hi] of the fp32 sum (the conv adapter's lora_down),
+    scaled by the fp32 vector col_scale [32]."""
     g = _capi.GemmArgs()
     Cin = x.shape[1]
     assert x.is_contiguous() and x.dtype == BF16 and x.shape[0] == B * H * W
@@ -514,8 +523,18 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     Wo = W if Wo is None else Wo
     g.lda, g.ldb, g.ldc = Cin, _row_major(w, "w"), _row_major(out, "out")
     N, K = w.shape
-    assert K == 9 * Cin and out.shape == (B * Ho * Wo, N)
+    assert K == 9 * Cin and out.shape == (B * Ho * Wo, 48 if split_slab else N)
     g.A, g.B, g.C = _ptr(x), _ptr(w), _ptr(out)
+    if split_slab:
+        assert N == 32 and bias is None and aux_in is None and a2 is None
+        flags |= _capi.EPI_SPLIT_SLAB
+    if col_scale is not None:
+        assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == N
+        flags |= _capi.EPI_COL_SCALE
+        g.col_scale = _ptr(col_scale)
+    if a2 is not None:
+        assert a2.shape[0] >= B * Ho * Wo and b2.shape[0] == N and a2.shape[1] == b2.shape[1]
+        g.A2, g.lda2, g.B2, g.ldb2, g.K2 = _ptr(a2), _row_major(a2, "a2"), _ptr(b2), _row_major(b2, "b2"), a2.shape[1]
     if bias is not None:
         flags |= EPI_BIAS
         g.bias = _ptr(bias)
@@ -747,6 +766,14 @@ def resample2x(src, dst, *, B, H, W, mode):
     assert src.is_contiguous() and dst.is_contiguous() and src.dtype == BF16 and dst.dtype == BF16 and src.shape[0] == B * H * W
     assert dst.shape == ((B * (H // 2) * (W // 2), Cc) if mode == 1 else (B * 4 * H * W, Cc))
     _call("aitk_resample2x", _ptr(src), _ptr(dst), B, H, W, Cc, mode)
+    return dst
+
+
+def pad_nhwc(src, dst, *, B, H, W):
+    """dst [B*(H+2)*(W+2), C] = src [B*H*W, C] inside a one-pixel zero border."""
+    Cc = src.shape[1]
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape[0] == B * H * W and dst.shape == (B * (H + 2) * (W + 2), Cc)
+    _call("aitk_pad_nhwc", _ptr(src), _ptr(dst), B, H, W, Cc)
     return dst
 
 

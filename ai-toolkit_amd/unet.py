@@ -112,8 +112,21 @@ class _Norm(nn.Module):
         return self._mod
 
 
+class ResnetBlock2D(_Holder):
+    """Class names matter: with `network.conv` set the reference's LoRA discovery also targets the Linear / Conv2d children of
+    ResnetBlock2D, Downsample2D and Upsample2D (toolkit/kohya_lora.py:751, toolkit/lora_special.py:678-681)."""
+
+
+class Downsample2D(_Holder):
+    pass
+
+
+class Upsample2D(_Holder):
+    pass
+
+
 def _resnet(cin, cout, temb, dtype, device, groups):
-    r = _Holder()
+    r = ResnetBlock2D()
     r.norm1 = _Norm(cin, 1e-5, dtype, device, groups)
     r.conv1 = Conv3x3(cin, cout, 1, dtype, device)
     r.time_emb_proj = Linear(temb, cout, True, dtype, device)
@@ -164,11 +177,11 @@ class Transformer2DModel(nn.Module):
 
 def _block(resnets, attentions=None, sampler=None, kind="down"):
     b = _Holder()
-    b.resnets = nn.ModuleList(resnets)
-    if attentions is not None:
+    if attentions is not None:  # diffusers registers attentions before resnets (the order named_modules() walks = adapter creation order)
         b.attentions = nn.ModuleList(attentions)
+    b.resnets = nn.ModuleList(resnets)
     if sampler is not None:
-        s = _Holder()
+        s = Downsample2D() if kind == "down" else Upsample2D()
         s.conv = sampler
         setattr(b, "downsamplers" if kind == "down" else "upsamplers", nn.ModuleList([s]))
     return b

@@ -35,6 +35,9 @@ typedef uint16_t aitk_bf16;
 #define AITK_EPI_GATE_RES 16 /* aux_out = y; C = aux_in(residual) + gate[m / gate_rows][n] * y   */
 #define AITK_EPI_BIAS_ROW 32 /* + bias[m]  (transposed products, e.g. V^T = W_v x^T)             */
 #define AITK_EPI_ADD_AUX 64  /* + aux_in[m][n]  (residual add of ResnetBlock2D / VAE attention)  */
+#define AITK_EPI_SPLIT_SLAB 256 /* N = 32 = [P_hi ; P_lo] (bf16 hi / lo halves of a rank-16 fp32 projection stacked as B rows): the fp32 sum of
+                                  columns n and n + 16 is written as the K-slab triple [hi | lo | hi] (C is [M, >= 48]) — lora_down of a 3x3-conv
+                                  adapter (toolkit/lora_special.py:95-104) on the implicit-GEMM kernel; only COL_SCALE may accompany it */
 #define AITK_EPI_COL_SCALE 128 /* product * col_scale[n] before the bias: DoRA magnitude / ||W + dW||_row (toolkit/models/DoRA.py:126-148) */
 
 /*
@@ -294,7 +297,11 @@ int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
  *   kind 2 (lora_up B [out, r]):   d0 = [out, 3r] rows = [B_hi | B_hi | B_lo] (B2 of the forward K-slab),
  *                                  d1 = hi transposed [r, out], d2 = lo transposed [r, out] (P / P_lo of the backward aitk_lora_down).
  *   kind 3 (low-rank LoKr factor, toolkit/models/lokr.py:184-197): the arena holds a [rows, aux] followed by b [aux, cols];
- *                                  d0 = bf16(a @ b) [rows, cols] composed in fp32, d1 = its transpose [cols, rows]. */
+ *                                  d0 = bf16(a @ b) [rows, cols] composed in fp32, d1 = its transpose [cols, rows].
+ *   kind 4 (lora_down of a 3x3-conv adapter: Conv2d weight [r, Cin, 3, 3] = [rows, cols = 9 Cin], column cin*9 + tap; aux = Cin,
+ *           toolkit/lora_special.py:95-104): d0 = [2r, 9 Cin] = [A_hi ; A_lo] with tap-major columns tap*Cin + cin (B operand of the
+ *           implicit-GEMM lora_down, AITK_EPI_SPLIT_SLAB); d1 = [Cin, 9*3r], column (8 - tap)*3r + j = [A_hi | A_hi | A_lo] (the rotated
+ *           filter of the data gradient, a 3x3 convolution over the dT slab image [hi | lo | hi]); d2 unused. */
 typedef struct AitkShadowDesc { int64_t src_off; int64_t d0; int64_t d1; int64_t d2; int32_t rows, cols, kind, aux; } AitkShadowDesc;
 int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                               aitk_stream_t stream);
@@ -425,6 +432,9 @@ int aitk_geglu_bwd(const aitk_bf16* dy, int64_t ld_dy, const aitk_bf16* hg, int6
  * mode 1: 2x2 sum (its backward) -> [B,H/2,W/2,C]; mode 2: zero insertion -> [B,2H,2W,C] (data gradient of a stride-2 conv as a stride-1
  * conv with the rotated filter). */
 int aitk_resample2x(const aitk_bf16* src, aitk_bf16* dst, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode, aitk_stream_t stream);
+/* dst [B, H+2, W+2, C] = src [B, H, W, C] inside a one-pixel zero border (contiguous NHWC, C % 8 == 0): operands of the nine per-tap
+ * aitk_lora_wgrad launches that form lora_down.weight.grad of a 3x3-conv adapter (toolkit/lora_special.py:95-104). */
+int aitk_pad_nhwc(const aitk_bf16* src, aitk_bf16* dst, int32_t B, int32_t H, int32_t W, int32_t C, aitk_stream_t stream);
 /* per-head column copy with zero fill: dst[m][h*d_dst + j] = j < d_src ? src[m][h*d_src + j] : 0 (j < d_dst) — pads head_dim 40 / 64 / 80 to
  * the flash kernels' 128 (exact: zero columns change neither q.k nor softmax) and drops the padding again. */
 int aitk_copy_heads(const aitk_bf16* src, int64_t ld_src, aitk_bf16* dst, int64_t ld_dst, int64_t M, int32_t H, int32_t d_src, int32_t d_dst,

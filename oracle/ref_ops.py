@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX = 1, 2, 4, 8, 16, 32, 64
+EPI_SPLIT_SLAB = 256
 
 
 def _seg_view(t, seg, M):
@@ -111,14 +112,19 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     return out
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0):
-    """autograd of lora_down / lora_up weights (split: s is the slab layout, read as hi + lo)."""
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
+    """autograd of lora_down / lora_up weights (split: s is the slab layout, read as hi + lo); out_strides: strided destination
+    (one tap of a conv adapter's [r, Cin, 3, 3] gradient)."""
     if M is None:
         M = s.shape[0]
     if split:
         c_hi, c_lo, _ = _split_cols(s.shape[1] // 3, split)
         s = s[:M, c_hi].float() + s[:M, c_lo].float()
     v = s[:M].float().t() @ _seg_view(g, g_seg, M).float()
+    if out_strides is not None:
+        dst = torch.as_strided(out, v.shape, out_strides)
+        dst.add_(v) if accumulate else dst.copy_(v)
+        return out
     if transpose_out:
         v = v.t()
     if accumulate:
@@ -387,6 +393,15 @@ def refresh_shadows(arena, shadow, table):
             continue
         w = arena[so:so + r * c].view(r, c)
         hi = w.to(shadow.dtype)
+        if kind == 4:  # lora_down of a 3x3-conv adapter: [r, Cin, 3, 3] -> [A_hi ; A_lo] tap-major, and the rotated dgrad filter over the slab
+            cin = aux[0]
+            lo = (w - hi.float()).to(shadow.dtype)
+            tm = lambda t: t.view(r, cin, 9).permute(0, 2, 1).reshape(r, 9 * cin)  # noqa: E731  columns tap*Cin + cin
+            shadow[d0:d0 + 2 * r * c].view(2 * r, c).copy_(torch.cat((tm(hi), tm(lo)), dim=0))
+            h3, l3 = hi.view(r, cin, 9).flip(2), lo.view(r, cin, 9).flip(2)  # [r, cin, tap'] with tap' = 8 - tap
+            blk = torch.cat((h3, h3, l3), dim=0)  # [3r, cin, tap']: slab channel j -> (A_hi | A_hi | A_lo)
+            shadow[d1:d1 + 3 * r * c].view(cin, 27 * r).copy_(blk.permute(1, 2, 0).reshape(cin, 27 * r))
+            continue
         if kind == 0:
             shadow[d0:d0 + r * c].view(r, c).copy_(hi)
             shadow[d1:d1 + r * c].view(c, r).copy_(hi.t())
@@ -403,8 +418,11 @@ def refresh_shadows(arena, shadow, table):
 
 
 # ---------------------------------------------------------------------------------------------------------- VAE encoder
-def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):
-    """nn.Conv2d 3x3 on NHWC rows (diffusers AutoencoderKL, reached from toolkit/stable_diffusion_model.py:2567)."""
+def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None, a2=None, b2=None,
+            split_slab=False, col_scale=None):
+    """nn.Conv2d 3x3 on NHWC rows (diffusers AutoencoderKL, reached from toolkit/stable_diffusion_model.py:2567); with a2 / b2 the
+    lora_up K-slab of a conv adapter is added; split_slab: the conv adapter's lora_down (w = [A_hi ; A_lo]) written as [hi | lo | hi]
+    (toolkit/lora_special.py:95-104, toolkit/network_mixins.py:304-342)."""
     Cin = x.shape[1]
     Ho = H if Ho is None else Ho
     Wo = W if Wo is None else Wo
@@ -415,12 +433,32 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     xi = F.pad(xi, (pad_l, max(pad_r, 0), pad_t, max(pad_b, 0)))
     y = F.conv2d(xi, wk, None, stride=stride)[:, :, :Ho, :Wo]
     v = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, -1)
+    if split_slab:
+        t = v[:, :16] + v[:, 16:32]
+        if col_scale is not None:
+            t = t * col_scale.float()[:16]
+        hi = t.to(out.dtype)
+        lo = (t - hi.float()).to(out.dtype)
+        out.copy_(torch.cat((hi, lo, hi), dim=1))
+        return out
+    if a2 is not None:
+        v = v + a2[:v.shape[0]].float() @ b2.float().t()
+    if col_scale is not None:
+        v = v * col_scale.float()[None, :]
     if bias is not None:
         v = v + bias.float()
     if flags & EPI_ADD_AUX:
         v = v + aux_in.float()
     out.copy_(v.to(out.dtype))
     return out
+
+
+def pad_nhwc(src, dst, *, B, H, W):
+    Cc = src.shape[1]
+    y = torch.zeros(B, H + 2, W + 2, Cc, dtype=dst.dtype, device=dst.device)
+    y[:, 1:H + 1, 1:W + 1] = src.view(B, H, W, Cc).to(dst.dtype)
+    dst.copy_(y.view(dst.shape))
+    return dst
 
 
 def conv3d(x, w, out, *, T, H, W, kt=3, ks=3, tstride=1, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None):

@@ -176,9 +176,11 @@ class Upsample2D(nn.Module):
 class _DownBlock(nn.Module):
     def __init__(self, cin, cout, layers, add_down, attn=None, temb=1280, groups=32):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
+        # registration order of diffusers' blocks (attentions, resnets, samplers): it is the order named_modules() walks, hence the
+        # order the reference creates adapters in (and consumes the RNG) once `network.conv` also wraps the ResnetBlock2D children
         if attn is not None:
             self.attentions = nn.ModuleList([Transformer2DModel(in_channels=cout, **attn) for _ in range(layers)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
 
     def forward(self, x, temb, context):
@@ -205,8 +207,8 @@ class DownBlock2D(_DownBlock):
 class UNetMidBlock2DCrossAttn(nn.Module):
     def __init__(self, ch, attn, temb=1280, groups=32):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb, groups), ResnetBlock2D(ch, ch, temb, groups)])
         self.attentions = nn.ModuleList([Transformer2DModel(in_channels=ch, **attn)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb, groups), ResnetBlock2D(ch, ch, temb, groups)])
 
     def forward(self, x, temb, context):
         x = self.resnets[0](x, temb)
@@ -222,9 +224,9 @@ class _UpBlock(nn.Module):
             skip = cin if i == layers - 1 else cout
             rin = prev if i == 0 else cout
             res.append(ResnetBlock2D(rin + skip, cout, temb, groups))
-        self.resnets = nn.ModuleList(res)
         if attn is not None:
             self.attentions = nn.ModuleList([Transformer2DModel(in_channels=cout, **attn) for _ in range(layers)])
+        self.resnets = nn.ModuleList(res)
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
 
     def forward(self, x, skips, temb, context):

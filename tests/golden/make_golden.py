@@ -724,12 +724,73 @@ def golden_unet_lora():
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_lora_tiny.safetensors"), {"meta": json.dumps(meta)})
 
 
+def golden_unet_conv_lora():
+    """The same as golden_unet_lora with `network.conv` set (conv_lora_dim / conv_alpha: toolkit/lora_special.py:585-587, 678-681): the
+    reference then also wraps every Linear / Conv2d child of ResnetBlock2D, Downsample2D and Upsample2D (toolkit/kohya_lora.py:750-751) —
+    3x3 convolutions at the conv rank (lora_down = Conv2d(in, r, 3, stride, padding), lora_up = Conv2d(r, out, 1): lora_special.py:95-104),
+    `time_emb_proj` and the 1x1 `conv_shortcut` at the linear rank."""
+    import hashlib
+
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, TINY_SDXL, _inputs
+
+    out, meta = {}, {}
+    for tag, cfg, is_xl in (("sd15", TINY_SD15, False), ("sdxl", TINY_SDXL, True)):
+        torch.manual_seed(0)
+        model = unet_ref.UNet2DConditionModel(**cfg)
+        unet_ref.init_synthetic_(model, seed=11)
+        torch.manual_seed(99)
+        net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=4, alpha=2.0, conv_lora_dim=2, conv_alpha=1.0, multiplier=1.0,
+                                 train_text_encoder=False, train_unet=True, is_sdxl=is_xl)
+        names = [m.lora_name for m in net.unet_loras]
+        for m in net.unet_loras:
+            out[f"{tag}/init/{m.lora_name}/down"] = m.lora_down.weight.detach().clone()
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in net.unet_loras:
+                m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+                out[f"{tag}/warm/{m.lora_name}/up"] = m.lora_up.weight.detach().clone()
+        net.force_to("cpu", torch.float32)
+        net._update_torch_multiplier()
+        net.apply_to(None, model, False, True)
+        lat, ts, ctx, added = _inputs(cfg)
+        with net:
+            pred = model(lat, ts, ctx, added)
+            wgt = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+            (pred * wgt).sum().backward()
+        out[f"{tag}/pred"], out[f"{tag}/wgt"] = pred.detach().clone(), wgt
+        for m in net.unet_loras:
+            out[f"{tag}/grad/{m.lora_name}/down"] = m.lora_down.weight.grad.detach().clone()
+            out[f"{tag}/grad/{m.lora_name}/up"] = m.lora_up.weight.grad.detach().clone()
+        sd = net.get_state_dict(dtype=torch.float32)
+        for k, v in sd.items():
+            out[f"{tag}/saved/{k}"] = v.clone()
+        meta[tag] = {"names": names, "saved_keys": list(sd.keys()), "scales": [m.scale for m in net.unet_loras],
+                     "dims": [m.lora_dim for m in net.unet_loras], "peft_format": bool(net.peft_format)}
+        print(f"unet conv-lora golden [{tag}]:", len(names), "adapters;", len(sd), "saved tensors")
+    for tag, cfg, is_xl in (("sd15_full", unet_ref.SD15, False), ("sdxl_full", unet_ref.SDXL, True)):
+        with torch.device("meta"):
+            model = unet_ref.UNet2DConditionModel(**cfg)
+        net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=4, alpha=4.0, conv_lora_dim=4, conv_alpha=4.0, multiplier=1.0,
+                                 train_text_encoder=False, train_unet=True, is_sdxl=is_xl)
+        names = [m.lora_name for m in net.unet_loras]
+        shapes = [[list(m.lora_down.weight.shape), list(m.lora_up.weight.shape)] for m in net.unet_loras]
+        meta[tag] = {"count": len(names), "names_sha256": hashlib.sha256("\n".join(names).encode()).hexdigest(), "first": names[:3], "last": names[-3:],
+                     "shapes_sha256": hashlib.sha256(json.dumps(shapes).encode()).hexdigest(),
+                     "params": int(sum(m.lora_down.weight.numel() + m.lora_up.weight.numel() for m in net.unet_loras))}
+        print(f"unet conv-lora golden [{tag}]:", meta[tag]["count"], "adapters,", meta[tag]["params"], "parameters")
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_conv_lora_tiny.safetensors"), {"meta": json.dumps(meta)})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python make_golden.py golden_unet_lora ...: regenerate selected fixtures only
         for fn in sys.argv[1:]:
             globals()[fn]()
         raise SystemExit(0)
     golden_unet_lora()
+    golden_unet_conv_lora()
     golden_unet_keymap_keys()
     golden_lora()
     golden_dora()
