@@ -45,7 +45,18 @@ class LoRAModule(nn.Module):
             use_bias = False
         if use_bias:
             raise NotImplementedError("use_bias LoRA is not on the fused path")
-        in_dim, out_dim = org_module.in_features, org_module.out_features
+        # 3x3 Conv2d (network.conv; toolkit/lora_special.py:95-104): lora_down = Conv2d(in, r, 3, stride, padding), lora_up = Conv2d(r, out, 1).
+        # Held as the flattened matrices [r, in*9] (columns cin*9 + ky*3 + kx = the Conv2d weight's own memory order) and [out, r]: the
+        # same number of kaiming draws with the same fan-in as the reference's Conv2d constructors, i.e. the same RNG consumption.
+        self.is_conv3x3 = bool(getattr(org_module, "is_conv3x3", False))
+        if self.is_conv3x3:
+            assert org_module.cin_pad == org_module.in_channels and org_module.cout_pad == org_module.out_channels
+            if dropout or rank_dropout or module_dropout:
+                raise NotImplementedError("dropout variants on 3x3-conv adapters are not on the fused path")
+            self.conv_cin, self.conv_stride = org_module.in_channels, org_module.stride
+            in_dim, out_dim = org_module.in_channels * 9, org_module.out_channels
+        else:
+            in_dim, out_dim = org_module.in_features, org_module.out_features
         self.lora_dim = lora_dim
         self.full_rank = False
         # same construction (hence same RNG consumption) as toolkit/lora_special.py:105-122
@@ -67,6 +78,7 @@ class LoRAModule(nn.Module):
         # arena bookkeeping (filled by FusedLoRANetwork._build_arena)
         self.off_down = self.off_up = -1
         self.sh_down = self.sh_down_lo = self.sh_downT3 = self.sh_up3 = self.sh_upT = self.sh_upT_lo = None  # build_arena
+        self.sh_down_stack = self.sh_down_dgrad = None  # 3x3-conv adapters: [A_hi ; A_lo] tap-major, rotated dgrad filter over the dT slab
         self.g_down = self.g_up = None
 
     def _set_runtime_scale(self, value):
@@ -276,7 +288,8 @@ class FusedLoRANetwork(nn.Module):
     def __init__(self, unet, lora_dim=4, alpha=1.0, multiplier=1.0, target_lin_modules=("FluxTransformer2DModel",),
                  transformer_only=True, transformer_block_names=None, ignore_if_contains=None, only_if_contains=None,
                  is_transformer=True, peft_format=True, network_type="lora", base_model_version="flux1", lokr_factor=-1,
-                 base_model=None, conv_lora_dim=None, dropout=None, rank_dropout=None, module_dropout=None):
+                 base_model=None, conv_lora_dim=None, conv_alpha=None, dropout=None, rank_dropout=None, module_dropout=None,
+                 target_conv_modules=("ResnetBlock2D", "Downsample2D", "Upsample2D")):
         super().__init__()
         self.dropout, self.rank_dropout, self.module_dropout = dropout, rank_dropout, module_dropout
         if (dropout or rank_dropout or module_dropout) and network_type.lower() != "lora":
@@ -287,8 +300,14 @@ class FusedLoRANetwork(nn.Module):
         # the reference holds a weak reference to the model plug-in for the save / load key-conversion hooks (lora_special.py:373-375)
         self.base_model_ref = weakref.ref(base_model) if base_model is not None else None
         assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
-        if conv_lora_dim:
-            raise NotImplementedError("conv-LoRA on 3x3 convolutions (network.conv) is not on the fused path; 1x1 convolutions are")
+        # network.conv (toolkit/lora_special.py:381-382, 585-590, 678-681; toolkit/kohya_lora.py:751): the Linear / Conv2d children of
+        # ResnetBlock2D, Downsample2D and Upsample2D are wrapped too — 3x3 convolutions at conv_lora_dim / conv_alpha, the rest at the
+        # linear rank.  UNet (kohya-format) plain-LoRA networks only.
+        self.conv_lora_dim, self.conv_alpha = (conv_lora_dim or None), conv_alpha
+        if self.conv_lora_dim is not None:
+            if network_type.lower() != "lora" or is_transformer or peft_format:
+                raise NotImplementedError("network.conv: plain LoRA on UNet (kohya-format) networks only on the fused path")
+            target_lin_modules = tuple(target_lin_modules) + tuple(target_conv_modules)
         # toolkit/lora_special.py:403-408
         module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]
         module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
@@ -321,7 +340,8 @@ class FusedLoRANetwork(nn.Module):
             for child_name, child in module.named_modules():
                 is_linear = child.__class__.__name__ in LINEAR_MODULES
                 is_conv1x1 = bool(getattr(child, "is_conv1x1", False))  # Conv2d with kernel (1, 1): lora_special.py:487-488, 585-587
-                if not (is_linear or is_conv1x1):
+                is_conv3x3 = bool(getattr(child, "is_conv3x3", False)) and self.conv_lora_dim is not None
+                if not (is_linear or is_conv1x1 or is_conv3x3):
                     continue
                 clean = ".".join([x for x in (prefix, name, child_name) if x])
                 lora_name = clean.replace(".", "$$") if self.peft_format else clean.replace(".", "_")
@@ -341,7 +361,8 @@ class FusedLoRANetwork(nn.Module):
                 names.add(lora_name)
                 if network_type.lower() == "lora":
                     module_kwargs = dict(dropout=dropout, rank_dropout=rank_dropout, module_dropout=module_dropout)
-                lora = module_class(lora_name, child, multiplier, lora_dim, self.alpha, network=self, **module_kwargs)
+                dim, al = (self.conv_lora_dim, self.conv_alpha) if is_conv3x3 else (lora_dim, self.alpha)  # lora_special.py:585-590
+                lora = module_class(lora_name, child, multiplier, dim, al, network=self, **module_kwargs)
                 lora.is_conv1x1 = is_conv1x1  # saved / loaded as Conv2d weights [r, in, 1, 1] / [out, r, 1, 1] like the reference's
                 self.unet_loras.append(lora)
         for lora in self.unet_loras:
@@ -414,7 +435,7 @@ class FusedLoRANetwork(nn.Module):
         #   lora_up   B [out, rp]: [out, 3rp] = [B_hi | B_hi | B_lo]          (B2 of the forward K-slab)
         #                          hi / lo transposed [rp, out]               (P, P_lo of the backward lora_down)
         #   LoKr factors: plain bf16, direct + transposed (the Kronecker kernel's operands).
-        sizes = {"hi": 0, "lo": 0, "t3": 0, "u3": 0, "uth": 0, "utl": 0}
+        sizes = {"hi": 0, "lo": 0, "t3": 0, "u3": 0, "uth": 0, "utl": 0, "cs": 0}
         for m, which in order:
             rows, cols = block_shape(m, which)
             cnt = rows * cols
@@ -422,6 +443,9 @@ class FusedLoRANetwork(nn.Module):
                 scnt = m.out_k * m.in_n if which == "down" else cnt  # the shadow of `down` is always the (composed) W2
                 sizes["hi"] += scnt
                 sizes["t3"] += scnt
+            elif which == "down" and getattr(m, "is_conv3x3", False):
+                sizes["cs"] += 2 * cnt  # [A_hi ; A_lo], tap-major
+                sizes["t3"] += 3 * cnt  # rotated data-gradient filter [Cin, 9 * 3 rp]
             elif which == "down":
                 sizes["hi"] += cnt
                 sizes["lo"] += cnt
@@ -431,7 +455,7 @@ class FusedLoRANetwork(nn.Module):
                 sizes["uth"] += cnt
                 sizes["utl"] += cnt
         cur, tot = {}, 0
-        for k in ("hi", "lo", "t3", "u3", "uth", "utl"):
+        for k in ("hi", "lo", "t3", "u3", "uth", "utl", "cs"):
             cur[k] = tot
             tot += (sizes[k] + 63) // 64 * 64  # regions start 128-byte aligned
         self.arena_shadow = torch.zeros(max(tot, 1), dtype=dt, device=device)
@@ -480,6 +504,12 @@ class FusedLoRANetwork(nn.Module):
                     m.off_down, m.g_down, m.sh_down, m.sh_downT, m.blk_down = off, gblock, sh, shT, (rows, cols)
                 else:
                     m.off_up, m.g_up, m.sh_up, m.sh_upT, m.blk_up = off, gblock, sh, shT, (rows, cols)
+            elif which == "down" and getattr(m, "is_conv3x3", False):
+                d0, stack = take("cs", 2 * cnt, (2 * rows, cols))
+                d1, dg = take("t3", 3 * cnt, (m.conv_cin, 27 * rows))
+                entries.append((off, rows, cols, 4, d0, d1, 0, m.conv_cin))
+                m.off_down, m.g_down, m.blk_down = off, gblock, (rows, cols)
+                m.sh_down_stack, m.sh_down_dgrad, m._sh_down_off = stack, dg, (d0, d1)
             elif which == "down":
                 d0, hi = take("hi", cnt, (rows, cols))
                 d1, lo = take("lo", cnt, (rows, cols))
@@ -719,6 +749,8 @@ class FusedLoRANetwork(nn.Module):
                     w = w.clone().contiguous()
                     if getattr(m, "is_conv1x1", False):
                         w = w[:, :, None, None]
+                    elif getattr(m, "is_conv3x3", False):  # Conv2d(in, r, 3) / Conv2d(r, out, 1) shapes (lora_special.py:95-104)
+                        w = w.view(w.shape[0], m.conv_cin, 3, 3) if which == "down" else w[:, :, None, None]
                     sd[f"{m.lora_name}.{key}.weight"] = w.to("cpu").to(dtype)
             if extra_state_dict is not None:
                 for k, v in extra_state_dict.items():
@@ -799,6 +831,8 @@ class FusedLoRANetwork(nn.Module):
                 hit = False
                 if v.dim() == 4 and v.shape[2:] == (1, 1):
                     v = v[:, :, 0, 0]  # 1x1-conv adapter weights
+                elif v.dim() == 4:
+                    v = v.reshape(v.shape[0], -1)  # 3x3-conv lora_down [r, in, 3, 3] -> [r, in*9] (the Conv2d weight's memory order)
                 for which, attr in suffixes:
                     if k.endswith(which) and k[: -len(which)] in by_name:
                         mod = by_name[k[: -len(which)]]
@@ -869,6 +903,13 @@ class FusedLoRANetwork(nn.Module):
                 continue
             if not bool(m.lora_up.weight.any()) or not bool(m.lora_down.weight.any()):
                 continue  # a zero delta merges to identity: skipped (matters on quantised bases; network_mixins.py:381-389)
+            if getattr(m, "is_conv3x3", False):
+                # 3x3-conv adapter (toolkit/network_mixins.py:424-433): W [out, in, 3, 3] += c * (up [out, r] @ down [r, in*9]).  A set-up time
+                # operation on the diffusers-layout weight in fp32 (not part of the step), followed by the kernel-layout rebuild.
+                delta = float(merge_weight) * m.scale * (m.lora_up.weight.data.float() @ m.lora_down.weight.data.float())
+                lin.weight.data.copy_((lin.weight.data.float() + delta.view_as(lin.weight.data)).to(lin.weight.dtype))
+                lin.prepare()
+                continue
             rp = m.rank_pad
             bs = torch.empty_like(m.sh_up3)  # (c B) as [B_hi | B_hi | B_lo]
             ops.ew(3, m.sh_up3, bs, alpha=float(merge_weight) * m.scale)

@@ -67,6 +67,7 @@ class Conv3x3(nn.Module):
     wk [out, 9*in] (k = (ky*3+kx)*in + cin) for forward and wd [in, 9*out] (rotated filter, in/out swapped) for the data gradient."""
 
     kernel_size = (3, 3)
+    is_conv3x3 = True  # LoRA discovery: wrapped when network.conv is set (toolkit/lora_special.py:585-590)
 
     def __init__(self, cin, cout, stride, dtype, device, cin_pad=None, cout_pad=None):
         super().__init__()
@@ -76,6 +77,7 @@ class Conv3x3(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.zeros(cout, dtype=dtype, device=device), requires_grad=False)
         self.wk = self.wd = self.bias_k = None
+        object.__setattr__(self, "lora", None)  # set by LoRAModule.apply_to when network.conv wraps 3x3 convolutions
 
     @torch.no_grad()
     def prepare(self, need_dgrad=True):
@@ -332,32 +334,99 @@ class UNet2DConditionModel(FusedGraphBase):
         return min(offs) if offs else network.arena_p.numel()
 
     # ------------------------------------------------------------------ kernel-level graph helpers (each records its backward)
+    def _conv_scale(self, lo):
+        """fp32 [32] column scale of a conv adapter's lora_down launch: runtime scale * network multiplier (uniform: the implicit-GEMM
+        epilogue has no per-row factor, so per-sample multipliers — slider training — are refused for 3x3-conv adapters)."""
+        mv = self.network._multiplier
+        vals = [float(v) for v in mv] if isinstance(mv, (list, tuple)) else [float(mv)]
+        if max(vals) != min(vals):
+            raise NotImplementedError("3x3-conv adapters with per-sample multipliers are not on the fused path")
+        c = lo.scale * vals[0]
+        cached = getattr(lo, "_cs", None)
+        if cached is None or cached[0] != c or cached[1].device != self._device():
+            cached = (c, torch.full((32,), c, dtype=torch.float32, device=self._device()))
+            lo._cs = cached
+        return cached[1]
+
     def _conv(self, x, conv, B, H, W, res=None, tape=None):
-        """y = conv3x3(x) + bias (+ res); NHWC contiguous in, [B*Ho*Wo, Cout] out."""
+        """y = conv3x3(x) + bias (+ res) (+ LoRA when network.conv wrapped the layer); NHWC contiguous in, [B*Ho*Wo, Cout] out.
+
+        3x3-conv adapter (toolkit/lora_special.py:95-104): lora_down = Conv2d(in, r, 3, stride, padding) is the same implicit-GEMM kernel
+        with the 32 stacked filters [A_hi ; A_lo] whose fp32 sum leaves the epilogue as the [hi | lo | hi] slab T; lora_up (1x1) is the
+        K-slab of the base convolution, exactly like a Linear's.  Backward: dT = c (dy B) and dB by the skinny kernels; dx += the 3x3
+        convolution of the dT slab image with the rotated [A_hi | A_hi | A_lo] filter; dA = nine per-tap skinny contractions of the
+        zero-framed dT and x grids (a flat shift per tap: wrapped pairs always meet a zero of the frame)."""
         ops = self.ops
         s = conv.stride
         Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
-        y = self._new(B * Ho * Wo, conv.cout_pad)
-        ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=EPI_ADD_AUX if res is not None else 0, aux_in=res)
-        if tape.needs(x, res):
+        Mo = B * Ho * Wo
+        y = self._new(Mo, conv.cout_pad)
+        lo = conv.lora if self._lora_active(conv) else None
+        T, kw = None, {}
+        if lo is not None:
+            T = self._new(Mo, 48)
+            ops.conv3x3(x, lo.sh_down_stack, T, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, split_slab=True, col_scale=self._conv_scale(lo))
+            kw = dict(a2=T, b2=lo.sh_up3)
+        ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=EPI_ADD_AUX if res is not None else 0,
+                    aux_in=res, **kw)
+        if tape.needs(x, res) or T is not None:
             need_x = tape.needs(x)
 
-            def bwd(dy, x=x, res=res):
+            def bwd(dy, x=x, res=res, T=T):
                 if res is not None:
                     tape.acc(res, dy, False)
-                if not need_x:
+                if not need_x and T is None:
                     return
                 g = dy if dy.is_contiguous() else self._contig(dy)
+                dT = None
+                if T is not None:
+                    rp = lo.rank_pad
+                    dT = self._new(Mo, 3 * rp)
+                    mult, rpb = self._mult(Ho * Wo, B)
+                    ops.lora_down(g, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=Mo, p_lo=lo.sh_upT_lo, split=rp)
+                    ops.lora_wgrad(T, g, lo.g_up, transpose_out=True, accumulate=True, M=Mo, split=rp)
                 if s == 2:  # zero insertion to the input grid (even H, W: pad 1 / stride 2 maps 2Ho x 2Wo back to H x W)
-                    z = self._new(B * 4 * Ho * Wo, conv.cout_pad)
-                    ops.resample2x(g, z, B=B, H=Ho, W=Wo, mode=2)
-                    g = z
+                    if need_x:
+                        z = self._new(B * 4 * Ho * Wo, conv.cout_pad)
+                        ops.resample2x(g, z, B=B, H=Ho, W=Wo, mode=2)
+                        g = z
+                    if dT is not None:
+                        zt = self._new(B * 4 * Ho * Wo, dT.shape[1])
+                        ops.resample2x(dT, zt, B=B, H=Ho, W=Wo, mode=2)
+                        dT = zt
+                if dT is not None:  # lora_down.weight.grad [r, Cin, 3, 3]: one skinny launch per tap on the framed grids
+                    Wp, Np, cin = W + 2, B * (H + 2) * (W + 2), lo.conv_cin
+                    dTp, xp = self._new(Np, dT.shape[1]), self._new(Np, cin)
+                    ops.pad_nhwc(dT, dTp, B=B, H=H, W=W)
+                    ops.pad_nhwc(x, xp, B=B, H=H, W=W)
+                    gflat = lo.g_down.view(-1)
+                    for tap in range(9):
+                        sh = (tap // 3 - 1) * Wp + (tap % 3 - 1)
+                        j0, j1 = max(0, -sh), min(Np, Np - sh)
+                        ops.lora_wgrad(dTp[j0:j1], xp[j0 + sh:j1 + sh], gflat[tap:], accumulate=True, M=j1 - j0, split=lo.rank_pad,
+                                       out_strides=(9 * cin, 9))
+                if not need_x:
+                    return
                 dx = self._new(B * H * W, conv.cin_pad)
                 ops.conv3x3(g, conv.wd, dx, B=B, H=H, W=W)
+                if dT is not None:
+                    ops.conv3x3(dT, lo.sh_down_dgrad, dx, B=B, H=H, W=W, flags=EPI_ACCUM)
                 tape.acc(x, dx, True)
 
             tape.record(y, bwd)
         return y, Ho, Wo
+
+    def _batch_indicator(self, B, HW, Rb):
+        """[B*HW, Rb] one-hot of the sample index (bf16, cached per shape): the S operand that turns aitk_lora_wgrad into a per-sample
+        column sum."""
+        key = (B, HW, Rb, str(self._device()))
+        cache = self.__dict__.setdefault("_ind_cache", {})
+        ind = cache.get(key)
+        if ind is None:
+            ind = torch.zeros(B * HW, Rb, dtype=self.dt, device=self._device())
+            ind.view(B, HW, Rb)[torch.arange(B), :, torch.arange(B)] = 1
+            cache[key] = ind
+        return ind
 
     def _contig(self, t):
         c = self._new(t.shape[0], t.shape[1])
@@ -541,12 +610,31 @@ class UNet2DConditionModel(FusedGraphBase):
         HW = H * W
         h = self._gn(x, r.norm1, B, HW, True, tape)
         h, _, _ = self._conv(h, r.conv1, B, H, W, tape=tape)
-        tp = self._new(B, r.conv1.out_channels)
-        ops.gemv_nt(temb_act, r.time_emb_proj.weight, tp, bias=r.time_emb_proj.bias)
+        tproj = r.time_emb_proj
+        if self._lora_active(tproj):  # network.conv also wraps the Linear children of ResnetBlock2D (toolkit/kohya_lora.py:751)
+            tp, Tt = self._ada_fwd(tproj, temb_act, B)
+        else:
+            tp, Tt = self._new(B, r.conv1.out_channels), None
+            ops.gemv_nt(temb_act, tproj.weight, tp, bias=tproj.bias)
         h2 = self._new(h.shape[0], h.shape[1])
         ops.ew(2, h, h2, a=tp, a_rows_per_batch=HW)
-        if tape.needs(h):
-            tape.record(h2, lambda dy, h=h: tape.acc(h, dy, False))
+        if tape.needs(h) or Tt is not None:
+            def bwd_t(dy, h=h, Tt=Tt):
+                tape.acc(h, dy, False)
+                if Tt is None:
+                    return
+                # d(time_emb_proj output)[b] = sum over the pixels of sample b of dy: one skinny contraction against the batch-indicator
+                # matrix (out[b][c] = sum_m [m in sample b] dy[m][c]), then the small-batch adapter backward of the adaLN projections
+                g = dy if dy.is_contiguous() else self._contig(dy)
+                Rb = (B + 15) // 16 * 16
+                ind = self._batch_indicator(B, HW, Rb)
+                part = torch.zeros(Rb, g.shape[1], dtype=torch.float32, device=g.device)
+                ops.lora_wgrad(ind, g, part, M=B * HW)
+                dtp = self._new(B, g.shape[1])
+                ops.colsum_finish(part, 1, B, 1, g.shape[1], dtp)
+                self._ada_bwd(tproj, dtp, Tt, temb_act, B)
+
+            tape.record(h2, bwd_t)
         h2 = self._gn(h2, r.norm2, B, HW, True, tape)
         sc = x
         if hasattr(r, "conv_shortcut"):

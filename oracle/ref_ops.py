@@ -167,6 +167,15 @@ def ln_mod_bwd(dxn, x, mean, rstd, scale, dx, *, B, S, dres=None, dshift=None, d
     return dx
 
 
+def colsum_finish(partial, nchunk, B, V, Cc, out0, out1=None):
+    """fp32 partial column sums [B][nchunk][V][C] -> out_v [B, C] (second stage of the deterministic column sums)."""
+    p = partial.view(-1)[: B * nchunk * V * Cc].view(B, nchunk, V, Cc).float().sum(1)
+    out0.copy_(p[:, 0].to(out0.dtype))
+    if out1 is not None:
+        out1.copy_(p[:, 1].to(out1.dtype))
+    return out0
+
+
 def gate_bwd(dx, y, gate, dy, dgate, *, B, S):
     M = B * S
     d = dx[:M].float()
@@ -449,6 +458,8 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
         v = v + bias.float()
     if flags & EPI_ADD_AUX:
         v = v + aux_in.float()
+    if flags & EPI_ACCUM:
+        v = v + out.float()
     out.copy_(v.to(out.dtype))
     return out
 

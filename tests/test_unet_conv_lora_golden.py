@@ -1,0 +1,148 @@
+"""`network.conv` (conv-LoRA, toolkit/lora_special.py:95-104, 585-590, 678-681; toolkit/kohya_lora.py:751) pinned to the reference's own
+LoRASpecialNetwork(conv_lora_dim=...) executed by tests/golden/make_golden.py::golden_unet_conv_lora on the oracle UNet trees: the wider
+adapter inventory (Linear / Conv2d children of ResnetBlock2D, Downsample2D, Upsample2D besides every Transformer2DModel), per-kind ranks and
+scales, init draws under the same seed, one forward + every adapter gradient through the reference's LoRAModule.forward — incl. the 3x3
+(stride 1 and 2) convolution adapters, the 1x1 conv_shortcut and the small-batch time_emb_proj adapters — and the kohya file it saves
+(lora_down [r, in, 3, 3], lora_up [out, r, 1, 1])."""
+import hashlib
+import json
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.lora import FusedLoRANetwork
+from ai_toolkit_amd.unet import UNet2DConditionModel
+from oracle import ref_ops, unet_ref
+from tests.test_unet_cpu import TINY_SD15, TINY_SDXL, _inputs, _nhwc8
+
+G = os.path.join(os.path.dirname(__file__), "golden", "unet_conv_lora_tiny.safetensors")
+KW = dict(target_lin_modules=("Transformer2DModel",), is_transformer=False, peft_format=False, transformer_only=False)
+
+
+def _golden():
+    with safe_open(G, "pt") as f:
+        meta = json.loads(f.metadata()["meta"])
+    return load_file(G), meta
+
+
+def build(cfg, dtype=torch.float32, device="cpu", ops=ref_ops):
+    torch.manual_seed(0)
+    ref = unet_ref.UNet2DConditionModel(**cfg)
+    unet_ref.init_synthetic_(ref, seed=11)
+    nat = UNet2DConditionModel(**cfg, dtype=dtype, device=device, ops=ops)
+    nat.load_state_dict({k: v.to(dtype) for k, v in ref.state_dict().items()}, strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=2, conv_alpha=1.0, **KW)
+    return nat, net
+
+
+def warm_and_attach(nat, net, t, tag, ops, device="cpu"):
+    with torch.no_grad():
+        for x in net.unet_loras:
+            x.lora_up.weight.copy_(t[f"{tag}/warm/{x.lora_name}/up"].reshape(x.lora_up.weight.shape))
+    net.apply_to()
+    net.build_arena(device, groups=nat.lora_groups())
+    net.refresh_shadows(ops)
+    nat.attach_network(net)
+    nat.prepare()
+
+
+@pytest.mark.parametrize("tag,cfg", [("sd15", TINY_SD15), ("sdxl", TINY_SDXL)])
+def test_fused_conv_lora_network_matches_reference_network(tag, cfg, tmp_path):
+    t, meta = _golden()
+    m = meta[tag]
+    nat, net = build(cfg)
+    assert [x.lora_name for x in net.unet_loras] == m["names"]
+    assert [x.lora_dim for x in net.unet_loras] == m["dims"] and [x.scale for x in net.unet_loras] == m["scales"]
+    kinds = {"conv3x3": sum(x.is_conv3x3 for x in net.unet_loras), "conv1x1": sum(bool(x.is_conv1x1) for x in net.unet_loras)}
+    assert kinds["conv3x3"] > 0 and any("time_emb_proj" in x.lora_name for x in net.unet_loras) and any("conv_shortcut" in x.lora_name for x in net.unet_loras)
+    for x in net.unet_loras:  # same construction order and fan-in => same RNG consumption => the reference's kaiming draws, bit for bit
+        want = t[f"{tag}/init/{x.lora_name}/down"]
+        assert torch.equal(x.lora_down.weight, want.reshape(x.lora_down.weight.shape)), x.lora_name
+    warm_and_attach(nat, net, t, tag, ref_ops)
+    lat, ts, ctx, added = _inputs(cfg)
+    B, _, H, W = lat.shape
+    with net:
+        pred = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W)
+        got = pred.view(B, H, W, 4).permute(0, 3, 1, 2)
+        assert torch.allclose(got, t[f"{tag}/pred"], rtol=2e-4, atol=2e-5), (got - t[f"{tag}/pred"]).abs().max()
+        net.zero_grad_arena()
+        nat.backward_native(t[f"{tag}/wgt"].permute(0, 2, 3, 1).reshape(B * H * W, 4).contiguous())
+    for x in net.unet_loras:
+        for nm, p_ in (("down", x.lora_down.weight), ("up", x.lora_up.weight)):
+            want = t[f"{tag}/grad/{x.lora_name}/{nm}"].reshape(p_.shape)
+            err = ((p_.grad - want).norm() / (want.norm() + 1e-12)).item()
+            assert err < 5e-4, (x.lora_name, nm, err)
+    f = tmp_path / "unet_conv.safetensors"
+    net.save_weights(str(f), dtype=torch.float32)
+    sd = load_file(str(f))
+    assert sorted(sd.keys()) == sorted(m["saved_keys"])
+    for k in m["saved_keys"]:
+        want = t[f"{tag}/saved/{k}"]
+        assert sd[k].shape == want.shape and torch.equal(sd[k], want), k
+    assert list(net.get_state_dict(dtype=torch.float32).keys()) == m["saved_keys"]
+    # round trip through load_weights into a fresh network (4-D conv shapes back into the flat arena blocks)
+    nat2, net2 = build(cfg)
+    net2.apply_to()
+    net2.build_arena("cpu", groups=nat2.lora_groups())
+    assert net2.load_weights(str(f)) is None
+    for a, b in zip(net.unet_loras, net2.unet_loras):
+        assert torch.equal(a.lora_down.weight, b.lora_down.weight) and torch.equal(a.lora_up.weight, b.lora_up.weight)
+
+
+def test_merge_in_of_conv_adapters_equals_the_active_network():
+    """ToolkitModuleMixin.merge_in on Conv2d adapters (toolkit/network_mixins.py:424-433): merged-weight forward == adapter-active forward."""
+    t, _ = _golden()
+    nat, net = build(TINY_SDXL)
+    warm_and_attach(nat, net, t, "sdxl", ref_ops)
+    lat, ts, ctx, added = _inputs(TINY_SDXL)
+    B, _, H, W = lat.shape
+    with net:
+        active = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W, save_for_backward=False).clone()
+    base = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W, save_for_backward=False).clone()
+    net.merge_in(1.0, ops=ref_ops)
+    merged = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W, save_for_backward=False).clone()
+    net.merge_out(1.0, ops=ref_ops)
+    restored = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W, save_for_backward=False).clone()
+    assert (active - base).abs().max() > 1e-4
+    assert torch.allclose(merged, active, rtol=1e-4, atol=1e-5) and torch.allclose(restored, base, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,cfg,count", [("sd15_full", unet_ref.SD15, 278), ("sdxl_full", unet_ref.SDXL, 788)])
+def test_full_size_conv_lora_inventory_equals_the_reference(tag, cfg, count):
+    _, meta = _golden()
+    m = meta[tag]
+    assert m["count"] == count
+    with torch.device("meta"):
+        nat = UNet2DConditionModel(**cfg, dtype=torch.float32)
+    net = FusedLoRANetwork(nat, lora_dim=4, alpha=4.0, conv_lora_dim=4, conv_alpha=4.0, **KW)
+    names = [x.lora_name for x in net.unet_loras]
+    assert len(names) == count and names[:3] == m["first"] and names[-3:] == m["last"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == m["names_sha256"]
+    shapes = []
+    for x in net.unet_loras:
+        d, u = list(x.lora_down.weight.shape), list(x.lora_up.weight.shape)
+        if x.is_conv1x1:
+            d, u = d + [1, 1], u + [1, 1]
+        elif x.is_conv3x3:
+            d, u = [d[0], x.conv_cin, 3, 3], u + [1, 1]
+        shapes.append([d, u])
+    assert hashlib.sha256(json.dumps(shapes).encode()).hexdigest() == m["shapes_sha256"]
+    assert sum(x.lora_down.weight.numel() + x.lora_up.weight.numel() for x in net.unet_loras) == m["params"]
+
+
+def test_refusals():
+    with torch.device("meta"):
+        nat = UNet2DConditionModel(**TINY_SD15, dtype=torch.float32)
+    with pytest.raises(NotImplementedError):
+        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, network_type="dora", **KW)
+    with pytest.raises(NotImplementedError):
+        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, dropout=0.1, **KW)
+    # conv_alpha None: the module falls back to alpha = rank (toolkit/lora_special.py:113-115), i.e. scale 1
+    net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, **KW)
+    conv = next(x for x in net.unet_loras if x.is_conv3x3)
+    assert conv.scale == 1.0 and conv.lora_dim == 8 and float(conv.alpha) == 8.0
