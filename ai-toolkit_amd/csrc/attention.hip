@@ -14,6 +14,7 @@
 // scalars, and P^T feeds the next MFMA straight from registers using a permuted contraction order
 // (slot (h,e) <-> row 8*(e>>2)+4h+(e&3) of each 16-row step).  Operands whose contraction index is the row of a
 // row-major LDS tile (V in PV, K in dQ, Q/dO in dK/dV) are consumed with ds_read_b64_tr_b16.
+#include <cstdlib>
 #include "common.h"
 #include "aitk_args.h"
 
@@ -578,6 +579,227 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
     }
 }
 
+// ============================================================================================ backward: dK, dV — software-pipelined (head_dim 128)
+// Same ownership as attn_bwd_dkdv_kernel (wave w owns kv rows [kv0 + 32 w, +32): K / V fragments and the dK / dV accumulators stay in
+// registers).  That kernel runs ONE wave per SIMD (its register budget) and a wave walks its phases one after the other — fragment reads,
+// S / dP MFMAs, softmax VALU, transpose reads, dV / dK MFMAs — so matrix time and everything-else time add up instead of overlapping
+// (profiles/r02_notes_attention_ablation.md: 1570 us of non-matrix work + 1082 us of MFMA = the 2893 us launch).  Here the query tile is
+// 128 rows = four 32-row sub-tiles and the wave pipelines them itself:
+//     A(0) [C(3 of the previous tile) || B(0)] | A(1) [C(0) || B(1)] | A(2) [C(1) || B(2)] | A(3) [C(2) || B(3)] | barrier
+// A(i) = S, dP products of sub-tile i, B(i) = its softmax / dS arithmetic (VALU), C(i) = its dV, dK products.  C(i-1) and B(i) are
+// independent, so their instruction streams are interleaved one MFMA : one accumulator register's worth of VALU — the matrix pipe runs
+// C(i-1) while the vector pipe runs B(i) (guide T15, done inside one wave).  The transpose reads of C(i-1) are issued inside A(i)'s MFMA
+// block and land behind it.  P / dS live as packed bf16 operands in two alternating register sets.
+#define DKDV_P_LDS (8 * SUBTILE_BYTES + 2 * 1024)
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const sm = (lds_char*)smem;  // buffer b at b*TB: Q sub-tiles (rows 0-63 | 64-127), then dO sub-tiles; stats at 2*TB + b*1024
+  constexpr int KS = 8, DB = 4;
+  constexpr int ST = SUBTILE_BYTES, TB = 4 * SUBTILE_BYTES;
+  typedef __attribute__((address_space(3))) float lds_float;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int hd = blockIdx.y, b = blockIdx.z;
+  const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
+  const int kvw = blockIdx.x * 128 + wave * 32;
+  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
+  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
+  const float* Lb = p.LSE + ((long)b * p.H + hd) * S;
+  const float* Db = p.delta + ((long)b * p.H + hd) * S;
+
+  s16x8_t kf[KS], vf[KS];
+  {
+    const int kr = min(kvw + l31, Skv - 1);
+    const bf16_t* kp = Kb + (long)kr * p.ldk + 8 * h;
+    const bf16_t* vp = Vb + (long)kr * p.ldv + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = *reinterpret_cast<const s16x8_t*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const s16x8_t*>(vp + 16 * ks);
+    }
+  }
+  f32x16_t dk[DB], dv[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) {
+    dk[d] = zero16();
+    dv[d] = zero16();
+  }
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int ntiles = (S + 127) / 128;
+  float stat = 0.f;
+  auto stage_load = [&](int t, int buf) {
+    {  // statistics: plain global loads issued BEFORE the tile DMAs, stored to LDS at the end of the iteration (see attn_bwd_dkdv_kernel)
+      const int q = t * 128 + (tid & 127);
+      stat = tid < 128 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
+    }
+  };
+  // one quarter (64 rows of Q or dO) of tile t's LDS-DMA: the four quarters of the NEXT tile are issued inside the MFMA streams of the
+  // current one (an LDS-DMA piece costs 100-185 cycles among fragment reads, 25-60 in a gap of the matrix stream: backward 4.02 -> 3.96 ms)
+  auto stage_quarter = [&](int t, int buf, int q) {
+    lds_char* b0 = sm + buf * TB + q * ST;
+    if (q < 2) glds_subtile64(b0, Qb, p.ldq, t * 128 + 64 * q, S, wave, lane);
+    else glds_subtile64(b0, dOb, p.lddo, t * 128 + 64 * (q - 2), S, wave, lane);
+  };
+  auto stage_store = [&](int buf) { ((lds_float*)(sm + 2 * TB + buf * 1024))[tid] = stat; };  // [0,128): L2, [128,256): delta
+  stage_load(0, 0);
+  for (int q = 0; q < 4; ++q) stage_quarter(0, 0, q);
+  stage_store(0);
+  __syncthreads();
+  const int hq = lane >> 5, gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
+  f32x16_t s, dp;
+  s16x8_t pf[2][2], df[2][2];                      // [sub-tile parity][kk]: packed P / dS operands
+  s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];          // transposed dO / Q fragments of ONE sub-tile, index 4*kk + d
+  // the pipeline runs across tiles (C(3) of tile t - 1 rides under B(0) of tile t): in front of the first tile the "previous" operands are zeros
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dlo[e] = dhi[e] = qlo[e] = qhi[e] = s16x4_t{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) pf[1][kk] = df[1][kk] = s16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const bool more = t + 1 < ntiles;
+    if (more) stage_load(t + 1, cur ^ 1);  // the statistics of the next tile (global loads, ahead of its LDS-DMA quarters)
+    const lds_char* qt = sm + cur * TB;
+    const lds_float* ltc = (const lds_float*)(sm + 2 * TB + cur * 1024);
+    const lds_float* dtc = ltc + 128;
+    // lane parts of the transpose-read addresses (rows with bit 3 clear / the rows 8 further), Q and dO tiles
+    const unsigned tlo_q = (unsigned)(size_t)qt + gq * SUBP + (i16 & 1) * 8 + (4 * hq + (i16 >> 2)) * 32 + (lh << 4);
+    const unsigned thi_q = tlo_q + 8 * 32 + ((lh ^ 1) - lh) * 16;
+    const unsigned tlo_d = tlo_q + 2 * ST, thi_d = thi_q + 2 * ST;
+
+#define DKDV_TR1(SUB, KK, D)                                                                                          \
+  tr16_issue_off<((SUB) >> 1) * ST + (32 * ((SUB) & 1) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dlo[4 * (KK) + (D)], tlo_d); \
+  tr16_issue_off<((SUB) >> 1) * ST + (32 * ((SUB) & 1) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dhi[4 * (KK) + (D)], thi_d); \
+  tr16_issue_off<((SUB) >> 1) * ST + (32 * ((SUB) & 1) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qlo[4 * (KK) + (D)], tlo_q); \
+  tr16_issue_off<((SUB) >> 1) * ST + (32 * ((SUB) & 1) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qhi[4 * (KK) + (D)], thi_q);
+#define DKDV_TR(SUB)                                                                                                     \
+  DKDV_TR1(SUB, 0, 0) DKDV_TR1(SUB, 0, 1) DKDV_TR1(SUB, 0, 2) DKDV_TR1(SUB, 0, 3) DKDV_TR1(SUB, 1, 0) DKDV_TR1(SUB, 1, 1) \
+  DKDV_TR1(SUB, 1, 2) DKDV_TR1(SUB, 1, 3)
+#define DKDV_TR_WAIT()                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" : TR_PIN8(dlo), TR_PIN8(dhi));    \
+  asm volatile("" : TR_PIN8(qlo), TR_PIN8(qhi));                        \
+  __builtin_amdgcn_sched_barrier(0);
+    // A(SUB): S = Q K^T, dP = dO V^T of sub-tile SUB (asm MFMAs: S / dP in arch VGPRs, K / V fragments in AccVGPRs).  TRSUB >= 0: the
+    // transpose reads of sub-tile TRSUB are issued after the first MFMA of the second k-batch, so they land behind the remaining seven pairs.
+#define DKDV_A(SUB, TR_STMT)                                                                                             \
+  {                                                                                                                      \
+    const lds_char* qsub = qt + ((SUB) >> 1) * ST;                                                                       \
+    const lds_char* dosub = qsub + 2 * ST;                                                                               \
+    _Pragma("unroll") for (int hk = 0; hk < 2; ++hk) {                                                                   \
+      s16x8_t qa[4], da[4];                                                                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                 \
+        qa[ks] = frag_rm_st(qsub, 32 * ((SUB) & 1), 16 * (4 * hk + ks), lane);                                           \
+        da[ks] = frag_rm_st(dosub, 32 * ((SUB) & 1), 16 * (4 * hk + ks), lane);                                          \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                 \
+        if (hk == 0 && ks == 0) {                                                                                        \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(s) : "v"(qa[ks]), "a"(kf[0]));                    \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(dp) : "v"(da[ks]), "a"(vf[0]));                   \
+        } else {                                                                                                         \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));         \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(da[ks]), "a"(vf[4 * hk + ks]));        \
+        }                                                                                                                \
+        if (hk == 1 && ks == 0) { TR_STMT }                                                                              \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s), "+v"(dp));                                                   \
+  }
+    // C(prev) || B(SUB): sixteen steps of [one dV / dK MFMA of the previous sub-tile (operand set PAR ^ 1, transposed fragments in
+    // dlo .. qhi)] + [the softmax / dS arithmetic of accumulator register r of sub-tile SUB]; the result is packed into operand set PAR
+    // keep the dS arithmetic scalar: the SLP vectoriser otherwise pairs registers r, r + 1 into v_pk_add_f32 / v_pk_mul_f32, which cost ~26
+    // cycles per MFMA gap beside the matrix stream (MI355X_MICROARCH.md; measured here: backward 4.16 -> 4.02 ms at B = 4, H = 24, S = 4608)
+#define DKDV_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DKDV_CB(SUB, PAR, STEP_STMT)                                                                                     \
+  {                                                                                                                      \
+    float ls[16], ds[16];                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                      \
+      const f32x4_t l4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 32 * (SUB) + 8 * g + 4 * h); \
+      const f32x4_t d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(dtc + 32 * (SUB) + 8 * g + 4 * h); \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                    \
+        ls[4 * g + e] = l4[e];                                                                                           \
+        ds[4 * g + e] = d4[e];                                                                                           \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                     \
+      const int kk = r >> 3, d = (r >> 1) & 3;                                                                           \
+      if ((r & 1) == 0)                                                                                                  \
+        dv[d] = mfma32(pf[(PAR) ^ 1][kk], join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);                           \
+      else                                                                                                               \
+        dk[d] = mfma32(df[(PAR) ^ 1][kk], join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);                           \
+      const float pr = ABL_EXP2(fmaf(s[r], c2, -ls[r]));                                                                 \
+      float dd = dp[r] - ds[r];                                                                                          \
+      DKDV_OPAQUE(dd);                                                                                                   \
+      dd *= pr;                                                                                                          \
+      DKDV_OPAQUE(dd);                                                                                                   \
+      s[r] = pr;                                                                                                         \
+      dp[r] = dd;                                                                                                        \
+      STEP_STMT                                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+    pf[PAR][0] = pack_acc8(s, 0);                                                                                        \
+    pf[PAR][1] = pack_acc8(s, 8);                                                                                        \
+    df[PAR][0] = pack_acc8(dp, 0);                                                                                       \
+    df[PAR][1] = pack_acc8(dp, 8);                                                                                       \
+  }
+#ifdef AITK_PIPE_NODMA
+#define DKDV_DMA(Q)
+#else
+#define DKDV_DMA(Q) if (r == 9 && more) stage_quarter(t + 1, cur ^ 1, Q);
+#endif
+    // across tiles: the last sub-tile's dV / dK products of tile t - 1 (operand set 1, transposed fragments read before that tile's
+    // closing barrier) ride under the first softmax of tile t instead of running bare at the end of their own tile
+    DKDV_A(0, )
+    DKDV_CB(0, 0, )
+    DKDV_A(1, DKDV_TR(0))
+    DKDV_TR_WAIT()
+    DKDV_CB(1, 1, DKDV_DMA(0))
+    DKDV_A(2, DKDV_TR(1))
+    DKDV_TR_WAIT()
+    DKDV_CB(2, 0, DKDV_DMA(1))
+    DKDV_A(3, DKDV_TR(2))
+    DKDV_TR_WAIT()
+#ifdef AITK_PIPE_NODMA
+#define DKDV_DMA23
+#else
+#define DKDV_DMA23 if ((r == 4 || r == 12) && more) stage_quarter(t + 1, cur ^ 1, r == 4 ? 2 : 3);
+#endif
+    DKDV_CB(3, 1, DKDV_DMA23)
+    DKDV_TR(3)
+    DKDV_TR_WAIT()   // in registers before the barrier: the next tile's LDS-DMA may overwrite this buffer one tile later
+#undef DKDV_DMA23
+#undef DKDV_CB
+#undef DKDV_A
+#undef DKDV_TR_WAIT
+#undef DKDV_TR
+#undef DKDV_TR1
+    if (t + 1 < ntiles) stage_store(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)  // the last tile's last sub-tile
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      dv[d] = mfma32(pf[1][kk], join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);
+      dk[d] = mfma32(df[1][kk], join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);
+    }
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv = kvw + crow(r, h);
+      if (kv < Skv) {
+        const long off = ((long)b * Skv + kv);
+        p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = f2bf(dk[d][r] * p.scale);
+        p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = f2bf(dv[d][r]);
+      }
+    }
+}
+
 // ============================================================================================ backward: dQ
 // grid (ceil(S/128), H, B); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
 // loops over KV tiles of 64 rows (K, V row-major in LDS).  S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP^T - delta[q]);
@@ -750,11 +972,32 @@ static void launch_fwd(const AitkAttnArgs* a, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<KS, DB>), grid, dim3(256), lds, s, *a);
 }
 
+// AITK_ATTN_DKDV_PIPE=0 selects the un-pipelined dK / dV kernel for head_dim 128 (same-box A/B); default: the pipelined one
+static bool dkdv_pipe_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AITK_ATTN_DKDV_PIPE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 template <int KS, int DB>
 static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   const int Skv = a->Skv > 0 ? a->Skv : a->S;
   dim3 grid((a->S + 127) / 128, a->H, a->B);
   dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
+  if (KS == 8 && DB == 4 && dkdv_pipe_enabled()) {
+    static bool pattr = false;
+    if (!pattr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_P_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
+      pattr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkdv_pipe_kernel, grid_kv, dim3(256), DKDV_P_LDS, s, *a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
+    return;
+  }
   const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
   const size_t lds2 = 4 * SUBTILE_BYTES;
   static bool attr = false;

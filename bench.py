@@ -56,7 +56,7 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=Fa
     return model, net, ops
 
 
-def build_unet(dev, kind="sdxl", rank=8):
+def build_unet(dev, kind="sdxl", rank=8, conv_rank=0):
     """BASELINE config 2 (SDXL UNet LoRA r8) / config 1 architecture (SD1.5) with synthetic weights: W ~ N(0, 1/fan_in)."""
     import math
 
@@ -74,7 +74,8 @@ def build_unet(dev, kind="sdxl", rank=8):
                 w.copy_((torch.randn(w.shape, device=dev, generator=g) / math.sqrt(w[0].numel())).to(torch.bfloat16))
     torch.manual_seed(1234)
     net = FusedLoRANetwork(model, lora_dim=rank, alpha=rank, target_lin_modules=("Transformer2DModel",), is_transformer=False,
-                           peft_format=False, transformer_only=False, base_model_version="sdxl" if kind == "sdxl" else "sd1")
+                           peft_format=False, transformer_only=False, base_model_version="sdxl" if kind == "sdxl" else "sd1",
+                           conv_lora_dim=conv_rank or None, conv_alpha=conv_rank or None)  # --conv-rank: network.conv (3x3-conv adapters too)
     with torch.no_grad():
         for m in net.unet_loras:
             m.lora_up.weight.normal_(0, 1e-3)
@@ -92,7 +93,7 @@ def bench_unet(args, dev):
     from ai_toolkit_amd.trainer import UNetLoRATrainStep
 
     kind = args.model
-    model, net, ops = build_unet(dev, kind, rank=args.rank if args.rank != 16 else (8 if kind == "sdxl" else 4))
+    model, net, ops = build_unet(dev, kind, rank=args.rank if args.rank != 16 else (8 if kind == "sdxl" else 4), conv_rank=args.conv_rank)
     step = UNetLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, seed=1000)
     # batch sweep on one MI355X (profiles/r02_bench_unet_*.json): SDXL 28.4 / 31.7 / 31.1 img/s at B = 8 / 12 / 16 (12 x 1024 tokens = 240 tiles
     # of 256^2 at the 32x32 level: 94 % of one tile round); SD1.5 105 / 139 / 159 img/s at B = 8 / 16 / 32
@@ -136,6 +137,8 @@ def bench_unet(args, dev):
     ms = sum(a.elapsed_time(b) for a, b, _ in recs)
     fl = sum(f for _, _, f in recs)
     name = "SDXL UNet LoRA r8 @1024^2" if kind == "sdxl" else "SD1.5 UNet LoRA r4 @512^2"
+    if args.conv_rank:
+        name += f" + conv-LoRA r{args.conv_rank} (network.conv)"
     out = {"metric": f"train images/sec, {name}", "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic (random-init architecture, N(0,1) latents, 0.5*N(0,1) text states)",
@@ -343,6 +346,8 @@ def main():
     ap.add_argument("--network", default="lora", choices=["lora", "dora", "lokr"], help="adapter type (headline metric: lora)")
     ap.add_argument("--model", default="flux", choices=["flux", "sdxl", "sd15"], help="flux = the headline metric; sdxl / sd15 = the UNet path "
                     "(BASELINE configs 2 / 1 architectures), single GPU")
+    ap.add_argument("--conv-rank", type=int, default=0, help="UNet bench: also wrap the 3x3 convolutions / time_emb_proj / conv_shortcut of the "
+                    "ResNet blocks and samplers (the reference's network.conv) at this rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")

@@ -12,9 +12,12 @@ b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 b.build(verbose=False)
 others = [os.path.join(b.OBJDIR, os.path.splitext(os.path.basename(s))[0] + ".o") for s in b.sources() if not s.endswith("attention.hip")]
-for tag, macro in (("b128", "AITK_ABL_ATTN_B128"), ("noexp", "AITK_ABL_NOEXP"), ("nomfma", "AITK_ABL_NOMFMA"), ("nolds", "AITK_ABL_NOLDS")):
+VARIANTS = {"r1": (("b128", "AITK_ABL_ATTN_B128"), ("noexp", "AITK_ABL_NOEXP"), ("nomfma", "AITK_ABL_NOMFMA"), ("nolds", "AITK_ABL_NOLDS")),
+            # experiments on the pipelined dK/dV kernel (numerically valid except `nodma`)
+            "pipe": (("p_nodma", "AITK_PIPE_NODMA"),)}
+for tag, macro in VARIANTS[sys.argv[1] if len(sys.argv) > 1 else "r1"]:
     obj = os.path.join(b.OBJDIR, f"attention_abl_{tag}.o")
-    subprocess.check_call([b._hipcc()] + b.FLAGS + [f"-D{macro}", "-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
+    subprocess.check_call([b._hipcc()] + b.FLAGS + [f"-D{m}" if i == 0 else m for i, m in enumerate(macro.split())] + ["-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
     out = os.path.join(b.HERE, f"libaitk_abl_attn_{tag}.so")
     subprocess.check_call([b._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + others + [obj])
     print(out)

@@ -16,6 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 
     B, H, S = 4, 24, 4608
     d = H * 128
+    torch.manual_seed(0)
     q, k, v, do = [torch.randn(B * S, d, device="cuda").to(torch.bfloat16) for _ in range(4)]
     o = torch.empty_like(q)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
@@ -40,11 +41,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     lse.clamp_(-50.0, 50.0)  # ablation libraries produce meaningless statistics: keep the backward's exp2 arguments finite
     bw = t(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc))
     fl = 4.0 * S * S * 128 * B * H
+    # bit-level fingerprint of the gradients (identical accumulation order in every valid build => identical bits)
+    chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (dq, dk, dv)]
     print("RESULT", json.dumps({"fwd_ms": round(fw, 3), "bwd_ms": round(bw, 3), "fwd_tflops": round(fl / fw / 1e9, 1),
-                                "bwd_tflops_alg": round(2.5 * fl / bw / 1e9, 1)}))
+                                "bwd_tflops_alg": round(2.5 * fl / bw / 1e9, 1), "chk": chk}))
 else:
     res = {}
-    variants = [("product", {})]
+    variants = [("product", {}), ("dkdv_unpipelined", {"AITK_ATTN_DKDV_PIPE": "0"})]
     variants += [(os.path.basename(l), {"AITK_LIB_PATH": l}) for l in sorted(glob.glob(os.path.join(ROOT, "ai-toolkit_amd", "libaitk_abl_attn*.so")))]
     for rep in range(2):
         for name, extra in variants:
