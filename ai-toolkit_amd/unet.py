@@ -626,12 +626,14 @@ class UNet2DConditionModel(FusedGraphBase):
                 # d(time_emb_proj output)[b] = sum over the pixels of sample b of dy: one skinny contraction against the batch-indicator
                 # matrix (out[b][c] = sum_m [m in sample b] dy[m][c]), then the small-batch adapter backward of the adaLN projections
                 g = dy if dy.is_contiguous() else self._contig(dy)
-                Rb = (B + 15) // 16 * 16
-                ind = self._batch_indicator(B, HW, Rb)
-                part = torch.zeros(Rb, g.shape[1], dtype=torch.float32, device=g.device)
-                ops.lora_wgrad(ind, g, part, M=B * HW)
                 dtp = self._new(B, g.shape[1])
-                ops.colsum_finish(part, 1, B, 1, g.shape[1], dtp)
+                for b0 in range(0, B, 64):  # the skinny kernel contracts against at most 64 indicator columns per launch
+                    nb = min(64, B - b0)
+                    Rb = (nb + 15) // 16 * 16
+                    ind = self._batch_indicator(nb, HW, Rb)
+                    part = torch.zeros(Rb, g.shape[1], dtype=torch.float32, device=g.device)
+                    ops.lora_wgrad(ind, g[b0 * HW:(b0 + nb) * HW], part, M=nb * HW)
+                    ops.colsum_finish(part, 1, nb, 1, g.shape[1], dtp[b0:b0 + nb])
                 self._ada_bwd(tproj, dtp, Tt, temb_act, B)
 
             tape.record(h2, bwd_t)

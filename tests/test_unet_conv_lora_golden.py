@@ -146,3 +146,51 @@ def test_refusals():
     net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, **KW)
     conv = next(x for x in net.unet_loras if x.is_conv3x3)
     assert conv.scale == 1.0 and conv.lora_dim == 8 and float(conv.alpha) == 8.0
+
+
+def _conv_dp_net():
+    t, _ = _golden()
+    nat, net = build(TINY_SDXL)
+    warm_and_attach(nat, net, t, "sdxl", ref_ops)
+    return nat, net
+
+
+def _conv_dp_worker(rank, world, port, out):
+    import datetime
+
+    import torch.distributed as dist
+
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+    from tests.test_unet_cpu import _dp_batch
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    torch.set_num_threads(2)
+    nat, net = _conv_dp_net()
+    step = UNetLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, min_snr_gamma=5.0, process_group=dist.group.WORLD)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _dp_batch(4, seed=40 + k)
+        sl = slice(rank * 2, rank * 2 + 2)
+        step.step(lat[sl], ctx[sl], pooled[sl], noise=noise[sl], timesteps=ts[sl])
+    torch.save(net.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_conv_lora_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
+    """SURVEY.md §8e with `network.conv`: the conv / time_emb_proj / conv_shortcut adapters live in the same flat gradient arena, so two ranks
+    on disjoint halves of the batch + one all-reduce(mean) == one rank on the whole batch; ranks end bit-identical."""
+    import torch.multiprocessing as mp
+
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+    from tests.conftest import free_port
+    from tests.test_unet_cpu import _dp_batch
+
+    mp.spawn(_conv_dp_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1)
+    nat, net = _conv_dp_net()
+    step = UNetLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, min_snr_gamma=5.0)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _dp_batch(4, seed=40 + k)
+        step.step(lat, ctx, pooled, noise=noise, timesteps=ts)
+    assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
