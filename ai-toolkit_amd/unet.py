@@ -424,7 +424,8 @@ class UNet2DConditionModel(FusedGraphBase):
         ind = cache.get(key)
         if ind is None:
             ind = torch.zeros(B * HW, Rb, dtype=self.dt, device=self._device())
-            ind.view(B, HW, Rb)[torch.arange(B), :, torch.arange(B)] = 1
+            ar = torch.arange(B, device=ind.device)
+            ind.view(B, HW, Rb)[ar, :, ar] = 1
             cache[key] = ind
         return ind
 
