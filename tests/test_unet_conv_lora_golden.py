@@ -142,6 +142,8 @@ def test_refusals():
         FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, network_type="dora", **KW)
     with pytest.raises(NotImplementedError):
         FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, dropout=0.1, **KW)
+    with pytest.raises(NotImplementedError):
+        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=32, **KW)
     # conv_alpha None: the module falls back to alpha = rank (toolkit/lora_special.py:113-115), i.e. scale 1
     net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, **KW)
     conv = next(x for x in net.unet_loras if x.is_conv3x3)
