@@ -42,6 +42,15 @@ class _Holder(nn.Module):
     pass
 
 
+class _DoraPS:
+    """Forward state of a DoRA layer under per-sample multipliers (slider-style batches; toolkit/network_mixins.py:313-340): the reference
+    output is c*(W x + m_mean B A x) + b + (m_b - m_mean) B A x, i.e. the column-scaled product carries the MEAN multiplier and a second,
+    un-scaled rank-r term carries each sample's deviation.  bar / delta = the two rank-space activations (split slabs)."""
+
+    def __init__(self, bar, delta, mbar, dvec, rpb):
+        self.bar, self.delta, self.mbar, self.dvec, self.rpb = bar, delta, mbar, dvec, rpb
+
+
 @torch.no_grad()
 def quantize_linear_fp8(lin, w):
     """lin.qweight / qweight_t / wscale from a [out, in] weight: OCP e4m3 bytes with one fp32 scale per output channel
@@ -175,6 +184,22 @@ class FusedGraphBase(nn.Module):
             tm = tm.repeat_interleave(B // tm.numel()).contiguous()
         return tm, rows_per_batch
 
+    def _dora_ps(self, lin, rows_per_batch, B):
+        """(m_mean, per-row deviation vector fp32 [B], rows_per_batch) when `lin` carries a DoRA adapter and the network multiplier differs
+        between samples; None otherwise.  Keeps the column scale c in step with the current mean."""
+        net = self.network
+        if lin.lora is None or lin.lora.magnitude is None:
+            return None
+        mbar = net.multiplier_mean()
+        if getattr(net, "_dora_mbar", None) != mbar:  # the multiplier changed since the column scales were computed (uniform values too)
+            net.refresh_dora(self.ops)
+        if not net.multiplier_is_per_sample():
+            return None
+        tm = net.torch_multiplier
+        if tm.numel() != B:
+            tm = tm.repeat_interleave(B // tm.numel())
+        return mbar, (tm - mbar).contiguous(), rows_per_batch
+
     def _group_down(self, lins, x, *, M, rows_per_batch, B):
         """One skinny launch for every adapter of a same-input group: returns {id(lin): T view [M, r]} (or {} when the
         group is not laid out adjacently / inactive)."""
@@ -182,6 +207,8 @@ class FusedGraphBase(nn.Module):
             return {}
         if self.network.training and self.network.has_dropout:
             return {}  # dropout decisions are per adapter: each layer draws its own mask in _lin_fwd
+        if any(self._dora_ps(l, rows_per_batch, B) is not None for l in lins):
+            return {}  # DoRA under per-sample multipliers: two rank-space activations per layer (_DoraPS), built in _lin_fwd
         grp = getattr(lins[0].lora, "group", None)
         if grp is None or [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             return {}
@@ -210,6 +237,22 @@ class FusedGraphBase(nn.Module):
             ops.gemm_nt(x, w, out, bias=lin.bias, flags=flags | EPI_ACCUM, aux_out=aux_out, aux_in=aux_in, gate=gate,
                         gate_rows=gate_rows, a_seg=a_seg, c_seg=c_seg, M=M)
             return _KRON
+        ps = self._dora_ps(lin, rows_per_batch, B) if self._lora_active(lin) else None
+        if ps is not None:
+            lo = lin.lora
+            assert T is None and c_seg is None and lin.qweight is None
+            mbar, dvec, rpb = ps
+            rp = lo.rank_pad
+            Tb, Td = self._new(M, 3 * rp), self._new(M, 3 * rp)
+            ops.lora_down(x, lo.sh_down, Tb, scale=lo.scale * mbar, x_seg=a_seg, M=M, p_lo=lo.sh_down_lo, split=rp)
+            ops.lora_down(x, lo.sh_down, Td, scale=lo.scale, mult=dvec, rows_per_batch=rpb, x_seg=a_seg, M=M, p_lo=lo.sh_down_lo, split=rp)
+            ylin = self._new(M, lin.out_features)  # c * (x W^T + T_mean B^T) + b: kept for d magnitude
+            ops.gemm_nt(x, lin.weight, ylin, bias=lin.bias, a_seg=a_seg, M=M, a2=Tb, b2=lo.sh_up3, col_scale=lo.c)
+            lo.y_lin = ylin
+            ops.ew(1, ylin, out[:M])
+            # out = epi(ylin + T_dev B^T): the accumulate epilogue precedes GELU / gate-residual in the epilogue order
+            ops.gemm_nt(Td, lo.sh_up3, out, flags=flags | EPI_ACCUM, aux_out=aux_out, aux_in=aux_in, gate=gate, gate_rows=gate_rows, M=M)
+            return _DoraPS(Tb, Td, mbar, dvec, rpb)
         plan = self.network.dropout_plan(lin.lora, M=M, rows_per_batch=rows_per_batch, B=B) if (T is None and self._lora_active(lin) and not lin.lora.is_lokr) else None
         if self._lora_active(lin) and plan != "skip":
             lo = lin.lora
@@ -307,6 +350,20 @@ class FusedGraphBase(nn.Module):
         lo = lin.lora
         assert lo.magnitude is None or getattr(dy, "_dora_dz", False), "DoRA: pass dy through _dora_dz() first"
         rp = lo.rank_pad
+        if isinstance(T, _DoraPS):
+            # mean term: gradient dz = c*dy through (W, A, B) at the mean multiplier; deviation term: the raw dy at (m_b - m_mean)
+            dT = dT_out if dT_out is not None else self._new(M, 3 * rp)
+            ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale * T.mbar, M=M, p_lo=lo.sh_upT_lo, split=rp)
+            ops.lora_wgrad(T.bar, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
+            if dT_out is None:
+                ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
+            raw = dy._raw
+            dTd = self._new(M, 3 * rp)
+            ops.lora_down(raw, lo.sh_upT, dTd, scale=lo.scale, mult=T.dvec, rows_per_batch=T.rpb, M=M, p_lo=lo.sh_upT_lo, split=rp)
+            ops.lora_wgrad(T.delta, raw, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
+            ops.lora_wgrad(dTd, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
+            dT._extra = dTd  # _lin_dgrad adds dT_dev A to the data gradient
+            return dT
         dT = dT_out if dT_out is not None else self._new(M, 3 * rp)
         mult, rpb = self._mult(rows_per_batch, B)
         tm, tm_rpb = getattr(T, "_tmask", (None, 0))
@@ -327,6 +384,7 @@ class FusedGraphBase(nn.Module):
         self.ops.dora_bwd(dy, lo.y_lin, lo.c, lin.bias, lo.magnitude.data, dz, lo.g_mag, M=M)
         lo.y_lin = None
         dz._dora_dz = True
+        dz._raw = dy  # per-sample multipliers: the deviation term (m_b - m_mean) B A x sits outside the column scale (_DoraPS)
         return dz
 
     def _group_bwd(self, lins, dys, Ts, x_in, dx, *, M, rows_per_batch, B, first_flags=0):
@@ -359,7 +417,12 @@ class FusedGraphBase(nn.Module):
             dT = None
         if dT is not None:
             shT = lin.lora.sh_downT3  # [in, 3r] = [A^T_hi | A^T_hi | A^T_lo] against dT = [hi | lo | hi]
-            kw = dict(a2=dT, b2=shT if w_rows is None else shT[w_rows[0]:w_rows[1]])
+            shT = shT if w_rows is None else shT[w_rows[0]:w_rows[1]]
+            extra = getattr(dT, "_extra", None)
+            if extra is not None:  # DoRA under per-sample multipliers: dx (+)= dT_dev A first, the main product then accumulates onto it
+                self.ops.gemm_nt(extra, shT, dx, flags=flags & EPI_ACCUM, c_seg=dx_seg, M=M)
+                flags |= EPI_ACCUM
+            kw = dict(a2=dT, b2=shT)
         if lin.qweight is not None:  # rows of W^T = input columns; scale runs along the contraction (out) axis
             qt = lin.qweight_t if w_rows is None else lin.qweight_t[w_rows[0]:w_rows[1]]
             wt = self._dequant(qt, lin.wscale, 2)
@@ -382,6 +445,20 @@ class FusedGraphBase(nn.Module):
             self._kron(ada_lin.lora, silu_temb, mod, M=B)
             ops.gemv_nt(silu_temb, ada_lin.weight, mod, bias=ada_lin.bias, accumulate=True)
             return mod, _KRON
+        ps = self._dora_ps(ada_lin, 1, B) if self._lora_active(ada_lin) else None
+        if ps is not None:
+            lo = ada_lin.lora
+            mbar, dvec, rpb = ps
+            rp = lo.rank_pad
+            Tb, Td = self._new(B, 3 * rp), self._new(B, 3 * rp)
+            ops.lora_down(silu_temb, lo.sh_down, Tb, scale=lo.scale * mbar, M=B, p_lo=lo.sh_down_lo, split=rp)
+            ops.lora_down(silu_temb, lo.sh_down, Td, scale=lo.scale, mult=dvec, rows_per_batch=rpb, M=B, p_lo=lo.sh_down_lo, split=rp)
+            ylin = self._new(B, ada_lin.out_features)
+            ops.gemv_nt(silu_temb, ada_lin.weight, ylin, bias=ada_lin.bias, t=Tb, bl=lo.sh_up3, col_scale=lo.c)
+            lo.y_lin = ylin
+            ops.ew(1, ylin, mod)
+            ops.gemm_nt(Td, lo.sh_up3, mod, flags=EPI_ACCUM, M=B)
+            return mod, _DoraPS(Tb, Td, mbar, dvec, rpb)
         plan = self.network.dropout_plan(ada_lin.lora, M=B, rows_per_batch=1, B=B) if self._lora_active(ada_lin) else None
         if self._lora_active(ada_lin) and plan != "skip":
             lo = ada_lin.lora
@@ -410,6 +487,9 @@ class FusedGraphBase(nn.Module):
         lo = ada_lin.lora
         dmod = self._dora_dz(ada_lin, dmod, B)
         rp = lo.rank_pad
+        if isinstance(T, _DoraPS):
+            self._lora_grads(ada_lin, dmod, T, silu_temb, M=B, rows_per_batch=1, B=B)
+            return
         dT = self._new(B, 3 * rp)
         mult, rpb = self._mult(1, B)
         tm, tm_rpb = getattr(T, "_tmask", (None, 0))

@@ -606,10 +606,9 @@ class FusedLoRANetwork(nn.Module):
         mods = [m for m in self.get_all_modules() if m.magnitude is not None]
         if not mods:
             return
-        mult = self._multiplier
-        vals = [float(x) for x in mult] if isinstance(mult, (list, tuple)) else [float(mult)]
-        if max(vals) != min(vals):
-            raise NotImplementedError("DoRA with per-sample multipliers (slider training) is not on the fused path")
+        # per-sample multipliers: the reference scales the DoRA weight by multiplier.mean() (toolkit/network_mixins.py:333-336)
+        mbar = self.multiplier_mean()
+        self._dora_mbar = mbar
         for m in mods:
             lin = m.org_module[0]
             if getattr(lin, "qweight", None) is not None:
@@ -620,7 +619,17 @@ class FusedLoRANetwork(nn.Module):
             gram = torch.zeros(r, r, dtype=torch.float32, device=dev)
             at = m.sh_downT3[:, :r]  # A^T_hi [in, r] (row stride 3r)
             ops.lora_wgrad(at, at, gram, M=m.in_features)
-            ops.dora_colscale(m.w2, tw, self.arena_view(self.arena_p, m, "up", padded=True), gram, m.magnitude.data, m.scale * vals[0], m.c)
+            ops.dora_colscale(m.w2, tw, self.arena_view(self.arena_p, m, "up", padded=True), gram, m.magnitude.data, m.scale * mbar, m.c)
+
+    def multiplier_mean(self):
+        mult = self._multiplier
+        vals = [float(x) for x in mult] if isinstance(mult, (list, tuple)) else [float(mult)]
+        return sum(vals) / len(vals)
+
+    def multiplier_is_per_sample(self):
+        mult = self._multiplier
+        vals = [float(x) for x in mult] if isinstance(mult, (list, tuple)) else [float(mult)]
+        return max(vals) != min(vals)
 
     @property
     def has_dropout(self):

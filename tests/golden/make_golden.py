@@ -168,8 +168,21 @@ def golden_dora():
     sd = net.get_state_dict(dtype=torch.float32)
     for k, v in sd.items():
         out["saved/" + k] = v.clone()
+    # per-sample multipliers (slider-style batch; toolkit/network_mixins.py:313-340: the LoRA term takes each sample's multiplier, the
+    # DoRA weight the mean): second forward / backward of the same network
+    for m in net.unet_loras:
+        m.lora_down.weight.grad = m.lora_up.weight.grad = m.magnitude.grad = None
+    net.multiplier = [1.0, 0.4]
+    net._update_torch_multiplier()
+    pred2 = model(*tiny_inputs())
+    (pred2 * w).sum().backward()
+    out["ps/pred"] = pred2.detach().clone()
+    for m in net.unet_loras:
+        out[f"ps/grad/{m.lora_name}/down"] = m.lora_down.weight.grad.clone()
+        out[f"ps/grad/{m.lora_name}/up"] = m.lora_up.weight.grad.clone()
+        out[f"ps/grad/{m.lora_name}/magnitude"] = m.magnitude.grad.clone()
     meta = {"names": json.dumps([m.lora_name for m in net.unet_loras]), "saved_keys": json.dumps(list(sd.keys())),
-            "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()])}
+            "param_order": json.dumps([n for n, _ in net.unet_loras[0].named_parameters()]), "ps_multiplier": json.dumps([1.0, 0.4])}
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "dora_flux_tiny.safetensors"), meta)
     print("dora golden:", len(net.unet_loras), "adapters;", len(sd), "saved tensors")
 

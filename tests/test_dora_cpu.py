@@ -118,3 +118,46 @@ def test_dora_train_steps_match_oracle_autograd_adamw():
         assert torch.allclose(a.magnitude, b.magnitude, rtol=2e-3, atol=2e-6), a.lora_name
         assert torch.allclose(a.lora_up.weight, b.lora_up.weight, rtol=2e-3, atol=2e-6), a.lora_name
         assert torch.allclose(a.lora_down.weight, b.lora_down.weight, rtol=2e-3, atol=2e-6), a.lora_name
+
+
+def test_dora_per_sample_multipliers_match_reference_golden():
+    """Slider-style batch: network.multiplier = [1.0, 0.4].  The reference adds each sample's multiplier to the LoRA term and scales the DoRA
+    weight by the MEAN multiplier (toolkit/network_mixins.py:313-340): y = c (W x + m_mean B A x) + b + (m_b - m_mean) B A x.  The fused graph
+    runs the mean part through the column-scale epilogue and the deviation as a second, un-scaled rank-r term (graph._DoraPS); prediction and
+    every gradient (magnitude / lora_up / lora_down) against the reference's own run."""
+    path = os.path.join(G, "dora_flux_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = {k: json.loads(v) for k, v in f.metadata().items()}
+    t = load_file(path)
+    ref = oracle_model()
+    nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=8, network_type="dora")
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(t[f"set/{m.lora_name}/up"])
+            m.magnitude.copy_(t[f"set/{m.lora_name}/magnitude"])
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    net.multiplier = meta["ps_multiplier"]
+    assert net.multiplier_is_per_sample() and abs(net.multiplier_mean() - 0.7) < 1e-12
+    with net:
+        pred = nat.forward_native(*tiny_inputs())
+        assert torch.allclose(pred, t["ps/pred"], rtol=2e-4, atol=2e-5), (pred - t["ps/pred"]).abs().max()
+        assert not torch.allclose(pred, t["fwd/pred"], atol=1e-2)  # the uniform-multiplier prediction is a different one
+        net.zero_grad_arena()
+        nat.backward_native(t["fwd/w"])
+    for m in net.unet_loras:
+        for nm, p_ in (("down", m.lora_down.weight), ("up", m.lora_up.weight), ("magnitude", m.magnitude)):
+            ref_g = t[f"ps/grad/{m.lora_name}/{nm}"]
+            err = ((p_.grad - ref_g).norm() / (ref_g.norm() + 1e-12)).item()
+            assert err < 5e-4, (m.lora_name, nm, err)
+    # back to a uniform multiplier: the column scale follows the new mean, the plain path reproduces the uniform golden
+    net.multiplier = 1.0
+    with net:
+        pred = nat.forward_native(*tiny_inputs())
+    assert torch.allclose(pred, t["fwd/pred"], rtol=2e-4, atol=2e-5)

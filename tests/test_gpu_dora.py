@@ -79,7 +79,10 @@ def test_gemv_col_scale_and_dora_kernels():
     assert _rel(dz, dz_ref) < 3e-3 and _rel(dm, dm_ref) < 1e-4
 
 
-def test_dora_train_step_vs_fp32_oracle():
+@pytest.mark.parametrize("multiplier", [None, [1.0, 0.4]], ids=["uniform", "per_sample"])
+def test_dora_train_step_vs_fp32_oracle(multiplier):
+    """per_sample: slider-style batch — the LoRA term takes each sample's multiplier, the DoRA weight the mean (toolkit/network_mixins.py:313-340;
+    fused as a second un-scaled rank-r term, graph._DoraPS; pinned to the reference's own run on the CPU in tests/test_dora_cpu.py)."""
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -118,6 +121,9 @@ def test_dora_train_step_vs_fp32_oracle():
     net.refresh_shadows(ops)
     nat.attach_network(net)
     nat.prepare()
+    if multiplier is not None:
+        net.multiplier = multiplier
+        ref_net.torch_multiplier = torch.tensor(multiplier, device=dev)
     lat, emb, pooled, noise, ts = _batch(2)
     oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
     loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
