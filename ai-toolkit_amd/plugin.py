@@ -1,5 +1,6 @@
 """Model-plugin surface of the reference (`BaseModel` subclasses registered in AI_TOOLKIT_MODELS, selected by `arch`,
-toolkit/util/get_model.py:20-50) for the two native transformer graphs.
+toolkit/util/get_model.py:20-50) for the two native transformer graphs, and the legacy `StableDiffusion` wrapper surface the reference
+uses for the SD1.5 / SDXL UNets (`StableDiffusionMI355Model`, toolkit/stable_diffusion_model.py:1824-1876, 1878-2055, 2260-2301).
 
 The classes are duck-typed mirrors: same attribute / method names, argument meaning and error behaviour as the reference's
 in-tree plug-ins, without importing the reference (its `BaseModel` pulls in diffusers / transformers):
@@ -170,3 +171,92 @@ class Wan21MI355Model(_PluginBase):
 
     def convert_lora_weights_before_load(self, state_dict):
         return wan_lora_to_diffusers(state_dict)
+
+
+class StableDiffusionMI355Model(_PluginBase):
+    """The part of the reference's legacy `StableDiffusion` wrapper the train step calls for SD1.5 / SDXL (`is_xl`): `predict_noise`
+    (toolkit/stable_diffusion_model.py:1878-1935 argument handling, SDXL branch 1968-2055, SD1.5 branch 2260-2265; training never runs
+    classifier-free guidance here: the embeddings' batch size equals the latents'), `get_time_ids_from_latents` (1824-1852), `add_noise`
+    through the DDPM schedule (1854-1876) and the eps / v-prediction loss target (SDTrainer.py:623-625, 650).  `model` is
+    ai_toolkit_amd.unet.UNet2DConditionModel, whose diffusers-signature forward returns `.sample` and carries the explicit backward."""
+
+    arch = "sd_mi355"
+    is_flow_matching = False
+    is_transformer = False
+    target_lora_modules = ["Transformer2DModel"]  # toolkit/kohya_lora.py:750 (+ ResnetBlock2D / Downsample2D / Upsample2D with network.conv)
+
+    def __init__(self, device, model=None, vae=None, dtype=torch.bfloat16, is_xl=False, prediction_type="epsilon", **kwargs):
+        super().__init__(device, model=model, vae=vae, dtype=dtype, **kwargs)
+        from .ddpm import DDPMTrainSchedule
+
+        self.is_xl = bool(is_xl)
+        self.prediction_type = prediction_type
+        self.noise_scheduler = DDPMTrainSchedule(prediction_type=prediction_type)
+
+    @staticmethod
+    def get_train_scheduler():
+        from .ddpm import DDPMTrainSchedule
+
+        return DDPMTrainSchedule()
+
+    def get_bucket_divisibility(self):
+        return 8  # vae scale factor 8; the UNet's three (SDXL: two) stride-2 levels are covered by the reference's 64-px bucket tolerance
+
+    def get_base_model_version(self):
+        return "sdxl_1.0" if self.is_xl else "sd_1.5"
+
+    def get_time_ids_from_latents(self, latents, requires_aesthetic_score=False):
+        """(H, W, 0, 0, H, W) per sample in pixels for SDXL, None for SD1.5 (stable_diffusion_model.py:1824-1852)."""
+        if not self.is_xl:
+            return None
+        if requires_aesthetic_score:
+            raise NotImplementedError("the SDXL refiner is not on the fused path")
+        bs, _, h, w = latents.shape
+        ids = torch.tensor([[h * 8, w * 8, 0, 0, h * 8, w * 8]]).to(latents.device, dtype=latents.dtype)
+        return torch.cat([ids for _ in range(bs)])
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a, s = self.noise_scheduler.noise_coefficients(timesteps.to(original_samples.device), original_samples.dtype)
+        a, s = a.to(original_samples.dtype).view(-1, 1, 1, 1), s.to(original_samples.dtype).view(-1, 1, 1, 1)
+        return a * original_samples + s * noise
+
+    def get_loss_target(self, *args, **kwargs):
+        noise, batch, timesteps = kwargs.get("noise"), kwargs.get("batch"), kwargs.get("timesteps")
+        if noise is None:
+            raise ValueError("Noise is not provided")
+        if self.prediction_type == "v_prediction":
+            if batch is None or timesteps is None:
+                raise ValueError("v_prediction needs the batch latents and the timesteps")
+            a, s = self.noise_scheduler.noise_coefficients(timesteps.to(noise.device), noise.dtype)
+            return (a.to(noise.dtype).view(-1, 1, 1, 1) * noise - s.to(noise.dtype).view(-1, 1, 1, 1) * batch.latents).detach()
+        return noise.detach()
+
+    def predict_noise(self, latents, text_embeddings=None, timestep=1, guidance_scale=7.5, guidance_rescale=0, add_time_ids=None,
+                      conditional_embeddings=None, unconditional_embeddings=None, **kwargs):
+        if text_embeddings is None and conditional_embeddings is None:
+            raise ValueError("Either text_embeddings or conditional_embeddings must be specified")
+        if unconditional_embeddings is not None:
+            raise NotImplementedError("classifier-free guidance inside predict_noise (sampling) is not on the fused path")
+        if text_embeddings is None:
+            text_embeddings = conditional_embeddings
+        text, pooled = _embeds(text_embeddings)
+        if latents.shape[0] != text.shape[0]:
+            raise ValueError("Batch size of latents must be the same or half the batch size of text embeddings")
+        dev = self.device_torch
+        timestep = torch.as_tensor(timestep).to(dev)
+        if timestep.dim() == 0:
+            timestep = timestep.unsqueeze(0)
+        if timestep.shape[0] == 1 and latents.shape[0] > 1:
+            timestep = timestep.repeat(latents.shape[0])
+        cast = self.model.dt
+        if self.is_xl:
+            with torch.no_grad():
+                if add_time_ids is None:
+                    add_time_ids = self.get_time_ids_from_latents(latents)
+                added = {"text_embeds": pooled.to(dev, cast), "time_ids": add_time_ids.to(dev)}
+            return self.model(latents.to(dev, cast), timestep, encoder_hidden_states=text.to(dev, cast), added_cond_kwargs=added).sample
+        return self.model(latents.to(dev, cast), timestep=timestep, encoder_hidden_states=text.to(dev, cast)).sample
+
+    # the BaseModel-style name for the same call (toolkit/models/base_model.py get_noise_prediction contract)
+    def get_noise_prediction(self, latent_model_input, timestep, text_embeddings, **kwargs):
+        return self.predict_noise(latent_model_input, text_embeddings=text_embeddings, timestep=timestep, **kwargs)

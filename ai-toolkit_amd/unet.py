@@ -150,6 +150,14 @@ def _attn(dim, heads, ctx_dim, dtype, device):
     return a
 
 
+class UNet2DConditionOutput(tuple):
+    """`(sample,)` with the `.sample` attribute of diffusers' output class."""
+
+    @property
+    def sample(self):
+        return self[0]
+
+
 class BasicTransformerBlock(nn.Module):
     def __init__(self, dim, heads, ctx_dim, dtype, device):
         super().__init__()
@@ -773,8 +781,10 @@ class UNet2DConditionModel(FusedGraphBase):
             self.grad_ready_hook("single")
             self.grad_ready_hook("double")
 
-    # diffusers-signature call used by the plug-in / reference-style trainers (NCHW in / out; autograd bridge like flux.py)
-    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=False, **kwargs):
+    # diffusers-signature call used by the plug-in / reference-style trainers (NCHW in / out; autograd bridge like flux.py).  The reference's
+    # legacy UNet call sites read `.sample` from the result (toolkit/stable_diffusion_model.py:2049-2055, 2260-2265): return_dict=True (the
+    # diffusers default) returns a tuple that also carries `.sample`; return_dict=False the plain tuple.
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **kwargs):
         B, Cc, H, W = sample.shape
         x = torch.zeros(B * H * W, 8, dtype=self.dt, device=sample.device)
         x[:, :Cc] = sample.to(self.dt).permute(0, 2, 3, 1).reshape(B * H * W, Cc)
@@ -785,4 +795,4 @@ class UNet2DConditionModel(FusedGraphBase):
 
             pred = _FluxGraphFn.apply(pred, self, self.network.arena_p.requires_grad_(True))
         out = pred.reshape(B, H, W, -1).permute(0, 3, 1, 2)
-        return (out,)
+        return UNet2DConditionOutput((out,)) if return_dict else (out,)

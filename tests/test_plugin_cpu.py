@@ -73,3 +73,60 @@ def test_plugin_contract_methods_follow_the_reference():
     conv = wan.convert_lora_weights_before_save(sd)
     assert list(conv) == ["diffusion_model.blocks.0.self_attn.q.lora_A.weight"]
     assert list(wan.convert_lora_weights_before_load(conv)) == list(sd)
+
+
+@pytest.mark.parametrize("xl", [False, True], ids=["sd15", "sdxl"])
+def test_stable_diffusion_wrapper_prediction_and_autograd_backward_match_oracle(xl):
+    """The legacy `StableDiffusion.predict_noise` surface for the UNets (toolkit/stable_diffusion_model.py:1878-2055, 2260-2265) on the fused
+    UNet: prediction == the oracle UNet called the way the reference calls diffusers' (`.sample`, SDXL `added_cond_kwargs` with
+    `get_time_ids_from_latents`), and `loss.backward()` through the autograd bridge == autograd of the oracle network."""
+    from ai_toolkit_amd.plugin import StableDiffusionMI355Model
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, TINY_SDXL, build_pair
+
+    cfg = TINY_SDXL if xl else TINY_SD15
+    ref, ref_net, nat, net = build_pair(cfg)
+    sd = StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, is_xl=xl)
+    assert sd.unet is nat and not sd.is_flow_matching and sd.get_base_model_version() == ("sdxl_1.0" if xl else "sd_1.5")
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 2, 16, 8
+    lat = torch.randn(B, 4, H, W, generator=g)
+    pooled_dim = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"] if xl else 8
+    pe = SimpleNamespace(text_embeds=torch.randn(B, 7, cfg["cross_attention_dim"], generator=g),
+                         pooled_embeds=torch.randn(B, pooled_dim, generator=g))
+    ts = torch.tensor([640, 17])
+    target = torch.randn(B, 4, H, W, generator=g)
+    tid = sd.get_time_ids_from_latents(lat)
+    if xl:
+        assert torch.equal(tid, unet_ref.time_ids_from_latents(lat)) and tuple(tid.shape) == (B, 6)
+        added = dict(text_embeds=pe.pooled_embeds, time_ids=tid)
+    else:
+        assert tid is None
+        added = None
+    with ref_net:
+        p_ref = ref(lat, ts.float(), pe.text_embeds, added)
+        torch.nn.functional.mse_loss(p_ref, target).backward()
+    net.zero_grad_arena()
+    with net:
+        pred = sd.predict_noise(lat, text_embeddings=pe, timestep=ts)
+        assert pred.shape == lat.shape and torch.allclose(pred, p_ref, rtol=2e-4, atol=2e-5), (pred - p_ref).abs().max()
+        torch.nn.functional.mse_loss(pred, target).backward()
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert torch.allclose(a.lora_down.weight.grad, b.lora_down.weight.grad.reshape(a.lora_down.weight.shape), rtol=5e-4, atol=1e-6), a.lora_name
+        assert torch.allclose(a.lora_up.weight.grad, b.lora_up.weight.grad.reshape(a.lora_up.weight.shape), rtol=5e-4, atol=1e-6), a.lora_name
+    # a single timestep is broadcast over the batch; conditional_embeddings is the other spelling of the same argument
+    with torch.no_grad(), net:
+        p1 = sd.predict_noise(lat, conditional_embeddings=pe, timestep=torch.tensor(640))
+        p2 = sd.get_noise_prediction(lat, torch.tensor([640, 640]), pe)
+    assert torch.allclose(p1, p2, atol=1e-6)
+    # DDPM add_noise and the loss targets (eps, v)
+    noise = torch.randn(B, 4, H, W, generator=g)
+    ac = unet_ref.ddpm_alphas_cumprod()
+    assert torch.allclose(sd.add_noise(lat, noise, ts), unet_ref.ddpm_add_noise(lat, noise, ts, ac), atol=1e-6)
+    assert torch.equal(sd.get_loss_target(noise=noise), noise)
+    sv = StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, is_xl=xl, prediction_type="v_prediction")
+    assert torch.allclose(sv.get_loss_target(noise=noise, batch=SimpleNamespace(latents=lat), timesteps=ts), unet_ref.ddpm_velocity(lat, noise, ts, ac), atol=1e-6)
+    with pytest.raises(ValueError):
+        sd.predict_noise(lat, timestep=ts)
+    with pytest.raises(NotImplementedError):
+        sd.predict_noise(lat, text_embeddings=pe, timestep=ts, unconditional_embeddings=pe)
