@@ -56,8 +56,14 @@ class FlowMatchTrainSchedule:
         w2[n // 2:] = w2[n // 2:].max()
         self.linear_timesteps_weights2 = w2
 
+    # few-step distillation-style schedules: a linear table, indices drawn from a fixed list (jobs/process/BaseSDTrainProcess.py:1196-1205, 1254-1272)
+    N_STEP_INDICES = {"one_step": [0], "two_step": [0, 499], "four_step": [0, 250, 500, 750],
+                      "eight_step": [0, 125, 250, 375, 500, 625, 750, 875]}
+
     def set_train_timesteps(self, num_timesteps, device, timestep_type="linear", latents=None, patch_size=1):
         self.timestep_type = timestep_type
+        if timestep_type in self.N_STEP_INDICES:  # the trainer hands the scheduler 'linear' for these (BaseSDTrainProcess.py:1196-1203)
+            timestep_type = "linear"
         if timestep_type in ("linear", "weighted"):
             self.timesteps = torch.linspace(1000, 1, num_timesteps, device=device)
         elif timestep_type == "sigmoid":
@@ -100,6 +106,15 @@ class FlowMatchTrainSchedule:
         'content' / 'style' -> cubic sampling u^3 / 1 - u^3 of u ~ U(0,1), mapped to [min_idx, max_idx] and clamped (1275-1298)."""
         if max_idx is None:
             max_idx = self.num_train_timesteps - 1
+        if self.timestep_type in self.N_STEP_INDICES:
+            import random
+
+            choices = self.N_STEP_INDICES[self.timestep_type]
+            if self.timestep_type == "one_step":
+                idx = torch.zeros((batch_size,), device=device, dtype=torch.long)
+            else:  # the reference draws with Python's global `random` (random.choices), not with torch
+                idx = torch.tensor(random.choices(choices, k=batch_size), device=device).long()
+            return self.timesteps[idx].float().contiguous(), idx
         if content_or_style == "balanced":
             if min_idx == max_idx:
                 idx = torch.full((batch_size,), min_idx, device=device).long()

@@ -247,3 +247,25 @@ def test_merge_in_equals_reference_merge_in(gold):
     net.merge_out(0.7, ops=ref_ops)
     for k, v in before.items():
         assert torch.allclose(nat.state_dict()[k], v, rtol=1e-5, atol=1e-6), k
+
+
+def test_n_step_timestep_types_follow_the_trainer():
+    """timestep_type one_step / two_step / four_step / eight_step (jobs/process/BaseSDTrainProcess.py:1196-1203, 1254-1272): a linear table,
+    indices from a fixed list drawn with Python's `random.choices` (same global-RNG consumption as the reference)."""
+    import random
+
+    from ai_toolkit_amd.flowmatch import FlowMatchTrainSchedule
+
+    s = FlowMatchTrainSchedule()
+    lin = torch.linspace(1000, 1, 1000)
+    for name, choices in (("two_step", [0, 499]), ("four_step", [0, 250, 500, 750]), ("eight_step", [0, 125, 250, 375, 500, 625, 750, 875])):
+        s.set_train_timesteps(1000, "cpu", name)
+        assert torch.equal(s.timesteps, lin)
+        random.seed(5)
+        t, idx = s.sample_timesteps(16, "cpu")
+        random.seed(5)
+        want = torch.tensor(random.choices(choices, k=16))
+        assert torch.equal(idx, want) and torch.equal(t, lin[want])
+    s.set_train_timesteps(1000, "cpu", "one_step")
+    t, idx = s.sample_timesteps(4, "cpu")
+    assert torch.equal(idx, torch.zeros(4, dtype=torch.long)) and torch.equal(t, torch.full((4,), 1000.0))
