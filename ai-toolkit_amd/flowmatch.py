@@ -144,13 +144,16 @@ class FlowMatchTrainSchedule:
 
 
 def get_noise(latents, generator=None, *, noise_offset=0.0, noise_multiplier=1.0, random_noise_shift=0.0,
-              random_noise_multiplier=0.0, dynamic_noise_offset=False, dtype=None):
+              random_noise_multiplier=0.0, dynamic_noise_offset=False, dtype=None, signal_correction_noise_scale=0.0,
+              batch_noise_correction_scale=0.0):
     """The reference's noise for one batch, same draw order on the same device generator:
       randn(latents.shape) in fp32 on the device                         toolkit/stable_diffusion_model.py:1803-1811
       + noise_offset * randn(B, C, 1, 1)   (4-D latents only)            toolkit/train_tools.py:132-139
       cast to the training dtype                                          jobs/process/BaseSDTrainProcess.py:1020-1027
       + latents channel mean / 2           (dynamic_noise_offset)         BaseSDTrainProcess.py:1331-1335
       * noise_multiplier                                                   1344-1351
+      + latents * randn(B, C, 1, 1) * signal_correction_noise_scale        1353-1361 (do_signal_correction_noise)
+      + roll(latents, randint(1, B)) * randn(B, C, 1, 1) * batch_noise_correction_scale   1363-1376 (do_batch_noise_correction, B > 1)
       + randn(B, C[, F], 1, 1) * random_noise_shift                        1378-1386
       * exp(randn(B, C[, F], 1, 1) * random_noise_multiplier)              1388-1391
     Tiny per-batch tensor plumbing on [B, C, h, w]; the mixing with the latents and the 2x2 packing are aitk_flow_noise_pack."""
@@ -166,6 +169,14 @@ def get_noise(latents, generator=None, *, noise_offset=0.0, noise_multiplier=1.0
         noise = noise + latents.mean(dim=(2, 3), keepdim=True).to(dtype) / 2
     s = (noise.shape[0], noise.shape[1], 1, 1) if noise.dim() == 4 else (noise.shape[0], noise.shape[1], noise.shape[2], 1, 1)
     noise = noise * noise_multiplier
+    if signal_correction_noise_scale:
+        scn = torch.randn(latents.shape[0], latents.shape[1], 1, 1, device=dev, dtype=dtype, generator=generator) * signal_correction_noise_scale
+        noise = noise + latents.to(dtype) * scn
+    if batch_noise_correction_scale and latents.shape[0] > 1:
+        # another sample of the batch, never the same position (the reference draws the shift with the global CPU generator)
+        shift = torch.randint(1, latents.shape[0], (1,)).item()
+        bn = latents.roll(shifts=shift, dims=0).to(dtype)
+        noise = noise + bn * (torch.randn(bn.shape[0], bn.shape[1], 1, 1, device=dev, dtype=dtype, generator=generator) * batch_noise_correction_scale)
     if random_noise_shift > 0.0:
         noise = noise + torch.randn(s, device=dev, dtype=dtype, generator=generator) * random_noise_shift
     if random_noise_multiplier > 0.0:

@@ -269,3 +269,25 @@ def test_n_step_timestep_types_follow_the_trainer():
     s.set_train_timesteps(1000, "cpu", "one_step")
     t, idx = s.sample_timesteps(4, "cpu")
     assert torch.equal(idx, torch.zeros(4, dtype=torch.long)) and torch.equal(t, torch.full((4,), 1000.0))
+
+
+def test_signal_and_batch_noise_correction_follow_the_trainer():
+    """do_signal_correction_noise / do_batch_noise_correction (jobs/process/BaseSDTrainProcess.py:1353-1376) restated line by line next to
+    flowmatch.get_noise under the same seeds."""
+    from ai_toolkit_amd.flowmatch import get_noise
+
+    lat = torch.randn(3, 4, 6, 5, generator=torch.Generator().manual_seed(1))
+    torch.manual_seed(11)
+    got = get_noise(lat, None, noise_multiplier=0.9, signal_correction_noise_scale=0.3, batch_noise_correction_scale=0.2)
+    torch.manual_seed(11)
+    noise = torch.randn(lat.shape) * 0.9
+    batch_noise = lat.clone()
+    noise = noise + batch_noise * (torch.randn(3, 4, 1, 1) * 0.3)
+    batch_noise = lat.clone().roll(shifts=torch.randint(1, 3, (1,)).item(), dims=0)
+    noise = noise + batch_noise * (torch.randn(3, 4, 1, 1) * 0.2)
+    assert torch.equal(got, noise)
+    # batch of one: the batch correction is skipped like the reference does
+    torch.manual_seed(3)
+    a = get_noise(lat[:1], None, batch_noise_correction_scale=0.2)
+    torch.manual_seed(3)
+    assert torch.equal(a, torch.randn(lat[:1].shape))
