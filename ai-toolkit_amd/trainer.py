@@ -21,8 +21,13 @@ class _LoRATrainStepBase:
 
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
-                 seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False):
+                 seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False,
+                 latent_multiplier=1.0, adaptive_scaling_factor=False, noisy_latent_multiplier=1.0):
         self.model, self.network, self.ops = model, network, ops
+        # jobs/process/BaseSDTrainProcess.py:1393-1401 (latents * latent_multiplier, or 1 / (per-channel std + 1e-6) with
+        # adaptive_scaling_factor) and 1467-1470 (noisy latents * noisy_latent_multiplier)
+        self.latent_multiplier, self.adaptive_scaling_factor = float(latent_multiplier), bool(adaptive_scaling_factor)
+        self.noisy_latent_multiplier = float(noisy_latent_multiplier)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.max_grad_norm, self.ema_decay = max_grad_norm, ema_decay
         self.timestep_type, self.guidance = timestep_type, guidance
@@ -60,6 +65,19 @@ class _LoRATrainStepBase:
         # arena split point: adapters at [split, n) get their final gradients first during backward
         self._split = model.grad_split_offset(network)
         model.grad_ready_hook = None  # set per backward pass (only the last micro-batch issues the all-reduce)
+
+    def _scale_latents(self, latents):
+        """batch.latents of the reference: the cached / encoded latents times latent_multiplier (BaseSDTrainProcess.py:1393-1411)."""
+        if self.adaptive_scaling_factor:
+            if latents.dim() != 4:
+                raise ValueError("adaptive_scaling_factor: image latents only (the reference reduces over dims (2, 3))")
+            return latents * (1 / (latents.std(dim=(2, 3), keepdim=True) + 1e-6))
+        return latents if self.latent_multiplier == 1.0 else latents * self.latent_multiplier
+
+    def _scale_noisy(self, noisy):
+        if self.noisy_latent_multiplier != 1.0:
+            self.ops.ew(3, noisy.view(-1, noisy.shape[-1]), noisy.view(-1, noisy.shape[-1]), alpha=self.noisy_latent_multiplier)
+        return noisy
 
     # ------------------------------------------------------------------ DP
     def _on_grads_ready(self, which):
@@ -217,7 +235,7 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B = latents.shape[0]
         dev = latents.device
-        latents = latents.to(dt).contiguous()
+        latents = self._scale_latents(latents.to(dt)).contiguous()
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
@@ -247,6 +265,7 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         noisy = torch.empty(B, n_tok, Cc * 4, dtype=dt, device=dev)
         target = torch.empty_like(noisy)
         ops.flow_noise_pack(latents, p["noise"], timesteps, noisy, target)
+        self._scale_noisy(noisy)
         img_ids, txt_ids = make_ids(Hh, W, p["prompt_embeds"].shape[1], dev)
         guidance = torch.full((B,), float(self.guidance), device=dev)
         prior = None
@@ -281,6 +300,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B, Cc, Fr, Hh, W = latents.shape
         dev = latents.device
+        latents = self._scale_latents(latents)
         self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
@@ -307,6 +327,7 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         noisy = torch.empty(B * Fr, n_tok, Cc * 4, dtype=dt, device=dev)
         target = torch.empty_like(noisy)
         ops.flow_noise_pack(lat_f, noi_f, timesteps.repeat_interleave(Fr).contiguous(), noisy, target)
+        self._scale_noisy(noisy)
         grid = (Fr, Hh // 2, W // 2)
         with net:
             pred = model.forward_native(noisy.view(B, Fr * n_tok, Cc * 4), timesteps, p["prompt_embeds"], grid)
@@ -335,7 +356,7 @@ class UNetLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B, Cc, Hh, W = latents.shape
         dev = latents.device
-        latents = latents.to(dt).contiguous()
+        latents = self._scale_latents(latents.to(dt)).contiguous()
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         timesteps = timesteps.to(dev).long()
@@ -367,6 +388,7 @@ class UNetLoRATrainStep(_LoRATrainStepBase):
         target = torch.empty(B * Hh * W, Cc, dtype=dt, device=dev)
         ops.ddpm_noise_nhwc(latents, p["noise"], p["alpha"], p["sigma"], noisy, target,
                             v_prediction=self.schedule.prediction_type == "v_prediction")
+        self._scale_noisy(noisy)
         added = dict(text_embeds=p["pooled_embeds"], time_ids=p["time_ids"]) if self.is_xl else None
         with net:
             pred = model.forward_native(noisy, p["t_float"], p["prompt_embeds"], added, B=B, H=Hh, W=W)

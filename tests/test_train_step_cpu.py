@@ -197,3 +197,33 @@ def test_weighted_timestep_type_scales_the_per_sample_loss_like_the_reference():
     assert la == lb and torch.equal(ga, net.arena_g)
     lc = b.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
     assert abs(lc - la) > 1e-3 * abs(la) and len(default_weighing_scheme()) == 1000
+
+
+def test_latent_multipliers_of_the_trainer():
+    """latent_multiplier / adaptive_scaling_factor / noisy_latent_multiplier (jobs/process/BaseSDTrainProcess.py:1393-1401, 1467-1470):
+    the step with the option == the plain step on the pre-scaled latents (batch.latents IS the scaled tensor, so the flow target follows it);
+    the noisy-latent multiplier scales the model input only."""
+    from ai_toolkit_amd import flowmatch
+    from tests.test_host_graph_cpu import build_pair
+
+    def run(kw, lat_scale=None):
+        ref, ref_net, nat, net = build_pair(rank=4)
+        st = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.0, **kw)
+        g = torch.Generator().manual_seed(3)
+        lat = torch.randn(2, 16, 8, 4, generator=g) * 1.7 + 0.2
+        emb, pooled = torch.randn(2, 6, 64, generator=g), torch.randn(2, 32, generator=g)
+        noise = torch.randn(2, 16, 8, 4, generator=g)
+        if lat_scale is not None:
+            lat = lat_scale(lat)
+        loss = st.step(lat, emb, pooled, noise=noise, timesteps=torch.tensor([310.0, 845.0])).item()
+        return loss, net.arena_p.clone()
+
+    l1, p1 = run(dict(latent_multiplier=0.5))
+    l2, p2 = run({}, lambda x: x * 0.5)
+    assert l1 == l2 and torch.equal(p1, p2)
+    l3, p3 = run(dict(adaptive_scaling_factor=True))
+    l4, p4 = run({}, lambda x: x * (1 / (x.std(dim=(2, 3), keepdim=True) + 1e-6)))
+    assert l3 == l4 and torch.equal(p3, p4)
+    l5, _ = run(dict(noisy_latent_multiplier=0.9))
+    l6, _ = run({})
+    assert l5 != l6 and abs(l5 - l6) < 0.5 * abs(l6)
