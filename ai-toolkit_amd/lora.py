@@ -975,13 +975,32 @@ class FusedLoRANetwork(nn.Module):
                 out += [self.arena_view(arena, m, "down"), self.arena_view(arena, m, "up")]
         return out
 
+    def _opt_ref_shapes(self):
+        """Shapes of the reference's parameters in _opt_slices order: conv adapters are Conv2d weights there ([r, in, 1, 1] / [r, in, 3, 3]
+        down, [out, r, 1, 1] up; toolkit/lora_special.py:95-104), so the exported Adam moments take those shapes."""
+        out = []
+        for m in self.unet_loras:
+            if m.magnitude is not None:
+                out += [tuple(m.magnitude.shape), tuple(m.lora_up.weight.shape), tuple(m.lora_down.weight.shape)]
+            elif getattr(m, "is_lokr", False):
+                out += [tuple(p.shape) for _, p in m.factor_params()]
+            else:
+                d, u = tuple(m.lora_down.weight.shape), tuple(m.lora_up.weight.shape)
+                if getattr(m, "is_conv3x3", False):
+                    d, u = (d[0], m.conv_cin, 3, 3), u + (1, 1)
+                elif getattr(m, "is_conv1x1", False):
+                    d, u = d + (1, 1), u + (1, 1)
+                out += [d, u]
+        return out
+
     def optimizer_state_dict(self, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01):
         """The fused AdamW state exported in torch.optim.AdamW.state_dict() layout (params in prepare_optimizer_params
         order), so `optimizer.pt` written here can be loaded by the reference's torch optimizer and vice versa."""
         state = {}
+        shapes = self._opt_ref_shapes()
         for i, (mv, vv) in enumerate(zip(self._opt_slices(self.arena_m), self._opt_slices(self.arena_v))):
-            state[i] = {"step": torch.tensor(float(step)), "exp_avg": mv.clone().contiguous().cpu(),
-                        "exp_avg_sq": vv.clone().contiguous().cpu()}
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": mv.clone().contiguous().cpu().reshape(shapes[i]),
+                        "exp_avg_sq": vv.clone().contiguous().cpu().reshape(shapes[i])}
         group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(state)))}
         return {"state": state, "param_groups": [group]}
@@ -994,9 +1013,9 @@ class FusedLoRANetwork(nn.Module):
             raise ValueError(f"optimizer state has {len(sd['state'])} tensors, the network has {len(ms)} trainable tensors")
         for i, (mv, vv) in enumerate(zip(ms, vs)):
             st = sd["state"][i]
-            if tuple(st["exp_avg"].shape) != tuple(mv.shape):
+            if st["exp_avg"].numel() != mv.numel() or tuple(st["exp_avg"].shape[:1]) != tuple(mv.shape[:1]):
                 raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} does not match parameter {tuple(mv.shape)}")
-            mv.copy_(st["exp_avg"])
-            vv.copy_(st["exp_avg_sq"])
+            mv.copy_(st["exp_avg"].reshape(mv.shape))  # conv adapters arrive as 4-D Conv2d-shaped moments
+            vv.copy_(st["exp_avg_sq"].reshape(vv.shape))
             step = int(float(st["step"]))
         return step

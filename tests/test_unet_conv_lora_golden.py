@@ -196,3 +196,33 @@ def test_conv_lora_dp2_gloo_equals_single_rank_on_concatenated_batch(tmp_path):
         lat, ctx, pooled, noise, ts = _dp_batch(4, seed=40 + k)
         step.step(lat, ctx, pooled, noise=noise, timesteps=ts)
     assert torch.allclose(net.arena_p, p0, rtol=1e-3, atol=1e-6), (net.arena_p - p0).abs().max()
+
+
+def test_optimizer_state_of_conv_adapters_loads_into_the_reference_shapes():
+    """optimizer.pt (BaseSDTrainProcess.py:701-714): the reference's torch.optim.AdamW holds Conv2d-shaped moments for conv adapters
+    ([r, in, 3, 3] / [r, in, 1, 1] down, [out, r, 1, 1] up).  The exported state loads into an AdamW over parameters of exactly those shapes
+    (the shapes of the file the reference's network saves) and comes back unchanged."""
+    t, meta = _golden()
+    nat, net = build(TINY_SD15)
+    warm_and_attach(nat, net, t, "sd15", ref_ops)
+    net.arena_m.copy_(torch.randn(net.arena_m.shape, generator=torch.Generator().manual_seed(1)))
+    net.arena_v.copy_(torch.rand(net.arena_v.shape, generator=torch.Generator().manual_seed(2)))
+    sd = net.optimizer_state_dict(step=4, lr=1e-4)
+    ref_params = []
+    for x in net.unet_loras:  # the reference module's parameters: lora_down.weight, lora_up.weight with the saved-file shapes
+        ref_params += [torch.nn.Parameter(torch.zeros_like(t[f"sd15/saved/{x.lora_name}.lora_down.weight"])),
+                       torch.nn.Parameter(torch.zeros_like(t[f"sd15/saved/{x.lora_name}.lora_up.weight"]))]
+    assert any(p.dim() == 4 and p.shape[2:] == (3, 3) for p in ref_params)
+    opt = torch.optim.AdamW(ref_params, lr=1e-4, eps=1e-6)
+    opt.load_state_dict(sd)
+    for i, p in enumerate(ref_params):
+        assert opt.state[p]["exp_avg"].shape == p.shape, (i, opt.state[p]["exp_avg"].shape, p.shape)
+    m0, v0 = net.arena_m.clone(), net.arena_v.clone()
+    net.arena_m.zero_()
+    net.arena_v.zero_()
+    assert net.load_optimizer_state_dict(opt.state_dict()) == 4
+    # the rank padding of the arena blocks is not part of any parameter: compare through the logical views
+    for a, b in zip(net._opt_slices(net.arena_m), net._opt_slices(m0)):
+        assert torch.equal(a, b)
+    for a, b in zip(net._opt_slices(net.arena_v), net._opt_slices(v0)):
+        assert torch.equal(a, b)
