@@ -727,6 +727,9 @@ class FusedLoRANetwork(nn.Module):
     def enable_gradient_checkpointing(self):
         pass  # the fused step keeps activations resident in HBM (288 GB); nothing to recompute
 
+    def disable_gradient_checkpointing(self):
+        pass  # toolkit/network_mixins.py:885-888
+
     def prepare_optimizer_params(self, text_encoder_lr=None, unet_lr=None, default_lr=None):
         """One group with every adapter weight (toolkit/kohya_lora.py:1030-1074, unet branch)."""
         params = []
