@@ -16,23 +16,25 @@ from typing import Dict, List, Sequence, Tuple
 
 
 def get_bucket_for_image_size(width: int, height: int, resolution: int = 512, divisibility: int = 8) -> Dict[str, int]:
-    total_pixels = width * height
-    max_pixels = resolution * resolution
-    target_pixels = min(total_pixels, max_pixels)
-    scaler = (target_pixels / total_pixels) ** 0.5
-    w_raw = (width * scaler) / divisibility
-    h_raw = (height * scaler) / divisibility
-    candidates = [
-        (math.floor(w_raw) * divisibility, math.floor(h_raw) * divisibility),
-        (math.floor(w_raw) * divisibility, math.ceil(h_raw) * divisibility),
-        (math.ceil(w_raw) * divisibility, math.floor(h_raw) * divisibility),
-        (math.ceil(w_raw) * divisibility, math.ceil(h_raw) * divisibility),
-    ]
-    capped = [(w, h) for w, h in candidates if w > 0 and h > 0 and w * h <= max_pixels]
-    if not capped:
-        capped = [(max(divisibility, math.floor(w_raw) * divisibility), max(divisibility, math.floor(h_raw) * divisibility))]
-    new_width, new_height = min(capped, key=lambda wh: abs(wh[0] * wh[1] - target_pixels))
-    return {"width": new_width, "height": new_height}
+    """Bucket (multiples of `divisibility`) for an image: shrink to at most resolution^2 pixels keeping the aspect ratio, then of the
+    four floor / ceil roundings of the two sides that fit the pixel budget take the one whose area is closest to the target (first
+    wins on ties, width-floor before width-ceil).  Same results as toolkit/buckets.py:17-48 (pinned by tests/golden/buckets.json)."""
+    area, budget = width * height, resolution * resolution
+    goal = min(area, budget)
+    shrink = (goal / area) ** 0.5
+    cells_w, cells_h = (width * shrink) / divisibility, (height * shrink) / divisibility
+    best = None
+    for round_w in (math.floor, math.ceil):
+        for round_h in (math.floor, math.ceil):
+            w, h = round_w(cells_w) * divisibility, round_h(cells_h) * divisibility
+            if w <= 0 or h <= 0 or w * h > budget:
+                continue
+            miss = abs(w * h - goal)
+            if best is None or miss < best[0]:
+                best = (miss, w, h)
+    if best is None:  # degenerate input: one cell per side at least
+        best = (0, max(divisibility, math.floor(cells_w) * divisibility), max(divisibility, math.floor(cells_h) * divisibility))
+    return {"width": best[1], "height": best[2]}
 
 
 @dataclass

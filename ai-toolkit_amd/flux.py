@@ -124,6 +124,18 @@ class FluxTransformer2DModel(FusedGraphBase):
         self.proj_out = Linear(d, in_channels, True, dtype, device)
         self._init_graph(ops, dtype)  # grad_ready_hook pieces: 'single' then 'double'
         self._rope_cache = {}
+        self.res_dt = dtype  # storage type of the residual stream and of its gradient (set_precision)
+
+    def set_precision(self, precision="default"):
+        """precision="high": hidden_states / encoder_hidden_states and their gradients are carried across the 57 blocks in fp32 (every
+        other activation stays in the model dtype).  The reference has no such switch (its stream is the model dtype); this is the
+        experiment of DESIGN.md section 7 against north_star's 1e-3 LoRA-delta bound."""
+        assert precision in ("default", "high")
+        self.res_dt = torch.float32 if precision == "high" else self.dt
+        return self
+
+    def _newr(self, *shape):
+        return torch.empty(*shape, dtype=self.res_dt, device=self._device())
 
     # ------------------------------------------------------------------ setup
     def _token_linears(self):
@@ -239,9 +251,9 @@ class FluxTransformer2DModel(FusedGraphBase):
         ops.ew(0, temb, silu_temb)
 
         # ---- token embedders
-        x_img = self._new(Mi, d)
+        x_img = self._newr(Mi, d)
         ops.gemm_nt(hidden_states.to(dt).reshape(Mi, Cin), self.x_embedder.weight, x_img, bias=self.x_embedder.bias)
-        x_txt = self._new(Mt, d)
+        x_txt = self._newr(Mt, d)
         ops.gemm_nt(encoder_hidden_states.to(dt).reshape(Mt, -1), self.context_embedder.weight, x_txt,
                     bias=self.context_embedder.bias)
 
@@ -286,7 +298,7 @@ class FluxTransformer2DModel(FusedGraphBase):
                 seg = (Ss, S * d)
                 o_view = o_j[s_off:]
                 y_attn = self._new(M, d)
-                x1 = self._new(M, d)
+                x1 = self._newr(M, d)
                 r["T_o"] = self._lin_fwd(out_lin, o_view, x1, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
                                          aux_out=y_attn, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=Ss, a_seg=seg)
                 mean, rstd = self._new(M, dtype=torch.float32), self._new(M, dtype=torch.float32)
@@ -296,7 +308,7 @@ class FluxTransformer2DModel(FusedGraphBase):
                 hbuf = self._new(M, 4 * d)
                 r["T_ff1"] = self._lin_fwd(ff.net[0].proj, xn2, hbuf, M=M, rows_per_batch=Ss, B=B, flags=EPI_GELU, aux_out=u)
                 y_ff = self._new(M, d)
-                x2 = self._new(M, d)
+                x2 = self._newr(M, d)
                 r["T_ff2"] = self._lin_fwd(ff.net[2], hbuf, x2, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
                                            aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss)
                 r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=hbuf, y_ff=y_ff)
@@ -309,7 +321,7 @@ class FluxTransformer2DModel(FusedGraphBase):
                 ctx["dbl"].append(rec)
 
         # ---- joint stream
-        x = self._new(Mj, d)
+        x = self._newr(Mj, d)
         xv = x.view(B, S, d)
         for b in range(B):
             ops.copy_rows(xv[b, :St], x_txt.view(B, St, d)[b])
@@ -337,7 +349,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             lse = self._new(B, H, S, dtype=torch.float32)
             ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], cat[:, 0:d], lse, B=B, H=H, S=S, scale=scale)
             y = self._new(Mj, d)
-            x_new = self._new(Mj, d)
+            x_new = self._newr(Mj, d)
             r["T_out"] = self._lin_fwd(blk.proj_out, cat, x_new, M=Mj, rows_per_batch=S, B=B, flags=EPI_GATE_RES,
                                        aux_out=y, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=S)
             r.update(mod=mod, x=x, mean=mean, rstd=rstd, xn=xn, qkv_raw=qkv_raw, cat=cat, u=u, qkv_j=qkv_j, lse=lse, y=y)
@@ -346,7 +358,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             x = x_new
 
         # ---- output head (frozen): AdaLayerNormContinuous ([scale, shift]) + proj_out on the image tokens
-        x_out = self._new(Mi, d)
+        x_out = self._newr(Mi, d)
         xv = x.view(B, S, d)
         for b in range(B):
             ops.copy_rows(x_out.view(B, Si, d)[b], xv[b, St:])
@@ -378,9 +390,9 @@ class FluxTransformer2DModel(FusedGraphBase):
         # ---- head
         dxn = self._new(Mi, d)
         ops.gemm_nt(dpred.to(self.dt).reshape(Mi, Cin).contiguous(), self.proj_out.weight_t, dxn)
-        dx_out = self._new(Mi, d)
+        dx_out = self._newr(Mi, d)
         ops.ln_mod_bwd(dxn, ctx["x_out"], ctx["mean_out"], ctx["rstd_out"], ctx["mod_out"][:, 0:d], dx_out, B=B, S=Si)
-        dx = torch.zeros(Mj, d, dtype=self.dt, device=dx_out.device)
+        dx = torch.zeros(Mj, d, dtype=self.res_dt, device=dx_out.device)
         dxv = dx.view(B, S, d)
         for b in range(B):
             ops.copy_rows(dxv[b, St:], dx_out.view(B, Si, d)[b])
@@ -413,7 +425,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             self._group_bwd((a.to_q, a.to_k, a.to_v, blk.proj_mlp),
                             [dqkv_raw[:, 0:d], dqkv_raw[:, d:2 * d], dqkv_raw[:, 2 * d:], du],
                             r["T_qkv"] + [r["T_mlp"]], r["xn"], dxn, M=Mj, rows_per_batch=S, B=B)
-            dx_prev = self._new(Mj, d)
+            dx_prev = self._newr(Mj, d)
             ops.ln_mod_bwd(dxn, r["x"], r["mean"], r["rstd"], mod[:, d:2 * d], dx_prev, B=B, S=S, dres=dx,
                            dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
             self._ada_bwd(blk.norm.linear, dmod, r["T_mod"], silu_temb, B)
@@ -424,7 +436,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             self.grad_ready_hook("single")
 
         # ---- split the joint gradient
-        dx_img, dx_txt = self._new(Mi, d), self._new(Mt, d)
+        dx_img, dx_txt = self._newr(Mi, d), self._newr(Mt, d)
         dxv = dx.view(B, S, d)
         for b in range(B):
             ops.copy_rows(dx_txt.view(B, St, d)[b], dxv[b, :St])
@@ -446,7 +458,7 @@ class FluxTransformer2DModel(FusedGraphBase):
                 self._lin_bwd(ff.net[2], dy, r["T_ff2"], r["h"], du, M=M, rows_per_batch=Ss, B=B, flags=EPI_DGELU, aux_in=r["u"])
                 dxn2 = self._new(M, d)
                 self._lin_bwd(ff.net[0].proj, du, r["T_ff1"], r["xn2"], dxn2, M=M, rows_per_batch=Ss, B=B)
-                dx1 = self._new(M, d)
+                dx1 = self._newr(M, d)
                 ops.ln_mod_bwd(dxn2, r["x1"], r["mean2"], r["rstd2"], mod[:, 4 * d:5 * d], dx1, B=B, S=Ss, dres=dx2,
                                dshift=dmod[:, 3 * d:4 * d], dscale=dmod[:, 4 * d:5 * d])
                 ops.gate_bwd(dx1, r["y_attn"], mod[:, 2 * d:3 * d], dy, dmod[:, 2 * d:3 * d], B=B, S=Ss)
@@ -474,7 +486,7 @@ class FluxTransformer2DModel(FusedGraphBase):
                 dxn = self._new(M, d)
                 self._group_bwd(qkv_lins, [dqkv_raw[:, j * d:(j + 1) * d] for j in range(3)], r["T_qkv"], r["xn"], dxn,
                                 M=M, rows_per_batch=Ss, B=B)
-                dx0 = self._new(M, d)
+                dx0 = self._newr(M, d)
                 ops.ln_mod_bwd(dxn, r["x"], r["mean1"], r["rstd1"], mod[:, d:2 * d], dx0, B=B, S=Ss, dres=dx1s[name],
                                dshift=dmod[:, 0:d], dscale=dmod[:, d:2 * d])
                 self._ada_bwd(norm1.linear, dmod, r["T_mod"], silu_temb, B)
@@ -504,8 +516,7 @@ class _FluxGraphFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx_, dpred):
         net = ctx_.model.network
-        mods = net.get_all_modules()
-        if mods and mods[0].lora_down.weight.grad is None:
+        if net.grads_dropped():
             # the trainer's optimizer.zero_grad(set_to_none=True) (SDTrainer.py:2249, 2288) dropped the .grad views: "none" means
             # zero, so the arena they alias is cleared and the views are re-attached before this backward accumulates into it
             net.zero_grad_arena()

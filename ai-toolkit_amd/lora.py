@@ -156,25 +156,24 @@ def add_model_hash_to_meta(state_dict, meta):
 
 
 def factorization(dimension: int, factor: int = -1):
-    """(m, n) with m * n == dimension, m <= n, m as close to `factor` as the divisors allow (factor -1: closest to sqrt) —
-    restates toolkit/models/lokr.py:22-59 (LyCORIS factorization)."""
+    """Split `dimension` into (m, n), m * n == dimension, m <= n.  Behaviour of the LyCORIS rule the reference uses
+    (toolkit/models/lokr.py:22-59): an exact divisor `factor` is taken as is; otherwise walk the divisor pairs upwards from (1, dim)
+    and keep the last pair whose sum did not grow and whose smaller member does not exceed `factor` (-1: no limit)."""
     if factor > 0 and dimension % factor == 0:
         return factor, dimension // factor
-    if factor == -1:
-        factor = dimension
-    m, n = 1, dimension
-    length = m + n
-    while m < n:
-        new_m = m + 1
-        while dimension % new_m != 0:
-            new_m += 1
-        new_n = dimension // new_m
-        if new_m + new_n > length or new_m > factor:
+    limit = dimension if factor == -1 else factor
+    best = (1, dimension)
+    for cand in range(2, dimension + 1):
+        if best[0] >= best[1]:
             break
-        m, n = new_m, new_n
-    if m > n:
-        n, m = m, n
-    return m, n
+        if dimension % cand:
+            continue
+        other = dimension // cand
+        if cand + other > best[0] + best[1] or cand > limit:
+            break
+        best = (cand, other)
+    lo, hi = min(best), max(best)
+    return lo, hi
 
 
 class _ParamProxy:
@@ -677,6 +676,14 @@ class FusedLoRANetwork(nn.Module):
                 m.lora_up.weight.grad = self.arena_view(self.arena_g, m, "up")
             if m.magnitude is not None and m.magnitude.grad is None:
                 m.magnitude.grad = m.g_mag
+
+    def grads_dropped(self):
+        """True when optimizer.zero_grad(set_to_none=True) removed the .grad views (any adapter type: asks the first trainable
+        Parameter, not lora_down — low-rank LoKr has no such matrix)."""
+        for par in self.parameters():
+            if par.requires_grad:
+                return par.grad is None
+        return False
 
     def zero_grad_arena(self):
         self.arena_g.zero_()

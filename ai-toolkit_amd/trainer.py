@@ -59,6 +59,7 @@ class _LoRATrainStepBase:
             self.gen.manual_seed(seed)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_per_sample = None
+        self._loss_per_sample_by_B = {}
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         if ema_decay > 0 and network.arena_ema is None:
             network.arena_ema = network.arena_p.clone()
@@ -89,6 +90,11 @@ class _LoRATrainStepBase:
         for piece in pieces:
             if piece.numel():
                 self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _table_type(self):
+        """timestep table the scheduler is set to: `linear_timesteps` / `linear_timesteps2` force 'linear' whatever timestep_type says
+        (jobs/process/BaseSDTrainProcess.py:1196-1203); timestep_type itself still selects the 'weighted' loss-weight lookup."""
+        return "linear" if (self.linear_timesteps or self.linear_timesteps2) else self.timestep_type
 
     def _timestep_loss_weight(self, timesteps, loss_weight):
         """per-sample loss weights of the flow-matching timestep weighting (None when off), folded into `loss_weight`."""
@@ -130,6 +136,10 @@ class _LoRATrainStepBase:
         key = self._graph_key(prepared)
         if key in self._graphs:
             return self._graphs[key]
+        if self.network.training and self.network.has_dropout:
+            # dropout / rank_dropout masks and the module_dropout coin are host draws made while the launch list is built: a captured
+            # graph would replay ONE draw for ever (toolkit/network_mixins.py:197-239 draws per call)
+            raise NotImplementedError("hipGraph replay with LoRA dropout / rank_dropout / module_dropout: use step() (eager launches)")
         static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in prepared.items()}
         # warm-up on a side stream (workspaces, function attributes, RoPE tables are created here, not under capture)
         side = torch.cuda.Stream()
@@ -143,10 +153,14 @@ class _LoRATrainStepBase:
         g = torch.cuda.CUDAGraph()
         self.network.zero_grad_arena()
         with torch.cuda.graph(g, pool=self._graph_pool):
-            self._run(static, final=False)
+            loss = self._run(static, final=False)
         if self._graph_pool is None:
             self._graph_pool = g.pool()
-        ent = {"graph": g, "static": static}
+        # the graph holds raw pointers: every grow-only kernel workspace as it was during capture (ops.workspace replaces a buffer
+        # when a larger bucket asks for more) and this batch size's per-sample loss buffer stay referenced by the entry, so a later
+        # reallocation cannot hand their memory to another tensor while the graph can still be replayed
+        ent = {"graph": g, "static": static, "loss": loss, "keepalive": (list(getattr(self.ops, "_ws", {}).values()),
+                                                                         dict(self._loss_per_sample_by_B))}
         self._graphs[key] = ent
         return ent
 
@@ -165,7 +179,7 @@ class _LoRATrainStepBase:
         self._optimizer_step()
         if self.lr_scheduler is not None:
             self.lr = self.lr_scheduler.step()
-        return self.loss
+        return ent["loss"]  # what _run returned under capture (with `preservation`: the SUM of both terms, not the last mse launch)
 
     def _single(self, final=True, **batch):
         return self._run(self._prepare(**batch), final=final)
@@ -193,8 +207,9 @@ class _LoRATrainStepBase:
         ops, model, net = self.ops, self.model, self.network
         B = pred.shape[0]
         dpred = torch.empty_like(pred)
-        if self.loss_per_sample is None or self.loss_per_sample.numel() != B:
-            self.loss_per_sample = torch.zeros(B, dtype=torch.float32, device=pred.device)
+        self.loss_per_sample = self._loss_per_sample_by_B.get(B)  # one buffer per batch size, never re-created (captured graphs point at it)
+        if self.loss_per_sample is None:
+            self.loss_per_sample = self._loss_per_sample_by_B[B] = torch.zeros(B, dtype=torch.float32, device=pred.device)
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
                           mask=loss_mask)
         model.grad_ready_hook = self._on_grads_ready if (final and self.dp) else None
@@ -235,13 +250,15 @@ class FluxLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B = latents.shape[0]
         dev = latents.device
-        latents = self._scale_latents(latents.to(dt)).contiguous()
-        self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
+        latents = latents.to(dt)
+        self.schedule.set_train_timesteps(1000, dev, self._table_type(), latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
-        if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812) + the noise options
+        if noise is None:  # randn in fp32 on device, then cast (toolkit/stable_diffusion_model.py:1803-1812) + the noise options;
+            # drawn and shaped from the UNSCALED latents: latent_multiplier is applied after it (BaseSDTrainProcess.py:1323-1401)
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
+        latents = self._scale_latents(latents).contiguous()
         p = dict(latents=latents, noise=noise.to(dt).contiguous(), timesteps=timesteps.float().contiguous(),
                  prompt_embeds=prompt_embeds, pooled_embeds=pooled_embeds, loss_weight=loss_weight,
                  loss_mask=self.pack_mask(loss_mask) if loss_mask is not None else None)
@@ -300,13 +317,13 @@ class WanLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B, Cc, Fr, Hh, W = latents.shape
         dev = latents.device
-        latents = self._scale_latents(latents)
-        self.schedule.set_train_timesteps(1000, dev, self.timestep_type, latents=latents, patch_size=2)
+        self.schedule.set_train_timesteps(1000, dev, self._table_type(), latents=latents, patch_size=2)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         loss_weight = self._timestep_loss_weight(timesteps, loss_weight)
-        if noise is None:
+        if noise is None:  # from the unscaled latents (BaseSDTrainProcess.py:1323-1401)
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
+        latents = self._scale_latents(latents)
         if loss_mask is not None:
             if loss_mask.dim() == 4:  # [B,1,H,W] -> repeated over frames (SDTrainer.py:955-958)
                 loss_mask = loss_mask[:, :, None].expand(-1, -1, Fr, -1, -1)
@@ -356,12 +373,13 @@ class UNetLoRATrainStep(_LoRATrainStepBase):
         dt = self.model.dt
         B, Cc, Hh, W = latents.shape
         dev = latents.device
-        latents = self._scale_latents(latents.to(dt)).contiguous()
+        latents = latents.to(dt)
         if timesteps is None:
             timesteps, _ = self.schedule.sample_timesteps(B, dev, generator=self.gen)
         timesteps = timesteps.to(dev).long()
-        if noise is None:
+        if noise is None:  # from the unscaled latents (BaseSDTrainProcess.py:1323-1401)
             noise = get_noise(latents, self.gen, dtype=dt, **self.noise_options)
+        latents = self._scale_latents(latents).contiguous()
         a, s = self.schedule.noise_coefficients(timesteps, dt)
         p = dict(latents=latents, noise=noise.to(dt).contiguous(), t_float=timesteps.float(), alpha=a, sigma=s,
                  prompt_embeds=prompt_embeds)

@@ -112,24 +112,20 @@ class RefDoRAModule(nn.Module):
 
 
 def factorization(dimension, factor=-1):
-    """toolkit/models/lokr.py:22-59."""
+    """ORACLE restatement of the LyCORIS split used at toolkit/models/lokr.py:22-59, written over the explicit divisor list: among the
+    divisor pairs (a, dim/a), a ascending from 1, advance while a < dim/a, the pair sum does not grow and a stays <= factor."""
     if factor > 0 and dimension % factor == 0:
         return factor, dimension // factor
-    if factor == -1:
-        factor = dimension
-    m, n = 1, dimension
-    length = m + n
-    while m < n:
-        new_m = m + 1
-        while dimension % new_m != 0:
-            new_m += 1
-        new_n = dimension // new_m
-        if new_m + new_n > length or new_m > factor:
+    cap = dimension if factor == -1 else factor
+    divisors = [a for a in range(1, dimension + 1) if dimension % a == 0]
+    pick = 0
+    while divisors[pick] < dimension // divisors[pick] and pick + 1 < len(divisors):
+        nxt = divisors[pick + 1]
+        if nxt + dimension // nxt > divisors[pick] + dimension // divisors[pick] or nxt > cap:
             break
-        m, n = new_m, new_n
-    if m > n:
-        n, m = m, n
-    return m, n
+        pick += 1
+    a, b = divisors[pick], dimension // divisors[pick]
+    return (a, b) if a <= b else (b, a)
 
 
 class RefLokrModule(nn.Module):

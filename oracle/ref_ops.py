@@ -72,7 +72,7 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
             F.gelu(u, approximate="tanh").sum().backward()
         v = v * u.grad
     if flags & EPI_GATE_RES:
-        y = v.to(out.dtype)
+        y = v.to(a.dtype)  # the branch output is rounded to the activation type; `out` (the residual stream) may be fp32 (precision="high")
         if aux_out is not None:
             aux_out[:M].copy_(y)
         g = gate.float().repeat_interleave(gate_rows, 0)[:M]
