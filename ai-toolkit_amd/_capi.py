@@ -143,14 +143,15 @@ class NoisePackArgs(C.Structure):
 
 class MseArgs(C.Structure):
     _fields_ = [("pred", vp), ("target", vp), ("weight", vp), ("dpred", vp), ("partial", vp),
-                ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("feat", i32), ("mask", vp)]
+                ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("feat", i32), ("mask", vp),
+                ("loss_type", i32), ("huber_c", C.c_float)]
 
 
 class AdamWArgs(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("ema", vp),
                 ("norm_partial", vp), ("norm_partial2", vp), ("norm_out", vp), ("n", i64)] + [
         (k, C.c_float) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1",
-                                 "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale")]
+                                 "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale", "ema_feedback", "param_multiplier")]
 
 
 class GroupNormArgs(C.Structure):

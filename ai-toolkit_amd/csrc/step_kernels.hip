@@ -132,15 +132,18 @@ extern "C" int aitk_flow_noise_pack(const AitkNoisePackArgs* a, aitk_stream_t st
 }
 
 // ------------------------------------------------------------------------------------------------ MSE loss + gradient
-// per-sample loss_b = mean_j (pred - target)^2 ; loss = mean_b (w_b * loss_b) ; dpred = 2 (pred - target) w_b / (n B)
+// per-sample loss_b = mean_j l(pred - target) ; loss = mean_b (w_b * loss_b) ; dpred = l'(pred - target) w_b / (n B)
+//   LT 0 (mse): l = d^2, l' = 2d     LT 1 (mae): l = |d|, l' = sign(d)     LT 2 (pseudo_huber): l = sqrt(d^2 + c^2) - c, l' = d / sqrt(d^2 + c^2)
 #define LOSS_CHUNK 8192
+template <int LT>
 __global__ __launch_bounds__(256) void mse_partial_kernel(AitkMseArgs p, int nchunk) {
   __shared__ float red[4];
   const int b = blockIdx.y;
   const long base = (long)b * p.n_per_sample + (long)blockIdx.x * LOSS_CHUNK;
   const long end = min((long)(b + 1) * p.n_per_sample, base + LOSS_CHUNK);
   const float wb = p.weight ? p.weight[b] : 1.0f;
-  const float gs = 2.0f * wb / ((float)p.n_per_sample * (float)p.B);
+  const float gs = (LT == 0 ? 2.0f : 1.0f) * wb / ((float)p.n_per_sample * (float)p.B);
+  const float c2 = p.huber_c * p.huber_c;
   float acc = 0.f;
   for (long i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
     const uint4 pv = *reinterpret_cast<const uint4*>(p.pred + i);
@@ -158,8 +161,17 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(AitkMseArgs p, int nch
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      acc += mk[e & 3] * d[e] * d[e];
-      d[e] *= mk[e & 3];
+      if (LT == 0) {
+        acc += mk[e & 3] * d[e] * d[e];
+        d[e] *= mk[e & 3];
+      } else if (LT == 1) {
+        acc += mk[e & 3] * fabsf(d[e]);
+        d[e] = mk[e & 3] * (d[e] > 0.f ? 1.0f : (d[e] < 0.f ? -1.0f : 0.f));
+      } else {
+        const float r = sqrtf(d[e] * d[e] + c2);
+        acc += mk[e & 3] * (r - p.huber_c);
+        d[e] = mk[e & 3] * d[e] / r;
+      }
     }
     uint4 g;
     g.x = pack2bf(d[0] * gs, d[1] * gs); g.y = pack2bf(d[2] * gs, d[3] * gs);
@@ -196,8 +208,14 @@ extern "C" int aitk_mse_loss_grad(const AitkMseArgs* a, aitk_stream_t stream) {
   if (!a || a->B <= 0 || a->B > 64 || a->n_per_sample <= 0 || (a->n_per_sample % 8)) return AITK_ERR_SHAPE;
   if (!a->pred || !a->target || !a->dpred || !a->partial || !a->loss || !a->loss_per_sample) return AITK_ERR_ARG;
   if (a->mask && (a->feat <= 0 || (a->feat % 8) || (a->n_per_sample % a->feat))) return AITK_ERR_ARG;
+  if (a->loss_type < AITK_LOSS_MSE || a->loss_type > AITK_LOSS_PSEUDO_HUBER || a->huber_c < 0.f) return AITK_ERR_ARG;
   const int nchunk = (int)((a->n_per_sample + LOSS_CHUNK - 1) / LOSS_CHUNK);
-  hipLaunchKernelGGL(mse_partial_kernel, dim3(nchunk, a->B), dim3(256), 0, (hipStream_t)stream, *a, nchunk);
+  AitkMseArgs args = *a;
+  if (args.loss_type == AITK_LOSS_PSEUDO_HUBER && args.huber_c == 0.f) args.huber_c = 0.01f;  // SDTrainer.py:905
+  const dim3 grid(nchunk, a->B);
+  if (args.loss_type == AITK_LOSS_MAE) hipLaunchKernelGGL(mse_partial_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, args, nchunk);
+  else if (args.loss_type == AITK_LOSS_PSEUDO_HUBER) hipLaunchKernelGGL(mse_partial_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, args, nchunk);
+  else hipLaunchKernelGGL(mse_partial_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, args, nchunk);
   AITK_LAUNCH_CHECK();
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, nchunk);
   AITK_LAUNCH_CHECK();
@@ -264,13 +282,16 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, int n2)
       const float v = p.beta2 * p.v[j] + (1.0f - p.beta2) * g * g;
       const float denom = sqrtf(v) / p.bias_correction2_sqrt + p.eps;
       w -= (p.lr / p.bias_correction1) * (m / denom);
-      p.p[j] = w;
       p.m[j] = m;
       p.v[j] = v;
-      if (p.ema) {
+      if (p.ema) {  // toolkit/ema.py:135-143: tmp = (1-d)(s - p); s -= tmp; p += 10 tmp (use_feedback); p *= param_multiplier
         const float s = p.ema[j];
-        p.ema[j] = s - (1.0f - p.ema_decay) * (s - w);
+        const float tmp = (1.0f - p.ema_decay) * (s - w);
+        p.ema[j] = s - tmp;
+        if (p.ema_feedback != 0.f) w += p.ema_feedback * tmp;
+        if (p.param_multiplier != 0.f && p.param_multiplier != 1.0f) w *= p.param_multiplier;
       }
+      p.p[j] = w;
     }
   }
 }

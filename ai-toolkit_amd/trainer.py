@@ -22,8 +22,19 @@ class _LoRATrainStepBase:
     def __init__(self, model, network, ops, *, lr=1e-4, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-6,
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
                  seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False,
-                 latent_multiplier=1.0, adaptive_scaling_factor=False, noisy_latent_multiplier=1.0):
+                 latent_multiplier=1.0, adaptive_scaling_factor=False, noisy_latent_multiplier=1.0, loss_type="mse",
+                 ema_use_feedback=False, ema_param_multiplier=1.0, ema_use_num_updates=False):
         self.model, self.network, self.ops = model, network, ops
+        # train.loss_type (SDTrainer.py:903-916): mse (default) / mae / pseudo_huber run as modes of aitk_mse_loss_grad; wavelet,
+        # stepped, pixelspace and mean_flow are other losses of the reference and are refused
+        if loss_type not in ("mse", "mae", "pseudo_huber"):
+            raise ValueError(f"loss_type {loss_type!r}: the fused step implements mse, mae and pseudo_huber")
+        self.loss_type = loss_type
+        # train.ema_config.use_feedback / param_multiplier (BaseSDTrainProcess.py:798-803 -> toolkit/ema.py:135-143) and the class's
+        # use_num_updates warm-up (ema.py:118-123: decay = min(decay, (1 + n) / (10 + n)))
+        self.ema_feedback = 10.0 if ema_use_feedback else 0.0
+        self.ema_param_multiplier = float(ema_param_multiplier)
+        self.ema_num_updates = 0 if ema_use_num_updates else None
         # jobs/process/BaseSDTrainProcess.py:1393-1401 (latents * latent_multiplier, or 1 / (per-channel std + 1e-6) with
         # adaptive_scaling_factor) and 1467-1470 (noisy latents * noisy_latent_multiplier)
         self.latent_multiplier, self.adaptive_scaling_factor = float(latent_multiplier), bool(adaptive_scaling_factor)
@@ -210,8 +221,9 @@ class _LoRATrainStepBase:
         self.loss_per_sample = self._loss_per_sample_by_B.get(B)  # one buffer per batch size, never re-created (captured graphs point at it)
         if self.loss_per_sample is None:
             self.loss_per_sample = self._loss_per_sample_by_B[B] = torch.zeros(B, dtype=torch.float32, device=pred.device)
+        kw = {} if self.loss_type == "mse" else {"loss_type": self.loss_type}
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
-                          mask=loss_mask)
+                          mask=loss_mask, **kw)
         model.grad_ready_hook = self._on_grads_ready if (final and self.dp) else None
         model.backward_native(dpred)  # inside `with network` like the reference (SDTrainer.py:2229-2238)
         return self.loss
@@ -229,10 +241,17 @@ class _LoRATrainStepBase:
                 e1.record()  # behind the stream-wait on the collective: e1 - e0 = exposed all-reduce time
                 self.dp_wait_events.append((e0, e1))
             grad_scale = 1.0 / self.world
+        decay, kw = self.ema_decay, {}
+        if self.ema_decay > 0:
+            if self.ema_num_updates is not None:
+                self.ema_num_updates += 1
+                decay = min(decay, (1 + self.ema_num_updates) / (10 + self.ema_num_updates))
+            if self.ema_feedback or self.ema_param_multiplier != 1.0:
+                kw = dict(ema_feedback=self.ema_feedback, param_multiplier=self.ema_param_multiplier)
         ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
                            max_norm=self.max_grad_norm, ema=net.arena_ema if self.ema_decay > 0 else None,
-                           ema_decay=self.ema_decay, grad_scale=grad_scale, norm_out=self.grad_norm)
+                           ema_decay=decay, grad_scale=grad_scale, norm_out=self.grad_norm, **kw)
         net.refresh_shadows(ops)
         return self.loss
 

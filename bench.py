@@ -125,7 +125,7 @@ def bench_unet(args, dev):
             graph = {"images_per_s": B * args.steps / dt_g, "ms_per_step": 1e3 * dt_g / args.steps}
             if dt_g < dt:
                 dt, per, loss, mode = dt_g, per_g, loss_g, "hipGraph replay (forward + loss + backward), optimizer eager"
-        except Exception as ex:
+        except torch.OutOfMemoryError as ex:  # the only tolerated failure of this leg (second memory pool); anything else is a bug: raise
             graph = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     recs = []
     ops._gemm_hook = lambda e0, e1, flops, shapes: recs.append((e0, e1, flops))
@@ -333,6 +333,79 @@ def gpu_comparator(dev, rank, steps=3):
             "clip_grad_norm_, torch AdamW; no gradient checkpointing)", "per_gpu_batch": 1, "steps": steps, "ms_per_step": 1e3 * dt / steps}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a cold shell: one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, the same contract torch.distributed.run provides), rendezvous on 127.0.0.1.  Only rank 0 prints the JSON line; the
+    children's stderr passes through.  Returns the exit code (first failing rank's, 0 when all succeed)."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        sys.stderr.write(f"bench.py --gpus {n}: {have} GPU(s) visible on this host, {n} needed\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            code = pr.wait()
+            if code != 0 and rc == 0:
+                rc = code
+                for other in procs:  # a dead rank leaves the others blocked in a collective: stop exactly the children we started
+                    if other.poll() is None:
+                        other.terminate()
+    except KeyboardInterrupt:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        rc = 130
+    return rc
+
+
+def parity_leg(dev):
+    """`parity` block of the JSON line (N = 1): one step of a small FLUX (2 double + 3 single blocks, 3 heads of 128, 96 image + 40 text
+    tokens, B = 2, LoRA r16) on the HIP path against the oracle on identical weights / inputs, measured in this run — the oracle is the
+    CHECKER here (fp32 = truth, ref16 = the reference's arithmetic: bf16 modules + fp32 adapter), never the thing timed.  The
+    full-size numbers (19+38 blocks @1024^2, SDXL, SD1.5, Wan config 4, fp8 r32) come from `pytest -m gpu` (tests/test_gpu_parity_r*.py)."""
+    import math
+
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import train_ref
+    from tests.test_gpu_e2e import _batch, _build
+
+    def rel(a, b):
+        num = sum(((x.float() - y.float()) ** 2).sum().item() for x, y in zip(a, b))
+        return math.sqrt(num / max(sum((y.float() ** 2).sum().item() for y in b), 1e-300))
+
+    ref, ref_net, nat, net = _build(rank=16, dev=str(dev))
+    lat, emb, pooled, noise, ts = _batch(2, dev=str(dev))
+    kw = dict(lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    l32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = [p.grad.clone() for p in oracle.params]
+    ref.to(torch.bfloat16)
+    l16 = oracle.step(lat, emb, pooled, noise, ts, dtype=torch.bfloat16).item()
+    g16 = [p.grad.clone() for p in oracle.params]
+    lo = FluxLoRATrainStep(nat, net, ops, **kw).step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    go = []
+    for m in net.unet_loras:
+        go += [m.lora_down.weight.grad, m.lora_up.weight.grad]
+    return {"config": "FLUX 2+3 blocks, 3x128 heads, 96 img + 40 txt tokens, B=2, LoRA r16 (same seeds / weights / inputs on every path)",
+            "tolerance": "north_star: 1e-3 relative on the bf16 loss and on LoRA deltas",
+            "loss_rel": abs(lo - l32) / abs(l32), "grad_rel": rel(go, g32), "ref16_floor": rel(g16, g32),
+            "ref16_loss_rel": abs(l16 - l32) / abs(l32), "grad_rel_vs_ref16": rel(go, g16),
+            "note": "grad_rel = adapter-gradient error of the HIP path vs the fp32 oracle (relative Frobenius over all 2 x adapters "
+                    "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,11 +427,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: spawn the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus} (or unset WORLD_SIZE to self-launch)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -389,6 +464,10 @@ def main():
             bt = torch.tensor([B], device=dev, dtype=torch.int64)
             torch.distributed.all_reduce(bt, op=torch.distributed.ReduceOp.MIN)
             B = int(bt.item())
+        batch_note = (f"auto: {avail_gib:.0f} GiB available on rank {rank}, {need} GiB needed for per-GPU batch 7" +
+                      ("" if B == 7 else " -> per-GPU batch 4 (the B = 7 rate needs a GPU with nothing else resident)"))
+    else:
+        batch_note = "--batch / AITK_BENCH_BATCH"
     lat, emb, pooled = make_batch(dev, B, seed=42 + rank)
 
     def one():
@@ -403,10 +482,13 @@ def main():
         one()
     step.collect_dp_timing = world > 1 or pg is not None
     dt, per_step_ms, loss = timed_steps(one, args.steps, barrier)
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
+        tr = torch.zeros(world, device=dev, dtype=torch.float64)
+        tr[rank] = dt
+        torch.distributed.all_reduce(tr, op=torch.distributed.ReduceOp.SUM)  # every rank's own wall time for the K steps
+        per_rank_ms = [1e3 * x / args.steps for x in tr.tolist()]
+        dt = max(tr.tolist())  # the job is as slow as its slowest rank
     final_loss = float(loss.item())
     ips = world * B * args.steps / dt
     workload = (f"FLUX.1-dev DiT {args.network.upper() if args.network != 'lora' else 'LoRA'} r{args.rank}, 1024x1024 (4096 img + 512 txt "
@@ -420,12 +502,16 @@ def main():
         "config": {"workload": workload,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
                    "lora_params": net.arena_p.numel(), "grad_checkpointing": False,
-                   "adapter_precision": "fp32 master + split bf16 (hi+lo) shadows on MFMA"},
+                   "adapter_precision": "fp32 master + split bf16 (hi+lo) shadows on MFMA", "batch_choice": batch_note},
         "final_loss": final_loss,
         "step_ms": {"median": _pct(per_step_ms, 0.5), "p10": _pct(per_step_ms, 0.1), "p90": _pct(per_step_ms, 0.9), "n": len(per_step_ms),
                     "note": "GPU time between step boundaries (events on the launch stream), rank 0"},
         "step_mfma_frac": FLOP_PER_IMAGE * (ips / world) / (PEAK_BF16 * 1e12),
     }
+    if pg is not None:
+        out["rccl"] = {"ranks": torch.distributed.get_world_size(pg), "backend": torch.distributed.get_backend(pg),
+                       "allreduce_bytes_per_step": 4 * net.arena_g.numel(), "pieces": 2,
+                       "ms_per_step_by_rank": per_rank_ms}
     if step.collect_dp_timing and step.dp_wait_events:
         waits = [a.elapsed_time(b) for a, b in step.dp_wait_events]
         out["allreduce_ms_exposed"] = {"median": _pct(waits, 0.5), "p90": _pct(waits, 0.9), "n": len(waits),
@@ -439,6 +525,7 @@ def main():
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
 
     extras = world == 1 and not args.no_extras and not args.fp8_base and args.network == "lora"
+    failed_legs = []
     if extras:
         # ---- batch sweep (single bucket): the headline B plus 1 and 4 (SURVEY.md §8d asked for B in {1, 2, 4})
         del lat, emb, pooled
@@ -468,8 +555,9 @@ def main():
             step._graphs.clear()
             step._graph_pool = None
             del l2, e2, p2, fn
-        except Exception as ex:  # never cost the headline line
+        except torch.OutOfMemoryError as ex:  # memory edge of the second pool only; any other exception is a bug and propagates
             out["graph_replay"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            failed_legs.append("graph_replay")
         # ---- bucketed run (BASELINE.json configs[2] "1024x1024 buckets"): the five resolutions of BASELINE.md §2 cycled so the
         # sequence length changes every step (toolkit/config_modules.py:1095-1113, toolkit/data_loader.py:718, 749-756)
         torch.cuda.empty_cache()
@@ -512,8 +600,9 @@ def main():
                                        "cached_latents_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s"),
                                        "note": "FLUX.1 VAE encoder (1024x1024 -> 16x128x128, one image per launch sequence) + train step"}
             del enc, imgs, e2, p2, fn_vae
-        except Exception as ex:  # never cost the headline line
+        except torch.OutOfMemoryError as ex:  # memory edge only; any other exception is a bug and propagates
             out["uncached_latents"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            failed_legs.append("uncached_latents")
     if rank == 0:
         if rf is not None:
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
@@ -546,8 +635,12 @@ def main():
         torch.cuda.empty_cache()
         try:
             out["gpu_comparator"] = gpu_comparator(dev, args.rank)
-        except Exception as ex:  # the comparator must never cost the headline line
+        except torch.OutOfMemoryError as ex:  # memory edge only (the eager path needs ~78 GiB); any other exception propagates
             out["gpu_comparator"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+            failed_legs.append("gpu_comparator")
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["parity"] = parity_leg(dev)
         gc.collect()
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -555,6 +648,8 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if failed_legs:
+        out["legs_out_of_memory"] = failed_legs
     if rank == 0:
         print(json.dumps(out), flush=True)
 

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 3 /* 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 4 /* 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs split-slab rank blocks > 16, aitk_resize_bilinear_nhwc; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -273,7 +273,12 @@ typedef struct AitkMseArgs {
   aitk_bf16* dpred; float* partial; float* loss_per_sample; float* loss;
   int64_t n_per_sample; int32_t B, feat;
   const float* mask;
+  int32_t loss_type; /* AITK_LOSS_MSE / _MAE / _PSEUDO_HUBER: train.loss_type (extensions_built_in/sd_trainer/SDTrainer.py:903-916) */
+  float huber_c;     /* pseudo_huber: sqrt(d^2 + c^2) - c; the reference hard-codes c = 0.01; 0 selects that default */
 } AitkMseArgs;
+#define AITK_LOSS_MSE 0          /* (pred - target)^2 */
+#define AITK_LOSS_MAE 1          /* |pred - target| (gradient sign(d), 0 at d = 0 like torch l1_loss) */
+#define AITK_LOSS_PSEUDO_HUBER 2 /* sqrt(d^2 + c^2) - c */
 int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample);
 int aitk_mse_loss_grad(const AitkMseArgs* args, aitk_stream_t stream);
 
@@ -285,6 +290,10 @@ typedef struct AitkAdamWArgs {
   float* norm_partial; float* norm_partial2; float* norm_out;
   int64_t n;
   float lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2_sqrt, max_norm, ema_decay, grad_scale;
+  /* toolkit/ema.py:126-152 options (train.ema_config.use_feedback / param_multiplier), applied to the parameter after the EMA update
+   * in the reference's order: tmp = (1-d)(s - p); s -= tmp; p += ema_feedback * tmp (use_feedback: 10, else 0); p *= param_multiplier
+   * (0 is read as 1).  Only with `ema`. */
+  float ema_feedback, param_multiplier;
 } AitkAdamWArgs;
 int64_t aitk_adamw_workspace_bytes(int64_t n);
 int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);

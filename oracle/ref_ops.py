@@ -322,7 +322,7 @@ def flow_noise_pack(latents, noise, t, noisy, target):
     target.copy_(pack(e - x0).to(target.dtype))
 
 
-def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None):
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None, loss_type="mse", huber_c=0.01):
     """mse(pred.float(), target.float()) [* mask_multiplier] -> mean over (C,H,W) -> * multiplier -> mean over batch
     (SDTrainer.py:916-1013); mask [B, tokens, 4] is the reference's [B,1,h,w] mask in the packed 2x2-patch layout."""
     B = pred.shape[0]
@@ -332,16 +332,24 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=
     if mask is not None:
         feat = pred.shape[-1]
         mk = mask.float().reshape(B, -1, 1, 4).expand(B, n // feat, feat // 4, 4).reshape(B, n)
-    lps = (mk * d * d).mean(1)
-    d = d * mk
+    if loss_type == "mse":
+        el, gr = d * d, 2.0 * d
+    elif loss_type == "mae":  # SDTrainer.py:907-908: l1_loss(reduction="none")
+        el, gr = d.abs(), torch.sign(d)
+    elif loss_type == "pseudo_huber":  # SDTrainer.py:903-906: sqrt(diff^2 + c^2) - c, c = 0.01
+        r = torch.sqrt(d * d + huber_c * huber_c)
+        el, gr = r - huber_c, d / r
+    else:
+        raise ValueError(loss_type)
+    lps = (mk * el).mean(1)
     w = weight.float() if weight is not None else torch.ones(B, device=pred.device)
     loss_per_sample.copy_(lps)
     loss.copy_((lps * w).mean().reshape(1))
-    dpred.copy_((2.0 * d * w[:, None] / (n * B)).reshape(dpred.shape).to(dpred.dtype))
+    dpred.copy_((gr * mk * w[:, None] / (n * B)).reshape(dpred.shape).to(dpred.dtype))
 
 
 def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
-                   grad_scale=1.0, norm_out=None):
+                   grad_scale=1.0, norm_out=None, ema_feedback=0.0, param_multiplier=1.0):
     """clip_grad_norm_ + torch.optim.AdamW + EMA (SDTrainer.py:2278-2293, toolkit/optimizer.py:78-79, toolkit/ema.py:116-152)."""
     gs = g * grad_scale
     norm = gs.double().pow(2).sum().sqrt().float()
@@ -357,8 +365,13 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     bc1 = 1 - beta1 ** step
     bc2s = math.sqrt(1 - beta2 ** step)
     p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
-    if ema is not None:
-        ema.sub_((1 - ema_decay) * (ema - p))
+    if ema is not None:  # toolkit/ema.py:135-143
+        tmp = (1 - ema_decay) * (ema - p)
+        ema.sub_(tmp)
+        if ema_feedback:
+            p.add_(tmp * ema_feedback)
+        if param_multiplier != 1.0:
+            p.mul_(param_multiplier)
 
 
 def make_shadow_table(entries, device):

@@ -488,6 +488,33 @@ def golden_optimizer_ema():
     print("optimizer + EMA golden written; grad norms", [round(float(n), 3) for n in norms])
 
 
+def golden_ema_options():
+    """toolkit/ema.py options the trainer passes (jobs/process/BaseSDTrainProcess.py:798-803): use_feedback (the parameter is pulled
+    10 x the EMA step towards the shadow) + param_multiplier, and the class's use_num_updates warm-up — three AdamW steps each, run on
+    the reference's own ExponentialMovingAverage."""
+    from toolkit.ema import ExponentialMovingAverage
+
+    out = {}
+    for tag, kw in (("fb", dict(use_feedback=True, param_multiplier=0.999)), ("nu", dict(use_num_updates=True)), ("pm", dict(param_multiplier=1.002))):
+        g = torch.Generator().manual_seed(43)
+        p = torch.nn.Parameter(torch.randn(4096, generator=g) * 0.1)
+        out[f"{tag}/p0"] = p.detach().clone()
+        opt = torch.optim.AdamW([p], lr=3e-3, eps=1e-6, weight_decay=0.01)
+        ema = ExponentialMovingAverage([p], decay=0.9, **kw)
+        grads = torch.randn(3, 4096, generator=g) * torch.tensor([0.02, 3.0, 0.5])[:, None]
+        for k in range(3):
+            p.grad = grads[k].clone()
+            torch.nn.utils.clip_grad_norm_([p], 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            ema.update()
+        out[f"{tag}/grads"] = grads
+        out[f"{tag}/p3"] = p.detach().clone()
+        out[f"{tag}/ema3"] = ema.shadow_params[0].clone()
+    save_file(out, os.path.join(HERE, "ema_options.safetensors"))
+    print("EMA options golden written")
+
+
 def golden_model_hash():
     """sshs_model_hash / sshs_legacy_hash the reference stamps on saved adapters (toolkit/metadata.py:32-48), computed by its own
     add_model_hash_to_meta on a small and on a > 1 MiB state dict (the legacy hash reads bytes at offset 0x100000)."""
@@ -802,6 +829,11 @@ if __name__ == "__main__":
         for fn in sys.argv[1:]:
             globals()[fn]()
         raise SystemExit(0)
+    if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
+        for name in sys.argv[1:]:
+            globals()[name]()
+        raise SystemExit(0)
+    golden_ema_options()
     golden_unet_lora()
     golden_unet_conv_lora()
     golden_unet_keymap_keys()
