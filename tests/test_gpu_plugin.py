@@ -1,0 +1,123 @@
+"""The drop-in surface itself on the GPU: the reference's trainer would drive the fused graphs exactly like this
+(extensions_built_in/diffusion_models/flux_kontext/flux_kontext.py:243-352, extensions_built_in/sd_trainer/SDTrainer.py:2226-2293):
+
+    optimizer.zero_grad()                                     # 2249
+    with network:
+        pred = sd.get_noise_prediction(...) / sd.predict_noise(...)
+        loss = mse_loss(pred.float(), target.float()).mean(); loss.backward()          # 916-1013, 2238
+    torch.nn.utils.clip_grad_norm_(params, max_grad_norm)     # 2278-2283
+    optimizer.step(); optimizer.zero_grad(set_to_none=True)   # 2285-2288  (torch.optim.AdamW(eps=1e-6), toolkit/optimizer.py:78-79)
+    ema.update()                                              # 2291-2293  (toolkit/ema.py:126-139)
+
+with the HIP kernels behind `pred` (forward) and behind `loss.backward()` (the autograd bridge -> explicit backward graph), torch's own
+optimizer on the arena-view Parameters, and must land where the fused `*LoRATrainStep` lands on the same inputs."""
+import math
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+
+
+def _unpack(t, B, h, w):
+    return t.reshape(B, h // 2, w // 2, 16, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(B, 16, h, w).contiguous()
+
+
+def _torch_trainer_step(net, params, opt, ema, ops, predict, target, max_norm=1.0, decay=0.99):
+    opt.zero_grad()
+    with net:
+        pred = predict()
+        loss = torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3]).mean()
+        loss.backward()
+    grad = net.arena_g.clone()
+    torch.nn.utils.clip_grad_norm_(params, max_norm)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    with torch.no_grad():  # toolkit/ema.py:126-139
+        for s, p in zip(ema, params):
+            s.sub_((s - p) * (1.0 - decay))
+    net.refresh_shadows(ops)  # the weights-changed hook: bf16 shadows follow the fp32 masters
+    return loss.detach(), grad
+
+
+def test_flux_plugin_trainer_loop_equals_fused_train_step():
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.plugin import Flux1MI355Model
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from tests.test_gpu_e2e import _batch, _build
+
+    _, _, nat_a, net_a = _build()
+    _, _, nat_b, net_b = _build()
+    assert torch.equal(net_a.arena_p, net_b.arena_p)
+    plug = Flux1MI355Model("cuda", model=nat_a, dtype=bf)
+    params = net_a.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    assert all(p.is_cuda and p.dtype == torch.float32 for p in params)
+    opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ema = [p.detach().clone() for p in params]
+    fused = FluxLoRATrainStep(nat_b, net_b, ops, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99)
+    for k in range(3):
+        lat, emb, pooled, noise, ts = _batch(2, seed=20 + k)
+        # what process_general_training_batch hands the trainer: noisy latents from the scheduler's add_noise, target = noise - latents
+        # (custom_flowmatch_sampler.py:91-102: fp32 mix, then the latent dtype).  The mix is taken from aitk_flow_noise_pack — un-packed back
+        # to [B,16,H,W] — so both paths see bit-identical inputs: an fp32-ulp difference of a torch mix flips a few bf16 roundings of the
+        # noisy latents, which this random-weight model amplifies to 1e-4 of the loss, hiding what the test is about (the boundary)
+        B_, _, h_, w_ = lat.shape
+        npk = torch.empty(B_, (h_ // 2) * (w_ // 2), 64, dtype=bf, device="cuda")
+        tpk = torch.empty_like(npk)
+        ops.flow_noise_pack(lat, noise, ts.float().contiguous(), npk, tpk)
+        noisy, target = _unpack(npk, B_, h_, w_), _unpack(tpk, B_, h_, w_)
+        t01 = (ts / 1000).view(-1, 1, 1, 1)
+        assert _rel(noisy, ((1 - t01) * lat.float() + t01 * noise.float())) < 3e-3  # = the reference's formula up to the bf16 rounding
+        pe = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled)
+        loss_a, g_a = _torch_trainer_step(net_a, params, opt, ema, ops,
+                                          lambda: plug.get_noise_prediction(noisy, ts, pe, guidance_embedding_scale=1.0), target)
+        loss_b = fused.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        assert abs(loss_a.item() - loss_b.item()) <= 2e-5 * abs(loss_b.item()), (k, loss_a.item(), loss_b.item())
+        # identical kernels behind both paths: gradients agree to the rounding of the loss gradient (torch fp32 -> bf16 vs the mse kernel)
+        assert _rel(g_a, net_b.arena_g) < 2e-3, (k, _rel(g_a, net_b.arena_g))
+        assert _rel(net_a.arena_p, net_b.arena_p) < 2e-3, (k, _rel(net_a.arena_p, net_b.arena_p))
+    ema_a = torch.cat([e.reshape(-1) for e in ema])
+    # arena order = optimizer parameter order for plain LoRA up to the rank padding: compare module by module
+    off = 0
+    for m in net_b.unet_loras:
+        for which, par in (("down", m.lora_down.weight), ("up", m.lora_up.weight)):
+            n = par.numel()
+            want = net_b.arena_view(net_b.arena_ema, m, which)
+            got = ema_a[off:off + n].view_as(want)
+            assert _rel(got, want) < 2e-3, (m.lora_name, which, _rel(got, want))
+            off += n
+    m0 = net_a.unet_loras[0]
+    assert m0.lora_up.weight.grad is None  # set_to_none dropped the views; the next backward re-attaches them
+
+
+@pytest.mark.parametrize("sdxl", [False, True], ids=["sd15", "sdxl"])
+def test_stable_diffusion_wrapper_trainer_loop_equals_fused_train_step(sdxl):
+    from ai_toolkit_amd.plugin import StableDiffusionMI355Model
+    from ai_toolkit_amd.trainer import UNetLoRATrainStep
+    from tests.test_gpu_unet import MID_SD15, MID_SDXL, _batch, _pair
+
+    cfg, ref, ref_net, native, finish, ops = _pair(MID_SDXL if sdxl else MID_SD15, sdxl)
+    nat_a, net_a = finish(*native(ops), ops)
+    nat_b, net_b = finish(*native(ops), ops)
+    sd = StableDiffusionMI355Model("cuda", model=nat_a, dtype=bf, is_xl=sdxl)
+    params = net_a.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ema = [p.detach().clone() for p in params]
+    fused = UNetLoRATrainStep(nat_b, net_b, ops, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _batch(cfg, seed=40 + k)
+        noisy = sd.add_noise(lat, noise, ts)  # toolkit/stable_diffusion_model.py:1854-1876 (latent dtype)
+        target = sd.get_loss_target(noise=noise)
+        pe = SimpleNamespace(text_embeds=ctx, pooled_embeds=pooled)
+        loss_a, g_a = _torch_trainer_step(net_a, params, opt, ema, ops, lambda: sd.predict_noise(noisy, text_embeddings=pe, timestep=ts), target)
+        loss_b = fused.step(lat, ctx, pooled if sdxl else None, noise=noise, timesteps=ts)
+        assert math.isfinite(loss_a.item())
+        assert abs(loss_a.item() - loss_b.item()) <= 1e-3 * abs(loss_b.item()), (k, loss_a.item(), loss_b.item())
+        assert _rel(g_a, net_b.arena_g) < 1e-2, (k, _rel(g_a, net_b.arena_g))
+        assert _rel(net_a.arena_p, net_b.arena_p) < 5e-3, (k, _rel(net_a.arena_p, net_b.arena_p))
