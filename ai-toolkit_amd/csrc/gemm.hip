@@ -445,10 +445,11 @@ extern "C" int aitk_gemm_nt_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b
   rc = gemm_check(b);
   if (rc) return rc;
   const bool same = a->N == b->N && a->K == b->K && a->K2 == b->K2 && a->flags == b->flags;
-  const bool plain = !a->conv_mode && !b->conv_mode && !a->b_scale_mode && !b->b_scale_mode && a->tile_mode == 0 && b->tile_mode == 0 &&
+  const bool w8a8 = a->b_scale_mode == 3 && b->b_scale_mode == 3;
+  const bool plain = !a->conv_mode && !b->conv_mode && ((!a->b_scale_mode && !b->b_scale_mode) || w8a8) && a->tile_mode == 0 && b->tile_mode == 0 &&
                      a->stage_mode == 1 && b->stage_mode == 1;
   const long t256 = (long)((a->M + 255) / 256 + (b->M + 255) / 256) * ((a->N + 255) / 256);
-  if (same && plain && a->N >= 512 && t256 >= big_tiles_min() && aitk_gemm8_try_launch_grouped(a, b, (hipStream_t)stream_) == AITK_OK) {
+  if (same && plain && a->N >= 512 && (w8a8 || t256 >= big_tiles_min()) && aitk_gemm8_try_launch_grouped(a, b, (hipStream_t)stream_) == AITK_OK) {
     AITK_LAUNCH_CHECK();
     return AITK_OK;
   }
@@ -460,6 +461,8 @@ static int gemm_check(const AitkGemmArgs* a) {
   if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0) return AITK_ERR_SHAPE;
   if ((a->K % 8) || (a->K2 % 8) || (a->N % 4)) return AITK_ERR_SHAPE;
   if ((a->lda % 8) || (a->ldb % 8) || (a->ldc % 4)) return AITK_ERR_ALIGN;
+  if (a->b_scale_mode < 0 || a->b_scale_mode > 3) return AITK_ERR_ARG;
+  if (a->b_scale_mode == 3 && (a->conv_mode || (a->K % 16) || (a->lda % 16) || (a->ldb % 16))) return AITK_ERR_ARG;
   if (a->K2 > 0 && (!a->A2 || !a->B2 || (a->lda2 % 8) || (a->ldb2 % 8))) return AITK_ERR_ARG;
   if ((a->flags & (AITK_EPI_BIAS | AITK_EPI_BIAS_ROW)) && !a->bias) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_ADD_AUX) && !a->aux_in) return AITK_ERR_ARG;
@@ -503,6 +506,11 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     return AITK_OK;
   }
   AitkGemmArgs tmp = *a;
+  if (a->b_scale_mode == 3) {  // W8A8 on the MX-scaled fp8 MFMA: the persistent 8-phase kernel is the only implementation (no fallback)
+    if (aitk_gemm8_try_launch(a, st) != AITK_OK) return AITK_ERR_SHAPE;
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
   if (a->b_scale_mode) {
     if (!a->b_scale || (a->ldb % 8) || (a->K % 16) || (a->K2 % 16)) return AITK_ERR_ARG;
     static bool f8attr = false;

@@ -60,6 +60,28 @@ __device__ __forceinline__ const bf16_t* seg_row8(const bf16_t* base, long ld, i
   return base + (long)m * ld;
 }
 
+// element offset of row m under the (seg_rows, seg_stride) row map (fp8 operands: elements are bytes)
+__device__ __forceinline__ long seg_off(long ld, int seg_rows, long seg_stride, int m) {
+  if (seg_rows > 0) {
+    int s = m / seg_rows;
+    int w = m - s * seg_rows;
+    return (long)s * seg_stride + (long)w * ld;
+  }
+  return (long)m * ld;
+}
+
+// W8A8 base segment (b_scale_mode 3): both operands are OCP e4m3 bytes and the K-tile is 128 elements = the same 128 B per LDS row as
+// 64 bf16, so staging, LDS layout, swizzle and fragment reads are byte-for-byte those of the bf16 kernel.  One
+// v_mfma_scale_f32_32x32x64_f8f6f4 (unit E8M0 block scales: 0x7f = 2^0) consumes TWO of the bf16 kernel's 16-B fragment reads per
+// operand: lane half h supplies chunks (4s + h) and (4s + 2 + h) of 64-byte contraction step s — the same (lane, byte) -> k map for A
+// and B, which is all the dot product needs.  64 cycles per instruction and SIMD for 2 x 32 x 32 x 64 flop: twice the bf16 rate.
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16_t mfma32_f8(const s16x8_t& a_lo, const s16x8_t& a_hi, const s16x8_t& b_lo, const s16x8_t& b_hi, f32x16_t c) {
+  const v8i_t a = __builtin_bit_cast(v8i_t, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+  const v8i_t b = __builtin_bit_cast(v8i_t, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 __device__ __forceinline__ void unpack8f(uint4 u, float* f) {
   f[0] = bf2f(u.x & 0xffff); f[1] = bf2f(u.x >> 16); f[2] = bf2f(u.y & 0xffff); f[3] = bf2f(u.y >> 16);
   f[4] = bf2f(u.z & 0xffff); f[5] = bf2f(u.z >> 16); f[6] = bf2f(u.w & 0xffff); f[7] = bf2f(u.w >> 16);
@@ -74,8 +96,11 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
 // is problem 0's tiles followed by problem 1's; a workgroup switches operand bases (buffer descriptors, row clamp, slab pointers)
 // when the tile it is STAGING changes problem, and epilogue arguments when the tile it is COMPUTING does.
 static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguous in the kernarg segment");
-template <bool GR>
+template <bool GR, bool F8>
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
+  constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
+  constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
+  constexpr int ESH = F8 ? 0 : 1;    // log2(bytes per base-segment element)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -84,10 +109,10 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   const int nt1 = tiles_m * tiles_n;
   const int tiles_m2 = GR ? (p2.M + BM - 1) / BM : 0;
   const int ntiles = nt1 + tiles_m2 * tiles_n;
-  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk1 = (p.K + KB - 1) / KB;
   const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
   const int nsteps = nk1 + nk2;   // >= 2 (launcher)
-  const int nfast = p.K / BK;     // K-tiles [0, nfast) are full 64-wide tiles of the base segment
+  const int nfast = p.K / KB;     // K-tiles [0, nfast) are full tiles of the base segment
 
   // ---- staging geometry: thread owns physical 16-B chunk pc of LDS rows srow + 64 i (i = 0..3) of A and of B
   // (recomputed from an opaque copy of tid at each use: these are needed once per output tile, and values the compiler
@@ -116,6 +141,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   int m0 = 0, n0 = 0;
   int sM = p.M;   // row count of the problem being STAGED (row clamp of the A operand)
   int sprob = 0;  // ... and its index (slab pointers)
+  int cprob = 0;  // problem of the tile being COMPUTED (epilogue arguments, fp8 operand scales)
   auto tile_origin = [&](int v, int& tm0, int& tn0, int& prob) {
     int lid = xcd_remap(v, ntiles);
     int tmx = tiles_m;
@@ -160,8 +186,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     const int srow = SROW(t_), cc = CC(t_);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      va[i] = ((unsigned)(seg_row8(q->A, q->lda, q->a_seg_rows, q->a_seg_stride, a_row(i, srow)) - q->A) + cc * 8) * 2;
-      vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * 8) * 2;
+      va[i] = ((unsigned)seg_off(q->lda, q->a_seg_rows, q->a_seg_stride, a_row(i, srow)) + cc * CH) << ESH;
+      vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * CH) << ESH;
     }
   };
 
@@ -193,9 +219,9 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     const int t_ = opaque_tid();
     const int srow = SROW(t_), cc = CC(t_);
     const bool second = kt >= nk1;
-    const int k0 = (second ? kt - nk1 : kt) * BK;
+    const int k0 = second ? (kt - nk1) * BK : kt * KB;
     const int Kseg = second ? p.K2 : p.K;
-    const bool kvalid = !dead && (k0 + cc * 8) < Kseg;
+    const bool kvalid = !dead && (k0 + cc * (second ? 8 : CH)) < Kseg;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
       const int i = 2 * half + ii;
@@ -205,7 +231,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       else voff = opnd ? vb[i] : va[i];
       if (!kvalid) voff = OOB;
       if (second) dma(ldst + ii * (NT * 16), voff, make_srd(opnd ? (const void*)qs->B2 : (const void*)qs->A2), (unsigned)k0 * 2);
-      else dma(ldst + ii * (NT * 16), voff, opnd ? srdB : srdA, (unsigned)k0 * 2);
+      else dma(ldst + ii * (NT * 16), voff, opnd ? srdB : srdA, (unsigned)k0 << ESH);
     }
   };
 
@@ -245,25 +271,61 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     }
   };
   // per_ks = fragment reads this phase issued per ks group (3: b+a0+a1, 2: a0+a1, 1: b, 0: none)
-  auto mma_quadrant = [&](int qm, int qn, const s16x8_t (&bf)[4], int per_ks) {
+  // f8: this K-tile belongs to the e4m3 base segment (F8 kernels; the LoRA-slab tiles that follow it are bf16)
+  auto mma_quadrant = [&](int qm, int qn, const s16x8_t (&bf)[4], int per_ks, bool f8 = true) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if (F8 && f8) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (per_ks > 0) wait_lgkm(per_ks * (3 - ks));
-      __builtin_amdgcn_sched_barrier(0);
+      for (int s2 = 0; s2 < 2; ++s2) {
+        __builtin_amdgcn_sched_barrier(0);  // keeps the wait of step 1 behind step 0's matrix instructions
+        if (per_ks > 0) wait_lgkm(per_ks * (2 - 2 * s2));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mm = 0; mm < 2; ++mm) acc[qm * 2 + mm][qn] = mfma32(bf[ks], af[mm][ks], acc[qm * 2 + mm][qn]);
+        for (int mm = 0; mm < 2; ++mm)
+          acc[qm * 2 + mm][qn] = mfma32_f8(bf[2 * s2], bf[2 * s2 + 1], af[mm][2 * s2], af[mm][2 * s2 + 1], acc[qm * 2 + mm][qn]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (per_ks > 0) wait_lgkm(per_ks * (3 - ks));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) acc[qm * 2 + mm][qn] = mfma32(bf[ks], af[mm][ks], acc[qm * 2 + mm][qn]);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  // F8: the e4m3 products carry the quantisation scales of their operands: acc[m][n] *= a_scale[m] * b_scale[n] once the base segment
+  // is complete and before the (unscaled, bf16) LoRA slab accumulates on top.  Lane owns row l31 of each 32-row block, register r
+  // column (r & 3) + 8 (r >> 2) + 4 h.  The loads are ordinary (compiler-counted) global loads: VMEM returns in order, so the waits the
+  // compiler places are exact for them whatever LDS-DMA traffic is older.
+  auto scale_acc = [&]() {
+    KArgsPtr q = kargs(cprob);
+    const float* as = q->a_scale;
+    const float* bs = q->b_scale;
+    float rs[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) rs[mi] = as ? as[min(m0 + wr * 128 + mi * 32 + l31, q->M - 1)] : 1.0f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wc * 64 + ni * 32 + 8 * g + 4 * h;
+        f32x4_t cs = {1.f, 1.f, 1.f, 1.f};
+        if (bs && n < q->N) cs = *reinterpret_cast<const f32x4_t*>(bs + n);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] *= rs[mi] * cs[e];
+      }
   };
 #define VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- first output tile: offsets + the six prologue half-tiles (K-tile 0: A0 B0 B1 A1, K-tile 1: A0 B0)
   int vt = blockIdx.x;
-  int cprob = 0;  // problem of the tile being COMPUTED (epilogue arguments)
   tile_origin(vt, m0, n0, cprob);
   set_offsets(m0, n0, cprob);
   int gk = 0;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
@@ -341,19 +403,21 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       const bool n1 = t1 >= nsteps, n2 = t2 >= nsteps;
       const int k1 = n1 ? t1 - nsteps : t1, k2 = n2 ? t2 - nsteps : t2;
       const int buf1 = (gk + t1) & 1, buf2 = (gk + t2) & 1;
+      const bool f8t = t < nk1;  // base-segment tile (e4m3 in the F8 kernels), else LoRA slab (bf16)
+      if (F8 && t == nk1) scale_acc();
       // phase 0
       read_frags(IC<0>{}, IC<0>{}, &b0f);
       stage_half(k1, buf1, 1, 1, n1 && !has_next);
       VMCNT8();
       BAR();
-      mma_quadrant(0, 0, b0f, 3);
+      mma_quadrant(0, 0, b0f, 3, f8t);
       BAR();
       // phase 1
       read_frags(IC<-1>{}, IC<1>{}, &b1f);
       stage_half(k1, buf1, 0, 1, n1 && !has_next);
       VMCNT8();
       BAR();
-      mma_quadrant(0, 1, b1f, 1);
+      mma_quadrant(0, 1, b1f, 1, f8t);
       BAR();
       // phase 2
       read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
@@ -363,18 +427,19 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       }
       stage_half(k2, buf2, 0, 0, n2 && !has_next);
       BAR();
-      mma_quadrant(1, 1, b1f, 2);
+      mma_quadrant(1, 1, b1f, 2, f8t);
       BAR();
       // phase 3
       stage_half(k2, buf2, 1, 0, n2 && !has_next);
       VMCNT8();
       BAR();
-      mma_quadrant(1, 0, b0f, 0);
+      mma_quadrant(1, 0, b0f, 0, f8t);
       flip();
       BAR();
     }
     if (wr == 0) BAR();  // pair the extra barrier of the second group
     gk += nsteps;
+    if (F8 && nk2 == 0) scale_acc();
 
     // ---------------- epilogue (tile m0, n0; wave block rows wr*128.., cols wc*64..) ----------------
 #ifdef AITK_ABL_NOEPI
@@ -487,15 +552,23 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #undef BAR
 }
 
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) { gemm8_body<false>(p, p); }
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true>(p, p2); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) { gemm8_body<false, false>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false>(p, p2); }
+// W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true>(p, p2); }
 
 // Called by aitk_gemm_nt (gemm.hip) for big bf16 problems.  Returns AITK_OK after launching, or 1 when the shape is
 // outside this kernel's contract (caller falls back to the 2-barrier kernels).
 static int gemm8_contract(const AitkGemmArgs* a) {
-  if (a->conv_mode || a->b_scale_mode) return 1;
+  const bool f8 = a->b_scale_mode == 3;
+  if (a->conv_mode || (a->b_scale_mode && !f8)) return 1;
   if ((a->K % 16) || (a->K2 % 16) || (a->N % 8) || (a->ldc % 8)) return 1;
-  const int nsteps = (a->K + BK - 1) / BK + (a->K2 > 0 ? (a->K2 + BK - 1) / BK : 0);
+  if (f8 && ((a->lda % 16) || (a->ldb % 16) || (a->a_seg_stride % 16) || (((uintptr_t)a->A | (uintptr_t)a->B) & 15) ||
+             (((uintptr_t)a->a_scale | (uintptr_t)a->b_scale) & 15)))
+    return 1;
+  const int kb = f8 ? 128 : BK;
+  const int nsteps = (a->K + kb - 1) / kb + (a->K2 > 0 ? (a->K2 + BK - 1) / BK : 0);
   if (nsteps < 2) return 1;
   if ((a->flags & (AITK_EPI_ADD_AUX | AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && (a->ld_aux_in % 8)) return 1;
   if ((a->flags & AITK_EPI_GELU) && (a->ld_aux_out % 8)) return 1;
@@ -514,6 +587,10 @@ static int gemm8_cus() {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EPI_OFF + 32768) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EPI_OFF + 32768) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EPI_OFF + 32768) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EPI_OFF + 32768) != hipSuccess) {
       n_cu = 0;
       return 0;
@@ -527,18 +604,20 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
-  hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  else hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   return AITK_OK;
 }
 // Two problems with equal N, K, K2 and flags in one persistent launch (aitk_gemm_nt_grouped); 1 = outside the contract.
 extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, hipStream_t st) {
   if (gemm8_contract(a) || gemm8_contract(b)) return 1;
-  if (a->N != b->N || a->K != b->K || a->K2 != b->K2 || a->flags != b->flags) return 1;
+  if (a->N != b->N || a->K != b->K || a->K2 != b->K2 || a->flags != b->flags || a->b_scale_mode != b->b_scale_mode) return 1;
   const int n_cu = gemm8_cus();
   if (!n_cu) return 1;
   const int tn = (a->N + BN - 1) / BN;
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  else hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   return AITK_OK;
 }

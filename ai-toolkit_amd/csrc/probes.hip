@@ -89,6 +89,7 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 19: return (int)sizeof(AitkKronApplyArgs);
     case 20: return (int)sizeof(AitkGroupNormBwdArgs);
     case 21: return (int)sizeof(AitkDdpmNoiseArgs);
+    case 22: return (int)sizeof(AitkQuantRowsArgs);
     default: return -1;
   }
 }

@@ -519,6 +519,63 @@ extern "C" int aitk_dora_bwd(const AitkDoraBwdArgs* a, aitk_stream_t stream) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ per-token fp8 quantisation
+// Q[m][k] = e4m3( x[m][k] * col_mul[k] * (1 / s_m) ),  s_m = max_k |x[m][k] * col_mul[k]| / 448  (>= 2^-126): the A operand of the W8A8
+// GEMM (AitkGemmArgs.b_scale_mode 3).  One wave per row: pass 1 row maximum, pass 2 re-reads the row (L2) and converts with
+// v_cvt_pk_fp8_f32 (OCP e4m3 on gfx950, round-to-nearest-even); 16-B loads, 8-B stores.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(AitkQuantRowsArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  long off;
+  if (p.seg_rows > 0) {
+    const int sgi = m / p.seg_rows;
+    off = (long)sgi * p.seg_stride + (long)(m - sgi * p.seg_rows) * p.ldx;
+  } else {
+    off = (long)m * p.ldx;
+  }
+  const bf16_t* x = p.X + off;
+  const int nch = p.K >> 3;
+  float amax = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + c * 8);
+    float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+    if (p.col_mul) {
+      const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(p.col_mul + c * 8), c1 = *reinterpret_cast<const f32x4_t*>(p.col_mul + c * 8 + 4);
+      f[0] *= c0[0]; f[1] *= c0[1]; f[2] *= c0[2]; f[3] *= c0[3]; f[4] *= c1[0]; f[5] *= c1[1]; f[6] *= c1[2]; f[7] *= c1[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+  }
+  amax = wave_max(amax);
+  const float sc = fmaxf(amax / 448.0f, 1.17549435e-38f);
+  const float inv = 1.0f / sc;
+  if (lane == 0) p.row_scale[m] = sc;
+  uint8_t* q = p.Q + (long)m * p.ldq;
+  for (int c = lane; c < nch; c += 64) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + c * 8);
+    float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+    if (p.col_mul) {
+      const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(p.col_mul + c * 8), c1 = *reinterpret_cast<const f32x4_t*>(p.col_mul + c * 8 + 4);
+      f[0] *= c0[0]; f[1] *= c0[1]; f[2] *= c0[2]; f[3] *= c0[3]; f[4] *= c1[0]; f[5] *= c1[1]; f[6] *= c1[2]; f[7] *= c1[3];
+    }
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, w1, true);
+    *reinterpret_cast<uint2*>(q + c * 8) = make_uint2((unsigned)w0, (unsigned)w1);
+  }
+}
+extern "C" int aitk_quant_rows_fp8(const AitkQuantRowsArgs* a, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->K <= 0 || (a->K % 16)) return AITK_ERR_SHAPE;
+  if (!a->X || !a->Q || !a->row_scale) return AITK_ERR_ARG;
+  if ((a->ldx % 8) || (a->ldq % 16) || (a->seg_stride % 8) || (((uintptr_t)a->X | (uintptr_t)a->Q | (uintptr_t)a->col_mul) & 15)) return AITK_ERR_ALIGN;
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ fp8 weight dequantisation
 // out[r][k] = bf16(e4m3(q[r][k]) * scale) with scale indexed by the row (mode 1: q = W [out,in]) or by the column (mode 2:
 // q = W^T [in,out]) — the value a weight-only-quantised Linear multiplies with (optimum-quanto qfloat8 / torchao

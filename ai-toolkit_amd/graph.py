@@ -108,13 +108,20 @@ class FusedGraphBase(nn.Module):
         return self
 
     @torch.no_grad()
-    def quantize_base_fp8(self, release_bf16=False):
+    def quantize_base_fp8(self, release_bf16=False, mfma=False):
         """Weight-only fp8 (OCP e4m3, per-output-channel scale) for every token-GEMM Linear of the blocks — BASELINE config 5;
         the reference does this with optimum-quanto qfloat8 / torchao Float8WeightOnly (toolkit/util/quantize.py:43-75,
         toolkit/stable_diffusion_model.py:794-801).  Activations and the LoRA adapter stay bf16 / fp32.  Each layer's weight is
         expanded to bf16(fp8 * scale) into a shared scratch right before its GEMM (_dequant): forward from `qweight` [out,in], dgrad
         from `qweight_t` [in,out]; aitk_gemm_nt can also consume the fp8 bytes directly (b_scale, slower).  adaLN / embedder
-        projections (B rows, weight streaming) keep bf16 weights."""
+        projections (B rows, weight streaming) keep bf16 weights.
+
+        mfma=True (opt-in; BASELINE config 5's "CDNA4 fp8 MFMA base"): the token GEMMs run W8A8 on the MX-scaled fp8 matrix instruction
+        (aitk_gemm_nt b_scale_mode 3, twice the bf16 MFMA rate): the activation operand of every base GEMM — x in forward, dY (times the
+        weight's per-channel scale, which runs along the contraction there) in the data gradient — is quantised per token to e4m3 by
+        aitk_quant_rows_fp8 right before its GEMM; the rank-r adapter slab, its operands and every adapter gradient stay bf16 / fp32.
+        This is NOT the reference's arithmetic (its quantisers are weight-only): DESIGN.md states the deviation and the measured parity."""
+        self.fp8_mfma = bool(mfma)
         for lin in self._token_linears():
             quantize_linear_fp8(lin, lin.weight.data)
             lin.weight_t = None
@@ -137,6 +144,22 @@ class FusedGraphBase(nn.Module):
         out = buf[:n].view(q.shape[0], q.shape[1])
         self.ops.dequant_fp8(q, scale, mode, out)
         return out
+
+    fp8_mfma = False
+
+    def _q8(self, x, M, x_seg=None, col_mul=None, tag=None):
+        """(e4m3 bytes [M, K], fp32 row scales [M]) of a GEMM activation operand.  The most recent result is kept: the q / k / v
+        (/ proj_mlp) projections read the same normalised activation back to back, and the two column ranges of a single block's
+        proj_out data gradient the same dY."""
+        key = (id(x), x.data_ptr(), M, x_seg, None if col_mul is None else col_mul.data_ptr(), tag)
+        last = self.__dict__.get("_q8_last")
+        if last is not None and last[0] == key:
+            return last[2], last[3]
+        q = torch.empty(M, x.shape[1], dtype=torch.uint8, device=x.device)
+        rs = torch.empty(M, dtype=torch.float32, device=x.device)
+        self.ops.quant_rows_fp8(x, q, rs, col_mul=col_mul, x_seg=x_seg, M=M)
+        self._q8_last = (key, x, q, rs)  # holds x: its id cannot be re-used while the entry lives
+        return q, rs
 
     def dequantized_weight(self, lin):
         return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)
@@ -273,6 +296,12 @@ class FusedGraphBase(nn.Module):
                 lo.y_lin = aux_out if (flags & (EPI_GELU | EPI_GATE_RES)) else out
         else:
             T = None
+        if lin.qweight is not None and self.fp8_mfma:  # W8A8 on the MX-scaled fp8 MFMA: x quantised per token, e4m3 weight codes as they are
+            assert "col_scale" not in kw
+            xq, xs = self._q8(x, M, x_seg=a_seg)
+            ops.gemm_nt(xq, lin.qweight, out, bias=lin.bias, flags=flags, aux_out=aux_out, aux_in=aux_in, gate=gate, gate_rows=gate_rows,
+                        c_seg=c_seg, M=M, a_scale=xs, b_scale=lin.wscale, b_scale_mode=3, **kw)
+            return T
         w = lin.weight if lin.qweight is None else self._dequant(lin.qweight, lin.wscale, 1)
         if "col_scale" in kw and (flags & EPI_ADD_AUX):
             # DoRA needs the bare linear output for d magnitude and the residual-add epilogue does not store it: product first,
@@ -423,6 +452,12 @@ class FusedGraphBase(nn.Module):
                 self.ops.gemm_nt(extra, shT, dx, flags=flags & EPI_ACCUM, c_seg=dx_seg, M=M)
                 flags |= EPI_ACCUM
             kw = dict(a2=dT, b2=shT)
+        if lin.qweight is not None and self.fp8_mfma:
+            # dX = dY W contracts over the output channels: the weight's per-channel scale multiplies dY before the per-token quantisation
+            qt = lin.qweight_t if w_rows is None else lin.qweight_t[w_rows[0]:w_rows[1]]
+            dyq, dys = self._q8(dy, M, col_mul=lin.wscale, tag=id(lin))
+            self.ops.gemm_nt(dyq, qt, dx, flags=flags, aux_in=aux_in, c_seg=dx_seg, M=M, a_scale=dys, b_scale=None, b_scale_mode=3, **kw)
+            return
         if lin.qweight is not None:  # rows of W^T = input columns; scale runs along the contraction (out) axis
             qt = lin.qweight_t if w_rows is None else lin.qweight_t[w_rows[0]:w_rows[1]]
             wt = self._dequant(qt, lin.wscale, 2)

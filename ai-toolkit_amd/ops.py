@@ -106,16 +106,27 @@ def _row_major(t, name):
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None,
             gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0,
-            col_scale=None):
+            col_scale=None, a_scale=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T + bias).
+    b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA): a AND b are e4m3 bytes, out = epi(a_scale[m] b_scale[n] (a b^T) + a2 b2^T + bias);
+    a_scale fp32 [M] comes from quant_rows_fp8, b_scale fp32 [N] (or None = 1) is the weight's per-channel scale.
 
     a_seg / c_seg = (seg_rows, seg_stride_elems): logical row m lives at base + (m // seg_rows) * seg_stride
     + (m % seg_rows) * ld (used for the image/text halves of joint attention buffers); then `a`/`out` is the 2-D
     view of the FIRST segment and M must be given.
     """
     g = _capi.GemmArgs()
-    g.lda = _row_major(a, "a")
-    if b_scale is not None:  # weight-only fp8 base: b is uint8/float8 bytes [N, K]
+    if b_scale_mode == 3:
+        assert a.element_size() == 1 and b.element_size() == 1 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+        assert a_scale is not None and a_scale.dtype == torch.float32 and a_scale.is_contiguous() and a_seg is None
+        assert b_scale is None or (b_scale.dtype == torch.float32 and b_scale.is_contiguous() and b_scale.numel() == b.shape[0])
+        g.lda, g.ldb = a.stride(0), b.stride(0)
+        g.a_scale, g.b_scale, g.b_scale_mode = _ptr(a_scale), _ptr(b_scale), 3
+    else:
+        g.lda = _row_major(a, "a")
+    if b_scale_mode == 3:
+        pass
+    elif b_scale is not None:  # weight-only fp8 base: b is uint8/float8 bytes [N, K]
         assert b.element_size() == 1 and b.dim() == 2 and b.stride(1) == 1 and b_scale.dtype == torch.float32 and b_scale_mode in (1, 2)
         g.ldb = b.stride(0)
         g.b_scale, g.b_scale_mode = _ptr(b_scale), b_scale_mode
@@ -183,6 +194,27 @@ def workspace(nbytes, device, tag="ws"):
 
 def rows_per_block():
     return _capi.lib().aitk_rows_per_block()
+
+
+def quant_rows_fp8(x, q, row_scale, *, col_mul=None, x_seg=None, M=None):
+    """q[M,K] (uint8 = OCP e4m3 bytes) = e4m3(x * col_mul / row_scale[:, None]), row_scale[m] = max_k |x col_mul| / 448 — the per-token
+    dynamic quantisation of a W8A8 GEMM's activation operand (gemm_nt b_scale_mode 3)."""
+    a = _capi.QuantRowsArgs()
+    a.ldx = _row_major(x, "x")
+    K = x.shape[1]
+    if M is None:
+        M = x.shape[0]
+    assert q.dtype == torch.uint8 and q.shape[1] == K and q.stride(1) == 1 and q.shape[0] >= M
+    assert row_scale.dtype == torch.float32 and row_scale.is_contiguous() and row_scale.numel() >= M
+    a.X, a.Q, a.row_scale, a.ldq = _ptr(x), _ptr(q), _ptr(row_scale), q.stride(0)
+    if x_seg is not None:
+        a.seg_rows, a.seg_stride = x_seg
+    if col_mul is not None:
+        assert col_mul.dtype == torch.float32 and col_mul.is_contiguous() and col_mul.numel() == K
+        a.col_mul = _ptr(col_mul)
+    a.M, a.K = M, K
+    _call("aitk_quant_rows_fp8", C.byref(a))
+    return q, row_scale
 
 
 def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=None, M=None, p_lo=None, split=0, tmask=None,

@@ -22,9 +22,10 @@ import torch  # noqa: E402
 
 FLOP_PER_IMAGE = 163.6e12  # fwd 74.4 + bwd 89.2 TFLOP, no recompute, LoRA/embedders excluded
 PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
+PEAK_FP8 = 5000.0  # TFLOP/s dense fp8 MFMA (MX-scaled K = 64 / 128 forms; measured ceiling 4.65 PF, MI355X_MICROARCH.md)
 
 
-def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False, network_type="lora"):
+def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False, network_type="lora", fp8_mfma=False):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -51,7 +52,7 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=Fa
     net.refresh_shadows(ops)
     model.attach_network(net)
     if fp8_base:  # BASELINE config 5: e4m3 weight-only base (per-output-channel scale) + bf16/fp32 adapter
-        model.quantize_base_fp8(release_bf16=True)
+        model.quantize_base_fp8(release_bf16=True, mfma=fp8_mfma)  # mfma: W8A8 on the MX-scaled fp8 MFMA (per-token e4m3 activations)
     model.prepare()
     return model, net, ops
 
@@ -416,6 +417,8 @@ def main():
                          "N=3072 GEMMs 5.9 tile rounds on 256 CUs instead of 3.4 at batch 4), else 4 (157 GiB)")
     ap.add_argument("--rank", type=int, default=16)
     ap.add_argument("--fp8-base", action="store_true", help="BASELINE config 5 variant (not the headline metric): fp8 e4m3 base weights")
+    ap.add_argument("--fp8-mfma", action="store_true", help="with --fp8-base (implied): run the base GEMMs W8A8 on the MX-scaled fp8 MFMA "
+                    "(v_mfma_scale_f32_32x32x64_f8f6f4; activations quantised per token to e4m3) instead of expanding the weights to bf16")
     ap.add_argument("--network", default="lora", choices=["lora", "dora", "lokr"], help="adapter type (headline metric: lora)")
     ap.add_argument("--model", default="flux", choices=["flux", "sdxl", "sd15"], help="flux = the headline metric; sdxl / sd15 = the UNet path "
                     "(BASELINE configs 2 / 1 architectures), single GPU")
@@ -426,6 +429,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
+    if args.fp8_mfma:
+        args.fp8_base = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: spawn the N ranks ourselves
@@ -451,7 +456,7 @@ def main():
 
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
 
-    model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base, network_type=args.network)
+    model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base, network_type=args.network, fp8_mfma=args.fp8_mfma)
     step = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99,
                              timestep_type="linear", process_group=pg, seed=1000 + rank)
     B = args.batch
@@ -492,13 +497,17 @@ def main():
     final_loss = float(loss.item())
     ips = world * B * args.steps / dt
     workload = (f"FLUX.1-dev DiT {args.network.upper() if args.network != 'lora' else 'LoRA'} r{args.rank}, 1024x1024 (4096 img + 512 txt "
-                "tokens), bf16" + (" activations over a weight-only fp8 e4m3 base" if args.fp8_base else "") + ", AdamW+EMA, clip 1.0")
+                "tokens), bf16" + (" activations, W8A8 base GEMMs on the MX-scaled fp8 MFMA (per-token e4m3 activations x per-channel e4m3 weights), "
+                                   "bf16 / fp32 adapter" if args.fp8_mfma else " activations over a weight-only fp8 e4m3 base" if args.fp8_base else "")
+                + ", AdamW+EMA, clip 1.0")
     out = {
-        "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 weight-only base)" if args.fp8_base else "")
+        "metric": f"train images/sec, FLUX.1-dev LoRA r{args.rank} @1024^2" + (" (fp8 e4m3 base, W8A8 fp8 MFMA)" if args.fp8_mfma else
+                                                                                 " (fp8 e4m3 weight-only base)" if args.fp8_base else "")
                   + (f" [adapter: {args.network}]" if args.network != "lora" else ""),
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16", "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
+        "dtype": ("fp8 e4m3 x e4m3 base GEMMs (fp32 accumulate) + bf16 everything else" if args.fp8_mfma else
+                  "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16"), "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
         "config": {"workload": workload,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
                    "lora_params": net.arena_p.numel(), "grad_checkpointing": False,
@@ -611,7 +620,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt / aitk_gemm_nt_grouped: gemm_nt_8phase_kernel, gemm_nt_8phase_grouped_kernel "
                                                          "(image+text stream of the double blocks in one launch), gemm_nt_kernel<1,128,128> "
                                                          "(LoRA-fused bf16 GEMM, all launches of one step)",
-                               "achieved": rf["tflops"], "peak": PEAK_BF16, "unit": "TFLOP/s", "frac": rf["tflops"] / PEAK_BF16,
+                               "achieved": rf["tflops"], "peak": PEAK_FP8 if args.fp8_mfma else PEAK_BF16, "unit": "TFLOP/s",
+                               "frac": rf["tflops"] / (PEAK_FP8 if args.fp8_mfma else PEAK_BF16),
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +

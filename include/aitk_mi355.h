@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 4 /* 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs split-slab rank blocks > 16, aitk_resize_bilinear_nhwc; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 4 /* 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -76,7 +76,27 @@ typedef struct AitkGemmArgs {
    * bf16(fp8 * scale) on the way into LDS.  1: scale[n] per B row (forward); 2: scale[k] per contraction index (dgrad on W^T). */
   const float* b_scale; int32_t b_scale_mode; int32_t _pad4;
   const float* col_scale; /* fp32 [N], AITK_EPI_COL_SCALE */
+  /* b_scale_mode 3 — W8A8 on the MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales; BASELINE config 5's "CDNA4 fp8
+   * MFMA base"): A AND B point to OCP e4m3 bytes ([M, K] / [N, K], lda / ldb / a_seg_stride in bytes, multiples of 16),
+   *   C = epi( a_scale[m] * b_scale[n] * (A B^T)  +  A2 B2^T  + bias ),   a_scale fp32 [M] / b_scale fp32 [N] (NULL = 1),
+   * i.e. per-token dynamic activation quantisation (aitk_quant_rows_fp8) against per-output-channel weight scales; the rank-r LoRA slab
+   * A2 B2^T stays bf16 (split hi + lo) and is added un-scaled.  Persistent 8-phase kernel only (any M, N % 8 == 0, K % 16 == 0). */
+  const float* a_scale;
 } AitkGemmArgs;
+
+/* Per-token (per-row) dynamic fp8 quantisation of a GEMM A operand for b_scale_mode 3:
+ *   Q[m][k] = e4m3(X[m][k] * col_mul[k] / row_scale[m]),  row_scale[m] = max_k |X[m][k] * col_mul[k]| / 448.
+ * X rows follow the (seg_rows, seg_stride) row map of AitkGemmArgs.A.  col_mul (optional, fp32 [K]) folds a scale that runs along the
+ * contraction axis into the operand: the data gradient dX = dY W contracts over the OUTPUT channels, whose per-channel weight scale
+ * (toolkit/util/quantize.py:43-75 quantises per output channel) therefore multiplies dY before it is quantised. */
+typedef struct AitkQuantRowsArgs {
+  const aitk_bf16* X; int64_t ldx; int32_t seg_rows; int32_t _pad0; int64_t seg_stride;
+  const float* col_mul;
+  uint8_t* Q; int64_t ldq;
+  float* row_scale;
+  int32_t M, K;
+} AitkQuantRowsArgs;
+int aitk_quant_rows_fp8(const AitkQuantRowsArgs* args, aitk_stream_t stream);
 
 int aitk_abi_version(void);
 int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */

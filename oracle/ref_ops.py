@@ -41,12 +41,35 @@ def rows_per_block():
     return 16
 
 
+def quant_rows_fp8(x, q, row_scale, *, col_mul=None, x_seg=None, M=None):
+    """Per-token dynamic e4m3 quantisation (the A operand of the W8A8 GEMM, b_scale_mode 3): row_scale = amax / 448 (IEEE division),
+    q = e4m3(x * col_mul * (1 / row_scale)), round-to-nearest-even — the standard per-token activation recipe of fp8 training stacks;
+    the reference itself has no activation quantisation (toolkit/util/quantize.py:43-75 is weight-only), see DESIGN.md."""
+    if M is None:
+        M = x.shape[0]
+    v = _seg_view(x, x_seg, M).float()
+    if col_mul is not None:
+        v = v * col_mul.float()[None, :]
+    sc = (v.abs().amax(dim=1) / torch.full((M,), 448.0, device=v.device)).clamp_min(1.17549435e-38)
+    inv = torch.ones_like(sc) / sc
+    q[:M].copy_((v * inv[:, None]).to(torch.float8_e4m3fn).view(torch.uint8))
+    row_scale[:M].copy_(sc)
+    return q, row_scale
+
+
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0, col_scale=None):
+            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0, col_scale=None, a_scale=None):
     """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342).  b_scale: weight-only fp8 base,
     dequantised as (fp8 * scale) rounded to the activation dtype (quanto / torchao weight-only semantics)."""
     if M is None:
         M = a.shape[0]
+    act_dt = torch.bfloat16 if b_scale_mode == 3 else a.dtype  # type the branch output y of GATE_RES is rounded to
+    if b_scale_mode == 3:  # W8A8: exact products of e4m3 values accumulated in fp32, scaled by the operands' quantisation scales
+        A = a[:M].view(torch.float8_e4m3fn).float() * a_scale[:M, None]
+        Bq = b.view(torch.float8_e4m3fn).float()
+        if b_scale is not None:
+            Bq = Bq * b_scale[:, None]
+        a, b, b_scale = A, Bq, None
     A = _seg_view(a, a_seg, M).float()
     if b_scale is not None:
         bq = b.view(torch.float8_e4m3fn).float()
@@ -72,7 +95,7 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
             F.gelu(u, approximate="tanh").sum().backward()
         v = v * u.grad
     if flags & EPI_GATE_RES:
-        y = v.to(a.dtype)  # the branch output is rounded to the activation type; `out` (the residual stream) may be fp32 (precision="high")
+        y = v.to(act_dt)  # the branch output is rounded to the activation type; `out` (the residual stream) may be fp32 (precision="high")
         if aux_out is not None:
             aux_out[:M].copy_(y)
         g = gate.float().repeat_interleave(gate_rows, 0)[:M]
