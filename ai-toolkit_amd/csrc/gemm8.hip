@@ -468,27 +468,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
           const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(q->col_scale + n), c1 = *reinterpret_cast<const f32x4_t*>(q->col_scale + n + 4);
           cs8[0] = c0[0]; cs8[1] = c0[1]; cs8[2] = c0[2]; cs8[3] = c0[3]; cs8[4] = c1[0]; cs8[5] = c1[1]; cs8[6] = c1[2]; cs8[7] = c1[3];
         }
-        // Epilogue operands that come from memory (residual / aux_in, C for ACCUM, gate) are fetched for a HALF of this wave's rows
-        // (2 blocks x 2 row groups = 4 chunks of 16 B each) before the patch round trips that consume them: the loads of a half are in
-        // flight together instead of one exposed L2 / HBM latency per 16-row group (GATE_RES on K = 3072 tiles: 845 -> see profiles/r03).
-        const bool pf_aux = (flags & (AITK_EPI_ADD_AUX | AITK_EPI_DGELU | AITK_EPI_GATE_RES)) != 0;
-        const bool pf_gate = (flags & AITK_EPI_GATE_RES) != 0;
-        const bool pf_c = (flags & AITK_EPI_ACCUM) != 0 && !pf_gate;  // second slot: gate OR old C (both at once: C is read in place)
-        uint4 pre_aux[4], pre_b[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          if ((mi & 1) == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int m = m0 + wr * 128 + (mi + (k >> 1)) * 32 + (k & 1) * 16 + rr;
-              pre_aux[k] = pre_b[k] = make_uint4(0u, 0u, 0u, 0u);
-              if (m < q->M && ncol) {
-                if (pf_aux) pre_aux[k] = *reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n);
-                if (pf_c) pre_b[k] = *reinterpret_cast<const uint4*>(seg_row8(q->C, q->ldc, q->c_seg_rows, q->c_seg_stride, m) + n);
-                if (pf_gate) pre_b[k] = *reinterpret_cast<const uint4*>(q->gate + (long)(m / q->gate_rows) * q->ld_gate + n);
-              }
-            }
-          }
           // acc block -> wave-private patch [32 rows][32 fp32], 16-B chunk (2g+h) swizzled by row&7
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -518,16 +499,15 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += br;
               }
-              const int pk = (mi & 1) * 2 + it;  // this row group's slot in the prefetched operands
               if (flags & AITK_EPI_ADD_AUX) {
                 float a8[8];
-                unpack8f(pre_aux[pk], a8);
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), a8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += a8[e];
               }
               if (flags & AITK_EPI_ACCUM) {
                 float c8[8];
-                unpack8f(pf_c ? pre_b[pk] : *reinterpret_cast<const uint4*>(crow), c8);
+                unpack8f(*reinterpret_cast<const uint4*>(crow), c8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += c8[e];
               }
@@ -539,7 +519,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               }
               if (flags & AITK_EPI_DGELU) {
                 float u8[8];
-                unpack8f(pre_aux[pk], u8);
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), u8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad_f(u8[e]);
               }
@@ -547,8 +527,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
                 // y = bf16(linear out) saved when asked (d_gate needs it); x_new = res + gate[b] * y
                 if (q->aux_out) *reinterpret_cast<uint4*>(q->aux_out + (long)m * q->ld_aux_out + n) = pack8f(v);
                 float r8[8], g8[8];
-                unpack8f(pre_aux[pk], r8);
-                unpack8f(pre_b[pk], g8);
+                unpack8f(*reinterpret_cast<const uint4*>(q->aux_in + (long)m * q->ld_aux_in + n), r8);
+                unpack8f(*reinterpret_cast<const uint4*>(q->gate + (long)(m / q->gate_rows) * q->ld_gate + n), g8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = r8[e] + g8[e] * bfround(v[e]);
               }
