@@ -245,6 +245,7 @@ def lib():
     L.aitk_softmax_rows.argtypes = [vp, i64, i32, i32, C.c_float, vp]
     L.aitk_kron_merge.argtypes = [vp, i64, vp, vp, i32, i32, i32, i32, C.c_float, vp]
     L.aitk_image_to_nhwc8.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.aitk_image_resize_to_nhwc8.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.aitk_latent_sample.argtypes = [vp, i64, vp, vp, i32, i32, i32, C.c_float, C.c_float, vp]
     L.aitk_latent_sample_affine.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp, vp, vp]
     L.aitk_rmsnorm_rows.argtypes = [vp, i64, vp, i64, vp, i64, i32, C.c_float, i32, vp]

@@ -94,9 +94,6 @@ struct TileStager {
 // fragment loads into flat loads that wait on vmcnt and drain the LDS-DMA prefetch.
 typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ s16x8_t frag_rm_sw(const lds_char* tile, int row0, int k0, int lane) {
-#ifdef AITK_ABL_NOLDS  /* timing-only: no LDS instruction, a lane-dependent constant instead */
-  { s16x8_t f_; for (int e_ = 0; e_ < 8; ++e_) f_[e_] = (short)(lane + e_); return f_; }
-#endif
   const int row = row0 + (lane & 31);
   const int c = (k0 >> 3) + (lane >> 5);
   return *reinterpret_cast<const __attribute__((address_space(3))) s16x8_t*>(tile + row * 256 + ((c ^ (row & 15)) << 4));
@@ -143,17 +140,11 @@ __device__ __forceinline__ void glds_tile(lds_char* tile, const bf16_t* base, lo
 #define SUBP 2176
 #define SUBTILE_BYTES (8 * SUBP)
 __device__ __forceinline__ s16x8_t frag_rm_st(const lds_char* tile, int row0, int k0, int lane) {
-#ifdef AITK_ABL_NOLDS  /* timing-only: no LDS instruction, a lane-dependent constant instead */
-  { s16x8_t f_; for (int e_ = 0; e_ < 8; ++e_) f_[e_] = (short)(lane + e_); return f_; }
-#endif
   const int r = row0 + (lane & 31);
   const int c = (k0 >> 3) + (lane >> 5);
   return *reinterpret_cast<const __attribute__((address_space(3))) s16x8_t*>(tile + (c >> 1) * SUBP + r * 32 + (((c & 1) ^ ((r >> 3) & 1)) << 4));
 }
 __device__ __forceinline__ s16x8_t frag_tr_perm_st(const lds_char* tile, int kb, int col0, int lane) {
-#ifdef AITK_ABL_NOLDS  /* timing-only: no LDS instruction, a lane-dependent constant instead */
-  { s16x8_t f_; for (int e_ = 0; e_ < 8; ++e_) f_[e_] = (short)(lane + e_); return f_; }
-#endif
   const int h = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15;
   const int row = kb + 4 * h + (i >> 2);
   const int sub = (col0 >> 4) + gq;
@@ -199,10 +190,6 @@ __device__ __forceinline__ void frag_tr_perm_st_issue(s16x4_t& lo, s16x4_t& hi, 
   tr16_issue(hi, base + row2 * 32 + ((lh ^ ((row2 >> 3) & 1)) << 4));
 }
 template <int OFF>
-__device__ __forceinline__ void lds_read128_abl(s16x8_t& out, unsigned addr) {  // ablation builds only
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(out) : "v"(addr & ~15u), "n"(OFF & ~15));
-}
-template <int OFF>
 __device__ __forceinline__ void tr16_issue_off(s16x4_t& out, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(out) : "v"(addr), "n"(OFF));
 }
@@ -211,20 +198,6 @@ __device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& h
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// TIMING-ONLY ablation (tools/build_abl_attn.py -> libaitk_abl_attn_b128.so, never the product library): -DAITK_ABL_ATTN_B128 replaces the
-// transposing 8-byte LDS reads (ds_read_b64_tr_b16, two per fragment) of the PV / dQ / dK-dV operands by ONE ds_read_b128 of the same
-// tile — numerically meaningless, same bytes, same MFMA count — to measure how much of the attention time is the rate of the 8-byte
-// transpose reads (MI355X_MICROARCH.md §LDS: b128 reaches the LDS rate from one wave per SIMD, 8-byte reads need ~4).
-#ifdef AITK_ABL_NOEXP  /* the softmax exponentials replaced by their (finite) argument: VALU transcendental share */
-#define ABL_EXP2(x) (x)
-#else
-#define ABL_EXP2(x) __builtin_amdgcn_exp2f(x)
-#endif
-#ifdef AITK_ABL_ATTN_B128
-#define ABL_TR(tile, kb, col0, lane) frag_rm_st(tile, (kb) & 32, (col0), lane)
-#else
-#define ABL_TR(tile, kb, col0, lane) frag_tr_perm_st(tile, kb, col0, lane)
-#endif
 
 // ============================================================================================ forward
 // grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
@@ -323,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = ABL_EXP2(fmaf(s[j][r], c2, -m_run));
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[j][r], c2, -m_run));
         s[j][r] = e;
         ps += e;
       }
@@ -332,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
     for (int kk = 0; kk < 4; ++kk) {
       const s16x8_t pf = pack_acc8(s[kk >> 1], 8 * (kk & 1));
 #pragma unroll
-      for (int d = 0; d < DB; ++d) o[d] = mfma32(ABL_TR(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
+      for (int d = 0; d < DB; ++d) o[d] = mfma32(frag_tr_perm_st(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
     }
     __syncthreads();
   }
@@ -467,9 +440,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
           // inline asm pins the register classes: S / dP accumulate in arch VGPRs (the softmax VALU reads them), the
           // loop-invariant K / V fragments sit in AccVGPRs.  Left to the allocator (389 registers, 1 wave per SIMD) S / dP
           // land in AccVGPRs time-shared with dK: 128 v_accvgpr_read/write per iteration.
-#ifdef AITK_ABL_NOMFMA
-          asm volatile("" : "+v"(s), "+v"(dp) : "v"(qa[ks]), "v"(da[ks]), "a"(kf[4 * hk + ks]), "a"(vf[4 * hk + ks]));
-#else
           if (hk == 0 && ks == 0) {  // first product of the chain: C = 0 (no zero-fill of the 32 accumulator registers)
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(s) : "v"(qa[ks]), "a"(kf[0]));
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(dp) : "v"(da[ks]), "a"(vf[0]));
@@ -477,7 +447,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(da[ks]), "a"(vf[4 * hk + ks]));
           }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -491,26 +460,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
         const int hq = lane >> 5, gq = (lane >> 4) & 1, i = lane & 15, lh = (i & 3) >> 1;
         const unsigned tlo = (unsigned)(size_t)qtc + gq * SUBP + (i & 1) * 8 + (4 * hq + (i >> 2)) * 32 + (lh << 4);
         const unsigned thi = tlo + 8 * 32 + ((lh ^ 1) - lh) * 16;
-#if defined(AITK_ABL_NOLDS)
-#define TRQ(KK, D)                                                                                     \
-  if constexpr (D < DB) {                                                                              \
-    dlo[4 * KK + D] = s16x4_t{(short)lane, 1, 2, 3};                                                   \
-    dhi[4 * KK + D] = s16x4_t{(short)lane, 2, 3, 4};                                                   \
-    qlo[4 * KK + D] = s16x4_t{(short)lane, 3, 4, 5};                                                   \
-    qhi[4 * KK + D] = s16x4_t{(short)lane, 4, 5, 6};                                                   \
-  }
-#elif defined(AITK_ABL_ATTN_B128)
-#define TRQ(KK, D)                                                                                     \
-  if constexpr (D < DB) {                                                                              \
-    s16x8_t fa_, fb_;                                                                                  \
-    lds_read128_abl<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(fa_, tlo);                          \
-    lds_read128_abl<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(fb_, tlo);                               \
-    dlo[4 * KK + D] = __builtin_shufflevector(fa_, fa_, 0, 1, 2, 3);                                   \
-    dhi[4 * KK + D] = __builtin_shufflevector(fa_, fa_, 4, 5, 6, 7);                                   \
-    qlo[4 * KK + D] = __builtin_shufflevector(fb_, fb_, 0, 1, 2, 3);                                   \
-    qhi[4 * KK + D] = __builtin_shufflevector(fb_, fb_, 4, 5, 6, 7);                                   \
-  }
-#else
 #define TRQ(KK, D)                                                                                     \
   if constexpr (D < DB) {                                                                              \
     tr16_issue_off<ST + (32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(dlo[4 * KK + D], tlo);               \
@@ -518,7 +467,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
     tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qlo[4 * KK + D], tlo);                    \
     tr16_issue_off<(32 * SUBI + 16 * KK) * 32 + 2 * D * SUBP>(qhi[4 * KK + D], thi);                    \
   }
-#endif
 #define TRQ8() TRQ(0, 0) TRQ(0, 1) TRQ(0, 2) TRQ(0, 3) TRQ(1, 0) TRQ(1, 1) TRQ(1, 2) TRQ(1, 3)
         if (sub == 0) {
 #define SUBI 0
@@ -542,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pr = ABL_EXP2(fmaf(s[r], c2, -ls[e]));
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[e]));
           s[r] = pr;
           dp[r] = pr * (dp[r] - ds[e]);
         }
@@ -731,7 +679,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
         dv[d] = mfma32(pf[(PAR) ^ 1][kk], join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);                           \
       else                                                                                                               \
         dk[d] = mfma32(df[(PAR) ^ 1][kk], join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);                           \
-      const float pr = ABL_EXP2(fmaf(s[r], c2, -ls[r]));                                                                 \
+      const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -ls[r]));                                                                 \
       float dd = dp[r] - ds[r];                                                                                          \
       DKDV_OPAQUE(dd);                                                                                                   \
       dd *= pr;                                                                                                          \
@@ -871,13 +819,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (2 * hh + u >= KS) continue;
-#if defined(AITK_ABL_NOLDS)
-            kfr[u] = frag_rm_st(ktc, 32 * j, 16 * (2 * hh + u), lane);
-            vfr[u] = frag_rm_st(vtc, 32 * j, 16 * (2 * hh + u), lane);
-#else
             kfr[u] = *reinterpret_cast<lds_v8>(k_rm + (2 * hh + u) * SUBP + 32 * j * 32);
             vfr[u] = *reinterpret_cast<lds_v8>(v_rm + (2 * hh + u) * SUBP + 32 * j * 32);
-#endif
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -894,8 +837,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
                                              // (profiles/r02_notes_attention_ablation.md); backward 4.29 -> 4.12 ms same-box at B = 4
             f32x2_t a = {s[r], s[r + 1]};
             a = __builtin_elementwise_fma(a, c2v, lv);
-            a[0] = ABL_EXP2(a[0]);
-            a[1] = ABL_EXP2(a[1]);
+            a[0] = __builtin_amdgcn_exp2f(a[0]);
+            a[1] = __builtin_amdgcn_exp2f(a[1]);
             if (tail) {
               if (t * 64 + 32 * j + crow(r, h) >= Skv) a[0] = 0.f;
               if (t * 64 + 32 * j + crow(r + 1, h) >= Skv) a[1] = 0.f;
@@ -911,15 +854,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
           const s16x8_t df = pack_acc8(dp, 8 * kk);
 #pragma unroll
           for (int d = 0; d < DB; ++d) {
-#if defined(AITK_ABL_NOLDS) || defined(AITK_ABL_ATTN_B128)
-            dq[d] = mfma32(ABL_TR(ktc, 32 * j + 16 * kk, 32 * d, lane), df, dq[d]);
-#else
             // rows kb + 4h + (i>>2) (+8) of column block 2d + gq: kb = 32j + 16kk is a multiple of 16, so the first read sits in a row
             // with bit 3 clear (lane part ln_tr_lo), the second 8 rows further (ln_tr_hi)
             const s16x4_t lo = tr16l(k_lo + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
             const s16x4_t hi = tr16l(k_hi + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
             dq[d] = mfma32(join_lohi(lo, hi), df, dq[d]);
-#endif
           }
         }
       }

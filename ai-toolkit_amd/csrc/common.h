@@ -45,10 +45,6 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 // D[i][j] += sum_k A[i][k] * B[k][j]; lane l supplies A[i=l&31][k=8*(l>>5)..+8] and B[k=8*(l>>5)..+8][j=l&31];
 // lane l receives D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31] in register r (guide: cdna_hip_programming.md §3).
 __device__ __forceinline__ f32x16_t mfma32(s16x8_t a, s16x8_t b, f32x16_t c) {
-#ifdef AITK_ABL_NOMFMA  /* timing-only ablation builds (tools/build_abl_attn.py): operands stay live, no matrix instruction is issued */
-  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-#endif
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 // 16x16x32: lane l supplies A[i=l&15][k=8*(l>>4)..+8], B[k=8*(l>>4)..+8][j=l&15]; receives D[i=4*(l>>4)+r][j=l&15].

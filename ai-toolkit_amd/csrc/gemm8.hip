@@ -397,14 +397,14 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       BAR();
     }
     bool switched = false;  // offsets already describe the NEXT output tile
-    for (; t < nsteps; ++t) {
+    // one tail iteration; f8_c: this K-tile belongs to the e4m3 base segment (compile-time so each loop below carries ONE matrix form)
+    auto tail_iter = [&](int t, auto f8_c) {
+      constexpr bool f8t = decltype(f8_c)::value != 0;
       // K-tiles t+1 / t+2 past this output tile are K-tiles 0 / 1 of the next one (or dead)
       const int t1 = t + 1, t2 = t + 2;
       const bool n1 = t1 >= nsteps, n2 = t2 >= nsteps;
       const int k1 = n1 ? t1 - nsteps : t1, k2 = n2 ? t2 - nsteps : t2;
       const int buf1 = (gk + t1) & 1, buf2 = (gk + t2) & 1;
-      const bool f8t = t < nk1;  // base-segment tile (e4m3 in the F8 kernels), else LoRA slab (bf16)
-      if (F8 && t == nk1) scale_acc();
       // phase 0
       read_frags(IC<0>{}, IC<0>{}, &b0f);
       stage_half(k1, buf1, 1, 1, n1 && !has_next);
@@ -436,15 +436,20 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       mma_quadrant(1, 0, b0f, 0, f8t);
       flip();
       BAR();
+    };
+    if constexpr (F8) {
+      const int nbase = min(nk1, nsteps);
+      for (; t < nbase; ++t) tail_iter(t, IC<1>{});
+      if (nk2 > 0) scale_acc();  // base segment complete: the bf16 slab accumulates on top of the scaled products
+      for (; t < nsteps; ++t) tail_iter(t, IC<0>{});
+    } else {
+      for (; t < nsteps; ++t) tail_iter(t, IC<0>{});
     }
     if (wr == 0) BAR();  // pair the extra barrier of the second group
     gk += nsteps;
     if (F8 && nk2 == 0) scale_acc();
 
     // ---------------- epilogue (tile m0, n0; wave block rows wr*128.., cols wc*64..) ----------------
-#ifdef AITK_ABL_NOEPI
-    if (p.K == 7)
-#endif
     {
       KArgsPtr q = kargs(cprob);
       const int flags = q->flags;

@@ -187,6 +187,44 @@ extern "C" int aitk_image_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, 
   return AITK_OK;
 }
 
+// ---------------------------------------------------------------- bilinear resize + NHWC conversion (Wan21.encode_images resizes inputs whose
+// sides are not multiples of 8 with F.interpolate(mode="bilinear", align_corners=False) in the VAE dtype, toolkit/models/wan21/wan21.py:652-657):
+// src = (in / out) * (dst + 0.5) - 0.5 clamped at 0, neighbours i0 = floor(src), i1 = min(i0 + 1, in - 1), weights in fp32 on the
+// bf16-rounded pixels, summed as  h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)  like ATen's upsample_bilinear2d kernel.
+__global__ void image_resize_to_nhwc8_kernel(const float* img, bf16_t* out, int B, int Hs, int Ws, int Hd, int Wd, float sh, float sw) {
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Hd * Wd;
+  if (pix >= total) return;
+  const int x = (int)(pix % Wd);
+  const int y = (int)((pix / Wd) % Hd);
+  const int b = (int)(pix / ((long)Wd * Hd));
+  const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+  const float h1 = fy - (float)y0, w1 = fx - (float)x0;
+  const float h0 = 1.0f - h1, w0 = 1.0f - w1;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* pl = img + ((long)b * 3 + c) * Hs * Ws;
+    const float v00 = bfround(pl[(long)y0 * Ws + x0]), v01 = bfround(pl[(long)y0 * Ws + x1]);
+    const float v10 = bfround(pl[(long)y1 * Ws + x0]), v11 = bfround(pl[(long)y1 * Ws + x1]);
+    v[c] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+  }
+  *reinterpret_cast<uint4*>(out + pix * 8) = pack8v(v);
+}
+extern "C" int aitk_image_resize_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd,
+                                          aitk_stream_t stream) {
+  if (!img || !out || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return AITK_ERR_SHAPE;
+  const long total = (long)B * Hd * Wd;
+  hipLaunchKernelGGL(image_resize_to_nhwc8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, Hs, Ws,
+                     Hd, Wd, (float)Hs / (float)Hd, (float)Ws / (float)Wd);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 // ---------------------------------------------------------------- latent sample: moments NHWC [B*hw, 2L] -> latents NCHW [B, L, h, w]
 // z = mean + exp(0.5 clamp(logvar,-30,20)) * eps ; out = scale * (z - shift)     (eps NCHW fp32, like randn_tensor(mean.shape))
 __global__ void latent_sample_kernel(const bf16_t* mom, long ldm, const float* eps, bf16_t* out, int B, int L, int hw,

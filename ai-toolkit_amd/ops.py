@@ -664,6 +664,14 @@ def image_to_nhwc8(img, out):
     return out
 
 
+def image_resize_to_nhwc8(img, out, *, Hd, Wd):
+    """bilinear (align_corners=False) resize of [B,3,Hs,Ws] fp32 images to [Hd, Wd], written as NHWC rows with 8 channels (bf16)."""
+    B, Cc, Hs, Ws = img.shape
+    assert Cc == 3 and img.dtype == torch.float32 and img.is_contiguous() and out.shape == (B * Hd * Wd, 8)
+    _call("aitk_image_resize_to_nhwc8", _ptr(img), _ptr(out), B, Hs, Ws, Hd, Wd)
+    return out
+
+
 def latent_sample(moments, eps, out, *, scale, shift):
     B, L, h, w = out.shape
     assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.shape == out.shape and out.is_contiguous()

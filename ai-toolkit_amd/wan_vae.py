@@ -192,13 +192,17 @@ class AutoencoderKLWanEncoder(nn.Module):
         if not self._prepared:
             self.prepare()
         ops, enc = self.ops, self.encoder
-        T, _, H, W = clip.shape
-        if H % 8 or W % 8:
-            raise NotImplementedError("Wan VAE encode: H and W must be multiples of 8 (the reference resizes bilinearly, wan21.py:652-657)")
+        T, _, Hs, Ws = clip.shape
+        H, W = Hs // 8 * 8, Ws // 8 * 8  # sides that are not multiples of 8 are resized bilinearly, every frame (wan21.py:652-657)
+        if H == 0 or W == 0:
+            raise ValueError(f"Wan VAE encode: image side below 8 pixels ({Hs}x{Ws})")
         T = 1 + 4 * ((T - 1) // 4)
         HW = H * W
         x8, x8_body = self._padded(T, HW, 8)
-        ops.image_to_nhwc8(clip[:T].float().contiguous(), x8_body)
+        if (H, W) != (Hs, Ws):
+            ops.image_resize_to_nhwc8(clip[:T].float().contiguous(), x8_body, Hd=H, Wd=W)
+        else:
+            ops.image_to_nhwc8(clip[:T].float().contiguous(), x8_body)
         x = self._new(T * HW, enc.conv_in.weight.shape[0])
         ops.conv3d(x8, enc.conv_in.wk, x, T=T, H=H, W=W, bias=enc.conv_in.bias)
         for blk in enc.down_blocks:

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 4 /* 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 4 /* 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -359,6 +359,9 @@ int aitk_groupnorm(const AitkGroupNormArgs* args, aitk_stream_t stream);
 int aitk_softmax_rows(aitk_bf16* x, int64_t ld, int32_t rows, int32_t n, float scale, aitk_stream_t stream);
 /* image [B,3,H,W] fp32 -> NHWC bf16 with channels padded to 8 (conv_in operand) */
 int aitk_image_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t H, int32_t W, aitk_stream_t stream);
+/* The same conversion behind a bilinear resize [Hs, Ws] -> [Hd, Wd] (align_corners = False, no antialiasing; pixels rounded to bf16 first, weights
+ * in fp32): Wan21.encode_images' F.interpolate of inputs whose sides are not multiples of 8 (toolkit/models/wan21/wan21.py:652-657). */
+int aitk_image_resize_to_nhwc8(const float* img, aitk_bf16* out, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd, int32_t Wd, aitk_stream_t stream);
 /* DiagonalGaussianDistribution.sample() + scaling_factor * (z - shift_factor): moments NHWC [B*hw, >=2L] -> NCHW [B,L,h,w]
  * (toolkit/stable_diffusion_model.py:2567-2573) */
 int aitk_latent_sample(const aitk_bf16* moments, int64_t ldm, const float* eps, aitk_bf16* out, int32_t B, int32_t L, int32_t hw,

@@ -654,6 +654,15 @@ def image_to_nhwc8(img, out):
     return out
 
 
+def image_resize_to_nhwc8(img, out, *, Hd, Wd):
+    """toolkit/models/wan21/wan21.py:652-657: F.interpolate(images.to(vae dtype), size, mode='bilinear', align_corners=False)."""
+    B = img.shape[0]
+    r = F.interpolate(img.to(out.dtype), size=(Hd, Wd), mode="bilinear", align_corners=False)
+    out.zero_()
+    out.view(B, Hd, Wd, 8)[..., :3].copy_(r.permute(0, 2, 3, 1))
+    return out
+
+
 def latent_sample(moments, eps, out, *, scale, shift):
     """DiagonalGaussianDistribution.sample + scaling (toolkit/stable_diffusion_model.py:2567-2573)."""
     B, L, h, w = out.shape

@@ -208,6 +208,11 @@ class AutoencoderKLWanEncoder(nn.Module):
             else:
                 raise ValueError(f"Invalid image shape: {im.shape}")
         images = torch.stack(norm)
+        B, C, T, H, W = images.shape
+        if H % 8 != 0 or W % 8 != 0:  # wan21.py:652-657
+            images = images.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+            images = torch.nn.functional.interpolate(images, size=(H // 8 * 8, W // 8 * 8), mode="bilinear", align_corners=False)
+            images = images.view(B, T, C, H // 8 * 8, W // 8 * 8).permute(0, 2, 1, 3, 4)
         mom = self.moments(images)
         mean, logvar = mom.chunk(2, dim=1)
         std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))

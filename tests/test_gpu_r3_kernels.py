@@ -46,3 +46,23 @@ def test_ema_option_kernel_vs_reference_class_golden(tag, kw):
                            step=k + 1, max_norm=1.0, ema=ema, ema_decay=0.9, **kw)
     assert torch.allclose(p.cpu(), t[f"{tag}/p3"], rtol=2e-5, atol=2e-7), (p.cpu() - t[f"{tag}/p3"]).abs().max()
     assert torch.allclose(ema.cpu(), t[f"{tag}/ema3"], rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("B,Hs,Ws", [(2, 37, 52), (1, 515, 509), (3, 64, 71)])
+def test_bilinear_resize_to_nhwc8_kernel_vs_torch_interpolate(B, Hs, Ws):
+    """aitk_image_resize_to_nhwc8 against F.interpolate(bilinear, align_corners=False) in bf16 on the same GPU (what Wan21.encode_images runs,
+    toolkit/models/wan21/wan21.py:652-657): equal to one bf16 rounding of the result."""
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    g = torch.Generator().manual_seed(Hs)
+    img = (torch.rand(B, 3, Hs, Ws, generator=g) * 2 - 1).cuda()
+    Hd, Wd = Hs // 8 * 8, Ws // 8 * 8
+    a = torch.full((B * Hd * Wd, 8), 7.0, dtype=torch.bfloat16, device="cuda")
+    b = torch.empty_like(a)
+    ops.image_resize_to_nhwc8(img, a, Hd=Hd, Wd=Wd)
+    ref_ops.image_resize_to_nhwc8(img, b, Hd=Hd, Wd=Wd)
+    assert float(a[:, 3:].abs().max()) == 0.0
+    d = (a.float() - b.float()).abs()
+    assert d.max().item() <= 2 ** -7, d.max().item()         # values in [-1, 1]: at most one bf16 ulp of the largest magnitude
+    assert (d > 0).float().mean().item() < 0.02              # and almost everywhere identical

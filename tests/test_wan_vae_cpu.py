@@ -59,10 +59,25 @@ def test_encode_images_matches_the_reference_lines():
     assert torch.allclose(nat.encode_images(ims, eps=e1), ref.encode_images(ims, e1), rtol=1e-4, atol=1e-5)
 
 
+def test_sides_that_are_not_multiples_of_8_are_resized_bilinearly_like_the_reference():
+    """Wan21.encode_images (wan21.py:652-657): H, W -> H // 8 * 8, W // 8 * 8 with F.interpolate(bilinear, align_corners=False) on every frame."""
+    ref, nat = build(seed=5)
+    g = torch.Generator().manual_seed(9)
+    clips = [torch.rand(5, 3, 37, 52, generator=g) * 2 - 1 for _ in range(2)]
+    eps = torch.randn(2, 4, 2, 4, 6, generator=g)
+    want = ref.encode_images(clips, eps)
+    got = nat.encode_images(clips, eps=eps)
+    assert got.shape == want.shape == (2, 4, 2, 4, 6)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+    img = [torch.rand(3, 45, 33, generator=g) * 2 - 1]
+    e1 = torch.randn(1, 4, 1, 5, 4, generator=g)
+    assert torch.allclose(nat.encode_images(img, eps=e1), ref.encode_images(img, e1), rtol=1e-4, atol=1e-5)
+
+
 def test_argument_errors_and_published_config():
     _, nat = build()
-    with pytest.raises(NotImplementedError):
-        nat.moments(torch.zeros(1, 3, 30, 32))
+    with pytest.raises(ValueError):
+        nat.moments(torch.zeros(1, 3, 6, 32))  # a side below one latent cell
     with pytest.raises(ValueError):
         nat.encode_images([torch.zeros(3, 32)])
     with pytest.raises(ValueError):
