@@ -115,20 +115,42 @@ __device__ __forceinline__ s16x8_t frag_tr_perm_sw(const lds_char* tile, int kb,
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
   return f;
 }
-// LDS-DMA fill of a [ROWS][128] swizzled tile from rows row0.. (clamped to S-1) of a [*, ld] matrix slice.
-template <int ROWS>
-__device__ __forceinline__ void glds_tile(lds_char* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
-  constexpr int NI = ROWS / 4;  // wave-instructions per tile (4 rows = 1 KiB each)
+// ---- LDS-DMA through a raw buffer descriptor (buffer_load_dwordx4 ... lds, as in gemm8.hip): the (batch, head) slice [rows][128] of an
+// operand is one buffer whose num_records ends with its last valid row, so rows >= nrows arrive as ZEROS (a zero K row scores 0 and is
+// masked to -inf by the tail code, a zero Q / dO row meets L2 = +inf -> P = 0) and a piece costs one s_mov m0 + one VALU add + the load
+// itself.  (The flat global_load_lds form needed a 64-bit per-lane address: ~10 VALU per 1-KiB piece, 80 per KV tile of the forward
+// kernel, and the compiler drained vmcnt in front of every LDS read that followed a piece.)  The compiler does not see these loads:
+// every tile is published by an explicit s_waitcnt vmcnt(0) in front of the workgroup barrier.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t slice_srd(const bf16_t* base, long ld, int nrows) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)(((long)(nrows - 1) * ld + 128) * 2));
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const v4i_t& srd) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(srd) : "memory");
+}
+// s_waitcnt vmcnt(0) as the BUILTIN (expcnt / lgkmcnt fields at their no-wait maxima): the waitcnt pass reads it and clears its own scoreboard
+// of outstanding global loads (Q / K / V fragments loaded at kernel entry) — with an asm wait it kept counting them down inside the tile loop
+// (vmcnt(7) .. vmcnt(0) in front of the first MFMAs), i.e. it drained the just-issued pieces of the next tile
+#define DMA_WAIT_ALL() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
+// per-lane byte offsets (relative to the tile's first row) of this wave's four 1-KiB pieces of a [64][128] tile in the swizzled
+// row-major layout: piece ins = wave + 4 ii covers rows 4 ins .. 4 ins + 3, lane -> (row, physical chunk), source chunk = chunk ^ (row & 15)
+__device__ __forceinline__ void rm_voff(unsigned (&v)[4], long ld, int wave, int lane) {
 #pragma unroll
-  for (int ii = 0; ii < NI / 4; ++ii) {
-    const int ins = wave + 4 * ii;
-    const int row = ins * 4 + (lane >> 4);
-    const int pc = lane & 15;
-    const int c = pc ^ (row & 15);
-    const int r = min(row0 + row, S - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)r * ld + c * 8),
-                                     (__attribute__((address_space(3))) void*)(tile + ins * 1024), 16, 0, 0);
+  for (int ii = 0; ii < 4; ++ii) {
+    const int row = (wave + 4 * ii) * 4 + (lane >> 4);
+    v[ii] = (unsigned)((row * ld + (((lane & 15) ^ (row & 15)) << 3)) * 2);
   }
+}
+__device__ __forceinline__ void dma_rm64(lds_char* tile, const unsigned (&v)[4], unsigned tile_off, const v4i_t& srd, int wave) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii)
+    dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)tile + (wave + 4 * ii) * 1024), v[ii] + tile_off, srd);
 }
 
 
@@ -158,16 +180,21 @@ __device__ __forceinline__ s16x8_t frag_tr_perm_st(const lds_char* tile, int kb,
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
   return f;
 }
-__device__ __forceinline__ void glds_subtile64(lds_char* tile, const bf16_t* base, long ld, int row0, int S, int wave, int lane) {
+// sub-tiled 64-row tile: piece ins = wave + 4 ii is column block ins >> 1, row half ins & 1 (32 rows x 32 B)
+__device__ __forceinline__ void st_voff(unsigned (&v)[4], long ld, int wave, int lane) {
 #pragma unroll
   for (int ii = 0; ii < 4; ++ii) {
-    const int ins = wave + 4 * ii;  // 16 wave-instructions: column block = ins>>1, row half = ins&1
-    const int sub = ins >> 1, rh = ins & 1;
-    const int r = rh * 32 + (lane >> 1);
+    const int ins = wave + 4 * ii;
+    const int sub = ins >> 1, r = (ins & 1) * 32 + (lane >> 1);
     const int lh = (lane & 1) ^ ((r >> 3) & 1);
-    const int rr = min(row0 + r, S - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (long)rr * ld + (2 * sub + lh) * 8),
-                                     (__attribute__((address_space(3))) void*)(tile + sub * SUBP + rh * 1024), 16, 0, 0);
+    v[ii] = (unsigned)((r * ld + (2 * sub + lh) * 8) * 2);
+  }
+}
+__device__ __forceinline__ void dma_st64(lds_char* tile, const unsigned (&v)[4], unsigned tile_off, const v4i_t& srd, int wave) {
+#pragma unroll
+  for (int ii = 0; ii < 4; ++ii) {
+    const int ins = wave + 4 * ii;
+    dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)tile + (ins >> 1) * SUBP + (ins & 1) * 1024), v[ii] + tile_off, srd);
   }
 }
 
@@ -237,16 +264,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
 
   const int ntiles = (Skv + 63) / 64;
-  glds_tile<64>(sm, Kb, p.ldk, 0, Skv, wave, lane);
-  glds_subtile64(sm + 16384, Vb, p.ldv, 0, Skv, wave, lane);
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv), srdV = slice_srd(Vb, p.ldv, Skv);
+  unsigned vK[4], vV[4];
+  rm_voff(vK, p.ldk, wave, lane);
+  st_voff(vV, p.ldv, wave, lane);
+  const unsigned stepK = (unsigned)(64 * p.ldk * 2), stepV = (unsigned)(64 * p.ldv * 2);  // bytes per KV tile
+  dma_rm64(sm, vK, 0, srdK, wave);
+  dma_st64(sm + 16384, vV, 0, srdV, wave);
+  DMA_WAIT_ALL();
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const lds_char* ktc = sm + cur * FBUF;
     const lds_char* vtc = ktc + 16384;
     if (t + 1 < ntiles) {
-      glds_tile<64>(sm + (cur ^ 1) * FBUF, Kb, p.ldk, (t + 1) * 64, Skv, wave, lane);
-      glds_subtile64(sm + (cur ^ 1) * FBUF + 16384, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
+      dma_rm64(sm + (cur ^ 1) * FBUF, vK, (t + 1) * stepK, srdK, wave);
+      dma_st64(sm + (cur ^ 1) * FBUF + 16384, vV, (t + 1) * stepV, srdV, wave);
     }
     // LDS fragment reads are issued in groups ahead of the MFMAs that consume them (the compiler otherwise emits
     // read -> lgkmcnt(0) -> mfma one by one and every MFMA eats a full LDS round trip)
@@ -307,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
 #pragma unroll
       for (int d = 0; d < DB; ++d) o[d] = mfma32(frag_tr_perm_st(vtc, 16 * kk, 32 * d, lane), pf, o[d]);
     }
+    DMA_WAIT_ALL();  // the next tile has landed (this wave's pieces) before the barrier publishes it
     __syncthreads();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -400,19 +434,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   // END of the iteration, otherwise their vmcnt wait (in-order counter) would also drain the just-issued LDS-DMA
   // prefetch and make it synchronous.
   float stat = 0.f;
+  const v4i_t srdQ = slice_srd(Qb, p.ldq, S), srdD = slice_srd(dOb, p.lddo, S);
+  unsigned vQ[4], vD[4];
+  st_voff(vQ, p.ldq, wave, lane);
+  st_voff(vD, p.lddo, wave, lane);
+  const unsigned stepQ = (unsigned)(64 * p.ldq * 2), stepD = (unsigned)(64 * p.lddo * 2);
   auto stage_load = [&](int t, int buf) {
     if (tid < 128) {
       const int q = t * 64 + (tid & 63);
       stat = tid < 64 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
     }
-    glds_subtile64(sm + buf * 2 * ST, Qb, p.ldq, t * 64, S, wave, lane);
-    glds_subtile64(sm + buf * 2 * ST + ST, dOb, p.lddo, t * 64, S, wave, lane);
+    dma_st64(sm + buf * 2 * ST, vQ, t * stepQ, srdQ, wave);
+    dma_st64(sm + buf * 2 * ST + ST, vD, t * stepD, srdD, wave);
   };
   auto stage_store = [&](int buf) {
     if (tid < 128) ((lds_float*)(sm + 4 * ST + buf * 512))[tid] = stat;  // [0,64): L2, [64,128): delta
   };
   stage_load(0, 0);
   stage_store(0);
+  DMA_WAIT_ALL();
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
@@ -511,6 +551,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
       }
     }
     if (t + 1 < ntiles) stage_store(cur ^ 1);
+    DMA_WAIT_ALL();
     __syncthreads();
   }
   // D[i = kv][j = d]: lane holds column d = 32*blk + l31 and rows kv = crow(r, h)
@@ -578,6 +619,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntiles = (S + 127) / 128;
   float stat = 0.f;
+  const v4i_t srdQ = slice_srd(Qb, p.ldq, S), srdD = slice_srd(dOb, p.lddo, S);
+  unsigned vQ[4], vD[4];
+  st_voff(vQ, p.ldq, wave, lane);
+  st_voff(vD, p.lddo, wave, lane);
+  const unsigned stepQ = (unsigned)(64 * p.ldq * 2), stepD = (unsigned)(64 * p.lddo * 2);  // bytes per 64-row quarter
   auto stage_load = [&](int t, int buf) {
     {  // statistics: plain global loads issued BEFORE the tile DMAs, stored to LDS at the end of the iteration (see attn_bwd_dkdv_kernel)
       const int q = t * 128 + (tid & 127);
@@ -588,13 +634,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
   // current one (an LDS-DMA piece costs 100-185 cycles among fragment reads, 25-60 in a gap of the matrix stream: backward 4.02 -> 3.96 ms)
   auto stage_quarter = [&](int t, int buf, int q) {
     lds_char* b0 = sm + buf * TB + q * ST;
-    if (q < 2) glds_subtile64(b0, Qb, p.ldq, t * 128 + 64 * q, S, wave, lane);
-    else glds_subtile64(b0, dOb, p.lddo, t * 128 + 64 * (q - 2), S, wave, lane);
+    if (q < 2) dma_st64(b0, vQ, (2 * t + q) * stepQ, srdQ, wave);
+    else dma_st64(b0, vD, (2 * t + q - 2) * stepD, srdD, wave);
   };
   auto stage_store = [&](int buf) { ((lds_float*)(sm + 2 * TB + buf * 1024))[tid] = stat; };  // [0,128): L2, [128,256): delta
   stage_load(0, 0);
   for (int q = 0; q < 4; ++q) stage_quarter(0, 0, q);
   stage_store(0);
+  DMA_WAIT_ALL();
   __syncthreads();
   const int hq = lane >> 5, gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
   f32x16_t s, dp;
@@ -694,11 +741,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
     df[PAR][0] = pack_acc8(dp, 0);                                                                                       \
     df[PAR][1] = pack_acc8(dp, 8);                                                                                       \
   }
-#ifdef AITK_PIPE_NODMA
-#define DKDV_DMA(Q)
-#else
 #define DKDV_DMA(Q) if (r == 9 && more) stage_quarter(t + 1, cur ^ 1, Q);
-#endif
     // across tiles: the last sub-tile's dV / dK products of tile t - 1 (operand set 1, transposed fragments read before that tile's
     // closing barrier) ride under the first softmax of tile t instead of running bare at the end of their own tile
     DKDV_A(0, )
@@ -711,11 +754,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
     DKDV_CB(2, 0, DKDV_DMA(1))
     DKDV_A(3, DKDV_TR(2))
     DKDV_TR_WAIT()
-#ifdef AITK_PIPE_NODMA
-#define DKDV_DMA23
-#else
 #define DKDV_DMA23 if ((r == 4 || r == 12) && more) stage_quarter(t + 1, cur ^ 1, r == 4 ? 2 : 3);
-#endif
     DKDV_CB(3, 1, DKDV_DMA23)
     DKDV_TR(3)
     DKDV_TR_WAIT()   // in registers before the barrier: the next tile's LDS-DMA may overwrite this buffer one tile later
@@ -726,6 +765,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
 #undef DKDV_TR
 #undef DKDV_TR1
     if (t + 1 < ntiles) stage_store(cur ^ 1);
+    DMA_WAIT_ALL();
     __syncthreads();
   }
 #pragma unroll
@@ -793,16 +833,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   const unsigned ln_rm = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) << 4);                                     // frag_rm_st (K and V, sub-tiled)
   const unsigned ln_tr_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);          // frag_tr_perm_st, rows with bit 3 clear
   const unsigned ln_tr_hi = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2) + 8) * 32 + ((lh ^ 1) << 4);  // ... and the rows 8 further
-  glds_subtile64(sm, Kb, p.ldk, 0, Skv, wave, lane);
-  glds_subtile64(sm + SUBTILE_BYTES, Vb, p.ldv, 0, Skv, wave, lane);
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv), srdV = slice_srd(Vb, p.ldv, Skv);
+  unsigned vK[4], vV[4];
+  st_voff(vK, p.ldk, wave, lane);
+  st_voff(vV, p.ldv, wave, lane);
+  const unsigned stepK = (unsigned)(64 * p.ldk * 2), stepV = (unsigned)(64 * p.ldv * 2);
+  dma_st64(sm, vK, 0, srdK, wave);
+  dma_st64(sm + SUBTILE_BYTES, vV, 0, srdV, wave);
+  DMA_WAIT_ALL();
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
     const lds_char* ktc = sm + cur * DBUF;
     const lds_char* vtc = ktc + SUBTILE_BYTES;
     if (t + 1 < ntiles) {
-      glds_subtile64(sm + (cur ^ 1) * DBUF, Kb, p.ldk, (t + 1) * 64, Skv, wave, lane);
-      glds_subtile64(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, Vb, p.ldv, (t + 1) * 64, Skv, wave, lane);
+      dma_st64(sm + (cur ^ 1) * DBUF, vK, (t + 1) * stepK, srdK, wave);
+      dma_st64(sm + (cur ^ 1) * DBUF + SUBTILE_BYTES, vV, (t + 1) * stepV, srdV, wave);
     }
     const lds_char* k_rm = ktc + ln_rm;
     const lds_char* v_rm = vtc + ln_rm;
@@ -863,6 +909,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
         }
       }
     }
+    DMA_WAIT_ALL();
     __syncthreads();
   }
   const int q = q0 + l31;
