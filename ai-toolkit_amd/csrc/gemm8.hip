@@ -299,22 +299,47 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   };
   // F8: the e4m3 products carry the quantisation scales of their operands: acc[m][n] *= a_scale[m] * b_scale[n] once the base segment
   // is complete and before the (unscaled, bf16) LoRA slab accumulates on top.  Lane owns row l31 of each 32-row block, register r
-  // column (r & 3) + 8 (r >> 2) + 4 h.  The loads are ordinary (compiler-counted) global loads: VMEM returns in order, so the waits the
-  // compiler places are exact for them whatever LDS-DMA traffic is older.
-  auto scale_acc = [&]() {
-    KArgsPtr q = kargs(cprob);
+  // column (r & 3) + 8 (r >> 2) + 4 h.  The scales of a tile travel through the wave's private epilogue patch in LDS (idle during the K loop):
+  // fetch_scales() issues the global loads where a vmcnt(0) follows anyway (kernel entry; end of the previous tile's epilogue),
+  // park_scales() stores them to the patch behind that wait, scale_acc() reads them back with LDS latency — the first version loaded
+  // them from global right here and paid one exposed L2 / HBM round trip per output tile (fixed cost 19.9 vs 9.7 us per tile round of the
+  // bf16 kernel, profiles/r03_gemm_ksweep.log).
+  f32x4_t sc_rows = {1.f, 1.f, 1.f, 1.f}, sc_cols = {1.f, 1.f, 1.f, 1.f};
+  auto fetch_scales = [&](int tm0, int tn0, int prob) {
+    KArgsPtr q = kargs(prob);
     const float* as = q->a_scale;
     const float* bs = q->b_scale;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    sc_rows = f32x4_t{1.f, 1.f, 1.f, 1.f};
+    sc_cols = f32x4_t{1.f, 1.f, 1.f, 1.f};
+    if (as && ln < 32) {  // rows tm0 + wr * 128 + 4 ln .. + 3 (a_scale is padded to a multiple of 4 by the contract: M rows rounded up are readable? no: clamp)
+      const int r0 = tm0 + wr * 128 + 4 * ln;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sc_rows[e] = as[min(r0 + e, q->M - 1)];
+    }
+    if (bs && ln < 16) {
+      const int c0 = tn0 + wc * 64 + 4 * ln;
+      if (c0 < q->N) sc_cols = *reinterpret_cast<const f32x4_t*>(bs + c0);
+    }
+  };
+  auto park_scales = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
+    if (ln < 32) *reinterpret_cast<f32x4_t*>(patch + ln * 16) = sc_rows;          // rows 4 ln .. 4 ln + 3 of the wave's 128
+    if (ln < 16) *reinterpret_cast<f32x4_t*>(patch + 512 + ln * 16) = sc_cols;   // columns 4 ln .. of the wave's 64
+  };
+  auto scale_acc = [&]() {
+    const char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
     float rs[4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) rs[mi] = as ? as[min(m0 + wr * 128 + mi * 32 + l31, q->M - 1)] : 1.0f;
+    for (int mi = 0; mi < 4; ++mi) rs[mi] = *reinterpret_cast<const float*>(patch + (mi * 32 + l31) * 4);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wc * 64 + ni * 32 + 8 * g + 4 * h;
-        f32x4_t cs = {1.f, 1.f, 1.f, 1.f};
-        if (bs && n < q->N) cs = *reinterpret_cast<const f32x4_t*>(bs + n);
+        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(patch + 512 + (ni * 8 + 2 * g + h) * 16);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -328,6 +353,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   int vt = blockIdx.x;
   tile_origin(vt, m0, n0, cprob);
   set_offsets(m0, n0, cprob);
+  if constexpr (F8) fetch_scales(m0, n0, cprob);  // ahead of the prologue DMAs: the first VMCNT8 covers them
   int gk = 0;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
   stage_half(0, 0, 0, 0, false);
   stage_half(0, 0, 1, 0, false);
@@ -351,6 +377,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     if (first) VMCNT8();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // prefetched K-tiles + this wave's epilogue traffic
     first = false;
+    if constexpr (F8) park_scales();  // this tile's operand scales (fetched before the wait above) into the wave's idle epilogue patch
     BAR();
     if (wr == 1) BAR();  // second wave of every SIMD runs one barrier behind
     // Steady part: K-tiles t+1, t+2 are full base-segment tiles of THIS output tile — straight-line fast staging, no
@@ -545,6 +572,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       }
     }
     if (!has_next) break;
+    if constexpr (F8) fetch_scales(m0n, n0n, probn);  // the next tile's operand scales ride under the vmcnt(0) at the top of the loop
     vt = vnext;
     m0 = m0n;
     n0 = n0n;
