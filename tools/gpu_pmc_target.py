@@ -21,6 +21,13 @@ bias = torch.randn(N, device=dev).to(bf)
 out = torch.empty(M, N, dtype=bf, device=dev)
 for _ in range(4):
     ops.gemm_nt(a, b, out, bias=bias, a2=a2, b2=b2)
+if os.environ.get("AITK_PMC_F8", "1") != "0":  # W8A8 (MX-scaled fp8 MFMA) GEMM of the same shape + the per-token quantisation that feeds it
+    ws = (b.float().abs().amax(1) / 448.0).contiguous()
+    wq = (b.float() / ws[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    xq, xs = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, device=dev)
+    for _ in range(4):
+        ops.quant_rows_fp8(a, xq, xs)
+        ops.gemm_nt(xq, wq, out, bias=bias, a2=a2, b2=b2, a_scale=xs, b_scale=ws, b_scale_mode=3)
 B, H, S = 1, 24, 4608
 HD = H * 128
 qkv = torch.randn(B * S, 3 * HD, device=dev).to(bf)

@@ -9,7 +9,8 @@ import json
 import os
 import sys
 
-KEEP = ("gemm_nt_8phase_kernel", "attn_fwd_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dq_kernel")
+KEEP = ("gemm_nt_8phase_f8_kernel", "gemm_nt_8phase_kernel", "quant_rows_fp8_kernel", "attn_fwd_kernel", "attn_bwd_dkdv_pipe_kernel", "attn_bwd_dkdv_kernel",
+        "attn_bwd_dq_kernel")
 
 
 def main():
@@ -34,6 +35,17 @@ def main():
             "fetch_bytes_per_launch": g["FETCH_SIZE"] * 1024 * 2, "write_bytes_per_launch": g["WRITE_SIZE"] * 1024,
             "hbm_bytes_per_launch": g["FETCH_SIZE"] * 1024 * 2 + g["WRITE_SIZE"] * 1024,
             "algorithmic_bytes": 2 * (M * (K + K2) + N * (K + K2) + M * N), "source": f"{d} (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"}}
+    f8 = means.get("gemm_nt_8phase_f8_kernel", {})
+    if "FETCH_SIZE" in f8 and "WRITE_SIZE" in f8:
+        N = K = 3072
+        res["gemm_nt_8phase_f8_kernel_by_M"] = {str(M): {
+            "fetch_bytes_per_launch": f8["FETCH_SIZE"] * 1024 * 2, "write_bytes_per_launch": f8["WRITE_SIZE"] * 1024,
+            "hbm_bytes_per_launch": f8["FETCH_SIZE"] * 1024 * 2 + f8["WRITE_SIZE"] * 1024,
+            "algorithmic_bytes": M * K + N * K + 2 * (M * K2 + N * K2 + M * N) + 4 * (M + N), "source": f"{d} (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"}}
+    for k, c in means.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
+            res.setdefault("mfma_busy", {})[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": c["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_BUSY_CYCLES": c["SQ_BUSY_CYCLES"],
+                                                  "ratio": c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"]}
     for k, c in means.items():
         if "SQ_WAVE_CYCLES" in c:
             wc = c["SQ_WAVE_CYCLES"]
