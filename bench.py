@@ -617,19 +617,22 @@ def main():
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
                 with open(os.environ["AITK_GEMM_CENSUS"], "w") as fh:
                     json.dump(rf["census"], fh, indent=0)
-            out["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt / aitk_gemm_nt_grouped: gemm_nt_8phase_kernel, gemm_nt_8phase_grouped_kernel "
-                                                         "(image+text stream of the double blocks in one launch), gemm_nt_kernel<1,128,128> "
-                                                         "(LoRA-fused bf16 GEMM, all launches of one step)",
+            out["roofline"] = {"bound": "mfma", "kernel": ("aitk_gemm_nt / aitk_gemm_nt_grouped: gemm_nt_8phase_f8_kernel, gemm_nt_8phase_f8_grouped_kernel (W8A8 on "
+                                                          "v_mfma_scale_f32_32x32x64_f8f6f4 + bf16 LoRA slab, all launches of one step)" if args.fp8_mfma else
+                                                          "aitk_gemm_nt / aitk_gemm_nt_grouped: gemm_nt_8phase_kernel, gemm_nt_8phase_grouped_kernel "
+                                                          "(image+text stream of the double blocks in one launch), gemm_nt_kernel<1,128,128> "
+                                                          "(LoRA-fused bf16 GEMM, all launches of one step)"),
                                "achieved": rf["tflops"], "peak": PEAK_FP8 if args.fp8_mfma else PEAK_BF16, "unit": "TFLOP/s",
                                "frac": rf["tflops"] / (PEAK_FP8 if args.fp8_mfma else PEAK_BF16),
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) for the dominant shape (B * 4608) x 3072 x 3072 (+ LoRA slab): newest round first
-            for pmc in (os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")):
+            for pmc in (os.path.join(ROOT, "profiles", "r03_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"),
+                        os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")):
                 if not os.path.exists(pmc):
                     continue
-                by_m = json.load(open(pmc)).get("gemm_nt_8phase_kernel_by_M", {})
+                by_m = json.load(open(pmc)).get("gemm_nt_8phase_f8_kernel_by_M" if args.fp8_mfma else "gemm_nt_8phase_kernel_by_M", {})
                 g8 = by_m.get(str(B * 4608))  # the most frequent launch of a step
                 if g8 is not None:
                     out["roofline"]["traffic"] = g8["hbm_bytes_per_launch"]
