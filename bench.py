@@ -334,6 +334,15 @@ def gpu_comparator(dev, rank, steps=3):
             "clip_grad_norm_, torch AdamW; no gradient checkpointing)", "per_gpu_batch": 1, "steps": steps, "ms_per_step": 1e3 * dt / steps}
 
 
+def _flush_c_stdio():
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a cold shell: one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment, the same contract torch.distributed.run provides), rendezvous on 127.0.0.1.  Only rank 0 prints the JSON line; the
@@ -658,12 +667,13 @@ def main():
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if failed_legs:
         out["legs_out_of_memory"] = failed_legs
     if rank == 0:
+        _flush_c_stdio()  # RCCL prints its version banner through C stdio: with stdout redirected to a file it would otherwise land BEHIND the JSON line
         print(json.dumps(out), flush=True)
 
 
