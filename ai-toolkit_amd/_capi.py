@@ -128,7 +128,7 @@ class AttnArgs(C.Structure):
         ("dO", vp), ("lddo", i64),
         ("dQ", vp), ("dK", vp), ("dV", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
         ("delta", vp),
-        ("scale", C.c_float), ("B", i32), ("H", i32), ("S", i32), ("D", i32), ("Skv", i32), ("Dv", i32), ("_r0", i32),
+        ("scale", C.c_float), ("B", i32), ("H", i32), ("S", i32), ("D", i32), ("Skv", i32), ("Dv", i32), ("hstride", i32),
     ]
 
 

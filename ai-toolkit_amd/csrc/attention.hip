@@ -6,7 +6,9 @@
 // and its autograd backward.
 //
 // Layout: Q,K,V,O are [B, S, H, 128] views (row stride ld elements, head h at column h*128) so they can alias the
-// GEMM outputs directly.  LSE is kept in the scaled log2 domain:  L2 = max2 + log2(sum exp2(s2 - max2)),
+// GEMM outputs directly.  Heads of 64 / 96 columns can also be read where the projections wrote them (AitkAttnArgs.hstride = head
+// width: head h at column h*hstride, no padded copies): tiles still fetch 128 columns per row — the surplus is the neighbouring head,
+// never contracted (KS / DB below) — and the buffer descriptor ends each (batch, head) slice at its own last column.  LSE is kept in the scaled log2 domain:  L2 = max2 + log2(sum exp2(s2 - max2)),
 // s2 = (q.k) * softmax_scale * log2(e).
 //
 // Structure (guide Appendix B "Fused attention prefill"): swapped QK^T — each wave computes S^T = K Q^T so a lane owns
@@ -58,35 +60,6 @@ __device__ __forceinline__ f32x16_t zero16() {
 // row index inside a 32-row accumulator block held by (register r, lane half h)
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// stage a [ROWS][128] bf16 tile (rows row0.. of one (b,h) slice) into registers / LDS, zero-filling rows >= S
-template <int ROWS>
-struct TileStager {
-  static constexpr int CH = ROWS * 16 / 256;  // 16-B chunks per thread
-  uint4 reg[CH];
-  __device__ __forceinline__ void load(const bf16_t* base, long ld, int row0, int S, int tid, bool zero_oob) {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int q = tid + 256 * i;
-      const int row = q >> 4, ch = q & 15;
-      int r = row0 + row;
-      const bool oob = r >= S;
-      if (oob) r = S - 1;
-      uint4 v = *reinterpret_cast<const uint4*>(base + (long)r * ld + ch * 8);
-      if (oob && zero_oob) v = make_uint4(0, 0, 0, 0);
-      reg[i] = v;
-    }
-  }
-  __device__ __forceinline__ void store(bf16_t* tile, int pitch, int tid) const {
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      const int q = tid + 256 * i;
-      const int row = q >> 4, ch = q & 15;
-      *reinterpret_cast<uint4*>(tile + row * pitch + ch * 8) = reg[i];
-    }
-  }
-};
-
-
 // ---- swizzled, unpadded tiles: [rows][128] bf16, 256-B rows, physical 16-B chunk = logical chunk ^ (row & 15).
 // Conflict-free for ds_read_b128 fragments and for tr16 reads, and lane-linear so LDS-DMA can fill them
 // (the XOR goes on the global SOURCE address, guide rule 21).
@@ -122,12 +95,12 @@ __device__ __forceinline__ s16x8_t frag_tr_perm_sw(const lds_char* tile, int kb,
 // kernel, and the compiler drained vmcnt in front of every LDS read that followed a piece.)  The compiler does not see these loads:
 // every tile is published by an explicit s_waitcnt vmcnt(0) in front of the workgroup barrier.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4i_t slice_srd(const bf16_t* base, long ld, int nrows) {
+__device__ __forceinline__ v4i_t slice_srd(const bf16_t* base, long ld, int nrows, int width = 128) {
   const unsigned long long a = (unsigned long long)base;
   v4i_t r;
   r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
   r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
-  r.z = __builtin_amdgcn_readfirstlane((int)(((long)(nrows - 1) * ld + 128) * 2));
+  r.z = __builtin_amdgcn_readfirstlane((int)(((long)(nrows - 1) * ld + width) * 2));
   r.w = 0x00020000;
   return r;
 }
@@ -243,12 +216,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;                        // query rows per batch
   const int Skv = p.Skv > 0 ? p.Skv : p.S;  // key/value rows per batch (cross-attention: Skv != S)
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
+  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
 
   s16x8_t qf[KS];
   {
@@ -264,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
 
   const int ntiles = (Skv + 63) / 64;
-  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv), srdV = slice_srd(Vb, p.ldv, Skv);
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv, HS), srdV = slice_srd(Vb, p.ldv, Skv, HS);
   unsigned vK[4], vV[4];
   rm_voff(vK, p.ldk, wave, lane);
   st_voff(vV, p.ldv, wave, lane);
@@ -347,11 +321,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
   if (q < S) {
-    bf16_t* op = p.O + ((long)b * S + q) * p.ldo + hd * 128;
+    bf16_t* op = p.O + ((long)b * S + q) * p.ldo + hd * HS;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        if (d >= DB && 32 * d >= HS) continue;  // native head layout: the columns past this head belong to the next one
         uint2 u = make_uint2(0u, 0u);
         if (d < DB) {
           u.x = pack2bf(o[d < DB ? d : 0][4 * g + 0] * inv, o[d < DB ? d : 0][4 * g + 1] * inv);
@@ -372,8 +347,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AitkAttnArgs p) {
   const int hd = (int)(pair % p.H);
   const long tok = pair / p.H;
   const int s = (int)(tok % p.S), b = (int)(tok / p.S);
-  uint4 a = *reinterpret_cast<const uint4*>(p.O + tok * p.ldo + hd * 128 + sub * 8);
-  uint4 g = *reinterpret_cast<const uint4*>(p.dO + tok * p.lddo + hd * 128 + sub * 8);
+  const int HS = p.hstride > 0 ? p.hstride : 128;
+  uint4 a = make_uint4(0, 0, 0, 0), g = a;
+  if (sub * 8 < HS) {  // native head layout: the head is HS columns wide (the padded layout carries zeros up to 128)
+    a = *reinterpret_cast<const uint4*>(p.O + tok * p.ldo + hd * HS + sub * 8);
+    g = *reinterpret_cast<const uint4*>(p.dO + tok * p.lddo + hd * HS + sub * 8);
+  }
   float acc = 0.f;
   acc += bf2f(a.x & 0xffff) * bf2f(g.x & 0xffff) + bf2f(a.x >> 16) * bf2f(g.x >> 16);
   acc += bf2f(a.y & 0xffff) * bf2f(g.y & 0xffff) + bf2f(a.y >> 16) * bf2f(g.y >> 16);
@@ -400,13 +379,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;
   const int Skv = p.Skv > 0 ? p.Skv : p.S;
   const int kvw = blockIdx.x * 128 + wave * 32;
-  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
-  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
+  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
+  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * HS;
   const float* Lb = p.LSE + ((long)b * p.H + hd) * S;
   const float* Db = p.delta + ((long)b * p.H + hd) * S;
 
@@ -434,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   // END of the iteration, otherwise their vmcnt wait (in-order counter) would also drain the just-issued LDS-DMA
   // prefetch and make it synchronous.
   float stat = 0.f;
-  const v4i_t srdQ = slice_srd(Qb, p.ldq, S), srdD = slice_srd(dOb, p.lddo, S);
+  const v4i_t srdQ = slice_srd(Qb, p.ldq, S, HS), srdD = slice_srd(dOb, p.lddo, S, HS);
   unsigned vQ[4], vD[4];
   st_voff(vQ, p.ldq, wave, lane);
   st_voff(vD, p.lddo, wave, lane);
@@ -560,10 +540,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kv = kvw + crow(r, h);
-      if (kv < Skv) {
+      if (kv < Skv && (d < DB || 32 * d < HS)) {
         const long off = ((long)b * Skv + kv);
-        p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = d < DB ? f2bf(dk[d < DB ? d : 0][r] * p.scale) : (bf16_t)0;
-        p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = d < DB ? f2bf(dv[d < DB ? d : 0][r]) : (bf16_t)0;
+        p.dK[off * p.lddk + hd * HS + 32 * d + l31] = d < DB ? f2bf(dk[d < DB ? d : 0][r] * p.scale) : (bf16_t)0;
+        p.dV[off * p.lddv + hd * HS + 32 * d + l31] = d < DB ? f2bf(dv[d < DB ? d : 0][r]) : (bf16_t)0;
       }
     }
 }
@@ -800,13 +780,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int hd = blockIdx.y, b = blockIdx.z;
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;
   const int Skv = p.Skv > 0 ? p.Skv : p.S;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
-  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
-  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
-  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
+  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
+  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * HS;
   const int qr = min(q0 + l31, S - 1);
   s16x8_t qf[KS], gf[KS];
   {
@@ -833,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   const unsigned ln_rm = l31 * 32 + ((h ^ ((l31 >> 3) & 1)) << 4);                                     // frag_rm_st (K and V, sub-tiled)
   const unsigned ln_tr_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);          // frag_tr_perm_st, rows with bit 3 clear
   const unsigned ln_tr_hi = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2) + 8) * 32 + ((lh ^ 1) << 4);  // ... and the rows 8 further
-  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv), srdV = slice_srd(Vb, p.ldv, Skv);
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv, HS), srdV = slice_srd(Vb, p.ldv, Skv, HS);
   unsigned vK[4], vV[4];
   st_voff(vK, p.ldk, wave, lane);
   st_voff(vV, p.ldv, wave, lane);
@@ -914,11 +895,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   }
   const int q = q0 + l31;
   if (q < S) {
-    bf16_t* op = p.dQ + ((long)b * S + q) * p.lddq + hd * 128;
+    bf16_t* op = p.dQ + ((long)b * S + q) * p.lddq + hd * HS;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        if (d >= DB && 32 * d >= HS) continue;
         uint2 u = make_uint2(0u, 0u);
         if (d < DB) {
           u.x = pack2bf(dq[d < DB ? d : 0][4 * g + 0] * p.scale, dq[d < DB ? d : 0][4 * g + 1] * p.scale);
@@ -932,6 +914,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
 static int attn_check(const AitkAttnArgs* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->S <= 0 || a->D != 128) return AITK_ERR_SHAPE;
   if (a->Dv < 0 || a->Dv > 128) return AITK_ERR_SHAPE;
+  // native head layout (head h at column h * hstride): the head must fill whole contraction steps and output blocks, because the tiles
+  // still fetch 128 columns per row and everything past the head is the NEXT head's data, not zeros
+  // (64 and 96 are the widths whose (KS, DB) instantiation is exact; 32 would run the 48-column variant)
+  if (a->hstride < 0 || (a->hstride > 0 && (a->hstride != a->Dv || (a->hstride != 64 && a->hstride != 96)))) return AITK_ERR_SHAPE;
   if ((a->ldq % 8) || (a->ldk % 8) || (a->ldv % 8) || (a->ldo % 8)) return AITK_ERR_ALIGN;
   return AITK_OK;
 }

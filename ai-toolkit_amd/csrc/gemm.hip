@@ -341,8 +341,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
         if (nb >= p.N) continue;
         float v[4];
         if (flags & AITK_EPI_SPLIT_SLAB) {
-          // N = 32 = [P_hi ; P_lo] (16 + 16 rows of B): t = A P_hi^T + A P_lo^T in fp32 — columns n and n + 16 sit in register groups g
-          // and g + 2 of the same lane — written as the K-slab triple [hi | lo | hi] (48 columns) like aitk_lora_down(split_rp = 16)
+          // B rows = 16-rank blocks [P_hi(16) ; P_lo(16)] of a rank-rp projection (rp = N / 2): t = A P_hi^T + A P_lo^T in fp32 — columns
+          // n and n + 16 of a 32-column block sit in register groups g and g + 2 of the same lane — written as the K-slab triple
+          // [hi(rp) | lo(rp) | hi(rp)] like aitk_lora_down(split_rp = rp)
           if (g >= 2) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * g + e] + acc[mi][ni][4 * (g + 2) + e];
@@ -354,9 +355,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(AitkGemmArgs p) {
           hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
           lo.x = pack2bf(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x));
           lo.y = pack2bf(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y));
-          *reinterpret_cast<uint2*>(crow + nb) = hi;
-          *reinterpret_cast<uint2*>(crow + 16 + nb) = lo;
-          *reinterpret_cast<uint2*>(crow + 32 + nb) = hi;
+          const int rp = p.N >> 1, rk = ((nb >> 5) << 4) + (nb & 31);  // rank of v[0]
+          *reinterpret_cast<uint2*>(crow + rk) = hi;
+          *reinterpret_cast<uint2*>(crow + rp + rk) = lo;
+          *reinterpret_cast<uint2*>(crow + 2 * rp + rk) = hi;
           continue;
         }
 #pragma unroll
@@ -470,8 +472,9 @@ static int gemm_check(const AitkGemmArgs* a) {
   if ((a->flags & AITK_EPI_GELU) && !a->aux_out) return AITK_ERR_ARG;  // GATE_RES: aux_out optional (only d_gate needs y)
   if ((a->flags & (AITK_EPI_DGELU | AITK_EPI_GATE_RES)) && !a->aux_in) return AITK_ERR_ARG;
   if ((a->flags & AITK_EPI_GATE_RES) && (!a->gate || a->gate_rows <= 0)) return AITK_ERR_ARG;
-  if (a->flags & AITK_EPI_SPLIT_SLAB) {  // [P_hi ; P_lo] product -> [hi | lo | hi] slab: rank block 16 only, no other epilogue but the column scale
-    if (a->N != 32 || a->ldc < 48 || a->c_seg_rows != 0 || (a->flags & ~(AITK_EPI_SPLIT_SLAB | AITK_EPI_COL_SCALE))) return AITK_ERR_ARG;
+  if (a->flags & AITK_EPI_SPLIT_SLAB) {  // [P_hi ; P_lo] blocks -> [hi | lo | hi] slab of rank N / 2 <= 64, no other epilogue but the column scale
+    if ((a->N % 32) || a->N > 128 || a->ldc < 3 * (a->N / 2) || a->c_seg_rows != 0 || (a->flags & ~(AITK_EPI_SPLIT_SLAB | AITK_EPI_COL_SCALE)))
+      return AITK_ERR_ARG;
   }
   if (((uintptr_t)a->A | (uintptr_t)a->C) & 15) return AITK_ERR_ALIGN;
   if ((uintptr_t)a->B & (a->b_scale_mode ? 7 : 15)) return AITK_ERR_ALIGN;

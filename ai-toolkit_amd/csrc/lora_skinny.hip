@@ -265,7 +265,9 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if ((a->K % 16) || (a->R % 4) || a->R > 64) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ldp % 8) || (a->ldt % 4)) return AITK_ERR_ALIGN;
   if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
-  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->R % a->split_rp)))) return AITK_ERR_ARG;
+  // split_rp >= R: the launch covers (a chunk of) ONE rank block — ranks above 64 go out in 64-rank chunks of the same slab
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
+  if (a->tmask && a->split_rp > a->R) return AITK_ERR_ARG;  // the mask rows are R wide: a chunk would read the wrong columns
   const int grid = (a->M + 31) / 32;
   if (a->K % 32 == 0) {
     static int u1 = 0;  // AITK_LORA_DOWN_U=8 selects the 3-waves-per-SIMD variant (A/B measurements)
@@ -444,7 +446,7 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
   if (!a->partial || !a->out) return AITK_ERR_ARG;
-  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->R % a->split_rp)))) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
   int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
   if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;  // millions of rows (LoKr): at most 512 row chunks
   const int nchunks = (a->M + mc - 1) / mc;

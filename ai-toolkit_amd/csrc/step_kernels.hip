@@ -350,9 +350,11 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena
       const bf16_t lo = f2bf(w - bf2f(hi));
       const long r = i / d.cols, c = i - r * d.cols;
       const long cin = c / 9, tap = c - cin * 9;
-      // d0: [2 rank, 9 Cin] = [A_hi ; A_lo], tap-major columns — B operand of the implicit-GEMM lora_down (AITK_EPI_SPLIT_SLAB)
-      shadow[d.d0 + r * d.cols + tap * cin_n + cin] = hi;
-      shadow[d.d0 + (d.rows + r) * d.cols + tap * cin_n + cin] = lo;
+      // d0: [2 rank, 9 Cin], tap-major columns, rows in 16-rank blocks [A_hi(16) ; A_lo(16)] — B operand of the implicit-GEMM lora_down
+      // (AITK_EPI_SPLIT_SLAB adds columns n and n + 16 of every 32-column block)
+      const long rh = (r >> 4) * 32 + (r & 15);
+      shadow[d.d0 + rh * d.cols + tap * cin_n + cin] = hi;
+      shadow[d.d0 + (rh + 16) * d.cols + tap * cin_n + cin] = lo;
       // d1: [Cin, 9 * 3 rank]: data-gradient filter over the dT slab image [hi | lo | hi] = rotated taps, [A_hi | A_hi | A_lo] per tap
       bf16_t* t3 = shadow + d.d1 + cin * (27 * d.rows) + (8 - tap) * 3 * d.rows + r;
       t3[0] = hi;

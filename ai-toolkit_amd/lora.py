@@ -306,9 +306,9 @@ class FusedLoRANetwork(nn.Module):
         if self.conv_lora_dim is not None:
             if network_type.lower() != "lora" or is_transformer or peft_format:
                 raise NotImplementedError("network.conv: plain LoRA on UNet (kohya-format) networks only on the fused path")
-            if self.conv_lora_dim > 16:
-                raise NotImplementedError("network.conv ranks above 16 are not on the fused path (the split-slab epilogue of the implicit-GEMM "
-                                          "lora_down writes one 16-wide rank block)")
+            if self.conv_lora_dim > 64:
+                raise NotImplementedError("network.conv ranks above 64 are not on the fused path (the split-slab epilogue of the implicit-GEMM "
+                                          "lora_down covers one 128-column tile = 64 ranks hi + lo)")
             target_lin_modules = tuple(target_lin_modules) + tuple(target_conv_modules)
         # toolkit/lora_special.py:403-408
         module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]

@@ -221,12 +221,28 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
               tmask_rows_per_batch=0):
     """out = scale * mult[m // rows_per_batch] * (x[M,K] @ (pmat + p_lo)[R,K]^T): [M,R] bf16, or — split = rank-block width —
     the [M,3R] K-slab layout [hi | lo | hi] per rank block (AitkLoraDownArgs in the header)."""
+    R, K = pmat.shape
+    if R > 64:  # the kernel contracts up to 64 ranks per launch: larger ranks go out in 64-rank chunks of the same slab (split >= R: one
+        #         rank block, the chunk's hi / lo / hi columns sit at its rank offset inside it)
+        if tmask is not None or (split and split < R):
+            raise NotImplementedError("lora_down: ranks above 64 with a dropout mask / several rank blocks per launch")
+        assert out.shape[1] == (3 * split if split else R)
+        for c0 in range(0, R, 64):
+            c1 = min(R, c0 + 64)
+            _lora_down_launch(x, pmat[c0:c1], out[:, c0:], scale, mult, rows_per_batch, x_seg, M, None if p_lo is None else p_lo[c0:c1],
+                              split, None, 0)
+        return out
+    assert out.shape[1] == (3 * R if split else R)
+    return _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo, split, tmask, tmask_rows_per_batch)
+
+
+def _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo, split, tmask, tmask_rows_per_batch):
     a = _capi.LoraDownArgs()
     a.ldx = _row_major(x, "x")
     a.ldp = _row_major(pmat, "pmat")
     a.ldt = _row_major(out, "out")
     R, K = pmat.shape
-    assert x.shape[1] == K and out.shape[1] == (3 * R if split else R)
+    assert x.shape[1] == K
     a.X, a.P, a.T = _ptr(x), _ptr(pmat), _ptr(out)
     if p_lo is not None:
         assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == a.ldp
@@ -251,10 +267,27 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
     split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo.
     out_strides = (stride_r, stride_l): element (r, l) goes to out.flatten()[r*stride_r + l*stride_l] (`out` = fp32 view starting at the
     first element; one tap of a conv adapter's [r, Cin, 3, 3] gradient: strides (9 Cin, 9))."""
+    R, L = (s.shape[1] // 3 if split else s.shape[1]), g.shape[1]
+    if R > 64:  # 64-rank chunks of one slab (see lora_down): rank r of the output at r * stride_r
+        if split and split < R:
+            raise NotImplementedError("lora_wgrad: ranks above 64 in several rank blocks per launch")
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        sr, sl = out_strides if out_strides is not None else ((1, R) if transpose_out else (L, 1))
+        if out_strides is None:
+            assert tuple(out.shape) == ((L, R) if transpose_out else (R, L))
+        flat = out.view(-1)
+        for c0 in range(0, R, 64):
+            c1 = min(R, c0 + 64)
+            sc = s[:, c0:] if split else s[:, c0:c1]
+            _lora_wgrad_launch(sc, g, flat[c0 * sr:], c1 - c0, L, accumulate, g_seg, M, split, (sr, sl), False)
+        return out
+    return _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out)
+
+
+def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out):
     a = _capi.LoraWgradArgs()
     a.lds = _row_major(s, "s")
     a.ldg = _row_major(g, "g")
-    R, L = (s.shape[1] // 3 if split else s.shape[1]), g.shape[1]
     a.split_rp = int(split)
     M = s.shape[0] if M is None else M
     assert out.dtype == torch.float32 and out.is_contiguous()
@@ -405,10 +438,11 @@ def copy_rows(dst, src):
     return dst
 
 
-def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0, dv=0):
+def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0, dv=0, hstride=0):
     a = _capi.AttnArgs()
     a.Skv = Skv
     a.Dv = dv  # valid head width inside the 128-column layout (0 = 128)
+    a.hstride = hstride  # elements between heads (0 = 128); == dv: heads read where the projections wrote them
     a.Q, a.K, a.V, a.O, a.LSE = _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse)
     a.ldq, a.ldk, a.ldv, a.ldo = _row_major(q, "q"), _row_major(k, "k"), _row_major(v, "v"), _row_major(o, "o")
     assert lse.dtype == torch.float32 and lse.numel() == B * H * S
@@ -416,16 +450,17 @@ def _attn_args(q, k, v, o, lse, B, H, S, scale, Skv=0, dv=0):
     return a
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0):
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0, hstride=0):
     """q,o: [B*S, >=H*128]; k,v: [B*Skv, >=H*128] bf16 views (row stride = token stride); lse [B,H,S] fp32.  dv: heads narrower than
-    128 are stored zero-padded to 128 columns; the kernels then skip the all-zero parts (exactly the padded result)."""
-    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dv)
+    128 are stored zero-padded to 128 columns; the kernels then skip the all-zero parts (exactly the padded result).  hstride == dv
+    (64 / 96): native [B*S, H*dv] layout, no padding."""
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dv, hstride)
     _call("aitk_attn_fwd", C.byref(a))
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0):
-    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dvalid)
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0, hstride=0):
+    a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dvalid, hstride)
     a.dO, a.lddo = _ptr(do), _row_major(do, "do")
     a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
     a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")
@@ -552,8 +587,8 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
             split_slab=False, col_scale=None):
     """Implicit-GEMM 3x3 convolution on NHWC: x [B*H*W, Cin], w [Cout, 9*Cin] (k = (ky*3+kx)*Cin + cin), out [B*Ho*Wo, Cout].
     a2 [M, K2] / b2 [Cout, K2]: LoRA K-slab added to the product (the lora_up of a conv adapter, fused like a Linear's).
-    split_slab: w = [A_hi ; A_lo] (32 rows) and out is the [M, 48] slab [hi | lo | hi] of the fp32 sum (the conv adapter's lora_down),
-    scaled by the fp32 vector col_scale [32]."""
+    split_slab: w = 16-rank blocks [A_hi ; A_lo] of a rank-rp projection (2 rp rows, rp <= 64) and out is the [M, 3 rp] slab
+    [hi | lo | hi] of the fp32 sum (the conv adapter's lora_down), scaled by the fp32 vector col_scale [2 rp]."""
     g = _capi.GemmArgs()
     Cin = x.shape[1]
     assert x.is_contiguous() and x.dtype == BF16 and x.shape[0] == B * H * W
@@ -561,10 +596,10 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     Wo = W if Wo is None else Wo
     g.lda, g.ldb, g.ldc = Cin, _row_major(w, "w"), _row_major(out, "out")
     N, K = w.shape
-    assert K == 9 * Cin and out.shape == (B * Ho * Wo, 48 if split_slab else N)
+    assert K == 9 * Cin and out.shape == (B * Ho * Wo, 3 * (N // 2) if split_slab else N)
     g.A, g.B, g.C = _ptr(x), _ptr(w), _ptr(out)
     if split_slab:
-        assert N == 32 and bias is None and aux_in is None and a2 is None
+        assert N % 32 == 0 and N <= 128 and bias is None and aux_in is None and a2 is None
         flags |= _capi.EPI_SPLIT_SLAB
     if col_scale is not None:
         assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == N

@@ -343,7 +343,7 @@ class UNet2DConditionModel(FusedGraphBase):
 
     # ------------------------------------------------------------------ kernel-level graph helpers (each records its backward)
     def _conv_scale(self, lo):
-        """fp32 [32] column scale of a conv adapter's lora_down launch: runtime scale * network multiplier (uniform: the implicit-GEMM
+        """fp32 [2 rank_pad] column scale of a conv adapter's lora_down launch: runtime scale * network multiplier (uniform: the implicit-GEMM
         epilogue has no per-row factor, so per-sample multipliers — slider training — are refused for 3x3-conv adapters)."""
         mv = self.network._multiplier
         vals = [float(v) for v in mv] if isinstance(mv, (list, tuple)) else [float(mv)]
@@ -352,7 +352,7 @@ class UNet2DConditionModel(FusedGraphBase):
         c = lo.scale * vals[0]
         cached = getattr(lo, "_cs", None)
         if cached is None or cached[0] != c or cached[1].device != self._device():
-            cached = (c, torch.full((32,), c, dtype=torch.float32, device=self._device()))
+            cached = (c, torch.full((2 * lo.rank_pad,), c, dtype=torch.float32, device=self._device()))
             lo._cs = cached
         return cached[1]
 
@@ -360,7 +360,7 @@ class UNet2DConditionModel(FusedGraphBase):
         """y = conv3x3(x) + bias (+ res) (+ LoRA when network.conv wrapped the layer); NHWC contiguous in, [B*Ho*Wo, Cout] out.
 
         3x3-conv adapter (toolkit/lora_special.py:95-104): lora_down = Conv2d(in, r, 3, stride, padding) is the same implicit-GEMM kernel
-        with the 32 stacked filters [A_hi ; A_lo] whose fp32 sum leaves the epilogue as the [hi | lo | hi] slab T; lora_up (1x1) is the
+        with the 2 rank_pad stacked filters (16-rank blocks [A_hi ; A_lo]) whose fp32 sum leaves the epilogue as the [hi | lo | hi] slab T; lora_up (1x1) is the
         K-slab of the base convolution, exactly like a Linear's.  Backward: dT = c (dy B) and dB by the skinny kernels; dx += the 3x3
         convolution of the dT slab image with the rotated [A_hi | A_hi | A_lo] filter; dA = nine per-tap skinny contractions of the
         zero-framed dT and x grids (a flat shift per tap: wrapped pairs always meet a zero of the frame)."""
@@ -372,7 +372,7 @@ class UNet2DConditionModel(FusedGraphBase):
         lo = conv.lora if self._lora_active(conv) else None
         T, kw = None, {}
         if lo is not None:
-            T = self._new(Mo, 48)
+            T = self._new(Mo, 3 * lo.rank_pad)
             ops.conv3x3(x, lo.sh_down_stack, T, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, split_slab=True, col_scale=self._conv_scale(lo))
             kw = dict(a2=T, b2=lo.sh_up3)
         ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=EPI_ADD_AUX if res is not None else 0,
@@ -498,7 +498,8 @@ class UNet2DConditionModel(FusedGraphBase):
 
     def _attention(self, xq, ctx, a, *, B, Sq, Skv, tape, res):
         """diffusers Attention (AttnProcessor2_0): to_q / to_k / to_v (+LoRA), SDPA over `heads` of dim_head, to_out[0] (+LoRA) + res.
-        ctx is None for self-attention (keys / values from xq).  Heads are zero-padded to 128 columns for the flash kernels."""
+        ctx is None for self-attention (keys / values from xq).  Heads of 40 / 80 columns are zero-padded to 128 for the flash kernels, 64-wide
+        heads are read in place."""
         ops, H, d = self.ops, a.heads, a.dim_head
         Mq, Mk = B * Sq, B * Skv
         self_attn = ctx is None
@@ -518,12 +519,17 @@ class UNet2DConditionModel(FusedGraphBase):
         lse = self._new(B, H, Sq, dtype=torch.float32)
         kvn = 0 if self_attn else Skv
         small = d > PAD_D  # SD1.5's head_dim 160: generic fp32 kernels on the unpadded heads (tiny sequences)
+        native = d in (64, 96)  # whole contraction steps and output blocks of an exact kernel instantiation: no padding needed
         if small:
             qp, kp, vp = q, k, v
             o = op_ = self._new(Mq, dim)
             ops.attn_small_fwd(q, k, v, o, lse, B=B, H=H, S=Sq, D=d, scale=scale, Skv=kvn)
+        elif native:  # SDXL's 64-wide heads: the flash kernels read q / k / v where the projections wrote them (AitkAttnArgs.hstride)
+            qp, kp, vp = q, k, v
+            o = op_ = self._new(Mq, dim)
+            ops.attn_fwd(q, k, v, o, lse, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dv=d, hstride=d)
         else:
-            if d != PAD_D:  # head_dim 40 / 64 / 80: zero-padded to the flash kernels' 128 columns (exact)
+            if d != PAD_D:  # head_dim 40 / 80: zero-padded to the flash kernels' 128 columns (exact)
                 qp, kp, vp = self._new(Mq, H * PAD_D), self._new(Mk, H * PAD_D), self._new(Mk, H * PAD_D)
                 for s_, d_ in ((q, qp), (k, kp), (v, vp)):
                     ops.copy_heads(s_, d_, H=H, d_src=d, d_dst=PAD_D)
@@ -550,6 +556,9 @@ class UNet2DConditionModel(FusedGraphBase):
             if small:
                 dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
                 ops.attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=Sq, D=d, scale=scale, Skv=kvn)
+            elif native:
+                dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
+                ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dvalid=d, hstride=d)
             else:
                 if d != PAD_D:
                     dop = self._new(Mq, H * PAD_D)

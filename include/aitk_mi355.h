@@ -35,9 +35,10 @@ typedef uint16_t aitk_bf16;
 #define AITK_EPI_GATE_RES 16 /* aux_out = y; C = aux_in(residual) + gate[m / gate_rows][n] * y   */
 #define AITK_EPI_BIAS_ROW 32 /* + bias[m]  (transposed products, e.g. V^T = W_v x^T)             */
 #define AITK_EPI_ADD_AUX 64  /* + aux_in[m][n]  (residual add of ResnetBlock2D / VAE attention)  */
-#define AITK_EPI_SPLIT_SLAB 256 /* N = 32 = [P_hi ; P_lo] (bf16 hi / lo halves of a rank-16 fp32 projection stacked as B rows): the fp32 sum of
-                                  columns n and n + 16 is written as the K-slab triple [hi | lo | hi] (C is [M, >= 48]) — lora_down of a 3x3-conv
-                                  adapter (toolkit/lora_special.py:95-104) on the implicit-GEMM kernel; only COL_SCALE may accompany it */
+#define AITK_EPI_SPLIT_SLAB 256 /* B rows = 16-rank blocks [P_hi(16) ; P_lo(16)] (bf16 hi / lo halves of a rank-rp fp32 projection, N = 2 rp <= 128):
+                                  the fp32 sum of columns n and n + 16 of every 32-column block is written as the K-slab triple
+                                  [hi(rp) | lo(rp) | hi(rp)] (C is [M, >= 3 rp]) — lora_down of a 3x3-conv adapter
+                                  (toolkit/lora_special.py:95-104) on the implicit-GEMM kernel; only COL_SCALE may accompany it */
 #define AITK_EPI_COL_SCALE 128 /* product * col_scale[n] before the bias: DoRA magnitude / ||W + dW||_row (toolkit/models/DoRA.py:126-148) */
 
 /*
@@ -250,8 +251,10 @@ typedef struct AitkAttnArgs {
   aitk_bf16* dQ; aitk_bf16* dK; aitk_bf16* dV; int64_t lddq, lddk, lddv;
   float* delta;
   float scale; int32_t B, H, S, D, Skv; /* Skv: key/value rows per batch (0 = S); cross-attention has Skv != S */
-  int32_t Dv, _r0; /* Dv: valid head width inside the 128-column layout (0 = 128): UNet heads of 40 / 64 / 80 are stored zero-padded; the
-                      all-zero contraction steps and output blocks are skipped, the padded output columns are written as zeros */
+  int32_t Dv, hstride; /* Dv: valid head width inside the 128-column layout (0 = 128): UNet heads of 40 / 64 / 80 are stored zero-padded; the
+                      all-zero contraction steps and output blocks are skipped, the padded output columns are written as zeros.
+                      hstride (0 = 128): elements between consecutive heads.  hstride == Dv in {64, 96} reads / writes the heads where
+                      the projections put them ([B, S, H*Dv] — SDXL's 64-wide heads), no padded copies; other widths must be padded */
 } AitkAttnArgs;
 int aitk_attn_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
 int aitk_attn_bwd(const AitkAttnArgs* args, aitk_stream_t stream);

@@ -283,32 +283,32 @@ def copy_rows(dst, src):
     return dst
 
 
-def _heads(t, B, S, H):
-    return t[: B * S, : H * 128].reshape(B, S, H, 128).transpose(1, 2).float()
+def _heads(t, B, S, H, hs=128):
+    return t[: B * S, : H * hs].reshape(B, S, H, hs).transpose(1, 2).float()
 
 
-def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0):
+def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0, hstride=0):
     """F.scaled_dot_product_attention (toolkit/models/flux_sage_attn.py:76; chroma/src/math.py:27; cross-attention:
-    toolkit/models/wan21/wan_attn.py:67-75)."""
-    Skv = Skv or S
-    qf, kf, vf = _heads(q, B, S, H), _heads(k, B, Skv, H), _heads(v, B, Skv, H)
+    toolkit/models/wan21/wan_attn.py:67-75).  hstride: head width of the native [tokens, H*hstride] layout (0: 128-column heads)."""
+    Skv, hs = Skv or S, hstride or 128
+    qf, kf, vf = _heads(q, B, S, H, hs), _heads(k, B, Skv, H, hs), _heads(v, B, Skv, H, hs)
     sc = (qf @ kf.transpose(-1, -2)) * scale
     lse.copy_(torch.logsumexp(sc, -1) / math.log(2.0))
     out = sc.softmax(-1) @ vf
-    o[: B * S, : H * 128].copy_(out.transpose(1, 2).reshape(B * S, H * 128).to(o.dtype))
+    o[: B * S, : H * hs].copy_(out.transpose(1, 2).reshape(B * S, H * hs).to(o.dtype))
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0):
-    Skv = Skv or S
-    qf = _heads(q, B, S, H).requires_grad_(True)
-    kf = _heads(k, B, Skv, H).requires_grad_(True)
-    vf = _heads(v, B, Skv, H).requires_grad_(True)
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0, hstride=0):
+    Skv, hs = Skv or S, hstride or 128
+    qf = _heads(q, B, S, H, hs).requires_grad_(True)
+    kf = _heads(k, B, Skv, H, hs).requires_grad_(True)
+    vf = _heads(v, B, Skv, H, hs).requires_grad_(True)
     with torch.enable_grad():
         out = ((qf @ kf.transpose(-1, -2)) * scale).softmax(-1) @ vf
-        out.backward(_heads(do, B, S, H))
+        out.backward(_heads(do, B, S, H, hs))
     for dst, src, n in ((dq, qf, S), (dk, kf, Skv), (dv, vf, Skv)):
-        dst[: B * n, : H * 128].copy_(src.grad.transpose(1, 2).reshape(B * n, H * 128).to(dst.dtype))
+        dst[: B * n, : H * hs].copy_(src.grad.transpose(1, 2).reshape(B * n, H * hs).to(dst.dtype))
 
 
 def gemv_nt(x, w, out, *, bias=None, t=None, bl=None, accumulate=False, col_scale=None):
@@ -442,7 +442,9 @@ def refresh_shadows(arena, shadow, table):
             cin = aux[0]
             lo = (w - hi.float()).to(shadow.dtype)
             tm = lambda t: t.view(r, cin, 9).permute(0, 2, 1).reshape(r, 9 * cin)  # noqa: E731  columns tap*Cin + cin
-            shadow[d0:d0 + 2 * r * c].view(2 * r, c).copy_(torch.cat((tm(hi), tm(lo)), dim=0))
+            # rows in 16-rank blocks [A_hi(16) ; A_lo(16)]: the slab epilogue adds columns n and n + 16 of every 32-column block
+            st = torch.stack((tm(hi).view(r // 16, 16, c), tm(lo).view(r // 16, 16, c)), dim=1)
+            shadow[d0:d0 + 2 * r * c].view(2 * r, c).copy_(st.reshape(2 * r, c))
             h3, l3 = hi.view(r, cin, 9).flip(2), lo.view(r, cin, 9).flip(2)  # [r, cin, tap'] with tap' = 8 - tap
             blk = torch.cat((h3, h3, l3), dim=0)  # [3r, cin, tap']: slab channel j -> (A_hi | A_hi | A_lo)
             shadow[d1:d1 + 3 * r * c].view(cin, 27 * r).copy_(blk.permute(1, 2, 0).reshape(cin, 27 * r))
@@ -466,7 +468,7 @@ def refresh_shadows(arena, shadow, table):
 def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None, a2=None, b2=None,
             split_slab=False, col_scale=None):
     """nn.Conv2d 3x3 on NHWC rows (diffusers AutoencoderKL, reached from toolkit/stable_diffusion_model.py:2567); with a2 / b2 the
-    lora_up K-slab of a conv adapter is added; split_slab: the conv adapter's lora_down (w = [A_hi ; A_lo]) written as [hi | lo | hi]
+    lora_up K-slab of a conv adapter is added; split_slab: the conv adapter's lora_down (w = 16-rank blocks [A_hi ; A_lo]) written as [hi | lo | hi]
     (toolkit/lora_special.py:95-104, toolkit/network_mixins.py:304-342)."""
     Cin = x.shape[1]
     Ho = H if Ho is None else Ho
@@ -479,9 +481,10 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     y = F.conv2d(xi, wk, None, stride=stride)[:, :, :Ho, :Wo]
     v = y.permute(0, 2, 3, 1).reshape(B * Ho * Wo, -1)
     if split_slab:
-        t = v[:, :16] + v[:, 16:32]
+        v4 = v.view(v.shape[0], -1, 2, 16)  # 16-rank blocks [hi | lo] of the stacked filter
+        t = (v4[:, :, 0] + v4[:, :, 1]).reshape(v.shape[0], -1)
         if col_scale is not None:
-            t = t * col_scale.float()[:16]
+            t = t * col_scale.float()[: t.shape[1]]
         hi = t.to(out.dtype)
         lo = (t - hi.float()).to(out.dtype)
         out.copy_(torch.cat((hi, lo, hi), dim=1))

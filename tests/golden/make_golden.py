@@ -824,11 +824,50 @@ def golden_unet_conv_lora():
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_conv_lora_tiny.safetensors"), {"meta": json.dumps(meta)})
 
 
+def golden_unet_conv_lora_highrank():
+    """golden_unet_conv_lora at ranks beyond one 16-wide rank block / one 64-rank skinny launch: conv rank 24 with linear rank 80 (SDXL-like
+    tree) and conv rank 40 with linear rank 4 (SD1.5-like tree) through the reference's LoRASpecialNetwork / LoRAModule.forward."""
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, TINY_SDXL, _inputs
+
+    out, meta = {}, {}
+    for tag, cfg, is_xl, lin_r, conv_r in (("sdxl", TINY_SDXL, True, 80, 24), ("sd15", TINY_SD15, False, 4, 40)):
+        torch.manual_seed(0)
+        model = unet_ref.UNet2DConditionModel(**cfg)
+        unet_ref.init_synthetic_(model, seed=11)
+        torch.manual_seed(99)
+        net = LoRASpecialNetwork(text_encoder=None, unet=model, lora_dim=lin_r, alpha=lin_r / 2, conv_lora_dim=conv_r, conv_alpha=conv_r / 4,
+                                 multiplier=1.0, train_text_encoder=False, train_unet=True, is_sdxl=is_xl)
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in net.unet_loras:  # the test repeats these draws (and the constructor's kaiming draws under seed 99, pinned bit for bit by
+                m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)  # golden_unet_conv_lora) instead of storing them
+        net.force_to("cpu", torch.float32)
+        net._update_torch_multiplier()
+        net.apply_to(None, model, False, True)
+        lat, ts, ctx, added = _inputs(cfg)
+        with net:
+            pred = model(lat, ts, ctx, added)
+            wgt = torch.randn(pred.shape, generator=torch.Generator().manual_seed(11))
+            (pred * wgt).sum().backward()
+        out[f"{tag}/pred"], out[f"{tag}/wgt"] = pred.detach().clone(), wgt
+        # every gradient matrix G [rows, cols] is stored through two fixed random projections (G v and u G, fp32) and its norm: the full
+        # matrices of a rank-80 network would be 25 MB of fixture
+        gp = torch.Generator().manual_seed(123)
+        for m in net.unet_loras:
+            for nm, w in (("down", m.lora_down.weight), ("up", m.lora_up.weight)):
+                G = w.grad.detach().reshape(w.shape[0], -1)
+                v, u = torch.randn(G.shape[1], generator=gp), torch.randn(G.shape[0], generator=gp)
+                out[f"{tag}/grad/{m.lora_name}/{nm}"] = torch.cat((G @ v, u @ G, G.norm().reshape(1)))
+        meta[tag] = {"names": [m.lora_name for m in net.unet_loras], "lin_rank": lin_r, "conv_rank": conv_r,
+                     "dims": [m.lora_dim for m in net.unet_loras], "scales": [m.scale for m in net.unet_loras]}
+        print(f"unet conv-lora high-rank golden [{tag}]:", len(meta[tag]["names"]), "adapters")
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_conv_lora_highrank.safetensors"), {"meta": json.dumps(meta)})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:  # python make_golden.py golden_unet_lora ...: regenerate selected fixtures only
-        for fn in sys.argv[1:]:
-            globals()[fn]()
-        raise SystemExit(0)
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:
             globals()[name]()
@@ -836,6 +875,7 @@ if __name__ == "__main__":
     golden_ema_options()
     golden_unet_lora()
     golden_unet_conv_lora()
+    golden_unet_conv_lora_highrank()
     golden_unet_keymap_keys()
     golden_lora()
     golden_dora()

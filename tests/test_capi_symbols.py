@@ -77,6 +77,14 @@ def test_round2_entry_points_validate_their_arguments_before_launching():
     at.Dv = 64
     at.ldq = at.ldk = at.ldv = at.ldo = 256
     assert lib.aitk_attn_fwd(ctypes.byref(at), None) == -3                             # null operands: AITK_ERR_ARG
+    at.hstride = 64
+    assert lib.aitk_attn_fwd(ctypes.byref(at), None) == -3                             # native 64-wide heads: accepted (operands still null)
+    for w in (40, 32):                                                                 # 40: not whole contraction steps / output blocks; 32: no exact instantiation
+        at.Dv, at.hstride = w, w
+        assert lib.aitk_attn_fwd(ctypes.byref(at), None) == -1
+    at.Dv, at.hstride = 64, 96                                                         # native layout means hstride == Dv
+    assert lib.aitk_attn_bwd(ctypes.byref(at), None) == -1
+    at.Dv, at.hstride = 64, 0
     assert lib.aitk_lokr_lowrank_grad(None, None, None, None, None, 8, 8, 4, 1, None) == -3
     sd = _capi.ShadowDesc()
     assert ctypes.sizeof(sd) == 48 and hasattr(sd, "aux")                              # kind 3 (composed low-rank LoKr factor) carries its rank here

@@ -21,32 +21,40 @@ def R(*shape, s=1.0, seed=0):
 
 
 @pytest.mark.parametrize("case", [dict(B=2, H=16, W=12, Cin=64, stride=1), dict(B=1, H=33, W=31, Cin=32, stride=1),
-                                  dict(B=2, H=16, W=24, Cin=128, stride=2), dict(B=1, H=64, W=64, Cin=320, stride=1)])
+                                  dict(B=2, H=16, W=24, Cin=128, stride=2), dict(B=1, H=64, W=64, Cin=320, stride=1),
+                                  dict(B=2, H=16, W=12, Cin=64, stride=1, rp=32), dict(B=1, H=33, W=31, Cin=32, stride=1, rp=48),
+                                  dict(B=2, H=16, W=24, Cin=128, stride=2, rp=64)])
 def test_conv_lora_down_split_slab(case):
+    """rp = padded rank of the adapter: the stacked filter is rp / 16 blocks [A_hi(16) ; A_lo(16)] (N = 2 rp GEMM columns), the slab
+    [hi(rp) | lo(rp) | hi(rp)]; checked against the oracle AND against the plain fp32 convolution with the un-split filter."""
     from ai_toolkit_amd import ops
     from oracle import ref_ops
 
     B, H, W, Cin, stride = (case[k] for k in ("B", "H", "W", "Cin", "stride"))
+    rp = case.get("rp", 16)
     x = R(B * H * W, Cin, seed=1).to(bf).cuda()
-    a32 = R(16, 9 * Cin, s=(9 * Cin) ** -0.5, seed=2)
+    a32 = R(rp, 9 * Cin, s=(9 * Cin) ** -0.5, seed=2)
     hi = a32.to(bf)
     lo = (a32 - hi.float()).to(bf)
-    w = torch.cat((hi, lo), 0).contiguous().cuda()
-    cs = torch.full((32,), 0.37, dtype=torch.float32, device="cuda")
+    w = torch.stack((hi.view(rp // 16, 16, -1), lo.view(rp // 16, 16, -1)), dim=1).reshape(2 * rp, -1).contiguous().cuda()
+    cs = torch.full((2 * rp,), 0.37, dtype=torch.float32, device="cuda")
     kw = dict(B=B, H=H, W=W)
     if stride == 2:
         kw.update(stride=2, Ho=H // 2, Wo=W // 2)
     M = B * kw.get("Ho", H) * kw.get("Wo", W)
-    out = torch.full((M, 48), float("nan"), dtype=bf, device="cuda")
-    ref = torch.empty(M, 48, dtype=torch.float32, device="cuda")
+    out = torch.full((M, 3 * rp), float("nan"), dtype=bf, device="cuda")
+    ref = torch.empty(M, 3 * rp, dtype=torch.float32, device="cuda")
     ops.conv3x3(x, w, out, split_slab=True, col_scale=cs, **kw)
     ref_ops.conv3x3(x, w, ref, split_slab=True, col_scale=cs, **kw)
     torch.cuda.synchronize()
-    assert torch.equal(out[:, :16], out[:, 32:])
-    t_ours = out[:, :16].float() + out[:, 16:32].float()
-    t_ref = ref[:, :16] + ref[:, 16:32]  # the fp32 value before the split (hi + lo of the oracle is exact to 2^-17)
+    assert torch.equal(out[:, :rp], out[:, 2 * rp:])
+    t_ours = out[:, :rp].float() + out[:, rp:2 * rp].float()
+    t_ref = ref[:, :rp] + ref[:, rp:2 * rp]  # the fp32 value before the split (hi + lo of the oracle is exact to 2^-17)
     assert rel(t_ours, t_ref) < 5e-5, rel(t_ours, t_ref)
-    assert rel(out[:, :16], ref[:, :16]) < 4e-3
+    assert rel(out[:, :rp], ref[:, :rp]) < 4e-3
+    plain = torch.empty(M, rp, dtype=torch.float32, device="cuda")  # rank r of the slab = filter r of the adapter, whatever the block order
+    ref_ops.conv3x3(x.float(), (hi.float() + lo.float()).cuda(), plain, **kw)
+    assert rel(t_ours, 0.37 * plain) < 5e-5, rel(t_ours, 0.37 * plain)
 
 
 def test_conv_with_lora_up_slab_accumulate_pad_and_strided_wgrad():
@@ -99,11 +107,12 @@ def test_conv_with_lora_up_slab_accumulate_pad_and_strided_wgrad():
     assert rel(g1.view(16, Cin, 3, 3), A.grad) < 2e-4
 
 
-def test_shadow_kind4_layouts_bit_equal():
+@pytest.mark.parametrize("rp", [16, 48])
+def test_shadow_kind4_layouts_bit_equal(rp):
     from ai_toolkit_amd import ops
     from oracle import ref_ops
 
-    rp, cin = 16, 24
+    cin = 24
     arena = R(rp * cin * 9 + 7, s=0.3, seed=11).cuda()
     ent = [(0, rp, cin * 9, 4, 0, 2 * rp * cin * 9, 0, cin)]
     n = 5 * rp * cin * 9
@@ -126,8 +135,9 @@ def _rel_lists(a, b):
     return math.sqrt(num / max(den, 1e-300))
 
 
-@pytest.mark.parametrize("sdxl", [False, True], ids=["sd15", "sdxl"])
-def test_unet_step_with_conv_adapters(sdxl):
+@pytest.mark.parametrize("sdxl,lin_r,conv_r", [(False, 8, 4), (True, 8, 4), (True, 80, 24), (False, 8, 40)],
+                         ids=["sd15", "sdxl", "sdxl-lin80-conv24", "sd15-conv40"])
+def test_unet_step_with_conv_adapters(sdxl, lin_r, conv_r):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.lora import FusedLoRANetwork
@@ -147,7 +157,7 @@ def test_unet_step_with_conv_adapters(sdxl):
         nat = UNet2DConditionModel(**cfg, dtype=dtype, device=dev, ops=table)
         nat.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
         torch.manual_seed(99)
-        net = FusedLoRANetwork(nat, lora_dim=8, alpha=4.0, conv_lora_dim=4, conv_alpha=2.0, target_lin_modules=("Transformer2DModel",),
+        net = FusedLoRANetwork(nat, lora_dim=lin_r, alpha=lin_r / 2, conv_lora_dim=conv_r, conv_alpha=conv_r / 2, target_lin_modules=("Transformer2DModel",),
                                is_transformer=False, peft_format=False, transformer_only=False)
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():

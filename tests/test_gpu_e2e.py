@@ -81,12 +81,15 @@ def test_native_library_loaded_and_fails_loudly_without_it(monkeypatch):
         _capi.lib()
 
 
-def test_step_gradients_and_loss_vs_oracle():
+@pytest.mark.parametrize("rank", [16, 128])
+def test_step_gradients_and_loss_vs_oracle(rank):
+    """rank 128: beyond the 64 ranks one skinny launch contracts — lora_down / lora_wgrad go out in 64-rank chunks of one slab, the GEMM
+    K-slab is 384 columns."""
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
     from oracle import train_ref
 
-    ref, ref_net, nat, net = _build()
+    ref, ref_net, nat, net = _build(rank)
     lat, emb, pooled, noise, ts = _batch(2)
     # fp32 oracle (truth)
     oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)

@@ -143,7 +143,7 @@ def test_refusals():
     with pytest.raises(NotImplementedError):
         FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, dropout=0.1, **KW)
     with pytest.raises(NotImplementedError):
-        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=32, **KW)
+        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=96, **KW)  # above one 128-column slab tile
     # conv_alpha None: the module falls back to alpha = rank (toolkit/lora_special.py:113-115), i.e. scale 1
     net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, **KW)
     conv = next(x for x in net.unet_loras if x.is_conv3x3)
@@ -226,3 +226,56 @@ def test_optimizer_state_of_conv_adapters_loads_into_the_reference_shapes():
         assert torch.equal(a, b)
     for a, b in zip(net._opt_slices(net.arena_v), net._opt_slices(v0)):
         assert torch.equal(a, b)
+
+
+GH = os.path.join(os.path.dirname(__file__), "golden", "unet_conv_lora_highrank.safetensors")
+
+
+@pytest.mark.parametrize("tag,cfg", [("sdxl", TINY_SDXL), ("sd15", TINY_SD15)])
+def test_conv_rank_above_16_and_linear_rank_above_64_match_the_reference_network(tag, cfg):
+    """Conv adapters of rank 24 / 40 (two / three 16-rank blocks of the split-slab epilogue, slab of rank_pad 32 / 48) and Linear adapters of
+    rank 80 (two skinny launches per product: 64 + 16 ranks of one slab) against the reference's LoRASpecialNetwork run
+    (tests/golden/make_golden.py::golden_unet_conv_lora_highrank): prediction, and every adapter gradient through two fixed random
+    projections + its norm."""
+    with safe_open(GH, "pt") as f:
+        meta = json.loads(f.metadata()["meta"])[tag]
+    t = load_file(GH)
+    lin_r, conv_r = meta["lin_rank"], meta["conv_rank"]
+    torch.manual_seed(0)
+    ref = unet_ref.UNet2DConditionModel(**cfg)
+    unet_ref.init_synthetic_(ref, seed=11)
+    nat = UNet2DConditionModel(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=lin_r, alpha=lin_r / 2, conv_lora_dim=conv_r, conv_alpha=conv_r / 4, **KW)
+    assert [x.lora_name for x in net.unet_loras] == meta["names"] and [x.lora_dim for x in net.unet_loras] == meta["dims"]
+    assert [x.scale for x in net.unet_loras] == meta["scales"]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for x in net.unet_loras:
+            x.lora_up.weight.copy_((torch.randn(tuple(x.lora_up.weight.shape) + ((1, 1) if (x.is_conv1x1 or x.is_conv3x3) else ()), generator=g)
+                                    * 0.05).reshape(x.lora_up.weight.shape))
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    conv = [x for x in net.unet_loras if x.is_conv3x3]
+    assert conv and all(x.rank_pad == (conv_r + 15) // 16 * 16 for x in conv)
+    lat, ts, ctx, added = _inputs(cfg)
+    B, _, H, W = lat.shape
+    with net:
+        pred = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W)
+        got = pred.view(B, H, W, 4).permute(0, 3, 1, 2)
+        assert torch.allclose(got, t[f"{tag}/pred"], rtol=2e-4, atol=2e-5), (got - t[f"{tag}/pred"]).abs().max()
+        net.zero_grad_arena()
+        nat.backward_native(t[f"{tag}/wgt"].permute(0, 2, 3, 1).reshape(B * H * W, 4).contiguous())
+    gp = torch.Generator().manual_seed(123)
+    for x in net.unet_loras:
+        for nm, p_ in (("down", x.lora_down.weight), ("up", x.lora_up.weight)):
+            G = p_.grad.reshape(p_.shape[0], -1)
+            v, u = torch.randn(G.shape[1], generator=gp), torch.randn(G.shape[0], generator=gp)
+            want = t[f"{tag}/grad/{x.lora_name}/{nm}"]
+            mine = torch.cat((G @ v, u @ G, G.norm().reshape(1)))
+            err = ((mine - want).norm() / (want.norm() + 1e-12)).item()
+            assert err < 5e-4, (x.lora_name, nm, err)
