@@ -171,7 +171,6 @@ __device__ __forceinline__ void dma_st64(lds_char* tile, const unsigned (&v)[4],
   }
 }
 
-
 // ---- tr16 reads hipcc does not see (guide §5.7 form ii): the builtin makes SIInsertWaitcnts drain vmcnt (= the in-flight
 // LDS-DMA prefetch of the NEXT tile) before the first transpose read of every iteration; the asm form leaves the prefetch in
 // flight for the whole iteration.  Safe because the tile being read was published by the previous barrier.  The matching
@@ -199,8 +198,25 @@ __device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& h
 }
 
 
+// ---- workgroup -> (row tile, head, batch) with the row tiles of ONE (batch, head) kept on ONE XCD.  The grid is 1-D; the dispatcher places
+// block i on XCD i % 8 (guide "Workgroups, grid, and XCD partitioning"), each XCD has its own 4-MiB L2, and every workgroup of a (batch,
+// head) streams the same K / V (or Q / dO) slice: 2.4 MB at 4608 tokens.  In plain blockIdx order the 36 row tiles of a head are dealt round
+// the 8 XCDs, every L2 sees every head in flight (14 heads x 2.4 MB against 4 MiB) and the slices are re-fetched from the fabric —
+// PMC round 3: 526 MB fetched per B = 1 launch against 85 MB of operands.  Here XCD k works through a contiguous range of the
+// (batch, head, tile) list: ~2 heads in flight per L2.  A performance mapping only: any bijection is correct.
+__device__ __forceinline__ void attn_wg_coords(int ntiles, int H, int& tile, int& hd, int& b) {
+  const int n = gridDim.x, id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int per = n >> 3, rem = n & 7;
+  const int l = xcd * per + min(xcd, rem) + slot;  // XCD k owns per + (k < rem) consecutive list entries
+  tile = l % ntiles;
+  const int r = l / ntiles;
+  hd = r % H;
+  b = r / H;
+}
+
 // ============================================================================================ forward
-// grid (ceil(S/128), H, B); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
+// grid = ceil(S/128) * H * B workgroups (attn_wg_coords); 4 waves x 32 query rows; KV tiles of 64 rows, LDS-DMA double buffer (64 KiB -> 2
 // workgroups per CU, <=256 registers -> 2 waves per SIMD so one workgroup's softmax overlaps the other's MFMAs).
 // Online softmax with deferred rescale (guide T13, threshold 2^8): O/l are only rescaled when the running max grows by
 // more than 8 in the log2 domain; P is then bounded by 2^8 instead of 1, exact in fp32 accumulation.
@@ -215,11 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AitkAttnArgs p) {
   constexpr int FBUF = 16384 + SUBTILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;                        // query rows per batch
   const int Skv = p.Skv > 0 ? p.Skv : p.S;  // key/value rows per batch (cross-attention: Skv != S)
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile_x, hd, b;
+  attn_wg_coords((S + 127) / 128, p.H, tile_x, hd, b);
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
+  const int q0 = tile_x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
   const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AitkAttnArgs p) {
 }
 
 // ============================================================================================ backward: dK, dV
-// grid (ceil(S/128), H, B); wave w owns kv rows [kv0 + 32 w, +32) (K, V fragments in registers, dK/dV accumulators);
+// grid = ceil(Skv/128) * H * B workgroups (attn_wg_coords); wave w owns kv rows [kv0 + 32 w, +32) (K, V fragments in registers, dK/dV accumulators);
 // loops over query tiles of 32 rows staged (Q, dO, L2, delta) in LDS.
 // S[q][kv] = Q K^T (lane owns one kv column), P = exp2(S c2 - L2[q]), dP = dO V^T, dS = P (dP - delta[q]);
 // dV += P^T dO, dK += scale * dS^T Q  (Q/dO consumed via tr16 with the permuted order of the packed P / dS registers).
@@ -378,11 +395,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AitkAttnArgs p) {
   typedef __attribute__((address_space(3))) float lds_float;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;
   const int Skv = p.Skv > 0 ? p.Skv : p.S;
-  const int kvw = blockIdx.x * 128 + wave * 32;
+  int tile_x, hd, b;
+  attn_wg_coords((Skv + 127) / 128, p.H, tile_x, hd, b);
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
+  const int kvw = tile_x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
   const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
@@ -568,10 +586,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
   typedef __attribute__((address_space(3))) float lds_float;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int hd = blockIdx.y, b = blockIdx.z;
   const int S = p.S;
   const int Skv = p.Skv > 0 ? p.Skv : p.S;
-  const int kvw = blockIdx.x * 128 + wave * 32;
+  int tile_x, hd, b;
+  attn_wg_coords((Skv + 127) / 128, p.H, tile_x, hd, b);
+  const int kvw = tile_x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
   const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
@@ -769,7 +788,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
 }
 
 // ============================================================================================ backward: dQ
-// grid (ceil(S/128), H, B); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
+// grid = ceil(S/128) * H * B workgroups (attn_wg_coords); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
 // loops over KV tiles of 64 rows (K, V row-major in LDS).  S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP^T - delta[q]);
 // dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q]  (K through tr16, dS^T straight from registers).
 template <int KS, int DB>
@@ -779,11 +798,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   constexpr int DBUF = 2 * SUBTILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int hd = blockIdx.y, b = blockIdx.z;
-  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
   const int S = p.S;
   const int Skv = p.Skv > 0 ? p.Skv : p.S;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int tile_x, hd, b;
+  attn_wg_coords((S + 127) / 128, p.H, tile_x, hd, b);
+  const int HS = p.hstride > 0 ? p.hstride : 128;  // elements between heads: 128 (padded layout) or the native head width
+  const int q0 = tile_x * 128 + wave * 32;
   const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * HS;
   const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * HS;
   const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * HS;
@@ -940,7 +960,7 @@ static void launch_fwd(const AitkAttnArgs* a, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
+  dim3 grid((unsigned)(((a->S + 127) / 128) * a->H * a->B));  // 1-D: attn_wg_coords deals the (batch, head, tile) list to the XCDs
   hipLaunchKernelGGL((attn_fwd_kernel<KS, DB>), grid, dim3(256), lds, s, *a);
 }
 
@@ -957,8 +977,8 @@ static bool dkdv_pipe_enabled() {
 template <int KS, int DB>
 static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   const int Skv = a->Skv > 0 ? a->Skv : a->S;
-  dim3 grid((a->S + 127) / 128, a->H, a->B);
-  dim3 grid_kv((Skv + 127) / 128, a->H, a->B);
+  dim3 grid((unsigned)(((a->S + 127) / 128) * a->H * a->B));
+  dim3 grid_kv((unsigned)(((Skv + 127) / 128) * a->H * a->B));
   if (KS == 8 && DB == 4 && dkdv_pipe_enabled()) {
     static bool pattr = false;
     if (!pattr) {

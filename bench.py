@@ -416,6 +416,59 @@ def parity_leg(dev):
                     "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
 
 
+def dvfs_leg(one, dev_index, steps=3):
+    """Shader clock and socket power while the step runs (rank 0, AFTER the timed region — never part of `value`): MI355X clocks to its
+    1400-W budget, so the MFMA-bound kernels of this step run well below the 2400 MHz that PEAK_BF16 is quoted at
+    (profiles/r03_clock_power_by_kernel.txt: the 8-phase GEMM alone sits at 1.50-1.75 GHz at 1400 W).  Polls rocm-smi from a thread while
+    `steps` more steps run; returns None when rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+
+    smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if smi is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                r = subprocess.run([smi, "--showclocks", "--showpower", "-d", str(dev_index)], capture_output=True, text=True, timeout=5).stdout
+                c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", r)
+                w = re.search(r"Power \(W\): ([\d.]+)", r)
+                if c and w:
+                    samples.append((int(c.group(1)), float(w.group(1))))
+            except Exception:  # noqa: BLE001 - telemetry is best effort
+                return
+            stop.wait(0.05)
+
+    cap = None
+    try:
+        r = subprocess.run([smi, "--showmaxpower", "-d", str(dev_index)], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", r)
+        cap = float(m.group(1)) if m else None
+    except Exception:  # noqa: BLE001
+        pass
+    one()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join(timeout=6)
+    if len(samples) < 4:
+        return None
+    clk, pw = sorted(c for c, _ in samples), sorted(w for _, w in samples)
+    return {"sclk_mhz": {"median": clk[len(clk) // 2], "min": clk[0], "max": clk[-1]}, "power_w": {"median": pw[len(pw) // 2], "max": pw[-1]},
+            "power_cap_w": cap, "samples": len(samples), "ms_per_step_while_polling": 1e3 * dt / steps,
+            "note": "rocm-smi polled from a thread during extra steps after the timed region; the roofline peak is quoted at 2400 MHz"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -436,6 +489,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")
+    ap.add_argument("--no-dvfs", action="store_true", help="skip the clock / power telemetry leg (3 extra steps under rocm-smi polling)")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
     if args.fp8_mfma:
@@ -541,6 +595,12 @@ def main():
         rf = gemm_roofline(one, ops)  # every rank runs the instrumented step (it contains the gradient all-reduce)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
+    if rank == 0 and not args.no_dvfs:
+        tele = dvfs_leg(one, local_rank)
+        if tele is not None:
+            out["dvfs"] = tele
+    if world > 1:
+        torch.distributed.barrier()
 
     extras = world == 1 and not args.no_extras and not args.fp8_base and args.network == "lora"
     failed_legs = []
@@ -635,6 +695,9 @@ def main():
                                "frac": rf["tflops"] / (PEAK_FP8 if args.fp8_mfma else PEAK_BF16),
                                "traffic": None, "launches_per_step": rf["launches"], "avg_launch_us": rf["avg_launch_us"],
                                "gemm_ms_per_step": rf["gemm_ms_per_step"]}
+            if out.get("dvfs"):  # the same rate against the MFMA peak at the clock the step sustained (step median: the GEMMs alone clock lower)
+                clk = out["dvfs"]["sclk_mhz"]["median"]
+                out["roofline"]["frac_at_step_clock"] = out["roofline"]["achieved"] / (out["roofline"]["peak"] * clk / 2400.0)
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) for the dominant shape (B * 4608) x 3072 x 3072 (+ LoRA slab): newest round first
             for pmc in (os.path.join(ROOT, "profiles", "r03_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"),

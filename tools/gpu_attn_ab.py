@@ -42,7 +42,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     bw = t(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc))
     fl = 4.0 * S * S * 128 * B * H
     # bit-level fingerprint of the gradients (identical accumulation order in every valid build => identical bits)
-    chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (dq, dk, dv)]
+    chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (o, dq, dk, dv)]
     print("RESULT", json.dumps({"fwd_ms": round(fw, 3), "bwd_ms": round(bw, 3), "fwd_tflops": round(fl / fw / 1e9, 1),
                                 "bwd_tflops_alg": round(2.5 * fl / bw / 1e9, 1), "chk": chk}))
 else:
