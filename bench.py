@@ -364,12 +364,17 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
-        for pr in procs:
-            code = pr.wait()
-            if code != 0 and rc == 0:
-                rc = code
-                for other in procs:  # a dead rank leaves the others blocked in a collective: stop exactly the children we started
-                    if other.poll() is None:
+        live = list(procs)
+        while live:  # poll every child: the rank that dies is rarely the one a sequential wait() would be sitting on
+            time.sleep(0.2)
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in live:  # a dead rank leaves the others blocked in a collective: stop exactly the children we started
                         other.terminate()
     except KeyboardInterrupt:
         for pr in procs:

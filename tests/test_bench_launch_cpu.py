@@ -28,3 +28,40 @@ def test_self_launch_stops_at_the_device_check_on_a_cpu_box():
 def test_launcher_world_size_mismatch_is_refused():
     r = _run({"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_self_launch_spawns_one_child_per_rank_and_stops_the_rest_when_one_dies(monkeypatch, tmp_path):
+    """self_launch with the device count and the child command stubbed: every rank gets the torchrun environment contract, the exit code of
+    the rank that fails is returned, and the ranks still running (they would sit in a collective forever) are terminated."""
+    import importlib.util
+    import time
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 3)
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0 and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        f"open(os.path.join({str(tmp_path)!r}, f'rank{{r}}'), 'w').write(os.environ['MASTER_PORT'])\n"
+        "if r == 1:\n"
+        "    time.sleep(0.5)\n"
+        "    sys.exit(7)\n"
+        "time.sleep(60)\n")
+    real_popen = subprocess.Popen
+
+    def fake_popen(cmd, env=None, **kw):
+        return real_popen([sys.executable, str(child)], env=env, **kw)
+
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    t0 = time.time()
+    rc = bench.self_launch(3)
+    assert rc == 7 and time.time() - t0 < 30  # the sleeping ranks were stopped, not waited for
+    ports = {open(tmp_path / f"rank{r}").read() for r in range(3)}
+    assert len(ports) == 1  # one rendezvous port for the job
