@@ -238,6 +238,7 @@ def lib():
     L.aitk_adamw_workspace_bytes.restype = C.c_int64
     L.aitk_adamw_workspace_bytes.argtypes = [i64]
     L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]
+    L.aitk_slab_rescale.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, vp]
     L.aitk_gemm_nt_grouped.argtypes = [vp, vp, vp]
     L.aitk_lokr_lowrank_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.aitk_groupnorm_workspace_bytes.restype = C.c_int64

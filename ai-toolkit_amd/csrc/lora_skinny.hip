@@ -289,6 +289,46 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// slab_rescale: T[m] = split( (T_hi + T_lo)[m][r] * rowf[m / rows_per_batch] * tmask[m / tmask_rows_per_batch][r] ) in place on a
+// [hi(rp) | lo(rp) | hi(rp)] slab.  The rank-space activation of a 3x3-conv adapter leaves the implicit-GEMM epilogue with a uniform scale;
+// per-sample multipliers (network.multiplier as a list) and the dropout / rank_dropout masks (toolkit/network_mixins.py:211-229) are row /
+// element factors on lx, applied here on the fp32 value before it is split again (aitk_lora_down does the same inside its epilogue).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_rescale_kernel(bf16_t* T, long ldt, int M, int rp, const float* rowf, int rows_per_batch, const float* tmask,
+                                                           int tmask_rows_per_batch) {
+  const int per_row = rp / 4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * per_row) return;
+  const int m = (int)(idx / per_row), rr = (int)(idx - (long)m * per_row) * 4;
+  bf16_t* row = T + (long)m * ldt + rr;
+  const uint2 hi = *reinterpret_cast<const uint2*>(row), lo = *reinterpret_cast<const uint2*>(row + rp);
+  float v[4] = {bf_lo(hi.x) + bf_lo(lo.x), bf_hi(hi.x) + bf_hi(lo.x), bf_lo(hi.y) + bf_lo(lo.y), bf_hi(hi.y) + bf_hi(lo.y)};
+  const float f = rowf ? rowf[m / rows_per_batch] : 1.f;
+  const float* tm = tmask ? tmask + (long)(tmask_rows_per_batch > 0 ? m / tmask_rows_per_batch : m) * rp + rr : nullptr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= tm ? f * tm[e] : f;
+  uint2 h2, l2;
+  h2.x = pack2bf(v[0], v[1]);
+  h2.y = pack2bf(v[2], v[3]);
+  l2.x = pack2bf(v[0] - bf_lo(h2.x), v[1] - bf_hi(h2.x));
+  l2.y = pack2bf(v[2] - bf_lo(h2.y), v[3] - bf_hi(h2.y));
+  *reinterpret_cast<uint2*>(row) = h2;
+  *reinterpret_cast<uint2*>(row + rp) = l2;
+  *reinterpret_cast<uint2*>(row + 2 * rp) = h2;
+}
+
+extern "C" int aitk_slab_rescale(aitk_bf16* T, int64_t ldt, int32_t M, int32_t rp, const float* rowf, int32_t rows_per_batch, const float* tmask,
+                                 int32_t tmask_rows_per_batch, aitk_stream_t stream) {
+  if (!T || M <= 0 || rp <= 0 || (rp % 4) || ldt < 3 * rp || (ldt % 4)) return AITK_ERR_SHAPE;
+  if ((rowf && rows_per_batch <= 0) || tmask_rows_per_batch < 0 || (!rowf && !tmask)) return AITK_ERR_ARG;
+  const long n = (long)M * (rp / 4);
+  hipLaunchKernelGGL(slab_rescale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)T, (long)ldt, M, rp, rowf,
+                     rows_per_batch, tmask, tmask_rows_per_batch);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // lora_wgrad: grid = (L/128 column tiles, row chunks of WG_MC rows).  Per 64-row sub-tile the block stages
 // G[64][128] and S[64][R] row-major into LDS and runs v_mfma_f32_16x16x32_bf16 with BOTH operands read through
 // ds_read_b64_tr_b16 (the contraction index is the tile row).  Chunk partials go to `partial`

@@ -51,8 +51,6 @@ class LoRAModule(nn.Module):
         self.is_conv3x3 = bool(getattr(org_module, "is_conv3x3", False))
         if self.is_conv3x3:
             assert org_module.cin_pad == org_module.in_channels and org_module.cout_pad == org_module.out_channels
-            if dropout or rank_dropout or module_dropout:
-                raise NotImplementedError("dropout variants on 3x3-conv adapters are not on the fused path")
             self.conv_cin, self.conv_stride = org_module.in_channels, org_module.stride
             in_dim, out_dim = org_module.in_channels * 9, org_module.out_channels
         else:

@@ -262,6 +262,19 @@ def _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo,
     return out
 
 
+def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_per_batch=0, M=None):
+    """In place on the [hi | lo | hi] slab T [M, 3 rp]: value * mult[m // rows_per_batch] * tmask[m // tmask_rows_per_batch][r], split again
+    (a conv adapter's per-sample multiplier / dropout masks: its lora_down comes out of the convolution epilogue with a uniform scale)."""
+    assert T.dtype == BF16 and T.shape[1] >= 3 * rp
+    if mult is not None:
+        assert mult.dtype == torch.float32 and mult.is_contiguous() and rows_per_batch > 0
+    if tmask is not None:
+        assert tmask.dtype == torch.float32 and tmask.is_contiguous() and tmask.shape[1] == rp
+    _call("aitk_slab_rescale", _ptr(T), _row_major(T, "T"), T.shape[0] if M is None else M, rp, _ptr(mult), int(rows_per_batch), _ptr(tmask),
+          int(tmask_rows_per_batch))
+    return T
+
+
 def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
     """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad).
     split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo.

@@ -343,13 +343,9 @@ class UNet2DConditionModel(FusedGraphBase):
 
     # ------------------------------------------------------------------ kernel-level graph helpers (each records its backward)
     def _conv_scale(self, lo):
-        """fp32 [2 rank_pad] column scale of a conv adapter's lora_down launch: runtime scale * network multiplier (uniform: the implicit-GEMM
-        epilogue has no per-row factor, so per-sample multipliers — slider training — are refused for 3x3-conv adapters)."""
-        mv = self.network._multiplier
-        vals = [float(v) for v in mv] if isinstance(mv, (list, tuple)) else [float(mv)]
-        if max(vals) != min(vals):
-            raise NotImplementedError("3x3-conv adapters with per-sample multipliers are not on the fused path")
-        c = lo.scale * vals[0]
+        """fp32 [2 rank_pad] column scale of a conv adapter's lora_down launch: the runtime scale.  The network multiplier (one number or one
+        per sample — slider training) is a row factor the implicit-GEMM epilogue cannot apply: aitk_slab_rescale multiplies the rows of T."""
+        c = lo.scale
         cached = getattr(lo, "_cs", None)
         if cached is None or cached[0] != c or cached[1].device != self._device():
             cached = (c, torch.full((2 * lo.rank_pad,), c, dtype=torch.float32, device=self._device()))
@@ -371,16 +367,24 @@ class UNet2DConditionModel(FusedGraphBase):
         y = self._new(Mo, conv.cout_pad)
         lo = conv.lora if self._lora_active(conv) else None
         T, kw = None, {}
+        # dropout / rank_dropout / module_dropout of the adapter (toolkit/network_mixins.py:198-229), training mode only
+        plan = self.network.dropout_plan(lo, M=Mo, rows_per_batch=Ho * Wo, B=B) if lo is not None else None
+        if plan == "skip":
+            lo = None
+        tm, tm_rpb = plan if isinstance(plan, tuple) else (None, 0)
         if lo is not None:
             T = self._new(Mo, 3 * lo.rank_pad)
             ops.conv3x3(x, lo.sh_down_stack, T, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, split_slab=True, col_scale=self._conv_scale(lo))
+            mult, rpb = self._mult(Ho * Wo, B)
+            if mult is not None or tm is not None:  # row factors the convolution epilogue cannot apply
+                ops.slab_rescale(T, lo.rank_pad, mult=mult, rows_per_batch=rpb, tmask=tm, tmask_rows_per_batch=tm_rpb, M=Mo)
             kw = dict(a2=T, b2=lo.sh_up3)
         ops.conv3x3(x, conv.wk, y, B=B, H=H, W=W, stride=s, Ho=Ho, Wo=Wo, bias=conv.bias_k, flags=EPI_ADD_AUX if res is not None else 0,
                     aux_in=res, **kw)
         if tape.needs(x, res) or T is not None:
             need_x = tape.needs(x)
 
-            def bwd(dy, x=x, res=res, T=T):
+            def bwd(dy, x=x, res=res, T=T, lo=lo, tm=tm, tm_rpb=tm_rpb):
                 if res is not None:
                     tape.acc(res, dy, False)
                 if not need_x and T is None:
@@ -391,7 +395,8 @@ class UNet2DConditionModel(FusedGraphBase):
                     rp = lo.rank_pad
                     dT = self._new(Mo, 3 * rp)
                     mult, rpb = self._mult(Ho * Wo, B)
-                    ops.lora_down(g, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=Mo, p_lo=lo.sh_upT_lo, split=rp)
+                    ops.lora_down(g, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=Mo, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
+                                  tmask_rows_per_batch=tm_rpb)
                     ops.lora_wgrad(T, g, lo.g_up, transpose_out=True, accumulate=True, M=Mo, split=rp)
                 if s == 2:  # zero insertion to the input grid (even H, W: pad 1 / stride 2 maps 2Ho x 2Wo back to H x W)
                     if need_x:

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 5 /* 5: AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 5 /* 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -154,6 +154,12 @@ typedef struct AitkLoraWgradArgs {
 } AitkLoraWgradArgs;
 int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t L);
 int aitk_lora_wgrad(const AitkLoraWgradArgs* args, aitk_stream_t stream);
+/* In place on a [hi(rp) | lo(rp) | hi(rp)] slab T [M, >= 3 rp]: (hi + lo)[m][r] * rowf[m / rows_per_batch] * tmask[m / tmask_rows_per_batch][r],
+ * split again (rowf / tmask may be NULL, not both; tmask fp32 [rows, rp], tmask_rows_per_batch 0 = one mask row per slab row).  The per-sample
+ * multiplier and the dropout / rank_dropout masks of a 3x3-conv adapter's rank-space activation, whose lora_down leaves the implicit-GEMM
+ * epilogue with a uniform scale (toolkit/network_mixins.py:211-229, 235-239 on toolkit/lora_special.py:95-104 modules). */
+int aitk_slab_rescale(aitk_bf16* T, int64_t ldt, int32_t M, int32_t rp, const float* rowf, int32_t rows_per_batch, const float* tmask,
+                      int32_t tmask_rows_per_batch, aitk_stream_t stream);
 
 
 /* ---- adaLN LayerNorm + modulate: out = LN(x; eps, no affine) * (1 + scale[b]) + shift[b],  b = m / rows_per_batch.

@@ -50,13 +50,19 @@ class RefLoRAModule(nn.Module):
         lx = self.lora_down(x.to(self.lora_down.weight.dtype))
         scale = self.scale
         if prov is not None and cfg.get("dropout"):
-            flat = lx.reshape(-1, self.lora_dim)
+            # F.dropout draws one number per element; the keyed provider hands them out as [positions, rank] with positions in (b, y, x)
+            # order for a Conv2d's [B, r, H, W] activation
+            chan_last = lx.permute(0, 2, 3, 1) if lx.dim() == 4 else lx
+            flat = chan_last.reshape(-1, self.lora_dim)
             keep = (prov(self.lora_name, "dropout", tuple(flat.shape), x.device) >= cfg["dropout"]).to(lx.dtype) / (1.0 - cfg["dropout"])
-            lx = (flat * keep).reshape(lx.shape)
+            flat = (flat * keep).reshape(chan_last.shape)
+            lx = flat.permute(0, 3, 1, 2) if lx.dim() == 4 else flat
         if prov is not None and cfg.get("rank_dropout"):
             mask = (prov(self.lora_name, "rank", (lx.size(0), self.lora_dim), x.device) > cfg["rank_dropout"]).to(lx.dtype)
             if lx.dim() == 3:
                 mask = mask.unsqueeze(1)
+            elif lx.dim() == 4:  # Conv2d (toolkit/network_mixins.py:223-224)
+                mask = mask.unsqueeze(-1).unsqueeze(-1)
             lx = lx * mask
             scale = scale * (1.0 / (1.0 - cfg["rank_dropout"]))
         lx = self.lora_up(lx) * scale
@@ -183,22 +189,30 @@ class RefLoRANetwork(nn.Module):
     """PEFT-format transformer network: module discovery + naming of toolkit/lora_special.py:457-647 (flux branch)."""
 
     def __init__(self, unet, lora_dim, multiplier=1.0, target=("FluxTransformer2DModel",), block_names=("transformer_blocks",),
-                 network_type="lora", lokr_factor=-1, kohya_unet=False, alpha=None):
+                 network_type="lora", lokr_factor=-1, kohya_unet=False, alpha=None, conv_lora_dim=None, conv_alpha=None):
         """kohya_unet: the UNet branch of toolkit/lora_special.py:457-647 — prefix lora_unet, dots -> underscores, Linear and 1x1
-        Conv2d children of every `target` module (Transformer2DModel), no block filter, alpha as configured (scale = alpha / rank)."""
+        Conv2d children of every `target` module (Transformer2DModel), no block filter, alpha as configured (scale = alpha / rank).
+        conv_lora_dim (network.conv; lora_special.py:381-382, 585-590, toolkit/kohya_lora.py:750-751): the ResnetBlock2D / Downsample2D /
+        Upsample2D modules are targets too, and 3x3 Conv2d children are wrapped at conv_lora_dim / conv_alpha."""
         super().__init__()
         self.is_active = False
         self.torch_multiplier = torch.tensor([float(multiplier)])
         self.unet_loras = []
+        if kohya_unet and conv_lora_dim:
+            target = tuple(target) + ("ResnetBlock2D", "Downsample2D", "Upsample2D")
         for name, module in unet.named_modules():
             if module.__class__.__name__ not in target:
                 continue
             for child_name, child in module.named_modules():
                 if kohya_unet:
-                    if not (child.__class__.__name__ == "Linear" or (child.__class__.__name__ == "Conv2d" and child.kernel_size == (1, 1))):
+                    is_conv = child.__class__.__name__ == "Conv2d"
+                    if not (child.__class__.__name__ == "Linear" or (is_conv and (child.kernel_size == (1, 1) or conv_lora_dim))):
                         continue
                     lora_name = ".".join([x for x in ("lora_unet", name, child_name) if x]).replace(".", "_")
-                    self.unet_loras.append(RefLoRAModule(lora_name, child, lora_dim, lora_dim if alpha is None else alpha, self))
+                    dim, al = lora_dim, (lora_dim if alpha is None else alpha)
+                    if is_conv and child.kernel_size != (1, 1):
+                        dim, al = conv_lora_dim, (conv_lora_dim if conv_alpha is None else conv_alpha)
+                    self.unet_loras.append(RefLoRAModule(lora_name, child, dim, al, self))
                     continue
                 if child.__class__.__name__ != "Linear":
                     continue

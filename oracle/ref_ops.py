@@ -135,6 +135,22 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     return out
 
 
+def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_per_batch=0, M=None):
+    """LoRAModule._call_forward's dropout / rank_dropout masks and forward()'s per-sample multiplier on the rank-space activation of a
+    conv adapter (toolkit/network_mixins.py:211-229, 235-239), applied to the fp32 value of the [hi | lo | hi] slab."""
+    M = T.shape[0] if M is None else M
+    v = T[:M, :rp].float() + T[:M, rp:2 * rp].float()
+    rows = torch.arange(M, device=T.device)
+    if mult is not None:
+        v = v * mult.float()[rows // rows_per_batch][:, None]
+    if tmask is not None:
+        v = v * (tmask.float()[rows // tmask_rows_per_batch] if tmask_rows_per_batch > 0 else tmask.float()[:M])
+    hi = v.to(T.dtype)
+    lo = (v - hi.float()).to(T.dtype)
+    T[:M, :3 * rp] = torch.cat((hi, lo, hi), dim=1)
+    return T
+
+
 def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
     """autograd of lora_down / lora_up weights (split: s is the slab layout, read as hi + lo); out_strides: strided destination
     (one tap of a conv adapter's [r, Cin, 3, 3] gradient)."""

@@ -135,9 +135,31 @@ def _rel_lists(a, b):
     return math.sqrt(num / max(den, 1e-300))
 
 
-@pytest.mark.parametrize("sdxl,lin_r,conv_r", [(False, 8, 4), (True, 8, 4), (True, 80, 24), (False, 8, 40)],
-                         ids=["sd15", "sdxl", "sdxl-lin80-conv24", "sd15-conv40"])
-def test_unet_step_with_conv_adapters(sdxl, lin_r, conv_r):
+@pytest.mark.parametrize("M,rp,rpb,tm_rpb", [(1000, 16, 250, 0), (777, 48, 0, 111), (640, 32, 160, 160)])
+def test_slab_rescale_vs_oracle(M, rp, rpb, tm_rpb):
+    """aitk_slab_rescale: per-sample row factor and dropout / rank masks on a conv adapter's [hi | lo | hi] slab, in place."""
+    from ai_toolkit_amd import ops
+    from oracle import ref_ops
+
+    v = R(M, rp, s=0.7, seed=3)
+    hi = v.to(bf)
+    lo = (v - hi.float()).to(bf)
+    T0 = torch.cat((hi, lo, hi, torch.full((M, 8), 5.0).to(bf)), 1).cuda()  # 8 guard columns behind the slab
+    mult = torch.tensor([1.0, -0.5, 2.0, 0.25, 3.0][: (M + rpb - 1) // rpb], device="cuda") if rpb else None
+    nrows = (M + tm_rpb - 1) // tm_rpb if tm_rpb else M
+    tmask = ((R(nrows, rp, seed=4) > 0).float() / 0.5).cuda() if (tm_rpb or rpb == 250) else None
+    a, b = T0.clone(), T0.clone()
+    ops.slab_rescale(a, rp, mult=mult, rows_per_batch=rpb, tmask=tmask, tmask_rows_per_batch=tm_rpb, M=M)
+    ref_ops.slab_rescale(b, rp, mult=mult, rows_per_batch=rpb, tmask=tmask, tmask_rows_per_batch=tm_rpb, M=M)
+    torch.cuda.synchronize()
+    assert torch.equal(a[:, 3 * rp:], T0[:, 3 * rp:])
+    va, vb = a[:, :rp].float() + a[:, rp:2 * rp].float(), b[:, :rp].float() + b[:, rp:2 * rp].float()
+    assert rel(va, vb) < 1e-6 and torch.equal(a[:, :rp], a[:, 2 * rp:3 * rp]) and rel(a[:, :rp], b[:, :rp]) < 1e-6
+
+
+@pytest.mark.parametrize("sdxl,lin_r,conv_r,drop", [(False, 8, 4, False), (True, 8, 4, False), (True, 80, 24, False), (False, 8, 40, False), (True, 8, 8, True)],
+                         ids=["sd15", "sdxl", "sdxl-lin80-conv24", "sd15-conv40", "sdxl-dropout-per-sample-multipliers"])
+def test_unet_step_with_conv_adapters(sdxl, lin_r, conv_r, drop):
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.lora import FusedLoRANetwork
@@ -157,8 +179,16 @@ def test_unet_step_with_conv_adapters(sdxl, lin_r, conv_r):
         nat = UNet2DConditionModel(**cfg, dtype=dtype, device=dev, ops=table)
         nat.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
         torch.manual_seed(99)
+        dkw = dict(dropout=0.1, rank_dropout=0.25, module_dropout=0.1) if drop else {}
         net = FusedLoRANetwork(nat, lora_dim=lin_r, alpha=lin_r / 2, conv_lora_dim=conv_r, conv_alpha=conv_r / 2, target_lin_modules=("Transformer2DModel",),
-                               is_transformer=False, peft_format=False, transformer_only=False)
+                               is_transformer=False, peft_format=False, transformer_only=False, **dkw)
+        if drop:  # one keyed source of uniforms for both graphs; training mode; one multiplier per sample (slider training)
+            import hashlib
+
+            net.mask_provider = lambda name, kind, shape, device: torch.rand(
+                shape, generator=torch.Generator().manual_seed(int(hashlib.sha256(f"{name}/{kind}".encode()).hexdigest()[:8], 16))).to(
+                "cpu" if kind == "module" else device)
+            net.train()
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():
             for m in net.unet_loras:
@@ -174,6 +204,10 @@ def test_unet_step_with_conv_adapters(sdxl, lin_r, conv_r):
     r32, r32_net = make(ref_ops, torch.float32, shadow_dtype=torch.float32)
     assert any(m.is_conv3x3 for m in net.unet_loras) and [m.lora_name for m in net.unet_loras] == [m.lora_name for m in r32_net.unet_loras]
     lat, ctx, pooled, noise, ts = _batch(cfg)
+    if drop:
+        mult = [1.0, -0.5, 0.75, 1.5][: lat.shape[0]]
+        net.multiplier = mult
+        r32_net.multiplier = mult
     kw = dict(lr=0.0, weight_decay=0.0, max_grad_norm=0.0, min_snr_gamma=5.0)
     l32 = UNetLoRATrainStep(r32, r32_net, ref_ops, **kw).step(lat.float(), ctx.float(), pooled.float(), noise=noise.float(), timesteps=ts).item()
     lo = UNetLoRATrainStep(nat, net, ops, **kw).step(lat, ctx, pooled, noise=noise, timesteps=ts).item()

@@ -141,8 +141,6 @@ def test_refusals():
     with pytest.raises(NotImplementedError):
         FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, network_type="dora", **KW)
     with pytest.raises(NotImplementedError):
-        FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=2, dropout=0.1, **KW)
-    with pytest.raises(NotImplementedError):
         FusedLoRANetwork(nat, lora_dim=4, conv_lora_dim=96, **KW)  # above one 128-column slab tile
     # conv_alpha None: the module falls back to alpha = rank (toolkit/lora_special.py:113-115), i.e. scale 1
     net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, **KW)
@@ -279,3 +277,78 @@ def test_conv_rank_above_16_and_linear_rank_above_64_match_the_reference_network
             mine = torch.cat((G @ v, u @ G, G.norm().reshape(1)))
             err = ((mine - want).norm() / (want.norm() + 1e-12)).item()
             assert err < 5e-4, (x.lora_name, nm, err)
+
+
+@pytest.mark.parametrize("per_sample", [False, True], ids=["dropout", "dropout+per-sample-multipliers"])
+def test_conv_adapters_with_dropout_variants_and_per_sample_multipliers_match_the_oracle(per_sample):
+    """network.conv adapters under dropout / rank_dropout / module_dropout (toolkit/network_mixins.py:198-229: the rank mask of a Conv2d
+    activation is [B, r, 1, 1]) and under a per-sample multiplier list (slider training): the convolution epilogue carries the runtime scale
+    only, aitk_slab_rescale applies the row factor and the masks to the rank-space activation, aitk_lora_down applies them to its gradient.
+    Oracle = the restated LoRAModule on nn.Conv2d (oracle/lora_ref.py) under autograd; both sides draw from one keyed provider."""
+    import hashlib
+
+    from oracle import lora_ref
+
+    def provider(name, kind, shape, device):
+        seed = int(hashlib.sha256(f"{name}/{kind}".encode()).hexdigest()[:8], 16)
+        return torch.rand(shape, generator=torch.Generator().manual_seed(seed))
+
+    cfg = TINY_SDXL
+    torch.manual_seed(0)
+    ref = unet_ref.UNet2DConditionModel(**cfg)
+    unet_ref.init_synthetic_(ref, seed=11)
+    nat = UNet2DConditionModel(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    drop = dict(dropout=0.1, rank_dropout=0.25, module_dropout=0.15)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=4, alpha=2.0, conv_lora_dim=8, conv_alpha=4.0, **drop, **KW)
+    net.mask_provider = provider
+    ref_net = lora_ref.RefLoRANetwork(ref, 4, target=("Transformer2DModel",), kohya_unet=True, alpha=2.0, conv_lora_dim=8, conv_alpha=4.0)
+    ref_net.dropout_cfg, ref_net.mask_provider = drop, provider
+    assert [m.lora_name for m in net.unet_loras] == [m.lora_name for m in ref_net.unet_loras]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            b.lora_up.weight.copy_(torch.randn(b.lora_up.weight.shape, generator=g) * 0.05)
+            b.lora_down.weight.copy_(a.lora_down.weight.reshape(b.lora_down.weight.shape))
+            a.lora_up.weight.copy_(b.lora_up.weight.reshape(a.lora_up.weight.shape))
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.prepare()
+    lat, ts, ctx, added = _inputs(cfg)
+    B, _, H, W = lat.shape
+    if per_sample:
+        mult = [1.0, -0.5][:B] if B <= 2 else [1.0, -0.5] * (B // 2)
+        net.multiplier = mult
+        ref_net.torch_multiplier = torch.tensor(mult)
+    conv3 = [m for m in net.unet_loras if m.is_conv3x3]
+    skipped = [m.lora_name for m in conv3 if float(provider(m.lora_name, "module", (1,), "cpu")) < drop["module_dropout"]]
+    assert conv3 and 0 < len(skipped) < len(conv3)
+    wgt = torch.randn(B, 4, H, W, generator=torch.Generator().manual_seed(11))
+    preds = {}
+    for mode in ("train", "eval"):
+        getattr(ref_net, mode)()
+        getattr(net, mode)()
+        for p_ in ref_net.parameters():
+            p_.grad = None
+        with ref_net:
+            pred_ref = ref(lat, ts, ctx, added)
+            (pred_ref * wgt).sum().backward()
+        with net:
+            pred = nat.forward_native(_nhwc8(lat), ts, ctx, added, B=B, H=H, W=W)
+            got = pred.view(B, H, W, 4).permute(0, 3, 1, 2)
+            assert torch.allclose(got, pred_ref, rtol=2e-4, atol=2e-5), (mode, (got - pred_ref).abs().max())
+            net.zero_grad_arena()
+            nat.backward_native(wgt.permute(0, 2, 3, 1).reshape(B * H * W, 4).contiguous())
+        preds[mode] = got.detach().clone()
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            if mode == "train" and b.lora_up.weight.grad is None:  # module_dropout fired
+                assert float(a.lora_up.weight.grad.abs().max()) == 0.0 and float(a.lora_down.weight.grad.abs().max()) == 0.0, a.lora_name
+                continue
+            for x, y, nm in ((a.lora_down.weight.grad, b.lora_down.weight.grad, "down"), (a.lora_up.weight.grad, b.lora_up.weight.grad, "up")):
+                err = ((x.reshape(-1) - y.reshape(-1)).norm() / (y.norm() + 1e-12)).item()
+                assert err < 5e-4, (mode, a.lora_name, nm, err)
+    assert not torch.allclose(preds["train"], preds["eval"], rtol=1e-3, atol=1e-4)  # the masks are live in training mode
