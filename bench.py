@@ -421,18 +421,22 @@ def parity_leg(dev):
                     "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
 
 
-def dvfs_leg(one, dev_index, steps=3):
+def dvfs_leg(one, dev_index, steps=3, poll_here=True):
     """Shader clock and socket power while the step runs (rank 0, AFTER the timed region — never part of `value`): MI355X clocks to its
     1400-W budget, so the MFMA-bound kernels of this step run well below the 2400 MHz that PEAK_BF16 is quoted at
     (profiles/r03_clock_power_by_kernel.txt: the 8-phase GEMM alone sits at 1.50-1.75 GHz at 1400 W).  Polls rocm-smi from a thread while
-    `steps` more steps run; returns None when rocm-smi is not there."""
+    `steps` more steps run; returns None when rocm-smi is not there.  Under data parallelism EVERY rank runs the extra steps (they contain
+    the gradient all-reduce); only the rank with poll_here polls."""
     import re
     import shutil
     import subprocess
     import threading
 
     smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
-    if smi is None:
+    if smi is None or not poll_here:
+        for _ in range(steps + 1):  # the same number of steps as the polling rank
+            one()
+        torch.cuda.synchronize()
         return None
     samples, stop = [], threading.Event()
 
@@ -600,8 +604,8 @@ def main():
         rf = gemm_roofline(one, ops)  # every rank runs the instrumented step (it contains the gradient all-reduce)
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
-    if rank == 0 and not args.no_dvfs:
-        tele = dvfs_leg(one, local_rank)
+    if not args.no_dvfs:
+        tele = dvfs_leg(one, local_rank, poll_here=rank == 0)
         if tele is not None:
             out["dvfs"] = tele
     if world > 1:
