@@ -310,6 +310,11 @@ class FusedLoRANetwork(nn.Module):
             target_lin_modules = tuple(target_lin_modules) + tuple(target_conv_modules)
         # toolkit/lora_special.py:403-408
         module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]
+        if network_type.lower() == "dora" and lora_dim > 64:
+            raise NotImplementedError("DoRA ranks above 64 are not on the fused path (aitk_dora_colscale holds one output channel's rank row per "
+                                      "thread, R <= 64); plain LoRA runs any rank in 64-rank chunks")
+        if (dropout or rank_dropout or module_dropout) and lora_dim > 64:
+            raise NotImplementedError("dropout variants at ranks above 64 are not on the fused path (the mask rides inside one aitk_lora_down launch)")
         module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
         self.lora_dim = lora_dim
         self.network_type = network_type
