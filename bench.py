@@ -351,6 +351,8 @@ def self_launch(n):
     import subprocess
 
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("AITK_BENCH_ONE_DEVICE") and have >= 1:
+        have = n  # control-flow rehearsal of the N-rank run on one GPU (every rank on device 0, gloo transport): not a measurement
     if have < n:
         sys.stderr.write(f"bench.py --gpus {n}: {have} GPU(s) visible on this host, {n} needed\n")
         return 2
@@ -511,6 +513,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with nproc-per-node {args.gpus} (or unset WORLD_SIZE to self-launch)")
+    # A run with a process group keeps stdout for the ONE JSON line: RCCL prints a version banner (and gloo its connection lines) on
+    # file descriptor 1 from C — everything written to fd 1 from here on goes to stderr, the JSON line is written to the saved descriptor
+    json_fd = None
+    if world > 1 or os.environ.get("AITK_BENCH_FORCE_PG"):
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+    one_device = bool(os.environ.get("AITK_BENCH_ONE_DEVICE"))  # rehearsal: all ranks share device 0 (needs AITK_BENCH_BACKEND=gloo)
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -519,10 +531,16 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("AITK_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only for the one-device rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     if args.model != "flux":
+        if json_fd is not None:  # the UNet legs are single-GPU and print their own line
+            os.dup2(json_fd, 1)
         bench_unet(args, dev)
         return
 
@@ -593,6 +611,9 @@ def main():
         out["rccl"] = {"ranks": torch.distributed.get_world_size(pg), "backend": torch.distributed.get_backend(pg),
                        "allreduce_bytes_per_step": 4 * net.arena_g.numel(), "pieces": 2,
                        "ms_per_step_by_rank": per_rank_ms}
+        if one_device:
+            out["rccl"]["rehearsal"] = "AITK_BENCH_ONE_DEVICE: every rank on device 0 — control flow only, `value` is NOT a multi-GPU measurement"
+            out["data"] += " [one-device rehearsal, not a measurement]"
     if step.collect_dp_timing and step.dp_wait_events:
         waits = [a.elapsed_time(b) for a, b in step.dp_wait_events]
         out["allreduce_ms_exposed"] = {"median": _pct(waits, 0.5), "p90": _pct(waits, 0.9), "n": len(waits),
@@ -745,8 +766,12 @@ def main():
     if failed_legs:
         out["legs_out_of_memory"] = failed_legs
     if rank == 0:
-        _flush_c_stdio()  # RCCL prints its version banner through C stdio: with stdout redirected to a file it would otherwise land BEHIND the JSON line
-        print(json.dumps(out), flush=True)
+        _flush_c_stdio()
+        sys.stdout.flush()
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
