@@ -204,15 +204,27 @@ __device__ __forceinline__ s16x8_t join_lohi(const s16x4_t& lo, const s16x4_t& h
 // the 8 XCDs, every L2 sees every head in flight (14 heads x 2.4 MB against 4 MiB) and the slices are re-fetched from the fabric —
 // PMC round 3: 526 MB fetched per B = 1 launch against 85 MB of operands.  Here XCD k works through a contiguous range of the
 // (batch, head, tile) list: ~2 heads in flight per L2.  A performance mapping only: any bijection is correct.
-__device__ __forceinline__ void attn_wg_coords(int ntiles, int H, int& tile, int& hd, int& b) {
-  const int n = gridDim.x, id = blockIdx.x;
+__host__ __device__ __forceinline__ void attn_wg_coords_of(int n, int id, int ntiles, int H, int& tile, int& hd, int& b) {
   const int xcd = id & 7, slot = id >> 3;
   const int per = n >> 3, rem = n & 7;
-  const int l = xcd * per + min(xcd, rem) + slot;  // XCD k owns per + (k < rem) consecutive list entries
+  const int l = xcd * per + (xcd < rem ? xcd : rem) + slot;  // XCD k owns per + (k < rem) consecutive list entries
   tile = l % ntiles;
   const int r = l / ntiles;
   hd = r % H;
   b = r / H;
+}
+__device__ __forceinline__ void attn_wg_coords(int ntiles, int H, int& tile, int& hd, int& b) {
+  attn_wg_coords_of((int)gridDim.x, (int)blockIdx.x, ntiles, H, tile, hd, b);
+}
+// the same function on the host (no launch): tests/test_capi_symbols.py checks that it is a bijection for ragged grid sizes
+extern "C" int aitk_probe_attn_wg_coords(int32_t n, int32_t id, int32_t ntiles, int32_t H, int32_t* out3) {
+  if (n <= 0 || id < 0 || id >= n || ntiles <= 0 || H <= 0 || !out3) return AITK_ERR_ARG;
+  int t, h, b;
+  attn_wg_coords_of(n, id, ntiles, H, t, h, b);
+  out3[0] = t;
+  out3[1] = h;
+  out3[2] = b;
+  return AITK_OK;
 }
 
 // ============================================================================================ forward

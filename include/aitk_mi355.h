@@ -497,6 +497,8 @@ typedef struct AitkDdpmNoiseArgs {
 int aitk_ddpm_noise_nhwc(const AitkDdpmNoiseArgs* args, aitk_stream_t stream);
 
 /* ---- hardware probes (test infrastructure for layout assumptions; not on the product path) ---- */
+/* host-side evaluation of the attention kernels' workgroup -> (row tile, head, batch) map for a 1-D grid of n blocks (XCD-grouped order) */
+int aitk_probe_attn_wg_coords(int32_t n, int32_t id, int32_t ntiles, int32_t H, int32_t* out3);
 int aitk_probe_tr16(int16_t* out /*[64*4]*/, int32_t pitch_elems, aitk_stream_t stream);
 int aitk_probe_glds(const int32_t* src /*[1024]*/, int32_t* out /*[1024]*/, aitk_stream_t stream);
 int aitk_probe_mfma32(const aitk_bf16* a /*[32*16]*/, const aitk_bf16* b /*[16*32]*/, float* d /*[32*32]*/, aitk_stream_t stream);

@@ -89,3 +89,26 @@ def test_round2_entry_points_validate_their_arguments_before_launching():
     sd = _capi.ShadowDesc()
     assert ctypes.sizeof(sd) == 48 and hasattr(sd, "aux")                              # kind 3 (composed low-rank LoKr factor) carries its rank here
     assert lib.aitk_lora_refresh_shadows(None, None, None, 1, None) == -3
+
+
+def test_attention_workgroup_order_is_a_bijection_that_keeps_a_head_on_one_xcd():
+    """aitk_probe_attn_wg_coords evaluates, on the host, the map the attention kernels apply to blockIdx.x (1-D grid): every (tile, head,
+    batch) exactly once for ragged grid sizes, and the row tiles of one (batch, head) on as few XCDs (= block id mod 8) as their count allows."""
+    import collections
+
+    lib = _capi.lib()
+    out = (ctypes.c_int32 * 3)()
+    for ntiles, H, B in ((36, 24, 7), (18, 24, 4), (5, 3, 2), (1, 1, 1), (9, 2, 3), (2, 10, 1)):
+        n = ntiles * H * B
+        seen = set()
+        xcds = collections.defaultdict(set)
+        for i in range(n):
+            assert lib.aitk_probe_attn_wg_coords(n, i, ntiles, H, out) == 0
+            t, h, b = out[0], out[1], out[2]
+            assert 0 <= t < ntiles and 0 <= h < H and 0 <= b < B
+            seen.add((t, h, b))
+            xcds[(h, b)].add(i % 8)
+        assert len(seen) == n
+        if n >= 8 * ntiles:  # an XCD's share is at least one head long: a head spans at most two XCDs (one boundary)
+            assert max(len(v) for v in xcds.values()) <= 2, (ntiles, H, B)
+    assert lib.aitk_probe_attn_wg_coords(8, 8, 2, 2, out) == -3 and lib.aitk_probe_attn_wg_coords(8, 0, 2, 2, None) == -3
