@@ -65,3 +65,38 @@ def test_self_launch_spawns_one_child_per_rank_and_stops_the_rest_when_one_dies(
     assert rc == 7 and time.time() - t0 < 30  # the sleeping ranks were stopped, not waited for
     ports = {open(tmp_path / f"rank{r}").read() for r in range(3)}
     assert len(ports) == 1  # one rendezvous port for the job
+
+
+def test_dvfs_leg_parses_rocm_smi_and_steps_on_every_rank(monkeypatch, tmp_path):
+    """bench.dvfs_leg against a stand-in rocm-smi that prints what the MI355X box prints: clock / power medians, the power cap, and the
+    step count — a rank that does not poll must run exactly as many steps as the one that does (the steps contain the all-reduce)."""
+    import importlib.util
+    import stat
+    import time
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    smi = tmp_path / "rocm-smi"
+    smi.write_text("#!/bin/sh\n"
+                   "case \"$*\" in\n"
+                   "  *showmaxpower*) echo 'GPU[0]\t\t: Max Graphics Package Power (W): 1400.0' ;;\n"
+                   "  *) echo 'GPU[0]\t\t: fclk clock level: 0: (1250Mhz)'; echo 'GPU[0]\t\t: sclk clock level: S: (1972Mhz)';\n"
+                   "     echo 'GPU[0]\t\t: Current Socket Graphics Package Power (W): 1311.0' ;;\n"
+                   "esac\n")
+    smi.chmod(smi.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{tmp_path}{os.pathsep}{os.environ['PATH']}")
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    calls = []
+
+    def one():
+        calls.append(1)
+        time.sleep(0.15)
+
+    out = bench.dvfs_leg(one, 0, steps=3)
+    assert out is not None and out["sclk_mhz"]["median"] == 1972 and out["power_w"]["median"] == 1311.0 and out["power_cap_w"] == 1400.0
+    assert out["samples"] >= 4 and len(calls) == 4
+    calls.clear()
+    assert bench.dvfs_leg(one, 1, steps=3, poll_here=False) is None and len(calls) == 4
