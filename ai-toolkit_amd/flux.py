@@ -341,13 +341,14 @@ class FluxTransformer2DModel(FusedGraphBase):
             u = self._new(Mj, 4 * d)
             r["T_mlp"] = self._lin_fwd(blk.proj_mlp, xn, cat[:, d:], M=Mj, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u,
                                        T=Tg.get(id(blk.proj_mlp)))
-            qkv_j = self._new(Mj, 3 * d)
+            # q, k: RMSNorm + RoPE into qkv_j; v needs neither and already sits in joint row order: attention reads it where the
+            # projection wrote it (the third, copy-only job of qkv_post is gone: 12 KB of HBM traffic per token and layer, both directions)
+            qkv_j = self._new(Mj, 2 * d)
             jobs = [dict(src=qkv_raw[:, 0:d], dst=qkv_j[:, 0:d], weight=a.norm_q.weight),
-                    dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=a.norm_k.weight),
-                    dict(src=qkv_raw[:, 2 * d:], dst=qkv_j[:, 2 * d:], weight=None)]
+                    dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=a.norm_k.weight)]
             ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
             lse = self._new(B, H, S, dtype=torch.float32)
-            ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], cat[:, 0:d], lse, B=B, H=H, S=S, scale=scale)
+            ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], cat[:, 0:d], lse, B=B, H=H, S=S, scale=scale)
             y = self._new(Mj, d)
             x_new = self._newr(Mj, d)
             r["T_out"] = self._lin_fwd(blk.proj_out, cat, x_new, M=Mj, rows_per_batch=S, B=B, flags=EPI_GATE_RES,
@@ -411,15 +412,15 @@ class FluxTransformer2DModel(FusedGraphBase):
             self._lin_dgrad(blk.proj_out, dy, dT, dcat_o, M=Mj, w_rows=(0, d))
             self._lin_dgrad(blk.proj_out, dy, dT, du, M=Mj, w_rows=(d, 5 * d), flags=EPI_DGELU, aux_in=r["u"])
             qkv_j = r["qkv_j"]
-            dqkv_j = self._new(Mj, 3 * d)
-            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_j[:, 2 * d:], r["cat"][:, 0:d], r["lse"], dcat_o,
-                         dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_j[:, 2 * d:], B=B, H=H, S=S, scale=scale)
-            dqkv_raw = self._new(Mj, 3 * d)
-            a = blk.attn
             qkv_raw = r["qkv_raw"]
+            dqkv_j = self._new(Mj, 2 * d)
+            dqkv_raw = self._new(Mj, 3 * d)
+            # dV goes straight to the raw-side gradient buffer (v was never copied), dQ / dK through the RoPE / RMSNorm backward
+            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], r["cat"][:, 0:d], r["lse"], dcat_o,
+                         dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_raw[:, 2 * d:], B=B, H=H, S=S, scale=scale)
+            a = blk.attn
             jobs = [dict(src=dqkv_raw[:, 0:d], dst=dqkv_j[:, 0:d], weight=a.norm_q.weight, raw=qkv_raw[:, 0:d]),
-                    dict(src=dqkv_raw[:, d:2 * d], dst=dqkv_j[:, d:2 * d], weight=a.norm_k.weight, raw=qkv_raw[:, d:2 * d]),
-                    dict(src=dqkv_raw[:, 2 * d:], dst=dqkv_j[:, 2 * d:], weight=None)]
+                    dict(src=dqkv_raw[:, d:2 * d], dst=dqkv_j[:, d:2 * d], weight=a.norm_k.weight, raw=qkv_raw[:, d:2 * d])]
             ops.qkv_post_bwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
             dxn = self._new(Mj, d)
             self._group_bwd((a.to_q, a.to_k, a.to_v, blk.proj_mlp),
