@@ -17,7 +17,6 @@ torch) to check this host logic against autograd of the oracle on CPU; the produ
 """
 import functools
 import math
-from typing import Dict, List, Optional
 
 import torch
 import torch.nn as nn

@@ -19,7 +19,7 @@ import math
 import os
 import weakref
 from collections import OrderedDict
-from typing import Dict, List, Optional
+from typing import List
 
 import torch
 import torch.nn as nn
