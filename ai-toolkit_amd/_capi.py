@@ -37,6 +37,10 @@ class QuantRowsArgs(C.Structure):
                 ("Q", vp), ("ldq", i64), ("row_scale", vp), ("M", i32), ("K", i32)]
 
 
+class WgradSrc2(C.Structure):
+    _fields_ = [("G2", vp), ("ldg2", i64), ("split_col", i32), ("act", i32)]
+
+
 class LoraDownArgs(C.Structure):
     _fields_ = [
         ("X", vp), ("ldx", i64), ("x_seg_rows", i32), ("_pad0", i32), ("x_seg_stride", i64),
@@ -207,7 +211,7 @@ EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AU
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
             12: MseArgs, 13: AdamWArgs, 14: ShadowDesc, 15: GroupNormArgs, 16: RmsFullArgs, 17: DoraColscaleArgs, 18: DoraBwdArgs,
-            19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs}
+            19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
 def lib():

@@ -27,7 +27,7 @@ def sources():
 
 def _stamp(path):
     h = hashlib.sha1()
-    for f in [path] + [os.path.join(CSRC, x) for x in sorted(os.listdir(CSRC)) if x.endswith(".h")] + [
+    for f in [path] + [os.path.join(CSRC, x) for x in sorted(os.listdir(CSRC)) if x.endswith((".h", ".inc"))] + [
         os.path.join(HERE, "..", "include", "aitk_mi355.h")
     ]:
         with open(f, "rb") as fh:

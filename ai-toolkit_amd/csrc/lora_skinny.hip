@@ -357,103 +357,15 @@ __device__ __forceinline__ s16x8_t load_frag_tr(const bf16_t* tile, int pitch, i
 
 template <int RB16>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, int mc) {
-  __shared__ __attribute__((aligned(16))) bf16_t gt[64 * WG_GPITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t st[2 * 64 * WG_SPITCH];  // [hi | lo] tiles of S (lo used when split_rp > 0)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l0 = blockIdx.x * WG_LT;
-  const bool split = p.split_rp > 0;
-  const int mbeg = blockIdx.y * mc;
-  const int mend = min(p.M, mbeg + mc);
-
-  f32x4_t acc[RB16][2];
-#pragma unroll
-  for (int a = 0; a < RB16; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
-
-  // Register-prefetched staging: the global loads of sub-tile i+1 are issued before the MFMAs of sub-tile i and written to
-  // LDS after them, so a workgroup overlaps its own HBM latency with its compute (before: load -> write -> sync -> compute).
-  const int chunks_per_row = p.R / 8;  // S: 64 rows x R cols = 64 * R/8 16-B chunks, <= 2 per thread
-  uint4 rg[4], rs[2], rl[2];
-  auto load_regs = [&](int ms) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = tid + 256 * i;
-      const int row = q >> 4, ch = q & 15;
-      const int m = ms + row, col = l0 + ch * 8;
-      rg[i] = make_uint4(0, 0, 0, 0);  // rows beyond M / cols beyond L are zero
-      if (m < mend && col < p.L) rg[i] = *reinterpret_cast<const uint4*>(seg_row2(p.G, p.ldg, p.g_seg_rows, p.g_seg_stride, m) + col);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 256 * i;
-      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
-      rs[i] = make_uint4(0, 0, 0, 0);
-      rl[i] = make_uint4(0, 0, 0, 0);
-      if (q < 64 * chunks_per_row && ms + row < mend) {
-        // split: rank r of the [hi | lo | hi] slab layout sits at column (r / rp) * 3 rp + r % rp, lo one rp further (rp % 8 == 0)
-        const int r = ch * 8, blk = split ? r / p.split_rp : 0;
-        const bf16_t* src = p.S + (long)(ms + row) * p.lds + r + 2 * blk * p.split_rp;
-        rs[i] = *reinterpret_cast<const uint4*>(src);
-        if (split) rl[i] = *reinterpret_cast<const uint4*>(src + p.split_rp);
-      }
-    }
-  };
-  auto write_lds = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int q = tid + 256 * i;
-      *reinterpret_cast<uint4*>(gt + (q >> 4) * WG_GPITCH + (q & 15) * 8) = rg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = tid + 256 * i;
-      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
-      if (q < 64 * chunks_per_row) {
-        *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = rs[i];
-        if (split) *reinterpret_cast<uint4*>(st + 64 * WG_SPITCH + row * WG_SPITCH + ch * 8) = rl[i];
-      }
-    }
-  };
-  load_regs(mbeg);
-  for (int ms = mbeg; ms < mend; ms += 64) {
-    write_lds();
-    __syncthreads();
-    if (ms + 64 < mend) load_regs(ms + 64);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {  // two 32-row contraction steps
-      s16x8_t bfr[2];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) bfr[cb] = load_frag_tr(gt, WG_GPITCH, kk * 32, (wave * 2 + cb) * 16, lane);
-#pragma unroll
-      for (int rb = 0; rb < RB16; ++rb) {
-        s16x8_t af = load_frag_tr(st, WG_SPITCH, kk * 32, rb * 16, lane);
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma16(af, bfr[cb], acc[rb][cb]);  // D[i=r][j=l]
-        if (split) {
-          s16x8_t al = load_frag_tr(st + 64 * WG_SPITCH, WG_SPITCH, kk * 32, rb * 16, lane);
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma16(al, bfr[cb], acc[rb][cb]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // partial[chunk][r][l]
-  float* part = p.partial + (long)blockIdx.y * p.R * p.L;
-  const int g = lane >> 4, i = lane & 15;
-#pragma unroll
-  for (int rb = 0; rb < RB16; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int col = l0 + (wave * 2 + cb) * 16 + i;
-      if (col < p.L) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[(long)(rb * 16 + 4 * g + r) * p.L + col] = acc[rb][cb][r];
-      }
-    }
+#define WG_SECOND 0
+#include "lora_wgrad_body.inc"
+#undef WG_SECOND
+}
+template <int RB16>
+__global__ __launch_bounds__(256) void lora_wgrad2_kernel(AitkLoraWgradArgs p, AitkWgradSrc2 s2, int mc) {
+#define WG_SECOND 1
+#include "lora_wgrad_body.inc"
+#undef WG_SECOND
 }
 
 // 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four
@@ -497,6 +409,35 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
     case 2: hipLaunchKernelGGL(lora_wgrad_kernel<2>, grid, dim3(256), 0, s, *a, mc); break;
     case 3: hipLaunchKernelGGL(lora_wgrad_kernel<3>, grid, dim3(256), 0, s, *a, mc); break;
     default: hipLaunchKernelGGL(lora_wgrad_kernel<4>, grid, dim3(256), 0, s, *a, mc); break;
+  }
+  AITK_LAUNCH_CHECK();
+  const long total = (long)a->R * a->L;
+  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// aitk_lora_wgrad with a two-part G operand: out[r][l] += sum_m S[m][r] * X[m][l],  X[m][l] = G[m][l] for l < split_col and
+// act(G2[m][l - split_col]) beyond — the lora_down gradient of a layer whose input is [attention output | gelu(pre-activation)] (FLUX single
+// blocks' proj_out) or gelu(pre-activation) alone (ff.net.2, split_col = 0) WITHOUT keeping the GELU output resident: 6.4 GB per image at 1024^2.
+extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2* q, aitk_stream_t stream) {
+  if (!a || !q || a->M <= 0 || a->R <= 0 || a->L <= 0) return AITK_ERR_SHAPE;
+  if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
+  if ((a->lds % 8) || (q->ldg2 % 8)) return AITK_ERR_ALIGN;
+  if (!a->partial || !a->out || !q->G2) return AITK_ERR_ARG;
+  if (q->split_col < 0 || q->split_col >= a->L || (q->split_col % WG_LT) || (q->act != 0 && q->act != 1)) return AITK_ERR_ARG;
+  if (q->split_col > 0 && (!a->G || (a->ldg % 8))) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
+  int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
+  if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
+  const int nchunks = (a->M + mc - 1) / mc;
+  dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  switch (a->R / 16) {
+    case 1: hipLaunchKernelGGL(lora_wgrad2_kernel<1>, grid, dim3(256), 0, s, *a, *q, mc); break;
+    case 2: hipLaunchKernelGGL(lora_wgrad2_kernel<2>, grid, dim3(256), 0, s, *a, *q, mc); break;
+    case 3: hipLaunchKernelGGL(lora_wgrad2_kernel<3>, grid, dim3(256), 0, s, *a, *q, mc); break;
+    default: hipLaunchKernelGGL(lora_wgrad2_kernel<4>, grid, dim3(256), 0, s, *a, *q, mc); break;
   }
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;

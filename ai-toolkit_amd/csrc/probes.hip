@@ -90,6 +90,7 @@ extern "C" int aitk_sizeof(int32_t which) {
     case 20: return (int)sizeof(AitkGroupNormBwdArgs);
     case 21: return (int)sizeof(AitkDdpmNoiseArgs);
     case 22: return (int)sizeof(AitkQuantRowsArgs);
+    case 23: return (int)sizeof(AitkWgradSrc2);
     default: return -1;
   }
 }

@@ -23,7 +23,7 @@ import torch.nn as nn
 
 
 
-from .graph import (EPI_ACCUM, EPI_DGELU, EPI_GATE_RES, EPI_GELU, FusedGraphBase, Linear, RMSNormW, _Holder)  # noqa: F401
+from .graph import (EPI_ACCUM, EPI_DGELU, EPI_GATE_RES, EPI_GELU, FusedGraphBase, Linear, RMSNormW, _ActInput, _Holder)  # noqa: F401
 
 
 def _ada(dim, mult, dtype, device):
@@ -124,6 +124,10 @@ class FluxTransformer2DModel(FusedGraphBase):
         self._init_graph(ops, dtype)  # grad_ready_hook pieces: 'single' then 'double'
         self._rope_cache = {}
         self.res_dt = dtype  # storage type of the residual stream and of its gradient (set_precision)
+        # recompute_gelu: the GELU outputs (the inputs of ff.net.2 / the mlp part of proj_out's input) are not kept for the backward pass —
+        # their only reader there, the lora_down gradient, rebuilds them from the saved pre-activation inside aitk_lora_wgrad2 (bit for bit
+        # the same values).  6.4 GB less per 1024^2 image; off until it has been timed on the GPU
+        self.recompute_gelu = False
 
     def set_precision(self, precision="default"):
         """precision="high": hidden_states / encoder_hidden_states and their gradients are carried across the 57 blocks in fp32 (every
@@ -135,6 +139,14 @@ class FluxTransformer2DModel(FusedGraphBase):
 
     def _newr(self, *shape):
         return torch.empty(*shape, dtype=self.res_dt, device=self._device())
+
+    def _drop_gelu_output(self, lin):
+        """may the GELU output that feeds `lin` be dropped after the forward pass?  Yes without an adapter (nothing reads it in backward) and
+        with a plain LoRA adapter (aitk_lora_wgrad2); DoRA / LoKr read their input tensor elsewhere too."""
+        if not self.recompute_gelu:
+            return False
+        lo = lin.lora
+        return lo is None or not self._lora_active(lin) or (not lo.is_lokr and lo.magnitude is None and lo.rank_pad <= 64)
 
     # ------------------------------------------------------------------ setup
     def _token_linears(self):
@@ -310,7 +322,8 @@ class FluxTransformer2DModel(FusedGraphBase):
                 x2 = self._newr(M, d)
                 r["T_ff2"] = self._lin_fwd(ff.net[2], hbuf, x2, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
                                            aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss)
-                r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=hbuf, y_ff=y_ff)
+                r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=None if self._drop_gelu_output(ff.net[2]) else hbuf,
+                         y_ff=y_ff)
                 outs[name] = x2
 
             self._paired([functools.partial(mlp_stream, "img", Mi, Si, St, blk.attn.to_out[0], blk.ff),
@@ -347,12 +360,19 @@ class FluxTransformer2DModel(FusedGraphBase):
                     dict(src=qkv_raw[:, d:2 * d], dst=qkv_j[:, d:2 * d], weight=a.norm_k.weight)]
             ops.qkv_post_fwd(jobs, cos, sin, B=B, H=H, S_src=S, S_dst=S, s_off=0)
             lse = self._new(B, H, S, dtype=torch.float32)
-            ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], cat[:, 0:d], lse, B=B, H=H, S=S, scale=scale)
+            drop = self._drop_gelu_output(blk.proj_out)
+            if drop:  # the attention output outlives `cat`: it gets its own buffer and is copied into the GEMM operand
+                o_buf = self._new(Mj, d)
+                ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], o_buf, lse, B=B, H=H, S=S, scale=scale)
+                ops.copy_rows(cat[:, 0:d], o_buf)
+            else:
+                o_buf = cat[:, 0:d]
+                ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], o_buf, lse, B=B, H=H, S=S, scale=scale)
             y = self._new(Mj, d)
             x_new = self._newr(Mj, d)
             r["T_out"] = self._lin_fwd(blk.proj_out, cat, x_new, M=Mj, rows_per_batch=S, B=B, flags=EPI_GATE_RES,
                                        aux_out=y, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=S)
-            r.update(mod=mod, x=x, mean=mean, rstd=rstd, xn=xn, qkv_raw=qkv_raw, cat=cat, u=u, qkv_j=qkv_j, lse=lse, y=y)
+            r.update(mod=mod, x=x, mean=mean, rstd=rstd, xn=xn, qkv_raw=qkv_raw, cat=None if drop else cat, o=o_buf, u=u, qkv_j=qkv_j, lse=lse, y=y)
             if ctx is not None:
                 ctx["sgl"].append(r)
             x = x_new
@@ -407,7 +427,8 @@ class FluxTransformer2DModel(FusedGraphBase):
             du = self._new(Mj, 4 * d)
             # proj_out: adapter grads once, then the two column ranges of d[attn | mlp]
             dy = self._dora_dz(blk.proj_out, dy, Mj)
-            dT = self._lora_grads(blk.proj_out, dy, r["T_out"], r["cat"], M=Mj, rows_per_batch=S, B=B)
+            cat_in = r["cat"] if r["cat"] is not None else _ActInput(r["o"], r["u"], "gelu")
+            dT = self._lora_grads(blk.proj_out, dy, r["T_out"], cat_in, M=Mj, rows_per_batch=S, B=B)
             self._lin_dgrad(blk.proj_out, dy, dT, dcat_o, M=Mj, w_rows=(0, d))
             self._lin_dgrad(blk.proj_out, dy, dT, du, M=Mj, w_rows=(d, 5 * d), flags=EPI_DGELU, aux_in=r["u"])
             qkv_j = r["qkv_j"]
@@ -415,7 +436,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             dqkv_j = self._new(Mj, 2 * d)
             dqkv_raw = self._new(Mj, 3 * d)
             # dV goes straight to the raw-side gradient buffer (v was never copied), dQ / dK through the RoPE / RMSNorm backward
-            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], r["cat"][:, 0:d], r["lse"], dcat_o,
+            ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], r["o"], r["lse"], dcat_o,
                          dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_raw[:, 2 * d:], B=B, H=H, S=S, scale=scale)
             a = blk.attn
             jobs = [dict(src=dqkv_raw[:, 0:d], dst=dqkv_j[:, 0:d], weight=a.norm_q.weight, raw=qkv_raw[:, 0:d]),
@@ -455,7 +476,8 @@ class FluxTransformer2DModel(FusedGraphBase):
                 dy = self._new(M, d)
                 ops.gate_bwd(dx2, r["y_ff"], mod[:, 5 * d:6 * d], dy, dmod[:, 5 * d:6 * d], B=B, S=Ss)
                 du = self._new(M, 4 * d)
-                self._lin_bwd(ff.net[2], dy, r["T_ff2"], r["h"], du, M=M, rows_per_batch=Ss, B=B, flags=EPI_DGELU, aux_in=r["u"])
+                h_in = r["h"] if r["h"] is not None else _ActInput(None, r["u"], "gelu")
+                self._lin_bwd(ff.net[2], dy, r["T_ff2"], h_in, du, M=M, rows_per_batch=Ss, B=B, flags=EPI_DGELU, aux_in=r["u"])
                 dxn2 = self._new(M, d)
                 self._lin_bwd(ff.net[0].proj, du, r["T_ff1"], r["xn2"], dxn2, M=M, rows_per_batch=Ss, B=B)
                 dx1 = self._newr(M, d)

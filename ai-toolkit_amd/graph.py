@@ -51,6 +51,14 @@ class _DoraPS:
         self.bar, self.delta, self.mbar, self.dvec, self.rpb = bar, delta, mbar, dvec, rpb
 
 
+class _ActInput:
+    """A layer input the backward pass does not hold as one tensor: [g | act(g2)] (g may be None).  With `recompute_gelu` the GELU outputs
+    are dropped after the forward pass; aitk_lora_wgrad2 forms lora_down.weight.grad from the saved pre-activation instead."""
+
+    def __init__(self, g, g2, act):
+        self.g, self.g2, self.act = g, g2, act
+
+
 @torch.no_grad()
 def quantize_linear_fp8(lin, w):
     """lin.qweight / qweight_t / wscale from a [out, in] weight: OCP e4m3 bytes with one fp32 scale per output channel
@@ -400,7 +408,11 @@ class FusedGraphBase(nn.Module):
                       tmask_rows_per_batch=tm_rpb)
         ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
         if dT_out is None:
-            ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
+            if isinstance(x_in, _ActInput):  # the input is [g | gelu(pre-activation)] and only the pre-activation was kept
+                assert x_seg is None
+                ops.lora_wgrad(dT, x_in.g, lo.g_down, accumulate=True, M=M, split=rp, g2=x_in.g2, g2_act=x_in.act)
+            else:
+                ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
         return dT
 
     def _dora_dz(self, lin, dy, M):

@@ -275,11 +275,22 @@ def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_p
     return T
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None, g2=None, g2_act=None):
     """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad).
+    g2 [M, L2] (aitk_lora_wgrad2): the operand is [g | act(g2)] — `g` may be None (L = L2) — with act "gelu" = tanh-GELU of a saved
+    pre-activation, so that the GELU output itself need not be kept for the backward pass.
     split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo.
     out_strides = (stride_r, stride_l): element (r, l) goes to out.flatten()[r*stride_r + l*stride_l] (`out` = fp32 view starting at the
     first element; one tap of a conv adapter's [r, Cin, 3, 3] gradient: strides (9 Cin, 9))."""
+    if g2 is not None:
+        assert g_seg is None and g2_act in (None, "gelu") and g2.dtype == BF16
+        split_col = 0 if g is None else g.shape[1]
+        assert split_col % 128 == 0, "the second part of the operand starts on a 128-column tile boundary"
+        R, L = (s.shape[1] // 3 if split else s.shape[1]), split_col + g2.shape[1]
+        if R > 64:
+            raise NotImplementedError("lora_wgrad with a two-part operand: ranks above 64")
+        return _lora_wgrad_launch(s, g, out, R, L, accumulate, None, M, split, out_strides, transpose_out,
+                                  second=(g2, split_col, 1 if g2_act == "gelu" else 0))
     R, L = (s.shape[1] // 3 if split else s.shape[1]), g.shape[1]
     if R > 64:  # 64-rank chunks of one slab (see lora_down): rank r of the output at r * stride_r
         if split and split < R:
@@ -297,10 +308,10 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
     return _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out)
 
 
-def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out):
+def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out, second=None):
     a = _capi.LoraWgradArgs()
     a.lds = _row_major(s, "s")
-    a.ldg = _row_major(g, "g")
+    a.ldg = _row_major(g, "g") if g is not None else 0
     a.split_rp = int(split)
     M = s.shape[0] if M is None else M
     assert out.dtype == torch.float32 and out.is_contiguous()
@@ -320,6 +331,12 @@ def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides
     a.S, a.G, a.partial, a.out = _ptr(s), _ptr(g), _ptr(ws), _ptr(out)
     a.accumulate = int(accumulate)
     a.M, a.R, a.L = M, R, L
+    if second is not None:
+        g2, split_col, act = second
+        q = _capi.WgradSrc2()
+        q.G2, q.ldg2, q.split_col, q.act = _ptr(g2), _row_major(g2, "g2"), split_col, act
+        _call("aitk_lora_wgrad2", C.byref(a), C.byref(q))
+        return out
     _call("aitk_lora_wgrad", C.byref(a))
     return out
 

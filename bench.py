@@ -500,6 +500,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")
+    ap.add_argument("--recompute-gelu", action="store_true", help="FLUX: drop the GELU outputs after the forward pass (the lora_down gradients "
+                    "rebuild them from the pre-activation inside aitk_lora_wgrad2): 6.4 GB less per image; not yet the default — "
+                    "tools/gpu_check_recompute_gelu.py validates and times it")
     ap.add_argument("--no-dvfs", action="store_true", help="skip the clock / power telemetry leg (3 extra steps under rocm-smi polling)")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
@@ -547,6 +550,7 @@ def main():
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
 
     model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base, network_type=args.network, fp8_mfma=args.fp8_mfma)
+    model.recompute_gelu = bool(args.recompute_gelu)
     step = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99,
                              timestep_type="linear", process_group=pg, seed=1000 + rank)
     B = args.batch

@@ -154,6 +154,15 @@ typedef struct AitkLoraWgradArgs {
 } AitkLoraWgradArgs;
 int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t L);
 int aitk_lora_wgrad(const AitkLoraWgradArgs* args, aitk_stream_t stream);
+/* aitk_lora_wgrad whose G operand has a second part: columns l >= split_col (a multiple of 128, may be 0) are act(G2[m][l - split_col]),
+ * act 0 = identity, 1 = tanh-GELU of a saved pre-activation (bit for bit the GEMM's AITK_EPI_GELU output).  G2 rows are plain (ldg2), the row map
+ * (g_seg_*) applies to G only.  Lets a trainer drop the GELU outputs after the forward pass: lora_down.weight.grad of ff.net.2 / proj_out
+ * (autograd of toolkit/network_mixins.py:309-321 on those layers) is formed from the pre-activation the GELU-backward epilogue keeps anyway. */
+typedef struct AitkWgradSrc2 {
+  const aitk_bf16* G2; int64_t ldg2;
+  int32_t split_col; int32_t act;
+} AitkWgradSrc2;
+int aitk_lora_wgrad2(const AitkLoraWgradArgs* args, const AitkWgradSrc2* second, aitk_stream_t stream);
 /* In place on a [hi(rp) | lo(rp) | hi(rp)] slab T [M, >= 3 rp]: (hi + lo)[m][r] * rowf[m / rows_per_batch] * tmask[m / tmask_rows_per_batch][r],
  * split again (rowf / tmask may be NULL, not both; tmask fp32 [rows, rp], tmask_rows_per_batch 0 = one mask row per slab row).  The per-sample
  * multiplier and the dropout / rank_dropout masks of a 3x3-conv adapter's rank-space activation, whose lora_down leaves the implicit-GEMM

@@ -151,11 +151,16 @@ def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_p
     return T
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None):
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None, g2=None, g2_act=None):
     """autograd of lora_down / lora_up weights (split: s is the slab layout, read as hi + lo); out_strides: strided destination
-    (one tap of a conv adapter's [r, Cin, 3, 3] gradient)."""
+    (one tap of a conv adapter's [r, Cin, 3, 3] gradient).  g2: the layer input was [g | act(g2)] with act = F.gelu(approximate="tanh") of the
+    pre-activation rounded to the activation dtype, exactly what the forward pass fed the layer (diffusers FeedForward / FluxSingleTransformerBlock)."""
     if M is None:
         M = s.shape[0]
+    if g2 is not None:
+        h = F.gelu(g2[:M].float(), approximate="tanh").to(g2.dtype) if g2_act == "gelu" else g2[:M]
+        g = h if g is None else torch.cat((g[:M], h), dim=1)
+        g_seg = None
     if split:
         c_hi, c_lo, _ = _split_cols(s.shape[1] // 3, split)
         s = s[:M, c_hi].float() + s[:M, c_lo].float()
