@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena
     if (d.kind == 1) {  // A [rank, in]
       shadow[d.d0 + i] = hi;
       shadow[d.d1 + i] = lo;
-      bf16_t* t3 = shadow + d.d2 + c * 3 * d.rows + r;
+      // aux > 0: row stride of the [in, 3 rank] block — the adapters of a same-input group share ONE [in, 3 R] matrix (column windows), the B2
+      // operand of the group's K-concatenated data-gradient GEMM
+      bf16_t* t3 = shadow + d.d2 + c * (d.aux > 0 ? (long)d.aux : 3L * d.rows) + r;
       t3[0] = hi;
       t3[d.rows] = hi;
       t3[2 * d.rows] = lo;

@@ -163,6 +163,16 @@ class FluxTransformer2DModel(FusedGraphBase):
     def _dgrad_linears(self):
         return self._token_linears() + [self.proj_out]
 
+    def _dgrad_groups(self):
+        out = []
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            out += [(a.to_q, a.to_k, a.to_v), (a.add_q_proj, a.add_k_proj, a.add_v_proj)]
+        for blk in self.single_transformer_blocks:
+            a = blk.attn
+            out.append((a.to_q, a.to_k, a.to_v, blk.proj_mlp))
+        return out
+
     def grad_split_offset(self, network):
         """Arena offset of the first single-stream adapter: [split, n) is final first during backward ('single')."""
         for m in network.unet_loras:
@@ -424,7 +434,10 @@ class FluxTransformer2DModel(FusedGraphBase):
             dy = self._new(Mj, d)
             ops.gate_bwd(dx, r["y"], mod[:, 2 * d:3 * d], dy, dmod[:, 2 * d:3 * d], B=B, S=S)
             dcat_o = self._new(Mj, d)
-            du = self._new(Mj, 4 * d)
+            # d[q | k | v | mlp pre-activation] side by side: the four layers read the same xn, so their data gradient is ONE GEMM over the
+            # concatenated 7 d output channels (graph._group_bwd)
+            dgrp = self._new(Mj, 7 * d)
+            du = dgrp[:, 3 * d:]
             # proj_out: adapter grads once, then the two column ranges of d[attn | mlp]
             dy = self._dora_dz(blk.proj_out, dy, Mj)
             cat_in = r["cat"] if r["cat"] is not None else _ActInput(r["o"], r["u"], "gelu")
@@ -434,7 +447,7 @@ class FluxTransformer2DModel(FusedGraphBase):
             qkv_j = r["qkv_j"]
             qkv_raw = r["qkv_raw"]
             dqkv_j = self._new(Mj, 2 * d)
-            dqkv_raw = self._new(Mj, 3 * d)
+            dqkv_raw = dgrp[:, :3 * d]
             # dV goes straight to the raw-side gradient buffer (v was never copied), dQ / dK through the RoPE / RMSNorm backward
             ops.attn_bwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], r["o"], r["lse"], dcat_o,
                          dqkv_j[:, 0:d], dqkv_j[:, d:2 * d], dqkv_raw[:, 2 * d:], B=B, H=H, S=S, scale=scale)

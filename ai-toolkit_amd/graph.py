@@ -25,6 +25,7 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features, dtype=dtype, device=device), requires_grad=False) if bias else None
         object.__setattr__(self, "lora", None)
         self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
+        self._dgroup = None   # (W^T_cat [in, sum(out)], column offset, ids of the group's Linears) when laid out with its same-input group
         self.qweight = self.qweight_t = self.wscale = None  # weight-only fp8 base (quantize_base_fp8)
 
     def forward(self, x):
@@ -107,11 +108,32 @@ class FusedGraphBase(nn.Module):
         """Linears whose data gradient is needed (default: all token linears)."""
         return self._token_linears()
 
+    def _dgrad_groups(self):
+        """Tuples of Linears that read the SAME activation (q, k, v[, proj_mlp]): their transposed copies are laid out as column
+        windows of one [in, sum(out)] matrix so that the group's data gradient is ONE GEMM contracting over the concatenated outputs
+        (_group_bwd).  Default: none."""
+        return []
+
+    concat_dgrad = os.environ.get("AITK_CONCAT_DGRAD", "1") != "0"
+
     def prepare(self):
         """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""
+        grouped = set()
+        for lins in (self._dgrad_groups() if self.concat_dgrad else []):
+            if any(l.qweight is not None for l in lins) or len({l.in_features for l in lins}) != 1:
+                continue
+            cat = torch.empty(lins[0].in_features, sum(l.out_features for l in lins), dtype=lins[0].weight.dtype, device=lins[0].weight.device)
+            c0 = 0
+            for l in lins:
+                l.weight_t = cat[:, c0:c0 + l.out_features]  # column window (row stride = sum(out)): every single-layer use reads it through its stride
+                l.weight_t.copy_(l.weight.data.t())
+                l._dgroup = (cat, c0, tuple(id(x) for x in lins))
+                c0 += l.out_features
+                grouped.add(id(l))
         for lin in self._dgrad_linears():
-            if lin.qweight is None:
+            if lin.qweight is None and id(lin) not in grouped:
                 lin.weight_t = lin.weight.data.t().contiguous()
+                lin._dgroup = None
         self._prepared = True
         return self
 
@@ -133,6 +155,7 @@ class FusedGraphBase(nn.Module):
         for lin in self._token_linears():
             quantize_linear_fp8(lin, lin.weight.data)
             lin.weight_t = None
+            lin._dgroup = None
             if release_bf16:
                 lin.weight.data = torch.empty(0, dtype=lin.weight.dtype, device=lin.weight.device)
         self._prepared = True
@@ -435,6 +458,20 @@ class FusedGraphBase(nn.Module):
         if grp is not None and [id(m) for m in grp["mods"]] != [id(l.lora) for l in lins]:
             grp = None
         dTcat = self._new(M, 3 * grp["R"]) if grp is not None else None
+        cat = self._concat_dgrad_operand(lins, dys, Ts, grp, M)
+        if cat is not None:
+            # ONE data-gradient GEMM for the group: dx = [dy_0 | dy_1 | ...] [W_0^T | W_1^T | ...]^T + [dT_0 | dT_1 | ...] [A_0^T3 | A_1^T3 | ...]^T
+            # (contraction over the concatenated output channels; fp32 accumulation across the whole group instead of bf16
+            # read-modify-write of dx between per-layer GEMMs)
+            for lin, dy, T in zip(lins, dys, Ts):
+                if grp is not None:
+                    c0 = 3 * grp["col"][id(lin.lora)]
+                    self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dTcat[:, c0:c0 + 3 * lin.lora.rank_pad])
+            kw = dict(a2=dTcat, b2=grp["sh_downT3"]) if grp is not None else {}
+            self.ops.gemm_nt(cat[0], cat[1], dx, flags=first_flags, M=M, **kw)
+            if grp is not None:
+                self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
+            return
         for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
             dy = self._dora_dz(lin, dy, M)
             dT_out = None
@@ -445,6 +482,30 @@ class FusedGraphBase(nn.Module):
             self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
         if grp is not None:
             self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
+
+    def _concat_dgrad_operand(self, lins, dys, Ts, grp, M):
+        """(dY_cat [M, sum(out)], W^T_cat [in, sum(out)]) when the group's data gradient can run as one K-concatenated GEMM: the transposed
+        weights were laid out together by prepare(), the output gradients are adjacent column windows of one buffer in the same order,
+        and every layer is either a plain LoRA layer of one laid-out adapter group or has no active adapter; None otherwise."""
+        dg = getattr(lins[0], "_dgroup", None)
+        if dg is None or dg[2] != tuple(id(l) for l in lins) or self.fp8_mfma or any(l.qweight is not None for l in lins):
+            return None
+        if grp is None and any(t is not None for t in Ts):
+            return None
+        if grp is not None and any((t is _KRON or isinstance(t, _DoraPS) or l.lora.magnitude is not None) for l, t in zip(lins, Ts)):
+            return None
+        d0 = dys[0]
+        if d0.dim() != 2 or d0.stride(1) != 1:
+            return None
+        ld, esz, p = d0.stride(0), d0.element_size(), d0.data_ptr()
+        for l, dy in zip(lins, dys):
+            if dy.dim() != 2 or dy.stride(1) != 1 or dy.stride(0) != ld or dy.data_ptr() != p or dy.shape[1] != l.out_features or dy.shape[0] < M:
+                return None
+            p += l.out_features * esz
+        tot = sum(l.out_features for l in lins)
+        if ld < tot:
+            return None
+        return torch.as_strided(d0, (d0.shape[0], tot), (ld, 1), d0.storage_offset()), dg[0]
 
     def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
         """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""

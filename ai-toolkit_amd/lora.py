@@ -472,6 +472,7 @@ class FusedLoRANetwork(nn.Module):
 
         entries = []
         off = 0
+        g_t3 = {}  # group index -> (shadow offset, [in, 3 R] view) of the group's data-gradient slab matrix
         for m, which in order:
             rows, cols = block_shape(m, which)
             cnt = rows * cols
@@ -518,8 +519,21 @@ class FusedLoRANetwork(nn.Module):
             elif which == "down":
                 d0, hi = take("hi", cnt, (rows, cols))
                 d1, lo = take("lo", cnt, (rows, cols))
-                d2, t3 = take("t3", 3 * cnt, (cols, 3 * rows))
-                entries.append((off, rows, cols, 1, d0, d1, d2))
+                gi = group_of.get(id(m))
+                if gi is None:
+                    d2, t3 = take("t3", 3 * cnt, (cols, 3 * rows))
+                    entries.append((off, rows, cols, 1, d0, d1, d2))
+                else:
+                    # same-input group: the [in, 3 rp] data-gradient blocks of its adapters are column windows of ONE [in, 3 R] matrix, so the
+                    # group's data gradient dx = [dy_q | dy_k | ...] [W_q^T | W_k^T | ...]^T + [dT_q | dT_k | ...] [that matrix]^T is one GEMM
+                    grp_m = groups[gi]
+                    R3 = 3 * sum(x.rank_pad for x in grp_m)
+                    if m is grp_m[0]:
+                        g_t3[gi] = take("t3", cols * R3, (cols, R3))
+                    gb, gmat = g_t3[gi]
+                    c3 = 3 * sum(x.rank_pad for x in grp_m[:[id(x) for x in grp_m].index(id(m))])
+                    d2, t3 = gb + c3, gmat[:, c3:c3 + 3 * rows]
+                    entries.append((off, rows, cols, 1, d0, d1, d2, R3))
                 m.off_down, m.g_down, m.blk_down = off, gblock, (rows, cols)
                 m.sh_down, m.sh_down_lo, m.sh_downT3, m._sh_down_off = hi, lo, t3, (d0, d1)
             else:
@@ -564,6 +578,7 @@ class FusedLoRANetwork(nn.Module):
             g = {"mods": grp, "R": rtot, "rp": first.rank_pad, "sh_down": self.arena_shadow[h0:h0 + rtot * cin].view(rtot, cin),
                  "sh_down_lo": self.arena_shadow[l0:l0 + rtot * cin].view(rtot, cin),
                  "g_down": self.arena_g[o0:o0 + rtot * cin].view(rtot, cin), "scale": first.scale,
+                 "sh_downT3": g_t3[groups.index(grp)][1],
                  "col": {id(x): sum(y.rank_pad for y in grp[:i]) for i, x in enumerate(grp)}}
             for x in grp:
                 x.group = g

@@ -318,6 +318,9 @@ class UNet2DConditionModel(FusedGraphBase):
         out += [m for m in self.modules() if isinstance(m, Conv1x1) and m not in out]
         return out
 
+    def _dgrad_groups(self):
+        return [(b.attn1.to_q, b.attn1.to_k, b.attn1.to_v) for t in self._transformers() for b in t.transformer_blocks]
+
     def prepare(self):
         super().prepare()
         for m in self.modules():
@@ -558,11 +561,16 @@ class UNet2DConditionModel(FusedGraphBase):
             g = dy if dy.stride(1) == 1 else self._contig(dy)
             do = self._new(Mq, dim)
             self._lin_bwd(a.to_out[0], g, To, o, do, M=Mq, rows_per_batch=Sq, B=B)
+            if self_attn:
+                dgrp = self._new(Mq, 3 * dim)  # d[q | k | v] side by side: one K-concatenated data-gradient GEMM for the group (graph._group_bwd)
+                _qkv_new = lambda: (dgrp[:, :dim], dgrp[:, dim:2 * dim], dgrp[:, 2 * dim:])  # noqa: E731
+            else:
+                _qkv_new = lambda: (self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim))  # noqa: E731
             if small:
-                dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
+                dq, dk, dv = _qkv_new()
                 ops.attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=Sq, D=d, scale=scale, Skv=kvn)
             elif native:
-                dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
+                dq, dk, dv = _qkv_new()
                 ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dvalid=d, hstride=d)
             else:
                 if d != PAD_D:
@@ -570,10 +578,10 @@ class UNet2DConditionModel(FusedGraphBase):
                     ops.copy_heads(do, dop, H=H, d_src=d, d_dst=PAD_D)
                 else:
                     dop = do
-                dqp, dkp, dvp = self._new(Mq, H * PAD_D), self._new(Mk, H * PAD_D), self._new(Mk, H * PAD_D)
+                dqp, dkp, dvp = (self._new(Mq, H * PAD_D), self._new(Mk, H * PAD_D), self._new(Mk, H * PAD_D)) if d != PAD_D else _qkv_new()
                 ops.attn_bwd(qp, kp, vp, op_, lse, dop, dqp, dkp, dvp, B=B, H=H, S=Sq, scale=scale, Skv=kvn, dvalid=d if d != PAD_D else 0)
                 if d != PAD_D:
-                    dq, dk, dv = self._new(Mq, dim), self._new(Mk, dim), self._new(Mk, dim)
+                    dq, dk, dv = _qkv_new()
                     for s_, d_ in ((dqp, dq), (dkp, dk), (dvp, dv)):
                         ops.copy_heads(s_, d_, H=H, d_src=PAD_D, d_dst=d)
                 else:

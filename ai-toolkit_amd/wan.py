@@ -112,6 +112,9 @@ class WanTransformer3DModel(FusedGraphBase):
             skip.update((id(blk.attn2.to_k), id(blk.attn2.to_v)))
         return [l for l in self._token_linears() if id(l) not in skip]
 
+    def _dgrad_groups(self):
+        return [(blk.attn1.to_q, blk.attn1.to_k, blk.attn1.to_v) for blk in self.blocks]
+
     def prepare(self):
         super().prepare()
         C4 = self.proj_out.out_features
@@ -354,15 +357,16 @@ class WanTransformer3DModel(FusedGraphBase):
             do1 = self._new(M, d)
             self._lin_bwd(a1.to_out[0], dy, r["T_o1"], r["o1"], do1, M=M, rows_per_batch=S, B=B)
             qkv = r["qkv"]
-            dqkv = self._new(M, 3 * d)
+            dqkv = self._new(M, 2 * d)
+            dgrp = self._new(M, 3 * d)  # d[q_raw | k_raw | v] side by side: one K-concatenated data-gradient GEMM for the group (graph._group_bwd)
             ops.attn_bwd(qkv[:, 0:d], qkv[:, d:2 * d], qkv[:, 2 * d:], r["o1"], r["lse1"], do1,
-                         dqkv[:, 0:d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B=B, H=H, S=S, scale=scale)
-            dqk_raw = self._new(M, 2 * d)
+                         dqkv[:, 0:d], dqkv[:, d:2 * d], dgrp[:, 2 * d:], B=B, H=H, S=S, scale=scale)
+            dqk_raw = dgrp[:, :2 * d]
             qk_raw = r["qk_raw"]
             ops.rms_full_bwd(dqkv[:, 0:d], qk_raw[:, 0:d], a1.norm_q.weight, dqk_raw[:, 0:d], S=S, cos=cos, sin=sin, eps=eps)
             ops.rms_full_bwd(dqkv[:, d:2 * d], qk_raw[:, d:2 * d], a1.norm_k.weight, dqk_raw[:, d:2 * d], S=S, cos=cos, sin=sin, eps=eps)
             qkv_lins = (a1.to_q, a1.to_k, a1.to_v)
-            dys = [dqk_raw[:, 0:d], dqk_raw[:, d:2 * d], dqkv[:, 2 * d:]]
+            dys = [dqk_raw[:, 0:d], dqk_raw[:, d:2 * d], dgrp[:, 2 * d:]]
             if i == nblk - 1:  # the first block's input (patch embedding) has no trainable ancestor: weight grads only
                 self._wgrad_only(qkv_lins, dys, r["T_qkv"], r["xn"], M, S, B)
                 r.clear()

@@ -340,7 +340,9 @@ int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
  * step.  hi = bf16(w), lo = bf16(w - hi).  Offsets are elements into `shadow`.
  *   kind 0 (plain; LoKr factors): d0 = hi [rows, cols], d1 = hi transposed [cols, rows].
  *   kind 1 (lora_down A [r, in]):  d0 = hi [r, in], d1 = lo [r, in] (P / P_lo of the forward aitk_lora_down),
- *                                  d2 = [in, 3r] rows = [A^T_hi | A^T_hi | A^T_lo] (B2 of the dgrad K-slab).
+ *                                  d2 = [in, 3r] rows = [A^T_hi | A^T_hi | A^T_lo] (B2 of the dgrad K-slab); aux > 0 = row stride of that
+ *                                  block in elements (the adapters of a same-input group are column windows of ONE [in, 3R] matrix, the
+ *                                  B2 operand of the group's K-concatenated data-gradient GEMM), aux = 0: 3r.
  *   kind 2 (lora_up B [out, r]):   d0 = [out, 3r] rows = [B_hi | B_hi | B_lo] (B2 of the forward K-slab),
  *                                  d1 = hi transposed [r, out], d2 = lo transposed [r, out] (P / P_lo of the backward aitk_lora_down).
  *   kind 3 (low-rank LoKr factor, toolkit/models/lokr.py:184-197): the arena holds a [rows, aux] followed by b [aux, cols];

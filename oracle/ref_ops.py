@@ -478,7 +478,8 @@ def refresh_shadows(arena, shadow, table):
         if kind == 1:  # A [rank, in]
             shadow[d0:d0 + r * c].view(r, c).copy_(hi)
             shadow[d1:d1 + r * c].view(r, c).copy_(lo)
-            shadow[d2:d2 + 3 * r * c].view(c, 3 * r).copy_(torch.cat((hi.t(), hi.t(), lo.t()), dim=1))
+            ld3 = aux[0] if aux and aux[0] > 0 else 3 * r  # aux: row stride of the [in, 3 rank] block (column window of a group's [in, 3 R])
+            torch.as_strided(shadow, (c, 3 * r), (ld3, 1), d2).copy_(torch.cat((hi.t(), hi.t(), lo.t()), dim=1))
         else:  # B [out, rank]
             shadow[d0:d0 + 3 * r * c].view(r, 3 * c).copy_(torch.cat((hi, hi, lo), dim=1))
             shadow[d1:d1 + r * c].view(c, r).copy_(hi.t())

