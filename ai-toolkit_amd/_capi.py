@@ -214,6 +214,9 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
+ABI_VERSION = 6  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+
+
 def lib():
     """Load libaitk_mi355.so (import torch first so its bundled HIP runtime is the one in the process)."""
     global _lib
@@ -228,6 +231,8 @@ def lib():
 
     L = C.CDLL(LIB_PATH)
     L.aitk_abi_version.restype = C.c_int
+    if L.aitk_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} is ABI version {L.aitk_abi_version()}, this package was written against {ABI_VERSION}: rebuild the library")
     L.aitk_sizeof.restype = C.c_int
     L.aitk_sizeof.argtypes = [i32]
     for which, st in _STRUCTS.items():

@@ -99,7 +99,21 @@ class FusedGraphBase(nn.Module):
 
     def attach_network(self, network):
         # not a registered sub-module: the adapter must stay out of the base model's state_dict / parameters()
+        if self.fp8_mfma:
+            self._refuse_w8a8_adapters(network)
         object.__setattr__(self, "network", network)
+
+    @staticmethod
+    def _refuse_w8a8_adapters(network):
+        """W8A8 base GEMMs (quantize_base_fp8(mfma=True)) are written for plain LoRA adapters: a DoRA layer's column scale has no place in
+        the scaled fp8 epilogue and a LoKr layer would silently run on the weight-only bf16 path, i.e. the model would mix two
+        arithmetics.  Refused up front instead of failing inside the first step."""
+        if network is None:
+            return
+        for m in network.get_all_modules():
+            if getattr(m, "is_lokr", False) or getattr(m, "magnitude", None) is not None:
+                raise NotImplementedError(f"W8A8 fp8 base (mfma=True) with a {'LoKr' if getattr(m, 'is_lokr', False) else 'DoRA'} adapter "
+                                          f"({m.lora_name}): use the weight-only fp8 base (mfma=False) or a bf16 base")
 
     def _token_linears(self):
         raise NotImplementedError
@@ -151,6 +165,8 @@ class FusedGraphBase(nn.Module):
         weight's per-channel scale, which runs along the contraction there) in the data gradient — is quantised per token to e4m3 by
         aitk_quant_rows_fp8 right before its GEMM; the rank-r adapter slab, its operands and every adapter gradient stay bf16 / fp32.
         This is NOT the reference's arithmetic (its quantisers are weight-only): DESIGN.md states the deviation and the measured parity."""
+        if mfma:
+            self._refuse_w8a8_adapters(self.network)
         self.fp8_mfma = bool(mfma)
         for lin in self._token_linears():
             quantize_linear_fp8(lin, lin.weight.data)
@@ -191,6 +207,12 @@ class FusedGraphBase(nn.Module):
         self.ops.quant_rows_fp8(x, q, rs, col_mul=col_mul, x_seg=x_seg, M=M)
         self._q8_last = (key, x, q, rs)  # holds x: its id cannot be re-used while the entry lives
         return q, rs
+
+    def _q8_reset(self):
+        """Forget the kept quantisation: called at every block boundary and at the end of forward / backward, so the entry never outlives the
+        group of launches it was made for (kernels rewrite buffers in place, which the identity key cannot see) and does not pin an
+        activation + its codes across steps."""
+        self.__dict__.pop("_q8_last", None)
 
     def dequantized_weight(self, lin):
         return (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.dt)

@@ -334,6 +334,51 @@ def gpu_comparator(dev, rank, steps=3):
             "clip_grad_norm_, torch AdamW; no gradient checkpointing)", "per_gpu_batch": 1, "steps": steps, "ms_per_step": 1e3 * dt / steps}
 
 
+def _run_leg(out, failed, name, fn):
+    """An optional leg of the JSON line: whatever it raises is recorded under its own key and in `failed_legs` — the headline `value`
+    measured before it must survive a side leg's failure (hipGraph capture error, a missing test module, out of memory, ...)."""
+    try:
+        out[name] = fn()
+    except Exception as ex:  # noqa: BLE001 - recorded, never silent: the line says which leg failed and why
+        out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        failed.append(name)
+        if isinstance(ex, torch.OutOfMemoryError):
+            torch.cuda.empty_cache()
+
+
+def _persist_headline(out):
+    """The measured headline object on disk before any optional leg runs (AITK_BENCH_HEADLINE_FILE, default under the system temp
+    directory): a crash the per-leg handler cannot catch (a fault inside a kernel, a killed process) still leaves the number."""
+    import tempfile
+
+    path = os.environ.get("AITK_BENCH_HEADLINE_FILE") or os.path.join(tempfile.gettempdir(), "aitk_bench_headline.json")
+    try:
+        with open(path, "w") as fh:
+            json.dump(out, fh)
+    except OSError:
+        pass
+
+
+def _smi_index(dev_index):
+    """rocm-smi's index of torch device `dev_index`: the two orders differ under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remapping, so the
+    device is looked up by its PCI bus address (rocm-smi --showbus).  Returns (index, how)."""
+    import re
+    import shutil
+    import subprocess
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}".lower()
+        txt = subprocess.run([smi, "--showbus"], capture_output=True, text=True, timeout=5).stdout
+        for m in re.finditer(r"GPU\[(\d+)\]\s*:\s*PCI Bus:\s*([0-9A-Fa-f:.]+)", txt):
+            if m.group(2).lower().startswith(want):
+                return int(m.group(1)), f"pci {want}"
+    except Exception:  # noqa: BLE001 - telemetry is best effort
+        pass
+    return dev_index, "torch device index (PCI lookup unavailable)"
+
+
 def _flush_c_stdio():
     import ctypes
 
@@ -423,6 +468,83 @@ def parity_leg(dev):
                     "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
 
 
+def _rel_lists(a, b):
+    import math
+
+    num = sum(((x.float() - y.float()) ** 2).sum().item() for x, y in zip(a, b))
+    return math.sqrt(num / max(sum((y.float() ** 2).sum().item() for y in b), 1e-300))
+
+
+def parity_full_depth_ours(model, net, ops, dev):
+    """HIP half of `parity.full_depth`: the benchmarked model itself (19 double + 38 single blocks, d = 3072, 4096 + 512 tokens, 494 adapters in
+    the state the timed steps left them), one B = 1 step with fixed noise / timestep and a zero learning rate -> loss + every adapter
+    gradient; returns what the oracle half needs (the frozen base weights by reference, the adapter matrices and gradients as copies)."""
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+
+    g = torch.Generator(device=dev).manual_seed(777)
+    lat = torch.randn(1, 16, 128, 128, device=dev, generator=g).to(torch.bfloat16)
+    emb = (torch.randn(1, 512, 4096, device=dev, generator=g) * 0.1).to(torch.bfloat16)
+    pooled = (torch.randn(1, 768, device=dev, generator=g) * 0.1).to(torch.bfloat16)
+    noise = torch.randn(1, 16, 128, 128, device=dev, generator=g).to(torch.bfloat16)
+    ts = torch.tensor([500.0], device=dev)
+    st = FluxLoRATrainStep(model, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    lo = st.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    grads, adapters = [], []
+    for m in net.unet_loras:
+        grads += [m.lora_down.weight.grad.detach().clone(), m.lora_up.weight.grad.detach().clone()]
+        adapters.append((m.lora_name, m.lora_down.weight.detach().clone(), m.lora_up.weight.detach().clone()))
+    sd = {k: v for k, v in model.state_dict().items()}  # references: the bf16 base weights outlive the fused model's other copies
+    return {"_loss": lo, "_grads": grads, "_adapters": adapters, "_state": sd, "_batch": (lat, emb, pooled, noise, ts), "_rank": net.lora_dim}
+
+
+def parity_full_depth_oracle(h, dev):
+    """Oracle half of `parity.full_depth` (the CHECKER, outside every timed region): the eager oracle on the same base weights, adapter state
+    and inputs — first the reference's own arithmetic (bf16 modules + fp32 adapter, toolkit/network_mixins.py:309-321), then fp32 = truth with
+    the blocks under activation checkpointing (SDTrainer.py:2226-2238 does the same to bound memory)."""
+    from torch.utils.checkpoint import checkpoint
+
+    from oracle import flux_ref, lora_ref, train_ref
+
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            ref = flux_ref.FluxTransformer2DModel()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    ref.load_state_dict(h.pop("_state"), strict=True)
+    for p in ref.parameters():
+        p.requires_grad_(False)
+    ref_net = lora_ref.RefLoRANetwork(ref, h["_rank"]).to(dev)
+    ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
+    with torch.no_grad():
+        for (name, down, up), b in zip(h["_adapters"], ref_net.unet_loras):
+            assert name == b.lora_name, (name, b.lora_name)
+            b.lora_down.weight.copy_(down)
+            b.lora_up.weight.copy_(up)
+    ref_net.apply_to()
+    for blk in list(ref.transformer_blocks) + list(ref.single_transformer_blocks):
+        f = blk.forward
+        blk.forward = (lambda *a, _f=f: checkpoint(_f, *a, use_reentrant=False))
+    lat, emb, pooled, noise, ts = h["_batch"]
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    l16 = oracle.step(lat, emb, pooled, noise, ts, dtype=torch.bfloat16).item()
+    g16 = [p.grad.clone() for p in oracle.params]
+    ref.float()
+    torch.cuda.empty_cache()
+    l32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = [p.grad.clone() for p in oracle.params]
+    go, lo = h["_grads"], h["_loss"]
+    worst_o = max(_rel_lists([a], [b]) for a, b in zip(go, g32))
+    worst_16 = max(_rel_lists([a], [b]) for a, b in zip(g16, g32))
+    return {"config": f"FLUX.1-dev 19 + 38 blocks, d = 3072, 4096 img + 512 txt tokens, B = 1, LoRA r{h['_rank']} on {len(h['_adapters'])} Linears: the "
+                      "benchmarked model after the timed steps, one step with fixed noise / timestep; oracle fp32 under activation checkpointing",
+            "loss_ours": lo, "loss_fp32": l32, "loss_rel": abs(lo - l32) / abs(l32), "ref16_loss_rel": abs(l16 - l32) / abs(l32),
+            "grad_rel": _rel_lists(go, g32), "ref16_floor": _rel_lists(g16, g32), "grad_rel_vs_ref16": _rel_lists(go, g16),
+            "worst_module_grad_rel": worst_o, "ref16_worst_module": worst_16,
+            "note": "grad_rel / ref16_floor as in the small case above; north_star's 1e-3 holds for the loss, not for adapter gradients of "
+                    "any bf16-operand execution (DESIGN.md section 7: measured floor ~6e-3)"}
+
+
 def dvfs_leg(one, dev_index, steps=3, poll_here=True):
     """Shader clock and socket power while the step runs (rank 0, AFTER the timed region — never part of `value`): MI355X clocks to its
     1400-W budget, so the MFMA-bound kernels of this step run well below the 2400 MHz that PEAK_BF16 is quoted at
@@ -435,6 +557,9 @@ def dvfs_leg(one, dev_index, steps=3, poll_here=True):
     import threading
 
     smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    how = None
+    if smi is not None and poll_here:
+        dev_index, how = _smi_index(dev_index)
     if smi is None or not poll_here:
         for _ in range(steps + 1):  # the same number of steps as the polling rank
             one()
@@ -476,7 +601,7 @@ def dvfs_leg(one, dev_index, steps=3, poll_here=True):
         return None
     clk, pw = sorted(c for c, _ in samples), sorted(w for _, w in samples)
     return {"sclk_mhz": {"median": clk[len(clk) // 2], "min": clk[0], "max": clk[-1]}, "power_w": {"median": pw[len(pw) // 2], "max": pw[-1]},
-            "power_cap_w": cap, "samples": len(samples), "ms_per_step_while_polling": 1e3 * dt / steps,
+            "power_cap_w": cap, "samples": len(samples), "ms_per_step_while_polling": 1e3 * dt / steps, "smi_device": dev_index, "smi_device_by": how,
             "note": "rocm-smi polled from a thread during extra steps after the timed region; the roofline peak is quoted at 2400 MHz"}
 
 
@@ -501,8 +626,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="UNet bench: skip the hipGraph-replay leg")
     ap.add_argument("--recompute-gelu", action="store_true", help="FLUX: drop the GELU outputs after the forward pass (the lora_down gradients "
-                    "rebuild them from the pre-activation inside aitk_lora_wgrad2): 6.4 GB less per image; not yet the default — "
-                    "tools/gpu_check_recompute_gelu.py validates and times it")
+                    "rebuild them from the pre-activation inside aitk_lora_wgrad2): 6 GB less per image (196 vs 238 GiB peak at B = 7), -0.7 %% step time, "
+                    "bit-identical gradients (profiles/r04_recompute_gelu.json); chosen automatically when B = 7 would not fit otherwise")
     ap.add_argument("--no-dvfs", action="store_true", help="skip the clock / power telemetry leg (3 extra steps under rocm-smi polling)")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
@@ -559,11 +684,22 @@ def main():
         # bf16 base: 245 GiB peak at B = 7; the fp8 base holds 23.8 GB less (weights as bytes, bf16 copies released): 7 fits from 232 GiB
         need = 232 if args.fp8_base else 252
         B = 7 if (avail_gib >= need and args.network == "lora") else 4
+        # between the two: B = 7 still fits once the GELU outputs are dropped after the forward pass (recompute_gelu: 196 GiB peak at B = 7
+        # against 238, -0.7 % step time, bit-identical gradients; profiles/r04_recompute_gelu.json) — better than falling to B = 4
+        need_rg = 190 if args.fp8_base else 210
+        if B == 4 and args.network == "lora" and avail_gib >= need_rg:
+            B = 7
+            model.recompute_gelu = True
         if world > 1:  # every rank must step the same shard size (global batch = B * world): take the smallest choice
             bt = torch.tensor([B], device=dev, dtype=torch.int64)
             torch.distributed.all_reduce(bt, op=torch.distributed.ReduceOp.MIN)
             B = int(bt.item())
+        if world > 1:  # ... and the same graph
+            rg = torch.tensor([int(model.recompute_gelu)], device=dev, dtype=torch.int64)
+            torch.distributed.all_reduce(rg, op=torch.distributed.ReduceOp.MAX)
+            model.recompute_gelu = bool(rg.item())
         batch_note = (f"auto: {avail_gib:.0f} GiB available on rank {rank}, {need} GiB needed for per-GPU batch 7" +
+                      (f" ({need_rg} with recompute_gelu)" if model.recompute_gelu and not args.recompute_gelu else "") +
                       ("" if B == 7 else " -> per-GPU batch 4 (the B = 7 rate needs a GPU with nothing else resident)"))
     else:
         batch_note = "--batch / AITK_BENCH_BATCH"
@@ -604,7 +740,7 @@ def main():
                   "bf16 (fp8 e4m3 weight-only base, expanded per layer to bf16 before its GEMM)" if args.fp8_base else "bf16"), "data": "synthetic (random-init FLUX.1-dev architecture, N(0,1) latents, 0.1*N(0,1) text embeds)",
         "config": {"workload": workload,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "adapters": len(net.unet_loras),
-                   "lora_params": net.arena_p.numel(), "grad_checkpointing": False,
+                   "lora_params": net.arena_p.numel(), "grad_checkpointing": False, "recompute_gelu": bool(model.recompute_gelu),
                    "adapter_precision": "fp32 master + split bf16 (hi+lo) shadows on MFMA", "batch_choice": batch_note},
         "final_loss": final_loss,
         "step_ms": {"median": _pct(per_step_ms, 0.5), "p10": _pct(per_step_ms, 0.1), "p90": _pct(per_step_ms, 0.9), "n": len(per_step_ms),
@@ -624,71 +760,87 @@ def main():
                                        "note": "launch-stream time between the end of backward and the optimizer kernel, i.e. the part "
                                                "of the gradient all-reduce not hidden behind the double-block backward (rank 0)"}
     step.collect_dp_timing = False
+    failed_legs = []
+    if rank == 0:
+        _persist_headline(out)  # the measured headline is on disk before anything else runs
     rf = None
     if not args.no_roofline:
-        rf = gemm_roofline(one, ops)  # every rank runs the instrumented step (it contains the gradient all-reduce)
+        tmp = {}
+        _run_leg(tmp, failed_legs, "roofline", lambda: gemm_roofline(one, ops))  # every rank runs the instrumented step (it contains the gradient all-reduce)
+        rf = tmp["roofline"] if "error" not in tmp["roofline"] else None
+        if rf is None:
+            out["roofline"] = tmp["roofline"]
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
     if not args.no_dvfs:
-        tele = dvfs_leg(one, local_rank, poll_here=rank == 0)
-        if tele is not None:
-            out["dvfs"] = tele
+        tmp = {}
+        _run_leg(tmp, failed_legs, "dvfs", lambda: dvfs_leg(one, local_rank, poll_here=rank == 0))
+        if tmp["dvfs"] is not None:
+            out["dvfs"] = tmp["dvfs"]
     if world > 1:
         torch.distributed.barrier()
 
     extras = world == 1 and not args.no_extras and not args.fp8_base and args.network == "lora"
-    failed_legs = []
+    full_parity = None
     if extras:
-        # ---- batch sweep (single bucket): the headline B plus 1 and 4 (SURVEY.md §8d asked for B in {1, 2, 4})
+        # ---- batch sweep (single bucket): the headline B plus 1 and 4 (SURVEY.md section 8d asked for B in {1, 2, 4})
         del lat, emb, pooled
         sweep = {str(B): {"images_per_s": ips, "ms_per_step": 1e3 * dt / args.steps}}
-        for b2 in (1, 4):
-            if b2 == B:
-                continue
-            l2, e2, p2 = make_batch(dev, b2, seed=43)
-            fn = lambda: step.step(l2, e2, p2)  # noqa: E731
-            fn()
-            d2, _, _ = timed_steps(fn, 3, barrier)
-            sweep[str(b2)] = {"images_per_s": b2 * 3 / d2, "ms_per_step": 1e3 * d2 / 3}
-            del l2, e2, p2
-        out["batch_sweep"] = sweep
+
+        def leg_sweep():
+            for b2 in (1, 4):
+                if b2 == B:
+                    continue
+                l2, e2, p2 = make_batch(dev, b2, seed=43)
+                fn = lambda: step.step(l2, e2, p2)  # noqa: E731
+                fn()
+                d2, _, _ = timed_steps(fn, 3, barrier)
+                sweep[str(b2)] = {"images_per_s": b2 * 3 / d2, "ms_per_step": 1e3 * d2 / 3}
+            return sweep
+
+        _run_leg(out, failed_legs, "batch_sweep", leg_sweep)
+
         # ---- hipGraph replay of the same step (trainer.step_graphed): the ~5 000 launches of forward + backward leave the Python
         # host path.  Measured at B = 1, the reference's default batch size, where the eager launch sequence is closest to host-bound.
-        try:
+        def leg_graph():
             torch.cuda.empty_cache()
             l2, e2, p2 = make_batch(dev, 1, seed=43)
             fn = lambda: step.step_graphed(latents=l2, prompt_embeds=e2, pooled_embeds=p2)  # noqa: E731
-            fn()
-            fn()
-            d2, _, _ = timed_steps(fn, 5, barrier)
-            out["graph_replay"] = {"per_gpu_batch": 1, "images_per_s": 5 / d2, "ms_per_step": 1e3 * d2 / 5,
-                                   "eager_images_per_s": sweep["1"]["images_per_s"] if "1" in sweep else None,
-                                   "note": "forward + loss + backward replayed as one hipGraph per bucket shape; clip/AdamW/EMA launched eagerly"}
-            step._graphs.clear()
-            step._graph_pool = None
-            del l2, e2, p2, fn
-        except torch.OutOfMemoryError as ex:  # memory edge of the second pool only; any other exception is a bug and propagates
-            out["graph_replay"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            failed_legs.append("graph_replay")
-        # ---- bucketed run (BASELINE.json configs[2] "1024x1024 buckets"): the five resolutions of BASELINE.md §2 cycled so the
-        # sequence length changes every step (toolkit/config_modules.py:1095-1113, toolkit/data_loader.py:718, 749-756)
-        torch.cuda.empty_cache()
+            try:
+                fn()
+                fn()
+                d2, _, _ = timed_steps(fn, 5, barrier)
+            finally:
+                step._graphs.clear()
+                step._graph_pool = None
+            return {"per_gpu_batch": 1, "images_per_s": 5 / d2, "ms_per_step": 1e3 * d2 / 5,
+                    "eager_images_per_s": sweep["1"]["images_per_s"] if "1" in sweep else None,
+                    "note": "forward + loss + backward replayed as one hipGraph per bucket shape; clip/AdamW/EMA launched eagerly"}
+
+        _run_leg(out, failed_legs, "graph_replay", leg_graph)
         bb = min(B, 4)
-        batches = [make_batch(dev, bb, w, h, seed=50 + i) for i, (w, h) in enumerate(BUCKETS)]
-        for bt in batches:  # first touch of every shape (allocator, RoPE tables) outside the timed region
-            step.step(*bt)
-        order = [batches[i % len(batches)] for i in range(2 * len(batches))]
-        it = iter(order)
-        db, per_b, _ = timed_steps(lambda: step.step(*next(it)), len(order), barrier)
-        out["bucketed"] = {"images_per_s": bb * len(order) / db, "per_gpu_batch": bb, "steps": len(order),
-                           "buckets": [f"{w}x{h}" for w, h in BUCKETS], "ms_per_step_by_bucket": {f"{w}x{h}": round((per_b[i] + per_b[i + 5]) / 2, 2)
-                                                                                                 for i, (w, h) in enumerate(BUCKETS)},
-                           "single_bucket_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s")}
-        del batches, order
+
+        # ---- bucketed run (BASELINE.json configs[2] "1024x1024 buckets"): the five resolutions of BASELINE.md section 2 cycled so the
+        # sequence length changes every step (toolkit/config_modules.py:1095-1113, toolkit/data_loader.py:718, 749-756)
+        def leg_bucketed():
+            torch.cuda.empty_cache()
+            batches = [make_batch(dev, bb, w, h, seed=50 + i) for i, (w, h) in enumerate(BUCKETS)]
+            for bt in batches:  # first touch of every shape (allocator, RoPE tables) outside the timed region
+                step.step(*bt)
+            order = [batches[i % len(batches)] for i in range(2 * len(batches))]
+            it = iter(order)
+            db, per_b, _ = timed_steps(lambda: step.step(*next(it)), len(order), barrier)
+            return {"images_per_s": bb * len(order) / db, "per_gpu_batch": bb, "steps": len(order),
+                    "buckets": [f"{w}x{h}" for w, h in BUCKETS],
+                    "ms_per_step_by_bucket": {f"{w}x{h}": round((per_b[i] + per_b[i + 5]) / 2, 2) for i, (w, h) in enumerate(BUCKETS)},
+                    "single_bucket_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s")}
+
+        _run_leg(out, failed_legs, "bucketed", leg_bucketed)
+
         # ---- uncached-latent mode (north_star "VAE latent encode" inside the hot loop; jobs/process/BaseSDTrainProcess.py:1133 calls
         # sd.encode_images when the batch carries no cached latents): the FLUX.1 AutoencoderKL encoder runs on the batch's images in
-        # front of every step, same batch size as the bucketed leg
-        try:
+        # front of every step (the whole batch in one launch sequence), same batch size as the bucketed leg
+        def leg_uncached():
             from ai_toolkit_amd import vae as nvae
 
             torch.cuda.empty_cache()
@@ -701,20 +853,28 @@ def main():
             enc.prepare()
             imgs = torch.rand(bb, 3, 1024, 1024, device=dev, generator=gv) * 2 - 1
             _, e2, p2 = make_batch(dev, bb, seed=44)
+            vb = int(os.environ.get("AITK_BENCH_VAE_BATCH", str(bb)))  # images per encoder launch sequence
 
             def fn_vae():
-                lat2 = torch.cat([enc.encode_images(imgs[i:i + 1], generator=gv) for i in range(bb)])
+                lat2 = torch.cat([enc.encode_images(imgs[i:i + vb], generator=gv) for i in range(0, bb, vb)])
                 return step.step(lat2, e2, p2)
 
             fn_vae()
             dv, _, _ = timed_steps(fn_vae, 3, barrier)
-            out["uncached_latents"] = {"images_per_s": bb * 3 / dv, "ms_per_step": 1e3 * dv / 3, "per_gpu_batch": bb,
-                                       "cached_latents_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s"),
-                                       "note": "FLUX.1 VAE encoder (1024x1024 -> 16x128x128, one image per launch sequence) + train step"}
-            del enc, imgs, e2, p2, fn_vae
-        except torch.OutOfMemoryError as ex:  # memory edge only; any other exception is a bug and propagates
-            out["uncached_latents"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-            failed_legs.append("uncached_latents")
+            return {"images_per_s": bb * 3 / dv, "ms_per_step": 1e3 * dv / 3, "per_gpu_batch": bb,
+                    "cached_latents_same_batch_images_per_s": sweep.get(str(bb), {}).get("images_per_s"),
+                    "note": f"FLUX.1 VAE encoder (1024x1024 -> 16x128x128, {vb} image(s) per launch sequence) + train step"}
+
+        _run_leg(out, failed_legs, "uncached_latents", leg_uncached)
+
+        # ---- the HIP half of the full-depth parity leg: THIS model — 19 + 38 blocks, 494 adapters, whatever state the
+        # timed steps left the adapter in — steps one B = 1 batch with fixed noise / timestep; the oracle half runs after the model is released
+        def leg_full_parity_ours():
+            return parity_full_depth_ours(model, net, ops, dev)
+
+        tmp = {}
+        _run_leg(tmp, failed_legs, "parity_full_depth", leg_full_parity_ours)
+        full_parity = tmp.get("parity_full_depth")
     if rank == 0:
         if rf is not None:
             if os.environ.get("AITK_GEMM_CENSUS"):  # per-shape breakdown of the instrumented step (not part of the JSON line)
@@ -734,7 +894,8 @@ def main():
                 out["roofline"]["frac_at_step_clock"] = out["roofline"]["achieved"] / (out["roofline"]["peak"] * clk / 2400.0)
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) for the dominant shape (B * 4608) x 3072 x 3072 (+ LoRA slab): newest round first
-            for pmc in (os.path.join(ROOT, "profiles", "r03_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"),
+            for pmc in (os.path.join(ROOT, "profiles", "r04_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r03_pmc", "summary.json"),
+                        os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"),
                         os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")):
                 if not os.path.exists(pmc):
                     continue
@@ -752,23 +913,30 @@ def main():
 
         gc.collect()
         torch.cuda.empty_cache()
-        try:
-            out["gpu_comparator"] = gpu_comparator(dev, args.rank)
-        except torch.OutOfMemoryError as ex:  # memory edge only (the eager path needs ~78 GiB); any other exception propagates
-            out["gpu_comparator"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
-            failed_legs.append("gpu_comparator")
+        _run_leg(out, failed_legs, "gpu_comparator", lambda: gpu_comparator(dev, args.rank))
         gc.collect()
         torch.cuda.empty_cache()
-        out["parity"] = parity_leg(dev)
+        _run_leg(out, failed_legs, "parity", lambda: parity_leg(dev))
+        gc.collect()
+        torch.cuda.empty_cache()
+        if isinstance(full_parity, dict) and "error" not in full_parity:
+            tmp = {}
+            _run_leg(tmp, failed_legs, "parity_full_depth", lambda: parity_full_depth_oracle(full_parity, dev))
+            full_parity = tmp["parity_full_depth"]
+        if isinstance(out.get("parity"), dict) and full_parity is not None:
+            out["parity"]["full_depth"] = full_parity
+        elif full_parity is not None:
+            out["parity_full_depth"] = full_parity
+        full_parity = None
         gc.collect()
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        _run_leg(out, failed_legs, "cpu_baseline", cpu_baseline)
     if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if failed_legs:
-        out["legs_out_of_memory"] = failed_legs
+        out["failed_legs"] = failed_legs  # each failed leg carries its own {"error": ...}; the headline fields above are unaffected
     if rank == 0:
         _flush_c_stdio()
         sys.stdout.flush()
