@@ -867,6 +867,63 @@ def golden_unet_conv_lora_highrank():
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "unet_conv_lora_highrank.safetensors"), {"meta": json.dumps(meta)})
 
 
+
+def golden_base_model_contract():
+    """The plug-in contract of the reference, read off its own classes by introspection (imported under the shims, nothing executed):
+    toolkit/models/base_model.py `BaseModel` — every public method with its parameter names, which of them are the "must be implemented in
+    child classes" hooks (their body raises NotImplementedError, base_model.py:306-360), the properties, and the class attribute `arch`;
+    and what the two in-tree plug-ins that our models mirror define themselves (extensions_built_in/diffusion_models/flux_kontext/
+    flux_kontext.py:41-419 `FluxKontextModel`, toolkit/models/wan21/wan21.py:310-736 `Wan21`), plus how a plug-in is registered and
+    selected (toolkit/util/get_model.py:20-50: module attribute AI_TOOLKIT_MODELS, match on `arch`).  tests/test_plugin_contract_cpu.py
+    holds ai_toolkit_amd.plugin to it."""
+    import inspect
+    import textwrap
+
+    ref_shims.install_stub_finder(("controlnet_aux", "PIL", "imageio", "librosa", "soundfile", "pytorch_wavelets", "torchdiffeq", "gguf",
+                                   "huggingface_hub", "accelerate", "flatten_json", "pytorch_fid", "clip", "scipy", "tqdm", "yaml",
+                                   "ftfy", "sentencepiece", "omegaconf", "moviepy", "decord"))
+    from toolkit.models.base_model import BaseModel
+
+    def describe(cls, own_only):
+        out = {}
+        for name, fn in (vars(cls).items() if own_only else inspect.getmembers(cls)):
+            if isinstance(fn, staticmethod):
+                fn, kind = fn.__func__, "static"
+            elif isinstance(fn, property):
+                out[name] = {"kind": "property", "settable": fn.fset is not None}
+                continue
+            else:
+                kind = "method"
+            if not inspect.isfunction(fn) or (name.startswith("__") and name != "__init__"):
+                continue
+            sig = inspect.signature(fn)
+            params = [{"name": p.name, "kind": p.kind.name, "has_default": p.default is not inspect._empty} for p in sig.parameters.values()]
+            try:
+                body = textwrap.dedent(inspect.getsource(fn))
+            except OSError:
+                body = ""
+            must = "raise NotImplementedError" in body and body.count("\n") < 16
+            out[name] = {"kind": kind, "params": params, "must_implement": bool(must)}
+        return out
+
+    contract = {"BaseModel": describe(BaseModel, own_only=True), "BaseModel_arch_default": BaseModel.arch}
+    from extensions_built_in.diffusion_models.flux_kontext.flux_kontext import FluxKontextModel
+    from toolkit.models.wan21.wan21 import Wan21
+
+    for cls in (FluxKontextModel, Wan21):
+        contract[cls.__name__] = {"arch": cls.arch, "bases": [b.__name__ for b in cls.__mro__[1:-1]], "defines": describe(cls, own_only=True)}
+    import toolkit.util.get_model as gm
+
+    src = inspect.getsource(gm.get_all_models) + inspect.getsource(gm.get_model_class)
+    contract["registration"] = {"module_attribute": "AI_TOOLKIT_MODELS" if "AI_TOOLKIT_MODELS" in src else None,
+                                "selected_by": "arch" if "ModelClass.arch == config.arch" in src else None,
+                                "extension_folders": ["extensions", "extensions_built_in"] if "extensions_built_in" in src else None}
+    with open(os.path.join(HERE, "base_model_contract.json"), "w") as f:
+        json.dump(contract, f, indent=1, sort_keys=True)
+    must = sorted(k for k, v in contract["BaseModel"].items() if v.get("must_implement"))
+    print("base_model_contract.json: BaseModel methods", len(contract["BaseModel"]), "must-implement:", must)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:

@@ -29,13 +29,32 @@ class _Anything:
         return _Anything()
 
 
+class _StubMeta(type):
+    """metaclass of the stub classes: class attributes that do not exist are stub classes too (transforms.ColorJitter, Enum-like members)"""
+
+    def __iter__(cls):
+        return iter(())
+
+    def __getattr__(cls, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        sub = _StubMeta(item, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None,
+                                   "__getattr__": lambda self, k: _Anything(), "__bool__": lambda self: False})
+        setattr(cls, item, sub)
+        return sub
+
+
 class _AutoStub(types.ModuleType):
     """module whose every missing attribute is a fresh stub class (so `from x import Y` and isinstance() work)."""
 
     def __getattr__(self, item):
         if item.startswith("__"):
             raise AttributeError(item)
-        cls = type(item, (), {"__init__": lambda self, *a, **k: None})
+        sub = sys.modules.get(f"{self.__name__}.{item}")
+        if sub is not None:
+            return sub
+        cls = _StubMeta(item, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None,
+                                   "__getattr__": lambda self, k: _Anything(), "__bool__": lambda self: False})
         setattr(self, item, cls)
         return cls
 
@@ -67,3 +86,31 @@ def install():
     qp = _auto("torchao.quantization.quant_primitives")
     qp._DTYPE_TO_BIT_WIDTH = {}
     sys.modules["dotenv"].load_dotenv = lambda *a, **k: None
+
+
+class _StubFinder:
+    """meta-path finder of last resort for the introspection-only generators (golden_base_model_contract): any not-installed sub-module
+    of a package that is already stubbed (diffusers.pipelines.x.y, optimum.quanto.z, ...) and any other missing top-level package
+    becomes an _AutoStub, so that the reference's class definitions can be IMPORTED and inspected (never executed)."""
+
+    def __init__(self, roots):
+        self.roots = tuple(roots)
+
+    def find_spec(self, name, path=None, target=None):
+        top = name.split(".")[0]
+        if top in self.roots or isinstance(sys.modules.get(top), _AutoStub):
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _AutoStub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_stub_finder(extra_roots=()):
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.append(_StubFinder(extra_roots))
