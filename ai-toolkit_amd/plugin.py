@@ -9,8 +9,11 @@ in-tree plug-ins, without importing the reference (its `BaseModel` pulls in diff
                        identical pack / ids / guidance / unpack to the legacy branch, toolkit/stable_diffusion_model.py:2154-2222)
   Wan21MI355Model   <- toolkit/models/wan21/wan21.py:330-342, 578-603, 717-736
 
-A maintainer makes them real plug-ins by adding `BaseModel` to the bases and listing them in AI_TOOLKIT_MODELS (INTEGRATION.md
-§2); everything below already runs on the fused graphs: `get_noise_prediction` calls the model's diffusers-signature
+`integration/extensions/aitk_mi355/__init__.py` turns them into REAL plug-ins — `type(name, (Mirror, BaseModel), ...)` listed in
+AI_TOOLKIT_MODELS — and tests/golden/plugin_registration.json records that package executed against the reference's own classes (subclass
+check, construction with the reference's ModelConfig, selection by toolkit/util/get_model.py's get_model_class); the hook set and every
+signature are held to tests/golden/base_model_contract.json, introspected from toolkit/models/base_model.py (tests/test_plugin_contract_cpu.py).
+`load_model` streams a diffusers checkpoint directory (sharded safetensors) into the native graph (loader.py).  Everything below runs on the fused graphs: `get_noise_prediction` calls the model's diffusers-signature
 `forward`, whose output carries the explicit HIP backward through torch.autograd, so `accelerator.backward(loss)`
 (SDTrainer.py:2238) fills the adapter gradient arena.
 """
@@ -35,17 +38,123 @@ def _embeds(text_embeddings):
     return text_embeddings, None
 
 
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "fp32": torch.float32,
+           "float32": torch.float32, "float": torch.float32}
+
+
+def _torch_dtype(dtype):
+    """the reference passes dtype names ('bf16', 'fp16', 'fp32': toolkit/train_tools.py get_torch_dtype); torch dtypes pass through"""
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    try:
+        return _DTYPES[str(dtype).lower()]
+    except KeyError:
+        raise ValueError(f"unknown dtype {dtype!r}") from None
+
+
 class _PluginBase:
+    """Constructor and hook set of `toolkit/models/base_model.py:98-360` (pinned by tests/golden/base_model_contract.json, generated from the
+    reference class): `(device, model_config, dtype, custom_pipeline, noise_scheduler, **kwargs)` like every in-tree plug-in; `model=` / `vae=`
+    hand over already-built native graphs (tests, bench), otherwise `load_model()` builds them from `model_config.name_or_path`."""
     is_flow_matching = True
     is_transformer = True
     use_old_lokr_format = False
+    arch = None
 
-    def __init__(self, device, model=None, vae=None, dtype=torch.bfloat16, **kwargs):
+    def __init__(self, device, model_config=None, dtype="bf16", custom_pipeline=None, noise_scheduler=None, *, model=None, vae=None, **kwargs):
+        self.device = device
         self.device_torch = torch.device(device)
-        self.torch_dtype = dtype
+        self.vae_device_torch = self.te_device_torch = self.device_torch
+        self.dtype = dtype
+        self.torch_dtype = _torch_dtype(dtype)
+        self.model_config = model_config
+        self.custom_pipeline = custom_pipeline
+        self.noise_scheduler = noise_scheduler
         self.model = model
         self.vae = vae
+        self.text_encoder = None   # text embeddings are cached in every example config of the reference (SURVEY.md section 8, row a17)
+        self.tokenizer = None
+        self.pipeline = None
         self.network = None
+        self.is_loaded = model is not None
+
+    # ---- "must be implemented in child classes" hooks (base_model.py:306-360)
+    _component = None            # diffusers sub-folder of the denoiser ('transformer')
+
+    def _build_native(self):     # -> un-initialised native graph of the architecture the checkpoint holds
+        raise NotImplementedError
+
+    def load_model(self):
+        """`model_config.name_or_path` = a diffusers pipeline directory (or the component directory itself, flux_kontext.py:84-92): the
+        denoiser's sharded safetensors stream into the native graph (loader.load_component), `model_config.quantize` selects the
+        weight-only fp8 base (toolkit/util/quantize.py:43-75), the VAE encoder is loaded when the directory has one.  Text encoders are
+        not loaded: prompts must be cached (`get_prompt_embeds` says so)."""
+        from . import loader
+
+        cfg = self.model_config
+        path = getattr(cfg, "name_or_path", None)
+        if not path:
+            raise ValueError("model_config.name_or_path is required")
+        self.model = self._build_native()
+        loader.load_component(self.model, loader.resolve_component_dir(path, self._component))
+        for p in self.model.parameters():
+            p.requires_grad_(False)
+        if getattr(cfg, "quantize", False):
+            self.model.quantize_base_fp8(release_bf16=True)
+        self.model.prepare()
+        base = getattr(cfg, "extras_name_or_path", None) or path
+        try:
+            vdir = loader.resolve_component_dir(base, "vae")
+        except FileNotFoundError:
+            vdir = None
+        if vdir is not None:
+            self.vae = self._build_vae()
+            loader.load_component(self.vae, vdir, strict=False, rename=lambda k: k if k.startswith(("encoder.", "quant_conv.")) else None)
+            self.vae.prepare()
+        self.noise_scheduler = self.get_train_scheduler()
+        self.is_loaded = True
+
+    def _build_vae(self):
+        from . import ops, vae as nvae
+
+        return nvae.AutoencoderKLEncoder(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+
+    def get_generation_pipeline(self):
+        raise NotImplementedError("sampling / preview generation is outside the accelerated path (SURVEY.md section 8: out of scope); "
+                                  "run previews through the reference's own pipeline on the saved LoRA")
+
+    def generate_single_image(self, pipeline, gen_config, conditional_embeds, unconditional_embeds, generator, extra):
+        raise NotImplementedError("sampling / preview generation is outside the accelerated path (SURVEY.md section 8: out of scope)")
+
+    def get_prompt_embeds(self, prompt, control_images=None):
+        raise NotImplementedError("text encoders are not part of the accelerated path: train with cached text embeddings "
+                                  "(datasets: cache_text_embeddings: true; ai_toolkit_amd.batches reads the reference's _t_e_cache files)")
+
+    def save_model(self, output_path, meta, save_dtype):
+        """BaseModel.save_model (base_model.py:350-360): the denoiser in diffusers layout under <output_path>/<component> + aitk_meta.yaml."""
+        import os
+
+        import yaml
+
+        from . import loader
+
+        loader.save_component(self.model, os.path.join(output_path, self._component), dtype=_torch_dtype(save_dtype))
+        with open(os.path.join(output_path, "aitk_meta.yaml"), "w") as f:
+            yaml.dump(dict(meta), f)
+
+    def encode_audio(self, audio_data_list):
+        raise NotImplementedError("Audio encoding not implemented for this model.")  # base_model.py:1178-1180
+
+    def get_model_to_train(self):
+        return self.model
+
+    @property
+    def transformer(self):
+        return self.model
+
+    @property
+    def model_unwrapped(self):
+        return self.model
 
     # the reference reads the denoiser through these aliases (toolkit/models/base_model.py:199-216)
     @property
@@ -87,6 +196,13 @@ class _PluginBase:
 class Flux1MI355Model(_PluginBase):
     arch = "flux_mi355"
     target_lora_modules = ["FluxTransformer2DModel"]
+    _component = "transformer"
+
+    def _build_native(self):
+        from . import ops
+        from .flux import FluxTransformer2DModel
+
+        return FluxTransformer2DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
 
     @staticmethod
     def get_train_scheduler():
@@ -137,6 +253,18 @@ class Flux1MI355Model(_PluginBase):
 class Wan21MI355Model(_PluginBase):
     arch = "wan21_mi355"
     target_lora_modules = ["WanTransformer3DModel"]
+    _component = "transformer"
+
+    def _build_native(self):
+        from . import ops
+        from .wan import WanTransformer3DModel
+
+        return WanTransformer3DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+
+    def _build_vae(self):
+        from . import ops, wan_vae
+
+        return wan_vae.AutoencoderKLWanEncoder(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
 
     @staticmethod
     def get_train_scheduler():
@@ -185,9 +313,26 @@ class StableDiffusionMI355Model(_PluginBase):
     is_transformer = False
     target_lora_modules = ["Transformer2DModel"]  # toolkit/kohya_lora.py:750 (+ ResnetBlock2D / Downsample2D / Upsample2D with network.conv)
 
-    def __init__(self, device, model=None, vae=None, dtype=torch.bfloat16, is_xl=False, prediction_type="epsilon", **kwargs):
-        super().__init__(device, model=model, vae=vae, dtype=dtype, **kwargs)
+    _component = "unet"
+
+    # BaseModel exposes is_xl as a read-only property of model_config (base_model.py:233); here it is also a constructor argument
+    @property
+    def is_xl(self):
+        return self._is_xl
+
+    @is_xl.setter
+    def is_xl(self, v):
+        self._is_xl = bool(v)
+
+    def __init__(self, device, model_config=None, dtype="bf16", custom_pipeline=None, noise_scheduler=None, *, model=None, vae=None,
+                 is_xl=None, prediction_type=None, **kwargs):
+        super().__init__(device, model_config, dtype, custom_pipeline, noise_scheduler, model=model, vae=vae, **kwargs)
         from .ddpm import DDPMTrainSchedule
+
+        if is_xl is None:  # toolkit/config_modules.py ModelConfig.is_xl / arch
+            is_xl = bool(getattr(model_config, "is_xl", False)) or getattr(model_config, "arch", None) == "sdxl"
+        if prediction_type is None:  # base_model.py:127
+            prediction_type = "v_prediction" if getattr(model_config, "is_v_pred", False) else "epsilon"
 
         self.is_xl = bool(is_xl)
         self.prediction_type = prediction_type
@@ -198,6 +343,12 @@ class StableDiffusionMI355Model(_PluginBase):
         from .ddpm import DDPMTrainSchedule
 
         return DDPMTrainSchedule()
+
+    def _build_native(self):
+        from . import ops
+        from .unet import SD15_CONFIG, SDXL_CONFIG, UNet2DConditionModel
+
+        return UNet2DConditionModel(**(SDXL_CONFIG if self.is_xl else SD15_CONFIG), dtype=self.torch_dtype, device=self.device_torch, ops=ops)
 
     def get_bucket_divisibility(self):
         return 8  # vae scale factor 8; the UNet's three (SDXL: two) stride-2 levels are covered by the reference's 64-px bucket tolerance

@@ -1,0 +1,30 @@
+"""ai-toolkit extension: the MI355X-native denoisers as model plug-ins.
+
+Install: copy (or symlink) this directory to `<ai-toolkit>/extensions/aitk_mi355/` and put this repository on PYTHONPATH.  ai-toolkit
+collects `AI_TOOLKIT_MODELS` from every package under `extensions/` and `extensions_built_in/` and selects a class by
+`model.arch` (toolkit/util/get_model.py:20-50), so a config with `model: {arch: flux_mi355, name_or_path: <FLUX.1-dev diffusers dir>}`
+(or `wan21_mi355`, `sd_mi355`) trains through the HIP kernels with the reference's own trainer, network and data code.
+
+Each entry is a REAL `toolkit.models.base_model.BaseModel` subclass: the mirror from ai_toolkit_amd.plugin comes first in the MRO, so its
+hooks (`load_model`, `get_noise_prediction`, `get_loss_target`, `encode_images`, `save_model`, ...) override BaseModel's, and everything the
+mirror does not define (device-state presets, `prepare_optimizer_params`, hooks, ...) is BaseModel's own code.
+"""
+from toolkit.models.base_model import BaseModel
+
+import ai_toolkit_amd  # noqa: F401  (import alias of the hyphenated package directory)
+from ai_toolkit_amd import plugin as _p
+
+
+def _real(mirror):
+    def __init__(self, device, model_config, dtype="bf16", custom_pipeline=None, noise_scheduler=None, **kwargs):
+        BaseModel.__init__(self, device, model_config, dtype=dtype, custom_pipeline=custom_pipeline, noise_scheduler=noise_scheduler, **kwargs)
+        mirror.__init__(self, device, model_config, dtype, custom_pipeline, noise_scheduler, **kwargs)
+
+    return type(mirror.__name__.replace("Model", ""), (mirror, BaseModel), {"__init__": __init__, "__doc__": mirror.__doc__, "arch": mirror.arch})
+
+
+Flux1MI355 = _real(_p.Flux1MI355Model)
+Wan21MI355 = _real(_p.Wan21MI355Model)
+StableDiffusionMI355 = _real(_p.StableDiffusionMI355Model)
+
+AI_TOOLKIT_MODELS = [Flux1MI355, Wan21MI355, StableDiffusionMI355]

@@ -924,6 +924,45 @@ def golden_base_model_contract():
     print("base_model_contract.json: BaseModel methods", len(contract["BaseModel"]), "must-implement:", must)
 
 
+
+def golden_plugin_registration():
+    """integration/extensions/aitk_mi355 executed against the reference's OWN classes (under the shims): every entry of its AI_TOOLKIT_MODELS
+    is a real `BaseModel` subclass whose hooks resolve to the MI355X mirror, it can be constructed with the reference's ModelConfig, and
+    the reference's selection logic (toolkit/util/get_model.py:44-50: first class whose `arch` equals `config.arch`) returns it."""
+    import importlib.util
+
+    ref_shims.install_stub_finder(("controlnet_aux", "PIL", "imageio", "librosa", "soundfile", "pytorch_wavelets", "torchdiffeq", "gguf",
+                                   "huggingface_hub", "accelerate", "flatten_json", "pytorch_fid", "clip", "scipy", "tqdm", "yaml",
+                                   "ftfy", "sentencepiece", "omegaconf", "moviepy", "decord"))
+    import toolkit.util.get_model as gm
+    from toolkit.config_modules import ModelConfig
+    from toolkit.models.base_model import BaseModel
+
+    spec = importlib.util.spec_from_file_location("aitk_mi355_ext", os.path.join(ROOT, "integration", "extensions", "aitk_mi355", "__init__.py"))
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    builtin = list(gm.BUILT_IN_MODELS)
+    gm.get_all_models = lambda: builtin + list(ext.AI_TOOLKIT_MODELS)
+    out = {"classes": []}
+    for cls in ext.AI_TOOLKIT_MODELS:
+        cfg = ModelConfig(name_or_path="/nonexistent", arch=cls.arch)
+        picked = gm.get_model_class(cfg)
+        obj = cls("cpu", cfg, dtype="bf16")
+        hooks = {}
+        for h in ("load_model", "get_noise_prediction", "get_model_has_grad", "get_te_has_grad", "get_prompt_embeds", "save_model",
+                  "get_generation_pipeline", "generate_single_image", "get_loss_target", "encode_images", "get_train_scheduler",
+                  "prepare_optimizer_params", "set_device_state_preset", "get_bucket_divisibility"):
+            fn = getattr(cls, h)
+            owner = next(k.__name__ for k in cls.__mro__ if h in vars(k))
+            hooks[h] = owner
+        out["classes"].append({"name": cls.__name__, "arch": cls.arch, "is_BaseModel_subclass": issubclass(cls, BaseModel),
+                               "selected_by_get_model_class": picked is cls, "mro": [k.__name__ for k in cls.__mro__],
+                               "constructed": type(obj).__name__, "torch_dtype": str(obj.torch_dtype), "hook_owner": hooks})
+    with open(os.path.join(HERE, "plugin_registration.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("plugin_registration.json:", [(c["name"], c["is_BaseModel_subclass"], c["selected_by_get_model_class"]) for c in out["classes"]])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:
