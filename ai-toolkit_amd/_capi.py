@@ -250,6 +250,8 @@ def lib():
     L.aitk_slab_rescale.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, vp]
     L.aitk_gemm_nt_grouped.argtypes = [vp, vp, vp]
     L.aitk_lokr_lowrank_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.aitk_grad_compress_bf16.argtypes = [vp, vp, i64, vp]
+    L.aitk_grad_expand_bf16.argtypes = [vp, vp, i64, vp]
     L.aitk_groupnorm_workspace_bytes.restype = C.c_int64
     L.aitk_groupnorm_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.aitk_softmax_rows.argtypes = [vp, i64, i32, i32, C.c_float, vp]

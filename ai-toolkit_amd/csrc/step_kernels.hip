@@ -401,6 +401,67 @@ extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, 
 }
 
 
+// ------------------------------------------------------------------------------------------------ bf16 gradient transport (DP all-reduce)
+// the LoRA-gradient all-reduce over xGMI may run in fp32 (parity) or bf16 (half the bytes on the links).  The flat fp32
+// gradient arena is rounded to bf16 into a transport buffer (one rounding per rank, round-to-nearest-even), RCCL sums the bf16 buffers,
+// and the sum is expanded back over the fp32 arena.  HBM-bound: 6 B per element each way, 16-B accesses, grid-stride.
+// `lead` scalar elements bring both pointers to a 16-byte boundary (the transport buffer is indexed like the arena, so one lead serves both);
+// lead = n: no common alignment, everything goes through the scalar path.
+__global__ __launch_bounds__(256) void grad_compress_bf16_kernel(const float* __restrict__ g, bf16_t* __restrict__ out, long n, int lead) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+  const long n8 = (n - lead) / 8;
+  const float* ga = g + lead;
+  bf16_t* oa = out + lead;
+  for (long i = tid; i < n8; i += nth) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ga + 8 * i), b = *reinterpret_cast<const f32x4_t*>(ga + 8 * i + 4);
+    uint4 o;
+    o.x = pack2bf(a[0], a[1]); o.y = pack2bf(a[2], a[3]); o.z = pack2bf(b[0], b[1]); o.w = pack2bf(b[2], b[3]);
+    *reinterpret_cast<uint4*>(oa + 8 * i) = o;
+  }
+  for (long i = tid; i < lead; i += nth) out[i] = f2bf(g[i]);
+  for (long i = lead + 8 * n8 + tid; i < n; i += nth) out[i] = f2bf(g[i]);
+}
+__global__ __launch_bounds__(256) void grad_expand_bf16_kernel(const bf16_t* __restrict__ in, float* __restrict__ g, long n, int lead) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+  const long n8 = (n - lead) / 8;
+  float* ga = g + lead;
+  const bf16_t* ia = in + lead;
+  for (long i = tid; i < n8; i += nth) {
+    const uint4 u = *reinterpret_cast<const uint4*>(ia + 8 * i);
+    f32x4_t a = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+    f32x4_t b = {bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+    *reinterpret_cast<f32x4_t*>(ga + 8 * i) = a;
+    *reinterpret_cast<f32x4_t*>(ga + 8 * i + 4) = b;
+  }
+  for (long i = tid; i < lead; i += nth) g[i] = bf2f(in[i]);
+  for (long i = lead + 8 * n8 + tid; i < n; i += nth) g[i] = bf2f(in[i]);
+}
+static int grad_lead(const void* f32p, const void* bf16p, int64_t n) {
+  const int lead = (int)(((16 - ((uintptr_t)bf16p & 15)) & 15) / 2);  // bf16 elements up to the next 16-byte boundary
+  if (lead >= n) return (int)n;
+  return (((uintptr_t)((const float*)f32p + lead)) & 15) ? (int)(n > 0x7fffffff ? 0x7fffffff : n) : lead;
+}
+extern "C" int aitk_grad_compress_bf16(const float* g, aitk_bf16* out, int64_t n, aitk_stream_t stream) {
+  if (!g || !out || n <= 0) return AITK_ERR_ARG;
+  if (((uintptr_t)g & 3) || ((uintptr_t)out & 1) || n > 0x7fffffffLL * 8) return AITK_ERR_ALIGN;
+  const int lead = grad_lead(g, out, n);
+  const long blocks = (n / 8 + 255) / 256;
+  hipLaunchKernelGGL(grad_compress_bf16_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, g,
+                     (bf16_t*)out, (long)n, lead);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+extern "C" int aitk_grad_expand_bf16(const aitk_bf16* in, float* g, int64_t n, aitk_stream_t stream) {
+  if (!g || !in || n <= 0) return AITK_ERR_ARG;
+  if (((uintptr_t)g & 3) || ((uintptr_t)in & 1) || n > 0x7fffffffLL * 8) return AITK_ERR_ALIGN;
+  const int lead = grad_lead(g, in, n);
+  const long blocks = (n / 8 + 255) / 256;
+  hipLaunchKernelGGL(grad_expand_bf16_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, g, (long)n, lead);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ low-rank LoKr factor gradients
 // W2 = a [O, r] @ b [r, I] (toolkit/models/lokr.py:184-197): from the gradient dW [O, I] of the composed factor,
 // ga (+)= dW b^T, gb (+)= a^T dW.  O, I <= a few hundred, r <= 64: one workgroup, fp32 VALU, fixed summation order.

@@ -595,6 +595,20 @@ def lokr_lowrank_grad(dw, a, b, ga, gb, *, accumulate=True):
     _call("aitk_lokr_lowrank_grad", _ptr(dw), _ptr(a), _ptr(b), _ptr(ga), _ptr(gb), O, I, r, int(accumulate))
 
 
+def grad_compress_bf16(g, out):
+    """out (bf16, flat) = round(g) for a slice of the fp32 gradient arena: transport format of the bf16 DP all-reduce"""
+    assert g.dtype == torch.float32 and out.dtype == BF16 and g.is_contiguous() and out.is_contiguous() and out.numel() >= g.numel()
+    _call("aitk_grad_compress_bf16", _ptr(g), _ptr(out), g.numel())
+    return out
+
+
+def grad_expand_bf16(src, g):
+    """g (fp32 arena slice) = float(src) after the collective"""
+    assert g.dtype == torch.float32 and src.dtype == BF16 and g.is_contiguous() and src.is_contiguous() and src.numel() >= g.numel()
+    _call("aitk_grad_expand_bf16", _ptr(src), _ptr(g), g.numel())
+    return g
+
+
 def refresh_shadows(arena, shadow, table):
     tab, n = table
     _call("aitk_lora_refresh_shadows", _ptr(arena), _ptr(shadow), _ptr(tab), n)

@@ -23,7 +23,7 @@ class _LoRATrainStepBase:
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
                  seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False,
                  latent_multiplier=1.0, adaptive_scaling_factor=False, noisy_latent_multiplier=1.0, loss_type="mse",
-                 ema_use_feedback=False, ema_param_multiplier=1.0, ema_use_num_updates=False):
+                 ema_use_feedback=False, ema_param_multiplier=1.0, ema_use_num_updates=False, allreduce_dtype="fp32"):
         self.model, self.network, self.ops = model, network, ops
         # train.loss_type (SDTrainer.py:903-916): mse (default) / mae / pseudo_huber run as modes of aitk_mse_loss_grad; wavelet,
         # stepped, pixelspace and mean_flow are other losses of the reference and are refused
@@ -51,6 +51,13 @@ class _LoRATrainStepBase:
         self.lr_scheduler = lr_scheduler  # LRSchedule or None (constant): stepped once per train-loop iteration
         if lr_scheduler is not None:
             self.lr = lr_scheduler.get_last_lr()[0]
+        # the gradient all-reduce runs in fp32 (default: DP(P) == one rank on the concatenated batch up to fp32 summation
+        # order) or in bf16 (half the bytes on the xGMI links: each rank's gradient is rounded once to bf16, RCCL sums in bf16, the sum is
+        # expanded over the fp32 arena — a stated deviation of ~2^-9 relative per element, tests/test_train_step_cpu.py)
+        if allreduce_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"allreduce_dtype {allreduce_dtype!r}: fp32 or bf16")
+        self.allreduce_dtype = allreduce_dtype
+        self._transport = None  # bf16 transport buffer, one per arena (allocated on first use)
         self.pg = process_group
         self.world = 1
         self.dp = process_group is not None  # a 1-rank group still walks the all-reduce path (RCCL smoke on one GPU)
@@ -97,10 +104,18 @@ class _LoRATrainStepBase:
 
         g = self.network.arena_g
         n_mat = getattr(self.network, "n_mat", g.numel())  # DoRA magnitude vectors sit at [n_mat, n): final only at the end
-        pieces = [g[self._split:n_mat]] if which in ("single", "late") else [g[: self._split], g[n_mat:]]
-        for piece in pieces:
-            if piece.numel():
-                self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        ranges = [(self._split, n_mat)] if which in ("single", "late") else [(0, self._split), (n_mat, g.numel())]
+        for a, b in ranges:
+            if b <= a:
+                continue
+            if self.allreduce_dtype == "bf16":
+                if self._transport is None:  # indexed like the arena: piece [a, b) travels as transport[a:b]
+                    self._transport = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
+                buf = self._transport[a:b]
+                self.ops.grad_compress_bf16(g[a:b], buf)
+                self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), buf, (a, b)))
+            else:
+                self._pending.append((dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True), None, None))
 
     def _table_type(self):
         """timestep table the scheduler is set to: `linear_timesteps` / `linear_timesteps2` force 'linear' whatever timestep_type says
@@ -115,8 +130,10 @@ class _LoRATrainStepBase:
         return tw if loss_weight is None else loss_weight * tw
 
     def _finish_allreduce(self):
-        for w in self._pending:
+        for w, buf, rng in self._pending:
             w.wait()
+            if buf is not None:
+                self.ops.grad_expand_bf16(buf, self.network.arena_g[rng[0]:rng[1]])
         self._pending = []
 
     @staticmethod

@@ -379,6 +379,56 @@ def _smi_index(dev_index):
     return dev_index, "torch device index (PCI lookup unavailable)"
 
 
+def allreduce_standalone(step, net, pg, world, dev, iters=5):
+    """The two gradient all-reduce pieces of a step on an otherwise idle GPU (after the timed region): per-piece duration from events on the
+    launch stream around a blocking collective, and the ring bus bandwidth 2 (P - 1) / P x bytes / time it corresponds to — what
+    `allreduce_ms_exposed` is to be read against."""
+    import torch.distributed as dist
+
+    g = net.arena_g
+    n_mat = getattr(net, "n_mat", g.numel())
+    ranges = [(step._split, n_mat), (0, step._split)] + ([(n_mat, g.numel())] if g.numel() > n_mat else [])
+    bf = step.allreduce_dtype == "bf16"
+    bufs = [torch.zeros(b - a, dtype=torch.bfloat16 if bf else torch.float32, device=dev) for a, b in ranges]
+    res = []
+    for (a, b), buf in zip(ranges, bufs):
+        dist.all_reduce(buf, group=pg)  # warm-up (communicator / channel set-up for this size)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf, group=pg)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        nbytes = buf.numel() * buf.element_size()
+        res.append({"arena_range": [a, b], "bytes": nbytes, "ms": ms,
+                    "bus_GBps": (2 * (world - 1) / world) * nbytes / (ms * 1e6) if world > 1 and ms > 0 else None})
+    return {"pieces": res, "total_ms": sum(r["ms"] for r in res), "note": "blocking all-reduce of each piece on an idle GPU, order of issue "
+            "(single-stream adapters first); bus_GBps = ring traffic per GPU / time"}
+
+
+def xgmi_topology():
+    """Link type and hop count between the GPUs of this node as rocm-smi reports them (`--showtopotype`, `--showtopohops`): xGMI is
+    point-to-point, a ring all-reduce is bound by the slowest link it crosses (7 links x ~153 GB/s per GPU on an 8-GPU MI355X board)."""
+    import re
+    import shutil
+    import subprocess
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    out = {}
+    try:
+        t = subprocess.run([smi, "--showtopotype"], capture_output=True, text=True, timeout=10).stdout
+        kinds = re.findall(r"\b(XGMI|PCIE)\b", t)
+        out["link_types"] = {k: kinds.count(k) for k in sorted(set(kinds))}
+        h = subprocess.run([smi, "--showtopohops"], capture_output=True, text=True, timeout=10).stdout
+        hops = [int(x) for line in h.splitlines() if line.startswith("GPU") for x in re.findall(r"\s(\d+)(?=\s|$)", line)]
+        out["max_hops"] = max(hops) if hops else None
+    except Exception as ex:  # noqa: BLE001 - telemetry is best effort
+        out["error"] = f"{type(ex).__name__}: {ex}"[:120]
+    return out
+
+
 def _flush_c_stdio():
     import ctypes
 
@@ -628,6 +678,12 @@ def main():
     ap.add_argument("--recompute-gelu", action="store_true", help="FLUX: drop the GELU outputs after the forward pass (the lora_down gradients "
                     "rebuild them from the pre-activation inside aitk_lora_wgrad2): 6 GB less per image (196 vs 238 GiB peak at B = 7), -0.7 %% step time, "
                     "bit-identical gradients (profiles/r04_recompute_gelu.json); chosen automatically when B = 7 would not fit otherwise")
+    ap.add_argument("--allreduce-dtype", default=os.environ.get("AITK_ALLREDUCE_DTYPE", "fp32"), choices=["fp32", "bf16"],
+                    help="transport of the LoRA-gradient all-reduce (N > 1): fp32 = parity with one rank on the concatenated batch (default), "
+                         "bf16 = half the bytes on the xGMI links, one bf16 rounding of each rank's gradient and of the sum (SURVEY.md section 8e)")
+    ap.add_argument("--rccl-channels", type=int, default=int(os.environ.get("AITK_RCCL_CHANNELS", "0")),
+                    help="N > 1: pin RCCL to this many channels (NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU "
+                         "taken from the persistent 256-workgroup compute kernels while a collective runs); 0 = RCCL's own choice")
     ap.add_argument("--no-dvfs", action="store_true", help="skip the clock / power telemetry leg (3 extra steps under rocm-smi polling)")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
@@ -654,14 +710,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
+    rccl_hi_prio = False
     if world > 1 or os.environ.get("AITK_BENCH_FORCE_PG"):  # FORCE_PG: 1-rank RCCL group, exercises the collective path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("AITK_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only for the one-device rehearsal
+        if args.rccl_channels > 0:  # must be in the environment before the communicator is created
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # the collective's kernels go to a HIGH-PRIORITY stream: the compute kernels of the step are persistent (one workgroup per CU,
+            # ~1 ms each), so an all-reduce kernel can only start when a compute kernel ends — with priority it is dispatched ahead of the
+            # next queued compute kernel instead of behind the whole queue
+            pg_opts = None
+            try:
+                pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:  # noqa: BLE001 - older torch builds: default stream priority
+                pass
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **({"pg_options": pg_opts} if pg_opts is not None else {}))
+            rccl_hi_prio = pg_opts is not None
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
@@ -677,7 +745,7 @@ def main():
     model, net, ops = build_flux(dev, rank=args.rank, fp8_base=args.fp8_base, network_type=args.network, fp8_mfma=args.fp8_mfma)
     model.recompute_gelu = bool(args.recompute_gelu)
     step = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99,
-                             timestep_type="linear", process_group=pg, seed=1000 + rank)
+                             timestep_type="linear", process_group=pg, seed=1000 + rank, allreduce_dtype=args.allreduce_dtype)
     B = args.batch
     if B <= 0:
         avail_gib = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30  # free + what this process holds
@@ -748,14 +816,30 @@ def main():
         "step_mfma_frac": FLOP_PER_IMAGE * (ips / world) / (PEAK_BF16 * 1e12),
     }
     if pg is not None:
+        esz = 2 if args.allreduce_dtype == "bf16" else 4
         out["rccl"] = {"ranks": torch.distributed.get_world_size(pg), "backend": torch.distributed.get_backend(pg),
-                       "allreduce_bytes_per_step": 4 * net.arena_g.numel(), "pieces": 2,
+                       "allreduce_dtype": args.allreduce_dtype, "allreduce_bytes_per_step": esz * net.arena_g.numel(), "pieces": 2,
+                       "high_priority_stream": rccl_hi_prio, "channels": args.rccl_channels or "rccl default",
+                       "env": {k: os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_ALGO", "NCCL_PROTO", "RCCL_MSCCL_ENABLE",
+                                                          "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ},
                        "ms_per_step_by_rank": per_rank_ms}
+        tmp = {}
+        _run_leg(tmp, [], "standalone", lambda: allreduce_standalone(step, net, pg, world, dev))  # every rank takes part
+        out["rccl"]["allreduce_standalone"] = tmp["standalone"]
+        if rank == 0:
+            out["rccl"]["topology"] = xgmi_topology()
         if one_device:
             out["rccl"]["rehearsal"] = "AITK_BENCH_ONE_DEVICE: every rank on device 0 — control flow only, `value` is NOT a multi-GPU measurement"
             out["data"] += " [one-device rehearsal, not a measurement]"
     if step.collect_dp_timing and step.dp_wait_events:
         waits = [a.elapsed_time(b) for a, b in step.dp_wait_events]
+        alone = (out.get("rccl", {}).get("allreduce_standalone") or {}).get("total_ms")
+        if alone:
+            # the line's own answer to "did RCCL starve beside the persistent compute kernels": the all-reduce needs `total_ms` on an idle GPU;
+            # hidden_fraction = how much of that disappeared behind the double-block backward, exposed_over_standalone > 1 = it ran SLOWER
+            # than alone AND none of it was hidden (starved for CUs)
+            out["rccl"]["hidden_fraction"] = max(0.0, 1.0 - _pct(waits, 0.5) / alone)
+            out["rccl"]["exposed_over_standalone"] = _pct(waits, 0.5) / alone
         out["allreduce_ms_exposed"] = {"median": _pct(waits, 0.5), "p90": _pct(waits, 0.9), "n": len(waits),
                                        "note": "launch-stream time between the end of backward and the optimizer kernel, i.e. the part "
                                                "of the gradient all-reduce not hidden behind the double-block backward (rank 0)"}

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 6 /* 6: aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 6 /* 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -354,6 +354,13 @@ int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
 typedef struct AitkShadowDesc { int64_t src_off; int64_t d0; int64_t d1; int64_t d2; int32_t rows, cols, kind, aux; } AitkShadowDesc;
 int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                               aitk_stream_t stream);
+
+/* bf16 transport of the flat fp32 gradient arena for the data-parallel all-reduce (SURVEY.md section 8e "fp32 (parity) or bf16 (speed)"; the
+ * reference's nominal DDP reduces whatever dtype the parameters have, jobs/process/BaseSDTrainProcess.py:1982-1983 keeps the network in fp32):
+ * out[i] = bf16(g[i]) (round to nearest even) before the collective, g[i] = float(in[i]) after it.  Any element alignment; the 16-byte path
+ * is taken when the two pointers reach a 16-byte boundary after the same number of elements (a transport buffer indexed like the arena). */
+int aitk_grad_compress_bf16(const float* g, aitk_bf16* out, int64_t n, aitk_stream_t stream);
+int aitk_grad_expand_bf16(const aitk_bf16* in, float* g, int64_t n, aitk_stream_t stream);
 
 /* Low-rank LoKr: gradients of the pair lokr_w2_a [O, r], lokr_w2_b [r, I] from the gradient dW [O, I] of their product
  * (autograd of `lokr_w2_a @ lokr_w2_b`, toolkit/models/lokr.py:236-241, 331-339): ga (+)= dW b^T, gb (+)= a^T dW; all fp32. */

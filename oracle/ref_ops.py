@@ -447,6 +447,17 @@ def lokr_lowrank_grad(dw, a, b, ga, gb, *, accumulate=True):
         gb.copy_(db)
 
 
+def grad_compress_bf16(g, out):
+    """transport format of the bf16 DP all-reduce: one round-to-nearest-even per element"""
+    out[: g.numel()].copy_(g.to(torch.bfloat16))
+    return out
+
+
+def grad_expand_bf16(src, g):
+    g.copy_(src[: g.numel()].float())
+    return g
+
+
 def refresh_shadows(arena, shadow, table):
     """hi = round(w), lo = round(w - hi) in the layouts of AitkShadowDesc (include/aitk_mi355.h)."""
     entries, _ = table

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir, shard, one_device=False):
+def _worker(rank, world, port, out_dir, shard, one_device=False, allreduce_dtype="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import datetime
 
@@ -28,7 +28,7 @@ def _worker(rank, world, port, out_dir, shard, one_device=False):
     from tests.test_gpu_e2e import _batch, _build
 
     ref, ref_net, nat, net = _build(dev=dev)
-    step = FluxLoRATrainStep(nat, net, ops, lr=1e-3, max_grad_norm=0.5, ema_decay=0.9, process_group=dist.group.WORLD)
+    step = FluxLoRATrainStep(nat, net, ops, lr=1e-3, max_grad_norm=0.5, ema_decay=0.9, process_group=dist.group.WORLD, allreduce_dtype=allreduce_dtype)
     per = 4 // world
     for k in range(2):
         lat, emb, pooled, noise, ts = _batch(4, dev=dev, seed=20 + k)
@@ -40,12 +40,12 @@ def _worker(rank, world, port, out_dir, shard, one_device=False):
     dist.destroy_process_group()
 
 
-def _spawn(world, tmp_path, shard=True, one_device=False):
+def _spawn(world, tmp_path, shard=True, one_device=False, allreduce_dtype="fp32"):
     import torch.multiprocessing as mp
 
     from tests.conftest import free_port
 
-    mp.spawn(_worker, args=(world, free_port(), str(tmp_path), shard, one_device), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), str(tmp_path), shard, one_device, allreduce_dtype), nprocs=world, join=True)
     return [torch.load(tmp_path / f"w{world}_r{r}.pt") for r in range(world)]
 
 
@@ -111,3 +111,28 @@ def test_dp2_two_processes_on_one_device_equal_single_rank_on_concatenated_batch
     _close_to_one_rank_on_the_whole_batch(r0["p"])
     # each rank reports the loss of its own shard (the reference logs per process too): finite and different shards -> different numbers
     assert torch.isfinite(r0["loss"]).all() and torch.isfinite(r1["loss"]).all() and not torch.equal(r0["loss"], r1["loss"])
+
+
+@pytest.mark.parametrize("n,off", [(1 << 20, 0), (100003, 3), (77, 5), (8 * 4096 + 1, 8)])
+def test_grad_compress_expand_bf16_kernels(n, off):
+    """aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (transport format of the bf16 all-reduce) at aligned and unaligned arena offsets:
+    exactly torch's round-to-nearest-even cast, neighbours untouched."""
+    from ai_toolkit_amd import ops
+
+    g = torch.randn(n + off + 16, device="cuda") * torch.logspace(-6, 3, n + off + 16, device="cuda")
+    buf = torch.full((n + off + 16,), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.grad_compress_bf16(g[off:off + n], buf[off:off + n])
+    assert torch.equal(buf[off:off + n], g[off:off + n].to(torch.bfloat16))
+    assert float((buf[:off].float() - 7).abs().sum()) == 0 and float((buf[off + n:].float() - 7).abs().sum()) == 0
+    back = torch.full_like(g, -3.0)
+    ops.grad_expand_bf16(buf[off:off + n], back[off:off + n])
+    assert torch.equal(back[off:off + n], buf[off:off + n].float())
+    assert float((back[:off] + 3).abs().sum()) == 0 and float((back[off + n:] + 3).abs().sum()) == 0
+
+
+def test_dp2_bf16_allreduce_on_the_hip_kernels_one_device(tmp_path):
+    """allreduce_dtype="bf16" with a real second rank on the HIP kernels (two processes on device 0, gloo transport): replicas stay
+    bit-identical and the two-step update stays within the bound stated for the fp32 transport plus the bf16 rounding of the gradient sum."""
+    r0, r1 = _spawn(2, tmp_path, one_device=True, allreduce_dtype="bf16")
+    assert torch.equal(r0["p"], r1["p"]) and torch.equal(r0["ema"], r1["ema"]), "replicas diverged"
+    _close_to_one_rank_on_the_whole_batch(r0["p"])

@@ -44,20 +44,46 @@ def test_three_steps_match_oracle_optimizer_sequence():
             i += 1
 
 
-def _dp_worker(rank, world, port, out, network_type):
+def _dp_worker(rank, world, port, out, network_type, allreduce_dtype="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import datetime
 
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     torch.set_num_threads(2)
     ref, ref_net, nat, net = build_pair(rank=4, network_type=network_type)
-    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD)
+    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD, allreduce_dtype=allreduce_dtype)
     for k in range(2):
         lat, emb, pooled, noise, ts = batch(4, seed=20 + k)
         sl = slice(rank * 2, rank * 2 + 2)  # disjoint shard of the bucket batch
         step.step(lat[sl], emb[sl], pooled[sl], noise=noise[sl], timesteps=ts[sl])
+        if k == 0:
+            torch.save(net.arena_g.clone(), os.path.join(out, f"g{rank}.pt"))  # the reduced gradient SUM of the first step
     torch.save(net.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
     dist.destroy_process_group()
+
+
+def test_dp2_bf16_allreduce_is_the_stated_deviation(tmp_path):
+    """allreduce_dtype="bf16" (SURVEY.md section 8e "fp32 (parity) or bf16 (speed)"): every rank rounds its gradient once to bf16, the
+    collective sums in bf16, the sum is expanded over the fp32 arena.  Replicas stay bit-identical; the reduced gradient is within 2^-8
+    relative (two bf16 roundings) of the fp32 all-reduce, the two-step update within 2e-2 of the fp32 path's (AdamW's first steps are sign-like)."""
+    from tests.conftest import free_port
+
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        d = tmp_path / mode
+        d.mkdir()
+        mp.spawn(_dp_worker, args=(2, free_port(), str(d), "lora", mode), nprocs=2, join=True)
+        outs[mode] = (torch.load(d / "g0.pt"), torch.load(d / "g1.pt"), torch.load(d / "p0.pt"), torch.load(d / "p1.pt"))
+    g32, g16 = outs["fp32"][0], outs["bf16"][0]
+    assert torch.equal(outs["bf16"][0], outs["bf16"][1]) and torch.equal(outs["bf16"][2], outs["bf16"][3]), "replicas must stay bit-identical"
+    assert torch.equal(g16, g16.to(torch.bfloat16).float()) and not torch.equal(g32, g32.to(torch.bfloat16).float())
+    rel = ((g16 - g32).norm() / g32.norm()).item()
+    assert 0 < rel < 2 ** -8, rel
+    assert float((g16 - g32).abs().max()) <= 2 ** -7 * float(g32.abs().max())
+    ref, ref_net, nat, net = build_pair(rank=4)
+    p_init = net.arena_p.clone()
+    d32, d16 = outs["fp32"][2] - p_init, outs["bf16"][2] - p_init
+    assert ((d16 - d32).norm() / d32.norm()).item() < 2e-2
 
 
 @pytest.mark.parametrize("network_type", ["lora", "dora"])
