@@ -499,6 +499,12 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
       cattr = true;
     }
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    // big convolutions: the persistent 8-phase kernel (gemm8.hip, conv mode); stage_mode 5 keeps the 2-barrier kernel (same-box A/B)
+    if (a->stage_mode != 5 && a->stage_mode != 0 && ((a->tile_mode == 0 && a->N >= 256 && t256 >= big_tiles_min()) || a->stage_mode == 4) &&
+        aitk_gemm8_try_launch(a, st) == AITK_OK) {
+      AITK_LAUNCH_CHECK();
+      return AITK_OK;
+    }
     if (a->tile_mode == 2 || (a->tile_mode == 0 && a->N >= 256 && t256 >= 192)) {
       hipLaunchKernelGGL((gemm_nt_kernel<1, 256, 256, 2, 4, true>), dim3((unsigned)t256), dim3(512), 131072, st, *a);
     } else {

@@ -96,8 +96,15 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
 // is problem 0's tiles followed by problem 1's; a workgroup switches operand bases (buffer descriptors, row clamp, slab pointers)
 // when the tile it is STAGING changes problem, and epilogue arguments when the tile it is COMPUTING does.
 static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguous in the kernarg segment");
-template <bool GR, bool F8>
+// CV: implicit-GEMM 3x3 convolution (AitkGemmArgs.conv_mode, 2-D form): A is the NHWC image [B, H, W, Cin], row m = output pixel (b, oy, ox),
+// K runs over (tap, cin) = 9 Cin with Cin % 64 == 0, so a K-tile lies inside ONE tap: the tap's pixel shift ((ky W + kx) Cin elements) and
+// the channel offset are wave-uniform and ride in the DMA's SGPR offset, exactly where the plain GEMM puts its K offset; what differs
+// per lane is only whether the tap's pixel exists — a 9-bit mask per staged row, built once per output tile — and a lane whose pixel lies
+// outside the image points its offset past the buffer window and receives zeros (the same mechanism as K tails and dead tiles).
+// The descriptor base is shifted one image row + one pixel down so that the base offset of a border pixel is never negative.
+template <bool GR, bool F8, bool CV = false>
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
+  static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
   constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
   constexpr int ESH = F8 ? 0 : 1;    // log2(bytes per base-segment element)
@@ -137,6 +144,13 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #endif
   };
   unsigned va[4], vb[4];  // byte offsets of this thread's chunk (K-tile 0) in A / B for the tile being STAGED
+  unsigned cm01 = 0, cm23 = 0;  // CV: tap-validity masks of staged rows i = 0, 1 (bits 0-8, 9-17) and i = 2, 3
+  // CV: wave-uniform constants of the tap walk (SGPRs for the whole kernel: scalar loads inside the K loop would share lgkmcnt with the
+  // hand-counted fragment reads)
+  const int cv_kpt = CV ? __builtin_amdgcn_readfirstlane(p.conv_Cin >> 6) : 1;                 // K-tiles per tap
+  const int cv_magic = CV ? __builtin_amdgcn_readfirstlane((65536 + cv_kpt - 1) / cv_kpt) : 0;  // kt / cv_kpt = (kt * magic) >> 16 for kt <= 9 * 64
+  const int cv_w = CV ? __builtin_amdgcn_readfirstlane(p.conv_W) : 0;
+  const int cv_cin2 = CV ? __builtin_amdgcn_readfirstlane(p.conv_Cin * 2) : 0;                  // bytes per pixel
   int om0 = 0, on0 = 0;   // origin of that tile (the K-tail / LoRA-slab path recomputes its row offsets from it)
   int m0 = 0, n0 = 0;
   int sM = p.M;   // row count of the problem being STAGED (row clamp of the A operand)
@@ -171,7 +185,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     r.w = 0x00020000;
     return r;
   };
-  v4i srdA = make_srd(p.A), srdB = make_srd(p.B);
+  v4i srdA = make_srd(CV ? (const void*)(p.A - (long)(p.conv_W + 1) * p.conv_Cin) : (const void*)p.A), srdB = make_srd(p.B);
   auto set_offsets = [&](int tm0, int tn0, int prob) {
     om0 = tm0;
     on0 = tn0;
@@ -184,11 +198,44 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     }
     const int t_ = opaque_tid();
     const int srow = SROW(t_), cc = CC(t_);
+    if constexpr (CV) {
+      const int HoWo = q->conv_HoWo, Wo = q->conv_Wo, cst = q->conv_stride, H = q->conv_H, W = q->conv_W, Cin = q->conv_Cin;
+      cm01 = cm23 = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      va[i] = ((unsigned)seg_off(q->lda, q->a_seg_rows, q->a_seg_stride, a_row(i, srow)) + cc * CH) << ESH;
-      vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * CH) << ESH;
+      for (int i = 0; i < 4; ++i) {
+        const int m = a_row(i, srow);
+        const int b = m / HoWo, rem = m - b * HoWo;
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const int iy0 = oy * cst - q->conv_pad_t, ix0 = ox * cst - q->conv_pad_l;  // input pixel of tap (0, 0): >= -1
+        va[i] = (unsigned)(((((long)b * H + iy0 + 1) * W + ix0 + 1) * Cin + cc * 8) * 2);  // relative to the shifted base: never negative
+        unsigned mk = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          if ((unsigned)(iy0 + ky) < (unsigned)H && (unsigned)(ix0 + kx) < (unsigned)W) mk |= 1u << tap;
+        }
+        if (i < 2) cm01 |= mk << (9 * i);
+        else cm23 |= mk << (9 * (i - 2));
+        vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * 8) * 2;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = ((unsigned)seg_off(q->lda, q->a_seg_rows, q->a_seg_stride, a_row(i, srow)) + cc * CH) << ESH;
+        vb[i] = ((unsigned)((long)b_row(i, srow) * q->ldb) + cc * CH) << ESH;
+      }
     }
+  };
+  // CV: K-tile kt of the base segment -> (tap, byte offset of the tap's pixel shift + channel offset); all scalar
+  auto conv_tap = [&](int kt, unsigned& soff) -> int {
+    const int tap = (kt * cv_magic) >> 16;
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;  // tap / 3 for tap <= 8
+    soff = (unsigned)((ky * cv_w + kx) * cv_cin2 + (kt - tap * cv_kpt) * (BK * 2));
+    return tap;
+  };
+  auto conv_voff = [&](int i, int tap) -> unsigned {
+    const unsigned m = (i < 2 ? cm01 : cm23) >> (tap + 9 * (i & 1));
+    return (m & 1u) ? va[i] : 0x80000000u;
   };
 
   // Raw buffer descriptors (stride 0, 2 GiB window): LDS-DMA through buffer_load ... lds takes base (SGPRs) + 32-bit lane
@@ -207,7 +254,13 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   auto stage_half = [&](int kt, int buf, int opnd, int half, bool dead) {
     const unsigned ldst = lds_wave + buf * BUF_BYTES + (opnd ? A_BYTES : 0) + half * (2 * NT * 16);
     if (!dead && kt < nfast) {  // full base-segment K-tile: no VALU at all
-      const unsigned soff = (unsigned)kt * (BK * 2);
+      unsigned soff = (unsigned)kt * (BK * 2);
+      if (CV && !opnd) {  // image operand: the tap's shift in the scalar offset, the tap's validity per staged row
+        const int tap = conv_tap(kt, soff);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) dma(ldst + ii * (NT * 16), conv_voff(2 * half + ii, tap), srdA, soff);
+        return;
+      }
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int i = 2 * half + ii;
@@ -383,8 +436,14 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     // Steady part: K-tiles t+1, t+2 are full base-segment tiles of THIS output tile — straight-line fast staging, no
     // branches.  Tail part (last <= 2 + LoRA-slab iterations): K tail, slab, and the next output tile's first K-tiles.
     auto stage_fast = [&](int kt, unsigned ldst_buf, int opnd, int half) {
-      const unsigned soff = (unsigned)kt * (BK * 2);
+      unsigned soff = (unsigned)kt * (BK * 2);
       const unsigned ldst = ldst_buf + (opnd ? A_BYTES : 0) + half * (2 * NT * 16);
+      if (CV && !opnd) {
+        const int tap = conv_tap(kt, soff);
+        dma(ldst, conv_voff(2 * half, tap), srdA, soff);
+        dma(ldst + NT * 16, conv_voff(2 * half + 1, tap), srdA, soff);
+        return;
+      }
       dma(ldst, opnd ? vb[2 * half] : va[2 * half], opnd ? srdB : srdA, soff);
       dma(ldst + NT * 16, opnd ? vb[2 * half + 1] : va[2 * half + 1], opnd ? srdB : srdA, soff);
     };
@@ -590,12 +649,22 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_kernel(AitkGemmArgs
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true>(p, p2); }
+// implicit-GEMM 3x3 convolution on the persistent 8-phase schedule (UNet / VAE convolutions and their data gradients)
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_conv_kernel(AitkGemmArgs p) { gemm8_body<false, false, true>(p, p); }
 
 // Called by aitk_gemm_nt (gemm.hip) for big bf16 problems.  Returns AITK_OK after launching, or 1 when the shape is
 // outside this kernel's contract (caller falls back to the 2-barrier kernels).
 static int gemm8_contract(const AitkGemmArgs* a) {
   const bool f8 = a->b_scale_mode == 3;
-  if (a->conv_mode || (a->b_scale_mode && !f8)) return 1;
+  if (a->b_scale_mode && !f8) return 1;
+  if (a->conv_mode) {
+    // 2-D 3x3 form only, K-tiles inside one tap, the split-slab epilogue stays on the 2-barrier kernel, and the whole image batch (plus
+    // the one-row shift of the descriptor base and the largest tap shift) inside the 2-GiB buffer window
+    if (f8 || a->conv_t3d || (a->conv_Cin % 64) || a->K != 9 * a->conv_Cin || (a->flags & AITK_EPI_SPLIT_SLAB) || a->a_seg_rows) return 1;
+    if (a->conv_pad_t < 0 || a->conv_pad_t > 1 || a->conv_pad_l < 0 || a->conv_pad_l > 1 || a->conv_stride < 1) return 1;
+    const long nb = ((long)a->M + a->conv_HoWo - 1) / a->conv_HoWo;
+    if (((nb * a->conv_H + 3) * a->conv_W + 4) * a->conv_Cin * 2 >= 0x7ff00000L) return 1;
+  }
   if ((a->K % 16) || (a->K2 % 16) || (a->N % 8) || (a->ldc % 8)) return 1;
   if (f8 && ((a->lda % 16) || (a->ldb % 16) || (a->a_seg_stride % 16) || (((uintptr_t)a->A | (uintptr_t)a->B) & 15) ||
              (((uintptr_t)a->a_scale | (uintptr_t)a->b_scale) & 15)))
@@ -624,6 +693,8 @@ static int gemm8_cus() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EPI_OFF + 32768) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            EPI_OFF + 32768) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EPI_OFF + 32768) != hipSuccess) {
       n_cu = 0;
       return 0;
@@ -637,13 +708,14 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   return AITK_OK;
 }
 // Two problems with equal N, K, K2 and flags in one persistent launch (aitk_gemm_nt_grouped); 1 = outside the contract.
 extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, hipStream_t st) {
-  if (gemm8_contract(a) || gemm8_contract(b)) return 1;
+  if (gemm8_contract(a) || gemm8_contract(b) || a->conv_mode || b->conv_mode) return 1;
   if (a->N != b->N || a->K != b->K || a->K2 != b->K2 || a->flags != b->flags || a->b_scale_mode != b->b_scale_mode) return 1;
   const int n_cu = gemm8_cus();
   if (!n_cu) return 1;

@@ -627,8 +627,11 @@ def _zero_page(device):
     return z
 
 
+CONV_STAGE = 5 if os.environ.get("AITK_CONV8", "1") == "0" else 1  # AITK_CONV8=0: 3x3 convolutions stay on the 2-barrier kernel (same-box A/B)
+
+
 def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None, bias=None, flags=0, aux_in=None, a2=None, b2=None,
-            split_slab=False, col_scale=None):
+            split_slab=False, col_scale=None, stage_mode=None):
     """Implicit-GEMM 3x3 convolution on NHWC: x [B*H*W, Cin], w [Cout, 9*Cin] (k = (ky*3+kx)*Cin + cin), out [B*Ho*Wo, Cout].
     a2 [M, K2] / b2 [Cout, K2]: LoRA K-slab added to the product (the lora_up of a conv adapter, fused like a Linear's).
     split_slab: w = 16-rank blocks [A_hi ; A_lo] of a rank-rp projection (2 rp rows, rp <= 64) and out is the [M, 3 rp] slab
@@ -658,7 +661,9 @@ def conv3x3(x, w, out, *, B, H, W, stride=1, pad_t=1, pad_l=1, Ho=None, Wo=None,
     if aux_in is not None:
         g.aux_in, g.ld_aux_in = _ptr(aux_in), _row_major(aux_in, "aux_in")
     g.M, g.N, g.K, g.flags = B * Ho * Wo, N, K, flags
-    g.stage_mode, g.tile_mode = 1, TILE_MODE
+    # stage_mode 1: the persistent 8-phase kernel's conv mode for big problems (Cin % 64 == 0, >= half a chip of 256^2 tiles), else the
+    # 2-barrier kernel; 4 forces the former where its contract allows, 5 the latter
+    g.stage_mode, g.tile_mode = (CONV_STAGE if stage_mode is None else stage_mode), TILE_MODE
     g.conv_mode, g.conv_H, g.conv_W, g.conv_Cin = 1, H, W, Cin
     g.conv_Wo, g.conv_HoWo, g.conv_stride, g.conv_pad_t, g.conv_pad_l = Wo, Ho * Wo, stride, pad_t, pad_l
     g.zero_page = _ptr(_zero_page(x.device))

@@ -21,7 +21,7 @@ with torch.no_grad():
             p.copy_((torch.randn(p.shape, device=dev, generator=g) * fan ** -0.5).to(p.dtype))
 enc.prepare()
 out = {}
-for B in (1, 2):
+for B in (1, 2, 4):
     img = torch.rand(B, 3, 1024, 1024, device=dev, generator=g) * 2 - 1
     for _ in range(2):
         lat = enc.encode_images(img, generator=g)
@@ -37,5 +37,6 @@ for B in (1, 2):
     print(B, out[f"B{B}"], flush=True)
 out["peak_mem_GiB"] = torch.cuda.max_memory_allocated() / 2 ** 30
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/vae_bench.json", "w"), indent=1)
+out["conv8"] = os.environ.get("AITK_CONV8", "1") != "0"
+json.dump(out, open(os.environ.get("AITK_VAE_BENCH_OUT", "gpurun_out/vae_bench.json"), "w"), indent=1)
 print(json.dumps(out))
