@@ -164,7 +164,10 @@ class FusedGraphBase(nn.Module):
         (aitk_gemm_nt b_scale_mode 3, twice the bf16 MFMA rate): the activation operand of every base GEMM — x in forward, dY (times the
         weight's per-channel scale, which runs along the contraction there) in the data gradient — is quantised per token to e4m3 by
         aitk_quant_rows_fp8 right before its GEMM; the rank-r adapter slab, its operands and every adapter gradient stay bf16 / fp32.
-        This is NOT the reference's arithmetic (its quantisers are weight-only): DESIGN.md states the deviation and the measured parity."""
+        This is NOT the reference's arithmetic (its quantisers are weight-only): DESIGN.md states the deviation and the measured parity.
+        Outlier statistics (a few residual channels at 10^2 - 10^3 x the rest, as real DiT weights produce) do not break the per-token e4m3
+        operand: adapter-gradient error 1.0e-2 at full depth with planted outliers vs 1.75e-2 without (profiles/r04_outlier_parity.log,
+        tests/test_gpu_outlier_parity.py) — the row scale follows the outlier and e4m3's exponent range covers the spread below it."""
         if mfma:
             self._refuse_w8a8_adapters(self.network)
         self.fp8_mfma = bool(mfma)
