@@ -500,7 +500,12 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     }
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
     // big convolutions: the persistent 8-phase kernel (gemm8.hip, conv mode); stage_mode 5 keeps the 2-barrier kernel (same-box A/B)
-    if (a->stage_mode != 5 && a->stage_mode != 0 && ((a->tile_mode == 0 && a->N >= 256 && t256 >= big_tiles_min()) || a->stage_mode == 4) &&
+    static long conv8_min_n = -1;  // AITK_CONV8_MIN_N: smallest Cout routed to the 8-phase kernel (A/B; a 256-wide tile is half empty at 128)
+    if (conv8_min_n < 0) {
+      const char* e = getenv("AITK_CONV8_MIN_N");
+      conv8_min_n = (e && atol(e) > 0) ? atol(e) : 256;
+    }
+    if (a->stage_mode != 5 && a->stage_mode != 0 && ((a->tile_mode == 0 && a->N >= conv8_min_n && t256 >= big_tiles_min()) || a->stage_mode == 4) &&
         aitk_gemm8_try_launch(a, st) == AITK_OK) {
       AITK_LAUNCH_CHECK();
       return AITK_OK;

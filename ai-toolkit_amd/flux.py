@@ -256,10 +256,14 @@ class FluxTransformer2DModel(FusedGraphBase):
         tte = self.time_text_embed
         # the pinned diffusers casts timestep/guidance to the model dtype BEFORE the *1000
         t_eff = (timestep.to(dt) * 1000).float().contiguous()
-        g_eff = (guidance.to(dt) * 1000).float().contiguous()
+        # guidance = None: the reference's bypass_flux_guidance (toolkit/models/flux.py:9-35, the FLUX.1-schnell training adapter path,
+        # stable_diffusion_model.py:2182-2183): the conditioning vector is timestep + pooled text only
+        embedders = [(tte.timestep_embedder, t_eff)]
+        if guidance is not None:
+            embedders.append((tte.guidance_embedder, (guidance.to(dt) * 1000).float().contiguous()))
         temb = self._new(B, d)
         first = True
-        for emb, src in ((tte.timestep_embedder, t_eff), (tte.guidance_embedder, g_eff)):
+        for emb, src in embedders:
             proj = self._new(B, 256)
             ops.timestep_embed(src, proj)
             h1 = self._new(B, d)

@@ -224,8 +224,6 @@ class Flux1MI355Model(_PluginBase):
                              bypass_guidance_embedding=False, **kwargs):
         """latent_model_input [B,16,H,W], timestep [B] on the 0..1000 scale -> prediction [B,16,H,W]
         (flux_kontext.py:243-352 without the kontext control branch)."""
-        if bypass_guidance_embedding:
-            raise NotImplementedError("bypass_guidance_embedding (FLUX.1-schnell training adapter) is not on the fused path")
         bs, c, h, w = latent_model_input.shape
         if c != 16:
             raise ValueError(f"expected 16 latent channels, got {c} (kontext control channels are not on the fused path)")
@@ -239,7 +237,9 @@ class Flux1MI355Model(_PluginBase):
             img_ids = img_ids.reshape(-1, 3).to(dev)
             img_ids._aitk_grid = (h // 2, w // 2, text.shape[1])
             txt_ids = torch.zeros(text.shape[1], 3, device=dev)
-            if isinstance(guidance_embedding_scale, list):
+            if bypass_guidance_embedding:  # toolkit/models/flux.py:9-35: the guidance embedder is skipped for this call
+                guidance = None
+            elif isinstance(guidance_embedding_scale, list):
                 guidance = torch.tensor(guidance_embedding_scale, device=dev, dtype=torch.float32)
             else:
                 guidance = torch.tensor([float(guidance_embedding_scale)], device=dev).expand(bs)

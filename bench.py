@@ -518,6 +518,94 @@ def parity_leg(dev):
                     "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
 
 
+def build_wan(dev, layers=30, rank=16):
+    """BASELINE config 4 architecture (Wan2.1-T2V-1.3B: 30 blocks, d = 1536, ffn 8960) with synthetic weights, LoRA r16 on the reference's
+    ['blocks'] filter (toolkit/models/wan21/wan21.py:330, 735)."""
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.wan import WanTransformer3DModel
+
+    torch.manual_seed(0)
+    model = WanTransformer3DModel(num_layers=layers, dtype=torch.bfloat16, device=dev, ops=ops)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "scale_shift_table" in n:
+                p.normal_(0, 1.0 / 1536 ** 0.5)
+            elif p.ndim >= 2:
+                p.normal_(0, 0.02)
+            elif n.endswith("bias"):
+                p.normal_(0, 0.01)
+    net = FusedLoRANetwork(model, lora_dim=rank, target_lin_modules=("WanTransformer3DModel",), transformer_block_names=["blocks"],
+                           base_model_version="wan_2.1")
+    net.apply_to()
+    net.build_arena(dev, groups=model.lora_groups())
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.normal_(0, 0.01)
+    net.refresh_shadows(ops)
+    model.attach_network(net)
+    model.prepare()
+    return model, net, ops
+
+
+def secondary_configs(dev, steps=3):
+    """The other BASELINE.json configs on this GPU, a few steps each, so that their rates are observed by whoever runs `python bench.py` and not
+    only by the builder: config 2 (SDXL UNet LoRA r8 @1024^2), config 1's architecture (SD1.5 r4 @512^2), config 4's per-GPU shape
+    (Wan2.1-T2V-1.3B r16, 13 x 64 x 64 latents), config 5 (FLUX r32 on the fp8 base, W8A8 on the fp8 MFMA).  Synthetic weights / data, full
+    train step (noise .. AdamW + EMA), eager launches.  Never part of `value`."""
+    import gc
+
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep, UNetLoRATrainStep, WanLoRATrainStep
+
+    out = {}
+
+    def timed(fn, B):
+        fn()
+        dt, _, _ = timed_steps(fn, steps, torch.cuda.synchronize)
+        return {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "per_gpu_batch": B, "steps": steps,
+                "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+
+    def unet(kind):
+        model, net, ops = build_unet(dev, kind, rank=8 if kind == "sdxl" else 4)
+        st = UNetLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, seed=1000)
+        B, side = (12, 128) if kind == "sdxl" else (32, 64)
+        gen = torch.Generator(device=dev).manual_seed(42)
+        lat = torch.randn(B, 4, side, side, device=dev, generator=gen).to(torch.bfloat16)
+        ctx = (torch.randn(B, 77, model.config["cross_attention_dim"], device=dev, generator=gen) * 0.5).to(torch.bfloat16)
+        pooled = (torch.randn(B, 1280, device=dev, generator=gen) * 0.5).to(torch.bfloat16) if kind == "sdxl" else None
+        r = timed(lambda: st.step(lat, ctx, pooled), B)
+        r.update(unit="images/s", workload="SDXL UNet LoRA r8 @1024^2 (config 2)" if kind == "sdxl" else "SD1.5 UNet LoRA r4 @512^2 (config 1 architecture)")
+        return r
+
+    def wan():
+        model, net, ops = build_wan(dev)
+        st = WanLoRATrainStep(model, net, ops, lr=1e-4, seed=1)
+        B = 4
+        lat = torch.randn(B, 16, 13, 64, 64, device=dev).to(torch.bfloat16)
+        txt = (torch.randn(B, 512, 4096, device=dev) * 0.3).to(torch.bfloat16)
+        r = timed(lambda: st.step(lat, txt), B)
+        r.update(unit="videos/s", workload="Wan2.1-T2V-1.3B LoRA r16, 49 x 512 x 512 clip = 13 x 64 x 64 latents, 13 312 tokens (config 4, per-GPU shape)")
+        return r
+
+    def flux_w8a8():
+        model, net, ops = build_flux(dev, rank=32, fp8_base=True, fp8_mfma=True)
+        st = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, timestep_type="linear", seed=1000)
+        B = 7 if (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30 >= 232 else 4
+        lat, emb, pooled = make_batch(dev, B, seed=42)
+        r = timed(lambda: st.step(lat, emb, pooled), B)
+        r.update(unit="images/s", workload="FLUX.1-dev LoRA r32 on the fp8 e4m3 base, W8A8 on v_mfma_scale_f32_32x32x64_f8f6f4 (config 5; opt-in mode: "
+                                           "per-token e4m3 activations are not the reference's weight-only arithmetic)")
+        return r
+
+    for name, fn in (("config2_sdxl", lambda: unet("sdxl")), ("config1_sd15", lambda: unet("sd15")), ("config4_wan21", wan), ("config5_flux_fp8_w8a8", flux_w8a8)):
+        torch.cuda.reset_peak_memory_stats()
+        _run_leg(out, [], name, fn)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def _rel_lists(a, b):
     import math
 
@@ -685,6 +773,7 @@ def main():
                     help="N > 1: pin RCCL to this many channels (NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS; one channel = one workgroup = one CU "
                          "taken from the persistent 256-workgroup compute kernels while a collective runs); 0 = RCCL's own choice")
     ap.add_argument("--no-dvfs", action="store_true", help="skip the clock / power telemetry leg (3 extra steps under rocm-smi polling)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the few-step runs of BASELINE configs 1, 2, 4 and 5 behind the headline (about 80 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch sweep, the bucketed run and the same-GPU eager comparator")
     args = ap.parse_args()
     if args.fp8_mfma:
@@ -1014,6 +1103,8 @@ def main():
         full_parity = None
         gc.collect()
         torch.cuda.empty_cache()
+        if not args.no_secondary:
+            _run_leg(out, failed_legs, "secondary_configs", lambda: secondary_configs(dev))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _run_leg(out, failed_legs, "cpu_baseline", cpu_baseline)
     if pg is not None:

@@ -83,6 +83,8 @@ class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
 
     def forward(self, timestep, guidance, pooled_projection):
         t_emb = self.timestep_embedder(get_timestep_embedding(timestep).to(pooled_projection.dtype))
+        if guidance is None:  # guidance_embed_bypass_forward (toolkit/models/flux.py:9-15): timestep + pooled text only
+            return t_emb + self.text_embedder(pooled_projection)
         g_emb = self.guidance_embedder(get_timestep_embedding(guidance).to(pooled_projection.dtype))
         return t_emb + g_emb + self.text_embedder(pooled_projection)
 
@@ -318,7 +320,7 @@ class FluxTransformer2DModel(nn.Module):
         toolkit/stable_diffusion_model.py:2192-2205)."""
         hidden_states = self.x_embedder(hidden_states)
         timestep = timestep.to(hidden_states.dtype) * 1000
-        guidance = guidance.to(hidden_states.dtype) * 1000
+        guidance = None if guidance is None else guidance.to(hidden_states.dtype) * 1000
         temb = self.time_text_embed(timestep, guidance, pooled_projections)
         encoder_hidden_states = self.context_embedder(encoder_hidden_states)
         ids = torch.cat((txt_ids, img_ids), dim=0)

@@ -43,8 +43,21 @@ def test_flux_plugin_prediction_and_autograd_backward_match_oracle():
     with torch.no_grad(), net:
         assert torch.allclose(plug.get_noise_prediction(lat, ts, (pe.text_embeds, pe.pooled_embeds), 1.0, False), pred.detach(), atol=1e-6)
     assert nat.ctx is None or True
-    with pytest.raises(NotImplementedError):
-        plug.get_noise_prediction(lat, ts, pe, 1.0, True)
+    # bypass_guidance_embedding (toolkit/models/flux.py:9-35; stable_diffusion_model.py:2182-2183, 2221-2222): the guidance embedder is
+    # skipped for the call — prediction AND adapter gradients equal the oracle with guidance_embed_bypass_forward's conditioning
+    for m in ref_net.unet_loras:
+        m.lora_down.weight.grad = m.lora_up.weight.grad = None
+    with ref_net:
+        p_byp = flux_ref.unpack_latents(ref(flux_ref.pack_latents(lat), pe.text_embeds, pe.pooled_embeds, ts / 1000, img_ids, txt_ids, None), Hl, Wl)
+        torch.nn.functional.mse_loss(p_byp, target).backward()
+    assert not torch.allclose(p_byp, p_ref, atol=1e-4)
+    net.zero_grad_arena()
+    with net:
+        pred_b = plug.get_noise_prediction(lat, ts, pe, 1.0, True)
+        assert torch.allclose(pred_b, p_byp, rtol=2e-4, atol=2e-5)
+        torch.nn.functional.mse_loss(pred_b, target).backward()
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert torch.allclose(a.lora_up.weight.grad, b.lora_up.weight.grad, rtol=3e-4, atol=1e-6), a.lora_name
     with pytest.raises(ValueError):
         plug.get_noise_prediction(torch.cat([lat, lat], 1), ts, pe, 1.0, False)
 
