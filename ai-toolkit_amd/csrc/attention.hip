@@ -799,6 +799,256 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
     }
 }
 
+// ============================================================================================ backward: dK, dV — wave-specialised (head_dim 128)
+// The pipelined kernel above runs ONE wave per SIMD (394 registers): whatever a wave waits for — fragment reads, transpose reads, the
+// softmax's quarter-rate exponentials — idles its SIMD's matrix pipe (PMC round 3: MFMA busy 0.37).  Here a workgroup is 8 waves, two per
+// SIMD, with different jobs on the same 32 kv rows:
+//   producer wave w (0-3):  S = Q K^T, dP = dO V^T of sub-tile i+1 (16 MFMAs) interleaved with the softmax / dS arithmetic of sub-tile i
+//                           (K / V fragments in AccVGPRs, two S / dP register sets); P and dS leave as the packed bf16 operands the
+//                           dV / dK products consume, through a lane-private 64-byte LDS slot — the accumulator layout of S IS the
+//                           A-operand layout of P^T (permuted contraction order, see frag_tr_perm_st), so nothing is transposed;
+//   consumer wave w + 4:    dV += P^T dO, dK += dS^T Q of sub-tile i-1 (16 MFMAs, transposed dO / Q fragments through tr16 reads),
+//                           owns the dK / dV accumulators (128 AccVGPRs) and the statistics loads.
+// Both fit 256 registers, so each SIMD always has a second wave to issue matrix work while the other waits or runs vector code — the
+// cross-wave MFMA || VALU overlap that profiles/r03_probe_mfma_valu_overlap.txt shows is free.  One workgroup barrier per 32-row sub-tile
+// hands the operand slots over (double-buffered); query tiles of 64 rows travel by LDS-DMA into a ring of three buffers (a tile is read
+// by the producer one step before and by the consumer one step after its own two steps), issued two steps ahead of their first use.
+// Same ownership, same products in the same order as attn_bwd_dkdv_pipe_kernel: the gradients are bit-identical to it.
+#define DKDV_WS_TILE (2 * SUBTILE_BYTES)              /* Q (64 rows) then dO (64 rows), sub-tiled */
+#define DKDV_WS_XOFF (3 * DKDV_WS_TILE)               /* operand slots: [parity 2][pair 4][vector 4][lane 64] x 16 B */
+#define DKDV_WS_SOFF (DKDV_WS_XOFF + 2 * 4 * 4096)    /* statistics: [tile ring 3][L2 64 | delta 64] floats */
+#define DKDV_WS_LDS (DKDV_WS_SOFF + 3 * 512)
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const sm = (lds_char*)smem;
+  constexpr int ST = SUBTILE_BYTES, TILE = DKDV_WS_TILE;
+  typedef __attribute__((address_space(3))) float lds_float;
+  typedef __attribute__((address_space(3))) s16x8_t lds_s16x8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave8 >> 2, w = wave8 & 3;  // role 0: producer, 1: consumer; pair w owns kv rows [kv0 + 32 w, +32)
+  const int l31 = lane & 31, h = lane >> 5;
+  const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
+  int tile_x, hd, b;
+  attn_wg_coords((Skv + 127) / 128, p.H, tile_x, hd, b);
+  const int kvw = tile_x * 128 + w * 32;
+  const bf16_t* Qb = p.Q + (long)b * S * p.ldq + hd * 128;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  const bf16_t* Vb = p.V + (long)b * Skv * p.ldv + hd * 128;
+  const bf16_t* dOb = p.dO + (long)b * S * p.lddo + hd * 128;
+  const float* Lb = p.LSE + ((long)b * p.H + hd) * S;
+  const float* Db = p.delta + ((long)b * p.H + hd) * S;
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int ntile = (S + 63) / 64;  // query tiles of 64 rows = two 32-row sub-tiles (rows >= S: zero Q / dO, L2 = +inf -> P = dS = 0)
+
+  // ---- tile staging: producers stage the Q half of a tile, consumers the dO half (four 1-KiB pieces per wave each); consumer waves 0 / 1
+  // also fetch the tile's statistics (plain global loads issued AHEAD of the DMA pieces, parked in a register for one step)
+  const v4i_t srd = role == 0 ? slice_srd(Qb, p.ldq, S) : slice_srd(dOb, p.lddo, S);
+  unsigned vo[4];
+  st_voff(vo, role == 0 ? p.ldq : p.lddo, w, lane);
+  const unsigned step_bytes = (unsigned)(64 * (role == 0 ? p.ldq : p.lddo) * 2);
+  float stat = 0.f;
+  const bool stat_wave = wave8 == 4 || wave8 == 5;
+  auto issue_tile = [&](int t) {
+    if (stat_wave) {
+      const int q = t * 64 + lane;
+      stat = wave8 == 4 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
+    }
+    dma_st64(sm + (t % 3) * TILE + role * ST, vo, (unsigned)t * step_bytes, srd, w);
+  };
+  auto store_stats = [&](int t) {
+    if (stat_wave) ((lds_float*)(sm + DKDV_WS_SOFF + (t % 3) * 512))[(wave8 - 4) * 64 + lane] = stat;
+  };
+  issue_tile(0);
+  store_stats(0);
+  if (ntile > 1) {
+    issue_tile(1);
+    store_stats(1);
+  }
+  DMA_WAIT_ALL();
+  __syncthreads();
+
+  if (role == 0) {
+    // ================================================================ producer
+    s16x8_t kf[8], vf[8];
+    {
+      const int kr = min(kvw + l31, Skv - 1);
+      const bf16_t* kp = Kb + (long)kr * p.ldk + 8 * h;
+      const bf16_t* vp = Vb + (long)kr * p.ldv + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        kf[ks] = *reinterpret_cast<const s16x8_t*>(kp + 16 * ks);
+        vf[ks] = *reinterpret_cast<const s16x8_t*>(vp + 16 * ks);
+      }
+    }
+    f32x16_t sA[2], dpA[2];  // S / dP of sub-tile parity 0 / 1
+    lds_char* const xw = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
+    // A(0): S, dP of sub-tile 0 (tile 0, rows 0-31), nothing to interleave with yet
+    {
+      const lds_char* qsub = sm;
+#pragma unroll
+      for (int hk = 0; hk < 2; ++hk) {
+        s16x8_t qa[4], da[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qa[ks] = frag_rm_st(qsub, 0, 16 * (4 * hk + ks), lane);
+          da[ks] = frag_rm_st(qsub + ST, 0, 16 * (4 * hk + ks), lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (hk == 0 && ks == 0) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sA[0]) : "v"(qa[ks]), "a"(kf[0]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dpA[0]) : "v"(da[ks]), "a"(vf[0]));
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[0]) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[0]) : "v"(da[ks]), "a"(vf[4 * hk + ks]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sA[0]), "+v"(dpA[0]));
+    }
+    // One producer step: the softmax / dS arithmetic of sub-tile parity PAR (statistics of tile TS, row half PAR) interleaved, one MFMA per
+    // accumulator register, with S / dP of the NEXT sub-tile (rows 32 * (PAR ^ 1) of the tile at QN) into the other register set; then the
+    // packed P / dS operands go to the pair's slot of parity PAR.  Past the last sub-tile QN points at stale data: its products are never read.
+#define DKDV_WS_OPAQUE(x) asm volatile("" : "+v"(x))
+#define DKDV_WS_PSTEP(PAR, TS, QN)                                                                                               \
+  {                                                                                                                              \
+    const lds_float* ltc = (const lds_float*)(sm + DKDV_WS_SOFF + ((TS) % 3) * 512) + 32 * (PAR);                                \
+    _Pragma("unroll") for (int hk = 0; hk < 2; ++hk) {                                                                           \
+      float ls[8], ds[8]; /* statistics of the eight query rows whose arithmetic rides in this half (registers 8 hk .. 8 hk + 7) */ \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                            \
+        const f32x4_t l4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 8 * (2 * hk + g) + 4 * h);   \
+        const f32x4_t d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 64 + 8 * (2 * hk + g) + 4 * h); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                          \
+          ls[4 * g + e] = l4[e];                                                                                                 \
+          ds[4 * g + e] = d4[e];                                                                                                 \
+        }                                                                                                                        \
+      }                                                                                                                          \
+      s16x8_t qa[4], da[4];                                                                                                      \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                         \
+        qa[ks] = frag_rm_st((QN), 32 * ((PAR) ^ 1), 16 * (4 * hk + ks), lane);                                                   \
+        da[ks] = frag_rm_st((QN) + ST, 32 * ((PAR) ^ 1), 16 * (4 * hk + ks), lane);                                              \
+      }                                                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                         \
+      _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                                                         \
+        const int r = 8 * hk + rr, ks = rr >> 1;                                                                                 \
+        if (hk == 0 && rr == 0)                                                                                                  \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sA[(PAR) ^ 1]) : "v"(qa[0]), "a"(kf[0]));                 \
+        else if (hk == 0 && rr == 1)                                                                                             \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dpA[(PAR) ^ 1]) : "v"(da[0]), "a"(vf[0]));                \
+        else if ((rr & 1) == 0)                                                                                                  \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[(PAR) ^ 1]) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));     \
+        else                                                                                                                     \
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[(PAR) ^ 1]) : "v"(da[ks]), "a"(vf[4 * hk + ks]));    \
+        const float pr = __builtin_amdgcn_exp2f(fmaf(sA[PAR][r], c2, -ls[rr]));                                                  \
+        float dd = dpA[PAR][r] - ds[rr];                                                                                         \
+        DKDV_WS_OPAQUE(dd);                                                                                                      \
+        dd *= pr;                                                                                                                \
+        DKDV_WS_OPAQUE(dd);                                                                                                      \
+        sA[PAR][r] = pr;                                                                                                         \
+        dpA[PAR][r] = dd;                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    lds_char* xs = xw + (PAR) * 16384;                                                                                           \
+    *reinterpret_cast<lds_s16x8*>(xs) = pack_acc8(sA[PAR], 0);                                                                   \
+    *reinterpret_cast<lds_s16x8*>(xs + 1024) = pack_acc8(sA[PAR], 8);                                                            \
+    *reinterpret_cast<lds_s16x8*>(xs + 2048) = pack_acc8(dpA[PAR], 0);                                                           \
+    *reinterpret_cast<lds_s16x8*>(xs + 3072) = pack_acc8(dpA[PAR], 8);                                                           \
+  }
+    for (int t = 0; t < ntile; ++t) {
+      const lds_char* tcur = sm + (t % 3) * TILE;
+      const lds_char* tnext = sm + ((t + 1) % 3) * TILE;
+      // step 2t: arithmetic of sub-tile 2t || products of sub-tile 2t + 1 (same tile, rows 32-63)
+      DKDV_WS_PSTEP(0, t, tcur)
+      DMA_WAIT_ALL();  // the tile issued one step ago (tile t + 1) has landed: this barrier publishes it
+      __syncthreads();
+      // step 2t + 1: tile t + 2 goes into the ring slot tile t - 1 left; arithmetic of sub-tile 2t + 1 || products of sub-tile 2t + 2
+      if (t + 2 < ntile) issue_tile(t + 2);
+      DKDV_WS_PSTEP(1, t, tnext)
+      __syncthreads();
+    }
+#undef DKDV_WS_PSTEP
+#undef DKDV_WS_OPAQUE
+  } else {
+    // ================================================================ consumer
+    f32x16_t dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dk[d] = zero16();
+      dv[d] = zero16();
+    }
+    const int gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
+    const unsigned ln_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);
+    const unsigned ln_hi = ln_lo + 8 * 32 + ((lh ^ 1) - lh) * 16;
+    const lds_char* const xr = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
+    // One consumer step: dV += P^T dO, dK += dS^T Q of the sub-tile in row half RH of the tile at TB, operands from the slot of parity XP
+#define DKDV_WS_TR1(RH, KK, D)                                                                             \
+  tr16_issue_off<ST + (32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dlo[4 * (KK) + (D)], tlo);            \
+  tr16_issue_off<ST + (32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dhi[4 * (KK) + (D)], thi);            \
+  tr16_issue_off<(32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qlo[4 * (KK) + (D)], tlo);                 \
+  tr16_issue_off<(32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qhi[4 * (KK) + (D)], thi);
+#define DKDV_WS_CSTEP(RH, XP, TB)                                                                                               \
+  {                                                                                                                             \
+    const lds_char* xs = xr + (XP) * 16384;                                                                                     \
+    s16x8_t pf[2], df[2];                                                                                                       \
+    pf[0] = *reinterpret_cast<const lds_s16x8*>(xs);                                                                            \
+    pf[1] = *reinterpret_cast<const lds_s16x8*>(xs + 1024);                                                                     \
+    df[0] = *reinterpret_cast<const lds_s16x8*>(xs + 2048);                                                                     \
+    df[1] = *reinterpret_cast<const lds_s16x8*>(xs + 3072);                                                                     \
+    const unsigned tlo = (unsigned)(size_t)(TB) + ln_lo, thi = (unsigned)(size_t)(TB) + ln_hi;                                  \
+    s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];                                                                                     \
+    DKDV_WS_TR1(RH, 0, 0) DKDV_WS_TR1(RH, 0, 1) DKDV_WS_TR1(RH, 0, 2) DKDV_WS_TR1(RH, 0, 3)                                     \
+    DKDV_WS_TR1(RH, 1, 0) DKDV_WS_TR1(RH, 1, 1) DKDV_WS_TR1(RH, 1, 2) DKDV_WS_TR1(RH, 1, 3)                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" : TR_PIN8(dlo), TR_PIN8(dhi));                                                          \
+    asm volatile("" : TR_PIN8(qlo), TR_PIN8(qhi));                                                                              \
+    asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                            \
+      _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                           \
+        dv[d] = mfma32(pf[kk], join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);                                            \
+        dk[d] = mfma32(df[kk], join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);                                            \
+      }                                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
+  }
+    for (int t = 0; t < ntile; ++t) {
+      const lds_char* tcur = sm + (t % 3) * TILE;
+      // step 2t: sub-tile 2t - 1 = rows 32-63 of tile t - 1, operands of parity 1
+      if (t > 0) {
+        const lds_char* tprev = sm + ((t + 2) % 3) * TILE;
+        DKDV_WS_CSTEP(1, 1, tprev)
+      }
+      DMA_WAIT_ALL();
+      if (t >= 1 && t + 1 < ntile) store_stats(t + 1);  // fetched one step ago together with tile t + 1
+      __syncthreads();
+      // step 2t + 1: sub-tile 2t = rows 0-31 of tile t, operands of parity 0
+      if (t + 2 < ntile) issue_tile(t + 2);
+      DKDV_WS_CSTEP(0, 0, tcur)
+      __syncthreads();
+    }
+    {  // the last sub-tile: rows 32-63 of the last tile
+      const lds_char* tlast = sm + ((ntile - 1) % 3) * TILE;
+      DKDV_WS_CSTEP(1, 1, tlast)
+    }
+#undef DKDV_WS_CSTEP
+#undef DKDV_WS_TR1
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = kvw + crow(r, h);
+        if (kv < Skv) {
+          const long off = ((long)b * Skv + kv);
+          p.dK[off * p.lddk + hd * 128 + 32 * d + l31] = f2bf(dk[d][r] * p.scale);
+          p.dV[off * p.lddv + hd * 128 + 32 * d + l31] = f2bf(dv[d][r]);
+        }
+      }
+  }
+}
+
 // ============================================================================================ backward: dQ
 // grid = ceil(S/128) * H * B workgroups (attn_wg_coords); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
 // loops over KV tiles of 64 rows (K, V row-major in LDS).  S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP^T - delta[q]);
@@ -976,6 +1226,11 @@ static void launch_fwd(const AitkAttnArgs* a, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<KS, DB>), grid, dim3(256), lds, s, *a);
 }
 
+// AITK_ATTN_DKDV_WS=1 selects the wave-specialised dK / dV kernel (8 waves, two per SIMD) for head_dim 128
+static bool dkdv_ws_enabled() {  // read at every launch (57 per step): tests and A/B runs switch it inside one process
+  const char* e = getenv("AITK_ATTN_DKDV_WS");
+  return e && e[0] == '1';
+}
 // AITK_ATTN_DKDV_PIPE=0 selects the un-pipelined dK / dV kernel for head_dim 128 (same-box A/B); default: the pipelined one
 static bool dkdv_pipe_enabled() {
   static int v = -1;
@@ -991,6 +1246,17 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   const int Skv = a->Skv > 0 ? a->Skv : a->S;
   dim3 grid((unsigned)(((a->S + 127) / 128) * a->H * a->B));
   dim3 grid_kv((unsigned)(((Skv + 127) / 128) * a->H * a->B));
+  if (KS == 8 && DB == 4 && dkdv_ws_enabled()) {
+    static bool wattr = false;
+    if (!wattr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
+      wattr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
+    return;
+  }
   if (KS == 8 && DB == 4 && dkdv_pipe_enabled()) {
     static bool pattr = false;
     if (!pattr) {

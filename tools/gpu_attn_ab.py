@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
 
-    B, H, S = 4, 24, 4608
+    B, H, S = int(os.environ.get("AITK_AB_B", "4")), 24, 4608
     d = H * 128
     torch.manual_seed(0)
     q, k, v, do = [torch.randn(B * S, d, device="cuda").to(torch.bfloat16) for _ in range(4)]
@@ -47,7 +47,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                                 "bwd_tflops_alg": round(2.5 * fl / bw / 1e9, 1), "chk": chk}))
 else:
     res = {}
-    variants = [("product", {}), ("dkdv_unpipelined", {"AITK_ATTN_DKDV_PIPE": "0"})]
+    variants = [("product", {}), ("dkdv_wave_specialised", {"AITK_ATTN_DKDV_WS": "1"}), ("dkdv_pipelined", {"AITK_ATTN_DKDV_WS": "0"})]
     variants += [(os.path.basename(l), {"AITK_LIB_PATH": l}) for l in sorted(glob.glob(os.path.join(ROOT, "ai-toolkit_amd", "libaitk_abl_attn*.so")))]
     for rep in range(2):
         for name, extra in variants:
