@@ -104,6 +104,15 @@ __device__ __forceinline__ v4i_t slice_srd(const bf16_t* base, long ld, int nrow
   r.w = 0x00020000;
   return r;
 }
+__device__ __forceinline__ v4i_t slice_srd_bytes(const void* base, long nbytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)(a >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)nbytes);
+  r.w = 0x00020000;
+  return r;
+}
 __device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, const v4i_t& srd) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(srd) : "memory");
 }
@@ -815,13 +824,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
 // by the producer one step before and by the consumer one step after its own two steps), issued two steps ahead of their first use.
 // Same ownership, same products in the same order as attn_bwd_dkdv_pipe_kernel: the gradients are bit-identical to it.
 #define DKDV_WS_TILE (2 * SUBTILE_BYTES)              /* Q (64 rows) then dO (64 rows), sub-tiled */
-#define DKDV_WS_XOFF (3 * DKDV_WS_TILE)               /* operand slots: [parity 2][pair 4][vector 4][lane 64] x 16 B */
-#define DKDV_WS_SOFF (DKDV_WS_XOFF + 2 * 4 * 4096)    /* statistics: [tile ring 3][L2 64 | delta 64] floats */
-#define DKDV_WS_LDS (DKDV_WS_SOFF + 3 * 512)
+#define DKDV_WS_NSLOT 4                               /* tile ring */
+#define DKDV_WS_XOFF (DKDV_WS_NSLOT * DKDV_WS_TILE)   /* operand slots: [pair 4][vector 4][lane 64] x 16 B (written in H2, read in the next H1) */
+#define DKDV_WS_SOFF (DKDV_WS_XOFF + 4 * 4096)        /* statistics: [tile ring][L2 64 | delta 64] floats */
+#define DKDV_WS_LDS (DKDV_WS_SOFF + DKDV_WS_NSLOT * 512)
+// TRACE: workgroup 0 records s_memtime around every barrier of tiles 8-11 for one producer and one consumer wave (aitk_probe_attn_ws_trace)
+__device__ unsigned long long g_ws_trace[2 * 4 * 8];
+template <bool TRACE>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const sm = (lds_char*)smem;
-  constexpr int ST = SUBTILE_BYTES, TILE = DKDV_WS_TILE;
+  constexpr int ST = SUBTILE_BYTES, TILE = DKDV_WS_TILE, NSLOT = DKDV_WS_NSLOT;
   typedef __attribute__((address_space(3))) float lds_float;
   typedef __attribute__((address_space(3))) s16x8_t lds_s16x8;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -842,33 +855,64 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
   const float c2 = p.scale * 1.4426950408889634f;
   const int ntile = (S + 63) / 64;  // query tiles of 64 rows = two 32-row sub-tiles (rows >= S: zero Q / dO, L2 = +inf -> P = dS = 0)
 
-  // ---- tile staging: producers stage the Q half of a tile, consumers the dO half (four 1-KiB pieces per wave each); consumer waves 0 / 1
-  // also fetch the tile's statistics (plain global loads issued AHEAD of the DMA pieces, parked in a register for one step)
+  // ---- tile staging.  Producers stage the Q half of a tile, consumers the dO half: four 1-KiB LDS-DMA pieces per wave and tile, issued two at a
+  // time INSIDE the matrix streams (a piece costs ~100 cycles of issue among LDS reads, ~30 in a gap of a running MFMA block) over the two
+  // steps after the ring slot became free, and retired by COUNTED waits: a wave always has exactly four younger pieces in flight when it needs
+  // a tile, so `vmcnt(4)` is the landing condition and nothing ever drains the queue.  Tiles past the end are issued all the same (rows >= S
+  // arrive as zeros through the buffer window) so that the counts stay exact.
   const v4i_t srd = role == 0 ? slice_srd(Qb, p.ldq, S) : slice_srd(dOb, p.lddo, S);
   unsigned vo[4];
   st_voff(vo, role == 0 ? p.ldq : p.lddo, w, lane);
   const unsigned step_bytes = (unsigned)(64 * (role == 0 ? p.ldq : p.lddo) * 2);
-  float stat = 0.f;
-  const bool stat_wave = wave8 == 4 || wave8 == 5;
-  auto issue_tile = [&](int t) {
-    if (stat_wave) {
-      const int q = t * 64 + lane;
-      stat = wave8 == 4 ? (q < S ? Lb[q] : INFINITY) : (q < S ? Db[q] : 0.f);
+  auto issue_pieces = [&](int t, int ii0) {  // pieces ii0, ii0 + 1 of this wave's four for tile t
+    lds_char* tb = sm + (t % NSLOT) * TILE + role * ST;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int ins = w + 4 * (ii0 + ii);
+      dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)tb + (ins >> 1) * SUBP + (ins & 1) * 1024), vo[ii0 + ii] + (unsigned)t * step_bytes, srd);
     }
-    dma_st64(sm + (t % 3) * TILE + role * ST, vo, (unsigned)t * step_bytes, srd, w);
   };
-  auto store_stats = [&](int t) {
-    if (stat_wave) ((lds_float*)(sm + DKDV_WS_SOFF + (t % 3) * 512))[(wave8 - 4) * 64 + lane] = stat;
+  // statistics of a tile (L2 and delta of its 64 query rows) also travel by LDS-DMA, one dword per lane: consumer wave w fetches L2 (w even) or
+  // delta (w odd) — waves 2 / 3 repeat what 0 / 1 fetch so that every consumer wave has the same five pieces per tile in flight.  Rows >= S
+  // arrive as zeros, which is as good as L2 = +inf there: their Q / dO rows are zeros too, so P^T dO = 0 and dS = P (0 - 0) = 0.
+  const v4i_t srd_st = slice_srd_bytes((w & 1) ? (const void*)Db : (const void*)Lb, (long)S * 4);
+  auto issue_stats = [&](int t) {
+    const unsigned dst = (unsigned)(size_t)(sm + DKDV_WS_SOFF + (t % NSLOT) * 512 + (w & 1) * 256);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(__builtin_amdgcn_readfirstlane(dst)),
+                 "v"((unsigned)((t * 64 + lane) * 4)), "s"(srd_st)
+                 : "memory");
   };
-  issue_tile(0);
-  store_stats(0);
-  if (ntile > 1) {
-    issue_tile(1);
-    store_stats(1);
+  // prologue: tiles 0 and 1 complete, then the in-flight state the loop's counted waits assume: tile 2 — producers pieces 0-1 (2-3 follow in
+  // H1 of step 0), consumers statistics + all four pieces
+  for (int t = 0; t < 2; ++t) {
+    if (role == 1) issue_stats(t);
+    issue_pieces(t, 0);
+    issue_pieces(t, 2);
   }
-  DMA_WAIT_ALL();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (role == 1) issue_stats(2);
+  issue_pieces(2, 0);
+  if (role == 1) issue_pieces(2, 2);
   __syncthreads();
+  int ws_bar = 0;  // barrier index inside the current tile (trace only)
+#define DKDV_WS_BAR(T)                                                                                                     \
+  {                                                                                                                        \
+    if (TRACE && blockIdx.x == 0 && w == 0 && lane == 0 && (T) >= 8 && (T) < 12) {                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+      g_ws_trace[(role * 4 + ((T) - 8)) * 8 + 2 * ws_bar] = __builtin_readcyclecounter();                                  \
+    }                                                                                                                      \
+    __syncthreads();                                                                                                       \
+    if (TRACE && blockIdx.x == 0 && w == 0 && lane == 0 && (T) >= 8 && (T) < 12)                                           \
+      g_ws_trace[(role * 4 + ((T) - 8)) * 8 + 2 * ws_bar + 1] = __builtin_readcyclecounter();                              \
+    ws_bar = (ws_bar + 1) & 3;                                                                                             \
+  }
 
+  // Every 32-row step is two half-steps separated by workgroup barriers, and the two waves of a SIMD are in OPPOSITE phases (the ping-pong
+  // of the 8-phase GEMM): in H1 the producer streams its 16 S / dP products of sub-tile i + 1 through the matrix pipe while the consumer
+  // fetches its operands (the pair's slot + 32 transpose reads of sub-tile i - 1); in H2 the consumer streams its 16 dV / dK products while
+  // the producer runs the softmax / dS arithmetic of sub-tile i on the vector ALU, hands P / dS over and fetches the Q / dO row fragments
+  // of sub-tile i + 2 (into AccVGPRs: ds_read straight into the register class the MFMA reads them from).  A wave that meets a busy
+  // matrix pipe stalls in order — interleaving the two waves' MFMAs instruction by instruction (version 1 of this kernel) serialised them.
   if (role == 0) {
     // ================================================================ producer
     s16x8_t kf[8], vf[8];
@@ -883,96 +927,114 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       }
     }
     f32x16_t sA[2], dpA[2];  // S / dP of sub-tile parity 0 / 1
+    s16x8_t qa[8], da[8];    // row fragments of ONE sub-tile (AccVGPRs), fetched half a step ahead of their products
+    f32x4_t lst[4], dst[4];  // statistics of the sub-tile whose arithmetic runs in the coming H2 (read at the end of H1)
     lds_char* const xw = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
-    // A(0): S, dP of sub-tile 0 (tile 0, rows 0-31), nothing to interleave with yet
-    {
-      const lds_char* qsub = sm;
-#pragma unroll
-      for (int hk = 0; hk < 2; ++hk) {
-        s16x8_t qa[4], da[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          qa[ks] = frag_rm_st(qsub, 0, 16 * (4 * hk + ks), lane);
-          da[ks] = frag_rm_st(qsub + ST, 0, 16 * (4 * hk + ks), lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          if (hk == 0 && ks == 0) {
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sA[0]) : "v"(qa[ks]), "a"(kf[0]));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dpA[0]) : "v"(da[ks]), "a"(vf[0]));
-          } else {
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[0]) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[0]) : "v"(da[ks]), "a"(vf[4 * hk + ks]));
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(sA[0]), "+v"(dpA[0]));
-    }
-    // One producer step: the softmax / dS arithmetic of sub-tile parity PAR (statistics of tile TS, row half PAR) interleaved, one MFMA per
-    // accumulator register, with S / dP of the NEXT sub-tile (rows 32 * (PAR ^ 1) of the tile at QN) into the other register set; then the
-    // packed P / dS operands go to the pair's slot of parity PAR.  Past the last sub-tile QN points at stale data: its products are never read.
-#define DKDV_WS_OPAQUE(x) asm volatile("" : "+v"(x))
-#define DKDV_WS_PSTEP(PAR, TS, QN)                                                                                               \
-  {                                                                                                                              \
-    const lds_float* ltc = (const lds_float*)(sm + DKDV_WS_SOFF + ((TS) % 3) * 512) + 32 * (PAR);                                \
-    _Pragma("unroll") for (int hk = 0; hk < 2; ++hk) {                                                                           \
-      float ls[8], ds[8]; /* statistics of the eight query rows whose arithmetic rides in this half (registers 8 hk .. 8 hk + 7) */ \
-      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                                            \
-        const f32x4_t l4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 8 * (2 * hk + g) + 4 * h);   \
-        const f32x4_t d4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 64 + 8 * (2 * hk + g) + 4 * h); \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                          \
-          ls[4 * g + e] = l4[e];                                                                                                 \
-          ds[4 * g + e] = d4[e];                                                                                                 \
-        }                                                                                                                        \
-      }                                                                                                                          \
-      s16x8_t qa[4], da[4];                                                                                                      \
-      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                         \
-        qa[ks] = frag_rm_st((QN), 32 * ((PAR) ^ 1), 16 * (4 * hk + ks), lane);                                                   \
-        da[ks] = frag_rm_st((QN) + ST, 32 * ((PAR) ^ 1), 16 * (4 * hk + ks), lane);                                              \
-      }                                                                                                                          \
-      __builtin_amdgcn_sched_barrier(0);                                                                                         \
-      _Pragma("unroll") for (int rr = 0; rr < 8; ++rr) {                                                                         \
-        const int r = 8 * hk + rr, ks = rr >> 1;                                                                                 \
-        if (hk == 0 && rr == 0)                                                                                                  \
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sA[(PAR) ^ 1]) : "v"(qa[0]), "a"(kf[0]));                 \
-        else if (hk == 0 && rr == 1)                                                                                             \
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dpA[(PAR) ^ 1]) : "v"(da[0]), "a"(vf[0]));                \
-        else if ((rr & 1) == 0)                                                                                                  \
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[(PAR) ^ 1]) : "v"(qa[ks]), "a"(kf[4 * hk + ks]));     \
-        else                                                                                                                     \
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[(PAR) ^ 1]) : "v"(da[ks]), "a"(vf[4 * hk + ks]));    \
-        const float pr = __builtin_amdgcn_exp2f(fmaf(sA[PAR][r], c2, -ls[rr]));                                                  \
-        float dd = dpA[PAR][r] - ds[rr];                                                                                         \
-        DKDV_WS_OPAQUE(dd);                                                                                                      \
-        dd *= pr;                                                                                                                \
-        DKDV_WS_OPAQUE(dd);                                                                                                      \
-        sA[PAR][r] = pr;                                                                                                         \
-        dpA[PAR][r] = dd;                                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                                       \
-      }                                                                                                                          \
-    }                                                                                                                            \
-    lds_char* xs = xw + (PAR) * 16384;                                                                                           \
-    *reinterpret_cast<lds_s16x8*>(xs) = pack_acc8(sA[PAR], 0);                                                                   \
-    *reinterpret_cast<lds_s16x8*>(xs + 1024) = pack_acc8(sA[PAR], 8);                                                            \
-    *reinterpret_cast<lds_s16x8*>(xs + 2048) = pack_acc8(dpA[PAR], 0);                                                           \
-    *reinterpret_cast<lds_s16x8*>(xs + 3072) = pack_acc8(dpA[PAR], 8);                                                           \
+    // frag_rm_st's address = tile + ks * SUBP + row * 32 + ((h ^ ((row >> 3) & 1)) << 4): the lane part is the same for rows l31 and 32 + l31
+    const unsigned ln_rm = (unsigned)(l31 * 32 + ((h ^ ((l31 >> 3) & 1)) << 4));
+#define DKDV_WS_FRAG1(RH, KS)                                                                                                       \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(qa[KS]) : "v"(fbase), "n"((RH) * 32 * 32 + (KS) * SUBP));                     \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(da[KS]) : "v"(fbase), "n"(ST + (RH) * 32 * 32 + (KS) * SUBP));
+#define DKDV_WS_FRAGS(RH, TB)                                                                                                       \
+  {                                                                                                                                 \
+    const unsigned fbase = (unsigned)(size_t)(TB) + ln_rm;                                                                          \
+    DKDV_WS_FRAG1(RH, 0) DKDV_WS_FRAG1(RH, 1) DKDV_WS_FRAG1(RH, 2) DKDV_WS_FRAG1(RH, 3)                                             \
+    DKDV_WS_FRAG1(RH, 4) DKDV_WS_FRAG1(RH, 5) DKDV_WS_FRAG1(RH, 6) DKDV_WS_FRAG1(RH, 7)                                             \
   }
+#define DKDV_WS_PIN8A(x) "+a"(x[0]), "+a"(x[1]), "+a"(x[2]), "+a"(x[3]), "+a"(x[4]), "+a"(x[5]), "+a"(x[6]), "+a"(x[7])
+    // H1: S = Q K^T, dP = dO V^T of the sub-tile whose fragments are in qa / da, into register set SET; two LDS-DMA pieces (DMA_STMT) ride in
+    // the matrix stream.  VALU = 1: the first two thirds of the CURRENT sub-tile's softmax / dS arithmetic (register set SET ^ 1, statistics of
+    // tile TS row half RH: t = s c2 - L2, dd = dP - delta, p = exp2(t)) ride in the same stream, three or two registers per MFMA pair from the
+    // third pair on — the matrix pipe belongs to this wave alone in H1 (the consumer is fetching operands), an MFMA runs 32 cycles and these
+    // are 16 cycles of vector work, and by the third pair the statistics have returned.  What is left for H2 (p * dd, packing, the hand-over)
+    // is short enough not to outlast the consumer's sixteen products: the vector ALU runs at ~0.6 of its rate beside the sibling's matrix
+    // stream (profiles/r04_attn_ws_trace_*.txt: version 3b of this kernel spent 1000 cycles per H2 on 384 cycles of vector instructions).
+    // Single fp32 instructions as asm statements: the scheduler may not pair them into v_pk_* forms (slower beside a matrix stream).
+#define DKDV_WS_VALU3(CUR, R)                                                                                                       \
+  {                                                                                                                                 \
+    asm volatile("v_fma_f32 %0, %1, %2, -%3" : "=v"(sA[CUR][R]) : "v"(sA[CUR][R]), "v"(c2), "v"(lst[(R) >> 2][(R) & 3]));           \
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(dpA[CUR][R]) : "v"(dpA[CUR][R]), "v"(dst[(R) >> 2][(R) & 3]));                       \
+    asm volatile("v_exp_f32 %0, %1" : "=v"(sA[CUR][R]) : "v"(sA[CUR][R]));                                                          \
+  }
+#define DKDV_WS_MMA(SET, VALU, DMA_STMT, TS, RH)                                                                                    \
+  {                                                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" : DKDV_WS_PIN8A(qa), DKDV_WS_PIN8A(da));                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    if (VALU) { /* the statistics of the current sub-tile: issued now, they return under the first two MFMA pairs */                 \
+      const lds_float* ltc = (const lds_float*)(sm + DKDV_WS_SOFF + ((TS) % NSLOT) * 512) + 32 * (RH);                              \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                                               \
+        lst[g] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 8 * g + 4 * h);                          \
+        dst[g] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(ltc + 64 + 8 * g + 4 * h);                     \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sA[SET]) : "a"(qa[0]), "a"(kf[0]));                               \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dpA[SET]) : "a"(da[0]), "a"(vf[0]));                              \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[SET]) : "a"(qa[1]), "a"(kf[1]));                               \
+    { DMA_STMT }                                                                                                                    \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[SET]) : "a"(da[1]), "a"(vf[1]));                              \
+    if (VALU) {                                                                                                                     \
+      /* the statistics must be in registers before the asm instructions below read them: the compiler waits for loads it issued   */ \
+      /* only in front of uses it can see, and it sees asm operands — pin them                                                     */ \
+      asm volatile("" : "+v"(lst[0]), "+v"(lst[1]), "+v"(lst[2]), "+v"(lst[3]), "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3])); \
+    }                                                                                                                               \
+    _Pragma("unroll") for (int ks = 2; ks < 8; ++ks) {                                                                              \
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sA[SET]) : "a"(qa[ks]), "a"(kf[ks]));                           \
+      if (VALU) {                                                                                                                   \
+        const int r0 = ks < 6 ? 3 * (ks - 2) : 12 + 2 * (ks - 6);                                                                   \
+        DKDV_WS_VALU3((SET) ^ 1, r0)                                                                                                \
+        if (ks < 6) DKDV_WS_VALU3((SET) ^ 1, r0 + 1)                                                                                \
+      }                                                                                                                             \
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dpA[SET]) : "a"(da[ks]), "a"(vf[ks]));                          \
+      if (VALU) {                                                                                                                   \
+        const int r1 = ks < 6 ? 3 * (ks - 2) + 2 : 12 + 2 * (ks - 6) + 1;                                                           \
+        DKDV_WS_VALU3((SET) ^ 1, r1)                                                                                                \
+      }                                                                                                                             \
+    }                                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+  }
+    // H2: the rest of the arithmetic of register set SET (dS = p * dd), packed operands into the pair's slot
+#define DKDV_WS_SOFTMAX(SET)                                                                                                        \
+  {                                                                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                  \
+      asm volatile("v_mul_f32 %0, %1, %2" : "=v"(dpA[SET][r]) : "v"(dpA[SET][r]), "v"(sA[SET][r]));                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    *reinterpret_cast<lds_s16x8*>(xw) = pack_acc8(sA[SET], 0);                                                                      \
+    *reinterpret_cast<lds_s16x8*>(xw + 1024) = pack_acc8(sA[SET], 8);                                                               \
+    *reinterpret_cast<lds_s16x8*>(xw + 2048) = pack_acc8(dpA[SET], 0);                                                              \
+    *reinterpret_cast<lds_s16x8*>(xw + 3072) = pack_acc8(dpA[SET], 8);                                                              \
+  }
+    // prologue: S / dP of sub-tile 0 + its statistics, fragments of sub-tile 1
+    DKDV_WS_FRAGS(0, sm)
+    DKDV_WS_MMA(0, 0, , 0, 0)
+    DKDV_WS_FRAGS(1, sm)
+    // state on entry of iteration t: sA[0] / dpA[0] = products of sub-tile 2t, qa / da = fragments of sub-tile 2t + 1
     for (int t = 0; t < ntile; ++t) {
-      const lds_char* tcur = sm + (t % 3) * TILE;
-      const lds_char* tnext = sm + ((t + 1) % 3) * TILE;
-      // step 2t: arithmetic of sub-tile 2t || products of sub-tile 2t + 1 (same tile, rows 32-63)
-      DKDV_WS_PSTEP(0, t, tcur)
-      DMA_WAIT_ALL();  // the tile issued one step ago (tile t + 1) has landed: this barrier publishes it
-      __syncthreads();
-      // step 2t + 1: tile t + 2 goes into the ring slot tile t - 1 left; arithmetic of sub-tile 2t + 1 || products of sub-tile 2t + 2
-      if (t + 2 < ntile) issue_tile(t + 2);
-      DKDV_WS_PSTEP(1, t, tnext)
-      __syncthreads();
+      const lds_char* tn1 = sm + ((t + 1) % NSLOT) * TILE;
+      // ---- step 2t.  H1: products of sub-tile 2t + 1 -> set 1 || t, dd, p of sub-tile 2t (set 0); pieces 2-3 of tile t + 2
+      DKDV_WS_MMA(1, 1, issue_pieces(t + 2, 2);, t, 0)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's pieces of tile t + 1 have landed (the four younger ones stay in flight)
+      DKDV_WS_BAR(t)
+      // H2: dS of sub-tile 2t, hand-over; fragments of sub-tile 2t + 2 = rows 0-31 of tile t + 1
+      DKDV_WS_FRAGS(0, tn1)  // issued first: they return under the arithmetic (the barrier's lgkmcnt(0) waits for every LDS operation of the wave)
+      DKDV_WS_SOFTMAX(0)
+      DKDV_WS_BAR(t)
+      // ---- step 2t + 1.  H1: products of sub-tile 2t + 2 -> set 0 (past the last tile: zeros, never read); pieces 0-1 of tile t + 3;
+      //      statistics of sub-tile 2t + 1
+      DKDV_WS_MMA(0, 1, issue_pieces(t + 3, 0);, t, 1)
+      DKDV_WS_BAR(t)
+      // H2: dS of sub-tile 2t + 1, hand-over; fragments of sub-tile 2t + 3 = rows 32-63 of tile t + 1
+      DKDV_WS_FRAGS(1, tn1)
+      DKDV_WS_SOFTMAX(1)
+      DKDV_WS_BAR(t)
     }
-#undef DKDV_WS_PSTEP
-#undef DKDV_WS_OPAQUE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DKDV_WS_PIN8A(qa), DKDV_WS_PIN8A(da));  // the last (unused) fetches retire before the wave ends
+#undef DKDV_WS_SOFTMAX
+#undef DKDV_WS_MMA
+#undef DKDV_WS_VALU3
+#undef DKDV_WS_PIN8A
+#undef DKDV_WS_FRAGS
+#undef DKDV_WS_FRAG1
   } else {
     // ================================================================ consumer
     f32x16_t dk[4], dv[4];
@@ -985,55 +1047,75 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
     const unsigned ln_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);
     const unsigned ln_hi = ln_lo + 8 * 32 + ((lh ^ 1) - lh) * 16;
     const lds_char* const xr = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
-    // One consumer step: dV += P^T dO, dK += dS^T Q of the sub-tile in row half RH of the tile at TB, operands from the slot of parity XP
+    s16x8_t pf[2], df[2];
+    s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];
+    // H1 of a consumer step: operands of the sub-tile in row half RH of the tile at TB into registers
 #define DKDV_WS_TR1(RH, KK, D)                                                                             \
   tr16_issue_off<ST + (32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dlo[4 * (KK) + (D)], tlo);            \
   tr16_issue_off<ST + (32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(dhi[4 * (KK) + (D)], thi);            \
   tr16_issue_off<(32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qlo[4 * (KK) + (D)], tlo);                 \
   tr16_issue_off<(32 * (RH) + 16 * (KK)) * 32 + 2 * (D) * SUBP>(qhi[4 * (KK) + (D)], thi);
-#define DKDV_WS_CSTEP(RH, XP, TB)                                                                                               \
+#define DKDV_WS_CLOAD(RH, TB)                                                                                                   \
   {                                                                                                                             \
-    const lds_char* xs = xr + (XP) * 16384;                                                                                     \
-    s16x8_t pf[2], df[2];                                                                                                       \
-    pf[0] = *reinterpret_cast<const lds_s16x8*>(xs);                                                                            \
-    pf[1] = *reinterpret_cast<const lds_s16x8*>(xs + 1024);                                                                     \
-    df[0] = *reinterpret_cast<const lds_s16x8*>(xs + 2048);                                                                     \
-    df[1] = *reinterpret_cast<const lds_s16x8*>(xs + 3072);                                                                     \
+    pf[0] = *reinterpret_cast<const lds_s16x8*>(xr);                                                                            \
+    pf[1] = *reinterpret_cast<const lds_s16x8*>(xr + 1024);                                                                     \
+    df[0] = *reinterpret_cast<const lds_s16x8*>(xr + 2048);                                                                     \
+    df[1] = *reinterpret_cast<const lds_s16x8*>(xr + 3072);                                                                     \
     const unsigned tlo = (unsigned)(size_t)(TB) + ln_lo, thi = (unsigned)(size_t)(TB) + ln_hi;                                  \
-    s16x4_t dlo[8], dhi[8], qlo[8], qhi[8];                                                                                     \
     DKDV_WS_TR1(RH, 0, 0) DKDV_WS_TR1(RH, 0, 1) DKDV_WS_TR1(RH, 0, 2) DKDV_WS_TR1(RH, 0, 3)                                     \
     DKDV_WS_TR1(RH, 1, 0) DKDV_WS_TR1(RH, 1, 1) DKDV_WS_TR1(RH, 1, 2) DKDV_WS_TR1(RH, 1, 3)                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" : TR_PIN8(dlo), TR_PIN8(dhi));                                                          \
     asm volatile("" : TR_PIN8(qlo), TR_PIN8(qhi));                                                                              \
     asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                          \
+  }
+    // H2: dV += P^T dO, dK += dS^T Q with the operands in registers; two LDS-DMA pieces (DMA_STMT) ride in the matrix stream
+#define DKDV_WS_CMMA(DMA_STMT)                                                                                                  \
+  {                                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                            \
       _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                                           \
         dv[d] = mfma32(pf[kk], join_lohi(dlo[4 * kk + d], dhi[4 * kk + d]), dv[d]);                                            \
         dk[d] = mfma32(df[kk], join_lohi(qlo[4 * kk + d], qhi[4 * kk + d]), dk[d]);                                            \
+        if (kk == 0 && d == 1) {                                                                                                \
+          __builtin_amdgcn_sched_barrier(0);                                                                                    \
+          DMA_STMT                                                                                                              \
+          __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        }                                                                                                                       \
       }                                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                          \
   }
     for (int t = 0; t < ntile; ++t) {
-      const lds_char* tcur = sm + (t % 3) * TILE;
-      // step 2t: sub-tile 2t - 1 = rows 32-63 of tile t - 1, operands of parity 1
+      const lds_char* tcur = sm + (t % NSLOT) * TILE;
+      // ---- step 2t.  H1: operands of sub-tile 2t - 1 = rows 32-63 of tile t - 1
       if (t > 0) {
-        const lds_char* tprev = sm + ((t + 2) % 3) * TILE;
-        DKDV_WS_CSTEP(1, 1, tprev)
+        const lds_char* tprev = sm + ((t + NSLOT - 1) % NSLOT) * TILE;
+        DKDV_WS_CLOAD(1, tprev)
       }
-      DMA_WAIT_ALL();
-      if (t >= 1 && t + 1 < ntile) store_stats(t + 1);  // fetched one step ago together with tile t + 1
-      __syncthreads();
-      // step 2t + 1: sub-tile 2t = rows 0-31 of tile t, operands of parity 0
-      if (t + 2 < ntile) issue_tile(t + 2);
-      DKDV_WS_CSTEP(0, 0, tcur)
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's pieces (and statistics) of tile t + 1 have landed; tile t + 2's five stay in flight
+      DKDV_WS_BAR(t)
+      // H2: its products; statistics + pieces 0-1 of tile t + 3
+      if (t > 0) {
+        DKDV_WS_CMMA(issue_stats(t + 3); issue_pieces(t + 3, 0);)
+      } else {
+        issue_stats(t + 3);
+        issue_pieces(t + 3, 0);
+      }
+      DKDV_WS_BAR(t)
+      // ---- step 2t + 1.  H1: operands of sub-tile 2t = rows 0-31 of tile t
+      DKDV_WS_CLOAD(0, tcur)
+      DKDV_WS_BAR(t)
+      DKDV_WS_CMMA(issue_pieces(t + 3, 2);)
+      DKDV_WS_BAR(t)
     }
     {  // the last sub-tile: rows 32-63 of the last tile
-      const lds_char* tlast = sm + ((ntile - 1) % 3) * TILE;
-      DKDV_WS_CSTEP(1, 1, tlast)
+      const lds_char* tlast = sm + ((ntile - 1) % NSLOT) * TILE;
+      DKDV_WS_CLOAD(1, tlast)
+      DKDV_WS_CMMA()
     }
-#undef DKDV_WS_CSTEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles issued past the end retire before the wave ends
+#undef DKDV_WS_CMMA
+#undef DKDV_WS_CLOAD
 #undef DKDV_WS_TR1
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -1048,6 +1130,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       }
   }
 }
+#undef DKDV_WS_BAR
 
 // ============================================================================================ backward: dQ
 // grid = ceil(S/128) * H * B workgroups (attn_wg_coords); wave w owns query rows [q0 + 32 w, +32) (Q, dO fragments in registers, dQ^T accumulators);
@@ -1226,10 +1309,17 @@ static void launch_fwd(const AitkAttnArgs* a, hipStream_t s) {
   hipLaunchKernelGGL((attn_fwd_kernel<KS, DB>), grid, dim3(256), lds, s, *a);
 }
 
-// AITK_ATTN_DKDV_WS=1 selects the wave-specialised dK / dV kernel (8 waves, two per SIMD) for head_dim 128
-static bool dkdv_ws_enabled() {  // read at every launch (57 per step): tests and A/B runs switch it inside one process
+// AITK_ATTN_DKDV_WS: 1 (default) = the wave-specialised dK / dV kernel for head_dim 128, 0 = the pipelined one-wave-per-SIMD kernel (same bits),
+// 2 = the wave-specialised kernel with the barrier trace.  Read at every launch (57 per step): tests and A/B runs switch it inside one process.
+static int dkdv_ws_mode() {
   const char* e = getenv("AITK_ATTN_DKDV_WS");
-  return e && e[0] == '1';
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+}
+static bool dkdv_ws_enabled() { return dkdv_ws_mode() != 0; }
+// the s_memtime stamps the TRACE instantiation left (64 values: [role 2][tile 8-11][barrier 4][before, after])
+extern "C" int aitk_probe_attn_ws_trace(uint64_t* out64) {
+  if (!out64) return AITK_ERR_ARG;
+  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_ws_trace), sizeof(unsigned long long) * 64, 0, hipMemcpyDeviceToHost);
 }
 // AITK_ATTN_DKDV_PIPE=0 selects the un-pipelined dK / dV kernel for head_dim 128 (same-box A/B); default: the pipelined one
 static bool dkdv_pipe_enabled() {
@@ -1249,11 +1339,13 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   if (KS == 8 && DB == 4 && dkdv_ws_enabled()) {
     static bool wattr = false;
     if (!wattr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
       wattr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    if (dkdv_ws_mode() == 2) hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<true>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<false>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
     return;
   }

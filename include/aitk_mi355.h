@@ -100,6 +100,8 @@ typedef struct AitkQuantRowsArgs {
 int aitk_quant_rows_fp8(const AitkQuantRowsArgs* args, aitk_stream_t stream);
 
 int aitk_abi_version(void);
+/* diagnostics: s_memtime stamps around the barriers of the wave-specialised dK/dV kernel's TRACE build (AITK_ATTN_DKDV_WS=2): 64 values */
+int aitk_probe_attn_ws_trace(uint64_t* out64);
 int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */
 int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
 /* Two independent problems in one call (e.g. the image- and text-stream projections of a FLUX double block:
