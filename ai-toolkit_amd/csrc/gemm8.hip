@@ -102,7 +102,10 @@ static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguou
 // per lane is only whether the tap's pixel exists — a 9-bit mask per staged row, built once per output tile — and a lane whose pixel lies
 // outside the image points its offset past the buffer window and receives zeros (the same mechanism as K tails and dead tiles).
 // The descriptor base is shifted one image row + one pixel down so that the base offset of a border pixel is never negative.
-template <bool GR, bool F8, bool CV = false>
+// FE: the fast epilogue forms (see the epilogue).  TRACE: s_memtime at the tile-switch points of tiles 1-3 of workgroups 0 and 100, waves 0 and 4
+// (aitk_probe_gemm8_trace).
+__device__ unsigned g_gemm8_trace[2 * 2 * 3 * 5];
+template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false>
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
   static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
@@ -144,6 +147,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #endif
   };
   unsigned va[4], vb[4];  // byte offsets of this thread's chunk (K-tile 0) in A / B for the tile being STAGED
+  unsigned va2[4], vb2[4];  // ... and in the LoRA slab operands A2 / B2 (K-tile 0 of the slab)
   unsigned cm01 = 0, cm23 = 0;  // CV: tap-validity masks of staged rows i = 0, 1 (bits 0-8, 9-17) and i = 2, 3
   // CV: wave-uniform constants of the tap walk (SGPRs for the whole kernel: scalar loads inside the K loop would share lgkmcnt with the
   // hand-counted fragment reads)
@@ -186,6 +190,15 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     return r;
   };
   v4i srdA = make_srd(CV ? (const void*)(p.A - (long)(p.conv_W + 1) * p.conv_Cin) : (const void*)p.A), srdB = make_srd(p.B);
+  v4i srdA2 = make_srd(p.A2), srdB2 = make_srd(p.B2);
+  // lanes whose 16-B chunk of the LAST slab K-tile lies beyond K2 (K2 = 48 for rank 16: chunks 6, 7): OR-ed into the lane offset, which then points
+  // outside the buffer window and reads zeros
+  constexpr bool SLAB_PRE = !F8;  // the W8A8 instantiation has no registers left for the eight precomputed offsets (it would spill 50 more)
+  unsigned slab_tail_oob = 0;
+  if (SLAB_PRE && nk2 > 0) {
+    const int t_ = opaque_tid();
+    slab_tail_oob = ((nk2 - 1) * BK + CC(t_) * 8 < p.K2) ? 0u : 0x80000000u;
+  }
   auto set_offsets = [&](int tm0, int tn0, int prob) {
     om0 = tm0;
     on0 = tn0;
@@ -195,9 +208,20 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       sM = q->M;
       srdA = make_srd(q->A);
       srdB = make_srd(q->B);
+      if constexpr (SLAB_PRE) {
+        srdA2 = make_srd(q->A2);
+        srdB2 = make_srd(q->B2);
+      }
     }
     const int t_ = opaque_tid();
     const int srow = SROW(t_), cc = CC(t_);
+    if (SLAB_PRE && nk2 > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va2[i] = ((unsigned)((long)a_row(i, srow) * q->lda2) + cc * 8) * 2;
+        vb2[i] = ((unsigned)((long)b_row(i, srow) * q->ldb2) + cc * 8) * 2;
+      }
+    }
     if constexpr (CV) {
       const int HoWo = q->conv_HoWo, Wo = q->conv_Wo, cst = q->conv_stride, H = q->conv_H, W = q->conv_W, Cin = q->conv_Cin;
       cm01 = cm23 = 0;
@@ -268,7 +292,17 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       }
       return;
     }
-    // K tail of the base segment / LoRA slab / dead tile: lanes whose chunk lies beyond the segment read zeros
+    if (SLAB_PRE && !dead && kt >= nk1) {  // LoRA-slab K-tile: offsets precomputed per output tile, no scalar loads (they would share lgkmcnt with the fragment reads)
+      const int ks = kt - nk1;
+      const unsigned tail = ks == nk2 - 1 ? slab_tail_oob : 0u;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * half + ii;
+        dma(ldst + ii * (NT * 16), (opnd ? vb2[i] : va2[i]) | tail, opnd ? srdB2 : srdA2, (unsigned)ks * (BK * 2));
+      }
+      return;
+    }
+    // K tail of the base segment / dead tile (and, W8A8, the LoRA slab): lanes whose chunk lies beyond the segment read zeros
     const int t_ = opaque_tid();
     const int srow = SROW(t_), cc = CC(t_);
     const bool second = kt >= nk1;
@@ -415,7 +449,15 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   stage_half(1, 1, 0, 0, false);
   stage_half(1, 1, 1, 0, false);
   bool first = true;
-
+  int tix = 0;   // output tiles this workgroup has finished
+  unsigned tr[3][5] = {};
+#define STAMP(k_)                                                                                                   \
+  if constexpr (TRACE) {                                                                                            \
+    const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime();                                                     \
+    if (tix == 1) tr[0][k_] = t_;                                                                                   \
+    else if (tix == 2) tr[1][k_] = t_;                                                                              \
+    else if (tix == 3) tr[2][k_] = t_;                                                                              \
+  }
   while (true) {
     const int vnext = vt + gridDim.x;
     const bool has_next = vnext < ntiles;
@@ -427,12 +469,14 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    STAMP(0);
     if (first) VMCNT8();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // prefetched K-tiles + this wave's epilogue traffic
     first = false;
     if constexpr (F8) park_scales();  // this tile's operand scales (fetched before the wait above) into the wave's idle epilogue patch
     BAR();
     if (wr == 1) BAR();  // second wave of every SIMD runs one barrier behind
+    STAMP(1);
     // Steady part: K-tiles t+1, t+2 are full base-segment tiles of THIS output tile — straight-line fast staging, no
     // branches.  Tail part (last <= 2 + LoRA-slab iterations): K tail, slab, and the next output tile's first K-tiles.
     auto stage_fast = [&](int kt, unsigned ldst_buf, int opnd, int half) {
@@ -482,6 +526,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       flip();
       BAR();
     }
+    STAMP(2);
     bool switched = false;  // offsets already describe the NEXT output tile
     // one tail iteration; f8_c: this K-tile belongs to the e4m3 base segment (compile-time so each loop below carries ONE matrix form)
     auto tail_iter = [&](int t, auto f8_c) {
@@ -536,7 +581,181 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     if (F8 && nk2 == 0) scale_acc();
 
     // ---------------- epilogue (tile m0, n0; wave block rows wr*128.., cols wc*64..) ----------------
-    {
+    // Two forms.  The GENERIC one takes any flag combination, ragged rows / columns and any row map; it tests the flags at run time, which the compiler
+    // turns into compute-both-and-select code, re-derives every row's address (a 64-bit multiply, or a division under a segmented row map) and re-reads
+    // kernel arguments per row group: ~60 vector instructions per row group for a bias-only tile.  The s_memtime trace of round 4
+    // (profiles/r04_gemm8_tile_switch.md) shows what that costs: 12,300 cycles per bias-only tile and 57,000 per gate-residual tile next to 2,456 per
+    // K-tile, while the same stores replayed without the arithmetic (tools/probes/epilogue_store.hip) take 3,700 — the epilogue is bound by vector issue
+    // and, where it reads, by sixteen SERIAL load -> use -> store round trips per wave (gfx9 retires vmcnt in order: waiting for a load issued behind a
+    // store also waits for that store's acknowledgement).  The FAST form (FE) is one straight-line instantiation per flag set the graphs actually use, for
+    // waves whose 128 x 64 block lies inside the matrix: flags are compile-time, a row group's address is a wave-uniform 64-bit base (walked incrementally
+    // through the segmented row map) + one per-lane 32-bit offset, bf16 round trips reuse the packed words that are stored anyway, gate columns are loaded
+    // once per sample instead of once per row group, and the operands a block READS (residual / pre-activation / old C) are requested two blocks ahead, in
+    // front of the stores of the blocks in between.  Same arithmetic, same order: bit-identical to the generic form.
+    STAMP(3);
+    bool epi_done = false;
+    if constexpr (FE) {
+      KArgsPtr q = kargs(cprob);
+      const int flags = q->flags;
+      const int mw = __builtin_amdgcn_readfirstlane(m0 + wr * 128), nw = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
+      const int csr = q->c_seg_rows, grows = q->gate_rows;
+      bool ok = mw + 128 <= q->M && nw + 64 <= q->N && (csr == 0 || (csr >= 128 && (csr & 15) == 0));
+      if (flags & AITK_EPI_GATE_RES) ok = ok && grows >= 128 && (grows & 15) == 0;
+      auto fast_epi = [&](auto fl_c) {
+        constexpr int FL = decltype(fl_c)::value;
+        constexpr bool BIAS = (FL & AITK_EPI_BIAS) != 0, GELU = (FL & AITK_EPI_GELU) != 0, DGELU = (FL & AITK_EPI_DGELU) != 0;
+        constexpr bool GATE = (FL & AITK_EPI_GATE_RES) != 0, ADDA = (FL & AITK_EPI_ADD_AUX) != 0, ACC = (FL & AITK_EPI_ACCUM) != 0;
+        constexpr bool RD_IN = DGELU || GATE || ADDA;  // reads aux_in
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
+        const int r_w = ln & 31, hh = ln >> 5, rr = ln >> 2, c4 = ln & 3;
+        const long ldc = q->ldc;
+        const long css = q->c_seg_stride;
+        const unsigned lofC = (unsigned)(rr * (int)ldc + c4 * 8) * 2u;  // byte offset of the lane's 16 B inside a 16-row group (< 2^31: 16 rows)
+        unsigned lofI = 0, lofO = 0;
+        const long ldi = RD_IN ? q->ld_aux_in : 0, ldo = (GELU || GATE) ? q->ld_aux_out : 0;
+        if constexpr (RD_IN) lofI = (unsigned)(rr * (int)ldi + c4 * 8) * 2u;
+        if constexpr (GELU || GATE) lofO = (unsigned)(rr * (int)ldo + c4 * 8) * 2u;
+        const char* Cb = reinterpret_cast<const char*>(q->C) + (long)nw * 2;
+        const char* Ib = RD_IN ? reinterpret_cast<const char*>(q->aux_in) + (long)nw * 2 : nullptr;
+        char* Ob = (GELU || GATE) ? const_cast<char*>(reinterpret_cast<const char*>(q->aux_out)) : nullptr;
+        const bool save_y = Ob != nullptr;  // gate-residual: y is only saved when asked
+        if (Ob) Ob += (long)nw * 2;
+        // wave-uniform walk through the segmented row map of C: group g = rows mw + 16 g .. + 15 sits in segment sg at row wg (at most one wrap per wave)
+        int sg0 = 0, wg0 = mw;
+        if (csr > 0) {
+          sg0 = mw / csr;
+          wg0 = mw - sg0 * csr;
+        }
+        auto c_group = [&](int g) -> char* {
+          int sg = sg0, wg = wg0 + 16 * g;
+          if (csr > 0 && wg >= csr) {
+            wg -= csr;
+            ++sg;
+          }
+          return const_cast<char*>(Cb) + ((long)sg * css + (long)wg * ldc) * 2;
+        };
+        // column operands: both halves requested now (packed), unpacked at the head of their column pass (ni outer: 8 + 4 live registers instead of 16)
+        uint4 bpk[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if constexpr (BIAS) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bpk[ni] = *reinterpret_cast<const uint4*>(q->bias + nw + ni * 32 + c4 * 8);
+        }
+        int gb0 = 0, gw0 = 0;
+        const bf16_t* gate_p = GATE ? q->gate + nw + c4 * 8 : nullptr;
+        const long ldg = GATE ? q->ld_gate : 0;
+        if constexpr (GATE) {
+          gb0 = mw / grows;
+          gw0 = mw - gb0 * grows;
+        }
+        // operands a block reads, requested two blocks ahead: blk = 4 ni + mi, row groups 2 mi, 2 mi + 1
+        uint4 pin[16], pacc[16];
+        auto request = [&](int blk) {
+          const int mi = blk & 3, ni = blk >> 2;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int g = 2 * mi + it;
+            if constexpr (RD_IN) pin[2 * blk + it] = *reinterpret_cast<const uint4*>(Ib + ((long)(mw + 16 * g) * ldi) * 2 + lofI + ni * 64);
+            if constexpr (ACC) pacc[2 * blk + it] = *reinterpret_cast<const uint4*>(c_group(g) + lofC + ni * 64);
+          }
+        };
+        if constexpr (RD_IN || ACC) {
+          request(0);
+          request(1);
+        }
+        float b8[8], g8[8];
+        int gb_loaded = -1;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+          const int mi = blk & 3, ni = blk >> 2;
+          if (mi == 0) {
+            if constexpr (BIAS) unpack8f(bpk[ni], b8);
+            gb_loaded = -1;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4_t v4 = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+            *reinterpret_cast<f32x4_t*>(patch + r_w * 128 + (((2 * g + hh) ^ (r_w & 7)) << 4)) = v4;
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same-wave LDS ops execute in order, no barrier needed
+          if constexpr (RD_IN || ACC) {
+            if (blk + 2 < 8) request(blk + 2);  // ahead of this block's stores
+          }
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int g = 2 * mi + it, r = it * 16 + rr;
+            const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4) ^ (r & 7)) << 4));
+            const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4 + 1) ^ (r & 7)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            char* crow = c_group(g) + lofC + ni * 64;
+            if constexpr (BIAS) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += b8[e];
+            }
+            if constexpr (ADDA) {
+              float a8[8];
+              unpack8f(pin[2 * blk + it], a8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += a8[e];
+            }
+            if constexpr (ACC) {
+              float c8[8];
+              unpack8f(pacc[2 * blk + it], c8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += c8[e];
+            }
+            if constexpr (GELU) {
+              // u = bf16(pre-activation) is saved for backward; h = gelu_tanh(u) on the rounded value: the packed words ARE the rounded values
+              const uint4 w = pack8f(v);
+              *reinterpret_cast<uint4*>(Ob + ((long)(mw + 16 * g) * ldo) * 2 + lofO + ni * 64) = w;
+              float u8[8];
+              unpack8f(w, u8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(u8[e]);
+            }
+            if constexpr (DGELU) {
+              float u8[8];
+              unpack8f(pin[2 * blk + it], u8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad_f(u8[e]);
+            }
+            if constexpr (GATE) {
+              // y = bf16(linear out) saved when asked (d_gate needs it); x_new = res + gate[sample] * y
+              const uint4 w = pack8f(v);
+              if (save_y) *reinterpret_cast<uint4*>(Ob + ((long)(mw + 16 * g) * ldo) * 2 + lofO + ni * 64) = w;
+              int gb = gb0;
+              if (gw0 + 16 * g >= grows) ++gb;
+              if (gb != gb_loaded) {  // wave-uniform: the sample changes at most once inside a wave's 128 rows
+                unpack8f(*reinterpret_cast<const uint4*>(gate_p + (long)gb * ldg + ni * 32), g8);
+                gb_loaded = gb;
+              }
+              float y8[8], r8[8];
+              unpack8f(w, y8);
+              unpack8f(pin[2 * blk + it], r8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = r8[e] + g8[e] * y8[e];
+            }
+            *reinterpret_cast<uint4*>(crow) = pack8f(v);
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // patch reads retired before the next block overwrites it
+        }
+      };
+      if (ok) {
+        epi_done = true;
+        switch (flags) {
+          case 0: fast_epi(IC<0>{}); break;
+          case AITK_EPI_BIAS: fast_epi(IC<AITK_EPI_BIAS>{}); break;
+          case AITK_EPI_BIAS | AITK_EPI_GELU: fast_epi(IC<(AITK_EPI_BIAS | AITK_EPI_GELU)>{}); break;
+          case AITK_EPI_DGELU: fast_epi(IC<AITK_EPI_DGELU>{}); break;
+          case AITK_EPI_BIAS | AITK_EPI_GATE_RES: fast_epi(IC<(AITK_EPI_BIAS | AITK_EPI_GATE_RES)>{}); break;
+          case AITK_EPI_BIAS | AITK_EPI_ADD_AUX: fast_epi(IC<(AITK_EPI_BIAS | AITK_EPI_ADD_AUX)>{}); break;
+          case AITK_EPI_ACCUM: fast_epi(IC<AITK_EPI_ACCUM>{}); break;
+          default: epi_done = false; break;
+        }
+      }
+    }
+    if (!epi_done) {
       KArgsPtr q = kargs(cprob);
       const int flags = q->flags;
       int ln = lane;
@@ -630,6 +849,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         }
       }
     }
+    STAMP(4);
+    ++tix;
     if (!has_next) break;
     if constexpr (F8) fetch_scales(m0n, n0n, probn);  // the next tile's operand scales ride under the vmcnt(0) at the top of the loop
     vt = vnext;
@@ -638,6 +859,16 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     cprob = probn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (TRACE) {
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && (wave == 0 || wave == 4) && lane == 0) {
+      unsigned* dst = g_gemm8_trace + ((blockIdx.x ? 1 : 0) * 2 + (wave ? 1 : 0)) * 15;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dst[i * 5 + k] = tr[i][k];
+    }
+  }
+#undef STAMP
 #undef VMCNT8
 #undef SROW
 #undef CC
@@ -646,9 +877,15 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_kernel(AitkGemmArgs p) { gemm8_body<false, false>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false>(p, p2); }
+// measurement instantiations: the generic epilogue only (AITK_GEMM8_FE=0: A/B and bit-exactness of the fast forms), the s_memtime stamps
+// (AITK_GEMM8_TRACE=1, plain kernel)
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_ge_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, false>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_ge_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, false>(p, p2); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, true>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_ge_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, false, true>(p, p); }
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true>(p, p); }
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true>(p, p2); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true, false, false>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true, false, false>(p, p2); }
 // implicit-GEMM 3x3 convolution on the persistent 8-phase schedule (UNet / VAE convolutions and their data gradients)
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_conv_kernel(AitkGemmArgs p) { gemm8_body<false, false, true>(p, p); }
 
@@ -679,6 +916,11 @@ static int gemm8_contract(const AitkGemmArgs* a) {
   if (((uintptr_t)a->aux_in | (uintptr_t)a->aux_out | (uintptr_t)a->gate | (uintptr_t)a->C) & 15) return 1;
   return 0;
 }
+// measurement knobs, re-read on every launch (the A/B tools flip them inside one process)
+static int gemm8_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 static int gemm8_cus() {
   static int n_cu = 0;
   if (!n_cu) {
@@ -686,19 +928,14 @@ static int gemm8_cus() {
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EPI_OFF + 32768) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EPI_OFF + 32768) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EPI_OFF + 32768) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_f8_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EPI_OFF + 32768) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_8phase_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EPI_OFF + 32768) != hipSuccess) {
-      n_cu = 0;
-      return 0;
-    }
+    const void* kernels[] = {(const void*)gemm_nt_8phase_kernel,        (const void*)gemm_nt_8phase_grouped_kernel,    (const void*)gemm_nt_8phase_f8_kernel,
+                             (const void*)gemm_nt_8phase_f8_grouped_kernel, (const void*)gemm_nt_8phase_conv_kernel,       (const void*)gemm_nt_8phase_ge_kernel,
+                             (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel};
+    for (const void* k : kernels)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_OFF + 32768) != hipSuccess) {
+        n_cu = 0;
+        return 0;
+      }
   }
   return n_cu;
 }
@@ -710,8 +947,20 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   const int grid = tiles < n_cu ? tiles : n_cu;
   if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
-  else hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  else {
+    const int fe = gemm8_env("AITK_GEMM8_FE", 1);
+    if (gemm8_env("AITK_GEMM8_TRACE", 0)) {
+      if (fe) hipLaunchKernelGGL(gemm_nt_8phase_tr_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+      else hipLaunchKernelGGL(gemm_nt_8phase_tr_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+    } else if (fe) hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+    else hipLaunchKernelGGL(gemm_nt_8phase_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  }
   return AITK_OK;
+}
+// the s_memtime stamps the TRACE instantiation left: [workgroup 0 / 100][wave 0 / 4][tile 1-3][top, after the top wait + barrier, end of the steady K loop,
+// end of the K loop, end of the epilogue]
+extern "C" int aitk_probe_gemm8_trace(unsigned* out60) {
+  return hipMemcpyFromSymbol(out60, HIP_SYMBOL(g_gemm8_trace), sizeof(unsigned) * 60) == hipSuccess ? AITK_OK : 1;
 }
 // Two problems with equal N, K, K2 and flags in one persistent launch (aitk_gemm_nt_grouped); 1 = outside the contract.
 extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGemmArgs* b, hipStream_t st) {
@@ -723,6 +972,7 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
   if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
-  else hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  else if (gemm8_env("AITK_GEMM8_FE", 1)) hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  else hipLaunchKernelGGL(gemm_nt_8phase_grouped_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   return AITK_OK;
 }
