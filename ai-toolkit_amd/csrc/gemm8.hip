@@ -448,7 +448,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   stage_half(0, 0, 0, 1, false);
   stage_half(1, 1, 0, 0, false);
   stage_half(1, 1, 1, 0, false);
-  bool first = true;
+  VMCNT8();  // first tile: K-tile 0 landed (the later tiles wait at the bottom of the loop)
   int tix = 0;   // output tiles this workgroup has finished
   unsigned tr[3][5] = {};
 #define STAMP(k_)                                                                                                   \
@@ -470,9 +470,6 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     STAMP(0);
-    if (first) VMCNT8();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // prefetched K-tiles + this wave's epilogue traffic
-    first = false;
     if constexpr (F8) park_scales();  // this tile's operand scales (fetched before the wait above) into the wave's idle epilogue patch
     BAR();
     if (wr == 1) BAR();  // second wave of every SIMD runs one barrier behind
@@ -851,8 +848,16 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     }
     STAMP(4);
     ++tix;
+    if constexpr (F8) {
+      if (has_next) fetch_scales(m0n, n0n, probn);  // the next tile's operand scales ride under the wait below
+    }
+    // vmcnt(0): the prefetched K-tiles of the next output tile + this wave's epilogue traffic.  The BUILTIN, and on EVERY path out of the epilogue (in front
+    // of the exit test: the compiler folds the `break` into the loop latch, and a path that reaches the latch without the wait counts as a back edge), so that
+    // the waitcnt pass sees it and clears its scoreboard: with an asm wait it keeps the epilogue's global loads "possibly pending" round the back edge and,
+    // whenever their destination registers are reused by the fragment reads, puts vmcnt(0) INSIDE the steady K loop — which drains the LDS-DMA pipeline every
+    // K-tile (measured: +20 % per K-tile, profiles/r04_gemm8_tile_switch.md)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     if (!has_next) break;
-    if constexpr (F8) fetch_scales(m0n, n0n, probn);  // the next tile's operand scales ride under the vmcnt(0) at the top of the loop
     vt = vnext;
     m0 = m0n;
     n0 = n0n;
