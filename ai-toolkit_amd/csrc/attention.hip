@@ -1332,6 +1332,15 @@ static bool dkdv_pipe_enabled() {
 }
 
 template <int KS, int DB>
+static void launch_dq(const AitkAttnArgs* a, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
+}
+template <int KS, int DB>
 static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   const int Skv = a->Skv > 0 ? a->Skv : a->S;
   dim3 grid((unsigned)(((a->S + 127) / 128) * a->H * a->B));
@@ -1346,7 +1355,7 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
     }
     if (dkdv_ws_mode() == 2) hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<true>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     else hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<false>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
+    launch_dq<KS, DB>(a, grid, s);
     return;
   }
   if (KS == 8 && DB == 4 && dkdv_pipe_enabled()) {
@@ -1357,7 +1366,7 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
       pattr = true;
     }
     hipLaunchKernelGGL(attn_bwd_dkdv_pipe_kernel, grid_kv, dim3(256), DKDV_P_LDS, s, *a);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), 4 * SUBTILE_BYTES, s, *a);
+    launch_dq<KS, DB>(a, grid, s);
     return;
   }
   const size_t lds1 = 4 * SUBTILE_BYTES + 4 * 64 * sizeof(float);
@@ -1369,7 +1378,7 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
     attr = true;
   }
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<KS, DB>), grid_kv, dim3(256), lds1, s, *a);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<KS, DB>), grid, dim3(256), lds2, s, *a);
+  launch_dq<KS, DB>(a, grid, s);
 }
 
 extern "C" int aitk_attn_fwd(const AitkAttnArgs* a, aitk_stream_t stream) {
