@@ -105,16 +105,9 @@ static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguou
 // FE: the fast epilogue forms (see the epilogue).  TRACE: s_memtime at the tile-switch points of tiles 1-3 of workgroups 0 and 100, waves 0 and 4
 // (aitk_probe_gemm8_trace).
 __device__ unsigned g_gemm8_trace[2 * 2 * 3 * 5];
-// PH: barrier intervals per K-tile and wave group.  8 = the schedule of the header comment (four phases of one 64 x 32 quadrant = 8 MFMAs between two barriers).
-// 4 = the phases merged in pairs: X = quadrants (0,0) + (0,1) (reads A0, B0, B1: 16 fragment reads, 16 MFMAs on four accumulators), Y = (1,1) + (1,0) (reads A1, keeps
-// B0 / B1: 8 reads, 16 MFMAs); X stages [B1, A1] of K-tile t + 1, Y stages [A0, B0] of K-tile t + 2 — the same half-tiles at the same distances as phases 0 + 1 and
-// 2 + 3, so prologue, tile switch and tail logic are unchanged; counted waits vmcnt(8) at the end of X's load segment (A1(t) landed for Y) and vmcnt(4) at the end of
-// Y's (A0, B0, B1 of t + 1 landed for the next X).  Why: the round-4 trace puts a steady K-tile at 2,456 cycles = 8 x (256 matrix cycles + ~51 of barrier turnaround);
-// four intervals of 512 + ~51 would be 2,250.  Same products in the same order per accumulator: bit-identical.
-template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, int PH = 8>
+template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false>
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
   static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
-  static_assert(PH == 8 || (PH == 4 && !F8), "merged phases: bf16 kernels only");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
   constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
   constexpr int ESH = F8 ? 0 : 1;    // log2(bytes per base-segment element)
@@ -361,8 +354,6 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
       case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); break;
       default: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
     }
   };
@@ -442,37 +433,6 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
           for (int e = 0; e < 4; ++e) acc[mi][ni][4 * g + e] *= rs[mi] * cs[e];
       }
   };
-  // PH 4: the merged segments.  X: fragment reads ks-major [b0, a0, a1, b1] (16), MFMAs per k-substep on four accumulators; Y: [a0, a1] of the second row half (8)
-  auto read_frags_x = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      lds_read128<A_BYTES>(b0f[ks], baddr[ks]);
-      lds_read128<0>(af[0][ks], aaddr[ks]);
-      lds_read128<32 * 128>(af[1][ks], aaddr[ks]);
-      lds_read128<A_BYTES + 128 * 128>(b1f[ks], baddr[ks]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto mma_pair = [&](int qm) {  // qm 0: X (reads counted 4 per k-substep), qm 1: Y (2 per k-substep: the A fragments only)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      wait_lgkm((qm ? 2 : 4) * (3 - ks));
-      __builtin_amdgcn_sched_barrier(0);
-      // X in the order (·,0), (·,1); Y in the order (·,1), (·,0) — the order the 8-interval schedule visits the quadrants in
-      const int n_first = qm ? 1 : 0;
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn) {
-        const int qn = nn ? 1 - n_first : n_first;
-#pragma unroll
-        for (int mm = 0; mm < 2; ++mm) acc[qm * 2 + mm][qn] = mfma32(qn ? b1f[ks] : b0f[ks], af[mm][ks], acc[qm * 2 + mm][qn]);
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#define VMCNT4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
 #define VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -488,10 +448,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   stage_half(0, 0, 0, 1, false);
   stage_half(1, 1, 0, 0, false);
   stage_half(1, 1, 1, 0, false);
-  // first tile: K-tile 0 landed (the later tiles wait at the bottom of the loop); the merged schedule reads B1 of K-tile 0 in its first segment: six of the
-  // twelve prologue DMAs must have landed instead of four
-  if constexpr (PH == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else VMCNT8();
+  VMCNT8();  // first tile: K-tile 0 landed (the later tiles wait at the bottom of the loop)
   int tix = 0;   // output tiles this workgroup has finished
   unsigned tr[3][5] = {};
 #define STAMP(k_)                                                                                                   \
@@ -542,47 +499,29 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     int t = 0;
     for (; t < nsteady; ++t) {
       const unsigned lb1 = lds_wave + ((gk + t + 1) & 1) * BUF_BYTES, lb2 = lds_wave + ((gk + t) & 1) * BUF_BYTES;
-      if constexpr (PH == 4) {
-        read_frags_x();
-        stage_fast(t + 1, lb1, 1, 1);
-        stage_fast(t + 1, lb1, 0, 1);
-        VMCNT8();
-        BAR();
-        mma_pair(0);
-        BAR();
-        read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
-        stage_fast(t + 2, lb2, 0, 0);
-        stage_fast(t + 2, lb2, 1, 0);
-        VMCNT4();
-        BAR();
-        mma_pair(1);
-        flip();
-        BAR();
-      } else {
-        read_frags(IC<0>{}, IC<0>{}, &b0f);
-        stage_fast(t + 1, lb1, 1, 1);
-        VMCNT8();
-        BAR();
-        mma_quadrant(0, 0, b0f, 3);
-        BAR();
-        read_frags(IC<-1>{}, IC<1>{}, &b1f);
-        stage_fast(t + 1, lb1, 0, 1);
-        VMCNT8();
-        BAR();
-        mma_quadrant(0, 1, b1f, 1);
-        BAR();
-        read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
-        stage_fast(t + 2, lb2, 0, 0);
-        BAR();
-        mma_quadrant(1, 1, b1f, 2);
-        BAR();
-        stage_fast(t + 2, lb2, 1, 0);
-        VMCNT8();
-        BAR();
-        mma_quadrant(1, 0, b0f, 0);
-        flip();
-        BAR();
-      }
+      read_frags(IC<0>{}, IC<0>{}, &b0f);
+      stage_fast(t + 1, lb1, 1, 1);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 0, b0f, 3);
+      BAR();
+      read_frags(IC<-1>{}, IC<1>{}, &b1f);
+      stage_fast(t + 1, lb1, 0, 1);
+      VMCNT8();
+      BAR();
+      mma_quadrant(0, 1, b1f, 1);
+      BAR();
+      read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
+      stage_fast(t + 2, lb2, 0, 0);
+      BAR();
+      mma_quadrant(1, 1, b1f, 2);
+      BAR();
+      stage_fast(t + 2, lb2, 1, 0);
+      VMCNT8();
+      BAR();
+      mma_quadrant(1, 0, b0f, 0);
+      flip();
+      BAR();
     }
     STAMP(2);
     bool switched = false;  // offsets already describe the NEXT output tile
@@ -594,30 +533,6 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       const bool n1 = t1 >= nsteps, n2 = t2 >= nsteps;
       const int k1 = n1 ? t1 - nsteps : t1, k2 = n2 ? t2 - nsteps : t2;
       const int buf1 = (gk + t1) & 1, buf2 = (gk + t2) & 1;
-      if constexpr (PH == 4) {
-        // segment X
-        read_frags_x();
-        stage_half(k1, buf1, 1, 1, n1 && !has_next);
-        stage_half(k1, buf1, 0, 1, n1 && !has_next);
-        VMCNT8();
-        BAR();
-        mma_pair(0);
-        BAR();
-        // segment Y
-        read_frags(IC<1>{}, IC<-1>{}, (s16x8_t(*)[4]) nullptr);
-        if (n2 && !switched) {  // every staging from here on belongs to the next output tile
-          if (has_next) set_offsets(m0n, n0n, probn);
-          switched = true;
-        }
-        stage_half(k2, buf2, 0, 0, n2 && !has_next);
-        stage_half(k2, buf2, 1, 0, n2 && !has_next);
-        VMCNT4();
-        BAR();
-        mma_pair(1);
-        flip();
-        BAR();
-        return;
-      }
       // phase 0
       read_frags(IC<0>{}, IC<0>{}, &b0f);
       stage_half(k1, buf1, 1, 1, n1 && !has_next);
@@ -960,7 +875,6 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   }
 #undef STAMP
 #undef VMCNT8
-#undef VMCNT4
 #undef SROW
 #undef CC
 #undef BAR
@@ -974,10 +888,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_ge_kernel(AitkGemmArgs p) {
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_ge_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, false>(p, p2); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, true>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_ge_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, false, true>(p, p); }
-// the merged-phase schedule (PH = 4) under measurement: AITK_GEMM8_PH=4
-__global__ __launch_bounds__(NT) void gemm_nt_4phase_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, 4>(p, p); }
-__global__ __launch_bounds__(NT) void gemm_nt_4phase_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, 4>(p, p2); }
-__global__ __launch_bounds__(NT) void gemm_nt_4phase_tr_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, true, 4>(p, p); }
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true, false, false>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true, false, false>(p, p2); }
@@ -1025,8 +935,7 @@ static int gemm8_cus() {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const void* kernels[] = {(const void*)gemm_nt_8phase_kernel,        (const void*)gemm_nt_8phase_grouped_kernel,    (const void*)gemm_nt_8phase_f8_kernel,
                              (const void*)gemm_nt_8phase_f8_grouped_kernel, (const void*)gemm_nt_8phase_conv_kernel,       (const void*)gemm_nt_8phase_ge_kernel,
-                             (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel,
-                             (const void*)gemm_nt_4phase_kernel,            (const void*)gemm_nt_4phase_grouped_kernel,    (const void*)gemm_nt_4phase_tr_kernel};
+                             (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel};
     for (const void* k : kernels)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_OFF + 32768) != hipSuccess) {
         n_cu = 0;
@@ -1044,11 +953,8 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else {
-    const int fe = gemm8_env("AITK_GEMM8_FE", 1), ph = gemm8_env("AITK_GEMM8_PH", 8);
-    if (ph == 4) {
-      if (gemm8_env("AITK_GEMM8_TRACE", 0)) hipLaunchKernelGGL(gemm_nt_4phase_tr_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
-      else hipLaunchKernelGGL(gemm_nt_4phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
-    } else if (gemm8_env("AITK_GEMM8_TRACE", 0)) {
+    const int fe = gemm8_env("AITK_GEMM8_FE", 1);
+    if (gemm8_env("AITK_GEMM8_TRACE", 0)) {
       if (fe) hipLaunchKernelGGL(gemm_nt_8phase_tr_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
       else hipLaunchKernelGGL(gemm_nt_8phase_tr_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
     } else if (fe) hipLaunchKernelGGL(gemm_nt_8phase_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
@@ -1071,7 +977,6 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
   if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
-  else if (gemm8_env("AITK_GEMM8_PH", 8) == 4) hipLaunchKernelGGL(gemm_nt_4phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (gemm8_env("AITK_GEMM8_FE", 1)) hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else hipLaunchKernelGGL(gemm_nt_8phase_grouped_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   return AITK_OK;

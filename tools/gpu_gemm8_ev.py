@@ -1,7 +1,7 @@
 """Epilogue forms of the persistent 8-phase GEMM (gemm8.hip; AITK_GEMM8_FE = 0: the generic epilogue only, 1: the fast forms, default): bit-exactness of the
 fast forms against the generic one over the epilogues, ragged shapes and segmented row maps, time(K) fits (fixed cost per tile round), the FLUX shapes with their
 epilogues, and the s_memtime trace of the tile switch (AITK_GEMM8_TRACE=1).  Prints JSON lines.   python tools/gpu_gemm8_ev.py [check] [sweep] [trace]
-(In the JSON keys "ev" is the variant: 0 generic epilogue, 1 fast epilogue forms, 2 fast forms + merged-phase K loop.)"""
+(In the JSON keys "ev" is the variant: 0 generic epilogue, 1 fast epilogue forms.)"""
 import ctypes as C
 import json
 import os
@@ -31,9 +31,8 @@ def timeit(fn, n=20):
 
 
 def set_ev(ev, trace=0):
-    """variant 0: generic epilogue, 8 barrier intervals per K-tile; 1: fast epilogue forms (the default build); 2: 1 + the merged-phase schedule (AITK_GEMM8_PH=4)"""
+    """variant 0: generic epilogue; 1: fast epilogue forms (the default build)"""
     os.environ["AITK_GEMM8_FE"] = "0" if ev == 0 else "1"
-    os.environ["AITK_GEMM8_PH"] = "4" if ev == 2 else "8"
     os.environ["AITK_GEMM8_TRACE"] = str(trace)
 
 
