@@ -9,6 +9,7 @@
 //   attention pre-processing:                    RMSNorm(head_dim, eps=1e-6, weight) on q,k then rotary embedding
 //                                                (order: toolkit/models/flux_sage_attn.py:36-74;
 //                                                 rotation: extensions_built_in/diffusion_models/chroma/src/math.py:47-51)
+#include <cstdlib>
 #include "common.h"
 #include "aitk_args.h"
 
@@ -169,13 +170,109 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(AitkLnModBwdArgs p) {
   }
 }
 
+// Single-pass form for C = 1024 NCW (FLUX: 3072).  The two-phase kernel above reads x and dxn twice (row means, then dx): 6 instead of 4 row streams per launch,
+// 2.85 TB/s of algorithmic traffic at 32256 x 3072.  Here a 16-row chunk belongs to the TWO waves of a 128-thread workgroup, wave w owning the 512-column chunks
+// 2 i + w of every row: a wave keeps its half of the row of x and dxn in registers (NCW 16-byte chunks per lane each), so both are read once; the two halves of the
+// row means meet through 16 bytes of LDS and one workgroup barrier per row (double-buffered by row parity); the column partials of the chunk's rows stay in registers
+// and are written as the chunk's partial exactly as before (same chunk list, same order of summation: the column sums are bit-identical, aitk_rows_per_block
+// unchanged).  A row's means are summed per-wave halves first, i.e. in a different order than above: same formulas, last-bit differences in dx (<= 1 bf16 ulp).
+// 278 -> 200 us per launch at 32256 x 3072 (3.96 TB/s; profiles/r04_rowkernels_ab.log); one wave per chunk with the whole row in registers (320 of them, one wave
+// per SIMD) reached 250 us and was dropped.
+template <int NCW>
+__global__ __launch_bounds__(128) void ln_mod_bwd_row2_kernel(AitkLnModBwdArgs p) {
+  __shared__ float st[2][2][2];  // [row parity][wave][a1, a2]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const int s0 = chunk * RPB;
+  const int nrows = min(RPB, p.S - s0);
+  const long mbase = (long)b * p.S + s0;
+  const bf16_t* sc = p.scale + (long)b * p.ld_mod;
+  const int col0 = lane * 8 + 512 * wave;
+  uint4 spk[NCW];
+  float dsh[NCW][8], dsc[NCW][8];
+#pragma unroll
+  for (int i = 0; i < NCW; ++i) {
+    spk[i] = *reinterpret_cast<const uint4*>(sc + col0 + 1024 * i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsh[i][e] = dsc[i][e] = 0.f;
+  }
+  for (int r = 0; r < nrows; ++r) {
+    const long m = mbase + r;
+    const float mean = p.mean[m], rstd = p.rstd[m];
+    uint4 xpk[NCW], gpk[NCW], rpk[NCW];
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      xpk[i] = *reinterpret_cast<const uint4*>(p.x + m * p.ldx + col0 + 1024 * i);
+      gpk[i] = *reinterpret_cast<const uint4*>(p.dxn + m * p.ld_dxn + col0 + 1024 * i);
+      if (p.dres) rpk[i] = *reinterpret_cast<const uint4*>(p.dres + m * p.ld_dres + col0 + 1024 * i);
+    }
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      float xv[8], gv[8], s8[8];
+      unpack8(xpk[i], xv);
+      unpack8(gpk[i], gv);
+      unpack8(spk[i], s8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g = gv[e] * (1.0f + s8[e]);
+        a1 += g;
+        a2 += g * (xv[e] - mean) * rstd;
+      }
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) {
+      st[r & 1][wave][0] = a1;
+      st[r & 1][wave][1] = a2;
+    }
+    __syncthreads();
+    const float c1 = (st[r & 1][0][0] + st[r & 1][1][0]) / (float)p.C, c2 = (st[r & 1][0][1] + st[r & 1][1][1]) / (float)p.C;
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      float xv[8], gv[8], s8[8], o[8];
+      unpack8(xpk[i], xv);
+      unpack8(gpk[i], gv);
+      unpack8(spk[i], s8);
+      if (p.dres) unpack8(rpk[i], o);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (xv[e] - mean) * rstd;
+        const float g = gv[e] * (1.0f + s8[e]);
+        o[e] += rstd * (g - c1 - xh * c2);
+        dsh[i][e] += gv[e];
+        dsc[i][e] += gv[e] * xh;
+      }
+      *reinterpret_cast<uint4*>(p.dx + m * p.ld_dx + col0 + 1024 * i) = pack8(o);
+    }
+  }
+  if (p.partial) {
+#pragma unroll
+    for (int i = 0; i < NCW; ++i) {
+      float* pp = p.partial + (((long)b * gridDim.x + chunk) * 2) * p.C + col0 + 1024 * i;
+      *reinterpret_cast<float4*>(pp) = make_float4(dsh[i][0], dsh[i][1], dsh[i][2], dsh[i][3]);
+      *reinterpret_cast<float4*>(pp + 4) = make_float4(dsh[i][4], dsh[i][5], dsh[i][6], dsh[i][7]);
+      *reinterpret_cast<float4*>(pp + p.C) = make_float4(dsc[i][0], dsc[i][1], dsc[i][2], dsc[i][3]);
+      *reinterpret_cast<float4*>(pp + p.C + 4) = make_float4(dsc[i][4], dsc[i][5], dsc[i][6], dsc[i][7]);
+    }
+  }
+}
+
 extern "C" int32_t aitk_rows_per_block(void) { return RPB; }
 
 extern "C" int aitk_ln_mod_bwd(const AitkLnModBwdArgs* a, aitk_stream_t stream) {
   if (!a || a->S <= 0 || a->B <= 0 || a->C <= 0 || (a->C % 8)) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ld_dxn % 8) || (a->ld_dx % 8) || (a->ld_mod % 8) || (a->dres && (a->ld_dres % 8))) return AITK_ERR_ALIGN;
   dim3 grid((a->S + RPB - 1) / RPB, a->B);
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  const bool two_phase = getenv("AITK_LN_BWD_TWO_PHASE") != nullptr;  // measurement knob: the two-phase kernel at every width
+  if (a->C == 3072 && !two_phase) hipLaunchKernelGGL(ln_mod_bwd_row2_kernel<3>, grid, dim3(128), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(ln_mod_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
@@ -272,96 +369,111 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// Work split (round 4): one WAVE per token; lane = (hq = lane >> 4: one of four consecutive heads, sub = lane & 15: the 8-column chunk), the wave walks the
+// token's heads four at a time — 1 KiB contiguous per load — and the token's cos / sin row and the norm weight are loaded once per lane instead of once per
+// (token, head).  The round-3 form gave each 16-lane group one (token, head) pair of a flat pair list: two 64-bit divisions + two modulos per 16 bytes (several
+// hundred vector instructions) and 64 B of fp32 rotary table per 16 B of data; it ran at 3.0 TB/s.  Same arithmetic per element: bit-identical.
 __global__ __launch_bounds__(256) void qkv_post_fwd_kernel(AitkQkvPostArgs p) {
   const AitkQkvJob job = p.job[blockIdx.y];
-  const int sub = threadIdx.x & 15;
-  const long pair0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const long npairs = (long)p.B * p.S_src * p.H;
-  for (long pair = pair0; pair < npairs; pair += (long)gridDim.x * 16) {
-    const int hd = (int)(pair % p.H);
-    const long tok = pair / p.H;
-    const int s = (int)(tok % p.S_src);
-    const int b = (int)(tok / p.S_src);
-    const bf16_t* src = job.src + ((long)b * p.S_src + s) * job.ld_src + hd * 128 + sub * 8;
-    bf16_t* dst = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + hd * 128 + sub * 8;
-    uint4 raw = *reinterpret_cast<const uint4*>(src);
+  const int lane = threadIdx.x & 63, sub = lane & 15, hq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntok = p.B * p.S_src;
+  float w[8];
+  if (job.weight) unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
+  for (int tok = blockIdx.x * 4 + wave; tok < ntok; tok += gridDim.x * 4) {
+    const int b = tok / p.S_src, s = tok - b * p.S_src;
+    const bf16_t* src = job.src + (long)tok * job.ld_src + sub * 8;
+    bf16_t* dst = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + sub * 8;
     if (!job.weight) {
-      *reinterpret_cast<uint4*>(dst) = raw;
+      for (int hd = hq; hd < p.H; hd += 4) *reinterpret_cast<uint4*>(dst + hd * 128) = *reinterpret_cast<const uint4*>(src + hd * 128);
       continue;
     }
-    float x[8], w[8], o[8];
-    unpack8(raw, x);
-    unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-    const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
-    const float* cs = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
-    const float* sn = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
-    float t[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = bfround(bfround(x[e] * rstd) * w[e]);
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      o[e] = t[e] * cs[e] - t[e + 1] * sn[e];
-      o[e + 1] = t[e + 1] * cs[e + 1] + t[e] * sn[e + 1];
+    float cs[8], sn[8];
+    {
+      const float* cp = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
+      const float* sp = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
+      const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+      sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
     }
-    *reinterpret_cast<uint4*>(dst) = pack8(o);
+    for (int hd = hq; hd < p.H; hd += 4) {
+      float x[8], o[8], t[8];
+      unpack8(*reinterpret_cast<const uint4*>(src + hd * 128), x);
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+      const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = bfround(bfround(x[e] * rstd) * w[e]);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        o[e] = t[e] * cs[e] - t[e + 1] * sn[e];
+        o[e + 1] = t[e + 1] * cs[e + 1] + t[e] * sn[e + 1];
+      }
+      *reinterpret_cast<uint4*>(dst + hd * 128) = pack8(o);
+    }
   }
 }
 
 // backward: src = grad wrt the joint (roped) tensor, raw = the forward input, dst = grad wrt raw
 __global__ __launch_bounds__(256) void qkv_post_bwd_kernel(AitkQkvPostArgs p) {
   const AitkQkvJob job = p.job[blockIdx.y];
-  const int sub = threadIdx.x & 15;
-  const long pair0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const long npairs = (long)p.B * p.S_src * p.H;
-  for (long pair = pair0; pair < npairs; pair += (long)gridDim.x * 16) {
-    const int hd = (int)(pair % p.H);
-    const long tok = pair / p.H;
-    const int s = (int)(tok % p.S_src);
-    const int b = (int)(tok / p.S_src);
+  const int lane = threadIdx.x & 63, sub = lane & 15, hq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntok = p.B * p.S_src;
+  float w[8];
+  if (job.weight) unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
+  for (int tok = blockIdx.x * 4 + wave; tok < ntok; tok += gridDim.x * 4) {
+    const int b = tok / p.S_src, s = tok - b * p.S_src;
     // here "dst" layout = joint grad (read), "src" layout = raw-side (write); see ops.qkv_post_bwd
-    const bf16_t* gj = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + hd * 128 + sub * 8;
-    bf16_t* graw = const_cast<bf16_t*>(job.src) + ((long)b * p.S_src + s) * job.ld_src + hd * 128 + sub * 8;
-    uint4 gv = *reinterpret_cast<const uint4*>(gj);
+    const bf16_t* gj = job.dst + ((long)b * p.S_dst + p.s_off + s) * job.ld_dst + sub * 8;
+    bf16_t* graw = const_cast<bf16_t*>(job.src) + (long)tok * job.ld_src + sub * 8;
     if (!job.weight) {
-      *reinterpret_cast<uint4*>(graw) = gv;
+      for (int hd = hq; hd < p.H; hd += 4) *reinterpret_cast<uint4*>(graw + hd * 128) = *reinterpret_cast<const uint4*>(gj + hd * 128);
       continue;
     }
-    const bf16_t* rawp = job.raw + ((long)b * p.S_src + s) * job.ld_raw + hd * 128 + sub * 8;
-    float g[8], x[8], w[8], dt[8], o[8];
-    unpack8(gv, g);
-    unpack8(*reinterpret_cast<const uint4*>(rawp), x);
-    unpack8(*reinterpret_cast<const uint4*>(job.weight + sub * 8), w);
-    const float* cs = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
-    const float* sn = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      // o_e = t_e c_e - t_{e+1} s_e ; o_{e+1} = t_{e+1} c_{e+1} + t_e s_{e+1}
-      dt[e] = g[e] * cs[e] + g[e + 1] * sn[e + 1];
-      dt[e + 1] = -g[e] * sn[e] + g[e + 1] * cs[e + 1];
+    const bf16_t* rawp = job.raw + (long)tok * job.ld_raw + sub * 8;
+    float cs[8], sn[8];
+    {
+      const float* cp = p.cos + (long)(p.s_off + s) * 128 + sub * 8;
+      const float* sp = p.sin + (long)(p.s_off + s) * 128 + sub * 8;
+      const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+      sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
     }
-    float ss = 0.f;
+    for (int hd = hq; hd < p.H; hd += 4) {
+      float g[8], x[8], dt[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(gj + hd * 128), g);
+      unpack8(*reinterpret_cast<const uint4*>(rawp + hd * 128), x);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-    const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
-    float dot = 0.f;
+      for (int e = 0; e < 8; e += 2) {
+        // o_e = t_e c_e - t_{e+1} s_e ; o_{e+1} = t_{e+1} c_{e+1} + t_e s_{e+1}
+        dt[e] = g[e] * cs[e] + g[e + 1] * sn[e + 1];
+        dt[e + 1] = -g[e] * sn[e] + g[e + 1] * cs[e + 1];
+      }
+      float ss = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      dt[e] *= w[e];              // through "* weight"
-      dot += dt[e] * x[e] * rstd; // sum_i dt1_i * xhat_i
+      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+      const float rstd = rsqrtf(group16_sum(ss) / 128.0f + p.eps);
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dt[e] *= w[e];              // through "* weight"
+        dot += dt[e] * x[e] * rstd; // sum_i dt1_i * xhat_i
+      }
+      dot = group16_sum(dot) / 128.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (dt[e] - x[e] * rstd * dot);
+      *reinterpret_cast<uint4*>(graw + hd * 128) = pack8(o);
     }
-    dot = group16_sum(dot) / 128.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = rstd * (dt[e] - x[e] * rstd * dot);
-    *reinterpret_cast<uint4*>(graw) = pack8(o);
   }
 }
 
 static int qkv_post_check(const AitkQkvPostArgs* a) {
   if (!a || a->njobs <= 0 || a->njobs > 3 || a->B <= 0 || a->H <= 0 || a->S_src <= 0) return AITK_ERR_SHAPE;
-  if (a->D != 128) return AITK_ERR_SHAPE;
+  if (a->D != 128 || (long)a->B * a->S_src > 0x7fffffffL) return AITK_ERR_SHAPE;
   for (int j = 0; j < a->njobs; ++j)
     if ((a->job[j].ld_src % 8) || (a->job[j].ld_dst % 8)) return AITK_ERR_ALIGN;
   return AITK_OK;
@@ -369,8 +481,8 @@ static int qkv_post_check(const AitkQkvPostArgs* a) {
 extern "C" int aitk_qkv_post_fwd(const AitkQkvPostArgs* a, aitk_stream_t stream) {
   int rc = qkv_post_check(a);
   if (rc) return rc;
-  const long npairs = (long)a->B * a->S_src * a->H;
-  dim3 grid((unsigned)min((npairs + 15) / 16, (long)8192), a->njobs);
+  const long ntok = (long)a->B * a->S_src;
+  dim3 grid((unsigned)min((ntok + 3) / 4, (long)16384), a->njobs);
   hipLaunchKernelGGL(qkv_post_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
@@ -378,8 +490,8 @@ extern "C" int aitk_qkv_post_fwd(const AitkQkvPostArgs* a, aitk_stream_t stream)
 extern "C" int aitk_qkv_post_bwd(const AitkQkvPostArgs* a, aitk_stream_t stream) {
   int rc = qkv_post_check(a);
   if (rc) return rc;
-  const long npairs = (long)a->B * a->S_src * a->H;
-  dim3 grid((unsigned)min((npairs + 15) / 16, (long)8192), a->njobs);
+  const long ntok = (long)a->B * a->S_src;
+  dim3 grid((unsigned)min((ntok + 3) / 4, (long)16384), a->njobs);
   hipLaunchKernelGGL(qkv_post_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
