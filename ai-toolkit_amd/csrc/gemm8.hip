@@ -657,9 +657,10 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
             if constexpr (ACC) pacc[2 * blk + it] = *reinterpret_cast<const uint4*>(c_group(g) + lofC + ni * 64);
           }
         };
+        constexpr int PFD = 2;  // blocks requested ahead (3 measured equal within noise and spills 8 registers: profiles/r04_gemm8_tile_switch.md)
         if constexpr (RD_IN || ACC) {
-          request(0);
-          request(1);
+#pragma unroll
+          for (int i = 0; i < PFD; ++i) request(i);
         }
         float b8[8], g8[8];
         int gb_loaded = -1;
@@ -677,7 +678,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): same-wave LDS ops execute in order, no barrier needed
           if constexpr (RD_IN || ACC) {
-            if (blk + 2 < 8) request(blk + 2);  // ahead of this block's stores
+            if (blk + PFD < 8) request(blk + PFD);  // ahead of this block's stores
           }
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
