@@ -214,7 +214,7 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
-ABI_VERSION = 6  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+ABI_VERSION = 7  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
 
 
 def lib():

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 6 /* 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 7 /* 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -102,6 +102,9 @@ int aitk_quant_rows_fp8(const AitkQuantRowsArgs* args, aitk_stream_t stream);
 int aitk_abi_version(void);
 /* diagnostics: s_memtime stamps around the barriers of the wave-specialised dK/dV kernel's TRACE build (AITK_ATTN_DKDV_WS=2): 64 values */
 int aitk_probe_attn_ws_trace(uint64_t* out64);
+/* diagnostics: s_memtime stamps the persistent GEMM's TRACE build (AITK_GEMM8_TRACE=1) left at its tile-switch points: 60 values = [workgroup 0 / 100][wave 0 / 4][tile 1-3]
+ * [top of the tile, after the top barrier, end of the steady K loop, end of the K loop, end of the epilogue] (tools/gpu_gemm8_ev.py trace) */
+int aitk_probe_gemm8_trace(uint32_t* out60);
 int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */
 int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
 /* Two independent problems in one call (e.g. the image- and text-stream projections of a FLUX double block:
