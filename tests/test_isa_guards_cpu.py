@@ -19,16 +19,21 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 OBJ = os.path.join(os.path.dirname(_capi.LIB_PATH), "build", "gemm8.o")
 
 
-def _disassemble(tmp_path):
-    if not os.path.exists(OBJ):
+def _code_object(tmp_path, obj=OBJ):
+    if not os.path.exists(obj):
         import __graft_entry__
 
         __graft_entry__.build()
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "gemm8.co")
-    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", OBJ, str(tmp_path / "host.o")])
+    base = os.path.basename(obj)
+    fat, co = str(tmp_path / (base + ".fat")), str(tmp_path / (base + ".co"))
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj, str(tmp_path / (base + ".host"))])
     subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                            f"--output={co}"])
-    return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+    return co
+
+
+def _disassemble(tmp_path):
+    return subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", _code_object(tmp_path)], text=True)
 
 
 @pytest.mark.skipif(not (os.path.exists(os.path.join(LLVM, "llvm-objdump")) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))),
@@ -60,3 +65,29 @@ def test_gemm8_k_loops_carry_only_the_counted_vmcnt_waits(tmp_path):
                 stretch_waits.append(int(w.group(1)))
         assert dense >= 4, (m.group(1), dense)  # the steady loop and the tail phases were found
     assert seen >= 5, seen
+
+
+# registers the hot kernels may spill (kernel-name fragment -> bound); the spills that exist sit outside the K / KV loops (epilogues, prologues)
+SPILL_BOUNDS = {
+    "gemm8.o": {"gemm_nt_8phase_kernel": 8, "gemm_nt_8phase_grouped_kernel": 8, "gemm_nt_8phase_conv_kernel": 16, "gemm_nt_8phase_ge_kernel": 0,
+                "gemm_nt_8phase_grouped_ge_kernel": 0},
+    "attention.o": {"attn_fwd_kernel": 0, "attn_bwd_dq_kernel": 0, "attn_bwd_dkdv_ws_kernel": 2, "attn_bwd_dkdv_pipe_kernel": 0, "attn_bwd_dkdv_kernel": 0},
+    "lora_skinny.o": {"lora_down16_kernel": 0, "lora_wgrad_kernel": 0},
+    "norm_elem.o": {"ln_mod_bwd_row2_kernel": 0, "qkv_post_fwd_kernel": 0, "qkv_post_bwd_kernel": 0},
+}
+
+
+@pytest.mark.skipif(not (os.path.exists(os.path.join(LLVM, "llvm-readelf")) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))),
+                    reason="needs the ROCm LLVM tools")
+def test_hot_kernels_stay_within_their_spill_bounds(tmp_path):
+    """A register spill inside a hand-scheduled loop is a silent 2x: the code-object metadata of every hot kernel is held to the spill count it has today."""
+    build_dir = os.path.dirname(OBJ)
+    for obj, bounds in SPILL_BOUNDS.items():
+        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", _code_object(tmp_path, os.path.join(build_dir, obj))], text=True)
+        kernels = re.findall(r"\.name:\s+(\S+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S)
+        assert kernels, obj
+        for frag, bound in bounds.items():
+            hits = [(n, int(c)) for n, c in kernels if frag in n]
+            assert hits, (obj, frag)
+            over = [(n, c) for n, c in hits if c > bound]
+            assert not over, (obj, over, bound)
