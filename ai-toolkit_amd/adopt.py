@@ -1,0 +1,435 @@
+"""Adoption of a LoRA network the REFERENCE built itself — the drop-in boundary without a trainer patch.
+
+The reference's trainer constructs its own `LoRASpecialNetwork` over `sd.get_model_to_train()` (jobs/process/BaseSDTrainProcess.py:1932-1978),
+moves it to the device in fp32 (1983), hands it to the model plug-in (`self.sd.network = self.network`, 1985) and calls `apply_to` (1988), which
+for every wrapped layer runs `LoRAModule.apply_to` (toolkit/lora_special.py:132-135):
+
+    self.org_forward = self.org_module[0].forward
+    self.org_module[0].forward = self.forward
+
+It then builds the optimizer over `network.prepare_optimizer_params()` (toolkit/kohya_lora.py:1030-1074), the EMA over the same Parameters
+(toolkit/ema.py) and activates the adapter with `with network:` (toolkit/network_mixins.py:849-853).  None of this can be replaced from a model
+plug-in, and the native graphs never call `Linear.forward` — so instead of asking the trainer to build another class, the fused path ADOPTS the
+objects the reference made:
+
+  * `graph.Linear.__setattr__` (and the UNet's convolution holders) see the `forward` swap and call `register_foreign_adapter`: the module that owns
+    the new forward becomes the layer's adapter (`lin.lora`), after a check that the fused graph can run it.  Anything it cannot run — LoRM,
+    full-rank / FullModule layers, `use_bias`, decomposed LoKr factors, unsupported ranks — raises HERE, at `apply_to`, never a base-only model.
+  * On the first forward of the native model (`FusedGraphBase._resolve_network`), `AdoptedNetwork` lays the flat fp32 arenas out exactly as
+    `FusedLoRANetwork.build_arena` does and RE-POINTS the storage of the reference's own Parameters at views of them (`param.data = view`,
+    `param.grad = grad view`).  Parameter identity is untouched, so the optimizer, `clip_grad_norm_`, `toolkit/ema.py`, `accelerator.prepare`,
+    `network.state_dict()` / `get_state_dict` / `save_weights` / `load_weights` / `merge_in` of the REFERENCE keep working on the same memory the
+    HIP kernels read (through the bf16 split shadows, refreshed at every adapter-active forward: the trainer has no "weights changed" hook).
+  * Activation, multipliers and dropout are read from the reference's network at launch time: `is_active` / `is_merged_in` / `_multiplier == 0`
+    (network_mixins.py:274-296), `torch_multiplier` incl. per-sample vectors (313-321), `scale`, `module.dropout / rank_dropout / module_dropout`
+    with the reference's draw order (197-239), `training`.
+  * If something replaced a Parameter's storage behind our back (`network.to(...)`, a rank-changing `load_weights`: network_mixins.py:737-775),
+    the next forward notices the pointer mismatch, copies the current values into the arena and re-points again (`AdoptedNetwork.sync`).
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+from .lora import FusedLoRANetwork, _ParamProxy
+
+# class names of the reference's adapter modules (toolkit/lora_special.py:46, toolkit/models/DoRA.py:36, toolkit/models/lokr.py:79) and of the
+# oracle's restatements of them (oracle/lora_ref.py: tests drive the adoption without importing the reference)
+_LORA_CLASSES = ("LoRAModule", "RefLoRAModule")
+_DORA_CLASSES = ("DoRAModule", "RefDoRAModule")
+_LOKR_CLASSES = ("LokrModule", "RefLokrModule")
+
+
+class AdoptionError(NotImplementedError):
+    """The reference built an adapter the fused graph cannot execute; raised where the reference attaches it (`apply_to`)."""
+
+
+def _kind(module):
+    name = module.__class__.__name__
+    if name in _LORA_CLASSES:
+        return "lora"
+    if name in _DORA_CLASSES:
+        return "dora"
+    if name in _LOKR_CLASSES:
+        return "lokr"
+    return None
+
+
+def _network_of(module):
+    ref = getattr(module, "network_ref", None)
+    net = ref() if callable(ref) else None
+    if net is None:
+        net = getattr(module, "network", None)
+        if isinstance(net, (list, tuple)):  # oracle modules keep the network in a list (out of the module tree)
+            net = net[0]
+    return net
+
+
+def check_foreign_network(net):
+    """Network-level options of a reference-built network (`sd.network = network`, BaseSDTrainProcess.py:1985) that have no fused
+    counterpart.  A FusedLoRANetwork passes untouched."""
+    if isinstance(net, FusedLoRANetwork):
+        return
+    if getattr(net, "is_lorm", False):
+        raise AdoptionError("network.type 'lorm' is not on the fused path")
+    if getattr(net, "full_rank", False) or str(getattr(net, "network_type", "lora")).lower() == "fullrank":
+        raise AdoptionError("network.type 'fullrank' is not on the fused path")
+    if getattr(net, "full_train_in_out", False):
+        raise AdoptionError("full_train_in_out retrains base layers: not on the fused path (frozen base)")
+    if len(getattr(net, "text_encoder_loras", None) or []):
+        raise AdoptionError("text-encoder adapters (train_text_encoder) are not on the fused path: text embeddings are cached")
+    cfg = getattr(net, "network_config", None)
+    if cfg is not None and getattr(cfg, "all_layers", False):
+        raise AdoptionError("network.all_layers (FullModule weights on norms / embeddings) is not on the fused path")
+    if getattr(net, "full_if_contains", None):
+        raise AdoptionError("network.full_if_contains (FullModule layers) is not on the fused path")
+
+
+def register_foreign_adapter(layer, new_forward):
+    """`layer.forward = new_forward` as issued by the reference's `apply_to`: validate the adapter module behind `new_forward` and make it the
+    layer's adapter.  Raises AdoptionError / TypeError instead of leaving a layer that would silently run base-only."""
+    owner = getattr(new_forward, "__self__", None)
+    kind = _kind(owner) if owner is not None else None
+    if kind is None:
+        raise TypeError(f"{layer.__class__.__name__}.forward cannot be replaced by {new_forward!r}: the fused graph never calls it. Only the "
+                        "reference's LoRAModule / DoRAModule / LokrModule (whose apply_to swaps forward) are adopted as adapters")
+    m = owner
+    name = getattr(m, "lora_name", "?")
+    net = _network_of(m)
+    if net is not None and getattr(net, "is_lorm", False):
+        raise AdoptionError(f"{name}: LoRM networks are not on the fused path")
+    if getattr(m, "full_rank", False):
+        raise AdoptionError(f"{name}: network.type 'fullrank' is not on the fused path")
+    is3 = bool(getattr(layer, "is_conv3x3", False))
+    if kind in ("dora", "lokr") and (is3 or getattr(layer, "is_conv1x1", False)):
+        raise AdoptionError(f"{name}: {kind} adapters on convolutions are not on the fused path (plain LoRA only)")
+    if kind in ("lora", "dora"):
+        up = getattr(m, "lora_up", None)
+        if getattr(up, "bias", None) is not None:
+            raise AdoptionError(f"{name}: use_bias adapters (LoRM) are not on the fused path")
+        if getattr(m, "lora_mid", None) is not None or hasattr(m, "scalar"):
+            raise AdoptionError(f"{name}: tucker / trainable-scalar (LoCon) adapters are not on the fused path")
+        r = int(m.lora_dim)
+        has_dropout = any(getattr(m, k, None) for k in ("dropout", "rank_dropout", "module_dropout"))
+        if isinstance(getattr(m, "dropout", None), nn.Module):
+            raise AdoptionError(f"{name}: nn.Dropout-module dropout is not on the fused path (float probabilities are)")
+        if kind == "dora" and (r > 64 or has_dropout):
+            raise AdoptionError(f"{name}: DoRA at rank {r}{' with dropout' if has_dropout else ''}: the fused path runs DoRA up to rank 64 without dropout")
+        if has_dropout and r > 64:
+            raise AdoptionError(f"{name}: dropout variants above rank 64 are not on the fused path")
+        if is3 and r > 64:
+            raise AdoptionError(f"{name}: 3x3-conv adapters above rank 64 are not on the fused path")
+        if is3 and (layer.cin_pad != layer.in_channels or layer.cout_pad != layer.out_channels):
+            raise AdoptionError(f"{name}: channel-padded convolutions (conv_in / conv_out) cannot carry an adapter on the fused path")
+    else:
+        if not hasattr(m, "lokr_w1") or hasattr(m, "lokr_w1_a") or getattr(m, "cp", False):
+            raise AdoptionError(f"{name}: LoKr with decompose_both / tucker factors is not on the fused path")
+        if getattr(m, "rank_dropout", 0) or getattr(m, "module_dropout", 0) or getattr(m, "dropout", 0):
+            raise AdoptionError(f"{name}: LoKr dropout variants are not on the fused path")
+        in_n = getattr(m, "_in_n", getattr(m, "in_n", None))
+        out_k = getattr(m, "_out_k", getattr(m, "out_k", None))
+        if in_n is None or out_k is None or in_n % 8 or out_k % 8:
+            raise AdoptionError(f"{name}: LoKr factor {out_k}x{in_n}: the kron kernel needs multiples of 8")
+    object.__setattr__(layer, "lora", m)
+    object.__setattr__(layer, "_foreign_adapter", True)
+
+
+def _graft(m, layer):
+    """Kernel-facing bookkeeping attributes of `lora.LoRAModule` / `DoRAModule` / `LoKrModule` on a module the reference constructed (plain
+    instance attributes: nothing registered, nothing that shows up in its state_dict)."""
+    kind = _kind(m)
+    put = lambda k, v: object.__setattr__(m, k, v)  # noqa: E731
+    put("is_lokr", kind == "lokr")
+    put("is_conv3x3", bool(getattr(layer, "is_conv3x3", False)))
+    put("is_conv1x1", bool(getattr(layer, "is_conv1x1", False)))
+    if m.is_conv3x3:
+        put("conv_cin", layer.in_channels)
+        put("conv_stride", layer.stride)
+        put("in_features", layer.in_channels * 9)
+        put("out_features", layer.out_channels)
+    else:
+        put("in_features", layer.in_features)
+        put("out_features", layer.out_features)
+    if kind != "dora" and "magnitude" not in m.__dict__ and "magnitude" not in m._parameters:
+        put("magnitude", None)
+    for k in ("dropout", "rank_dropout", "module_dropout"):
+        if not hasattr(m, k):
+            put(k, None)
+    if kind == "lokr":
+        put("in_m", getattr(m, "_in_m", getattr(m, "in_m", None)))
+        put("in_n", getattr(m, "_in_n", getattr(m, "in_n", None)))
+        put("out_l", getattr(m, "_out_l", getattr(m, "out_l", None)))
+        put("out_k", getattr(m, "_out_k", getattr(m, "out_k", None)))
+        put("_in", layer.in_features)
+        put("_out", layer.out_features)
+        put("lora_up", _ParamProxy(m, "lokr_w1"))
+        if m.use_w2:
+            put("lora_down", _ParamProxy(m, "lokr_w2"))
+        put("g_w2a", None)
+        put("g_w2b", None)
+        put("factor_params", lambda m=m: ([("lokr_w1", m.lokr_w1), ("lokr_w2", m.lokr_w2)] if m.use_w2 else
+                                          [("lokr_w1", m.lokr_w1), ("lokr_w2_a", m.lokr_w2_a), ("lokr_w2_b", m.lokr_w2_b)]))
+        put("composed_w2", lambda m=m: (m.lokr_w2.data if m.use_w2 else m.lokr_w2_a.data @ m.lokr_w2_b.data))
+    if kind == "dora":
+        put("c", None)
+        put("w2", None)
+        put("y_lin", None)
+        put("off_mag", -1)
+        put("g_mag", None)
+    if not hasattr(m, "org_module"):
+        put("org_module", [layer])
+    for k in ("off_down", "off_up"):
+        put(k, -1)
+    for k in ("sh_down", "sh_down_lo", "sh_downT3", "sh_downT", "sh_up", "sh_up3", "sh_upT", "sh_upT_lo", "sh_down_stack", "sh_down_dgrad",
+              "g_down", "g_up", "group"):
+        put(k, None)
+
+
+def _trainable(m):
+    if m.is_lokr:
+        return [p for _, p in m.factor_params()]
+    out = [m.lora_down.weight, m.lora_up.weight]
+    if m.magnitude is not None:
+        out.append(m.magnitude)
+    return out
+
+
+class AdoptedNetwork(FusedLoRANetwork):
+    """The kernel-facing half of `FusedLoRANetwork` (arenas, split shadows, same-input groups, dropout plans, DoRA column scales) built AROUND a
+    network object the reference constructed; everything the trainer talks to stays the reference's own object."""
+
+    _repoint = True
+
+    def __init__(self, foreign, model, ops, device=None):
+        nn.Module.__init__(self)
+        object.__setattr__(self, "_foreign", foreign)          # not a registered sub-module: its Parameters have one owner, the reference's network
+        object.__setattr__(self, "_model_ref", weakref.ref(model))
+        mods = list(foreign.get_all_modules() if hasattr(foreign, "get_all_modules") else foreign.unet_loras)
+        if len(getattr(foreign, "text_encoder_loras", None) or []):
+            raise AdoptionError("text-encoder adapters (train_text_encoder) are not on the fused path: text embeddings are cached")
+        if not mods:
+            raise AdoptionError("the network holds no adapter module")
+        layers = {id(l.lora): l for l in model.modules() if getattr(l, "_foreign_adapter", False) and getattr(l, "lora", None) is not None}
+        missing = [getattr(m, "lora_name", "?") for m in mods if id(m) not in layers]
+        if missing:
+            raise AdoptionError(f"{len(missing)} adapter module(s) of the network are not attached to a layer of the native model "
+                                f"(apply_to not called, or they wrap modules outside it): {missing[:4]}")
+        stray = [getattr(l.lora, "lora_name", "?") for l in layers.values() if id(l.lora) not in {id(m) for m in mods}]
+        if stray:
+            raise AdoptionError(f"layers of the native model carry adapters of ANOTHER network: {stray[:4]}")
+        for m in mods:
+            _graft(m, layers[id(m)])
+        kinds = {_kind(m) for m in mods}
+        if len(kinds) != 1:
+            raise AdoptionError(f"mixed adapter types in one network are not on the fused path: {sorted(kinds)}")
+        self.network_type = kinds.pop()
+        if self.network_type != "lora" and any(m.is_conv3x3 or m.is_conv1x1 for m in mods):
+            raise AdoptionError("DoRA / LoKr with convolution adapters are not on the fused path")
+        self.unet_loras = mods                                 # plain list attribute (nn.Module.__setattr__ leaves lists alone)
+        self._has_dropout = self.network_type == "lora" and any(bool(m.dropout or m.rank_dropout or m.module_dropout) for m in mods)
+        self.text_encoder_loras = []
+        self.lora_dim = int(getattr(foreign, "lora_dim", mods[0].lora_dim))
+        self.conv_lora_dim = getattr(foreign, "conv_lora_dim", None)
+        self.conv_alpha = getattr(foreign, "conv_alpha", None)
+        self.alpha = getattr(foreign, "alpha", self.lora_dim)
+        self.peft_format = bool(getattr(foreign, "peft_format", True))
+        self.is_transformer = bool(getattr(foreign, "is_transformer", True))
+        self.base_model_version = getattr(foreign, "base_model_version", None)
+        self.base_model_ref = getattr(foreign, "base_model_ref", None)
+        self.is_lorm = False
+        # the reference draws its dropout masks with torch.rand on the global generators (network_mixins.py:200, 220): same provider as
+        # FusedLoRANetwork's default
+        self.mask_provider = lambda name, kind, shape, dev: torch.rand(shape, device="cpu" if kind == "module" else dev)
+        self._arena_built = False
+        dev = device if device is not None else _trainable(mods[0])[0].device
+        if torch.device(dev).type != next(model.parameters()).device.type:
+            raise AdoptionError(f"the adapter lives on {dev} but the native model on {next(model.parameters()).device}: call "
+                                "network.force_to(device, torch.float32) first (BaseSDTrainProcess.py:1983)")
+        for m in mods:
+            for p in _trainable(m):
+                if p.dtype != torch.float32:
+                    raise AdoptionError(f"{m.lora_name}: adapter weights must be fp32 (network.force_to(device, torch.float32)), got {p.dtype}")
+        groups = model.lora_groups() if hasattr(model, "lora_groups") else None
+        self.build_arena(dev, ema=False, groups=groups)
+        self._ops = ops
+        self._expect = None
+        self._record_pointers()
+        self.refresh_shadows(ops)
+
+    # ---- state that lives on the reference's network object
+    @property
+    def foreign(self):
+        return self._foreign
+
+    @property
+    def training(self):
+        return bool(self._foreign.training)
+
+    @training.setter
+    def training(self, v):
+        pass
+
+    @property
+    def is_active(self):
+        return bool(self._foreign.is_active)
+
+    @is_active.setter
+    def is_active(self, v):
+        self._foreign.is_active = bool(v)
+
+    @property
+    def is_merged_in(self):
+        return bool(getattr(self._foreign, "is_merged_in", False))
+
+    @is_merged_in.setter
+    def is_merged_in(self, v):
+        self._foreign.is_merged_in = bool(v)
+
+    @property
+    def _multiplier(self):
+        f = self._foreign
+        v = f._multiplier if hasattr(f, "_multiplier") else (f.multiplier if hasattr(f, "multiplier") else f.torch_multiplier)
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().tolist()
+        if isinstance(v, (list, tuple)) and len(v) == 1:
+            v = v[0]
+        return v
+
+    @_multiplier.setter
+    def _multiplier(self, v):
+        self._foreign.multiplier = v
+
+    @property
+    def torch_multiplier(self):
+        tm = getattr(self._foreign, "torch_multiplier", None)
+        if tm is None:
+            v = self._multiplier
+            vals = [float(x) for x in v] if isinstance(v, (list, tuple)) else [float(v)]
+            return torch.tensor(vals, dtype=torch.float32, device=self.arena_p.device)
+        return tm.to(self.arena_p.device, torch.float32).reshape(-1)
+
+    @torch_multiplier.setter
+    def torch_multiplier(self, v):
+        pass  # FusedLoRANetwork._update_torch_multiplier: the reference's own tensor is the source
+
+    def _update_torch_multiplier(self):
+        pass
+
+    @property
+    def dropout(self):
+        return getattr(self._foreign, "dropout", None)
+
+    @property
+    def rank_dropout(self):
+        return getattr(self._foreign, "rank_dropout", None)
+
+    @property
+    def module_dropout(self):
+        return getattr(self._foreign, "module_dropout", None)
+
+    @property
+    def has_dropout(self):
+        return self._has_dropout
+
+    # ---- Parameter <-> arena aliasing
+    def _record_pointers(self):
+        self._expect = [(p, p.data_ptr()) for m in self.unet_loras for p in _trainable(m)]
+
+    def aliasing_intact(self):
+        return all(p.data_ptr() == ptr for p, ptr in self._expect)
+
+    def sync(self, refresh=True):
+        """Called at every forward of the native model.  Re-adopts Parameters whose storage was replaced since the arena was built (a
+        `.to()`, a rank-changing `load_weights`) and — with the adapter active — refreshes the bf16 split shadows (and DoRA's column scales)
+        from the fp32 arena: the reference's optimizer / EMA / load_state_dict write the Parameters without telling anyone."""
+        if not self.aliasing_intact():
+            dev = self.arena_p.device
+            with torch.no_grad():
+                for m in self.unet_loras:
+                    for p in _trainable(m):
+                        if p.device != dev or p.dtype != torch.float32:
+                            raise AdoptionError(f"{m.lora_name}: adapter moved to {p.device}/{p.dtype}; the fused path needs it on {dev} in fp32")
+            # same module set, possibly new shapes: rebuild (values are taken from the Parameters as they are now)
+            grads = [(p, None if p.grad is None else p.grad.detach().clone()) for p, _ in self._expect]
+            model = self._model_ref()
+            self.build_arena(dev, ema=False, groups=model.lora_groups() if hasattr(model, "lora_groups") else None)
+            with torch.no_grad():
+                for p, g in grads:
+                    if g is not None and g.shape == p.grad.shape:
+                        p.grad.copy_(g)
+            self._record_pointers()
+        if refresh:
+            self.refresh_shadows(self._ops)
+
+    def grads_dropped(self):
+        return self._expect[0][0].grad is None
+
+    def parameters(self, recurse=True):
+        for p, _ in self._expect:
+            yield p
+
+    def attach_grad_views(self):
+        super().attach_grad_views()
+        # a Parameter whose .grad the trainer replaced by its own tensor (not a view of the arena) would swallow the kernels' output
+        for m in self.unet_loras:
+            if m.is_lokr:
+                continue
+            for par, which in ((m.lora_down.weight, "down"), (m.lora_up.weight, "up")):
+                want = self.arena_view(self.arena_g, m, which)
+                if par.grad.data_ptr() != want.data_ptr():
+                    with torch.no_grad():
+                        want.copy_(par.grad.reshape(want.shape))
+                    par.grad = self._shaped_like(par, want)
+
+    # ---- the reference's own object does the I/O: these are here so that code written against FusedLoRANetwork keeps working
+    def get_state_dict(self, *a, **k):
+        return self._foreign.get_state_dict(*a, **k)
+
+    def save_weights(self, *a, **k):
+        return self._foreign.save_weights(*a, **k)
+
+    def load_weights(self, *a, **k):
+        out = self._foreign.load_weights(*a, **k)
+        self.sync()
+        return out
+
+    def prepare_optimizer_params(self, *a, **k):
+        return self._foreign.prepare_optimizer_params(*a, **k)
+
+    def __enter__(self):
+        self._foreign.__enter__()
+
+    def __exit__(self, *a):
+        self._foreign.__exit__(*a)
+
+
+def foreign_network_of(model):
+    """The reference-built network whose adapters are attached to layers of `model` (None: no foreign adapter attached).  The layer that
+    answered last time is asked first, so the steady-state cost is one attribute walk."""
+    probe = model.__dict__.get("_foreign_probe")
+    layers = [probe] if probe is not None and getattr(probe, "_foreign_adapter", False) and probe.lora is not None else model.modules()
+    for l in layers:
+        if getattr(l, "_foreign_adapter", False) and getattr(l, "lora", None) is not None:
+            net = _network_of(l.lora)
+            if net is None:
+                raise AdoptionError(f"{getattr(l.lora, 'lora_name', '?')}: the adapter's network is gone (weak reference dead)")
+            object.__setattr__(model, "_foreign_probe", l)
+            return net
+    return None
+
+
+def resolve_network(model):
+    """The network object the explicit graph consults for this forward: a FusedLoRANetwork attached with `attach_network`, or the
+    AdoptedNetwork around the reference's own network (built on first use, synced on every use)."""
+    net = model.__dict__.get("network")
+    if net is not None and not isinstance(net, AdoptedNetwork):
+        return net
+    foreign = foreign_network_of(model)
+    if foreign is None:
+        return net
+    if net is None or net.foreign is not foreign:
+        net = AdoptedNetwork(foreign, model, model.ops)
+        model.attach_network(net)
+        return net  # shadows are fresh
+    net.sync(refresh=net.is_active)
+    return net

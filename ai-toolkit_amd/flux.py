@@ -233,6 +233,7 @@ class FluxTransformer2DModel(FusedGraphBase):
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids, guidance,
                 return_dict=False, **kwargs):
+        self._resolve_network()  # adopts / syncs a network the reference built itself (adopt.py)
         pred = self.forward_native(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
                                    guidance, save_for_backward=torch.is_grad_enabled())
         if torch.is_grad_enabled() and self.network is not None and self.network.is_active:

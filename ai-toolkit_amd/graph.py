@@ -27,9 +27,34 @@ class Linear(nn.Module):
         self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
         self._dgroup = None   # (W^T_cat [in, sum(out)], column offset, ids of the group's Linears) when laid out with its same-input group
         self.qweight = self.qweight_t = self.wscale = None  # weight-only fp8 base (quantize_base_fp8)
+        self.register_load_state_dict_post_hook(_linear_weights_loaded)
 
     def forward(self, x):
         raise RuntimeError("fused path: Linear is executed inside the model's explicit graph (forward_native)")
+
+    def __setattr__(self, name, value):
+        # The reference attaches an adapter by swapping the wrapped layer's forward (`LoRAModule.apply_to`, toolkit/lora_special.py:132-135:
+        # `self.org_forward = org.forward; org.forward = self.forward`).  The explicit graph never calls Linear.forward, so the assignment is
+        # taken as what it means: the module that owns the new forward becomes this layer's adapter (adopt.register_foreign_adapter validates it
+        # and raises for anything the fused graph cannot run — never a silent base-only model).
+        if name == "forward":
+            from .adopt import register_foreign_adapter
+
+            register_foreign_adapter(self, value)
+            return
+        super().__setattr__(name, value)
+
+
+def _linear_weights_loaded(module, incompatible_keys):
+    """`load_state_dict` on a prepared layer (the reference's `merge_in` writes the merged weight back this way, toolkit/network_mixins.py:
+    452-462): the transposed copy the data-gradient GEMM reads follows the new weight."""
+    if getattr(module, "qweight", None) is not None:
+        raise NotImplementedError("load_state_dict into a weight-only fp8 Linear: merge through FusedLoRANetwork.merge_in (re-quantises), "
+                                  "or reload the base model")
+    wt = getattr(module, "weight_t", None)
+    if wt is not None:
+        with torch.no_grad():
+            wt.copy_(module.weight.data.t())
 
 
 class RMSNormW(nn.Module):
@@ -114,6 +139,14 @@ class FusedGraphBase(nn.Module):
             if getattr(m, "is_lokr", False) or getattr(m, "magnitude", None) is not None:
                 raise NotImplementedError(f"W8A8 fp8 base (mfma=True) with a {'LoKr' if getattr(m, 'is_lokr', False) else 'DoRA'} adapter "
                                           f"({m.lora_name}): use the weight-only fp8 base (mfma=False) or a bf16 base")
+
+    def _resolve_network(self):
+        """The adapter network of this forward: the FusedLoRANetwork attached with attach_network, or — when the reference's trainer built its
+        own LoRASpecialNetwork over this model and called apply_to (jobs/process/BaseSDTrainProcess.py:1949-1993) — the AdoptedNetwork around
+        it (adopt.py: arena re-pointing on first use, pointer check + shadow refresh on every use)."""
+        from .adopt import resolve_network
+
+        return resolve_network(self)
 
     def _token_linears(self):
         raise NotImplementedError

@@ -383,6 +383,28 @@ class FusedLoRANetwork(nn.Module):
         for lora in self.get_all_modules():
             lora.apply_to()
 
+    # False: every adapter matrix becomes a NEW nn.Parameter viewing the arena (a network this class built itself).  True (adopt.AdoptedNetwork):
+    # the existing Parameter objects are kept and only their storage is re-pointed (`.data = view`), because the reference's trainer already
+    # holds them (optimizer param groups, EMA, accelerate) when the arena is built; Conv2d-shaped weights ([r, in, k, k] / [out, r, 1, 1]) view
+    # the same [rank_pad, in*k*k] / [out, rank_pad] blocks.
+    _repoint = False
+
+    def _bind(self, holder, attr, view, gview):
+        if not self._repoint:
+            par = nn.Parameter(view, requires_grad=True)
+            setattr(holder, attr, par)
+            par.grad = gview
+            return par
+        par = getattr(holder, attr)
+        if par.dim() == 4:
+            if par.shape[2:] == (1, 1):
+                view, gview = view[:, :, None, None], gview[:, :, None, None]
+            else:
+                view, gview = view.view(par.shape), gview.view(par.shape)
+        par.data = view
+        par.grad = gview
+        return par
+
     def build_arena(self, device, ema: bool = False, groups=None, shadow_dtype=None):
         """Move every adapter matrix into flat fp32 arenas on `device` (reference: network.force_to(device, fp32),
         jobs/process/BaseSDTrainProcess.py:1982-1983) and create grad / Adam / EMA / bf16-shadow arenas.
@@ -405,7 +427,7 @@ class FusedLoRANetwork(nn.Module):
             w = (m.lora_down if which == "down" else m.lora_up).weight
             if m.is_lokr:
                 return tuple(w.shape)
-            return (m.rank_pad, w.shape[1]) if which == "down" else (w.shape[0], m.rank_pad)
+            return (m.rank_pad, w.shape[1:].numel()) if which == "down" else (w.shape[0], m.rank_pad)
 
         groups = [g for g in (groups or []) if sum(x.rank_pad for x in g) <= 64]
         n = sum(block_shape(m, "down")[0] * block_shape(m, "down")[1] + block_shape(m, "up")[0] * block_shape(m, "up")[1] for m in mods)
@@ -481,9 +503,7 @@ class FusedLoRANetwork(nn.Module):
                 for name, o, shape in (("lokr_w2_a", off, (m.out_k, r)), ("lokr_w2_b", off + na, (r, m.in_n))):
                     view = self.arena_p[o:o + shape[0] * shape[1]].view(*shape)
                     view.copy_(getattr(m, name).data)
-                    par = nn.Parameter(view, requires_grad=True)
-                    par.grad = self.arena_g[o:o + shape[0] * shape[1]].view(*shape)
-                    setattr(m, name, par)
+                    self._bind(m, name, view, self.arena_g[o:o + shape[0] * shape[1]].view(*shape))
                 m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
                 scnt = m.out_k * m.in_n
                 d0, sh = take("hi", scnt, (m.out_k, m.in_n))
@@ -496,12 +516,12 @@ class FusedLoRANetwork(nn.Module):
                 continue
             lin = m.lora_down if which == "down" else m.lora_up
             w = lin.weight.data
+            w = w.reshape(w.shape[0], -1)  # Conv2d-shaped adapter weights of an adopted network: the [r, in*k*k] / [out, r] matrix
             block = self.arena_p[off:off + cnt].view(rows, cols)
             view = block[: w.shape[0], : w.shape[1]]  # logical matrix: leading rows (down) / leading columns (up) of the block
             view.copy_(w)
-            lin.weight = nn.Parameter(view, requires_grad=True)
             gblock = self.arena_g[off:off + cnt].view(rows, cols)
-            lin.weight.grad = gblock[: w.shape[0], : w.shape[1]]
+            self._bind(lin, "weight", view, gblock[: w.shape[0], : w.shape[1]])
             if m.is_lokr:
                 d0, sh = take("hi", cnt, (rows, cols))
                 d1, shT = take("t3", cnt, (cols, rows))
@@ -551,9 +571,8 @@ class FusedLoRANetwork(nn.Module):
             cnt = m.magnitude.numel()
             view = self.arena_p[off:off + cnt]
             view.copy_(m.magnitude.data)
-            m.magnitude = nn.Parameter(view, requires_grad=True)
             m.g_mag = self.arena_g[off:off + cnt]
-            m.magnitude.grad = m.g_mag
+            self._bind(m, "magnitude", view, m.g_mag)
             m.off_mag = off
             m.c = torch.ones(cnt, dtype=torch.float32, device=device)
             w = m.org_module[0].weight.data
@@ -562,7 +581,8 @@ class FusedLoRANetwork(nn.Module):
         for m in mods:
             if hasattr(m, "alpha"):
                 m.alpha = m.alpha.to(device)
-            m._runtime_scale = m._runtime_scale.to(device)
+            if getattr(m, "_runtime_scale", None) is not None:
+                m._runtime_scale = m._runtime_scale.to(device)
             m.group = None
         self.groups = []
         for grp in groups or []:
@@ -604,7 +624,14 @@ class FusedLoRANetwork(nn.Module):
         if padded:
             return block
         w = (m.lora_down if which == "down" else m.lora_up).weight
-        return block[: w.shape[0], : w.shape[1]]
+        return block[: w.shape[0], : w.shape[1:].numel()]
+
+    @staticmethod
+    def _shaped_like(par, view2d):
+        """a 2-D arena view in the shape of the Parameter it backs (Conv2d-shaped adapter weights of an adopted network)"""
+        if par.dim() != 4:
+            return view2d
+        return view2d[:, :, None, None] if par.shape[2:] == (1, 1) else view2d.view(par.shape)
 
     def refresh_shadows(self, ops):
         """bf16 shadows (split hi + lo, every layout the kernels read) of every adapter matrix; call after each optimizer step /
@@ -689,9 +716,9 @@ class FusedLoRANetwork(nn.Module):
                 m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
                 continue
             if m.lora_down.weight.grad is None:
-                m.lora_down.weight.grad = self.arena_view(self.arena_g, m, "down")
+                m.lora_down.weight.grad = self._shaped_like(m.lora_down.weight, self.arena_view(self.arena_g, m, "down"))
             if m.lora_up.weight.grad is None:
-                m.lora_up.weight.grad = self.arena_view(self.arena_g, m, "up")
+                m.lora_up.weight.grad = self._shaped_like(m.lora_up.weight, self.arena_view(self.arena_g, m, "up"))
             if m.magnitude is not None and m.magnitude.grad is None:
                 m.magnitude.grad = m.g_mag
 
@@ -809,16 +836,20 @@ class FusedLoRANetwork(nn.Module):
                     sd[f"{base}.{key}"] = w.clone().contiguous().to("cpu").to(dtype)
                 sd[f"{base}.alpha"] = m.alpha.detach().clone().to("cpu").to(dtype)
                 continue
-            for key, lin, which in (("lora_A", m.lora_down, "down"), ("lora_B", m.lora_up, "up")):
-                w = lin.weight.detach()
-                if src is not None:
-                    w = self.arena_view(src, m, which)
-                sd[f"{base}.{key}.weight"] = w.clone().contiguous().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
+            order = (("lora_A", m.lora_down, "down"), ("lora_B", m.lora_up, "up"))
             if m.magnitude is not None:
+                # DoRAModule.state_dict() order: its own Parameter first, then the sub-modules in creation order (lora_up before lora_down,
+                # toolkit/models/DoRA.py:84-98)
                 w = m.magnitude.detach()
                 if src is not None:
                     w = src[m.off_mag:m.off_mag + w.numel()]
                 sd[f"{base}.magnitude"] = w.clone().to("cpu").to(dtype)
+                order = order[::-1]
+            for key, lin, which in order:
+                w = lin.weight.detach()
+                if src is not None:
+                    w = self.arena_view(src, m, which)
+                sd[f"{base}.{key}.weight"] = w.clone().contiguous().to("cpu").to(dtype)  # alpha dropped in PEFT format (607-624)
         if extra_state_dict is not None:
             for k, v in extra_state_dict.items():
                 sd[k] = v.detach().clone().to("cpu").to(dtype)

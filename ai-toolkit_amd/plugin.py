@@ -77,6 +77,15 @@ class _PluginBase:
         self.pipeline = None
         self.network = None
         self.is_loaded = model is not None
+        # As a real plug-in (integration/extensions/aitk_mi355) BaseModel.__init__ has run before this constructor and left INSTANCE attributes
+        # is_flow_matching = is_transformer = False, use_old_lokr_format = True (toolkit/models/base_model.py:158-185) that shadow the class
+        # attributes above.  The trainer reads them off the instance: is_transformer decides PEFT format and the `transformer` key prefix of the
+        # LoRA network (BaseSDTrainProcess.py:1976, toolkit/lora_special.py:423, 466), is_flow_matching the timestep / noise branches
+        # (BaseSDTrainProcess.py:1699, 1730), use_old_lokr_format the LoKr file layout (lora_special.py:412-416).
+        cls = type(self)
+        self.is_flow_matching = bool(cls.is_flow_matching)
+        self.is_transformer = bool(cls.is_transformer)
+        self.use_old_lokr_format = bool(cls.use_old_lokr_format)
 
     # ---- "must be implemented in child classes" hooks (base_model.py:306-360)
     _component = None            # diffusers sub-folder of the denoiser ('transformer')
@@ -148,22 +157,46 @@ class _PluginBase:
     def get_model_to_train(self):
         return self.model
 
+    # the reference reads AND assigns the denoiser through these aliases (toolkit/models/base_model.py:199-224; `self.sd.unet =
+    # self.accelerator.prepare(self.sd.unet)`, jobs/process/BaseSDTrainProcess.py:751)
     @property
     def transformer(self):
         return self.model
 
-    @property
-    def model_unwrapped(self):
-        return self.model
+    @transformer.setter
+    def transformer(self, value):
+        self.model = value
 
-    # the reference reads the denoiser through these aliases (toolkit/models/base_model.py:199-216)
     @property
     def unet(self):
         return self.model
 
+    @unet.setter
+    def unet(self, value):
+        self.model = value
+
+    @property
+    def model_unwrapped(self):
+        return getattr(self.model, "module", self.model) if self.model.__class__.__name__ == "DistributedDataParallel" else self.model
+
     @property
     def unet_unwrapped(self):
-        return self.model
+        return self.model_unwrapped
+
+    # `self.sd.network = self.network` (BaseSDTrainProcess.py:1985): a network the reference built itself is checked here for the options the
+    # fused graph cannot honour (network level; each module is checked when apply_to attaches it, adopt.register_foreign_adapter), so a
+    # config outside the accelerated path fails at set-up, not as a base-only model in the first step
+    @property
+    def network(self):
+        return self.__dict__.get("_network")
+
+    @network.setter
+    def network(self, value):
+        if value is not None:
+            from .adopt import check_foreign_network
+
+            check_foreign_network(value)
+        self.__dict__["_network"] = value
 
     def get_model_has_grad(self):
         return False  # frozen base: only the adapter trains

@@ -807,6 +807,7 @@ class UNet2DConditionModel(FusedGraphBase):
     # legacy UNet call sites read `.sample` from the result (toolkit/stable_diffusion_model.py:2049-2055, 2260-2265): return_dict=True (the
     # diffusers default) returns a tuple that also carries `.sample`; return_dict=False the plain tuple.
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, return_dict=True, **kwargs):
+        self._resolve_network()  # adopts / syncs a network the reference built itself (adopt.py)
         B, Cc, H, W = sample.shape
         x = torch.zeros(B * H * W, 8, dtype=self.dt, device=sample.device)
         x[:, :Cc] = sample.to(self.dt).permute(0, 2, 3, 1).reshape(B * H * W, Cc)

@@ -183,6 +183,7 @@ class WanTransformer3DModel(FusedGraphBase):
 
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, timestep, encoder_hidden_states, return_dict=False, **kwargs):
+        self._resolve_network()  # adopts / syncs a network the reference built itself (adopt.py)
         B, C, Fr, Hh, W = hidden_states.shape
         grid = (Fr, Hh // 2, W // 2)
         tokens = self.pack_tokens(hidden_states.to(self.dt)).contiguous()

@@ -232,9 +232,50 @@ class RefLoRANetwork(nn.Module):
     def multiplier_is_zero(self):
         return bool((self.torch_multiplier == 0).all())
 
-    def apply_to(self):
+    def apply_to(self, text_encoder=None, unet=None, apply_text_encoder=True, apply_unet=True):
+        """toolkit/kohya_lora.py:952-965 (every module's apply_to swaps its layer's forward)"""
         for lo in self.unet_loras:
             lo.apply_to()
+
+    # ---- the rest of the surface the reference's trainer touches (toolkit/network_mixins.py:791-883, toolkit/kohya_lora.py:1030-1074),
+    # restated so that tests can walk the trainer's sequence (BaseSDTrainProcess.py:1949-2039) without importing the reference
+    is_merged_in = False
+    is_lorm = False
+    text_encoder_loras = ()
+
+    @property
+    def multiplier(self):
+        m = self.torch_multiplier.tolist()
+        return m[0] if len(m) == 1 else m
+
+    @multiplier.setter
+    def multiplier(self, value):
+        vals = [float(v) for v in value] if isinstance(value, (list, tuple)) else (value.flatten().tolist() if isinstance(value, torch.Tensor) else [float(value)])
+        self.torch_multiplier = torch.tensor(vals, dtype=torch.float32, device=self.torch_multiplier.device)
+
+    def _update_torch_multiplier(self):
+        dev = next(self.unet_loras[0].parameters()).device
+        self.torch_multiplier = self.torch_multiplier.to(dev, torch.float32)
+
+    def get_all_modules(self):
+        return list(self.unet_loras)
+
+    def force_to(self, device, dtype):
+        self.to(device, dtype)
+        for lo in self.unet_loras:
+            lo.to(device, dtype)
+
+    def prepare_grad_etc(self, *a, **k):
+        self.requires_grad_(True)
+
+    def prepare_optimizer_params(self, text_encoder_lr=None, unet_lr=None, default_lr=None):
+        params = []
+        for lo in self.unet_loras:
+            params.extend(lo.parameters())
+        group = {"params": params}
+        if unet_lr is not None:
+            group["lr"] = unet_lr
+        return [group]
 
     def __enter__(self):
         self.is_active = True

@@ -957,10 +957,182 @@ def golden_plugin_registration():
             hooks[h] = owner
         out["classes"].append({"name": cls.__name__, "arch": cls.arch, "is_BaseModel_subclass": issubclass(cls, BaseModel),
                                "selected_by_get_model_class": picked is cls, "mro": [k.__name__ for k in cls.__mro__],
-                               "constructed": type(obj).__name__, "torch_dtype": str(obj.torch_dtype), "hook_owner": hooks})
+                               "constructed": type(obj).__name__, "torch_dtype": str(obj.torch_dtype), "hook_owner": hooks,
+                               # read off the INSTANCE, after BaseModel.__init__ (which resets them, base_model.py:158-185) and the mirror's
+                               # constructor: what BaseSDTrainProcess.py:1976 / 1699 / 1730 and lora_special.py:412-423 actually see
+                               "instance_flags": {"is_flow_matching": bool(obj.is_flow_matching), "is_transformer": bool(obj.is_transformer),
+                                                  "use_old_lokr_format": bool(obj.use_old_lokr_format)}})
     with open(os.path.join(HERE, "plugin_registration.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("plugin_registration.json:", [(c["name"], c["is_BaseModel_subclass"], c["selected_by_get_model_class"]) for c in out["classes"]])
+
+
+ADOPT_CFG = dict(in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2,
+                 joint_attention_dim=64, pooled_projection_dim=32)
+
+
+def adoption_batches(n, seed=9, B=2, Hl=8, Wl=4, n_txt=6):
+    """the synthetic batches of the adoption run (shared with tests/test_adoption_cpu.py, which imports this function's twin)"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        lat = torch.randn(B, 16, Hl, Wl, generator=g)
+        emb = torch.randn(B, n_txt, ADOPT_CFG["joint_attention_dim"], generator=g) * 0.5
+        pooled = torch.randn(B, ADOPT_CFG["pooled_projection_dim"], generator=g) * 0.5
+        target = torch.randn(B, 16, Hl, Wl, generator=g)
+        out.append((lat, emb, pooled, torch.tensor([700.0, 250.0]), target))
+    return out
+
+
+def golden_adoption(out_dir=None):
+    """THE boundary test vector: the reference's OWN trainer sequence (jobs/process/BaseSDTrainProcess.py:1932-2007 network construction with
+    its literal keyword set, force_to, `sd.network = network`, apply_to, prepare_grad_etc, prepare_optimizer_params; then
+    extensions_built_in/sd_trainer/SDTrainer.py:2243-2293: zero_grad, `with network:` prediction through the plug-in, mse, backward,
+    clip_grad_norm_, torch.optim.AdamW(eps=1e-6), toolkit/ema.py ExponentialMovingAverage) executed with the reference's own
+    LoRASpecialNetwork / LoRAModule / DoRAModule / LokrModule / ExponentialMovingAverage classes over the REAL plug-in class of
+    integration/extensions/aitk_mi355 wrapping a native FluxTransformer2DModel (oracle kernel table, fp32, CPU).  Nothing of the
+    reference is patched: the native model adopts the network the reference built (ai_toolkit_amd/adopt.py).  Recorded: per-step losses, the
+    gradients of the last step, final parameters, EMA shadows, the state dict the reference's get_state_dict returns and the file its
+    save_weights writes (model hash).  tests/test_adoption_cpu.py holds a FusedLoRANetwork twin to these bit for bit."""
+    import importlib.util
+    import tempfile
+    from collections import OrderedDict
+    from types import SimpleNamespace
+
+    from safetensors import safe_open
+
+    ref_shims.install_stub_finder(("controlnet_aux", "PIL", "imageio", "librosa", "soundfile", "pytorch_wavelets", "torchdiffeq", "gguf",
+                                   "huggingface_hub", "accelerate", "flatten_json", "pytorch_fid", "clip", "scipy", "tqdm", "yaml",
+                                   "ftfy", "sentencepiece", "omegaconf", "moviepy", "decord"))
+    import types
+
+    sys.modules.setdefault("info", types.SimpleNamespace(software_meta={"name": "ai-toolkit"}))
+    from toolkit.config_modules import ModelConfig, NetworkConfig
+    from toolkit.ema import ExponentialMovingAverage
+    from toolkit.lora_special import LoRASpecialNetwork
+
+    from ai_toolkit_amd.adopt import AdoptedNetwork, AdoptionError
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from oracle import ref_ops
+
+    spec = importlib.util.spec_from_file_location("aitk_mi355_ext", os.path.join(ROOT, "integration", "extensions", "aitk_mi355", "__init__.py"))
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+
+    def plugin():
+        torch.manual_seed(0)
+        ref = flux_ref.FluxTransformer2DModel(**ADOPT_CFG)
+        flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+        nat = FluxTransformer2DModel(**ADOPT_CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+        nat.load_state_dict(ref.state_dict(), strict=True)
+        nat.prepare()
+        cfg = ModelConfig(name_or_path="/nonexistent", arch="flux_mi355")
+        return cfg, ext.Flux1MI355("cpu", cfg, dtype="fp32", model=nat), nat
+
+    def build_network(cfg, sd, ncfg, **over):
+        """jobs/process/BaseSDTrainProcess.py:1932-1978, keyword for keyword"""
+        network_kwargs = dict(ncfg.network_kwargs)
+        is_lorm = ncfg.type.lower() == "lorm"
+        if hasattr(sd, "target_lora_modules"):
+            network_kwargs["target_lin_modules"] = sd.target_lora_modules
+        kw = dict(text_encoder=None, unet=sd.get_model_to_train(), lora_dim=ncfg.linear, multiplier=1.0, alpha=ncfg.linear_alpha, train_unet=True,
+                  train_text_encoder=False, conv_lora_dim=ncfg.conv, conv_alpha=ncfg.conv_alpha, is_sdxl=cfg.is_xl or cfg.is_ssd, is_v2=cfg.is_v2,
+                  is_v3=cfg.is_v3, is_pixart=cfg.is_pixart, is_auraflow=cfg.is_auraflow, is_flux=cfg.is_flux, is_lumina2=cfg.is_lumina2,
+                  is_ssd=cfg.is_ssd, is_vega=cfg.is_vega, dropout=ncfg.dropout, use_text_encoder_1=cfg.use_text_encoder_1,
+                  use_text_encoder_2=cfg.use_text_encoder_2, use_bias=is_lorm, is_lorm=is_lorm, network_config=ncfg, network_type=ncfg.type,
+                  transformer_only=ncfg.transformer_only, is_transformer=sd.is_transformer, base_model=sd, **network_kwargs)
+        kw.update(over)
+        return LoRASpecialNetwork(**kw)
+
+    def run(tag, ncfg, steps, out, multiplier=None, warm=False):
+        cfg, sd, nat = plugin()
+        assert sd.is_transformer and sd.is_flow_matching and not sd.use_old_lokr_format
+        torch.manual_seed(99)
+        net = build_network(cfg, sd, ncfg)
+        net.force_to(torch.device("cpu"), dtype=torch.float32)   # 1983
+        sd.network = net                                         # 1985
+        net._update_torch_multiplier()                           # 1986
+        net.apply_to(None, sd.unet, False, True)                 # 1988-1993
+        net.prepare_grad_etc(None, sd.unet)                      # 2021
+        if warm:  # non-zero lora_up / w2 so that every gradient family is exercised from step 1 (load_state_dict: in place, like a resume)
+            g = torch.Generator().manual_seed(7)
+            warm_sd = {k: (torch.randn(v.shape, generator=g) * 0.05 if ("lora_up" in k or "lokr_w2" in k) else v.clone())
+                       for k, v in net.state_dict().items()}
+            net.load_state_dict(warm_sd)
+        params = net.prepare_optimizer_params(text_encoder_lr=1e-3, unet_lr=1e-3, default_lr=1e-3)  # 2027-2039
+        plist = [p for grp in params for p in grp["params"]]
+        opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)  # toolkit/optimizer.py:78-79
+        ema = ExponentialMovingAverage(plist, decay=0.99)                       # BaseSDTrainProcess.py:798-803
+        if multiplier is not None:
+            net.multiplier = multiplier
+        losses = []
+        for k, (lat, emb, pooled, ts, target) in enumerate(adoption_batches(steps)):
+            pe = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled)
+            opt.zero_grad()
+            with net:
+                pred = sd.get_noise_prediction(lat, ts, pe, guidance_embedding_scale=1.0, bypass_guidance_embedding=False)
+                loss = torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3]).mean()
+                loss.backward()
+            if k == steps - 1:
+                for i, p in enumerate(plist):
+                    out[f"{tag}/last_grad/{i}"] = p.grad.detach().clone()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            ema.update()
+            losses.append(loss.detach().clone())
+        assert isinstance(nat.network, AdoptedNetwork) and nat.network.foreign is net and nat.network.aliasing_intact()
+        out[f"{tag}/losses"] = torch.stack(losses)
+        for i, p in enumerate(plist):
+            out[f"{tag}/param/{i}"] = p.detach().clone()
+            out[f"{tag}/ema/{i}"] = ema.shadow_params[i].detach().clone()
+        sdict = net.get_state_dict(dtype=torch.float32)
+        for k2, v in sdict.items():
+            out[f"{tag}/saved/{k2}"] = v.clone()
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "lora.safetensors")
+            net.save_weights(f, dtype=torch.float16, metadata=OrderedDict(name="adoption", step=str(steps), format="pt"))
+            with safe_open(f, "pt") as fh:
+                fmeta = dict(fh.metadata())
+                fkeys = list(fh.keys())
+        # the adapter-inactive prediction == base model (no_grad: sampling / prior prediction path)
+        lat, emb, pooled, ts, _ = adoption_batches(1, seed=21)[0]
+        with torch.no_grad():
+            out[f"{tag}/pred_inactive"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
+            with net:
+                out[f"{tag}/pred_active"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
+        return {"names": [m.lora_name for m in net.unet_loras], "saved_keys": list(sdict.keys()), "n_params": len(plist),
+                "file_keys": fkeys, "sshs_model_hash": fmeta.get("sshs_model_hash"), "sshs_legacy_hash": fmeta.get("sshs_legacy_hash"),
+                "peft_format": bool(net.peft_format), "module_class": type(net.unet_loras[0]).__name__, "steps": steps}
+
+    out, meta = {}, {}
+    meta["lora"] = run("lora", NetworkConfig(type="lora", linear=8, linear_alpha=8, transformer_only=True), 3, out)
+    meta["lora_mvec"] = run("lora_mvec", NetworkConfig(type="lora", linear=4, linear_alpha=4), 2, out, multiplier=[0.5, -1.5], warm=True)
+    meta["dora"] = run("dora", NetworkConfig(type="dora", linear=4, linear_alpha=4), 2, out, warm=True)
+    meta["lokr"] = run("lokr", NetworkConfig(type="lokr", lokr_full_rank=True, lokr_factor=-1), 2, out, warm=True)
+    meta["lokr_lowrank"] = run("lokr_lowrank", NetworkConfig(type="lokr", lokr_full_rank=False, linear=4, linear_alpha=4, lokr_factor=-1), 2, out, warm=True)
+
+    # what cannot be adopted raises where the reference attaches it (apply_to), never a base-only model
+    refused = {}
+    for tag, ncfg, over in (("lorm_use_bias", NetworkConfig(type="lora", linear=4, linear_alpha=4), dict(use_bias=True)),
+                            ("fullrank", NetworkConfig(type="fullrank", linear=4, linear_alpha=4), {}),
+                            ("full_if_contains", NetworkConfig(type="lora", linear=4, linear_alpha=4), dict(full_if_contains=["attn.to_q"]))):
+        cfg, sd, nat = plugin()
+        net = build_network(cfg, sd, ncfg, **over)
+        net.force_to(torch.device("cpu"), dtype=torch.float32)
+        try:
+            sd.network = net
+            net._update_torch_multiplier()
+            net.apply_to(None, sd.unet, False, True)
+            refused[tag] = "NOT REFUSED"
+        except (AdoptionError, TypeError) as e:
+            refused[tag] = type(e).__name__
+    meta["refused"] = refused
+    assert all(v != "NOT REFUSED" for v in refused.values()), refused
+    out_dir = out_dir or HERE
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, "adoption_flux_tiny.safetensors"),
+              {"meta": json.dumps(meta, sort_keys=True)})
+    print("adoption golden:", {k: (v if k == "refused" else (v["module_class"], v["n_params"], v["sshs_model_hash"][:12])) for k, v in meta.items()})
 
 
 if __name__ == "__main__":
@@ -987,3 +1159,4 @@ if __name__ == "__main__":
     golden_kohya_to_peft()
     golden_flowmatch()
     golden_wan_lora_keys()
+    golden_adoption()
