@@ -154,14 +154,15 @@ class NoisePackArgs(C.Structure):
 class MseArgs(C.Structure):
     _fields_ = [("pred", vp), ("target", vp), ("weight", vp), ("dpred", vp), ("partial", vp),
                 ("loss_per_sample", vp), ("loss", vp), ("n_per_sample", i64), ("B", i32), ("feat", i32), ("mask", vp),
-                ("loss_type", i32), ("huber_c", C.c_float)]
+                ("loss_type", i32), ("huber_c", C.c_float), ("max_loss", C.c_float), ("_pad_guard", i32), ("guard", vp)]
 
 
 class AdamWArgs(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("ema", vp),
                 ("norm_partial", vp), ("norm_partial2", vp), ("norm_out", vp), ("n", i64)] + [
         (k, C.c_float) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1",
-                                 "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale", "ema_feedback", "param_multiplier")]
+                                 "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale", "ema_feedback", "param_multiplier")] + [
+        ("guard", vp), ("n_micro", i32), ("_pad_micro", i32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -214,7 +215,7 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
-ABI_VERSION = 7  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+ABI_VERSION = 8  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
 
 
 def lib():

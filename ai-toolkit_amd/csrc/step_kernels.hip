@@ -198,8 +198,25 @@ __global__ void mse_finish_kernel(AitkMseArgs p, int nchunk) {
   if (b == 0) {
     float t = 0.f;
     for (int k = 0; k < p.B; ++k) t += ls[k];
-    p.loss[0] = t / (float)p.B;
+    t /= (float)p.B;
+    if (p.guard) {
+      // SDTrainer.py:1049-1050: loss = clamp(loss, max=max_loss) — above the bound the clamp's derivative is 0, nothing flows back;
+      // SDTrainer.py:2221-2224: a non-finite loss is replaced by a fresh zero (no graph): this micro-batch contributes no gradient.
+      // guard[0] counts the gated micro-batches of the current step (the optimizer reads and clears it), [1] / [2] are running totals.
+      int gate = 0;
+      if (!isfinite(t)) { t = 0.f; gate = 1; p.guard[1] += 1; }
+      else if (p.max_loss > 0.f && t > p.max_loss) { t = p.max_loss; gate = 1; p.guard[2] += 1; }
+      if (gate) p.guard[0] += 1;
+      p.guard[6] = gate;
+    }
+    p.loss[0] = t;
   }
+}
+// zeroes dpred when the finish kernel gated this micro-batch (every block reads one flag; 1 launch, no host round trip)
+__global__ __launch_bounds__(256) void mse_gate_kernel(AitkMseArgs p, long n16) {
+  if (p.guard[6] == 0) return;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) reinterpret_cast<uint4*>(p.dpred)[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 extern "C" int64_t aitk_mse_workspace_bytes(int32_t B, int64_t n_per_sample) {
   return (int64_t)B * ((n_per_sample + LOSS_CHUNK - 1) / LOSS_CHUNK) * 4;
@@ -219,6 +236,11 @@ extern "C" int aitk_mse_loss_grad(const AitkMseArgs* a, aitk_stream_t stream) {
   AITK_LAUNCH_CHECK();
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, nchunk);
   AITK_LAUNCH_CHECK();
+  if (a->guard) {
+    const long n16 = (long)a->B * a->n_per_sample / 8;
+    hipLaunchKernelGGL(mse_gate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, n16);
+    AITK_LAUNCH_CHECK();
+  }
   return AITK_OK;
 }
 
@@ -257,34 +279,60 @@ __global__ __launch_bounds__(256) void sumsq_level2_kernel(const float* partial,
   if (threadIdx.x == 0) out2[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, int n2) {
-  __shared__ float s_coef;
-  if (threadIdx.x == 0) {
-    float tot = 0.f;
-    for (int i = 0; i < n2; ++i) tot += p.norm_partial2[i];
-    const float norm = sqrtf(tot) * fabsf(p.grad_scale);  // norm of the scaled (e.g. rank-averaged) gradient
-    float coef = 1.0f;
-    if (p.max_norm > 0.f) coef = fminf(1.0f, p.max_norm / (norm + 1e-6f));
-    s_coef = coef * p.grad_scale;
-    if (blockIdx.x == 0 && p.norm_out) p.norm_out[0] = norm;
+// One thread decides the step: total norm -> clip coefficient; with a guard buffer also whether the update happens at all and which bias
+// corrections apply.  ctl = {coef * grad_scale, skip, bias_correction1, bias_correction2_sqrt} (the tail of the norm workspace).
+//   skip <=> the gradient norm is not finite (a NaN / Inf batch reached the arena), or every micro-batch of the step was gated by the loss
+//   guard (non-finite loss / max_loss): the reference then has no gradient on any parameter and torch.optim.AdamW skips them all — no weight
+//   decay, no moment decay, no step count (SDTrainer.py:2221-2224 + torch/optim/adamw.py "if p.grad is None: continue").  The bias
+//   corrections follow the number of APPLIED steps, kept on the device (guard[3]): no host sync, and a skipped step does not advance them.
+__global__ void adamw_decide_kernel(AitkAdamWArgs p, int n2, float* ctl) {
+  float tot = 0.f;
+  for (int i = 0; i < n2; ++i) tot += p.norm_partial2[i];
+  const float norm = sqrtf(tot) * fabsf(p.grad_scale);  // norm of the scaled (e.g. rank-averaged) gradient
+  float coef = 1.0f;
+  if (p.max_norm > 0.f) coef = fminf(1.0f, p.max_norm / (norm + 1e-6f));
+  float bc1 = p.bias_correction1, bc2s = p.bias_correction2_sqrt;
+  int skip = 0;
+  if (p.guard) {
+    skip = !isfinite(norm) || (p.n_micro > 0 && p.guard[0] >= p.n_micro);
+    p.guard[0] = 0;
+    p.guard[5] = skip;
+    if (skip) p.guard[4] += 1;
+    else p.guard[3] += 1;
+    const double step = (double)(p.guard[3] + (skip ? 1 : 0));  // the step this update is (or would have been)
+    bc1 = (float)(1.0 - pow((double)p.beta1, step));
+    bc2s = (float)sqrt(1.0 - pow((double)p.beta2, step));
   }
-  __syncthreads();
-  const float coef = s_coef;
+  ctl[0] = coef * p.grad_scale;
+  ctl[1] = skip ? 1.0f : 0.0f;
+  ctl[2] = bc1;
+  ctl[3] = bc2s;
+  if (p.norm_out) p.norm_out[0] = norm;
+}
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, const float* ctl) {
+  const float coef = ctl[0];
+  const bool skip = ctl[1] != 0.f;
+  const float bc1 = ctl[2], bc2s = ctl[3];
   const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
 #pragma unroll
   for (int i = 0; i < OPT_BLOCK_ELEMS / 256; ++i) {
     const long j = base + i * 256 + threadIdx.x;
     if (j < p.n) {
-      const float g = p.g[j] * coef;
       float w = p.p[j];
-      w -= p.lr * p.weight_decay * w;
-      const float m = p.beta1 * p.m[j] + (1.0f - p.beta1) * g;
-      const float v = p.beta2 * p.v[j] + (1.0f - p.beta2) * g * g;
-      const float denom = sqrtf(v) / p.bias_correction2_sqrt + p.eps;
-      w -= (p.lr / p.bias_correction1) * (m / denom);
-      p.m[j] = m;
-      p.v[j] = v;
-      if (p.ema) {  // toolkit/ema.py:135-143: tmp = (1-d)(s - p); s -= tmp; p += 10 tmp (use_feedback); p *= param_multiplier
+      if (!skip) {
+        const float g = p.g[j] * coef;
+        w -= p.lr * p.weight_decay * w;
+        const float m = p.beta1 * p.m[j] + (1.0f - p.beta1) * g;
+        const float v = p.beta2 * p.v[j] + (1.0f - p.beta2) * g * g;
+        const float denom = sqrtf(v) / bc2s + p.eps;
+        w -= (p.lr / bc1) * (m / denom);
+        p.m[j] = m;
+        p.v[j] = v;
+      } else if (!p.ema) {
+        continue;  // skipped step without EMA: nothing is touched
+      }
+      if (p.ema) {  // on a skipped step too: the reference's ema.update() runs after every train-loop iteration (SDTrainer.py:2291-2293)  // toolkit/ema.py:135-143: tmp = (1-d)(s - p); s -= tmp; p += 10 tmp (use_feedback); p *= param_multiplier
         const float s = p.ema[j];
         const float tmp = (1.0f - p.ema_decay) * (s - w);
         p.ema[j] = s - tmp;
@@ -299,7 +347,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, int n2)
 extern "C" int64_t aitk_adamw_workspace_bytes(int64_t n) {
   const int64_t n1 = (n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS;
   const int64_t n2 = (n1 + 1023) / 1024;
-  return (n1 + n2) * 4;
+  return (n1 + n2 + 8) * 4;  // two levels of norm partials + the 4-float control block of adamw_decide_kernel
 }
 
 extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream) {
@@ -315,7 +363,10 @@ extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream)
   AITK_LAUNCH_CHECK();
   hipLaunchKernelGGL(sumsq_level2_kernel, dim3(n2), dim3(256), 0, s, a->norm_partial, (int)n1, args.norm_partial2);
   AITK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)n1), dim3(256), 0, s, args, n2);
+  float* ctl = a->norm_partial + n1 + n2;
+  hipLaunchKernelGGL(adamw_decide_kernel, dim3(1), dim3(1), 0, s, args, n2, ctl);
+  AITK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)n1), dim3(256), 0, s, args, (const float*)ctl);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

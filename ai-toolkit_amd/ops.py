@@ -536,9 +536,11 @@ def flow_noise_pack(latents, noise, t, noisy, target):
 LOSS_TYPES = {"mse": 0, "mae": 1, "pseudo_huber": 2}
 
 
-def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None, loss_type="mse", huber_c=0.01):
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None, loss_type="mse", huber_c=0.01, guard=None,
+                  max_loss=None):
     """loss_b = mean(mask*l(pred-target)), l = d^2 | |d| | sqrt(d^2+c^2)-c (train.loss_type mse / mae / pseudo_huber), loss = mean_b(w_b loss_b);
-    dpred = dloss/dpred (bf16).  mask: fp32 [B, tokens, 4] (per 2x2-patch position), pred [B, tokens, feat]."""
+    dpred = dloss/dpred (bf16).  mask: fp32 [B, tokens, 4] (per 2x2-patch position), pred [B, tokens, feat].  guard: int32[8] device buffer
+    (AitkMseArgs.guard): a non-finite loss -> 0 and a loss above max_loss -> max_loss, each with a zero gradient, decided on the device."""
     a = _capi.MseArgs()
     B = pred.shape[0]
     n = pred[0].numel()
@@ -551,13 +553,20 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=
         assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == B * (n // pred.shape[-1]) * 4
         a.mask, a.feat = _ptr(mask), pred.shape[-1]
     a.loss_type, a.huber_c = LOSS_TYPES[loss_type], huber_c
+    if guard is not None:
+        assert guard.dtype == torch.int32 and guard.numel() >= 8 and guard.is_contiguous()
+        a.guard, a.max_loss = _ptr(guard), float(max_loss or 0.0)
+    elif max_loss:
+        raise ValueError("max_loss needs the guard buffer (the clamp is decided on the device)")
     _call("aitk_mse_loss_grad", C.byref(a))
 
 
 def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
-                   grad_scale=1.0, norm_out=None, ema_feedback=0.0, param_multiplier=1.0):
+                   grad_scale=1.0, norm_out=None, ema_feedback=0.0, param_multiplier=1.0, guard=None, n_micro=1):
     """In-place clip_grad_norm_ -> AdamW -> EMA over flat fp32 arenas (step is the 1-based AdamW step count); ema_feedback /
-    param_multiplier: toolkit/ema.py's use_feedback (10) and param_multiplier applied to the parameter after the EMA update."""
+    param_multiplier: toolkit/ema.py's use_feedback (10) and param_multiplier applied to the parameter after the EMA update.  guard
+    (int32[8], AitkAdamWArgs.guard): the update is skipped on the device when the gradient norm is not finite or all n_micro loss launches
+    of the step were gated; the step count of the bias corrections then lives in guard[3] (`step` is ignored)."""
     a = _capi.AdamWArgs()
     n = p.numel()
     for t_ in (p, g, m, v):
@@ -570,6 +579,9 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     a.bias_correction2_sqrt = (1.0 - beta2 ** step) ** 0.5
     a.max_norm, a.ema_decay, a.grad_scale = max_norm, ema_decay, grad_scale
     a.ema_feedback, a.param_multiplier = ema_feedback, param_multiplier
+    if guard is not None:
+        assert guard.dtype == torch.int32 and guard.numel() >= 8 and guard.is_contiguous()
+        a.guard, a.n_micro = _ptr(guard), int(n_micro)
     _call("aitk_adamw_ema_step", C.byref(a))
 
 

@@ -23,8 +23,18 @@ class _LoRATrainStepBase:
                  max_grad_norm=1.0, ema_decay=0.0, timestep_type="linear", guidance=1.0, process_group=None,
                  seed=None, schedule=None, lr_scheduler=None, noise_options=None, linear_timesteps=False, linear_timesteps2=False,
                  latent_multiplier=1.0, adaptive_scaling_factor=False, noisy_latent_multiplier=1.0, loss_type="mse",
-                 ema_use_feedback=False, ema_param_multiplier=1.0, ema_use_num_updates=False, allreduce_dtype="fp32"):
+                 ema_use_feedback=False, ema_param_multiplier=1.0, ema_use_num_updates=False, allreduce_dtype="fp32",
+                 nonfinite_guard=True, max_loss=None):
         self.model, self.network, self.ops = model, network, ops
+        # Failure handling of the reference's loop, on the device (no host sync; the reference reads loss.item(), we never do):
+        #   * non-finite loss -> the micro-batch contributes no gradient and reports 0 (SDTrainer.py:2221-2224);
+        #   * train.max_loss -> clamp(loss, max=max_loss): above it the gradient is zero (SDTrainer.py:1049-1050);
+        #   * a step whose every micro-batch was gated, or whose gradient arena holds a NaN / Inf (norm not finite), is SKIPPED: p, m, v and
+        #     the AdamW step count stay as they are — what torch.optim.AdamW does when no parameter has a .grad — and one bad batch cannot
+        #     poison the moments, the EMA or the bf16 shadows.  `guard_counters()` reads the tallies back (a host sync, call it rarely).
+        self.max_loss = float(max_loss) if max_loss else None
+        self.guard = torch.zeros(8, dtype=torch.int32, device=network.arena_p.device) if (nonfinite_guard or self.max_loss) else None
+        self._n_micro = 0
         # train.loss_type (SDTrainer.py:903-916): mse (default) / mae / pseudo_huber run as modes of aitk_mse_loss_grad; wavelet,
         # stepped, pixelspace and mean_flow are other losses of the reference and are refused
         if loss_type not in ("mse", "mae", "pseudo_huber"):
@@ -84,6 +94,13 @@ class _LoRATrainStepBase:
         # arena split point: adapters at [split, n) get their final gradients first during backward
         self._split = model.grad_split_offset(network)
         model.grad_ready_hook = None  # set per backward pass (only the last micro-batch issues the all-reduce)
+
+    def guard_counters(self):
+        """{'nonfinite_losses', 'clamped_losses', 'steps_applied', 'steps_skipped', 'last_step_skipped'} read back from the device (host sync)."""
+        if self.guard is None:
+            return None
+        g = self.guard.tolist()
+        return {"nonfinite_losses": g[1], "clamped_losses": g[2], "steps_applied": g[3], "steps_skipped": g[4], "last_step_skipped": bool(g[5])}
 
     def _scale_latents(self, latents):
         """batch.latents of the reference: the cached / encoded latents times latent_multiplier (BaseSDTrainProcess.py:1393-1411)."""
@@ -180,15 +197,20 @@ class _LoRATrainStepBase:
         torch.cuda.empty_cache()  # the warm-up's activations go back to the driver: the graph pool takes their place
         g = torch.cuda.CUDAGraph()
         self.network.zero_grad_arena()
+        n0 = self._n_micro
         with torch.cuda.graph(g, pool=self._graph_pool):
             loss = self._run(static, final=False)
+        n_loss = self._n_micro - n0  # loss launches inside the graph: what a replay adds to the step's micro-batch count
+        self._n_micro = 0
+        if self.guard is not None:
+            self.guard[0:1].zero_()  # the warm-up run is not a step: its gate count must not reach the next optimizer launch
         if self._graph_pool is None:
             self._graph_pool = g.pool()
         # the graph holds raw pointers: every grow-only kernel workspace as it was during capture (ops.workspace replaces a buffer
         # when a larger bucket asks for more) and this batch size's per-sample loss buffer stay referenced by the entry, so a later
         # reallocation cannot hand their memory to another tensor while the graph can still be replayed
-        ent = {"graph": g, "static": static, "loss": loss, "keepalive": (list(getattr(self.ops, "_ws", {}).values()),
-                                                                         dict(self._loss_per_sample_by_B))}
+        ent = {"graph": g, "static": static, "loss": loss, "n_loss": n_loss, "keepalive": (list(getattr(self.ops, "_ws", {}).values()),
+                                                                                          dict(self._loss_per_sample_by_B))}
         self._graphs[key] = ent
         return ent
 
@@ -201,6 +223,7 @@ class _LoRATrainStepBase:
                 ent["static"][k].copy_(v)
         self.network.zero_grad_arena()
         ent["graph"].replay()
+        self._n_micro = ent.get("n_loss", 0)
         if self.dp:  # replay finishes every gradient at once: both pieces go out back to back (not overlapped with backward)
             self._on_grads_ready("single")
             self._on_grads_ready("double")
@@ -239,6 +262,9 @@ class _LoRATrainStepBase:
         if self.loss_per_sample is None:
             self.loss_per_sample = self._loss_per_sample_by_B[B] = torch.zeros(B, dtype=torch.float32, device=pred.device)
         kw = {} if self.loss_type == "mse" else {"loss_type": self.loss_type}
+        if self.guard is not None:
+            kw.update(guard=self.guard, max_loss=self.max_loss)
+            self._n_micro += 1
         ops.mse_loss_grad(pred, target, dpred, self.loss_per_sample, self.loss, weight=loss_weight,
                           mask=loss_mask, **kw)
         model.grad_ready_hook = self._on_grads_ready if (final and self.dp) else None
@@ -265,6 +291,9 @@ class _LoRATrainStepBase:
                 decay = min(decay, (1 + self.ema_num_updates) / (10 + self.ema_num_updates))
             if self.ema_feedback or self.ema_param_multiplier != 1.0:
                 kw = dict(ema_feedback=self.ema_feedback, param_multiplier=self.ema_param_multiplier)
+        if self.guard is not None:
+            kw.update(guard=self.guard, n_micro=self._n_micro)
+            self._n_micro = 0
         ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,
                            max_norm=self.max_grad_norm, ema=net.arena_ema if self.ema_decay > 0 else None,

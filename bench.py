@@ -491,7 +491,7 @@ def parity_leg(dev):
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
     from oracle import train_ref
-    from tests.test_gpu_e2e import _batch, _build
+    from oracle.pairs import batch as _batch, build as _build
 
     def rel(a, b):
         num = sum(((x.float() - y.float()) ** 2).sum().item() for x, y in zip(a, b))
@@ -510,10 +510,28 @@ def parity_leg(dev):
     go = []
     for m in net.unet_loras:
         go += [m.lora_down.weight.grad, m.lora_up.weight.grad]
+    # ref16_self: the SAME reference arithmetic on a second backend — the oracle's bf16 step on the host CPU's kernels vs
+    # the run above on the GPU (rocBLAS), identical weights / adapter state / inputs.  If two executions of the reference's own code differ by
+    # as much as the HIP path differs from either, north_star's 1e-3 on LoRA deltas is not attainable by the reference itself.
+    from oracle.pairs import cpu_twin
+
+    ref.float()
+    twin, twin_net = cpu_twin(ref, ref_net, 16)
+    cpu = [t.cpu() for t in (lat, emb, pooled, noise, ts)]
+    o_cpu = train_ref.RefTrainStep(twin, twin_net, **kw)
+    l32c = o_cpu.step(cpu[0].float(), cpu[1].float(), cpu[2].float(), cpu[3].float(), cpu[4]).item()
+    g32c = [p.grad.clone().to(dev) for p in o_cpu.params]
+    twin.to(torch.bfloat16)
+    l16c = o_cpu.step(*cpu[:4], cpu[4], dtype=torch.bfloat16).item()
+    g16c = [p.grad.clone().to(dev) for p in o_cpu.params]
     return {"config": "FLUX 2+3 blocks, 3x128 heads, 96 img + 40 txt tokens, B=2, LoRA r16 (same seeds / weights / inputs on every path)",
             "tolerance": "north_star: 1e-3 relative on the bf16 loss and on LoRA deltas",
             "loss_rel": abs(lo - l32) / abs(l32), "grad_rel": rel(go, g32), "ref16_floor": rel(g16, g32),
             "ref16_loss_rel": abs(l16 - l32) / abs(l32), "grad_rel_vs_ref16": rel(go, g16),
+            "ref16_self": {"grad_rel_gpu_vs_cpu": rel(g16, g16c), "loss_rel_gpu_vs_cpu": abs(l16 - l16c) / abs(l16c),
+                           "fp32_grad_rel_gpu_vs_cpu": rel(g32, g32c), "grad_rel_ours_vs_ref16_cpu": rel(go, g16c),
+                           "what": "the oracle's bf16 step (reference arithmetic: bf16 modules + fp32 adapter) on the GPU vs the same code on "
+                                   "the host CPU; fp32_* = the same pair in fp32 (control: summation order only)"},
             "note": "grad_rel = adapter-gradient error of the HIP path vs the fp32 oracle (relative Frobenius over all 2 x adapters "
                     "matrices); ref16_floor = the same for the reference's own bf16 arithmetic.  Full-size cases: DESIGN.md section 7"}
 

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 7 /* 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 8 /* 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -318,6 +318,14 @@ typedef struct AitkMseArgs {
   const float* mask;
   int32_t loss_type; /* AITK_LOSS_MSE / _MAE / _PSEUDO_HUBER: train.loss_type (extensions_built_in/sd_trainer/SDTrainer.py:903-916) */
   float huber_c;     /* pseudo_huber: sqrt(d^2 + c^2) - c; the reference hard-codes c = 0.01; 0 selects that default */
+  /* Failure handling of the reference's train loop, on the device (no host sync).  guard: int32[8] device buffer shared with
+   * aitk_adamw_ema_step, NULL = off.  A non-finite loss is reported as 0 and its gradient zeroed (SDTrainer.py:2221-2224: `loss =
+   * zeros_like(loss)`); with max_loss > 0 a loss above it is reported as max_loss and its gradient zeroed (SDTrainer.py:1049-1050:
+   * torch.clamp(loss, max=max_loss) has derivative 0 there).  guard[0] = gated micro-batches of the current step (cleared by the optimizer
+   * launch), [1] = non-finite losses so far, [2] = clamped losses so far, [3] = optimizer steps applied, [4] = optimizer steps skipped,
+   * [5] = 1 if the last optimizer launch skipped, [6] = 1 if the last loss launch was gated. */
+  float max_loss; int32_t _pad_guard;
+  int32_t* guard;
 } AitkMseArgs;
 #define AITK_LOSS_MSE 0          /* (pred - target)^2 */
 #define AITK_LOSS_MAE 1          /* |pred - target| (gradient sign(d), 0 at d = 0 like torch l1_loss) */
@@ -337,6 +345,11 @@ typedef struct AitkAdamWArgs {
    * in the reference's order: tmp = (1-d)(s - p); s -= tmp; p += ema_feedback * tmp (use_feedback: 10, else 0); p *= param_multiplier
    * (0 is read as 1).  Only with `ema`. */
   float ema_feedback, param_multiplier;
+  /* guard (int32[8], see AitkMseArgs; NULL = off): the parameter update is SKIPPED — p, m, v untouched, the EMA still follows p like the
+   * reference's ema.update() — when the gradient norm is not finite or all n_micro loss launches of the step were gated; the bias
+   * corrections are then derived on the device from the number of applied steps (guard[3] + 1; bias_correction1 / bias_correction2_sqrt
+   * of this struct are ignored), so a skipped step does not advance them — torch.optim.AdamW on parameters without .grad. */
+  int32_t* guard; int32_t n_micro; int32_t _pad_micro;
 } AitkAdamWArgs;
 int64_t aitk_adamw_workspace_bytes(int64_t n);
 int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);

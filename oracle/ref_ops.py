@@ -366,7 +366,7 @@ def flow_noise_pack(latents, noise, t, noisy, target):
     target.copy_(pack(e - x0).to(target.dtype))
 
 
-def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None, loss_type="mse", huber_c=0.01):
+def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=None, loss_type="mse", huber_c=0.01, guard=None, max_loss=None):
     """mse(pred.float(), target.float()) [* mask_multiplier] -> mean over (C,H,W) -> * multiplier -> mean over batch
     (SDTrainer.py:916-1013); mask [B, tokens, 4] is the reference's [B,1,h,w] mask in the packed 2x2-patch layout."""
     B = pred.shape[0]
@@ -390,11 +390,28 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=
     loss_per_sample.copy_(lps)
     loss.copy_((lps * w).mean().reshape(1))
     dpred.copy_((gr * mk * w[:, None] / (n * B)).reshape(dpred.shape).to(dpred.dtype))
+    if guard is not None:  # SDTrainer.py:2221-2224 (non-finite loss -> a fresh zero) and 1049-1050 (clamp(loss, max=max_loss): zero derivative above)
+        gate = 0
+        if not bool(torch.isfinite(loss).all()):
+            loss.zero_()
+            gate = 1
+            guard[1] += 1
+        elif max_loss and float(loss) > max_loss:
+            loss.fill_(max_loss)
+            gate = 1
+            guard[2] += 1
+        if gate:
+            guard[0] += 1
+            dpred.zero_()
+        guard[6] = gate
 
 
 def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max_norm=0.0, ema=None, ema_decay=0.0,
-                   grad_scale=1.0, norm_out=None, ema_feedback=0.0, param_multiplier=1.0):
-    """clip_grad_norm_ + torch.optim.AdamW + EMA (SDTrainer.py:2278-2293, toolkit/optimizer.py:78-79, toolkit/ema.py:116-152)."""
+                   grad_scale=1.0, norm_out=None, ema_feedback=0.0, param_multiplier=1.0, guard=None, n_micro=1):
+    """clip_grad_norm_ + torch.optim.AdamW + EMA (SDTrainer.py:2278-2293, toolkit/optimizer.py:78-79, toolkit/ema.py:116-152).  guard: the
+    step is skipped (p, m, v untouched; EMA still updated, as ema.update() runs regardless) when the gradient norm is not finite or every
+    micro-batch was gated by the loss guard — torch.optim.AdamW over parameters whose .grad is None; the step count of the bias corrections is
+    guard[3] (applied steps)."""
     gs = g * grad_scale
     norm = gs.double().pow(2).sum().sqrt().float()
     coef = 1.0
@@ -403,12 +420,20 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     gs = gs * coef
     if norm_out is not None:
         norm_out.copy_(norm.reshape(1))
-    p.mul_(1 - lr * weight_decay)
-    m.mul_(beta1).add_(gs, alpha=1 - beta1)
-    v.mul_(beta2).addcmul_(gs, gs, value=1 - beta2)
-    bc1 = 1 - beta1 ** step
-    bc2s = math.sqrt(1 - beta2 ** step)
-    p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
+    skip = False
+    if guard is not None:
+        skip = (not bool(torch.isfinite(norm))) or (n_micro > 0 and int(guard[0]) >= n_micro)
+        guard[0] = 0
+        guard[5] = int(skip)
+        guard[4 if skip else 3] += 1
+        step = int(guard[3]) + (1 if skip else 0)
+    if not skip:
+        p.mul_(1 - lr * weight_decay)
+        m.mul_(beta1).add_(gs, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gs, gs, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2s = math.sqrt(1 - beta2 ** step)
+        p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
     if ema is not None:  # toolkit/ema.py:135-143
         tmp = (1 - ema_decay) * (ema - p)
         ema.sub_(tmp)

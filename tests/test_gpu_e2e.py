@@ -14,57 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CFG = dict(in_channels=64, num_layers=2, num_single_layers=3, attention_head_dim=128, num_attention_heads=3,
-           joint_attention_dim=256, pooled_projection_dim=64)
-
-
-def _build(rank=16, dev="cuda"):
-    import ai_toolkit_amd  # noqa: F401
-    from ai_toolkit_amd import ops
-    from ai_toolkit_amd.flux import FluxTransformer2DModel
-    from ai_toolkit_amd.lora import FusedLoRANetwork
-    from oracle import flux_ref, lora_ref
-
-    torch.manual_seed(0)
-    ref = flux_ref.FluxTransformer2DModel(**CFG)
-    flux_ref.init_synthetic_(ref, seed=1234, std=0.03)
-    with torch.no_grad():
-        for n, p in ref.named_parameters():
-            if n.endswith("bias"):
-                p.copy_(torch.randn_like(p) * 0.02)
-            if "norm_" in n and n.endswith("weight"):
-                p.copy_(1 + 0.1 * torch.randn_like(p))
-            p.copy_(p.to(torch.bfloat16).float())  # bf16-representable base so every path sees identical weights
-    ref = ref.to(dev)
-    nat = FluxTransformer2DModel(**CFG, dtype=torch.bfloat16, device=dev, ops=ops)
-    nat.load_state_dict({k: v.to(torch.bfloat16) for k, v in ref.state_dict().items()}, strict=True)
-    ref_net = lora_ref.RefLoRANetwork(ref, rank).to(dev)
-    net = FusedLoRANetwork(nat, lora_dim=rank)
-    g = torch.Generator().manual_seed(7)
-    with torch.no_grad():
-        for a, b in zip(net.unet_loras, ref_net.unet_loras):
-            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.02
-            b.lora_up.weight.copy_(up)
-            a.lora_down.weight.copy_(b.lora_down.weight.cpu())
-            a.lora_up.weight.copy_(up)
-    ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
-    ref_net.apply_to()
-    net.apply_to()
-    net.build_arena(dev, groups=nat.lora_groups())
-    net.refresh_shadows(ops)
-    nat.attach_network(net)
-    nat.prepare()
-    return ref, ref_net, nat, net
-
-
-def _batch(B, Hl=16, Wl=12, n_txt=40, dev="cuda", seed=5):
-    g = torch.Generator().manual_seed(seed)
-    lat = torch.randn(B, 16, Hl, Wl, generator=g).to(torch.bfloat16)
-    emb = (torch.randn(B, n_txt, CFG["joint_attention_dim"], generator=g) * 0.5).to(torch.bfloat16)
-    pooled = (torch.randn(B, CFG["pooled_projection_dim"], generator=g) * 0.5).to(torch.bfloat16)
-    noise = torch.randn(B, 16, Hl, Wl, generator=g).to(torch.bfloat16)
-    ts = torch.tensor([700.0, 250.0, 999.0, 31.0][:B])
-    return [t.to(dev) for t in (lat, emb, pooled, noise, ts)]
+from oracle.pairs import CFG, batch as _batch, build as _build  # noqa: E402,F401  (shared with bench.py / __graft_entry__.smoke())
 
 
 def _rel(a, b):
@@ -74,7 +24,7 @@ def _rel(a, b):
 def test_native_library_loaded_and_fails_loudly_without_it(monkeypatch):
     from ai_toolkit_amd import _capi
 
-    assert _capi.lib().aitk_abi_version() == _capi.ABI_VERSION == 7
+    assert _capi.lib().aitk_abi_version() == _capi.ABI_VERSION == 8
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libaitk.so")
     with pytest.raises(RuntimeError):

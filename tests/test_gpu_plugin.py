@@ -124,3 +124,78 @@ def test_stable_diffusion_wrapper_trainer_loop_equals_fused_train_step(sdxl):
         assert abs(loss_a.item() - loss_b.item()) <= (1e-3 if k == 0 else 5e-3) * abs(loss_b.item()), (k, loss_a.item(), loss_b.item())
         assert _rel(g_a, net_b.arena_g) < (1e-2 if k == 0 else 5e-2), (k, _rel(g_a, net_b.arena_g))
         assert _rel(net_a.arena_p, net_b.arena_p) < (5e-3 if k == 0 else 2e-2), (k, _rel(net_a.arena_p, net_b.arena_p))
+
+
+def test_reference_built_network_adopted_on_the_hip_kernels_equals_the_fused_network_bit_for_bit():
+    """The boundary without a trainer patch, on the GPU (CPU twin + the run with the reference's own classes: tests/test_adoption_cpu.py): the
+    trainer's sequence — network constructed over sd.get_model_to_train(), force_to(device, fp32), `sd.network = network`, apply_to (forward
+    swap), prepare_optimizer_params -> torch.optim.AdamW, `with network:` prediction, loss.backward(), clip_grad_norm_, step, zero_grad —
+    with the oracle's restatement of the reference network protocol (oracle/lora_ref.py) over the native model.  The native graph adopts
+    that network (ai_toolkit_amd/adopt.py): same arena layout, same kernels as a FusedLoRANetwork, so everything must be BIT-IDENTICAL, with the
+    optimizer still holding the network's own Parameter objects."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.adopt import AdoptedNetwork
+    from ai_toolkit_amd.plugin import Flux1MI355Model
+    from oracle import lora_ref
+    from oracle.pairs import batch as _batch, build as _build
+
+    _, _, nat_f, net_f = _build()
+    _, _, nat_a, none = _build(attach=False)
+    assert none is None
+    sd_f = Flux1MI355Model("cuda", model=nat_f, dtype=bf)
+    sd_a = Flux1MI355Model("cuda", model=nat_a, dtype=bf)
+    # --- the trainer's side (BaseSDTrainProcess.py:1949-2039)
+    net_a = lora_ref.RefLoRANetwork(sd_a.get_model_to_train(), 16, 1.0)
+    with torch.no_grad():
+        for a, b in zip(net_a.unet_loras, net_f.unet_loras):
+            assert a.lora_name == b.lora_name
+            a.lora_down.weight.copy_(b.lora_down.weight.cpu())
+            a.lora_up.weight.copy_(b.lora_up.weight.cpu())
+    net_a.force_to(torch.device("cuda"), torch.float32)
+    sd_a.network = net_a
+    net_a._update_torch_multiplier()
+    net_a.apply_to(None, sd_a.unet, False, True)
+    net_a.prepare_grad_etc(None, sd_a.unet)
+    groups_a = net_a.prepare_optimizer_params(text_encoder_lr=1e-3, unet_lr=1e-3, default_lr=1e-3)
+    params_a = [p for g in groups_a for p in g["params"]]
+    ids = [id(p) for p in params_a]
+    opt_a = torch.optim.AdamW(groups_a, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    params_f = net_f.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    opt_f = torch.optim.AdamW(params_f, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ema_a, ema_f = [p.detach().clone() for p in params_a], [p.detach().clone() for p in params_f]
+
+    for k in range(3):
+        lat, emb, pooled, noise, ts = _batch(2, seed=30 + k)
+        B_, _, h_, w_ = lat.shape
+        npk = torch.empty(B_, (h_ // 2) * (w_ // 2), 64, dtype=bf, device="cuda")
+        tpk = torch.empty_like(npk)
+        ops.flow_noise_pack(lat, noise, ts.float().contiguous(), npk, tpk)
+        noisy, target = _unpack(npk, B_, h_, w_), _unpack(tpk, B_, h_, w_)
+        pe = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled)
+        opt_a.zero_grad()
+        with net_a:
+            pred = sd_a.get_noise_prediction(noisy, ts, pe, guidance_embedding_scale=1.0)
+            loss_a = torch.nn.functional.mse_loss(pred.float(), target.float(), reduction="none").mean([1, 2, 3]).mean()
+            loss_a.backward()
+        ad = nat_a.network
+        assert isinstance(ad, AdoptedNetwork) and ad.foreign is net_a and ad.aliasing_intact()
+        g_a = ad.arena_g.clone()
+        torch.nn.utils.clip_grad_norm_(params_a, 1.0)
+        opt_a.step()
+        opt_a.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for s, p in zip(ema_a, params_a):
+                s.sub_((s - p) * (1.0 - 0.99))
+        loss_f, g_f = _torch_trainer_step(net_f, params_f, opt_f, ema_f, ops, lambda: sd_f.get_noise_prediction(noisy, ts, pe, guidance_embedding_scale=1.0), target)
+        assert torch.equal(loss_a.detach(), loss_f), (k, loss_a.item(), loss_f.item())
+        assert torch.equal(g_a, g_f), (k, _rel(g_a, g_f))
+        assert torch.equal(ad.arena_p, net_f.arena_p), (k, _rel(ad.arena_p, net_f.arena_p))
+    assert [id(p) for g in opt_a.param_groups for p in g["params"]] == ids
+    assert all(torch.equal(a, b) for a, b in zip(ema_a, ema_f))
+    # what the reference-side object saves is the arena content
+    sd_ref = net_a.peft_state_dict(dtype=torch.float32)
+    sd_fus = net_f.get_state_dict(dtype=torch.float32)
+    assert list(sd_ref) == list(sd_fus) and all(torch.equal(sd_ref[k2], sd_fus[k2]) for k2 in sd_ref)
+    # inactive network == base model, bit for bit with the fused network's inactive pass
+    with torch.no_grad():
+        assert torch.equal(sd_a.get_noise_prediction(noisy, ts, pe, 1.0), sd_f.get_noise_prediction(noisy, ts, pe, 1.0))
