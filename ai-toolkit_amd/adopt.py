@@ -364,6 +364,25 @@ class AdoptedNetwork(FusedLoRANetwork):
     def grads_dropped(self):
         return self._expect[0][0].grad is None
 
+    # ---- data parallelism under the reference's trainer
+    # The reference wraps the network with accelerate / DDP (BaseSDTrainProcess.py:765-767), whose gradient all-reduce hangs off autograd's
+    # per-parameter accumulation hooks.  The explicit backward writes the adapter gradients straight into the arena, so those hooks never
+    # fire: under `accelerate launch` with N processes the replicas would silently train on their own shards only.  With a process group
+    # initialised, every backward ends with ONE all-reduce(average) of the flat gradient arena (the same collective the fused train step
+    # issues, RCCL over xGMI on the GPU).  Under gradient accumulation the arena holds avg(g_1) + local g_2 after the second backward and
+    # averaging that again leaves avg(g_1) + avg(g_2): correct without a no_sync protocol.  dp_allreduce = False turns it off.
+    dp_allreduce = True
+
+    def after_backward(self):
+        if not self.dp_allreduce:
+            return
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return
+        dist.all_reduce(self.arena_g, op=dist.ReduceOp.SUM)
+        self.arena_g.div_(dist.get_world_size())
+
     def parameters(self, recurse=True):
         for p, _ in self._expect:
             yield p

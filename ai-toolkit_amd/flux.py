@@ -100,7 +100,6 @@ class FluxTransformer2DModel(FusedGraphBase):
                  axes_dims_rope=(16, 56, 56), dtype=torch.bfloat16, device=None, ops=None):
         super().__init__()
         assert attention_head_dim == 128, "attention kernels are specialised for head_dim 128"
-        assert guidance_embeds
         self.config = dict(in_channels=in_channels, num_layers=num_layers, num_single_layers=num_single_layers,
                            attention_head_dim=attention_head_dim, num_attention_heads=num_attention_heads,
                            joint_attention_dim=joint_attention_dim, pooled_projection_dim=pooled_projection_dim,
@@ -110,7 +109,8 @@ class FluxTransformer2DModel(FusedGraphBase):
         d = self.dim
         tte = _Holder()
         tte.timestep_embedder = _TimestepEmbedding(256, d, dtype, device)
-        tte.guidance_embedder = _TimestepEmbedding(256, d, dtype, device)
+        if guidance_embeds:  # FLUX.1-schnell checkpoints (config.json: guidance_embeds false) have no guidance embedder
+            tte.guidance_embedder = _TimestepEmbedding(256, d, dtype, device)
         tte.text_embedder = _TextProj(pooled_projection_dim, d, dtype, device)
         self.time_text_embed = tte
         self.context_embedder = Linear(joint_attention_dim, d, True, dtype, device)
@@ -260,7 +260,7 @@ class FluxTransformer2DModel(FusedGraphBase):
         # guidance = None: the reference's bypass_flux_guidance (toolkit/models/flux.py:9-35, the FLUX.1-schnell training adapter path,
         # stable_diffusion_model.py:2182-2183): the conditioning vector is timestep + pooled text only
         embedders = [(tte.timestep_embedder, t_eff)]
-        if guidance is not None:
+        if guidance is not None and self.config["guidance_embeds"]:  # diffusers ignores `guidance` without the embedder (CombinedTimestepTextProjEmbeddings)
             embedders.append((tte.guidance_embedder, (guidance.to(dt) * 1000).float().contiguous()))
         temb = self._new(B, d)
         first = True
@@ -571,4 +571,7 @@ class _FluxGraphFn(torch.autograd.Function):
             # zero, so the arena they alias is cleared and the views are re-attached before this backward accumulates into it
             net.zero_grad_arena()
         ctx_.model.backward_native(dpred)
+        hook = getattr(net, "after_backward", None)
+        if hook is not None:
+            hook()  # adopted reference networks: the data-parallel average of the gradient arena (adopt.AdoptedNetwork.after_backward)
         return None, None, None

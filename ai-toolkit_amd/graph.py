@@ -517,6 +517,12 @@ class FusedGraphBase(nn.Module):
             grp = None
         dTcat = self._new(M, 3 * grp["R"]) if grp is not None else None
         cat = self._concat_dgrad_operand(lins, dys, Ts, grp, M)
+        # census of the K-concatenated path: a group whose transposed weights prepare() laid out together but whose output
+        # gradients did not arrive as adjacent windows of one buffer falls back to per-layer GEMMs — a different summation order, silently.
+        # Counted so that tests can assert the production graphs never take that branch (dgrad_census()).
+        if getattr(lins[0], "_dgroup", None) is not None and lins[0]._dgroup[2] == tuple(id(l) for l in lins):
+            c = self.__dict__.setdefault("_dgrad_census", {"concat": 0, "fallback": 0})
+            c["concat" if cat is not None else "fallback"] += 1
         if cat is not None:
             # ONE data-gradient GEMM for the group: dx = [dy_0 | dy_1 | ...] [W_0^T | W_1^T | ...]^T + [dT_0 | dT_1 | ...] [A_0^T3 | A_1^T3 | ...]^T
             # (contraction over the concatenated output channels; fp32 accumulation across the whole group instead of bf16
@@ -540,6 +546,14 @@ class FusedGraphBase(nn.Module):
             self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
         if grp is not None:
             self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
+
+    def dgrad_census(self, reset=False):
+        """{'concat': n, 'fallback': n} of the same-input groups seen by _group_bwd since the last reset (groups laid out for the concatenated
+        data-gradient GEMM only)."""
+        c = dict(self.__dict__.get("_dgrad_census", {"concat": 0, "fallback": 0}))
+        if reset:
+            self.__dict__["_dgrad_census"] = {"concat": 0, "fallback": 0}
+        return c
 
     def _concat_dgrad_operand(self, lins, dys, Ts, grp, M):
         """(dY_cat [M, sum(out)], W^T_cat [in, sum(out)]) when the group's data gradient can run as one K-concatenated GEMM: the transposed

@@ -70,6 +70,8 @@ def load_component(model, component_dir, *, strict=True, rename=None):
                     unexpected.append(name)
                     continue
                 src = f.get_tensor(name)
+                if src.dim() == 4 and dst.dim() == 2 and tuple(src.shape[2:]) == (1, 1) and tuple(src.shape[:2]) == tuple(dst.shape):
+                    src = src[:, :, 0, 0]  # 1x1 Conv2d weights of the diffusers file ([out, in, 1, 1]) held as the [out, in] matrix of a token GEMM (unet.Conv1x1)
                 if tuple(src.shape) != tuple(dst.shape):
                     raise ValueError(f"{name}: checkpoint shape {tuple(src.shape)} != model shape {tuple(dst.shape)}")
                 dst.copy_(src.to(dst.dtype) if src.dtype != dst.dtype and not dst.is_cuda else src, non_blocking=False)

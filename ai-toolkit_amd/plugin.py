@@ -29,6 +29,13 @@ FLUX_SCHEDULER_CONFIG = {"base_image_seq_len": 256, "base_shift": 0.5, "max_imag
 WAN_SCHEDULER_CONFIG = {"num_train_timesteps": 1000, "shift": 3.0, "use_dynamic_shifting": False}
 
 
+def _native_ops():
+    """the kernel table the plug-ins hand to the native graphs they build in load_model (CPU tests inject the oracle table here)"""
+    from . import ops
+
+    return ops
+
+
 def _embeds(text_embeddings):
     """PromptEmbeds-like object (.text_embeds / .pooled_embeds, toolkit/prompt_utils.py) or a (text, pooled) tuple."""
     if hasattr(text_embeddings, "text_embeds"):
@@ -90,8 +97,28 @@ class _PluginBase:
     # ---- "must be implemented in child classes" hooks (base_model.py:306-360)
     _component = None            # diffusers sub-folder of the denoiser ('transformer')
 
-    def _build_native(self):     # -> un-initialised native graph of the architecture the checkpoint holds
+    def _build_native(self, config=None):     # -> un-initialised native graph of the architecture the checkpoint's config.json describes
         raise NotImplementedError
+
+    @staticmethod
+    def _read_config(component_dir):
+        """<component>/config.json of a diffusers checkpoint ({} when absent): the reference's from_pretrained builds the module from it, so
+        FLUX.1-schnell (guidance_embeds false), Wan2.1 14B (40 layers / 40 heads / ffn 13824) or a non-default UNet load as what they are."""
+        import json
+        import os
+
+        f = os.path.join(component_dir, "config.json")
+        if not os.path.exists(f):
+            return {}
+        with open(f) as fh:
+            return json.load(fh)
+
+    @staticmethod
+    def _pick(config, keys):
+        return {k: (tuple(config[k]) if isinstance(config[k], list) else config[k]) for k in keys if k in config and config[k] is not None}
+
+    def _make_scheduler(self):
+        return type(self).get_train_scheduler()
 
     def load_model(self):
         """`model_config.name_or_path` = a diffusers pipeline directory (or the component directory itself, flux_kontext.py:84-92): the
@@ -104,8 +131,9 @@ class _PluginBase:
         path = getattr(cfg, "name_or_path", None)
         if not path:
             raise ValueError("model_config.name_or_path is required")
-        self.model = self._build_native()
-        loader.load_component(self.model, loader.resolve_component_dir(path, self._component))
+        cdir = loader.resolve_component_dir(path, self._component)
+        self.model = self._build_native(self._read_config(cdir))
+        loader.load_component(self.model, cdir)
         for p in self.model.parameters():
             p.requires_grad_(False)
         if getattr(cfg, "quantize", False):
@@ -117,16 +145,29 @@ class _PluginBase:
         except FileNotFoundError:
             vdir = None
         if vdir is not None:
-            self.vae = self._build_vae()
-            loader.load_component(self.vae, vdir, strict=False, rename=lambda k: k if k.startswith(("encoder.", "quant_conv.")) else None)
+            self.vae = self._build_vae(self._read_config(vdir))
+            # only the encoder half is built: decoder.* / post_quant_conv.* of the file are skipped; every encoder tensor must be there
+            missing, _ = loader.load_component(self.vae, vdir, strict=False,
+                                               rename=lambda k: k if k.startswith(("encoder.", "quant_conv.")) else None)
+            if missing:
+                raise KeyError(f"VAE checkpoint {vdir} lacks {len(missing)} encoder tensor(s) of the configured architecture, e.g. {missing[:4]}: "
+                               "encode_images would run on uninitialised weights")
             self.vae.prepare()
-        self.noise_scheduler = self.get_train_scheduler()
+        self.noise_scheduler = self._make_scheduler()
         self.is_loaded = True
 
-    def _build_vae(self):
-        from . import ops, vae as nvae
+    def _build_vae(self, config=None):
+        """AutoencoderKL encoder from vae/config.json (latent_channels, scaling / shift factor, use_quant_conv, widths); without a config
+        the FLUX.1 defaults of the class."""
+        from . import vae as nvae
 
-        return nvae.AutoencoderKLEncoder(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+        ops = _native_ops()
+        kw = self._pick(config or {}, ("latent_channels", "block_out_channels", "layers_per_block", "scaling_factor", "shift_factor", "use_quant_conv"))
+        if config and "norm_num_groups" in config:
+            kw["groups"] = config["norm_num_groups"]
+        if config and config.get("shift_factor", 0.0) is None:
+            kw["shift_factor"] = 0.0
+        return nvae.AutoencoderKLEncoder(dtype=self.torch_dtype, device=self.device_torch, ops=ops, **kw)
 
     def get_generation_pipeline(self):
         raise NotImplementedError("sampling / preview generation is outside the accelerated path (SURVEY.md section 8: out of scope); "
@@ -231,11 +272,13 @@ class Flux1MI355Model(_PluginBase):
     target_lora_modules = ["FluxTransformer2DModel"]
     _component = "transformer"
 
-    def _build_native(self):
-        from . import ops
+    def _build_native(self, config=None):
         from .flux import FluxTransformer2DModel
 
-        return FluxTransformer2DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+        ops = _native_ops()
+        kw = self._pick(config or {}, ("in_channels", "num_layers", "num_single_layers", "attention_head_dim", "num_attention_heads",
+                                       "joint_attention_dim", "pooled_projection_dim", "guidance_embeds", "axes_dims_rope"))
+        return FluxTransformer2DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops, **kw)
 
     @staticmethod
     def get_train_scheduler():
@@ -288,15 +331,20 @@ class Wan21MI355Model(_PluginBase):
     target_lora_modules = ["WanTransformer3DModel"]
     _component = "transformer"
 
-    def _build_native(self):
-        from . import ops
+    def _build_native(self, config=None):
         from .wan import WanTransformer3DModel
 
-        return WanTransformer3DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+        ops = _native_ops()
+        kw = self._pick(config or {}, ("patch_size", "num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "text_dim",
+                                       "freq_dim", "ffn_dim", "num_layers", "eps"))
+        if (config or {}).get("image_dim") or (config or {}).get("added_kv_proj_dim"):
+            raise NotImplementedError("Wan2.1 image-to-video checkpoints (image_dim / added_kv_proj_dim) are not on the fused path: text-to-video only")
+        return WanTransformer3DModel(dtype=self.torch_dtype, device=self.device_torch, ops=ops, **kw)
 
-    def _build_vae(self):
-        from . import ops, wan_vae
+    def _build_vae(self, config=None):
+        from . import wan_vae
 
+        ops = _native_ops()
         return wan_vae.AutoencoderKLWanEncoder(dtype=self.torch_dtype, device=self.device_torch, ops=ops)
 
     @staticmethod
@@ -377,11 +425,29 @@ class StableDiffusionMI355Model(_PluginBase):
 
         return DDPMTrainSchedule()
 
-    def _build_native(self):
-        from . import ops
+    def _build_native(self, config=None):
         from .unet import SD15_CONFIG, SDXL_CONFIG, UNet2DConditionModel
 
-        return UNet2DConditionModel(**(SDXL_CONFIG if self.is_xl else SD15_CONFIG), dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+        ops = _native_ops()
+        base = dict(SDXL_CONFIG if self.is_xl else SD15_CONFIG)
+        over = self._pick(config or {}, tuple(base) + ("norm_num_groups",))
+        if config and (config.get("addition_embed_type") == "text_time") != self.is_xl:
+            raise ValueError(f"unet/config.json says addition_embed_type={config.get('addition_embed_type')!r} but the model was configured as "
+                             f"{'SDXL' if self.is_xl else 'SD1.x'} (model.arch / is_xl)")
+        base.update(over)
+        return UNet2DConditionModel(**base, dtype=self.torch_dtype, device=self.device_torch, ops=ops)
+
+    def _build_vae(self, config=None):
+        """SD1.x / SDXL AutoencoderKL: 4 latent channels, `quant_conv` on the moments, scaling 0.18215 / 0.13025, no shift — read from
+        vae/config.json when present (the FLUX defaults of the encoder class do not apply here)."""
+        cfg = dict(latent_channels=4, use_quant_conv=True, scaling_factor=0.13025 if self.is_xl else 0.18215, shift_factor=0.0)
+        cfg.update({k: v for k, v in (config or {}).items() if v is not None})
+        return super()._build_vae(cfg)
+
+    def _make_scheduler(self):
+        from .ddpm import DDPMTrainSchedule
+
+        return DDPMTrainSchedule(prediction_type=self.prediction_type)  # is_v_pred survives load_model
 
     def get_bucket_divisibility(self):
         return 8  # vae scale factor 8; the UNet's three (SDXL: two) stride-2 levels are covered by the reference's 64-px bucket tolerance

@@ -41,7 +41,8 @@ class Conv1x1(Linear):
     [out, in] matrix the token GEMM multiplies with; state_dict keeps the diffusers [out, in, 1, 1] layout."""
 
     is_conv1x1 = True
-    kernel_size = (1, 1)
+    # the attributes the reference's LoRAModule reads off a Conv2d when it builds the adapter (toolkit/lora_special.py:80-104)
+    kernel_size, stride, padding, dilation, groups = (1, 1), (1, 1), (0, 0), (1, 1), 1
 
     def __init__(self, cin, cout, dtype, device):
         super().__init__(cin, cout, True, dtype, device)
@@ -66,7 +67,7 @@ class Conv3x3(nn.Module):
     """Frozen 3x3 Conv2d (diffusers parameter layout [out, in, 3, 3]); prepare() builds the implicit-GEMM operands:
     wk [out, 9*in] (k = (ky*3+kx)*in + cin) for forward and wd [in, 9*out] (rotated filter, in/out swapped) for the data gradient."""
 
-    kernel_size = (3, 3)
+    kernel_size, padding, dilation, groups = (3, 3), (1, 1), (1, 1), 1
     is_conv3x3 = True  # LoRA discovery: wrapped when network.conv is set (toolkit/lora_special.py:585-590)
 
     def __init__(self, cin, cout, stride, dtype, device, cin_pad=None, cout_pad=None):
@@ -94,6 +95,21 @@ class Conv3x3(nn.Module):
 
     def forward(self, x):
         raise RuntimeError("fused path: executed inside UNet2DConditionModel.forward_native")
+
+    def __setattr__(self, name, value):
+        if name == "forward":  # the reference's LoRAModule.apply_to swaps forward: adopt its module as this layer's adapter (graph.Linear does the same)
+            from .adopt import register_foreign_adapter
+
+            register_foreign_adapter(self, value)
+            return
+        super().__setattr__(name, value)
+
+
+# The reference's adapter discovery goes by CLASS NAME: a child is wrapped when `child.__class__.__name__` is in LINEAR_MODULES / CONV_MODULES
+# (toolkit/lora_special.py:29-40, 488-490), and `kernel_size == (1, 1)` separates the 1x1 projections (linear rank) from the 3x3 convolutions
+# (network.conv rank).  The two holders therefore carry diffusers' class name, so that the reference's OWN LoRASpecialNetwork finds exactly the
+# layers it finds on a diffusers UNet2DConditionModel (state-dict keys and shapes are diffusers' already).
+Conv1x1.__name__ = Conv3x3.__name__ = "Conv2d"
 
 
 class _Norm(nn.Module):

@@ -840,6 +840,16 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
+        # preflight: the collective must actually span the ranks the line will claim.  One all-reduce of ones; every rank
+        # prints what it saw FIRST (stderr), and a job whose communicator is smaller than --gpus stops here instead of timing replicas.
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe, group=pg)
+        seen = int(round(probe.item()))
+        sys.stderr.write(json.dumps({"rccl.ranks": seen, "expected": max(args.gpus, world), "rank": rank, "backend": backend,
+                                     "device": torch.cuda.get_device_name(dev)}) + "\n")
+        sys.stderr.flush()
+        if seen != world or (args.gpus > 1 and seen != args.gpus):
+            raise SystemExit(f"preflight: the all-reduce spans {seen} rank(s), expected {max(args.gpus, world)}: refusing to report a multi-GPU number")
 
     if args.model != "flux":
         if json_fd is not None:  # the UNet legs are single-GPU and print their own line

@@ -18,7 +18,7 @@ class RefLoRAModule(nn.Module):
         super().__init__()
         self.lora_name = lora_name
         self.lora_dim = lora_dim
-        if isinstance(org_module, nn.Conv2d):  # toolkit/lora_special.py:95-104 (UNet: 1x1 proj_in / proj_out of SD1.5)
+        if isinstance(org_module, nn.Conv2d) or org_module.__class__.__name__ == "Conv2d":  # toolkit/lora_special.py:80-104 goes by class name (UNet: 1x1 proj_in / proj_out of SD1.5, 3x3 with network.conv)
             self.lora_down = nn.Conv2d(org_module.in_channels, lora_dim, org_module.kernel_size, org_module.stride, org_module.padding, bias=False)
             self.lora_up = nn.Conv2d(lora_dim, org_module.out_channels, (1, 1), (1, 1), bias=False)
         else:

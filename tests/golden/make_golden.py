@@ -1112,6 +1112,124 @@ def golden_adoption(out_dir=None):
     meta["lokr"] = run("lokr", NetworkConfig(type="lokr", lokr_full_rank=True, lokr_factor=-1), 2, out, warm=True)
     meta["lokr_lowrank"] = run("lokr_lowrank", NetworkConfig(type="lokr", lokr_full_rank=False, linear=4, linear_alpha=4, lokr_factor=-1), 2, out, warm=True)
 
+    # ---- the UNet (kohya-format) branch with network.conv over the StableDiffusion-style plug-in: Conv2d-shaped adapters
+    def run_unet(tag, xl, out):
+        from ai_toolkit_amd.unet import UNet2DConditionModel
+        from oracle import unet_ref
+        from tests.test_unet_cpu import TINY_SD15, TINY_SDXL
+
+        ucfg = TINY_SDXL if xl else TINY_SD15
+        torch.manual_seed(0)
+        ref = unet_ref.UNet2DConditionModel(**ucfg)
+        unet_ref.init_synthetic_(ref, seed=11)
+        nat = UNet2DConditionModel(**ucfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+        nat.load_state_dict(ref.state_dict(), strict=True)
+        nat.prepare()
+        cfg = ModelConfig(name_or_path="/nonexistent", arch="sd_mi355")
+        sd = ext.StableDiffusionMI355("cpu", cfg, dtype="fp32", model=nat, is_xl=xl)
+        assert not sd.is_transformer and not sd.is_flow_matching
+        ncfg = NetworkConfig(type="lora", linear=4, linear_alpha=2.0, conv=2, conv_alpha=1.0)
+        torch.manual_seed(99)
+        net = build_network(cfg, sd, ncfg, is_sdxl=xl)
+        net.force_to(torch.device("cpu"), dtype=torch.float32)
+        sd.network = net
+        net._update_torch_multiplier()
+        net.apply_to(None, sd.unet, False, True)
+        net.prepare_grad_etc(None, sd.unet)
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in net.unet_loras:
+                m.lora_up.weight.copy_((torch.randn(m.lora_up.weight.shape[:2], generator=g) * 0.05).reshape(m.lora_up.weight.shape))
+        params = net.prepare_optimizer_params(text_encoder_lr=1e-3, unet_lr=1e-3, default_lr=1e-3)
+        plist = [p for grp in params for p in grp["params"]]
+        opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+        gen = torch.Generator().manual_seed(4)
+        B, H, W = 2, 16, 8
+        pooled_dim = ucfg["projection_class_embeddings_input_dim"] - 6 * ucfg["addition_time_embed_dim"] if xl else 8
+        losses = []
+        for k in range(2):
+            lat, tgt = torch.randn(B, 4, H, W, generator=gen), torch.randn(B, 4, H, W, generator=gen)
+            pe = SimpleNamespace(text_embeds=torch.randn(B, 7, ucfg["cross_attention_dim"], generator=gen),
+                                 pooled_embeds=torch.randn(B, pooled_dim, generator=gen))
+            opt.zero_grad()
+            with net:
+                pred = sd.predict_noise(lat, text_embeddings=pe, timestep=torch.tensor([640, 17]))
+                loss = torch.nn.functional.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3]).mean()
+                loss.backward()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.detach().clone())
+        assert isinstance(nat.network, AdoptedNetwork) and nat.network.aliasing_intact()
+        out[f"{tag}/losses"] = torch.stack(losses)
+        for i, p in enumerate(plist):
+            out[f"{tag}/param/{i}"] = p.detach().clone()
+        sdict = net.get_state_dict(dtype=torch.float32)
+        for k2, v in sdict.items():
+            out[f"{tag}/saved/{k2}"] = v.clone()
+        return {"names": [m.lora_name for m in net.unet_loras], "saved_keys": list(sdict.keys()), "n_params": len(plist),
+                "peft_format": bool(net.peft_format), "module_class": type(net.unet_loras[0]).__name__,
+                "n_conv3x3": sum(1 for m in net.unet_loras if tuple(m.lora_down.weight.shape[2:]) == (3, 3)),
+                "n_conv1x1": sum(1 for m in net.unet_loras if tuple(m.lora_down.weight.shape[2:]) == (1, 1))}
+
+    # ---- Wan2.1 (BASELINE config 4): block filter from the plug-in's get_transformer_block_names(), keys converted to the original repo's names
+    # on save through the plug-in's convert_lora_weights_before_save hook (toolkit/models/wan21/wan21.py:726-730)
+    def run_wan(tag, out):
+        from ai_toolkit_amd.wan import WanTransformer3DModel
+        from oracle import wan_ref
+        from tests.test_wan_cpu import CFG as WCFG
+
+        torch.manual_seed(0)
+        ref = wan_ref.WanTransformer3DModel(**WCFG)
+        wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+        nat = WanTransformer3DModel(**WCFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+        nat.load_state_dict(ref.state_dict(), strict=True)
+        nat.prepare()
+        cfg = ModelConfig(name_or_path="/nonexistent", arch="wan21_mi355")
+        sd = ext.Wan21MI355("cpu", cfg, dtype="fp32", model=nat)
+        ncfg = NetworkConfig(type="lora", linear=8, linear_alpha=8)
+        torch.manual_seed(99)
+        net = build_network(cfg, sd, ncfg)
+        net.force_to(torch.device("cpu"), dtype=torch.float32)
+        sd.network = net
+        net._update_torch_multiplier()
+        net.apply_to(None, sd.unet, False, True)
+        net.prepare_grad_etc(None, sd.unet)
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for m in net.unet_loras:
+                m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+        params = net.prepare_optimizer_params(text_encoder_lr=1e-3, unet_lr=1e-3, default_lr=1e-3)
+        plist = [p for grp in params for p in grp["params"]]
+        opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+        gen = torch.Generator().manual_seed(3)
+        losses = []
+        for k in range(2):
+            lat, tgt = torch.randn(2, 16, 3, 8, 4, generator=gen), torch.randn(2, 16, 3, 8, 4, generator=gen)
+            pe = SimpleNamespace(text_embeds=torch.randn(2, 5, WCFG["text_dim"], generator=gen), pooled_embeds=None)
+            opt.zero_grad()
+            with net:
+                pred = sd.get_noise_prediction(lat, torch.tensor([310.0, 845.0]), pe)
+                loss = torch.nn.functional.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3, 4]).mean()
+                loss.backward()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.detach().clone())
+        assert isinstance(nat.network, AdoptedNetwork) and nat.network.aliasing_intact()
+        out[f"{tag}/losses"] = torch.stack(losses)
+        for i, p in enumerate(plist):
+            out[f"{tag}/param/{i}"] = p.detach().clone()
+        sdict = net.get_state_dict(dtype=torch.float32)
+        for k2, v in sdict.items():
+            out[f"{tag}/saved/{k2}"] = v.clone()
+        return {"names": [m.lora_name for m in net.unet_loras], "saved_keys": list(sdict.keys()), "n_params": len(plist),
+                "peft_format": bool(net.peft_format), "module_class": type(net.unet_loras[0]).__name__}
+
+    meta["wan"] = run_wan("wan", out)
+    meta["unet_sd15_conv"] = run_unet("unet_sd15_conv", False, out)
+    meta["unet_sdxl_conv"] = run_unet("unet_sdxl_conv", True, out)
+
     # what cannot be adopted raises where the reference attaches it (apply_to), never a base-only model
     refused = {}
     for tag, ncfg, over in (("lorm_use_bias", NetworkConfig(type="lora", linear=4, linear_alpha=4), dict(use_bias=True)),
@@ -1132,7 +1250,7 @@ def golden_adoption(out_dir=None):
     out_dir = out_dir or HERE
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, "adoption_flux_tiny.safetensors"),
               {"meta": json.dumps(meta, sort_keys=True)})
-    print("adoption golden:", {k: (v if k == "refused" else (v["module_class"], v["n_params"], v["sshs_model_hash"][:12])) for k, v in meta.items()})
+    print("adoption golden:", {k: (v if k == "refused" else (v["module_class"], v["n_params"], (v.get("sshs_model_hash") or "")[:12])) for k, v in meta.items()})
 
 
 if __name__ == "__main__":

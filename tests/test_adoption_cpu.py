@@ -414,3 +414,213 @@ def test_plugin_instance_flags_survive_basemodel_init_order():
     assert flags["Flux1MI355"] == {"is_flow_matching": True, "is_transformer": True, "use_old_lokr_format": False}
     assert flags["Wan21MI355"] == {"is_flow_matching": True, "is_transformer": True, "use_old_lokr_format": False}
     assert flags["StableDiffusionMI355"] == {"is_flow_matching": False, "is_transformer": False, "use_old_lokr_format": False}
+
+
+def _adopted_dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    torch.set_num_threads(2)
+    _, nat, sd = native_plugin()
+    net, params, plist = ref_sequence(nat, sd, rank=4)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+    opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ema = [p.detach().clone() for p in plist]
+    for lat, emb, pooled, ts, target in batches(2, B=4):
+        sl = slice(rank * 2, rank * 2 + 2)
+        tsr = torch.tensor([700.0, 250.0, 999.0, 31.0])[sl]
+        trainer_step(net, plist, opt, ema, sd, (lat[sl], emb[sl], pooled[sl], tsr, target[sl]))
+    torch.save(nat.network.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_adopted_network_under_two_ranks_averages_gradients_like_one_rank_on_the_whole_batch(tmp_path):
+    """`accelerate launch` with 2 processes over the unmodified trainer: DDP's autograd hooks never see the explicit backward, so the adopted
+    network all-reduces its gradient arena itself at the end of every backward — replicas bit-identical, equal to one rank on the
+    concatenated batch."""
+    import torch.multiprocessing as mp
+
+    from tests.conftest import free_port
+
+    mp.spawn(_adopted_dp_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
+    assert torch.equal(p0, p1)
+    _, nat, sd = native_plugin()
+    net, params, plist = ref_sequence(nat, sd, rank=4)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+    p_init = torch.cat([p.detach().reshape(-1) for p in plist]).clone()
+    opt = torch.optim.AdamW(params, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    ema = [p.detach().clone() for p in plist]
+    for lat, emb, pooled, ts, target in batches(2, B=4):
+        trainer_step(net, plist, opt, ema, sd, (lat, emb, pooled, torch.tensor([700.0, 250.0, 999.0, 31.0]), target))
+    one = nat.network.arena_p
+    assert torch.allclose(one, p0, rtol=1e-3, atol=2e-6), (one - p0).abs().max()
+    assert not torch.equal(torch.cat([p.detach().reshape(-1) for p in plist]), p_init)
+
+
+@pytest.mark.parametrize("xl", [False, True], ids=["sd15", "sdxl"])
+def test_unet_kohya_network_with_conv_adapters_is_adopted_bit_for_bit(xl):
+    """SD1.5 / SDXL UNets (BASELINE configs 1-2): the reference finds the adapters by CLASS NAME (`Linear`, `Conv2d` with kernel_size (1, 1) or —
+    with network.conv — (3, 3); toolkit/lora_special.py:488-490, 585-590), builds Conv2d-shaped lora_down / lora_up for the convolutions
+    (lora_special.py:95-104) and swaps their forward.  The native UNet's holders carry that class name; the adopted network views the 4-D
+    Conv2d weights inside the same [rank_pad, in*k*k] / [out, rank_pad] arena blocks a FusedLoRANetwork uses.  Same trainer sequence, bit for bit."""
+    from ai_toolkit_amd.plugin import StableDiffusionMI355Model
+    from ai_toolkit_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, TINY_SDXL
+
+    cfg = TINY_SDXL if xl else TINY_SD15
+
+    def native():
+        torch.manual_seed(0)
+        ref = unet_ref.UNet2DConditionModel(**cfg)
+        unet_ref.init_synthetic_(ref, seed=11)
+        nat = UNet2DConditionModel(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+        nat.load_state_dict(ref.state_dict(), strict=True)
+        nat.prepare()
+        return nat, StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, is_xl=xl)
+
+    nat_a, sd_a = native()
+    nat_f, sd_f = native()
+    # the discovery the reference runs: class names only
+    names = {m.__class__.__name__ for m in nat_a.modules()}
+    assert "Conv2d" in names and "Linear" in names and not ({"Conv1x1", "Conv3x3"} & names)
+    torch.manual_seed(99)
+    net_a = lora_ref.RefLoRANetwork(sd_a.get_model_to_train(), 4, 1.0, target=tuple(sd_a.target_lora_modules), kohya_unet=True, alpha=2.0,
+                                    conv_lora_dim=2, conv_alpha=1.0)
+    torch.manual_seed(99)
+    net_f = FusedLoRANetwork(nat_f, lora_dim=4, alpha=2.0, conv_lora_dim=2, conv_alpha=1.0, target_lin_modules=("Transformer2DModel",),
+                             is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl" if xl else "sd1")
+    assert [m.lora_name for m in net_a.unet_loras] == [m.lora_name for m in net_f.unet_loras]
+    n3 = sum(1 for m in net_a.unet_loras if m.lora_down.weight.dim() == 4 and m.lora_down.weight.shape[2:] == (3, 3))
+    n1 = sum(1 for m in net_a.unet_loras if m.lora_down.weight.dim() == 4 and m.lora_down.weight.shape[2:] == (1, 1))
+    assert n3 > 0 and (n1 > 0 or xl)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net_a.unet_loras, net_f.unet_loras):
+            assert torch.equal(a.lora_down.weight.reshape(b.lora_down.weight.shape), b.lora_down.weight), a.lora_name  # same init draws
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.05
+            a.lora_up.weight.copy_(up.reshape(a.lora_up.weight.shape))
+            b.lora_up.weight.copy_(up)
+    net_a.force_to(torch.device("cpu"), torch.float32)
+    sd_a.network = net_a
+    net_a._update_torch_multiplier()
+    net_a.apply_to(None, sd_a.unet, False, True)
+    pa = [p for grp in net_a.prepare_optimizer_params(None, 1e-3, 1e-3) for p in grp["params"]]
+    net_f.apply_to()
+    net_f.build_arena("cpu", groups=nat_f.lora_groups())
+    net_f.refresh_shadows(ref_ops)
+    nat_f.attach_network(net_f)
+    pf = net_f.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    oa, of = torch.optim.AdamW(pa, lr=1e-3, eps=1e-6, weight_decay=0.01), torch.optim.AdamW(pf, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    gen = torch.Generator().manual_seed(4)
+    B, H, W = 2, 16, 8
+    pooled_dim = cfg["projection_class_embeddings_input_dim"] - 6 * cfg["addition_time_embed_dim"] if xl else 8
+    losses = []
+    for k in range(2):
+        lat, tgt = torch.randn(B, 4, H, W, generator=gen), torch.randn(B, 4, H, W, generator=gen)
+        pe = SimpleNamespace(text_embeds=torch.randn(B, 7, cfg["cross_attention_dim"], generator=gen), pooled_embeds=torch.randn(B, pooled_dim, generator=gen))
+        ts = torch.tensor([640, 17])
+        out = []
+        for net, sd, opt, plist in ((net_a, sd_a, oa, pa), (net_f, sd_f, of, pf)):
+            opt.zero_grad()
+            with net:
+                pred = sd.predict_noise(lat, text_embeddings=pe, timestep=ts)
+                loss = torch.nn.functional.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3]).mean()
+                loss.backward()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append(loss.detach())
+        net_f.refresh_shadows(ref_ops)
+        assert torch.equal(out[0], out[1]), (k, out)
+        losses.append(out[1])
+    ad = nat_a.network
+    assert isinstance(ad, AdoptedNetwork) and ad.aliasing_intact() and torch.equal(ad.arena_p, net_f.arena_p)
+    for a, b in zip(pa, pf):
+        assert torch.equal(a.detach().reshape(b.shape), b.detach())
+    # ... and both equal the run of the reference's OWN LoRASpecialNetwork (Conv2d LoRAModules, kohya keys) over the real plug-in class
+    tag = "unet_sdxl_conv" if xl else "unet_sd15_conv"
+    gold = load_file(GOLD)
+    with safe_open(GOLD, "pt") as fh:
+        meta = json.loads(fh.metadata()["meta"])[tag]
+    assert meta["names"] == [m.lora_name for m in net_f.unet_loras] and meta["n_conv3x3"] == n3 and meta["n_conv1x1"] == n1 and not meta["peft_format"]
+    assert torch.equal(torch.stack(losses), gold[f"{tag}/losses"])
+    for i, b in enumerate(pf):
+        assert torch.equal(gold[f"{tag}/param/{i}"].reshape(b.shape), b.detach()), i
+    sf_all = net_f.get_state_dict(dtype=torch.float32)
+    assert list(sf_all) == meta["saved_keys"]
+    for k, v in sf_all.items():
+        assert torch.equal(v, gold[f"{tag}/saved/{k}"]), k
+    # the reference-side state dict (what its get_state_dict walks): Conv2d-shaped tensors with the arena's values
+    sa = {k: v for k, v in net_a.state_dict().items()}
+    sf = net_f.get_state_dict(dtype=torch.float32)
+    for k, v in sf.items():
+        assert torch.equal(sa[k].detach().reshape(v.shape), v), k
+        if k.endswith("lora_down.weight") and v.dim() == 4:
+            assert tuple(sa[k].shape) == tuple(v.shape)
+
+
+def test_wan_network_built_by_the_reference_over_the_wan_plugin_equals_the_fused_twin():
+    """BASELINE config 4: the golden `wan` run is the reference's LoRASpecialNetwork over the real Wan21MI355 plug-in (block filter from
+    get_transformer_block_names(), save keys through convert_lora_weights_before_save: toolkit/models/wan21/wan21.py:726-735)."""
+    from ai_toolkit_amd.plugin import Wan21MI355Model
+    from ai_toolkit_amd.wan import WanTransformer3DModel
+    from oracle import wan_ref
+    from tests.test_wan_cpu import CFG as WCFG
+
+    gold = load_file(GOLD)
+    with safe_open(GOLD, "pt") as fh:
+        meta = json.loads(fh.metadata()["meta"])["wan"]
+    torch.manual_seed(0)
+    ref = wan_ref.WanTransformer3DModel(**WCFG)
+    wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+    nat = WanTransformer3DModel(**WCFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    nat.prepare()
+    sd = Wan21MI355Model("cpu", model=nat, dtype=torch.float32)
+    torch.manual_seed(99)
+    net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, target_lin_modules=tuple(sd.target_lora_modules), transformer_block_names=sd.get_transformer_block_names(),
+                           base_model_version="wan_2.1", base_model=sd)
+    assert [m.lora_name for m in net.unet_loras] == meta["names"] and len(net.unet_loras) == 10 * WCFG["num_layers"]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lora_up.weight.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.05)
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    plist = net.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    opt = torch.optim.AdamW(plist, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    gen = torch.Generator().manual_seed(3)
+    losses = []
+    for k in range(2):
+        lat, tgt = torch.randn(2, 16, 3, 8, 4, generator=gen), torch.randn(2, 16, 3, 8, 4, generator=gen)
+        pe = SimpleNamespace(text_embeds=torch.randn(2, 5, WCFG["text_dim"], generator=gen), pooled_embeds=None)
+        opt.zero_grad()
+        with net:
+            pred = sd.get_noise_prediction(lat, torch.tensor([310.0, 845.0]), pe)
+            loss = torch.nn.functional.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3, 4]).mean()
+            loss.backward()
+        torch.nn.utils.clip_grad_norm_(plist, 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        net.refresh_shadows(ref_ops)
+        losses.append(loss.detach())
+    assert torch.equal(torch.stack(losses), gold["wan/losses"])
+    for i, p in enumerate(plist):
+        assert torch.equal(p.detach(), gold[f"wan/param/{i}"]), i
+    sdict = net.get_state_dict(dtype=torch.float32)
+    assert list(sdict) == meta["saved_keys"] and next(iter(sdict)).startswith("diffusion_model.blocks.0.")
+    for k, v in sdict.items():
+        assert torch.equal(v, gold[f"wan/saved/{k}"]), k

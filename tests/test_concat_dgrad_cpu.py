@@ -44,6 +44,8 @@ def test_group_dgrad_is_one_k_concatenated_launch(monkeypatch):
     assert sum(1 for k, n, k2, f in seen1 if k == 3 * d and n == d and k2 == 3 * 3 * rp) == 2 * n_dbl
     assert not [s for s in seen0 if s[0] in (7 * d, 3 * d)]
     assert len(seen0) - len(seen1) == 3 * n_sgl + 2 * 2 * n_dbl
+    # the census the production graphs are held to: every laid-out group resolved to the concatenated path, none fell back
+    assert nat.dgrad_census() == {"concat": n_sgl + 2 * n_dbl, "fallback": 0}
     # no accumulate-epilogue launches are left among the group data gradients (the remaining ACCUM users are other ops)
     assert sum(1 for s in seen1 if s[3] & 2) < sum(1 for s in seen0 if s[3] & 2)
     for (a0, b0), (a1, b1), m in zip(g0, g1, net.unet_loras):
@@ -69,3 +71,5 @@ def test_concat_falls_back_for_dora(monkeypatch):
     seen, grads, _, _ = _run(monkeypatch, True, network_type="dora")
     assert not [s for s in seen if s[0] in (7 * d, 3 * d)]
     assert all(float(a.abs().max()) > 0 for a, _ in grads)
+    _, _, nat, _ = _run(monkeypatch, True, network_type="dora")
+    assert nat.dgrad_census()["concat"] == 0 and nat.dgrad_census()["fallback"] > 0  # visible, not silent

@@ -52,8 +52,13 @@ def test_step_gradients_and_loss_vs_oracle(rank):
     ref.float()
     # ours
     ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    nat.dgrad_census(reset=True)
     loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
     assert math.isfinite(loss)
+    # every same-input group of the production graph took the K-concatenated data-gradient GEMM (ranks <= 16 per adapter: a group's slab
+    # fits one launch); none fell back to per-layer launches with their different summation order
+    if rank <= 16:
+        assert nat.dgrad_census() == {"concat": CFG["num_single_layers"] + 2 * CFG["num_layers"], "fallback": 0}, nat.dgrad_census()
     assert abs(loss - loss32) <= 1e-3 * abs(loss32), (loss, loss32, loss16)
     mine = []
     for m in net.unet_loras:

@@ -141,7 +141,12 @@ def test_sharded_safetensors_round_trip_and_plugin_load_model(tmp_path, monkeypa
         loader.resolve_component_dir(str(tmp_path / "nope"), "transformer")
     # BaseModel.load_model through the plug-in: model_config.name_or_path -> native graph, frozen, prepared, train scheduler set
     plug = plugin.Flux1MI355Model("cpu", types.SimpleNamespace(name_or_path=str(root), quantize=False, extras_name_or_path=None), dtype="fp32")
-    monkeypatch.setattr(plugin.Flux1MI355Model, "_build_native", lambda self: _tiny_flux(5))
+    # the architecture comes from the checkpoint's own config.json, like the reference's from_pretrained
+    from tests.test_host_graph_cpu import CFG
+
+    with open(root / "transformer" / "config.json", "w") as f:
+        json.dump(dict(CFG, _class_name="FluxTransformer2DModel", guidance_embeds=True, axes_dims_rope=[16, 56, 56]), f)
+    monkeypatch.setattr(plugin, "_native_ops", lambda: __import__("oracle.ref_ops", fromlist=["x"]))
     assert not plug.is_loaded
     plug.load_model()
     assert plug.is_loaded and plug.model._prepared and plug.vae is None and plug.noise_scheduler is not None
@@ -155,3 +160,88 @@ def test_sharded_safetensors_round_trip_and_plugin_load_model(tmp_path, monkeypa
     # save_model: diffusers layout + aitk_meta.yaml (base_model.py:350-360)
     plug.save_model(str(tmp_path / "out"), {"name": "x"}, "bf16")
     assert os.path.exists(tmp_path / "out" / "transformer" / loader.WEIGHTS_NAME) and os.path.exists(tmp_path / "out" / "aitk_meta.yaml")
+
+
+def _ns(path, **kw):
+    return types.SimpleNamespace(name_or_path=str(path), quantize=False, extras_name_or_path=None, **kw)
+
+
+def test_load_model_builds_what_config_json_describes(tmp_path, monkeypatch):
+    """ADVICE r4 (medium x2, low): FLUX.1-schnell (no guidance embedder), a Wan checkpoint of another size, SD / SDXL VAE factors and
+    `quant_conv`, v-prediction surviving load_model, and a VAE file that lacks encoder tensors is refused instead of encoding with noise."""
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from ai_toolkit_amd.unet import UNet2DConditionModel
+    from ai_toolkit_amd.vae import AutoencoderKLEncoder
+    from ai_toolkit_amd.wan import WanTransformer3DModel
+    from oracle import ref_ops
+    from tests.test_host_graph_cpu import CFG
+    from tests.test_unet_cpu import TINY_SDXL
+
+    monkeypatch.setattr(plugin, "_native_ops", lambda: ref_ops)
+
+    def write(model, root, sub, config):
+        torch.manual_seed(11)
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.copy_(torch.randn_like(p_) * 0.05)
+        loader.save_component(model, str(root / sub))
+        with open(root / sub / "config.json", "w") as f:
+            json.dump(config, f)
+
+    # ---- FLUX.1-schnell: guidance_embeds false -> no guidance_embedder tensors in the file, none expected by the model
+    schnell_cfg = dict(CFG, guidance_embeds=False)
+    src = FluxTransformer2DModel(**schnell_cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    assert not any("guidance_embedder" in k for k in src.state_dict())
+    write(src, tmp_path / "schnell", "transformer", dict(schnell_cfg, _class_name="FluxTransformer2DModel"))
+    plug = plugin.Flux1MI355Model("cpu", _ns(tmp_path / "schnell"), dtype="fp32")
+    plug.load_model()
+    assert plug.model.config["guidance_embeds"] is False and plug.model.config["num_layers"] == CFG["num_layers"]
+    g = torch.Generator().manual_seed(0)
+    lat, emb, pooled = torch.randn(1, 16, 4, 4, generator=g), torch.randn(1, 5, CFG["joint_attention_dim"], generator=g), torch.randn(1, CFG["pooled_projection_dim"], generator=g)
+    with torch.no_grad():
+        a = plug.get_noise_prediction(lat, torch.tensor([500.0]), (emb, pooled), guidance_embedding_scale=1.0)
+        b = plug.get_noise_prediction(lat, torch.tensor([500.0]), (emb, pooled), bypass_guidance_embedding=True)
+    assert torch.equal(a, b)  # without the embedder the guidance value cannot matter (diffusers: CombinedTimestepTextProjEmbeddings)
+    # a dev-style config over the schnell file fails loudly on the missing embedder, as before
+    with open(tmp_path / "schnell" / "transformer" / "config.json", "w") as f:
+        json.dump(dict(CFG, guidance_embeds=True), f)
+    with pytest.raises(KeyError, match="guidance_embedder"):
+        plugin.Flux1MI355Model("cpu", _ns(tmp_path / "schnell"), dtype="fp32").load_model()
+    # ---- Wan of another size (the 14B layout differs from the 1.3B one in exactly these keys)
+    wcfg = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=320, num_layers=3, text_dim=64, freq_dim=32)
+    wsrc = WanTransformer3DModel(**wcfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+    write(wsrc, tmp_path / "wan", "transformer", dict(wcfg, _class_name="WanTransformer3DModel", patch_size=[1, 2, 2], in_channels=16, out_channels=16))
+    wplug = plugin.Wan21MI355Model("cpu", _ns(tmp_path / "wan"), dtype="fp32")
+    wplug.load_model()
+    assert len(wplug.model.blocks) == 3 and wplug.model.config["ffn_dim"] == 320
+    with open(tmp_path / "wan" / "transformer" / "config.json", "w") as f:
+        json.dump(dict(wcfg, image_dim=1280), f)
+    with pytest.raises(NotImplementedError, match="image-to-video"):
+        plugin.Wan21MI355Model("cpu", _ns(tmp_path / "wan"), dtype="fp32").load_model()
+    # ---- SDXL-shaped UNet + its VAE: 4 latent channels, quant_conv, 0.13025, no shift; v-prediction kept
+    usrc = UNet2DConditionModel(**TINY_SDXL, dtype=torch.float32, device="cpu", ops=ref_ops)
+    write(usrc, tmp_path / "sdxl", "unet", dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in TINY_SDXL.items()}, _class_name="UNet2DConditionModel"))
+    vkw = dict(latent_channels=4, block_out_channels=(32, 64), layers_per_block=1, scaling_factor=0.13025, shift_factor=0.0, use_quant_conv=True)
+    vsrc = AutoencoderKLEncoder(**vkw, dtype=torch.float32, device="cpu", ops=ref_ops)
+    write(vsrc, tmp_path / "sdxl", "vae", dict(latent_channels=4, block_out_channels=[32, 64], layers_per_block=1, scaling_factor=0.13025, norm_num_groups=32,
+                                               _class_name="AutoencoderKL"))
+    splug = plugin.StableDiffusionMI355Model("cpu", _ns(tmp_path / "sdxl", is_xl=True, is_v_pred=True, arch="sdxl"), dtype="fp32")
+    splug.load_model()
+    assert splug.vae.latent_channels == 4 and splug.vae.quant_conv is not None and splug.vae.scaling_factor == 0.13025 and splug.vae.shift_factor == 0.0
+    assert splug.noise_scheduler.prediction_type == "v_prediction" and splug.prediction_type == "v_prediction"
+    assert splug.model.config["block_out_channels"] == tuple(TINY_SDXL["block_out_channels"])
+    # SD1.x defaults without a vae/config.json: 0.18215
+    os.remove(tmp_path / "sdxl" / "vae" / "config.json")
+    p15 = plugin.StableDiffusionMI355Model("cpu", None, dtype="fp32", is_xl=False)
+    v15 = p15._build_vae({})
+    assert v15.latent_channels == 4 and v15.quant_conv is not None and v15.scaling_factor == 0.18215
+    # a VAE file without the encoder tensors the configured architecture needs is refused (before: silently random weights)
+    from safetensors.torch import load_file, save_file
+
+    f = str(tmp_path / "sdxl" / "vae" / loader.WEIGHTS_NAME)
+    sd = load_file(f)
+    save_file({k: v for k, v in sd.items() if not k.startswith("quant_conv.")}, f)
+    with open(tmp_path / "sdxl" / "vae" / "config.json", "w") as fh:
+        json.dump(dict(latent_channels=4, block_out_channels=[32, 64], layers_per_block=1, scaling_factor=0.13025), fh)
+    with pytest.raises(KeyError, match="encoder tensor"):
+        plugin.StableDiffusionMI355Model("cpu", _ns(tmp_path / "sdxl", is_xl=True, is_v_pred=False, arch="sdxl"), dtype="fp32").load_model()

@@ -253,3 +253,90 @@ def test_latent_multipliers_of_the_trainer():
     l5, _ = run(dict(noisy_latent_multiplier=0.9))
     l6, _ = run({})
     assert l5 != l6 and abs(l5 - l6) < 0.5 * abs(l6)
+
+
+# ---------------------------------------------------------------------------------------------------------------- 8 ranks
+def _item(idx, h, w, n_txt=6):
+    """deterministic synthetic cache entry of image `idx` (latents of its bucket's shape, text embeds, pooled, noise, timestep)"""
+    g = torch.Generator().manual_seed(1000 + idx)
+    return (torch.randn(16, h, w, generator=g), torch.randn(n_txt, CFG["joint_attention_dim"], generator=g) * 0.5,
+            torch.randn(CFG["pooled_projection_dim"], generator=g) * 0.5, torch.randn(16, h, w, generator=g),
+            torch.tensor(float(31 + (idx * 97) % 900)))
+
+
+def _dataset():
+    """three latent bucket shapes with ragged populations (11 / 5 / 9 images): with a global batch of 8 every bucket ends in a short batch
+    that the reference pads by repeating its members (toolkit/buckets.py behaviour restated in ai_toolkit_amd.buckets.build_batch_indices)"""
+    from ai_toolkit_amd import buckets as bk
+
+    shapes = [(8, 4)] * 11 + [(4, 8)] * 5 + [(4, 4)] * 9
+    bks = {}
+    for idx, (h, w) in enumerate(shapes):
+        bks.setdefault(f"{w}x{h}", bk.Bucket(w, h)).file_list_idx.append(idx)
+    return shapes, bks
+
+
+def _stack(idxs, shapes):
+    its = [_item(i, *shapes[i]) for i in idxs]
+    return tuple(torch.stack([it[k] for it in its]) for k in range(5))
+
+
+def _dp8_worker(rank, world, port, out, allreduce_dtype, n_steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+
+    from ai_toolkit_amd import buckets as bk
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    torch.set_num_threads(1)
+    shapes, bks = _dataset()
+    gb = bk.epoch_batches(bks, world, seed=5, epoch=0)  # per-rank batch 1 -> global batch = world
+    mine = bk.shard_batches(gb, rank, world)
+    assert all(len(m) == 1 for m in mine) and len(mine) == len(gb)
+    ref, ref_net, nat, net = build_pair(rank=4)
+    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5, process_group=dist.group.WORLD, allreduce_dtype=allreduce_dtype)
+    seen_shapes = []
+    for idxs in mine[:n_steps]:
+        lat, emb, pooled, noise, ts = _stack(idxs, shapes)
+        seen_shapes.append(tuple(lat.shape[2:]))
+        step.step(lat, emb, pooled, noise=noise, timesteps=ts)
+    torch.save({"p": net.arena_p.clone(), "shapes": seen_shapes, "idx": mine[:n_steps]}, os.path.join(out, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("allreduce_dtype", ["fp32", "bf16"])
+def test_dp8_gloo_ragged_buckets_identical_replicas_and_single_rank_equivalence(tmp_path, allreduce_dtype):
+    """8 ranks (the node the driver scales to), per-rank batch 1, three bucket shapes with ragged populations: every global batch lies in ONE
+    bucket (same latent shape on every rank of a step), short last batches are padded by repetition so the shards stay equal, the steps walk
+    through different shapes, and after 3 steps all 8 replicas hold bit-identical adapters — equal (fp32 transport) to ONE rank stepping the
+    concatenated batches.  Reference behaviour matched: per-process batches + main-process-only logging (BaseSDTrainProcess.py:283, 506, 2708,
+    2813); the gradient averaging itself is ours (the reference's DDP likely never all-reduces)."""
+    from ai_toolkit_amd import buckets as bk
+    from tests.conftest import free_port
+
+    world, n_steps = 8, 3
+    shapes, bks = _dataset()
+    gb = bk.epoch_batches(bks, world, seed=5, epoch=0)
+    assert all(len(b) == world for b in gb) and len(gb) == 2 + 1 + 2           # ceil(11/8) + ceil(5/8) + ceil(9/8)
+    assert all(len({shapes[i] for i in b}) == 1 for b in gb)                    # one bucket shape per global batch
+    assert len({shapes[b[0]] for b in gb[:n_steps]}) >= 2                       # the first steps change shape
+    assert any(len(set(b)) < world for b in gb)                                 # a padded (ragged) batch exists
+    shards = [bk.shard_batches(gb, r, world) for r in range(world)]
+    for k, b in enumerate(gb):
+        assert sorted(i for r in range(world) for i in shards[r][k]) == sorted(b)
+    mp.spawn(_dp8_worker, args=(world, free_port(), str(tmp_path), allreduce_dtype, n_steps), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    for o in outs[1:]:
+        assert torch.equal(o["p"], outs[0]["p"]), "replicas must stay bit-identical"
+        assert o["shapes"] == outs[0]["shapes"]
+    # one rank on the concatenated batches
+    ref, ref_net, nat, net = build_pair(rank=4)
+    p_init = net.arena_p.clone()
+    step = FluxLoRATrainStep(nat, net, ref_ops, lr=1e-3, max_grad_norm=0.5)
+    for b in gb[:n_steps]:
+        lat, emb, pooled, noise, ts = _stack(b, shapes)
+        step.step(lat, emb, pooled, noise=noise, timesteps=ts)
+    d_one, d_dp = net.arena_p - p_init, outs[0]["p"] - p_init
+    rel = ((d_dp - d_one).norm() / d_one.norm()).item()
+    assert rel < (2e-3 if allreduce_dtype == "fp32" else 5e-2), rel
