@@ -242,6 +242,9 @@ def lib():
             raise RuntimeError(f"ABI mismatch: struct {st.__name__} is {C.sizeof(st)} B in Python, {n} B in C")
     L.aitk_lora_wgrad_workspace_bytes.restype = C.c_int64
     L.aitk_lora_wgrad_workspace_bytes.argtypes = [i32, i32, i32]
+    L.aitk_lora_bwd_fused_workspace_bytes.restype = C.c_int64
+    L.aitk_lora_bwd_fused_workspace_bytes.argtypes = [i32, i32, i32]
+    L.aitk_lora_bwd_fused.argtypes = [vp, vp, vp, vp]
     L.aitk_rows_per_block.restype = i32
     L.aitk_mse_workspace_bytes.restype = C.c_int64
     L.aitk_mse_workspace_bytes.argtypes = [i32, i64]

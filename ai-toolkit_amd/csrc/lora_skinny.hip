@@ -355,17 +355,53 @@ __device__ __forceinline__ s16x8_t load_frag_tr(const bf16_t* tile, int pitch, i
   return f;
 }
 
+struct WgradFuse {  // operands of the fused dT partial (lora_wgrad_fused_kernel)
+  const bf16_t* P; const bf16_t* P_lo; long ldp; float* dt_partial;
+};
+
 template <int RB16>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(AitkLoraWgradArgs p, int mc) {
 #define WG_SECOND 0
+#define WG_FUSE 0
 #include "lora_wgrad_body.inc"
+#undef WG_FUSE
 #undef WG_SECOND
 }
 template <int RB16>
 __global__ __launch_bounds__(256) void lora_wgrad2_kernel(AitkLoraWgradArgs p, AitkWgradSrc2 s2, int mc) {
 #define WG_SECOND 1
+#define WG_FUSE 0
 #include "lora_wgrad_body.inc"
+#undef WG_FUSE
 #undef WG_SECOND
+}
+// dB = dY^T T AND the column-tile partials of dT = dY (P + P_lo)^T from ONE pass over dY (aitk_lora_bwd_fused)
+template <int RB16>
+__global__ __launch_bounds__(256) void lora_wgrad_fused_kernel(AitkLoraWgradArgs p, WgradFuse fz, int mc) {
+#define WG_SECOND 0
+#define WG_FUSE 1
+#include "lora_wgrad_body.inc"
+#undef WG_FUSE
+#undef WG_SECOND
+}
+
+// dT[m][r..r+3] = c[m] * sum over the column tiles (fixed order: deterministic) of the partials, written like aitk_lora_down writes it
+// (bf16, or the [hi | lo | hi] K-slab of the rank block; dropout mask applied on the fp32 value)
+__global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p, const float* part, int ntiles) {
+  const int per_row = p.R / 4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * per_row) return;
+  const int m = (int)(idx / per_row), rr = (int)(idx - (long)m * per_row) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < ntiles; ++t) {
+    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(part + ((long)t * p.M + m) * p.R + rr);
+    v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+  }
+  float c = p.scale;
+  if (p.mult) c *= p.mult[m / p.rows_per_batch];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= c;
+  store_t4(p, m, rr, v);
 }
 
 // 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four
@@ -442,6 +478,46 @@ extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2*
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;
   hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// aitk_lora_bwd_fused: both adapter-side products of a layer's backward that stream dY — dT = c (dY (P + P_lo)^T) (aitk_lora_down with
+// X = dY) and lora_up.weight.grad = dY^T T (aitk_lora_wgrad with G = dY) — from ONE read of dY.  Column-tile partials of dT
+// ([L / 128][M][R] fp32, `dt_partial`) are summed in a fixed order by a finish pass that writes dT exactly as aitk_lora_down would.
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int64_t aitk_lora_bwd_fused_workspace_bytes(int32_t M, int32_t R, int32_t L) {
+  return (int64_t)((L + WG_LT - 1) / WG_LT) * M * R * 4;
+}
+
+extern "C" int aitk_lora_bwd_fused(const AitkLoraWgradArgs* a, const AitkLoraDownArgs* d, float* dt_partial, aitk_stream_t stream) {
+  if (!a || !d || a->M <= 0 || a->R <= 0 || a->L <= 0) return AITK_ERR_SHAPE;
+  if ((a->R != 16 && a->R != 32) || (a->L % 8)) return AITK_ERR_SHAPE;  // P fragments live in registers: 16 VGPRs per 16 ranks and precision half
+  if ((a->ldg % 8) || (a->lds % 8) || (d->ldp % 8) || (d->ldt % 4)) return AITK_ERR_ALIGN;
+  if (!a->partial || !a->out || !dt_partial || !d->P || !d->T) return AITK_ERR_ARG;
+  // the two argument blocks must describe the same dY and the same rank block
+  if ((const void*)d->X != (const void*)a->G || d->ldx != a->ldg || d->x_seg_rows != a->g_seg_rows || d->x_seg_stride != a->g_seg_stride) return AITK_ERR_ARG;
+  if (d->M != a->M || d->K != a->L || d->R != a->R) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
+  if (d->split_rp < 0 || (d->split_rp > 0 && ((d->split_rp % 4) || (d->split_rp < d->R && (d->R % d->split_rp))))) return AITK_ERR_ARG;
+  if (d->mult && d->rows_per_batch <= 0) return AITK_ERR_ARG;
+  if (d->tmask && d->split_rp > d->R) return AITK_ERR_ARG;
+  int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
+  if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
+  const int nchunks = (a->M + mc - 1) / mc;
+  const int ntiles = (a->L + WG_LT - 1) / WG_LT;
+  dim3 grid(ntiles, nchunks);
+  hipStream_t s = (hipStream_t)stream;
+  WgradFuse fz{(const bf16_t*)d->P, (const bf16_t*)d->P_lo, (long)d->ldp, dt_partial};
+  if (a->R == 16) hipLaunchKernelGGL(lora_wgrad_fused_kernel<1>, grid, dim3(256), 0, s, *a, fz, mc);
+  else hipLaunchKernelGGL(lora_wgrad_fused_kernel<2>, grid, dim3(256), 0, s, *a, fz, mc);
+  AITK_LAUNCH_CHECK();
+  const long total = (long)a->R * a->L;
+  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
+  AITK_LAUNCH_CHECK();
+  const long nt = (long)d->M * (d->R / 4);
+  hipLaunchKernelGGL(lora_dt_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, *d, (const float*)dt_partial, ntiles);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

@@ -162,6 +162,8 @@ class FusedGraphBase(nn.Module):
         return []
 
     concat_dgrad = os.environ.get("AITK_CONCAT_DGRAD", "1") != "0"
+    # one pass over dY for dT and lora_up.weight.grad (aitk_lora_bwd_fused) instead of aitk_lora_down + aitk_lora_wgrad; 0 = the two launches
+    lora_bwd_fused = os.environ.get("AITK_LORA_BWD_FUSED", "0") != "0"
 
     def prepare(self):
         """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""
@@ -485,9 +487,14 @@ class FusedGraphBase(nn.Module):
         dT = dT_out if dT_out is not None else self._new(M, 3 * rp)
         mult, rpb = self._mult(rows_per_batch, B)
         tm, tm_rpb = getattr(T, "_tmask", (None, 0))
-        ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
-                      tmask_rows_per_batch=tm_rpb)
-        ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
+        if self.lora_bwd_fused and rp in (16, 32) and M >= 2048 and hasattr(ops, "lora_bwd_fused") and dy.dim() == 2 and dy.stride(1) == 1:
+            # dT = c (dy B) and lora_up.weight.grad = dy^T T from ONE read of dy (aitk_lora_bwd_fused) instead of one read each
+            ops.lora_bwd_fused(dy, T, lo.sh_upT, lo.sh_upT_lo, dT, lo.g_up, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, split=rp,
+                               tmask=tm, tmask_rows_per_batch=tm_rpb)
+        else:
+            ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
+                          tmask_rows_per_batch=tm_rpb)
+            ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
         if dT_out is None:
             if isinstance(x_in, _ActInput):  # the input is [g | gelu(pre-activation)] and only the pre-activation was kept
                 assert x_seg is None

@@ -262,6 +262,42 @@ def _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo,
     return out
 
 
+def lora_bwd_fused(dy, T, pmat, p_lo, dT, g_up, *, scale=1.0, mult=None, rows_per_batch=0, M=None, split=0, tmask=None, tmask_rows_per_batch=0,
+                   g_seg=None):
+    """One pass over dy [M, L] for BOTH adapter-side products of a layer's backward that stream it (aitk_lora_bwd_fused):
+         dT [M, 3R] (slab) = scale * mult * (dy @ (pmat + p_lo)[R, L]^T) [* tmask]      — what lora_down(dy, pmat, dT, ...) writes
+         g_up [L, R] (fp32) += dy^T @ T                                                   — what lora_wgrad(T, dy, g_up, transpose_out=True, accumulate=True) adds
+    R = 16 or 32 ranks in one rank block layout (`split`)."""
+    R, L = pmat.shape
+    assert R in (16, 32) and dy.shape[1] == L and tuple(g_up.shape) == (L, R) and g_up.dtype == torch.float32 and g_up.is_contiguous()
+    assert T.shape[1] == (3 * R if split else R) and dT.shape[1] == (3 * R if split else R)
+    M = dy.shape[0] if M is None else M
+    w, d = _capi.LoraWgradArgs(), _capi.LoraDownArgs()
+    w.lds, w.ldg, w.split_rp = _row_major(T, "T"), _row_major(dy, "dy"), int(split)
+    w.out_stride_r, w.out_stride_l = 1, R
+    if g_seg is not None:
+        w.g_seg_rows, w.g_seg_stride = g_seg
+        d.x_seg_rows, d.x_seg_stride = g_seg
+    ws = workspace(_capi.lib().aitk_lora_wgrad_workspace_bytes(M, R, L), dy.device, "wgrad")
+    wsd = workspace(_capi.lib().aitk_lora_bwd_fused_workspace_bytes(M, R, L), dy.device, "bwd_fused")
+    w.S, w.G, w.partial, w.out = _ptr(T), _ptr(dy), _ptr(ws), _ptr(g_up)
+    w.accumulate, w.M, w.R, w.L = 1, M, R, L
+    d.X, d.ldx, d.P, d.ldp, d.T, d.ldt = _ptr(dy), w.ldg, _ptr(pmat), _row_major(pmat, "pmat"), _ptr(dT), _row_major(dT, "dT")
+    if p_lo is not None:
+        assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == d.ldp
+        d.P_lo = _ptr(p_lo)
+    d.split_rp, d.scale = int(split), float(scale)
+    if tmask is not None:
+        assert tmask.dtype == torch.float32 and tmask.is_contiguous() and tmask.shape[1] == R
+        d.tmask, d.tmask_rows_per_batch = _ptr(tmask), int(tmask_rows_per_batch)
+    if mult is not None:
+        assert mult.dtype == torch.float32 and mult.is_contiguous()
+        d.mult, d.rows_per_batch = _ptr(mult), rows_per_batch
+    d.M, d.K, d.R = M, L, R
+    _call("aitk_lora_bwd_fused", C.byref(w), C.byref(d), _ptr(wsd))
+    return dT
+
+
 def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_per_batch=0, M=None):
     """In place on the [hi | lo | hi] slab T [M, 3 rp]: value * mult[m // rows_per_batch] * tmask[m // tmask_rows_per_batch][r], split again
     (a conv adapter's per-sample multiplier / dropout masks: its lora_down comes out of the convolution epilogue with a uniform scale)."""

@@ -168,6 +168,14 @@ typedef struct AitkWgradSrc2 {
   int32_t split_col; int32_t act;
 } AitkWgradSrc2;
 int aitk_lora_wgrad2(const AitkLoraWgradArgs* args, const AitkWgradSrc2* second, aitk_stream_t stream);
+/* The two adapter-side products of a layer's backward that stream dY, from ONE read of it (autograd of toolkit/network_mixins.py:309-321:
+ * lora_up.weight.grad = dY^T T and the gradient of the rank-r activation dT = c (dY B)):
+ *   wgrad : aitk_lora_wgrad's arguments with S = T (slab), G = dY, out = lora_up.weight.grad (strides (1, R))
+ *   down  : aitk_lora_down's arguments with X = dY (the same pointer / pitch / row map as wgrad->G), P / P_lo = lora_up^T shadows, T = dT
+ *   dt_partial : aitk_lora_bwd_fused_workspace_bytes(M, R, L) bytes of scratch ([L / 128][M][R] fp32 column-tile partials of dT, summed in
+ *   a fixed order).  R = 16 or 32.  Results equal the two separate calls up to fp32 summation order of dT. */
+int64_t aitk_lora_bwd_fused_workspace_bytes(int32_t M, int32_t R, int32_t L);
+int aitk_lora_bwd_fused(const AitkLoraWgradArgs* wgrad, const AitkLoraDownArgs* down, float* dt_partial, aitk_stream_t stream);
 /* In place on a [hi(rp) | lo(rp) | hi(rp)] slab T [M, >= 3 rp]: (hi + lo)[m][r] * rowf[m / rows_per_batch] * tmask[m / tmask_rows_per_batch][r],
  * split again (rowf / tmask may be NULL, not both; tmask fp32 [rows, rp], tmask_rows_per_batch 0 = one mask row per slab row).  The per-sample
  * multiplier and the dropout / rank_dropout masks of a 3x3-conv adapter's rank-space activation, whose lora_down leaves the implicit-GEMM

@@ -190,3 +190,48 @@ def test_fused_linear_matches_eager_adapter_and_runtime_scale_updates_apply_on_d
 
     run_fused_vs_eager(ops, torch.bfloat16, "cuda", rank=4)   # the reference's rank; lives in a zero-padded 16-wide rank block
     run_fused_vs_eager(ops, torch.bfloat16, "cuda", rank=8)
+
+
+@pytest.mark.parametrize("M,L,R,opts", [(4608, 3072, 16, {}), (2304 + 17, 12288, 16, {"mult": True}), (2100, 3072, 32, {"tmask": True}),
+                                        (4608, 18432, 16, {}), (2048, 3000, 16, {})])
+def test_lora_bwd_fused_equals_lora_down_plus_lora_wgrad(M, L, R, opts):
+    """aitk_lora_bwd_fused: dT = c (dY (P + P_lo)^T) and lora_up.weight.grad += dY^T T from ONE read of dY.  lora_up.weight.grad is the
+    same code path as aitk_lora_wgrad (bit-identical); dT differs from aitk_lora_down's only in the fp32 summation order (column-tile
+    partials in a fixed order instead of four K-quarters): compared on the fp32 value the [hi | lo | hi] slab carries."""
+    from ai_toolkit_amd import ops
+
+    g = torch.Generator().manual_seed(M + L)
+    dy = (torch.randn(M, L, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = torch.randn(R, L, generator=g) * 0.05
+    p_hi = w.to(torch.bfloat16)
+    p_lo = (w - p_hi.float()).to(torch.bfloat16)
+    p_hi, p_lo = p_hi.cuda(), p_lo.cuda()
+    t = torch.randn(M, R, generator=g) * 0.3
+    t_hi = t.to(torch.bfloat16)
+    T = torch.cat((t_hi, (t - t_hi.float()).to(torch.bfloat16), t_hi), 1).cuda().contiguous()
+    mult = torch.tensor([0.5, -1.5, 2.0], device="cuda") if opts.get("mult") else None
+    rpb = (M + 2) // 3 if mult is not None else 0
+    tmask = ((torch.rand(M, R, generator=g) > 0.3).float() / 0.7).cuda() if opts.get("tmask") else None
+    kw = dict(scale=0.75, mult=mult, rows_per_batch=rpb, M=M, split=R, tmask=tmask, tmask_rows_per_batch=0)
+    g0 = (torch.randn(L, R, generator=g) * 0.01).cuda()
+    dT_a, gu_a = torch.zeros(M, 3 * R, dtype=torch.bfloat16, device="cuda"), g0.clone()
+    ops.lora_down(dy, p_hi, dT_a, p_lo=p_lo, **kw)
+    ops.lora_wgrad(T, dy, gu_a, transpose_out=True, accumulate=True, M=M, split=R)
+    dT_b, gu_b = torch.zeros(M, 3 * R, dtype=torch.bfloat16, device="cuda"), g0.clone()
+    ops.lora_bwd_fused(dy, T, p_hi, p_lo, dT_b, gu_b, **kw)
+    assert torch.equal(gu_a, gu_b)
+    va = dT_a[:, :R].float() + dT_a[:, R:2 * R].float()
+    vb = dT_b[:, :R].float() + dT_b[:, R:2 * R].float()
+    assert torch.equal(dT_b[:, :R], dT_b[:, 2 * R:])
+    want = (dy.float() @ (p_hi.float() + p_lo.float()).t()) * 0.75
+    if mult is not None:
+        want = want * mult.repeat_interleave(rpb)[:M, None]
+    if tmask is not None:
+        want = want * tmask
+    for v in (va, vb):
+        assert ((v - want).norm() / want.norm()).item() < 2e-5
+    assert ((va - vb).norm() / va.norm()).item() < 1e-5
+    # deterministic: a second launch writes the same bits
+    dT_c, gu_c = torch.zeros_like(dT_b), g0.clone()
+    ops.lora_bwd_fused(dy, T, p_hi, p_lo, dT_c, gu_c, **kw)
+    assert torch.equal(dT_b, dT_c) and torch.equal(gu_b, gu_c)

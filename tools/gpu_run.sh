@@ -1,12 +1,12 @@
 #!/bin/bash
 # ONE runner for every gpurun call:  gpurun --timeout T -- 'bash tools/gpu_run.sh TAG task [task ...]'
 # Outputs go to gpurun_out/<TAG>_*.  Tasks (each under its own timeout so a hang cannot take the box's whole budget):
-#   tests:<pytest args>        pytest -m gpu on the given files / -k expression (":" separates words)   -> <TAG>_pytest_<n>.log
+#   tests:<pytest args>        pytest -m gpu on the given files / node ids / -k expression ("," separates words) -> <TAG>_pytest_<n>.log
 #   alltests                   the whole -m gpu tier                                                      -> <TAG>_pytest_gpu_full.log
-#   bench[:<args>]             python bench.py <args> (":" separates words)                              -> <TAG>_bench_<n>.json/.err
+#   bench[:<args>]             python bench.py <args> ("," separates words)                              -> <TAG>_bench_<n>.json/.err
 #   prof[:<args>]              rocprofv3 --kernel-trace --stats around bench.py --no-extras <args>        -> <TAG>_rocprof_kernel_stats.csv
 #   pmc                        three --pmc passes (SQ activity, FETCH_SIZE, WRITE_SIZE) over tools/gpu_pmc_target.py -> <TAG>_pmc_summary.json
-#   py:<script>[:<args>]       python <script> <args>                                                     -> <TAG>_<script>.log
+#   py:<script>[,<args>]       python <script> <args>                                                     -> <TAG>_<script>.log
 #   env:<NAME>=<value>         export for the following tasks
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 export TMPDIR=/tmp
@@ -16,7 +16,7 @@ n=0
 for task in "$@"; do
   n=$((n+1))
   kind="${task%%:*}"; rest=""; [ "$task" != "$kind" ] && rest="${task#*:}"
-  args="${rest//:/ }"
+  args="${rest//,/ }"
   case "$kind" in
     env) export "$rest"; echo "[run] export $rest";;
     tests) timeout 1500 python -m pytest $args -q -m gpu -x --durations=8 > "gpurun_out/${TAG}_pytest_$n.log" 2>&1; echo "[run] tests rc=$?"; tail -30 "gpurun_out/${TAG}_pytest_$n.log" | cut -c1-600;;
@@ -46,7 +46,7 @@ PY
        done
        python tools/pmc_round_summary.py gpurun_out/_pmc "gpurun_out/${TAG}_pmc_summary.json" 32256 48 | tail -40
        rm -rf gpurun_out/_pmc;;
-    py) script="${rest%%:*}"; sargs=""; [ "$rest" != "$script" ] && sargs="${rest#*:}"; sargs="${sargs//:/ }"
+    py) script="${rest%%,*}"; sargs=""; [ "$rest" != "$script" ] && sargs="${rest#*,}"; sargs="${sargs//,/ }"
        b=$(basename "$script" .py)
        timeout 1500 python "$script" $sargs > "gpurun_out/${TAG}_${b}_$n.log" 2>&1; echo "[run] py $script rc=$?"; grep -v "amdgpu.ids" "gpurun_out/${TAG}_${b}_$n.log" | tail -12 | cut -c1-2500;;
     *) echo "[run] unknown task $task";;
