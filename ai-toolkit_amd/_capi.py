@@ -162,7 +162,7 @@ class AdamWArgs(C.Structure):
                 ("norm_partial", vp), ("norm_partial2", vp), ("norm_out", vp), ("n", i64)] + [
         (k, C.c_float) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_correction1",
                                  "bias_correction2_sqrt", "max_norm", "ema_decay", "grad_scale", "ema_feedback", "param_multiplier")] + [
-        ("guard", vp), ("n_micro", i32), ("_pad_micro", i32)]
+        ("guard", vp), ("n_micro", i32), ("_pad_micro", i32), ("beta1_d", C.c_double), ("beta2_d", C.c_double)]
 
 
 class GroupNormArgs(C.Structure):

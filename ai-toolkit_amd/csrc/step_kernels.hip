@@ -300,8 +300,8 @@ __global__ void adamw_decide_kernel(AitkAdamWArgs p, int n2, float* ctl) {
     if (skip) p.guard[4] += 1;
     else p.guard[3] += 1;
     const double step = (double)(p.guard[3] + (skip ? 1 : 0));  // the step this update is (or would have been)
-    bc1 = (float)(1.0 - pow((double)p.beta1, step));
-    bc2s = (float)sqrt(1.0 - pow((double)p.beta2, step));
+    bc1 = (float)(1.0 - pow(p.beta1_d, step));  // the doubles the host's `1 - beta ** step` is made of (float(beta) would not reproduce them)
+    bc2s = (float)sqrt(1.0 - pow(p.beta2_d, step));
   }
   ctl[0] = coef * p.grad_scale;
   ctl[1] = skip ? 1.0f : 0.0f;

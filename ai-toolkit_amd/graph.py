@@ -163,7 +163,7 @@ class FusedGraphBase(nn.Module):
 
     concat_dgrad = os.environ.get("AITK_CONCAT_DGRAD", "1") != "0"
     # one pass over dY for dT and lora_up.weight.grad (aitk_lora_bwd_fused) instead of aitk_lora_down + aitk_lora_wgrad; 0 = the two launches
-    lora_bwd_fused = os.environ.get("AITK_LORA_BWD_FUSED", "0") != "0"
+    lora_bwd_fused = os.environ.get("AITK_LORA_BWD_FUSED", "1") != "0"
 
     def prepare(self):
         """Build the transposed weight copies used by the data-gradient GEMMs (frozen => one-time)."""

@@ -3,6 +3,8 @@ enqueue on the current HIP stream.  No arithmetic happens in Python."""
 import ctypes as C
 import os
 
+import math
+
 import torch
 
 from . import _capi
@@ -612,7 +614,8 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     a.norm_partial, a.norm_out, a.n = _ptr(ws), _ptr(norm_out), n
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, beta1, beta2, eps, weight_decay
     a.bias_correction1 = 1.0 - beta1 ** step
-    a.bias_correction2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    a.bias_correction2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    a.beta1_d, a.beta2_d = float(beta1), float(beta2)
     a.max_norm, a.ema_decay, a.grad_scale = max_norm, ema_decay, grad_scale
     a.ema_feedback, a.param_multiplier = ema_feedback, param_multiplier
     if guard is not None:

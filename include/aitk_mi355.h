@@ -358,6 +358,7 @@ typedef struct AitkAdamWArgs {
    * corrections are then derived on the device from the number of applied steps (guard[3] + 1; bias_correction1 / bias_correction2_sqrt
    * of this struct are ignored), so a skipped step does not advance them — torch.optim.AdamW on parameters without .grad. */
   int32_t* guard; int32_t n_micro; int32_t _pad_micro;
+  double beta1_d, beta2_d; /* the betas in double, as the host's `1 - beta ** step` uses them: with `guard` the device forms the same doubles */
 } AitkAdamWArgs;
 int64_t aitk_adamw_workspace_bytes(int64_t n);
 int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);

@@ -19,7 +19,7 @@ for task in "$@"; do
   args="${rest//,/ }"
   case "$kind" in
     env) export "$rest"; echo "[run] export $rest";;
-    tests) timeout 1500 python -m pytest $args -q -m gpu -x --durations=8 > "gpurun_out/${TAG}_pytest_$n.log" 2>&1; echo "[run] tests rc=$?"; tail -30 "gpurun_out/${TAG}_pytest_$n.log" | cut -c1-600;;
+    tests) timeout 1500 python -m pytest $args -q -m gpu --durations=8 > "gpurun_out/${TAG}_pytest_$n.log" 2>&1; echo "[run] tests rc=$?"; tail -30 "gpurun_out/${TAG}_pytest_$n.log" | cut -c1-600;;
     alltests) timeout 2400 python -m pytest tests -q -m gpu --durations=15 > "gpurun_out/${TAG}_pytest_gpu_full.log" 2>&1; echo "[run] alltests rc=$?"; tail -25 "gpurun_out/${TAG}_pytest_gpu_full.log" | cut -c1-400;;
     bench) timeout 1200 python bench.py $args > "gpurun_out/${TAG}_bench_$n.json" 2> "gpurun_out/${TAG}_bench_$n.err"; echo "[run] bench rc=$?"; tail -2 "gpurun_out/${TAG}_bench_$n.err" | cut -c1-400
        python - "gpurun_out/${TAG}_bench_$n.json" <<'PY'
