@@ -36,6 +36,66 @@ def _native_ops():
     return ops
 
 
+class PromptEmbeds:
+    """Mirror of the reference's container (toolkit/prompt_utils.py:23-100: `.text_embeds`, `.pooled_embeds`, `.attention_mask`, `to`, `detach`,
+    `clone`) for code that runs without the reference importable; as a real plug-in the reference's own class is returned."""
+
+    def __init__(self, args, attention_mask=None):
+        if isinstance(args, (list, tuple)):
+            self.text_embeds, self.pooled_embeds = args[0], args[1]
+        else:
+            self.text_embeds, self.pooled_embeds = args, None
+        self.attention_mask = attention_mask
+
+    def _map(self, fn):
+        out = PromptEmbeds([fn(self.text_embeds), None if self.pooled_embeds is None else fn(self.pooled_embeds)],
+                           None if self.attention_mask is None else fn(self.attention_mask))
+        return out
+
+    def to(self, *a, **k):
+        n = self._map(lambda t: t.to(*a, **k))
+        self.text_embeds, self.pooled_embeds, self.attention_mask = n.text_embeds, n.pooled_embeds, n.attention_mask
+        return self
+
+    def detach(self):
+        return self._map(lambda t: t.detach())
+
+    def clone(self):
+        return self._map(lambda t: t.clone())
+
+
+def _prompt_embeds_class():
+    try:
+        from toolkit.prompt_utils import PromptEmbeds as Ref  # the reference's own container when it is importable (real plug-in)
+
+        return Ref
+    except Exception:  # noqa: BLE001
+        return PromptEmbeds
+
+
+def encode_prompts_flux(tokenizer, text_encoder, prompts, truncate=True, max_length=None, dropout_prob=0.0, attn_mask=False):
+    """toolkit/train_tools.py:510-574 restated: CLIP-L pooled output + T5 last hidden state (max_length 512) for FLUX.  `tokenizer` /
+    `text_encoder` = [CLIP, T5] pairs of `transformers` objects.  LIBRARY PATH: the text encoders run through
+    `transformers` on PyTorch-ROCm, once per caption when the text-embedding cache is filled — they are not part of the per-step hot path and
+    are not re-implemented as HIP kernels; the fused step consumes the embeddings this returns (or the reference's `_t_e_cache` files)."""
+    if max_length is None:
+        max_length = 512
+    if dropout_prob > 0.0:
+        prompts = [p if torch.rand(1).item() > dropout_prob else "" for p in prompts]
+    device, dtype = text_encoder[0].device, text_encoder[0].dtype
+    ti = tokenizer[0](prompts, padding="max_length", max_length=tokenizer[0].model_max_length, truncation=True, return_overflowing_tokens=False,
+                      return_length=False, return_tensors="pt")
+    pooled = text_encoder[0](ti.input_ids.to(device), output_hidden_states=False).pooler_output.to(dtype=dtype, device=device)
+    ti = tokenizer[1](prompts, padding="max_length", max_length=max_length, truncation=True, return_length=False, return_overflowing_tokens=False,
+                      return_tensors="pt")
+    embeds = text_encoder[1](ti.input_ids.to(device), output_hidden_states=False)[0]
+    embeds = embeds.to(dtype=text_encoder[1].dtype, device=device)
+    if attn_mask:
+        m = ti["attention_mask"].unsqueeze(-1).expand(embeds.shape)
+        embeds = embeds * m.to(dtype=embeds.dtype, device=embeds.device)
+    return embeds, pooled
+
+
 def _embeds(text_embeddings):
     """PromptEmbeds-like object (.text_embeds / .pooled_embeds, toolkit/prompt_utils.py) or a (text, pooled) tuple."""
     if hasattr(text_embeddings, "text_embeds"):
@@ -295,6 +355,42 @@ class Flux1MI355Model(_PluginBase):
 
     def get_transformer_block_names(self):
         return ["transformer_blocks", "single_transformer_blocks"]
+
+    def load_text_encoders(self, path=None):
+        """CLIP-L (`text_encoder` / `tokenizer`) and T5 (`text_encoder_2` / `tokenizer_2`) of a diffusers FLUX pipeline directory through
+        `transformers` (flux_kontext.py:120-170 loads the same four sub-folders) — only when prompts must be encoded here (no text-embedding
+        cache); frozen, model dtype, on the plug-in's device.  Library path, see encode_prompts_flux."""
+        import os
+
+        from transformers import CLIPTextModel, CLIPTokenizer, T5EncoderModel, T5TokenizerFast
+
+        cfg = self.model_config
+        path = path or getattr(cfg, "extras_name_or_path", None) or getattr(cfg, "name_or_path", None)
+        for sub in ("tokenizer", "tokenizer_2", "text_encoder", "text_encoder_2"):
+            if not os.path.isdir(os.path.join(str(path), sub)):
+                raise FileNotFoundError(f"{path!r} has no '{sub}' sub-folder: prompts cannot be encoded here — train with cached text embeddings "
+                                        "(datasets: cache_text_embeddings: true)")
+        kw = dict(local_files_only=True)
+        self.tokenizer = [CLIPTokenizer.from_pretrained(path, subfolder="tokenizer", **kw), T5TokenizerFast.from_pretrained(path, subfolder="tokenizer_2", **kw)]
+        te = [CLIPTextModel.from_pretrained(path, subfolder="text_encoder", torch_dtype=self.torch_dtype, **kw),
+              T5EncoderModel.from_pretrained(path, subfolder="text_encoder_2", torch_dtype=self.torch_dtype, **kw)]
+        for m in te:
+            m.to(self.te_device_torch).requires_grad_(False).eval()
+        self.text_encoder = te
+        return te
+
+    def get_prompt_embeds(self, prompt, control_images=None):
+        """flux_kontext.py:354-367: encode_prompts_flux(tokenizer, text_encoder, prompt, max_length=512) -> PromptEmbeds(text) + pooled_embeds.
+        Encoders are loaded on first use (load_text_encoders) or taken from `self.text_encoder` / `self.tokenizer` if the caller set them."""
+        if not self.text_encoder or not self.tokenizer:
+            self.load_text_encoders()
+        if not isinstance(prompt, (list, tuple)):
+            prompt = [prompt]
+        with torch.no_grad():
+            embeds, pooled = encode_prompts_flux(self.tokenizer, self.text_encoder, list(prompt), max_length=512)
+        pe = _prompt_embeds_class()(embeds)
+        pe.pooled_embeds = pooled
+        return pe
 
     def get_noise_prediction(self, latent_model_input, timestep, text_embeddings, guidance_embedding_scale=1.0,
                              bypass_guidance_embedding=False, **kwargs):

@@ -1253,6 +1253,155 @@ def golden_adoption(out_dir=None):
     print("adoption golden:", {k: (v if k == "refused" else (v["module_class"], v["n_params"], (v.get("sshs_model_hash") or "")[:12])) for k, v in meta.items()})
 
 
+def golden_flux_glue():
+    """Pins the FLUX glue that only diffusers' (un-vendored) classes spell out — adaLN chunk order, the final layer's (scale, shift) order, the
+    timestep-embedding layout and the embedder composition — against code the reference DOES hold:
+
+      * scripts/convert_diffusers_to_comfy.py: its `diffusers_map` (diffusers key -> BFL key, which tensors are concatenated in which order) and
+        `swap_scale_shift` — extracted from the script by AST and EXECUTED (the script itself is a CLI that runs at import);
+      * extensions_built_in/diffusion_models/flux2/src/model.py: the in-tree BFL-lineage `Modulation` (lin(silu(vec)).chunk -> shift, scale, gate
+        [x2]), `LastLayer` (shift, scale = chunk(2); (1 + scale) * norm(x) + shift), `MLPEmbedder`, `timestep_embedding`;
+      * toolkit/models/flux.py: `guidance_embed_bypass_forward` (conditioning = timestep_embedder(time_proj(t)) + text_embedder(pooled)).
+
+    Recorded: inputs, the weights in diffusers naming, and the outputs of the REFERENCE-side modules loaded through the converter's mapping.
+    tests/test_flux_glue_golden.py runs the oracle's diffusers-named restatement (and the native graph's pieces) on the same inputs."""
+    import ast
+    import importlib.util
+
+    src = open(os.path.join(ref_shims.REFERENCE, "scripts", "convert_diffusers_to_comfy.py")).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "swap_scale_shift":
+            exec(compile(ast.Module([node], []), "convert_diffusers_to_comfy.py", "exec"), ns)
+        if isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id == "diffusers_map" for t in node.targets):
+            exec(compile(ast.Module([node], []), "convert_diffusers_to_comfy.py", "exec"), ns)
+    dmap, swap = ns["diffusers_map"], ns["swap_scale_shift"]
+    spec = importlib.util.spec_from_file_location("flux2_model_ref", os.path.join(ref_shims.REFERENCE, "extensions_built_in", "diffusion_models", "flux2", "src", "model.py"))
+    f2 = importlib.util.module_from_spec(spec)
+    sys.modules["flux2_model_ref"] = f2
+    spec.loader.exec_module(f2)
+    from toolkit.models.flux import guidance_embed_bypass_forward
+
+    d, B, S = 64, 2, 5
+    g = torch.Generator().manual_seed(123)
+    rnd = lambda *sh: torch.randn(*sh, generator=g)  # noqa: E731
+    out = {}
+    # ---- the map itself: which diffusers tensors make which BFL tensor, in which order
+    meta = {"img_mod": dmap["double_blocks.().img_mod.lin.weight"], "txt_mod": dmap["double_blocks.().txt_mod.lin.weight"],
+            "single_mod": dmap["single_blocks.().modulation.lin.weight"], "img_qkv": dmap["double_blocks.().img_attn.qkv.weight"],
+            "txt_qkv": dmap["double_blocks.().txt_attn.qkv.weight"], "single_linear1": dmap["single_blocks.().linear1.weight"],
+            "final_mod": dmap["final_layer.adaLN_modulation.1.weight"], "final_linear": dmap["final_layer.linear.weight"],
+            "time_in": [dmap["time_in.in_layer.weight"], dmap["time_in.out_layer.weight"]],
+            "vector_in": [dmap["vector_in.in_layer.weight"], dmap["vector_in.out_layer.weight"]],
+            "guidance_in": [dmap["guidance_in.in_layer.weight"], dmap["guidance_in.out_layer.weight"]]}
+    # ---- AdaLayerNormZero (norm1 / norm1_context) == BFL Modulation(double) with the SAME weight (the converter copies it un-swapped)
+    vec, x = rnd(B, d), rnd(B, S, d)
+    w6, b6 = rnd(6 * d, d) * 0.2, rnd(6 * d) * 0.1
+    mod = f2.Modulation(d, double=True)
+    with torch.no_grad():
+        mod.lin.weight.copy_(w6)
+        mod.lin.bias.copy_(b6)
+        (sh1, sc1, g1), (sh2, sc2, g2) = mod(vec)
+        ln = torch.nn.functional.layer_norm(x, (d,), eps=1e-6)
+        out.update({"zero/vec": vec, "zero/x": x, "zero/linear.weight": w6, "zero/linear.bias": b6, "zero/x_mod": (1 + sc1) * ln + sh1,
+                    "zero/gate_msa": g1[:, 0], "zero/shift_mlp": sh2[:, 0], "zero/scale_mlp": sc2[:, 0], "zero/gate_mlp": g2[:, 0]})
+        # ---- AdaLayerNormZeroSingle == Modulation(single)
+        w3, b3 = rnd(3 * d, d) * 0.2, rnd(3 * d) * 0.1
+        ms = f2.Modulation(d, double=False)
+        ms.lin.weight.copy_(w3)
+        ms.lin.bias.copy_(b3)
+        (sh, sc, gt), _none = ms(vec)
+        out.update({"single/linear.weight": w3, "single/linear.bias": b3, "single/x_mod": (1 + sc) * ln + sh, "single/gate": gt[:, 0]})
+        # ---- norm_out + proj_out == LastLayer with adaLN weight = swap_scale_shift(norm_out.linear.weight)
+        w2, wp = rnd(2 * d, d) * 0.2, rnd(16, d) * 0.2
+        last = f2.LastLayer(d, 16)
+        last.adaLN_modulation[1].weight.copy_(swap(w2))
+        last.linear.weight.copy_(wp)
+        out.update({"final/norm_out.linear.weight": w2, "final/proj_out.weight": wp, "final/out": last(x, vec)})
+        # ---- timestep embedding + embedder MLP (time_in <- time_text_embed.timestep_embedder.linear_1 / linear_2)
+        t = torch.tensor([0.3, 0.8])
+        out["temb/t"] = t
+        out["temb/proj"] = f2.timestep_embedding(t, 256)  # time_factor 1000 inside: diffusers is handed t * 1000
+        emb = f2.MLPEmbedder(256, d)
+        for p_ in emb.parameters():
+            p_.copy_(rnd(*p_.shape) * 0.1)
+        out.update({"temb/linear_1.weight": emb.in_layer.weight.detach().clone(), "temb/linear_1.bias": emb.in_layer.bias.detach().clone(),
+                    "temb/linear_2.weight": emb.out_layer.weight.detach().clone(), "temb/linear_2.bias": emb.out_layer.bias.detach().clone(),
+                    "temb/out": emb(out["temb/proj"])})
+        # ---- the embedder composition of the bypass path, executed on the oracle's diffusers-named module by the reference's own function
+        torch.manual_seed(5)
+        tte = flux_ref.CombinedTimestepGuidanceTextProjEmbeddings(d, 32)
+        pooled = rnd(B, 32)
+        out["bypass/pooled"] = pooled
+        for k, v in tte.state_dict().items():
+            out[f"bypass/sd/{k}"] = v.clone()
+        out["bypass/conditioning"] = guidance_embed_bypass_forward(tte, t * 1000, None, pooled)
+    save_file({k: v.detach().contiguous() for k, v in out.items()}, os.path.join(HERE, "flux_glue.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
+    print("flux glue golden:", len(out), "tensors;", {k: v for k, v in meta.items() if k in ("img_qkv", "single_linear1", "final_mod")})
+
+
+class HashTokenizer:
+    """Deterministic stand-in for a `transformers` tokenizer (no vocabulary files in this image): words -> ids by a fixed hash, padded /
+    truncated to max_length, with the call signature and return fields encode_prompts_flux uses.  Shared with tests/test_text_encoders_cpu.py."""
+
+    def __init__(self, vocab_size, model_max_length, pad_id=0, eos_id=1):
+        self.vocab_size, self.model_max_length, self.pad_id, self.eos_id = vocab_size, model_max_length, pad_id, eos_id
+
+    def __call__(self, prompts, padding=None, max_length=None, truncation=True, return_tensors="pt", **kw):
+        import hashlib
+        from types import SimpleNamespace
+
+        ids, mask = [], []
+        for p in prompts:
+            toks = [2 + int(hashlib.sha256(w.encode()).hexdigest(), 16) % (self.vocab_size - 2) for w in p.split()][: max_length - 1] + [self.eos_id]
+            mask.append([1] * len(toks) + [0] * (max_length - len(toks)))
+            ids.append(toks + [self.pad_id] * (max_length - len(toks)))
+        out = SimpleNamespace(input_ids=torch.tensor(ids), attention_mask=torch.tensor(mask))
+        out.__getitem__ = None
+        return _TokOut(out.input_ids, out.attention_mask)
+
+
+class _TokOut(dict):
+    def __init__(self, input_ids, attention_mask):
+        super().__init__(input_ids=input_ids, attention_mask=attention_mask)
+        self.input_ids, self.attention_mask = input_ids, attention_mask
+
+
+def tiny_text_encoders(seed=31):
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+
+    torch.manual_seed(seed)
+    clip = CLIPTextModel(CLIPTextConfig(vocab_size=99, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                        max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)).eval()
+    t5 = T5EncoderModel(T5Config(vocab_size=101, d_model=24, d_kv=8, d_ff=48, num_layers=2, num_heads=3, is_encoder_decoder=False, use_cache=False)).eval()
+    toks = [HashTokenizer(99, 16), HashTokenizer(101, 512)]
+    return toks, [clip, t5]
+
+
+PROMPTS = ["a photo of a red fox in the snow", "", "two words"]
+
+
+def golden_text_encoders():
+    """Row a17 (toolkit/train_tools.py:510-574): the reference's own encode_prompts_flux executed on tiny random CLIP / T5 text encoders of the
+    `transformers` classes it uses, with a deterministic stand-in tokenizer — pins the restatement in ai_toolkit_amd/plugin.py (which pads CLIP to
+    tokenizer.model_max_length, T5 to 512, takes CLIP's pooler_output and T5's last hidden state, optional attention masking)."""
+    sys.modules.setdefault("info", __import__("types").SimpleNamespace(software_meta={"name": "ai-toolkit"}))
+    ref_shims.install_stub_finder(("controlnet_aux", "PIL", "imageio", "librosa", "soundfile", "pytorch_wavelets", "torchdiffeq", "gguf",
+                                   "huggingface_hub", "accelerate", "flatten_json", "pytorch_fid", "clip", "scipy", "tqdm", "yaml",
+                                   "ftfy", "sentencepiece", "omegaconf", "moviepy", "decord"))
+    from toolkit.train_tools import encode_prompts_flux
+
+    toks, tes = tiny_text_encoders()
+    out = {}
+    with torch.no_grad():
+        for tag, kw in (("plain", {}), ("masked", {"attn_mask": True}), ("len64", {"max_length": 64})):
+            emb, pooled = encode_prompts_flux(toks, tes, list(PROMPTS), **kw)
+            out[f"{tag}/embeds"], out[f"{tag}/pooled"] = emb.clone(), pooled.clone()
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "text_encoders_flux.safetensors"))
+    print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:
@@ -1278,3 +1427,5 @@ if __name__ == "__main__":
     golden_flowmatch()
     golden_wan_lora_keys()
     golden_adoption()
+    golden_flux_glue()
+    golden_text_encoders()

@@ -154,9 +154,11 @@ def test_sharded_safetensors_round_trip_and_plugin_load_model(tmp_path, monkeypa
     assert torch.equal(plug.model.x_embedder.weight, src.x_embedder.weight.to(torch.bfloat16).float())
     assert plug.unet is plug.model and plug.transformer is plug.model and plug.get_model_to_train() is plug.model
     # the refused hooks say why
-    for call in (plug.get_generation_pipeline, lambda: plug.get_prompt_embeds("a photo"), lambda: plug.encode_audio([])):
+    for call in (plug.get_generation_pipeline, lambda: plug.encode_audio([])):
         with pytest.raises(NotImplementedError):
             call()
+    with pytest.raises(FileNotFoundError, match="cache_text_embeddings"):  # no text_encoder / tokenizer folders in this checkpoint directory
+        plug.get_prompt_embeds("a photo")
     # save_model: diffusers layout + aitk_meta.yaml (base_model.py:350-360)
     plug.save_model(str(tmp_path / "out"), {"name": "x"}, "bf16")
     assert os.path.exists(tmp_path / "out" / "transformer" / loader.WEIGHTS_NAME) and os.path.exists(tmp_path / "out" / "aitk_meta.yaml")
