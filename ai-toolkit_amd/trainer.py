@@ -95,6 +95,13 @@ class _LoRATrainStepBase:
         self._split = model.grad_split_offset(network)
         model.grad_ready_hook = None  # set per backward pass (only the last micro-batch issues the all-reduce)
 
+    def set_step_count(self, n):
+        """Number of optimizer steps applied so far (AdamW's bias corrections count from it).  With the failure guard the count lives on the
+        device (guard[3]: a skipped step does not advance it), so resuming from a checkpoint or replaying a step sets both copies."""
+        self.step_num = int(n)
+        if self.guard is not None:
+            self.guard[3:4].fill_(int(n))
+
     def guard_counters(self):
         """{'nonfinite_losses', 'clamped_losses', 'steps_applied', 'steps_skipped', 'last_step_skipped'} read back from the device (host sync)."""
         if self.guard is None:

@@ -168,7 +168,7 @@ def test_full_model_determinism_zero_adapter_and_batch_independence():
     net.arena_p.copy_(p0)
     net.arena_m.copy_(m0)
     net.arena_v.copy_(v0)
-    step.step_num = n0
+    step.set_step_count(n0)  # host copy + the device-resident count of applied steps
     net.refresh_shadows(ops)
     l2 = step.step(lat, emb, pooled, noise=noise, timesteps=ts)
     assert torch.equal(l1, l2) and torch.equal(net.arena_p, p1)

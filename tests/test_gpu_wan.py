@@ -166,7 +166,7 @@ def test_wan_step_is_bitwise_reproducible_and_zero_adapter_is_base():
     net.arena_m.zero_()
     net.arena_v.zero_()
     net.refresh_shadows(ops)
-    ours.step_num = 0
+    ours.set_step_count(0)  # host copy + the device-resident count of applied steps
     l2 = ours.step(lat, txt, noise=noise, timesteps=ts)
     assert torch.equal(l1, l2) and torch.equal(g1, net.arena_g) and torch.equal(p1, net.arena_p)
     # adapter with lora_up = 0 (the reference's init) predicts exactly like the base model
