@@ -385,6 +385,150 @@ __global__ __launch_bounds__(256) void lora_wgrad_fused_kernel(AitkLoraWgradArgs
 #undef WG_SECOND
 }
 
+// Second form of the fused pass: one workgroup walks CT consecutive 128-column tiles of its row chunk, so the dT partial of a 64-row sub-tile is
+// accumulated over CT * 128 columns in registers before it is written: the partial traffic ([column group][M][R] fp32, written and read back by
+// the finish pass) shrinks by CT — at 128 columns per partial it is HALF the bytes of dY itself at rank 16 (measured: lora_dt_finish 7.5 ms per
+// step).  dB accumulators: one set per column tile (CT * RB16 * 8 registers); the tile's P / P_lo slices sit in LDS for the whole row chunk.
+// Same register-prefetched staging as the wgrad body, linearised over (sub-tile, column tile).  dB stays bit-identical to aitk_lora_wgrad.
+template <int RB16, int CT>
+__global__ __launch_bounds__(256) void lora_bwd_fused_ct_kernel(AitkLoraWgradArgs p, WgradFuse fz, int mc) {
+  constexpr int PP = CT * WG_LT + 8;  // LDS pitch of the P slices (elements): + 16 B per row spreads the rows over the banks
+  __shared__ __attribute__((aligned(16))) bf16_t gt[64 * WG_GPITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t st[2 * 64 * WG_SPITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t pt[2 * RB16 * 16 * PP];  // [hi | lo][rank][CT * 128 columns]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int lbase = blockIdx.x * (CT * WG_LT);
+  const bool split = p.split_rp > 0;
+  const int mbeg = blockIdx.y * mc;
+  const int mend = min(p.M, mbeg + mc);
+  constexpr int R = RB16 * 16;
+
+  f32x4_t acc[CT][RB16][2];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int a = 0; a < RB16; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[c][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  {  // P / P_lo slices of this column group -> LDS (zero beyond L; P_lo may be absent)
+    constexpr int CW8 = CT * WG_LT / 8;
+    for (int q = tid; q < 2 * R * CW8; q += 256) {
+      const int half = q / (R * CW8), rem = q - half * (R * CW8);
+      const int r = rem / CW8, c8 = rem - r * CW8;
+      const int col = lbase + c8 * 8;
+      const bf16_t* src = half ? fz.P_lo : fz.P;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (src && col < p.L) v = *reinterpret_cast<const uint4*>(src + (long)r * fz.ldp + col);
+      *reinterpret_cast<uint4*>(pt + (half * R + r) * PP + c8 * 8) = v;
+    }
+  }
+  const int chunks_per_row = R / 8;
+  uint4 rg[4], rs[2], rl[2];
+  auto load_regs = [&](int ms, int l0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q >> 4, ch = q & 15;
+      const int m = ms + row, col = l0 + ch * 8;
+      rg[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend && col < p.L) rg[i] = *reinterpret_cast<const uint4*>(seg_row2(p.G, p.ldg, p.g_seg_rows, p.g_seg_stride, m) + col);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
+      rs[i] = make_uint4(0, 0, 0, 0);
+      rl[i] = make_uint4(0, 0, 0, 0);
+      if (q < 64 * chunks_per_row && ms + row < mend) {
+        const int r = ch * 8, blk = split ? r / p.split_rp : 0;
+        const bf16_t* src = p.S + (long)(ms + row) * p.lds + r + 2 * blk * p.split_rp;
+        rs[i] = *reinterpret_cast<const uint4*>(src);
+        if (split) rl[i] = *reinterpret_cast<const uint4*>(src + p.split_rp);
+      }
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      *reinterpret_cast<uint4*>(gt + (q >> 4) * WG_GPITCH + (q & 15) * 8) = rg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 256 * i;
+      const int row = q / chunks_per_row, ch = q - row * chunks_per_row;
+      if (q < 64 * chunks_per_row) {
+        *reinterpret_cast<uint4*>(st + row * WG_SPITCH + ch * 8) = rs[i];
+        if (split) *reinterpret_cast<uint4*>(st + 64 * WG_SPITCH + row * WG_SPITCH + ch * 8) = rl[i];
+      }
+    }
+  };
+  load_regs(mbeg, lbase);
+  for (int ms = mbeg; ms < mend; ms += 64) {
+    f32x4_t dt[RB16];
+#pragma unroll
+    for (int rb = 0; rb < RB16; ++rb) dt[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      write_lds();
+      __syncthreads();  // also publishes pt on the first pass
+      if (ct + 1 < CT) load_regs(ms, lbase + (ct + 1) * WG_LT);
+      else if (ms + 64 < mend) load_regs(ms + 64, lbase);
+      // dT partial over this tile's 128 columns: D rows = ranks 4 g .. 4 g + 3, column = dY row i
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const s16x8_t yf = *reinterpret_cast<const s16x8_t*>(gt + (wave * 16 + i16) * WG_GPITCH + k4 * 32 + 8 * g4);
+#pragma unroll
+        for (int rb = 0; rb < RB16; ++rb) {
+          const bf16_t* pr = pt + (rb * 16 + i16) * PP + ct * WG_LT + k4 * 32 + 8 * g4;
+          dt[rb] = mfma16(*reinterpret_cast<const s16x8_t*>(pr), yf, dt[rb]);
+          dt[rb] = mfma16(*reinterpret_cast<const s16x8_t*>(pr + R * PP), yf, dt[rb]);
+        }
+      }
+      // dB of this column tile (the wgrad body's product, same operand order)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        s16x8_t bfr[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) bfr[cb] = load_frag_tr(gt, WG_GPITCH, kk * 32, (wave * 2 + cb) * 16, lane);
+#pragma unroll
+        for (int rb = 0; rb < RB16; ++rb) {
+          s16x8_t af = load_frag_tr(st, WG_SPITCH, kk * 32, rb * 16, lane);
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[ct][rb][cb] = mfma16(af, bfr[cb], acc[ct][rb][cb]);
+          if (split) {
+            s16x8_t al = load_frag_tr(st + 64 * WG_SPITCH, WG_SPITCH, kk * 32, rb * 16, lane);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[ct][rb][cb] = mfma16(al, bfr[cb], acc[ct][rb][cb]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int m = ms + wave * 16 + i16;
+    if (m < mend) {
+      float* dst = fz.dt_partial + ((long)blockIdx.x * p.M + m) * p.R + 4 * g4;
+#pragma unroll
+      for (int rb = 0; rb < RB16; ++rb) *reinterpret_cast<f32x4_t*>(dst + rb * 16) = dt[rb];
+    }
+  }
+  float* part = p.partial + (long)blockIdx.y * p.R * p.L;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int rb = 0; rb < RB16; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int col = lbase + ct * WG_LT + (wave * 2 + cb) * 16 + i16;
+        if (col < p.L) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(long)(rb * 16 + 4 * g4 + r) * p.L + col] = acc[ct][rb][cb][r];
+        }
+      }
+}
+
 // dT[m][r..r+3] = c[m] * sum over the column tiles (fixed order: deterministic) of the partials, written like aitk_lora_down writes it
 // (bf16, or the [hi | lo | hi] K-slab of the rank block; dropout mask applied on the fp32 value)
 __global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p, const float* part, int ntiles) {
@@ -506,12 +650,30 @@ extern "C" int aitk_lora_bwd_fused(const AitkLoraWgradArgs* a, const AitkLoraDow
   int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
   if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
   const int nchunks = (a->M + mc - 1) / mc;
-  const int ntiles = (a->L + WG_LT - 1) / WG_LT;
+  const int ntiles1 = (a->L + WG_LT - 1) / WG_LT;
+  // column tiles per workgroup: as many (4 at rank 16, 2 at rank 32: the P slices must fit LDS beside the tiles) as still leave >= ~2 workgroups
+  // per CU; AITK_LORA_BWD_CT = 1 | 2 | 4 forces a form (A/B measurements)
+  const char* e_ct = getenv("AITK_LORA_BWD_CT");  // read per launch: the micro-benchmark switches forms inside one process
+  const int forced = e_ct ? atoi(e_ct) : 0;
+  int ct = 1;
+  for (int c : {4, 2}) {
+    if (a->R == 32 && c == 4) continue;
+    if ((long)((ntiles1 + c - 1) / c) * nchunks >= 600) { ct = c; break; }
+  }
+  if (forced == 1 || forced == 2 || (forced == 4 && a->R == 16)) ct = forced;
+  const int ntiles = (ntiles1 + ct - 1) / ct;
   dim3 grid(ntiles, nchunks);
   hipStream_t s = (hipStream_t)stream;
   WgradFuse fz{(const bf16_t*)d->P, (const bf16_t*)d->P_lo, (long)d->ldp, dt_partial};
-  if (a->R == 16) hipLaunchKernelGGL(lora_wgrad_fused_kernel<1>, grid, dim3(256), 0, s, *a, fz, mc);
-  else hipLaunchKernelGGL(lora_wgrad_fused_kernel<2>, grid, dim3(256), 0, s, *a, fz, mc);
+  if (ct == 1) {
+    if (a->R == 16) hipLaunchKernelGGL(lora_wgrad_fused_kernel<1>, grid, dim3(256), 0, s, *a, fz, mc);
+    else hipLaunchKernelGGL(lora_wgrad_fused_kernel<2>, grid, dim3(256), 0, s, *a, fz, mc);
+  } else if (ct == 2) {
+    if (a->R == 16) hipLaunchKernelGGL((lora_bwd_fused_ct_kernel<1, 2>), grid, dim3(256), 0, s, *a, fz, mc);
+    else hipLaunchKernelGGL((lora_bwd_fused_ct_kernel<2, 2>), grid, dim3(256), 0, s, *a, fz, mc);
+  } else {
+    hipLaunchKernelGGL((lora_bwd_fused_ct_kernel<1, 4>), grid, dim3(256), 0, s, *a, fz, mc);
+  }
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;
   hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);

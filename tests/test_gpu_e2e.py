@@ -3,9 +3,9 @@
 Tolerances (bf16 storage, fp32 accumulate): north_star asks 1e-3 relative on the bf16 loss and on LoRA deltas.
   * loss: |loss - loss_oracle_fp32| <= 1e-3 * loss
   * adapter gradients / deltas: compared with the fp32 oracle in relative Frobenius norm, next to the SAME quantity for
-    the oracle itself run in bf16 (the reference-equivalent PyTorch bf16 path): ours must be within 1.5x of that floor
-    or below 1e-2 absolute, whichever is larger — bf16 rounding noise through the block stack bounds any bf16
-    implementation, including the reference's own.
+    the oracle itself run in bf16 (the reference-equivalent PyTorch bf16 path): ours must be within 1.25x of that distance
+    overall and within 1.5x (+2e-3) of its worst module — bf16 rounding noise through the block stack bounds any bf16
+    implementation, including the reference's own (its self-distance across backends: DESIGN.md section 7, ref16_self).
 """
 import math
 
@@ -68,9 +68,12 @@ def test_step_gradients_and_loss_vs_oracle(rank):
     den = sum((b ** 2).sum().item() for b in g32)
     e_ours, e_ref16 = math.sqrt(num_o / den), math.sqrt(num_r / den)
     print(f"loss ours {loss:.6f} fp32 {loss32:.6f} bf16-oracle {loss16:.6f}; grad rel err ours {e_ours:.4e} bf16-oracle {e_ref16:.4e}")
-    assert e_ours <= max(1.5 * e_ref16, 1e-2), (e_ours, e_ref16)
-    worst = max(_rel(a, b) for a, b in zip(mine, g32))
-    assert worst < 0.1, worst
+    # relative to the reference arithmetic's own distance from fp32, overall and per module (no absolute escape hatches):
+    # measured ours 6.6e-3 vs ref16 7.8e-3 at rank 16
+    assert e_ours <= 1.25 * e_ref16, (e_ours, e_ref16)
+    per_o = [_rel(a, b) for a, b in zip(mine, g32)]
+    per_r = [_rel(a, b) for a, b in zip(g16, g32)]
+    assert max(per_o) <= 1.5 * max(per_r) + 2e-3, (max(per_o), max(per_r))
 
 
 def test_three_training_steps_track_oracle():

@@ -235,3 +235,16 @@ def test_lora_bwd_fused_equals_lora_down_plus_lora_wgrad(M, L, R, opts):
     dT_c, gu_c = torch.zeros_like(dT_b), g0.clone()
     ops.lora_bwd_fused(dy, T, p_hi, p_lo, dT_c, gu_c, **kw)
     assert torch.equal(dT_b, dT_c) and torch.equal(gu_b, gu_c)
+    # every form of the kernel (1 / 2 / 4 column tiles per workgroup; AITK_LORA_BWD_CT forces one): same dB bits, dT to summation order
+    import os
+
+    try:
+        for ct in ("1", "2", "4"):
+            os.environ["AITK_LORA_BWD_CT"] = ct
+            dT_f, gu_f = torch.zeros_like(dT_b), g0.clone()
+            ops.lora_bwd_fused(dy, T, p_hi, p_lo, dT_f, gu_f, **kw)
+            assert torch.equal(gu_f, gu_a), ct
+            vf = dT_f[:, :R].float() + dT_f[:, R:2 * R].float()
+            assert ((vf - want).norm() / want.norm()).item() < 2e-5 and torch.equal(dT_f[:, :R], dT_f[:, 2 * R:]), ct
+    finally:
+        os.environ.pop("AITK_LORA_BWD_CT", None)

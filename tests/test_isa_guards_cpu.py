@@ -72,7 +72,7 @@ SPILL_BOUNDS = {
     "gemm8.o": {"gemm_nt_8phase_kernel": 8, "gemm_nt_8phase_grouped_kernel": 8, "gemm_nt_8phase_conv_kernel": 16, "gemm_nt_8phase_ge_kernel": 0,
                 "gemm_nt_8phase_grouped_ge_kernel": 0},
     "attention.o": {"attn_fwd_kernel": 0, "attn_bwd_dq_kernel": 0, "attn_bwd_dkdv_ws_kernel": 2, "attn_bwd_dkdv_pipe_kernel": 0, "attn_bwd_dkdv_kernel": 0},
-    "lora_skinny.o": {"lora_down16_kernel": 0, "lora_wgrad_kernel": 0},
+    "lora_skinny.o": {"lora_down16_kernel": 0, "lora_wgrad_kernel": 0, "lora_wgrad_fused_kernel": 0, "lora_bwd_fused_ct_kernel": 0},
     "norm_elem.o": {"ln_mod_bwd_row2_kernel": 0, "qkv_post_fwd_kernel": 0, "qkv_post_bwd_kernel": 0},
 }
 

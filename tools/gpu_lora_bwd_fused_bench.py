@@ -30,7 +30,7 @@ def timed(fn, cold, iters=12):
 
 def main():
     out = []
-    for M, L in ((32256, 3072), (32256, 12288), (32256, 15360), (3584, 3072), (32256, 9216)):
+    for M, L in ((32256, 3072), (32256, 12288), (32256, 15360), (3584, 3072), (32256, 9216), (4608, 3072), (4608, 12288)):
         R = 16
         g = torch.Generator(device="cuda").manual_seed(1)
         dy = (torch.randn(M, L, device="cuda", generator=g) * 0.5).to(bf)
@@ -51,12 +51,17 @@ def main():
             fused()
         row = {"M": M, "L": L, "dY_MB": M * L * 2 / 1e6}
         for cold in (True, False):
-            a, b = timed(sep, cold), timed(fused, cold)
-            row["cold" if cold else "warm"] = {"separate_us": round(a, 1), "fused_us": round(b, 1), "separate_TBps_dY": round(2 * M * L * 2 / a / 1e6, 2),
-                                               "fused_TBps_dY": round(M * L * 2 / b / 1e6, 2)}
+            a = timed(sep, cold)
+            r = {"separate_us": round(a, 1), "separate_TBps_dY": round(2 * M * L * 2 / a / 1e6, 2)}
+            for ct in ("1", "2", "4", "0"):  # column tiles per workgroup: forced forms, then the launcher's own choice ("0")
+                os.environ["AITK_LORA_BWD_CT"] = ct
+                b = timed(fused, cold)
+                r[f"fused_ct{ct if ct != '0' else '_auto'}_us"] = round(b, 1)
+            os.environ.pop("AITK_LORA_BWD_CT", None)
+            row["cold" if cold else "warm"] = r
         out.append(row)
         print(json.dumps(row), flush=True)
-    with open("gpurun_out/r05_lora_bwd_fused_bench.json", "w") as f:
+    with open("gpurun_out/r05_lora_bwd_fused_bench_ct.json", "w") as f:
         json.dump(out, f, indent=1)
 
 
