@@ -651,15 +651,13 @@ extern "C" int aitk_lora_bwd_fused(const AitkLoraWgradArgs* a, const AitkLoraDow
   if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
   const int nchunks = (a->M + mc - 1) / mc;
   const int ntiles1 = (a->L + WG_LT - 1) / WG_LT;
-  // column tiles per workgroup: as many (4 at rank 16, 2 at rank 32: the P slices must fit LDS beside the tiles) as still leave >= ~2 workgroups
-  // per CU; AITK_LORA_BWD_CT = 1 | 2 | 4 forces a form (A/B measurements)
+  // column tiles per workgroup (4 only at rank 16: the P slices must fit LDS beside the tiles); AITK_LORA_BWD_CT = 1 | 2 | 4 forces a form (A/B measurements)
   const char* e_ct = getenv("AITK_LORA_BWD_CT");  // read per launch: the micro-benchmark switches forms inside one process
   const int forced = e_ct ? atoi(e_ct) : 0;
-  int ct = 1;
-  for (int c : {4, 2}) {
-    if (a->R == 32 && c == 4) continue;
-    if ((long)((ntiles1 + c - 1) / c) * nchunks >= 600) { ct = c; break; }
-  }
+  // measured (profiles/r05_lora_bwd_fused_bench_ct.json): two tiles per workgroup beat one at every shape of the step (L = 3072: 114 -> 101 us at
+  // M = 32256, 30.6 -> 28.8 at M = 4608); four beat two from L = 12288 up (325 -> 271 us; also at M = 4608: 82 -> 72) and lose at L = 9216 (224 vs 236)
+  int ct = ntiles1 >= 2 ? 2 : 1;
+  if (a->R == 16 && ntiles1 >= 96) ct = 4;
   if (forced == 1 || forced == 2 || (forced == 4 && a->R == 16)) ct = forced;
   const int ntiles = (ntiles1 + ct - 1) / ct;
   dim3 grid(ntiles, nchunks);

@@ -24,7 +24,10 @@ def main():
            ("attn_bwd_dq_kernel", "attention backward dQ (3 matmuls, recomputes S, dP)", 6 * PAIR),
            ("attn_fwd_kernel", "attention forward", 4 * PAIR),
            ("lora_down16_kernel", "LoRA skinny down (T = x A^T, dT = dy B), split precision", 0),
-           ("lora_wgrad", "LoRA weight gradients (+ finish)", 0),
+           ("lora_wgrad_fused", "LoRA backward, one read of dY: dT partials + lora_up gradient (aitk_lora_bwd_fused, 128 columns per workgroup)", 0),
+           ("lora_bwd_fused_ct", "LoRA backward, one read of dY: dT partials + lora_up gradient (aitk_lora_bwd_fused, 2 / 4 column tiles per workgroup)", 0),
+           ("lora_dt_finish", "dT finish (sum of the column partials -> [hi | lo | hi] slab)", 0),
+           ("lora_wgrad", "LoRA weight gradients (lora_down gradient; + finish passes)", 0),
            ("ln_mod_", "adaLN LayerNorm fwd / bwd", 0), ("qkv_post", "QK-RMSNorm + RoPE fwd / bwd", 0), ("gate_bwd", "gate backward", 0),
            ("colsum_finish", "column-sum finish", 0), ("gemv_nt", "adaLN / embedder GEMV", 0), ("attn_delta", "attention delta", 0),
            ("adamw_ema", "clip + AdamW + EMA", 0), ("refresh_shadows", "split-precision shadow refresh", 0)]
