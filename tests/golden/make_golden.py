@@ -1095,12 +1095,48 @@ def golden_adoption(out_dir=None):
             with safe_open(f, "pt") as fh:
                 fmeta = dict(fh.metadata())
                 fkeys = list(fh.keys())
+            if tag == "lora":
+                # resume (BaseSDTrainProcess.py:2060-2066): a FRESH plug-in + network, the reference's own load_weights(file) BEFORE the first
+                # forward (values land in the reference's tensors, adoption then takes them over), same rank and a rank-8 file into a rank-4
+                # network (shrink: network_mixins.py:737-775)
+                lat, emb, pooled, ts, _ = adoption_batches(1, seed=21)[0]
+                pe = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled)
+                for sub, rank in (("loaded", 8), ("loaded_shrunk", 4)):
+                    cfg2, sd2, nat2 = plugin()
+                    torch.manual_seed(123)
+                    net2 = build_network(cfg2, sd2, NetworkConfig(type="lora", linear=rank, linear_alpha=rank, transformer_only=True))
+                    net2.force_to(torch.device("cpu"), dtype=torch.float32)
+                    sd2.network = net2
+                    net2._update_torch_multiplier()
+                    net2.apply_to(None, sd2.unet, False, True)
+                    net2.prepare_grad_etc(None, sd2.unet)
+                    extra = net2.load_weights(f)
+                    assert extra is None
+                    with torch.no_grad(), net2:
+                        out[f"{tag}/pred_{sub}"] = sd2.get_noise_prediction(lat, ts, pe, 1.0, False).clone()
+                    assert isinstance(nat2.network, AdoptedNetwork) and nat2.network.aliasing_intact()
         # the adapter-inactive prediction == base model (no_grad: sampling / prior prediction path)
         lat, emb, pooled, ts, _ = adoption_batches(1, seed=21)[0]
         with torch.no_grad():
             out[f"{tag}/pred_inactive"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
             with net:
                 out[f"{tag}/pred_active"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
+        if tag == "lora":
+            # the reference's own merge_in / merge_out on the adopted network (toolkit/network_mixins.py:370-462, 894-906): every wrapped layer's
+            # weight is rewritten through org_module.load_state_dict, which the native Linear answers by refreshing the transposed copy its
+            # data-gradient GEMM reads; merged + skipped adapter == active adapter, merge_out restores the base
+            with torch.no_grad():
+                net.merge_in(1.0)
+                assert net.is_merged_in
+                with net:
+                    out[f"{tag}/pred_merged"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
+                lin = nat.single_transformer_blocks[0].attn.to_k
+                assert torch.equal(lin.weight_t, lin.weight.data.t()), "weight_t must follow a merged weight"
+                net.merge_out(1.0)
+                out[f"{tag}/pred_after_merge_out"] = sd.get_noise_prediction(lat, ts, SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), 1.0, False).clone()
+            e_m = ((out[f"{tag}/pred_merged"] - out[f"{tag}/pred_active"]).norm() / out[f"{tag}/pred_active"].norm()).item()
+            e_o = ((out[f"{tag}/pred_after_merge_out"] - out[f"{tag}/pred_inactive"]).norm() / out[f"{tag}/pred_inactive"].norm()).item()
+            assert e_m < 1e-5 and e_o < 1e-5, (e_m, e_o)
         return {"names": [m.lora_name for m in net.unet_loras], "saved_keys": list(sdict.keys()), "n_params": len(plist),
                 "file_keys": fkeys, "sshs_model_hash": fmeta.get("sshs_model_hash"), "sshs_legacy_hash": fmeta.get("sshs_legacy_hash"),
                 "peft_format": bool(net.peft_format), "module_class": type(net.unet_loras[0]).__name__, "steps": steps}

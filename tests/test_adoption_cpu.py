@@ -149,6 +149,23 @@ def test_fused_twin_lands_bit_for_bit_where_the_reference_network_landed_over_th
             assert sorted(fh.keys()) == sorted(meta["file_keys"])
             assert fh.metadata()["sshs_model_hash"] == meta["sshs_model_hash"]
             assert fh.metadata()["sshs_legacy_hash"] == meta["sshs_legacy_hash"]
+        if tag == "lora":
+            # resume: the golden holds what the reference's own load_weights produced in a fresh adopted network — same rank, and the rank-8
+            # file into a rank-4 network (shrink, network_mixins.py:737-775); the fused network's load_weights must land on the same prediction
+            lat_, emb_, pooled_, ts_, _ = batches(1, seed=21)[0]
+            pe_ = SimpleNamespace(text_embeds=emb_, pooled_embeds=pooled_)
+            for sub, rank in (("loaded", 8), ("loaded_shrunk", 4)):
+                _, nat2, sd2 = native_plugin()
+                torch.manual_seed(123)
+                net2 = FusedLoRANetwork(nat2, lora_dim=rank, alpha=rank, transformer_block_names=sd2.get_transformer_block_names(), base_model=sd2)
+                net2.apply_to()
+                net2.build_arena("cpu", groups=nat2.lora_groups())
+                net2.refresh_shadows(ref_ops)
+                nat2.attach_network(net2)
+                assert net2.load_weights(f) is None
+                with torch.no_grad(), net2:
+                    assert torch.equal(sd2.get_noise_prediction(lat_, ts_, pe_, 1.0, False), gold[f"lora/pred_{sub}"]), sub
+            assert not torch.equal(gold["lora/pred_loaded"], gold["lora/pred_loaded_shrunk"])
     lat, emb, pooled, ts, _ = batches(1, seed=21)[0]
     pe = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled)
     with torch.no_grad():
@@ -156,6 +173,19 @@ def test_fused_twin_lands_bit_for_bit_where_the_reference_network_landed_over_th
         with net:
             assert torch.equal(sd.get_noise_prediction(lat, ts, pe, 1.0, False), gold[f"{tag}/pred_active"])
     assert not torch.equal(gold[f"{tag}/pred_inactive"], gold[f"{tag}/pred_active"])
+    if tag == "lora":
+        lat_, emb_, pooled_, ts_, pe_ = lat, emb, pooled, ts, pe
+        # the reference's own merge_in / merge_out over the adopted network (recorded by the generator, which also checks that the native
+        # layer's transposed copy followed the merged weight): merged == active, merge_out == base; the fused network's merge agrees
+        def r(a, b):
+            return ((a - b).norm() / b.norm()).item()
+
+        assert r(gold["lora/pred_merged"], gold["lora/pred_active"]) < 1e-5 and r(gold["lora/pred_after_merge_out"], gold["lora/pred_inactive"]) < 1e-5
+        with torch.no_grad():
+            net.merge_in(1.0, ops=ref_ops)
+            with net:
+                assert r(sd.get_noise_prediction(lat_, ts_, pe_, 1.0, False), gold["lora/pred_merged"]) < 1e-5
+            net.merge_out(1.0, ops=ref_ops)
 
 
 def test_golden_records_where_unsupported_reference_networks_are_refused():
