@@ -14,7 +14,7 @@ objects the reference made:
 
   * `graph.Linear.__setattr__` (and the UNet's convolution holders) see the `forward` swap and call `register_foreign_adapter`: the module that owns
     the new forward becomes the layer's adapter (`lin.lora`), after a check that the fused graph can run it.  Anything it cannot run — LoRM,
-    full-rank / FullModule layers, `use_bias`, decomposed LoKr factors, unsupported ranks — raises HERE, at `apply_to`, never a base-only model.
+    full-rank / FullModule layers, `use_bias`, decomposed LoKr factors, DoRA above rank 64 — raises HERE, at `apply_to`, never a base-only model.
   * On the first forward of the native model (`FusedGraphBase._resolve_network`), `AdoptedNetwork` lays the flat fp32 arenas out exactly as
     `FusedLoRANetwork.build_arena` does and RE-POINTS the storage of the reference's own Parameters at views of them (`param.data = view`,
     `param.grad = grad view`).  Parameter identity is untouched, so the optimizer, `clip_grad_norm_`, `toolkit/ema.py`, `accelerator.prepare`,
@@ -115,8 +115,6 @@ def register_foreign_adapter(layer, new_forward):
             raise AdoptionError(f"{name}: nn.Dropout-module dropout is not on the fused path (float probabilities are)")
         if kind == "dora" and (r > 64 or has_dropout):
             raise AdoptionError(f"{name}: DoRA at rank {r}{' with dropout' if has_dropout else ''}: the fused path runs DoRA up to rank 64 without dropout")
-        if has_dropout and r > 64:
-            raise AdoptionError(f"{name}: dropout variants above rank 64 are not on the fused path")
         if is3 and r > 64:
             raise AdoptionError(f"{name}: 3x3-conv adapters above rank 64 are not on the fused path")
         if is3 and (layer.cin_pad != layer.in_channels or layer.cout_pad != layer.out_channels):

@@ -267,7 +267,7 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
   // split_rp >= R: the launch covers (a chunk of) ONE rank block — ranks above 64 go out in 64-rank chunks of the same slab
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
-  if (a->tmask && a->split_rp > a->R) return AITK_ERR_ARG;  // the mask rows are R wide: a chunk would read the wrong columns
+  // tmask rows are R wide = the ranks of THIS launch: a 64-rank chunk of a wider slab (split_rp > R) brings its own contiguous [rows, R] mask
   const int grid = (a->M + 31) / 32;
   if (a->K % 32 == 0) {
     static int u1 = 0;  // AITK_LORA_DOWN_U=8 selects the 3-waves-per-SIMD variant (A/B measurements)
@@ -646,7 +646,6 @@ extern "C" int aitk_lora_bwd_fused(const AitkLoraWgradArgs* a, const AitkLoraDow
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
   if (d->split_rp < 0 || (d->split_rp > 0 && ((d->split_rp % 4) || (d->split_rp < d->R && (d->R % d->split_rp))))) return AITK_ERR_ARG;
   if (d->mult && d->rows_per_batch <= 0) return AITK_ERR_ARG;
-  if (d->tmask && d->split_rp > d->R) return AITK_ERR_ARG;
   int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
   if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
   const int nchunks = (a->M + mc - 1) / mc;

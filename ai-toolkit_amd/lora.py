@@ -313,8 +313,6 @@ class FusedLoRANetwork(nn.Module):
         if network_type.lower() == "dora" and lora_dim > 64:
             raise NotImplementedError("DoRA ranks above 64 are not on the fused path (aitk_dora_colscale holds one output channel's rank row per "
                                       "thread, R <= 64); plain LoRA runs any rank in 64-rank chunks")
-        if (dropout or rank_dropout or module_dropout) and lora_dim > 64:
-            raise NotImplementedError("dropout variants at ranks above 64 are not on the fused path (the mask rides inside one aitk_lora_down launch)")
         module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
         self.lora_dim = lora_dim
         self.network_type = network_type

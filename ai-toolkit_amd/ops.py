@@ -226,13 +226,15 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     R, K = pmat.shape
     if R > 64:  # the kernel contracts up to 64 ranks per launch: larger ranks go out in 64-rank chunks of the same slab (split >= R: one
         #         rank block, the chunk's hi / lo / hi columns sit at its rank offset inside it)
-        if tmask is not None or (split and split < R):
-            raise NotImplementedError("lora_down: ranks above 64 with a dropout mask / several rank blocks per launch")
+        if split and split < R:
+            raise NotImplementedError("lora_down: ranks above 64 in several rank blocks per launch")
         assert out.shape[1] == (3 * split if split else R)
         for c0 in range(0, R, 64):
             c1 = min(R, c0 + 64)
+            # the dropout mask of a chunk: its own [rows, chunk ranks] matrix (the kernel indexes the mask by the rank inside the launch)
+            tm = None if tmask is None else tmask[:, c0:c1].contiguous()
             _lora_down_launch(x, pmat[c0:c1], out[:, c0:], scale, mult, rows_per_batch, x_seg, M, None if p_lo is None else p_lo[c0:c1],
-                              split, None, 0)
+                              split, tm, tmask_rows_per_batch)
         return out
     assert out.shape[1] == (3 * R if split else R)
     return _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo, split, tmask, tmask_rows_per_batch)

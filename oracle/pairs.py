@@ -8,7 +8,7 @@ CFG = dict(in_channels=64, num_layers=2, num_single_layers=3, attention_head_dim
            joint_attention_dim=256, pooled_projection_dim=64)
 
 
-def build(rank=16, dev="cuda", attach=True):
+def build(rank=16, dev="cuda", attach=True, dropout_cfg=None, mask_provider=None):
     """attach=False: the native model is returned WITHOUT an adapter network (4th value None) — for the adoption tests, where the
     reference-side network is built over it afterwards"""
     import ai_toolkit_amd  # noqa: F401
@@ -40,7 +40,10 @@ def build(rank=16, dev="cuda", attach=True):
         ref_net.apply_to()
         nat.prepare()
         return ref, ref_net, nat, None
-    net = FusedLoRANetwork(nat, lora_dim=rank)
+    net = FusedLoRANetwork(nat, lora_dim=rank, **(dropout_cfg or {}))
+    if dropout_cfg:  # LoRA dropout / rank_dropout / module_dropout: both sides draw their uniforms from the same keyed provider
+        ref_net.dropout_cfg, ref_net.mask_provider = dict(dropout_cfg), mask_provider
+        net.mask_provider = mask_provider
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for a, b in zip(net.unet_loras, ref_net.unet_loras):

@@ -276,7 +276,8 @@ def test_split_adapter_branch_reaches_fp32_class_precision_on_bf16_operands():
 
 
 # ---------------------------------------------------------------------------------------------------- dropout variants
-def test_lora_dropout_rank_dropout_and_module_dropout_match_the_oracle():
+@pytest.mark.parametrize("rank", [8, 80], ids=["r8", "r80-two-64-rank-chunks"])
+def test_lora_dropout_rank_dropout_and_module_dropout_match_the_oracle(rank):
     """toolkit/network_mixins.py:198-228 in training mode: neuron dropout on lx = lora_down(x), rank_dropout (one keep mask per
     sample and rank, output rescaled by 1 / (1 - p)) and module_dropout (the adapter is skipped for this call) — executed as a
     multiplier inside aitk_lora_down on the rank-space activation and on its gradient.  Both sides draw their uniforms from the same
@@ -297,9 +298,9 @@ def test_lora_dropout_rank_dropout_and_module_dropout_match_the_oracle():
     from oracle import lora_ref
 
     cfg = dict(dropout=0.1, rank_dropout=0.25, module_dropout=0.2)
-    ref_net = lora_ref.RefLoRANetwork(ref, 8)
+    ref_net = lora_ref.RefLoRANetwork(ref, rank)
     ref_net.dropout_cfg, ref_net.mask_provider = cfg, provider
-    net = FusedLoRANetwork(nat, lora_dim=8, **cfg)
+    net = FusedLoRANetwork(nat, lora_dim=rank, **cfg)
     net.mask_provider = provider
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
