@@ -119,6 +119,30 @@ class FusedGraphBase(nn.Module):
     def _device(self):
         return next(self.parameters()).device
 
+    # diffusers' ModelMixin surface the reference reads off the denoiser (toolkit/models/base_model.py:961-968: `self.unet.device`, `.dtype`)
+    @property
+    def device(self):
+        return self._device()
+
+    @property
+    def dtype(self):
+        return self.dt
+
+    def _apply(self, fn, recurse=True):
+        """`.to()` / `.cuda()` / `.cpu()` / `.float()` / `.half()` are no-ops on a native graph.  The reference's trainer and its device-state
+        presets shuttle models between cpu and cuda and re-cast them (`unet.to(self.device_torch, dtype=dtype)`, jobs/process/
+        BaseSDTrainProcess.py:1899; BaseModel.set_device_state; `self.sd.unet.to('cpu')`, SDTrainer.py:298) to make room on 24-80 GB cards; here the
+        frozen base, its transposed / quantised copies and every kernel-layout buffer stay where they were built (288 GB of HBM: nothing needs
+        to leave) and in the dtype the kernels are written for.  Build the model on the device and in the dtype you want."""
+        return self
+
+    def enable_gradient_checkpointing(self):
+        """accepted and ignored (BaseSDTrainProcess.py:1864-1866): the explicit backward keeps every activation it needs resident, there is
+        nothing to recompute (the `recompute_gelu` switch of the FLUX graph is the one memory lever)"""
+
+    def disable_gradient_checkpointing(self):
+        pass
+
     def set_ops(self, ops):
         self.ops = ops
 

@@ -96,6 +96,53 @@ def encode_prompts_flux(tokenizer, text_encoder, prompts, truncate=True, max_len
     return embeds, pooled
 
 
+class FakeTextEncoder(torch.nn.Module):
+    """Stand-in for a text encoder that is not loaded (toolkit/unloader.py:10-33 does the same after caching the embeddings): the reference's
+    trainer calls `requires_grad_`, `eval`, `to`, `.device`, `.dtype` on whatever `sd.text_encoder` holds (BaseSDTrainProcess.py:1892-1898)."""
+
+    def __init__(self, device, dtype):
+        super().__init__()
+        self.dummy_param = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self._device, self._dtype = device, dtype
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("no text encoder is loaded: train with cached text embeddings (datasets: cache_text_embeddings: true) or point "
+                                  "model.name_or_path at a pipeline directory that has the text_encoder / tokenizer sub-folders")
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def to(self, *args, **kwargs):
+        return self
+
+
+class FakeVAE(torch.nn.Module):
+    """Stand-in for a VAE that is not loaded (latents cached on disk): takes the trainer's `vae.to(...)`, `requires_grad_`, `eval` and says what
+    is missing when something tries to encode with it."""
+
+    def __init__(self, device, dtype):
+        super().__init__()
+        self.dummy_param = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self._device, self._dtype = device, dtype
+        self.config = {}
+
+    device = property(lambda self: self._device)
+    dtype = property(lambda self: self._dtype)
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def encode(self, *a, **k):
+        raise RuntimeError("no VAE encoder is loaded (the checkpoint directory has no 'vae' sub-folder): latents must be cached (cache_latents_to_disk)")
+
+    encode_images = encode
+
+
 def _embeds(text_embeddings):
     """PromptEmbeds-like object (.text_embeds / .pooled_embeds, toolkit/prompt_utils.py) or a (text, pooled) tuple."""
     if hasattr(text_embeddings, "text_embeds"):
@@ -204,7 +251,9 @@ class _PluginBase:
             vdir = loader.resolve_component_dir(base, "vae")
         except FileNotFoundError:
             vdir = None
-        if vdir is not None:
+        if vdir is None:
+            self.vae = FakeVAE(self.vae_device_torch, self.torch_dtype)
+        else:
             self.vae = self._build_vae(self._read_config(vdir))
             # only the encoder half is built: decoder.* / post_quant_conv.* of the file are skipped; every encoder tensor must be there
             missing, _ = loader.load_component(self.vae, vdir, strict=False,
@@ -213,8 +262,19 @@ class _PluginBase:
                 raise KeyError(f"VAE checkpoint {vdir} lacks {len(missing)} encoder tensor(s) of the configured architecture, e.g. {missing[:4]}: "
                                "encode_images would run on uninitialised weights")
             self.vae.prepare()
-        self.noise_scheduler = self._make_scheduler()
+        self._load_text_side(base)
+        if self.noise_scheduler is None:  # the trainer hands its sampler (ModelClass.get_train_scheduler()) to the constructor: keep it
+            self.noise_scheduler = self._make_scheduler()
         self.is_loaded = True
+
+    def _load_text_side(self, path):
+        """text encoders / tokenizers after load_model: stand-ins, so that the reference's trainer can freeze / move / unload "them"
+        (BaseSDTrainProcess.py:1892-1898, toolkit/unloader.py); the FLUX plug-in loads the real CLIP-L + T5 when the pipeline directory has them."""
+        n = getattr(self, "_n_text_encoders", 1)
+        self.text_encoder = [FakeTextEncoder(self.te_device_torch, self.torch_dtype) for _ in range(n)]
+        self.tokenizer = [None] * n
+        if n == 1:
+            self.text_encoder, self.tokenizer = self.text_encoder[0], None
 
     def _build_vae(self, config=None):
         """AutoencoderKL encoder from vae/config.json (latent_channels, scaling / shift factor, use_quant_conv, widths); without a config
@@ -331,6 +391,15 @@ class Flux1MI355Model(_PluginBase):
     arch = "flux_mi355"
     target_lora_modules = ["FluxTransformer2DModel"]
     _component = "transformer"
+    _n_text_encoders = 2  # CLIP-L + T5 (flux_kontext.py:120-170)
+
+    def _load_text_side(self, path):
+        import os
+
+        if all(os.path.isdir(os.path.join(str(path), sub)) for sub in ("tokenizer", "tokenizer_2", "text_encoder", "text_encoder_2")):
+            self.load_text_encoders(path)  # real encoders: prompts can be encoded (and cached) by the trainer
+        else:
+            super()._load_text_side(path)
 
     def _build_native(self, config=None):
         from .flux import FluxTransformer2DModel
@@ -382,7 +451,8 @@ class Flux1MI355Model(_PluginBase):
     def get_prompt_embeds(self, prompt, control_images=None):
         """flux_kontext.py:354-367: encode_prompts_flux(tokenizer, text_encoder, prompt, max_length=512) -> PromptEmbeds(text) + pooled_embeds.
         Encoders are loaded on first use (load_text_encoders) or taken from `self.text_encoder` / `self.tokenizer` if the caller set them."""
-        if not self.text_encoder or not self.tokenizer:
+        te = self.text_encoder
+        if not te or not self.tokenizer or any(isinstance(t, FakeTextEncoder) or t.__class__.__name__ == "FakeTextEncoder" for t in (te if isinstance(te, (list, tuple)) else [te])):
             self.load_text_encoders()
         if not isinstance(prompt, (list, tuple)):
             prompt = [prompt]

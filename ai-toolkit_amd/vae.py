@@ -57,6 +57,19 @@ class _Holder(nn.Module):
 
 
 class AutoencoderKLEncoder(nn.Module):
+    def _apply(self, fn, recurse=True):
+        """`.to()` / `.cpu()` / `.float()` are no-ops: the reference's trainer parks the VAE on the CPU and re-casts it (jobs/process/
+        BaseSDTrainProcess.py:1902); the native encoder stays on its device in its dtype (kernel-layout buffers are not nn.Parameters)."""
+        return self
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return self.dt
+
     def __init__(self, latent_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2, groups=32,
                  scaling_factor=0.3611, shift_factor=0.1159, use_quant_conv=False, dtype=torch.bfloat16, device=None, ops=None):
         """Defaults = FLUX.1's VAE.  SD1.5 / SDXL: latent_channels=4, scaling_factor=0.18215 / 0.13025, shift_factor=0.0,

@@ -75,6 +75,19 @@ class _Holder(nn.Module):
 
 
 class AutoencoderKLWanEncoder(nn.Module):
+    def _apply(self, fn, recurse=True):
+        """`.to()` / `.cpu()` / `.float()` are no-ops: the reference's trainer parks the VAE on the CPU and re-casts it (jobs/process/
+        BaseSDTrainProcess.py:1902); the native encoder stays on its device in its dtype (kernel-layout buffers are not nn.Parameters)."""
+        return self
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return self.dt
+
     def __init__(self, base_dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
                  latents_mean=None, latents_std=None, dtype=torch.bfloat16, device=None, ops=None):
         super().__init__()

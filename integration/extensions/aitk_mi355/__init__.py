@@ -15,16 +15,39 @@ import ai_toolkit_amd  # noqa: F401  (import alias of the hyphenated package dir
 from ai_toolkit_amd import plugin as _p
 
 
-def _real(mirror):
+def _flowmatch_scheduler(config):
+    """The reference's OWN training scheduler, like every in-tree flow-matching plug-in returns from get_train_scheduler (e.g.
+    extensions_built_in/diffusion_models/flux_kontext/flux_kontext.py:28-36, 412-414): the trainer's process_general_training_batch talks to it
+    through the diffusers scheduler API (set_train_timesteps / timesteps / add_noise / config / get_weights_for_timesteps,
+    jobs/process/BaseSDTrainProcess.py:1188-1323) — plumbing on 1000-entry tables, not part of the accelerated path."""
+    def get_train_scheduler():
+        from toolkit.samplers.custom_flowmatch_sampler import CustomFlowMatchEulerDiscreteScheduler
+
+        return CustomFlowMatchEulerDiscreteScheduler(**config)
+
+    return staticmethod(get_train_scheduler)
+
+
+def _ddpm_scheduler():
+    def get_train_scheduler():
+        from toolkit.sampler import get_sampler  # the legacy StableDiffusion path builds its DDPM scheduler here (BaseSDTrainProcess.py:1773-1786)
+
+        return get_sampler("ddpm", {"prediction_type": "epsilon"}, arch="sd")
+
+    return staticmethod(get_train_scheduler)
+
+
+def _real(mirror, get_train_scheduler):
     def __init__(self, device, model_config, dtype="bf16", custom_pipeline=None, noise_scheduler=None, **kwargs):
         BaseModel.__init__(self, device, model_config, dtype=dtype, custom_pipeline=custom_pipeline, noise_scheduler=noise_scheduler, **kwargs)
         mirror.__init__(self, device, model_config, dtype, custom_pipeline, noise_scheduler, **kwargs)
 
-    return type(mirror.__name__.replace("Model", ""), (mirror, BaseModel), {"__init__": __init__, "__doc__": mirror.__doc__, "arch": mirror.arch})
+    return type(mirror.__name__.replace("Model", ""), (mirror, BaseModel),
+                {"__init__": __init__, "__doc__": mirror.__doc__, "arch": mirror.arch, "get_train_scheduler": get_train_scheduler})
 
 
-Flux1MI355 = _real(_p.Flux1MI355Model)
-Wan21MI355 = _real(_p.Wan21MI355Model)
-StableDiffusionMI355 = _real(_p.StableDiffusionMI355Model)
+Flux1MI355 = _real(_p.Flux1MI355Model, _flowmatch_scheduler(_p.FLUX_SCHEDULER_CONFIG))
+Wan21MI355 = _real(_p.Wan21MI355Model, _flowmatch_scheduler(_p.WAN_SCHEDULER_CONFIG))
+StableDiffusionMI355 = _real(_p.StableDiffusionMI355Model, _ddpm_scheduler())
 
 AI_TOOLKIT_MODELS = [Flux1MI355, Wan21MI355, StableDiffusionMI355]

@@ -1404,13 +1404,13 @@ class _TokOut(dict):
         self.input_ids, self.attention_mask = input_ids, attention_mask
 
 
-def tiny_text_encoders(seed=31):
+def tiny_text_encoders(seed=31, t5_dim=24):
     from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
 
     torch.manual_seed(seed)
     clip = CLIPTextModel(CLIPTextConfig(vocab_size=99, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
                                         max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)).eval()
-    t5 = T5EncoderModel(T5Config(vocab_size=101, d_model=24, d_kv=8, d_ff=48, num_layers=2, num_heads=3, is_encoder_decoder=False, use_cache=False)).eval()
+    t5 = T5EncoderModel(T5Config(vocab_size=101, d_model=t5_dim, d_kv=8, d_ff=48, num_layers=2, num_heads=3, is_encoder_decoder=False, use_cache=False)).eval()
     toks = [HashTokenizer(99, 16), HashTokenizer(101, 512)]
     return toks, [clip, t5]
 
@@ -1436,6 +1436,198 @@ def golden_text_encoders():
             out[f"{tag}/embeds"], out[f"{tag}/pooled"] = emb.clone(), pooled.clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "text_encoders_flux.safetensors"))
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
+
+
+def golden_trainer_loop(out_dir=None):
+    """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
+    trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
+    picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
+    checkpoint directory; oracle kernel table, fp32), the freeze / move / gradient-checkpointing calls on unet / vae / text encoders, its own
+    `LoRASpecialNetwork` (adopted by the native graph), `prepare_optimizer_params` -> `toolkit.optimizer.get_optimizer('adamw')`, accelerate,
+    EMA, `hook_before_train_loop` (static prompts encoded, text encoders unloaded through toolkit/unloader.py), then per step
+    `process_general_training_batch` (its scheduler: timesteps, noise, add_noise), `BaseModel.predict_noise` -> our `get_noise_prediction`,
+    `calculate_loss`, `accelerator.backward`, clip, optimizer step, EMA, and its periodic `save()`.
+    Stand-ins, all on the DATA side: the dataloader function is replaced by a synthetic iterator of duck-typed batches carrying cached latents
+    and cached prompt embeddings (no image files in this image), the text encoders are tiny random `transformers` CLIP / T5 models with the
+    hash tokenizer.  Recorded: what every `get_noise_prediction` call received and the loss target the trainer formed, the losses it logged, the
+    LoRA file and optimizer state it saved.  tests/test_trainer_loop_cpu.py replays the recorded calls through a FusedLoRANetwork twin."""
+    import importlib.util
+    import tempfile
+    import types
+    from collections import OrderedDict
+
+    from safetensors.torch import load_file
+
+    ref_shims.install_stub_finder(("controlnet_aux", "PIL", "imageio", "librosa", "soundfile", "pytorch_wavelets", "torchdiffeq", "gguf",
+                                   "huggingface_hub", "flatten_json", "pytorch_fid", "clip", "scipy", "tqdm", "yaml",
+                                   "ftfy", "sentencepiece", "omegaconf", "moviepy", "decord"))
+    sys.modules.setdefault("info", types.SimpleNamespace(software_meta={"name": "ai-toolkit"}))
+    import jobs.process.BaseSDTrainProcess  # noqa: F401
+    import toolkit.util.get_model as gm
+    from extensions_built_in.sd_trainer.SDTrainer import SDTrainer
+    from toolkit.prompt_utils import PromptEmbeds
+
+    bsp = sys.modules["jobs.process.BaseSDTrainProcess"]
+    spec = importlib.util.spec_from_file_location("aitk_mi355_ext", os.path.join(ROOT, "integration", "extensions", "aitk_mi355", "__init__.py"))
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    builtin = list(gm.BUILT_IN_MODELS)
+    gm.get_all_models = lambda: builtin + list(ext.AI_TOOLKIT_MODELS)  # = dropping the package into <ai-toolkit>/extensions/
+
+    from ai_toolkit_amd import loader, plugin
+    from ai_toolkit_amd.adopt import AdoptedNetwork
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from oracle import ref_ops
+
+    plugin._native_ops = lambda: ref_ops  # CPU: the oracle kernel table behind the native graph
+
+    def tiny_te(self, path=None):
+        toks, tes = tiny_text_encoders(t5_dim=ADOPT_CFG["joint_attention_dim"])
+        self.tokenizer, self.text_encoder = toks, [t.requires_grad_(False) for t in tes]
+        return self.text_encoder
+
+    ext.Flux1MI355.load_text_encoders = tiny_te
+    ext.Flux1MI355._load_text_side = lambda self, path: self.load_text_encoders(path)
+
+    rec = {"calls": [], "targets": []}
+    orig_pred, orig_target = ext.Flux1MI355.get_noise_prediction, ext.Flux1MI355.get_loss_target
+
+    import functools
+
+    @functools.wraps(orig_pred)  # keeps the signature BaseModel.predict_noise inspects (guidance_embedding_scale / bypass_guidance_embedding)
+    def rec_pred(self, latent_model_input, timestep, text_embeddings, **kw):
+        rec["calls"].append((latent_model_input.detach().clone(), timestep.detach().clone(), text_embeddings.text_embeds.detach().clone(),
+                             text_embeddings.pooled_embeds.detach().clone(), bool(torch.is_grad_enabled()),
+                             {k: v for k, v in kw.items() if isinstance(v, (int, float, bool))}))
+        return orig_pred(self, latent_model_input, timestep, text_embeddings, **kw)
+
+    def rec_target(self, *a, **kw):
+        t = orig_target(self, *a, **kw)
+        rec["targets"].append(t.detach().clone())
+        return t
+
+    ext.Flux1MI355.get_noise_prediction, ext.Flux1MI355.get_loss_target = rec_pred, rec_target
+
+    tmp = tempfile.mkdtemp()
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**ADOPT_CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+    nat = FluxTransformer2DModel(**ADOPT_CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict())
+    loader.save_component(nat, os.path.join(tmp, "ckpt", "transformer"))
+    with open(os.path.join(tmp, "ckpt", "transformer", "config.json"), "w") as f:
+        json.dump(dict(ADOPT_CFG, guidance_embeds=True, _class_name="FluxTransformer2DModel"), f)
+
+    class Duck:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return None
+
+    class DuckBatch(Duck):  # the attribute set of toolkit/data_transfer_object/data_loader.py DataLoaderBatchDTO the FLUX LoRA step reads
+        def __init__(self, B, seed):
+            g = torch.Generator().manual_seed(seed)
+            pe = PromptEmbeds(torch.randn(B, 6, ADOPT_CFG["joint_attention_dim"], generator=g) * 0.5)
+            pe.pooled_embeds = torch.randn(B, ADOPT_CFG["pooled_projection_dim"], generator=g) * 0.5
+            super().__init__(latents=torch.randn(B, 16, 8, 4, generator=g), tensor=None, prompt_embeds=pe, loss_multiplier_list=[1.0] * B,
+                             file_items=[Duck(path=f"img{i}.png", dataset_config=Duck(), is_reg=False, prior_reg=False, network_weight=1.0) for i in range(B)])
+            self.B = B
+
+        def get_caption_list(self, *a, **k):
+            return ["a photo"] * self.B
+
+        def get_caption_short_list(self, *a, **k):
+            return ["a"] * self.B
+
+        def get_is_reg_list(self):
+            return [False] * self.B
+
+        def get_network_weight_list(self):
+            return [1.0] * self.B
+
+        def cleanup(self):
+            pass
+
+    class DuckLoader:
+        dataset = types.SimpleNamespace(datasets=[])
+
+        def __init__(self):
+            self.n = 0
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            self.n += 1
+            return DuckBatch(2, 100 + self.n)
+
+        def __len__(self):
+            return 1000
+
+    bsp.get_dataloader_from_datasets = lambda *a, **k: DuckLoader()
+    bsp.trigger_dataloader_setup_epoch = lambda *a, **k: None
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    steps = 3
+    config = OrderedDict(type="sd_trainer", training_folder=os.path.join(tmp, "out"), device="cpu",
+                         network=dict(type="lora", linear=8, linear_alpha=8),
+                         save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
+                         datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
+                         train=dict(batch_size=2, steps=steps, gradient_accumulation=1, train_unet=True, train_text_encoder=False,
+                                    gradient_checkpointing=True, noise_scheduler="flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
+                                    disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
+                                    ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
+                         model=dict(arch="flux_mi355", name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
+                         sample=dict(sample_every=10 ** 9, prompts=[]))
+    job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
+                                raw_config={"config": {"name": "aitk_trainer_run"}}, log_dir=None, training_seed=7,
+                                config=OrderedDict(name="aitk_trainer_run"), gpu_id=0)
+    tr = SDTrainer(0, job, config)
+    losses = []
+    orig_loop = tr.hook_train_loop
+
+    keep = {}
+
+    def loop(batch):
+        if "init" not in keep:  # the adapter as the trainer initialised it (its RNG stream), before the first step
+            keep["init"] = OrderedDict((k, v.detach().clone()) for k, v in tr.network.state_dict().items())
+        d = orig_loop(batch)
+        losses.append(float(d["loss"]))
+        keep.update(sd=tr.sd, network=tr.network, ema=tr.ema, step=tr.step_num)  # run() deletes self.sd / self.network on its way out
+        return d
+
+    tr.hook_train_loop = loop
+    tr.run()
+    sd_, net_, ema_ = keep["sd"], keep["network"], keep["ema"]
+    assert len(losses) == steps and isinstance(sd_.unet.network, AdoptedNetwork) and sd_.unet.network.aliasing_intact()
+    assert sd_.unet.network.foreign is net_ and type(net_).__name__ == "LoRASpecialNetwork"
+    assert type(sd_.noise_scheduler).__name__ == "CustomFlowMatchEulerDiscreteScheduler"
+    assert all(type(t).__name__ == "FakeTextEncoder" for t in sd_.text_encoder)  # unloaded by toolkit/unloader.py after the static prompts
+    train_calls = [c for c in rec["calls"] if c[4]]
+    assert len(train_calls) == steps and len(rec["targets"]) == steps
+    out = {"losses": torch.tensor(losses, dtype=torch.float64)}
+    for i, ((lat, ts, emb, pooled, _, kw), tgt) in enumerate(zip(train_calls, rec["targets"])):
+        out[f"step{i}/latent_model_input"], out[f"step{i}/timestep"], out[f"step{i}/text"], out[f"step{i}/pooled"], out[f"step{i}/target"] = lat, ts, emb, pooled, tgt
+    save_root = os.path.join(tmp, "out", "aitk_trainer_run")
+    sd_final = load_file(os.path.join(save_root, "aitk_trainer_run.safetensors"))
+    for k, v in sd_final.items():
+        out[f"saved/{k}"] = v
+    opt_sd = torch.load(os.path.join(save_root, "optimizer.pt"), weights_only=True)
+    for i, st in opt_sd["state"].items():
+        out[f"opt/{i}/exp_avg"], out[f"opt/{i}/exp_avg_sq"] = st["exp_avg"], st["exp_avg_sq"]
+    for k, v in keep["init"].items():
+        out[f"init/{k}"] = v
+    for i, sp in enumerate(ema_.shadow_params):
+        out[f"ema/{i}"] = sp.detach().clone()
+    meta = {"steps": steps, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+            "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
+            "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
+            "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
+    out_dir = out_dir or HERE
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, "trainer_loop_flux_tiny.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
+    print("trainer loop golden:", meta["trainer"], meta["model"], meta["network"], meta["scheduler"], "losses", [round(x, 5) for x in losses], meta["files"])
 
 
 if __name__ == "__main__":
@@ -1465,3 +1657,4 @@ if __name__ == "__main__":
     golden_adoption()
     golden_flux_glue()
     golden_text_encoders()
+    golden_trainer_loop()

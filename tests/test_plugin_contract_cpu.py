@@ -149,7 +149,18 @@ def test_sharded_safetensors_round_trip_and_plugin_load_model(tmp_path, monkeypa
     monkeypatch.setattr(plugin, "_native_ops", lambda: __import__("oracle.ref_ops", fromlist=["x"]))
     assert not plug.is_loaded
     plug.load_model()
-    assert plug.is_loaded and plug.model._prepared and plug.vae is None and plug.noise_scheduler is not None
+    assert plug.is_loaded and plug.model._prepared and plug.noise_scheduler is not None
+    # no vae / text_encoder folders in this checkpoint: stand-ins that take the trainer's freeze / move calls (toolkit/unloader.py does the same)
+    assert isinstance(plug.vae, plugin.FakeVAE) and plug.vae.to("cpu") is plug.vae
+    assert [type(t) for t in plug.text_encoder] == [plugin.FakeTextEncoder] * 2 and plug.tokenizer == [None, None]
+    for te in plug.text_encoder:
+        te.requires_grad_(False).eval()
+    with pytest.raises(RuntimeError, match="latents must be cached"):
+        plug.encode_images([torch.zeros(3, 16, 16)])
+    # the native graph stays where it was built, whatever the trainer's device-state presets ask for (BaseSDTrainProcess.py:1899)
+    w = plug.model.x_embedder.weight
+    assert plug.model.to("cpu", dtype=torch.float16) is plug.model and plug.model.x_embedder.weight is w and w.dtype == torch.float32
+    assert plug.model.device == w.device and plug.model.dtype == torch.float32
     assert all(not p.requires_grad for p in plug.model.parameters())
     assert torch.equal(plug.model.x_embedder.weight, src.x_embedder.weight.to(torch.bfloat16).float())
     assert plug.unet is plug.model and plug.transformer is plug.model and plug.get_model_to_train() is plug.model
