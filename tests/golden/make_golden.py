@@ -1584,22 +1584,37 @@ def golden_trainer_loop(out_dir=None):
     job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
                                 raw_config={"config": {"name": "aitk_trainer_run"}}, log_dir=None, training_seed=7,
                                 config=OrderedDict(name="aitk_trainer_run"), gpu_id=0)
-    tr = SDTrainer(0, job, config)
     losses = []
-    orig_loop = tr.hook_train_loop
-
     keep = {}
 
-    def loop(batch):
-        if "init" not in keep:  # the adapter as the trainer initialised it (its RNG stream), before the first step
-            keep["init"] = OrderedDict((k, v.detach().clone()) for k, v in tr.network.state_dict().items())
-        d = orig_loop(batch)
-        losses.append(float(d["loss"]))
-        keep.update(sd=tr.sd, network=tr.network, ema=tr.ema, step=tr.step_num)  # run() deletes self.sd / self.network on its way out
-        return d
+    def run_trainer(cfg):
+        tr = SDTrainer(0, job, cfg)
+        orig_loop = tr.hook_train_loop
 
-    tr.hook_train_loop = loop
-    tr.run()
+        def loop(batch):
+            if "init" not in keep:  # the adapter as the trainer initialised it (its RNG stream), before the first step
+                keep["init"] = OrderedDict((k, v.detach().clone()) for k, v in tr.network.state_dict().items())
+            d = orig_loop(batch)
+            losses.append(float(d["loss"]))
+            keep.update(sd=tr.sd, network=tr.network, ema=tr.ema, step=tr.step_num)  # run() deletes self.sd / self.network on its way out
+            return d
+
+        tr.hook_train_loop = loop
+        tr.run()
+        return tr
+
+    tr = run_trainer(config)
+    # ---- RESUME (jobs/process/BaseSDTrainProcess.py:2057-2066, 2190-2215): a second process over the same training folder finds the latest LoRA
+    # file, loads it with the network's own load_weights (BEFORE the native graph's first forward: the adoption then takes those values over),
+    # restores optimizer.pt and the step count from the file's metadata, and trains on to step 5
+    import copy
+
+    resumed = copy.deepcopy(config)
+    resumed["train"]["steps"] = steps + 2
+    n_before = len(losses)
+    tr = run_trainer(resumed)
+    assert len(losses) == n_before + 2, losses
+    steps = steps + 2
     sd_, net_, ema_ = keep["sd"], keep["network"], keep["ema"]
     assert len(losses) == steps and isinstance(sd_.unet.network, AdoptedNetwork) and sd_.unet.network.aliasing_intact()
     assert sd_.unet.network.foreign is net_ and type(net_).__name__ == "LoRASpecialNetwork"
@@ -1621,7 +1636,7 @@ def golden_trainer_loop(out_dir=None):
         out[f"init/{k}"] = v
     for i, sp in enumerate(ema_.shadow_params):
         out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}

@@ -30,9 +30,9 @@ def test_the_run_was_the_references_own_trainer_network_and_scheduler():
         meta = json.loads(fh.metadata()["meta"])
     assert meta["trainer"] == "SDTrainer" and meta["network"] == "LoRASpecialNetwork" and meta["scheduler"] == "CustomFlowMatchEulerDiscreteScheduler"
     assert meta["model_mro"][:2] == ["Flux1MI355", "Flux1MI355Model"]  # the real BaseModel subclass of the extension, hooks from the mirror
-    assert meta["steps"] == 3 and meta["n_predict_calls"] == 3
+    assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5  # three steps, then a second process resumed for two more
     assert meta["opt_group"] == {"betas": [0.9, 0.999], "eps": 1e-06, "lr": 0.001, "weight_decay": 0.01}  # toolkit/optimizer.py:78-79 defaults
-    assert "aitk_trainer_run.safetensors" in meta["files"] and "optimizer.pt" in meta["files"] and "aitk_trainer_run_000000002.safetensors" in meta["files"]
+    assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
     assert meta["kw"] == {"guidance_embedding_scale": 1.0, "bypass_guidance_embedding": False}  # what BaseModel.predict_noise passed down
     assert all(k.startswith("transformer.") and (k.endswith("lora_A.weight") or k.endswith("lora_B.weight")) for k in meta["saved_keys"])
 
@@ -64,6 +64,15 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     ema = [p.detach().clone() for p in plist]
     losses = []
     for i in range(meta["steps"]):
+        if i == meta["resume_at"]:
+            # the second trainer process resumed here (BaseSDTrainProcess.py:2057-2066, 2190-2215): the network's own load_weights read the saved
+            # file — which holds the EMA weights (fp32 save dtype in this run) — optimizer.pt restored the AdamW moments and step counts, and a
+            # fresh EMA started from the loaded parameters
+            with torch.no_grad():
+                for p_, e_ in zip(plist, ema):
+                    p_.copy_(e_)
+            ema = [p_.detach().clone() for p_ in plist]
+            net.refresh_shadows(ref_ops)
         pe = SimpleNamespace(text_embeds=g[f"step{i}/text"], pooled_embeds=g[f"step{i}/pooled"])
         opt.zero_grad()
         with net:
