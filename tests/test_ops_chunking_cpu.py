@@ -12,11 +12,14 @@ from oracle import ref_ops
 
 def _down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo, split, tmask, tmask_rows_per_batch):
     Rc = pmat.shape[0]
-    assert Rc <= 64 and tmask is None and x_seg is None
+    assert Rc <= 64 and x_seg is None
     M = x.shape[0] if M is None else M
     t = x[:M].float() @ (pmat.float() + (p_lo.float() if p_lo is not None else 0)).t() * scale
     if mult is not None:
         t = t * mult[torch.arange(M) // rows_per_batch][:, None]
+    if tmask is not None:  # the kernel indexes the mask by the rank INSIDE the launch: a chunk brings its own contiguous [rows, Rc] matrix
+        assert tmask.is_contiguous() and tmask.shape[1] == Rc
+        t = t * (tmask[torch.arange(M) // tmask_rows_per_batch] if tmask_rows_per_batch else tmask[:M])
     if not split:
         out[:M, :Rc] = t.to(out.dtype)
         return out
@@ -70,5 +73,10 @@ def test_rank_chunks_write_one_slab_and_one_gradient(monkeypatch, R):
     ops.lora_wgrad(Tpr, gy, a, M=M)
     ref_ops.lora_wgrad(Tpr, gy, b, M=M)
     assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
-    with pytest.raises(NotImplementedError):  # the mask rides inside one launch
-        ops.lora_down(x, hi, T, M=M, split=R, p_lo=lo, tmask=torch.ones(M, R))
+    # dropout / rank_dropout masks above 64 ranks (round 5): every 64-rank launch takes its own contiguous slice of the mask
+    for rpb, rows in ((0, M), (100, 3)):  # neuron dropout (one mask row per token) / rank dropout (one per sample)
+        tm = (torch.rand(rows, R, generator=g) > 0.3).float() / 0.7
+        Tm, Tmr = torch.zeros(M, 3 * R, dtype=torch.bfloat16), torch.zeros(M, 3 * R, dtype=torch.bfloat16)
+        ops.lora_down(x, hi, Tm, scale=0.7, M=M, split=R, p_lo=lo, tmask=tm, tmask_rows_per_batch=rpb)
+        ref_ops.lora_down(x, hi, Tmr, scale=0.7, M=M, split=R, p_lo=lo, tmask=tm, tmask_rows_per_batch=rpb)
+        assert torch.equal(Tm, Tmr) and not torch.equal(Tm, T)
