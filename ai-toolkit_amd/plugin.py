@@ -96,6 +96,91 @@ def encode_prompts_flux(tokenizer, text_encoder, prompts, truncate=True, max_len
     return embeds, pooled
 
 
+def _text_tokenize(tokenizer, prompts, truncate=True, max_length=None, max_length_multiplier=4):
+    """toolkit/train_tools.py:192-230: pad / truncate to max_length; long prompts (truncate False) keep up to 4 windows of model_max_length and
+    drop the windows that are nothing but padding"""
+    if max_length is None:
+        max_length = tokenizer.model_max_length if truncate else tokenizer.model_max_length * max_length_multiplier
+    ids = tokenizer(prompts, padding="max_length", max_length=max_length, truncation=True, return_tensors="pt").input_ids
+    if truncate or max_length == tokenizer.model_max_length:
+        return ids
+    chunks = torch.chunk(ids, chunks=ids.shape[1] // tokenizer.model_max_length, dim=1)
+    return torch.cat([c for c in chunks if not c.eq(c[0, 0]).all()], dim=1)
+
+
+def encode_prompts(tokenizer, text_encoder, prompts, truncate=True, max_length=None, dropout_prob=0.0):
+    """SD1.x (toolkit/train_tools.py:379-422): CLIP last hidden state, long prompts window by window.  LIBRARY PATH like encode_prompts_flux."""
+    if max_length is None:
+        max_length = tokenizer.model_max_length
+    if dropout_prob > 0.0:
+        prompts = [p if torch.rand(1).item() > dropout_prob else "" for p in prompts]
+    tokens = _text_tokenize(tokenizer, prompts, truncate=truncate, max_length=max_length).to(text_encoder.device)
+    if truncate:
+        return text_encoder(tokens)[0]
+    return torch.cat([text_encoder(tokens[:, i:i + max_length])[0] for i in range(0, tokens.shape[-1], max_length)], dim=1)
+
+
+def encode_prompts_xl(tokenizers, text_encoders, prompts, prompts2=None, num_images_per_prompt=1, use_text_encoder_1=True, use_text_encoder_2=True,
+                      truncate=True, max_length=None, dropout_prob=0.0):
+    """SDXL (toolkit/train_tools.py:234-323): penultimate hidden states of both CLIP encoders concatenated on the feature axis, pooled output of
+    the second (the first window's for long prompts); a disabled encoder sees empty prompts.  LIBRARY PATH like encode_prompts_flux."""
+    embeds, pooled = [], None
+    prompts2 = prompts if prompts2 is None else prompts2
+    for idx, (tok, te) in enumerate(zip(tokenizers, text_encoders)):
+        use = prompts if idx == 0 else prompts2
+        if (idx == 0 and not use_text_encoder_1) or (idx == 1 and not use_text_encoder_2):
+            use = ["" for _ in prompts]
+        if dropout_prob > 0.0:
+            use = [p if torch.rand(1).item() > dropout_prob else "" for p in use]
+        ids = _text_tokenize(tok, use, truncate=truncate, max_length=max_length)
+        if idx == 0:
+            max_length = ids.shape[-1]
+        ids = ids.to(te.device)
+        if truncate:
+            o = te(ids, output_hidden_states=True)
+            pooled, e = o[0], o.hidden_states[-2]
+        else:
+            parts, pooled = [], None
+            for i in range(0, ids.shape[-1], tok.model_max_length):
+                o = te(ids[:, i:i + tok.model_max_length], output_hidden_states=True)
+                pooled = o[0] if pooled is None else pooled
+                parts.append(o.hidden_states[-2])
+            e = torch.cat(parts, dim=1)
+        bs, seq, _ = e.shape
+        embeds.append(e.repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, seq, -1))
+    bs = pooled.shape[0]
+    pooled = pooled.repeat(1, num_images_per_prompt).view(bs * num_images_per_prompt, -1)
+    return torch.concat(embeds, dim=-1), pooled
+
+
+def encode_prompts_wan(tokenizer, text_encoder, prompts, max_sequence_length=512, dtype=None):
+    """Wan2.1 (`Wan21.get_prompt_embeds`, toolkit/models/wan21/wan21.py:605-615, calls diffusers' `WanPipeline.encode_prompt(prompt,
+    do_classifier_free_guidance=False, max_sequence_length=512)`).  PARITY UNPINNED: the pipeline class is not vendored by the reference; this is the
+    published algorithm of its `_get_t5_prompt_embeds` — clean the text (html-unescape twice + whitespace collapse; `ftfy.fix_text` first when ftfy is
+    installed), tokenize to max_sequence_length with the attention mask, UMT5 last hidden state, every sequence cut at its own length and
+    zero-padded back to max_sequence_length.  LIBRARY PATH like encode_prompts_flux."""
+    import html
+    import re
+
+    def clean(t):
+        try:
+            import ftfy
+
+            fixed = ftfy.fix_text(t)
+            t = fixed if isinstance(fixed, str) else t
+        except ImportError:
+            pass
+        return re.sub(r"\s+", " ", html.unescape(html.unescape(t)).strip()).strip()
+
+    ti = tokenizer([clean(p) for p in prompts], padding="max_length", max_length=max_sequence_length, truncation=True, add_special_tokens=True,
+                   return_attention_mask=True, return_tensors="pt")
+    ids, mask = ti.input_ids, ti.attention_mask
+    lens = mask.gt(0).sum(dim=1).long()
+    e = text_encoder(ids.to(text_encoder.device), mask.to(text_encoder.device)).last_hidden_state
+    e = e.to(dtype=dtype or text_encoder.dtype)
+    return torch.stack([torch.cat([u[:v], u.new_zeros(max_sequence_length - int(v), u.size(1))]) for u, v in zip(e, lens)], dim=0)
+
+
 class FakeTextEncoder(torch.nn.Module):
     """Stand-in for a text encoder that is not loaded (toolkit/unloader.py:10-33 does the same after caching the embeddings): the reference's
     trainer calls `requires_grad_`, `eval`, `to`, `.device`, `.dtype` on whatever `sd.text_encoder` holds (BaseSDTrainProcess.py:1892-1898)."""
@@ -226,6 +311,9 @@ class _PluginBase:
 
     def _make_scheduler(self):
         return type(self).get_train_scheduler()
+
+    def get_transformer_block_names(self):
+        return None  # base_model.py:1636-1638 default: no block filter on the adapter discovery (the DiT families override)
 
     def load_model(self):
         """`model_config.name_or_path` = a diffusers pipeline directory (or the component directory itself, flux_kontext.py:84-92): the
@@ -528,6 +616,39 @@ class Wan21MI355Model(_PluginBase):
     def get_transformer_block_names(self):
         return ["blocks"]
 
+    def load_text_encoders(self, path=None):
+        """UMT5 encoder + tokenizer of a diffusers Wan2.1 pipeline directory through `transformers` (library path)."""
+        import os
+
+        from transformers import AutoTokenizer, UMT5EncoderModel
+
+        cfg = self.model_config
+        path = path or getattr(cfg, "extras_name_or_path", None) or getattr(cfg, "name_or_path", None)
+        for sub in ("tokenizer", "text_encoder"):
+            if not os.path.isdir(os.path.join(str(path), sub)):
+                raise FileNotFoundError(f"{path!r} has no '{sub}' sub-folder: prompts cannot be encoded here — train with cached text embeddings "
+                                        "(datasets: cache_text_embeddings: true)")
+        self.tokenizer = AutoTokenizer.from_pretrained(path, subfolder="tokenizer", local_files_only=True)
+        self.text_encoder = UMT5EncoderModel.from_pretrained(path, subfolder="text_encoder", torch_dtype=self.torch_dtype, local_files_only=True)
+        self.text_encoder.to(self.te_device_torch).requires_grad_(False).eval()
+        return self.text_encoder
+
+    def _load_text_side(self, path):
+        import os
+
+        if all(os.path.isdir(os.path.join(str(path), sub)) for sub in ("tokenizer", "text_encoder")):
+            self.load_text_encoders(path)
+        else:
+            super()._load_text_side(path)
+
+    def get_prompt_embeds(self, prompt, control_images=None):
+        te = self.text_encoder
+        if te is None or te.__class__.__name__ == "FakeTextEncoder":
+            self.load_text_encoders()
+        prompt = list(prompt) if isinstance(prompt, (list, tuple)) else [prompt]
+        with torch.no_grad():
+            return _prompt_embeds_class()(encode_prompts_wan(self.tokenizer, self.text_encoder, prompt, 512, self.torch_dtype))
+
     def get_noise_prediction(self, latent_model_input, timestep, text_embeddings, **kwargs):
         """latent_model_input [B,16,F,H,W], timestep [B] on the 0..1000 scale (wan21.py:578-603)."""
         text, _ = _embeds(text_embeddings)
@@ -583,7 +704,11 @@ class StableDiffusionMI355Model(_PluginBase):
 
         self.is_xl = bool(is_xl)
         self.prediction_type = prediction_type
-        self.noise_scheduler = DDPMTrainSchedule(prediction_type=prediction_type)
+        # the trainer hands the sampler it built (ModelClass.get_train_scheduler(), BaseSDTrainProcess.py:1767-1770, 1794-1801) to the constructor
+        # and later drives THAT object (set_timesteps / timesteps / config): keep it when it is a working DDPM table (diffusers DDPMScheduler:
+        # `alphas_cumprod`), the native schedule otherwise
+        if not torch.is_tensor(getattr(noise_scheduler, "alphas_cumprod", None)):
+            self.noise_scheduler = DDPMTrainSchedule(prediction_type=prediction_type)
 
     @staticmethod
     def get_train_scheduler():
@@ -618,6 +743,51 @@ class StableDiffusionMI355Model(_PluginBase):
     def get_bucket_divisibility(self):
         return 8  # vae scale factor 8; the UNet's three (SDXL: two) stride-2 levels are covered by the reference's 64-px bucket tolerance
 
+    @property
+    def _n_text_encoders(self):
+        return 2 if self.is_xl else 1
+
+    def load_text_encoders(self, path=None):
+        """CLIP text encoder(s) + tokenizer(s) of a diffusers SD1.x / SDXL pipeline directory through `transformers` (library path)."""
+        import os
+
+        from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+
+        cfg = self.model_config
+        path = path or getattr(cfg, "extras_name_or_path", None) or getattr(cfg, "name_or_path", None)
+        subs = (("tokenizer", "text_encoder", CLIPTextModel),) + ((("tokenizer_2", "text_encoder_2", CLIPTextModelWithProjection),) if self.is_xl else ())
+        for tk, te, _ in subs:
+            for sub in (tk, te):
+                if not os.path.isdir(os.path.join(str(path), sub)):
+                    raise FileNotFoundError(f"{path!r} has no '{sub}' sub-folder: prompts cannot be encoded here — train with cached text embeddings "
+                                            "(datasets: cache_text_embeddings: true)")
+        toks = [CLIPTokenizer.from_pretrained(path, subfolder=tk, local_files_only=True) for tk, _, _ in subs]
+        tes = [cls.from_pretrained(path, subfolder=te, torch_dtype=self.torch_dtype, local_files_only=True).to(self.te_device_torch).requires_grad_(False).eval()
+               for _, te, cls in subs]
+        self.tokenizer, self.text_encoder = (toks, tes) if self.is_xl else (toks[0], tes[0])
+        return self.text_encoder
+
+    def _load_text_side(self, path):
+        import os
+
+        if all(os.path.isdir(os.path.join(str(path), sub)) for sub in (("tokenizer", "text_encoder") + (("tokenizer_2", "text_encoder_2") if self.is_xl else ()))):
+            self.load_text_encoders(path)
+        else:
+            super()._load_text_side(path)
+
+    def get_prompt_embeds(self, prompt, control_images=None, prompt2=None, long_prompts=False, max_length=None, dropout_prob=0.0):
+        """toolkit/stable_diffusion_model.py:2400-2440 (the sd1 / sdxl branches of encode_prompt)."""
+        te = self.text_encoder
+        tes = te if isinstance(te, (list, tuple)) else [te]
+        if not te or any(t.__class__.__name__ == "FakeTextEncoder" for t in tes):
+            self.load_text_encoders()
+        prompt = list(prompt) if isinstance(prompt, (list, tuple)) else [prompt]
+        with torch.no_grad():
+            if self.is_xl:
+                e, pooled = encode_prompts_xl(self.tokenizer, self.text_encoder, prompt, prompt2, truncate=not long_prompts, max_length=max_length, dropout_prob=dropout_prob)
+                return _prompt_embeds_class()([e, pooled])
+            return _prompt_embeds_class()(encode_prompts(self.tokenizer, self.text_encoder, prompt, truncate=not long_prompts, max_length=max_length, dropout_prob=dropout_prob))
+
     def get_base_model_version(self):
         return "sdxl_1.0" if self.is_xl else "sd_1.5"
 
@@ -631,8 +801,21 @@ class StableDiffusionMI355Model(_PluginBase):
         ids = torch.tensor([[h * 8, w * 8, 0, 0, h * 8, w * 8]]).to(latents.device, dtype=latents.dtype)
         return torch.cat([ids for _ in range(bs)])
 
-    def add_noise(self, original_samples, noise, timesteps):
-        a, s = self.noise_scheduler.noise_coefficients(timesteps.to(original_samples.device), original_samples.dtype)
+    def _noise_coefficients(self, timesteps, dtype):
+        """(sqrt(alphas_cumprod[t]), sqrt(1 - alphas_cumprod[t])) from whichever schedule object this model holds: the native one, or the
+        trainer's diffusers DDPMScheduler (its add_noise / get_velocity read the same table the same way)."""
+        sch = self.noise_scheduler
+        if hasattr(sch, "noise_coefficients"):
+            return sch.noise_coefficients(timesteps, dtype)
+        acp = sch.alphas_cumprod.to(device=timesteps.device, dtype=dtype)
+        t = timesteps.long().reshape(-1)
+        return acp[t] ** 0.5, (1 - acp[t]) ** 0.5
+
+    def add_noise(self, original_samples, noise, timesteps, **kwargs):
+        timesteps = timesteps.to(original_samples.device).reshape(-1)
+        if timesteps.numel() == 1 and original_samples.shape[0] > 1:  # stable_diffusion_model.py:1865-1866
+            timesteps = timesteps.expand(original_samples.shape[0])
+        a, s = self._noise_coefficients(timesteps, original_samples.dtype)
         a, s = a.to(original_samples.dtype).view(-1, 1, 1, 1), s.to(original_samples.dtype).view(-1, 1, 1, 1)
         return a * original_samples + s * noise
 
@@ -643,7 +826,7 @@ class StableDiffusionMI355Model(_PluginBase):
         if self.prediction_type == "v_prediction":
             if batch is None or timesteps is None:
                 raise ValueError("v_prediction needs the batch latents and the timesteps")
-            a, s = self.noise_scheduler.noise_coefficients(timesteps.to(noise.device), noise.dtype)
+            a, s = self._noise_coefficients(timesteps.to(noise.device), noise.dtype)
             return (a.to(noise.dtype).view(-1, 1, 1, 1) * noise - s.to(noise.dtype).view(-1, 1, 1, 1) * batch.latents).detach()
         return noise.detach()
 

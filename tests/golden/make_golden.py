@@ -1434,11 +1434,29 @@ def golden_text_encoders():
         for tag, kw in (("plain", {}), ("masked", {"attn_mask": True}), ("len64", {"max_length": 64})):
             emb, pooled = encode_prompts_flux(toks, tes, list(PROMPTS), **kw)
             out[f"{tag}/embeds"], out[f"{tag}/pooled"] = emb.clone(), pooled.clone()
+    # ---- SD1.x / SDXL (toolkit/train_tools.py:192-323, 379-422): CLIP hidden states, long prompts in windows, SDXL's two encoders + pooled
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+
+    from toolkit.train_tools import encode_prompts, encode_prompts_xl
+
+    torch.manual_seed(41)
+    ccfg = dict(vocab_size=99, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)
+    c1 = CLIPTextModel(CLIPTextConfig(hidden_size=32, **ccfg)).eval()
+    c2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=48, projection_dim=40, **ccfg)).eval()
+    tk = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
+    long_prompts = [" ".join(f"w{i}" for i in range(40)), "short one"]
+    with torch.no_grad():
+        out["sd/plain"] = encode_prompts(tk[0], c1, list(PROMPTS)).clone()
+        for tag, kw in (("plain", {}), ("no_te1", {"use_text_encoder_1": False}), ("two_images", {"num_images_per_prompt": 2})):
+            e, p_ = encode_prompts_xl(tk, [c1, c2], list(PROMPTS), None, **kw)
+            out[f"sdxl/{tag}/embeds"], out[f"sdxl/{tag}/pooled"] = e.clone(), p_.clone()
+        e, p_ = encode_prompts_xl(tk, [c1, c2], long_prompts, None, truncate=False, max_length=16 * 4)
+        out["sdxl/long/embeds"], out["sdxl/long/pooled"] = e.clone(), p_.clone()
     save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(HERE, "text_encoders_flux.safetensors"))
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
-def golden_trainer_loop(out_dir=None):
+def golden_trainer_loop(out_dir=None, kind="flux"):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1486,18 +1504,37 @@ def golden_trainer_loop(out_dir=None):
         self.tokenizer, self.text_encoder = toks, [t.requires_grad_(False) for t in tes]
         return self.text_encoder
 
-    ext.Flux1MI355.load_text_encoders = tiny_te
-    ext.Flux1MI355._load_text_side = lambda self, path: self.load_text_encoders(path)
+    def tiny_umt5(self, path=None):
+        from transformers import UMT5Config, UMT5EncoderModel
+
+        torch.manual_seed(31)
+        self.text_encoder = UMT5EncoderModel(UMT5Config(vocab_size=101, d_model=48, d_kv=8, d_ff=48, num_layers=2, num_heads=3)).eval().requires_grad_(False)
+        self.tokenizer = HashTokenizer(101, 512)
+        return self.text_encoder
+
+    def tiny_clip(self, path=None):
+        from transformers import CLIPTextConfig, CLIPTextModel
+
+        torch.manual_seed(31)
+        self.text_encoder = CLIPTextModel(CLIPTextConfig(vocab_size=99, hidden_size=24, intermediate_size=48, num_hidden_layers=2, num_attention_heads=2,
+                                                         max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)).eval().requires_grad_(False)
+        self.tokenizer = HashTokenizer(99, 16)
+        return self.text_encoder
+
+    Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355}[kind]
+    Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip}[kind]
+    Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
 
     rec = {"calls": [], "targets": []}
-    orig_pred, orig_target = ext.Flux1MI355.get_noise_prediction, ext.Flux1MI355.get_loss_target
+    orig_pred, orig_target = Plug.get_noise_prediction, Plug.get_loss_target
 
     import functools
 
     @functools.wraps(orig_pred)  # keeps the signature BaseModel.predict_noise inspects (guidance_embedding_scale / bypass_guidance_embedding)
     def rec_pred(self, latent_model_input, timestep, text_embeddings, **kw):
+        pooled = text_embeddings.pooled_embeds
         rec["calls"].append((latent_model_input.detach().clone(), timestep.detach().clone(), text_embeddings.text_embeds.detach().clone(),
-                             text_embeddings.pooled_embeds.detach().clone(), bool(torch.is_grad_enabled()),
+                             torch.zeros(0) if pooled is None else pooled.detach().clone(), bool(torch.is_grad_enabled()),
                              {k: v for k, v in kw.items() if isinstance(v, (int, float, bool))}))
         return orig_pred(self, latent_model_input, timestep, text_embeddings, **kw)
 
@@ -1506,17 +1543,53 @@ def golden_trainer_loop(out_dir=None):
         rec["targets"].append(t.detach().clone())
         return t
 
-    ext.Flux1MI355.get_noise_prediction, ext.Flux1MI355.get_loss_target = rec_pred, rec_target
+    if kind == "sd15":  # the legacy-StableDiffusion mirror answers `predict_noise` itself (stable_diffusion_model.py:1878), one level above
+        orig_pn = Plug.predict_noise
+
+        @functools.wraps(orig_pn)
+        def rec_pn(self, latents, text_embeddings=None, timestep=1, **kw):
+            te = text_embeddings if text_embeddings is not None else kw.get("conditional_embeddings")
+            rec["calls"].append((latents.detach().clone(), torch.as_tensor(timestep).detach().clone(), te.text_embeds.detach().clone(), torch.zeros(0),
+                                 bool(torch.is_grad_enabled()), {k: v for k, v in kw.items() if isinstance(v, (int, float, bool))}))
+            return orig_pn(self, latents, text_embeddings=text_embeddings, timestep=timestep, **kw)
+
+        Plug.predict_noise, Plug.get_loss_target = rec_pn, rec_target
+    else:
+        Plug.get_noise_prediction, Plug.get_loss_target = rec_pred, rec_target
 
     tmp = tempfile.mkdtemp()
     torch.manual_seed(0)
-    ref = flux_ref.FluxTransformer2DModel(**ADOPT_CFG)
-    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
-    nat = FluxTransformer2DModel(**ADOPT_CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    if kind == "flux":
+        ref = flux_ref.FluxTransformer2DModel(**ADOPT_CFG)
+        flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+        nat = FluxTransformer2DModel(**ADOPT_CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+        cfg_json = dict(ADOPT_CFG, guidance_embeds=True, _class_name="FluxTransformer2DModel")
+        lat_shape, txt_dim, pooled_dim = (16, 8, 4), ADOPT_CFG["joint_attention_dim"], ADOPT_CFG["pooled_projection_dim"]
+    elif kind == "sd15":  # SD1.5 UNet (BASELINE config 1): eps-prediction over the DDPM schedule, CLIP hidden states
+        from ai_toolkit_amd.unet import UNet2DConditionModel
+        from oracle import unet_ref
+        from tests.test_unet_cpu import TINY_SD15
+
+        ref = unet_ref.UNet2DConditionModel(**TINY_SD15)
+        unet_ref.init_synthetic_(ref, seed=5, std=0.05)
+        nat = UNet2DConditionModel(**TINY_SD15, dtype=torch.float32, device="cpu", ops=ref_ops)
+        cfg_json = dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in TINY_SD15.items()}, _class_name="UNet2DConditionModel")
+        lat_shape, txt_dim, pooled_dim = (4, 8, 8), TINY_SD15["cross_attention_dim"], None
+    else:  # Wan2.1 (BASELINE config 4): video latents [B, 16, F, H, W], UMT5 text states, no pooled vector
+        from ai_toolkit_amd.wan import WanTransformer3DModel
+        from oracle import wan_ref
+        from tests.test_wan_cpu import CFG as WCFG
+
+        ref = wan_ref.WanTransformer3DModel(**WCFG)
+        wan_ref.init_synthetic_(ref, seed=99, std=0.05)
+        nat = WanTransformer3DModel(**WCFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+        cfg_json = dict(WCFG, patch_size=[1, 2, 2], _class_name="WanTransformer3DModel")
+        lat_shape, txt_dim, pooled_dim = (16, 3, 8, 4), WCFG["text_dim"], None
     nat.load_state_dict(ref.state_dict())
-    loader.save_component(nat, os.path.join(tmp, "ckpt", "transformer"))
-    with open(os.path.join(tmp, "ckpt", "transformer", "config.json"), "w") as f:
-        json.dump(dict(ADOPT_CFG, guidance_embeds=True, _class_name="FluxTransformer2DModel"), f)
+    comp = "unet" if kind == "sd15" else "transformer"
+    loader.save_component(nat, os.path.join(tmp, "ckpt", comp))
+    with open(os.path.join(tmp, "ckpt", comp, "config.json"), "w") as f:
+        json.dump(cfg_json, f)
 
     class Duck:
         def __init__(self, **kw):
@@ -1530,9 +1603,10 @@ def golden_trainer_loop(out_dir=None):
     class DuckBatch(Duck):  # the attribute set of toolkit/data_transfer_object/data_loader.py DataLoaderBatchDTO the FLUX LoRA step reads
         def __init__(self, B, seed):
             g = torch.Generator().manual_seed(seed)
-            pe = PromptEmbeds(torch.randn(B, 6, ADOPT_CFG["joint_attention_dim"], generator=g) * 0.5)
-            pe.pooled_embeds = torch.randn(B, ADOPT_CFG["pooled_projection_dim"], generator=g) * 0.5
-            super().__init__(latents=torch.randn(B, 16, 8, 4, generator=g), tensor=None, prompt_embeds=pe, loss_multiplier_list=[1.0] * B,
+            pe = PromptEmbeds(torch.randn(B, 6, txt_dim, generator=g) * 0.5)
+            if pooled_dim is not None:
+                pe.pooled_embeds = torch.randn(B, pooled_dim, generator=g) * 0.5
+            super().__init__(latents=torch.randn(B, *lat_shape, generator=g), tensor=None, prompt_embeds=pe, loss_multiplier_list=[1.0] * B,
                              file_items=[Duck(path=f"img{i}.png", dataset_config=Duck(), is_reg=False, prior_reg=False, network_weight=1.0) for i in range(B)])
             self.B = B
 
@@ -1576,10 +1650,10 @@ def golden_trainer_loop(out_dir=None):
                          save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
                          datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
                          train=dict(batch_size=2, steps=steps, gradient_accumulation=1, train_unet=True, train_text_encoder=False,
-                                    gradient_checkpointing=True, noise_scheduler="flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
+                                    gradient_checkpointing=True, noise_scheduler="ddpm" if kind == "sd15" else "flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
                                     disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
                                     ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
-                         model=dict(arch="flux_mi355", name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
+                         model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355"}[kind], name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
                          sample=dict(sample_every=10 ** 9, prompts=[]))
     job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
                                 raw_config={"config": {"name": "aitk_trainer_run"}}, log_dir=None, training_seed=7,
@@ -1618,10 +1692,13 @@ def golden_trainer_loop(out_dir=None):
     sd_, net_, ema_ = keep["sd"], keep["network"], keep["ema"]
     assert len(losses) == steps and isinstance(sd_.unet.network, AdoptedNetwork) and sd_.unet.network.aliasing_intact()
     assert sd_.unet.network.foreign is net_ and type(net_).__name__ == "LoRASpecialNetwork"
-    assert type(sd_.noise_scheduler).__name__ == "CustomFlowMatchEulerDiscreteScheduler"
-    assert all(type(t).__name__ == "FakeTextEncoder" for t in sd_.text_encoder)  # unloaded by toolkit/unloader.py after the static prompts
+    # sd15: diffusers is not installed here, toolkit/sampler.py hands back an import stub, and the plug-in falls back to its native DDPM schedule
+    # (a real DDPMScheduler is kept: tests/test_plugin_cpu.py); FLUX / Wan train on the reference's own flow-match scheduler object
+    assert type(sd_.noise_scheduler).__name__ == ("DDPMTrainSchedule" if kind == "sd15" else "CustomFlowMatchEulerDiscreteScheduler"), type(sd_.noise_scheduler)
+    tes_ = sd_.text_encoder if isinstance(sd_.text_encoder, (list, tuple)) else [sd_.text_encoder]
+    assert all(type(t).__name__ == "FakeTextEncoder" for t in tes_)  # unloaded by toolkit/unloader.py after the static prompts
     train_calls = [c for c in rec["calls"] if c[4]]
-    assert len(train_calls) == steps and len(rec["targets"]) == steps
+    assert len(train_calls) == steps and len(rec["targets"]) == steps, (len(rec["calls"]), len(train_calls), len(rec["targets"]))
     out = {"losses": torch.tensor(losses, dtype=torch.float64)}
     for i, ((lat, ts, emb, pooled, _, kw), tgt) in enumerate(zip(train_calls, rec["targets"])):
         out[f"step{i}/latent_model_input"], out[f"step{i}/timestep"], out[f"step{i}/text"], out[f"step{i}/pooled"], out[f"step{i}/target"] = lat, ts, emb, pooled, tgt
@@ -1641,8 +1718,16 @@ def golden_trainer_loop(out_dir=None):
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
     out_dir = out_dir or HERE
-    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, "trainer_loop_flux_tiny.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, f"trainer_loop_{kind}_tiny.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
     print("trainer loop golden:", meta["trainer"], meta["model"], meta["network"], meta["scheduler"], "losses", [round(x, 5) for x in losses], meta["files"])
+
+
+def golden_trainer_loop_wan(out_dir=None):
+    golden_trainer_loop(out_dir, kind="wan")
+
+
+def golden_trainer_loop_sd15(out_dir=None):
+    golden_trainer_loop(out_dir, kind="sd15")
 
 
 if __name__ == "__main__":
@@ -1673,3 +1758,5 @@ if __name__ == "__main__":
     golden_flux_glue()
     golden_text_encoders()
     golden_trainer_loop()
+    golden_trainer_loop(kind="wan")
+    golden_trainer_loop(kind="sd15")

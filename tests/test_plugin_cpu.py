@@ -143,3 +143,43 @@ def test_stable_diffusion_wrapper_prediction_and_autograd_backward_match_oracle(
         sd.predict_noise(lat, timestep=ts)
     with pytest.raises(NotImplementedError):
         sd.predict_noise(lat, text_embeddings=pe, timestep=ts, unconditional_embeddings=pe)
+
+
+def test_stable_diffusion_wrapper_keeps_the_trainers_own_ddpm_scheduler():
+    """BaseSDTrainProcess builds the sampler (ModelClass.get_train_scheduler(), jobs/process/BaseSDTrainProcess.py:1767-1770), passes it to
+    the model constructor (:1794-1801) and later drives that same object (set_timesteps / timesteps): a working DDPM table (diffusers
+    DDPMScheduler: `alphas_cumprod`) must stay the model's `noise_scheduler`, and add_noise / the v target read ITS table the way the
+    scheduler's own add_noise / get_velocity do; anything else (None, an import stub) falls back to the native schedule."""
+    from ai_toolkit_amd.ddpm import DDPMTrainSchedule
+    from ai_toolkit_amd.plugin import StableDiffusionMI355Model
+    from oracle import unet_ref
+    from tests.test_unet_cpu import TINY_SD15, build_pair
+
+    class TrainersDDPM:  # the attribute surface of diffusers' DDPMScheduler the train step touches, on a DIFFERENT table than the native default
+        def __init__(self):
+            self.alphas_cumprod = torch.cumprod(1.0 - torch.linspace(1e-4, 0.02, 1000), 0)
+            self.config = SimpleNamespace(num_train_timesteps=1000, prediction_type="epsilon")
+
+        def add_noise(self, x, n, t):  # published diffusers formula
+            a = self.alphas_cumprod[t].sqrt().view(-1, 1, 1, 1)
+            s = (1 - self.alphas_cumprod[t]).sqrt().view(-1, 1, 1, 1)
+            return a * x + s * n
+
+        def get_velocity(self, x, n, t):
+            a = self.alphas_cumprod[t].sqrt().view(-1, 1, 1, 1)
+            s = (1 - self.alphas_cumprod[t]).sqrt().view(-1, 1, 1, 1)
+            return a * n - s * x
+
+    _, _, nat, _ = build_pair(TINY_SD15)
+    sch = TrainersDDPM()
+    sd = StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, noise_scheduler=sch)
+    assert sd.noise_scheduler is sch
+    g = torch.Generator().manual_seed(0)
+    lat, noise, ts = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 8, 8, generator=g), torch.tensor([999, 3, 500])
+    assert torch.allclose(sd.add_noise(lat, noise, ts), sch.add_noise(lat, noise, ts), atol=1e-6)
+    assert not torch.allclose(sd.add_noise(lat, noise, ts), unet_ref.ddpm_add_noise(lat, noise, ts, unet_ref.ddpm_alphas_cumprod()), atol=1e-3)
+    assert torch.allclose(sd.add_noise(lat, noise, torch.tensor([500])), sch.add_noise(lat, noise, torch.tensor([500, 500, 500])), atol=1e-6)  # one timestep, whole batch
+    sv = StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, noise_scheduler=sch, prediction_type="v_prediction")
+    assert torch.allclose(sv.get_loss_target(noise=noise, batch=SimpleNamespace(latents=lat), timesteps=ts), sch.get_velocity(lat, noise, ts), atol=1e-6)
+    for other in (None, SimpleNamespace(), type("Stub", (), {"__getattr__": lambda self, k: self})()):
+        assert isinstance(StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, noise_scheduler=other).noise_scheduler, DDPMTrainSchedule)

@@ -74,6 +74,63 @@ def test_without_text_encoder_folders_the_hook_says_what_to_do(tmp_path):
     plug = plugin.Flux1MI355Model("cpu", __import__("types").SimpleNamespace(name_or_path=str(tmp_path), extras_name_or_path=None), dtype=torch.float32)
     with pytest.raises(FileNotFoundError, match="cache_text_embeddings"):
         plug.get_prompt_embeds("a photo")
-    # the other families keep cached-embeddings-only
-    with pytest.raises(NotImplementedError):
-        plugin.Wan21MI355Model("cpu").get_prompt_embeds("a photo")
+    for other in (plugin.Wan21MI355Model, plugin.StableDiffusionMI355Model):
+        with pytest.raises(FileNotFoundError, match="cache_text_embeddings"):
+            other("cpu", __import__("types").SimpleNamespace(name_or_path=str(tmp_path), extras_name_or_path=None), dtype=torch.float32).get_prompt_embeds("a photo")
+
+
+def test_wan_prompt_encoding_cuts_at_the_sequence_length_and_zero_pads():
+    """Wan2.1: PARITY UNPINNED (diffusers' WanPipeline.encode_prompt is not vendored) — the published behaviour is checked: text cleaned, UMT5 last
+    hidden state kept up to each prompt's own token count, zeros from there to max_sequence_length"""
+    from transformers import T5Config, UMT5Config, UMT5EncoderModel
+
+    torch.manual_seed(5)
+    te = UMT5EncoderModel(UMT5Config(vocab_size=101, d_model=24, d_kv=8, d_ff=48, num_layers=2, num_heads=3)).eval()
+    tok = HashTokenizer(101, 512)
+    with torch.no_grad():
+        out = plugin.encode_prompts_wan(tok, te, ["a  red &amp;amp; blue   fox", "two words", ""], max_sequence_length=32)
+    assert tuple(out.shape) == (3, 32, 24)
+    lens = [len("a red & blue fox".split()) + 1, 3, 1]  # tokens + eos of the CLEANED text (html-unescaped twice, whitespace collapsed)
+    for row, n in zip(out, lens):
+        assert float(row[n:].abs().max()) == 0.0 and float(row[:n].abs().min(dim=1).values.max()) > 0.0
+    wan = plugin.Wan21MI355Model("cpu", dtype=torch.float32)
+    wan.tokenizer, wan.text_encoder = tok, te
+    pe = wan.get_prompt_embeds("two words")
+    assert tuple(pe.text_embeds.shape) == (1, 512, 24) and pe.pooled_embeds is None
+    del T5Config
+
+
+def _clips(seed=41):
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+
+    torch.manual_seed(seed)
+    ccfg = dict(vocab_size=99, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)
+    c1 = CLIPTextModel(CLIPTextConfig(hidden_size=32, **ccfg)).eval()
+    c2 = CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=48, projection_dim=40, **ccfg)).eval()
+    return [HashTokenizer(99, 16), HashTokenizer(99, 16)], [c1, c2]
+
+
+def test_sd_and_sdxl_prompt_encoding_equal_the_reference_functions():
+    """toolkit/train_tools.py:192-323, 379-422 (encode_prompts / encode_prompts_xl incl. long prompts in windows, a disabled first encoder,
+    num_images_per_prompt) executed on tiny CLIP encoders — the plug-in's restatements land on the same tensors"""
+    gold = load_file(GOLD)
+    tk, (c1, c2) = _clips()
+    long_prompts = [" ".join(f"w{i}" for i in range(40)), "short one"]
+    with torch.no_grad():
+        assert torch.equal(plugin.encode_prompts(tk[0], c1, list(PROMPTS)), gold["sd/plain"])
+        for tag, kw in (("plain", {}), ("no_te1", {"use_text_encoder_1": False}), ("two_images", {"num_images_per_prompt": 2})):
+            e, p = plugin.encode_prompts_xl(tk, [c1, c2], list(PROMPTS), None, **kw)
+            assert torch.equal(e, gold[f"sdxl/{tag}/embeds"]) and torch.equal(p, gold[f"sdxl/{tag}/pooled"]), tag
+        e, p = plugin.encode_prompts_xl(tk, [c1, c2], long_prompts, None, truncate=False, max_length=64)
+        assert torch.equal(e, gold["sdxl/long/embeds"]) and torch.equal(p, gold["sdxl/long/pooled"])
+    assert gold["sdxl/plain/embeds"].shape == (3, 16, 32 + 48) and gold["sdxl/plain/pooled"].shape == (3, 40)
+    assert gold["sdxl/long/embeds"].shape[1] == 48 and gold["sdxl/two_images/embeds"].shape[0] == 6
+    # the plug-in hook (toolkit/stable_diffusion_model.py encode_prompt, sd1 / sdxl branches)
+    for xl in (False, True):
+        sd = plugin.StableDiffusionMI355Model("cpu", dtype=torch.float32, is_xl=xl)
+        sd.tokenizer, sd.text_encoder = (tk, [c1, c2]) if xl else (tk[0], c1)
+        pe = sd.get_prompt_embeds(list(PROMPTS))
+        if xl:
+            assert torch.equal(pe.text_embeds, gold["sdxl/plain/embeds"]) and torch.equal(pe.pooled_embeds, gold["sdxl/plain/pooled"])
+        else:
+            assert torch.equal(pe.text_embeds, gold["sd/plain"]) and pe.pooled_embeds is None

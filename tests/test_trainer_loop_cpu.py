@@ -17,43 +17,78 @@ from safetensors.torch import load_file
 import ai_toolkit_amd  # noqa: F401
 from ai_toolkit_amd.flux import FluxTransformer2DModel
 from ai_toolkit_amd.lora import FusedLoRANetwork
-from ai_toolkit_amd.plugin import Flux1MI355Model
-from oracle import flux_ref, ref_ops
+from ai_toolkit_amd.plugin import Flux1MI355Model, StableDiffusionMI355Model, Wan21MI355Model
+from ai_toolkit_amd.unet import UNet2DConditionModel
+from ai_toolkit_amd.wan import WanTransformer3DModel
+from oracle import flux_ref, ref_ops, unet_ref, wan_ref
+from tests.test_unet_cpu import TINY_SD15
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_loop_flux_tiny.safetensors")
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 CFG = dict(in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2,
            joint_attention_dim=64, pooled_projection_dim=32)
+WAN_CFG = dict(num_attention_heads=2, attention_head_dim=128, in_channels=16, out_channels=16, text_dim=48, freq_dim=256, ffn_dim=320, num_layers=3)
+# kind -> (fixture, native class, mirror class, oracle module, its config, synthetic-weight seed, what BaseModel.predict_noise passed down, key prefix)
+KINDS = {
+    "flux": (Flux1MI355Model, FluxTransformer2DModel, flux_ref.FluxTransformer2DModel, flux_ref.init_synthetic_, CFG, 1234,
+             {"guidance_embedding_scale": 1.0, "bypass_guidance_embedding": False}, "transformer."),
+    # Wan2.1 (BASELINE config 4): video latents [B, 16, F, H, W], UMT5 text states, no pooled vector; the LoRA file is written with the
+    # `diffusion_model.` prefix of the reference's Wan convert_lora_weights_before_save (extensions_built_in/diffusion_models/wan22/…, toolkit/models/wan21)
+    "wan": (Wan21MI355Model, WanTransformer3DModel, wan_ref.WanTransformer3DModel, wan_ref.init_synthetic_, WAN_CFG, 99, {}, "diffusion_model."),
+    # SD1.5 UNet (BASELINE config 1): eps-prediction over the DDPM schedule; the trainer calls the legacy-StableDiffusion `predict_noise` surface with
+    # its guidance arguments (all neutral in training); the LoRA file is in the kohya layout (lora_unet_* names, lora_down / lora_up / alpha)
+    "sd15": (StableDiffusionMI355Model, UNet2DConditionModel, unet_ref.UNet2DConditionModel, unet_ref.init_synthetic_, TINY_SD15, 5,
+             {"bypass_guidance_embedding": False, "detach_unconditional": False, "guidance_embedding_scale": 1.0, "guidance_scale": 1.0, "rescale_cfg": 1.0},
+             "lora_unet_"),
+}
+SCHEDULER = {"flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
+             # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
+             # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
+             "sd15": "DDPMTrainSchedule"}
 
 
-def test_the_run_was_the_references_own_trainer_network_and_scheduler():
-    with safe_open(GOLD, "pt") as fh:
+def gold(kind):
+    return os.path.join(HERE, "golden", f"trainer_loop_{kind}_tiny.safetensors")
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_the_run_was_the_references_own_trainer_network_and_scheduler(kind):
+    Mirror, _, _, _, _, _, kw, prefix = KINDS[kind]
+    with safe_open(gold(kind), "pt") as fh:
         meta = json.loads(fh.metadata()["meta"])
-    assert meta["trainer"] == "SDTrainer" and meta["network"] == "LoRASpecialNetwork" and meta["scheduler"] == "CustomFlowMatchEulerDiscreteScheduler"
-    assert meta["model_mro"][:2] == ["Flux1MI355", "Flux1MI355Model"]  # the real BaseModel subclass of the extension, hooks from the mirror
+    assert meta["trainer"] == "SDTrainer" and meta["network"] == "LoRASpecialNetwork" and meta["scheduler"] == SCHEDULER[kind]
+    assert meta["model_mro"][1] == Mirror.__name__ and meta["model_mro"][0] == Mirror.__name__[:-len("Model")]  # the real BaseModel subclass of the extension, hooks from the mirror
     assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5  # three steps, then a second process resumed for two more
     assert meta["opt_group"] == {"betas": [0.9, 0.999], "eps": 1e-06, "lr": 0.001, "weight_decay": 0.01}  # toolkit/optimizer.py:78-79 defaults
     assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
-    assert meta["kw"] == {"guidance_embedding_scale": 1.0, "bypass_guidance_embedding": False}  # what BaseModel.predict_noise passed down
-    assert all(k.startswith("transformer.") and (k.endswith("lora_A.weight") or k.endswith("lora_B.weight")) for k in meta["saved_keys"])
+    assert meta["kw"] == kw
+    tails = ("lora_down.weight", "lora_up.weight", "alpha") if kind == "sd15" else ("lora_A.weight", "lora_B.weight")
+    assert all(k.startswith(prefix) and k.endswith(tails) for k in meta["saved_keys"])
 
 
-def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optimizer_state_and_ema():
-    g = load_file(GOLD)
-    with safe_open(GOLD, "pt") as fh:
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optimizer_state_and_ema(kind):
+    Mirror, Native, Ref, init_, cfg, seed, _, prefix = KINDS[kind]
+    g = load_file(gold(kind))
+    with safe_open(gold(kind), "pt") as fh:
         meta = json.loads(fh.metadata()["meta"])
     torch.manual_seed(0)
-    ref = flux_ref.FluxTransformer2DModel(**CFG)
-    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
-    nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    ref = Ref(**cfg)
+    init_(ref, seed=seed, std=0.05)
+    nat = Native(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
     nat.load_state_dict(ref.state_dict(), strict=True)
     nat.prepare()
-    sd = Flux1MI355Model("cpu", model=nat, dtype=torch.float32)
-    net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, transformer_block_names=sd.get_transformer_block_names(), base_model=sd)
+    sd = Mirror("cpu", model=nat, dtype=torch.float32)
+    # what BaseSDTrainProcess passes per family (jobs/process/BaseSDTrainProcess.py:1937-1990)
+    extra = {"flux": {}, "wan": dict(target_lin_modules=tuple(sd.target_lora_modules), base_model_version="wan_2.1"),
+             "sd15": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sd1")}[kind]
+    net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
     init = {k[len("init/"):]: v for k, v in g.items() if k.startswith("init/")}
     with torch.no_grad():  # the adapter as the trainer's RNG stream initialised it
         for m in net.unet_loras:
-            m.lora_down.weight.copy_(init[f"{m.lora_name}.lora_down.weight"])
-            m.lora_up.weight.copy_(init[f"{m.lora_name}.lora_up.weight"])
+            m.lora_down.weight.copy_(init[f"{m.lora_name}.lora_down.weight"].reshape(m.lora_down.weight.shape))  # 1x1-conv adapters: [r, in, 1, 1]
+            m.lora_up.weight.copy_(init[f"{m.lora_name}.lora_up.weight"].reshape(m.lora_up.weight.shape))
     net.apply_to()
     net.build_arena("cpu", groups=nat.lora_groups())
     net.refresh_shadows(ref_ops)
@@ -73,12 +108,13 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
                     p_.copy_(e_)
             ema = [p_.detach().clone() for p_ in plist]
             net.refresh_shadows(ref_ops)
-        pe = SimpleNamespace(text_embeds=g[f"step{i}/text"], pooled_embeds=g[f"step{i}/pooled"])
+        pe = SimpleNamespace(text_embeds=g[f"step{i}/text"], pooled_embeds=g[f"step{i}/pooled"] if g[f"step{i}/pooled"].numel() else None)
         opt.zero_grad()
         with net:
             pred = sd.get_noise_prediction(g[f"step{i}/latent_model_input"], g[f"step{i}/timestep"], pe, **meta["kw"])
-            # SDTrainer.calculate_loss default branch (SDTrainer.py:903-1013): mse(reduction none) -> mean(1,2,3) -> * loss_multiplier (1) -> mean
-            loss = torch.nn.functional.mse_loss(pred.float(), g[f"step{i}/target"].float(), reduction="none").mean([1, 2, 3]).mean()
+            # SDTrainer.calculate_loss default branch (SDTrainer.py:903-1013): mse(reduction none) -> mean over all but the batch axis (:987-990; 5-D for video) -> * loss_multiplier (1) -> mean
+            loss = torch.nn.functional.mse_loss(pred.float(), g[f"step{i}/target"].float(), reduction="none")
+            loss = loss.mean(list(range(1, loss.dim()))).mean()
             loss.backward()
         torch.nn.utils.clip_grad_norm_(plist, meta["max_grad_norm"])
         opt.step()
@@ -91,38 +127,42 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
         net.refresh_shadows(ref_ops)
         losses.append(loss.item())
     assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-6, atol=0)
-    saved = net.get_state_dict(dtype=torch.float32)
+    saved = sd.convert_lora_weights_before_save(net.get_state_dict(dtype=torch.float32))
     assert sorted(saved) == sorted(meta["saved_keys"])
     # with train.ema_config.use_ema the trainer's save() writes the EMA weights (BaseSDTrainProcess.save: ema.store / copy_to around the save):
     # the file must equal the twin's EMA shadows, parameter by parameter
-    by_param = {id(p): e for p, e in zip(plist, ema)}
-    for m in net.unet_loras:
-        base = m.lora_name.replace("$$", ".")
-        assert torch.equal(by_param[id(m.lora_down.weight)], g[f"saved/{base}.lora_A.weight"]), base
-        assert torch.equal(by_param[id(m.lora_up.weight)], g[f"saved/{base}.lora_B.weight"]), base
-        assert not torch.equal(m.lora_up.weight.detach(), g[f"saved/{base}.lora_B.weight"])  # ... and not the live weights
-    for i, p in enumerate(plist):
-        assert torch.equal(opt.state[p]["exp_avg"], g[f"opt/{i}/exp_avg"]) and torch.equal(opt.state[p]["exp_avg_sq"], g[f"opt/{i}/exp_avg_sq"]), i
-        assert torch.equal(ema[i], g[f"ema/{i}"]), i
+    live_sd = {k: v.clone() for k, v in sd.convert_lora_weights_before_save(net.get_state_dict(dtype=torch.float32)).items()}
+    with torch.no_grad():  # ema.store / copy_to: the parameters hold the EMA while the file is written
+        for p_, e_ in zip(plist, ema):
+            p_.copy_(e_)
+    ema_sd = sd.convert_lora_weights_before_save(net.get_state_dict(dtype=torch.float32))  # Wan: the file's own key names
+    assert sorted(ema_sd) == sorted(meta["saved_keys"])
+    for k, v in ema_sd.items():
+        assert torch.equal(v.reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]), k
+    ups = [k for k in live_sd if k.endswith(("lora_B.weight", "lora_up.weight"))]
+    differ = sum(not torch.equal(live_sd[k].reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]) for k in ups)
+    assert ups and differ >= 0.9 * len(ups), (differ, len(ups))  # ... and not the live weights (an adapter whose gradient is exactly 0 stays at its zero init in both)
+    for i, p in enumerate(plist):  # (reshape: the reference's 1x1-conv adapters keep [.., 1, 1] axes)
+        assert torch.equal(opt.state[p]["exp_avg"], g[f"opt/{i}/exp_avg"].reshape(p.shape)) and torch.equal(opt.state[p]["exp_avg_sq"], g[f"opt/{i}/exp_avg_sq"].reshape(p.shape)), i
+        assert torch.equal(ema[i], g[f"ema/{i}"].reshape(p.shape)), i
 
 
 import subprocess  # noqa: E402
 import sys  # noqa: E402
 
-import pytest  # noqa: E402
-
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/toolkit"), reason="the reference tree is not mounted here")
-def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_today(tmp_path):
+@pytest.mark.parametrize("kind", list(KINDS))
+def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_today(tmp_path, kind):
     """run the reference's SDTrainer over the plug-in again (separate process: the import shims and accelerate's state stay out of this one)
     and compare with the committed fixture"""
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r)"
-            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path)))
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r)"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    new, old = load_file(str(tmp_path / "trainer_loop_flux_tiny.safetensors")), load_file(GOLD)
+    new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
     assert set(new) == set(old)
     for k in old:
         assert torch.equal(new[k], old[k]), k
