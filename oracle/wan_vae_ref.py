@@ -7,7 +7,10 @@ arithmetic is diffusers' `AutoencoderKLWan` (un-vendored, `requirements_base.txt
 unpinned** for the block arithmetic and for the parameter names (diffusers' names as published: `encoder.conv_in`,
 `encoder.down_blocks.N.{norm1,conv1,norm2,conv2,conv_shortcut}` / `.resample.1` / `.time_conv`, `encoder.mid_block.{resnets,attentions}`,
 `encoder.norm_out`, `encoder.conv_out`, `quant_conv`).  What IS pinned: the input handling and the per-channel latent normalisation are
-the reference's own lines above (tests/test_wan_vae_cpu.py restates them next to the call).
+the reference's own lines above (tests/test_wan_vae_cpu.py restates them next to the call); and — since round 5 — the encoder's stage order and
+the chunked evaluation itself (chunking, feature caches, first chunk past the time convolution): the reference's in-tree copy of the encoder forward and
+its cache-free temporal down-sampler (toolkit/models/wan21/autoencoder_kl_wan.py:32-77, 132-141, stated there to equal the chunked path exactly) are
+executed over THIS file's blocks (tests/golden/make_golden.py golden_wan_vae_flow) and `encoder(...)` chunk by chunk must reproduce the result.
 
 The restatement keeps the published CHUNKED evaluation literally — first frame alone, then 4 frames at a time, every causal convolution
 carrying a 2-frame feature cache, the temporal down-sampler passing the first chunk through without its time convolution — so that the

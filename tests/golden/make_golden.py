@@ -1722,6 +1722,75 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
     print("trainer loop golden:", meta["trainer"], meta["model"], meta["network"], meta["scheduler"], "losses", [round(x, 5) for x in losses], meta["files"])
 
 
+def golden_wan_vae_flow(out_dir=None):
+    """The part of the Wan2.1 video-VAE encoder the reference holds IN TREE (toolkit/models/wan21/autoencoder_kl_wan.py): its own copy of the
+    encoder forward (`_wan_encoder_forward`, :32-77: conv_in -> down blocks -> mid block -> norm_out -> nonlinearity -> conv_out) and the
+    cache-free temporal down-sampler it states to be EXACTLY the published chunked semantics (`_wan_resample_forward`, :132-141:
+    out = cat([x[:, :, :1], time_conv(x)], dim=2)).  Those two functions are loaded from the reference file and executed here, cache-free over the
+    whole clip, with the oracle's blocks as `self` (the block classes come from diffusers, which is not in this image: the module is imported
+    with placeholder classes of those names).  The result pins (a) the encoder's stage order and (b) the oracle's chunked evaluation — first frame
+    alone, four frames at a time, 2-frame feature caches, first chunk past the time convolution — against the reference's statement of what that
+    evaluation equals.  Block internals (residual block, RMS norm, attention, causal padding) stay diffusers-only: unpinned."""
+    import importlib.util
+    import types
+
+    from oracle import wan_vae_ref
+
+    ph = types.ModuleType("diffusers.models.autoencoders.autoencoder_kl_wan")
+    ph.CACHE_T = wan_vae_ref.CACHE_T
+    for name in ("AutoencoderKLWan", "WanDecoder3d", "WanEncoder3d", "WanResample"):
+        setattr(ph, name, type(name, (), {"forward": lambda self, *a, **k: (_ for _ in ()).throw(RuntimeError("placeholder"))}))
+    ph.patchify = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("placeholder"))
+    saved = {k: sys.modules.get(k) for k in ("diffusers", "diffusers.models", "diffusers.models.autoencoders", ph.__name__)}
+    for k in ("diffusers", "diffusers.models", "diffusers.models.autoencoders"):
+        if k not in sys.modules:
+            m = types.ModuleType(k)
+            m.__path__ = []
+            sys.modules[k] = m
+    sys.modules[ph.__name__] = ph
+    try:
+        spec = importlib.util.spec_from_file_location("ref_autoencoder_kl_wan", os.path.join(ref_shims.REFERENCE, "toolkit", "models", "wan21", "autoencoder_kl_wan.py"))
+        refmod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(refmod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    class Down(torch.nn.Module):  # an oracle WanResample behind the reference's cache-free forward
+        def __init__(self, blk):
+            super().__init__()
+            self.blk = blk
+
+        def forward(self, x, feat_cache=None, feat_idx=None):
+            assert feat_cache is None
+            if self.blk.mode == "downsample3d":
+                return refmod._wan_resample_forward(self.blk, x)
+            return self.blk(x)  # downsample2d: no temporal part (the reference routes it to the stock forward)
+
+    out, meta = {}, {"cases": []}
+    for tag, cfg, seed, T, hw in (("tiny", dict(base_dim=32, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=1, temperal_downsample=(False, True, True)), 0, 9, (32, 32)),
+                                  ("two_res", dict(base_dim=16, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)), 5, 13, (16, 24)),
+                                  # (a single frame cannot take this route: the reference's cache-free time_conv needs >= 3 frames)
+                                  ("five_frames", dict(base_dim=16, z_dim=4, dim_mult=(1, 2, 4, 4), num_res_blocks=1, temperal_downsample=(False, True, True)), 2, 5, (16, 16))):
+        vae = wan_vae_ref.AutoencoderKLWanEncoder(**cfg)
+        wan_vae_ref.init_synthetic_(vae, seed)
+        enc = vae.encoder
+        duck = types.SimpleNamespace(gradient_checkpointing=False, conv_in=enc.conv_in, mid_block=enc.mid_block, norm_out=enc.norm_out,
+                                     nonlinearity=torch.nn.SiLU(), conv_out=enc.conv_out,
+                                     down_blocks=[Down(b) if isinstance(b, wan_vae_ref.WanResample) else b for b in enc.down_blocks])
+        g = torch.Generator().manual_seed(100 + seed)
+        x = torch.rand(1, 3, T, *hw, generator=g) * 2 - 1
+        with torch.no_grad():
+            y = refmod._wan_encoder_forward(duck, x)  # cache-free, whole clip: the reference's own forward
+        out[f"{tag}/x"], out[f"{tag}/encoder_out"] = x, y
+        meta["cases"].append({"tag": tag, "cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, "seed": seed, "T": T})
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir or HERE, "wan_vae_flow.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
+    print("wan vae flow golden:", {c["tag"]: list(out[c["tag"] + "/encoder_out"].shape) for c in meta["cases"]})
+
+
 def golden_trainer_loop_wan(out_dir=None):
     golden_trainer_loop(out_dir, kind="wan")
 
@@ -1757,6 +1826,7 @@ if __name__ == "__main__":
     golden_adoption()
     golden_flux_glue()
     golden_text_encoders()
+    golden_wan_vae_flow()
     golden_trainer_loop()
     golden_trainer_loop(kind="wan")
     golden_trainer_loop(kind="sd15")

@@ -119,3 +119,56 @@ def test_conv3d_table_entry_is_a_causal_conv3d():
     ref_ops.conv3d(x.reshape(T * H * W, Cin)[: (2 * n + 1) * H * W].contiguous(), wt.reshape(Cin, Cin, 3).permute(0, 2, 1).reshape(Cin, 3 * Cin),
                    out_t, T=n, H=H, W=W, kt=3, ks=1, tstride=2, pad_t=0, pad_l=0)
     assert torch.allclose(out_t, want_t, rtol=1e-5, atol=1e-5)
+
+
+# ---- pinned to the reference's in-tree encoder flow (tests/golden/make_golden.py golden_wan_vae_flow) ----
+import json  # noqa: E402
+import os  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+from safetensors import safe_open  # noqa: E402
+from safetensors.torch import load_file  # noqa: E402
+
+FLOW = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wan_vae_flow.safetensors")
+
+
+def _flow_cases():
+    with safe_open(FLOW, "pt") as fh:
+        return json.loads(fh.metadata()["meta"])["cases"]
+
+
+@pytest.mark.parametrize("case", _flow_cases(), ids=lambda c: c["tag"])
+def test_chunked_oracle_and_whole_clip_graph_equal_the_references_own_encoder_forward(case):
+    """toolkit/models/wan21/autoencoder_kl_wan.py holds the reference's copy of the encoder forward and a cache-free temporal down-sampler it
+    states to equal the chunked-cache evaluation exactly (:132-141).  The fixture = those two functions executed cache-free over the whole clip on
+    the oracle's blocks.  (a) the oracle's literal CHUNKED evaluation (first frame, then 4 at a time, 2-frame caches) must land on it — the chunking
+    / caching restatement is pinned to the reference's own statement of it; (b) so must the product's whole-clip graph."""
+    g = load_file(FLOW)
+    cfg = dict(case["cfg"], dim_mult=tuple(case["cfg"]["dim_mult"]), temperal_downsample=tuple(case["cfg"]["temperal_downsample"]))
+    ref, nat = build(cfg, seed=case["seed"])
+    x, want = g[f"{case['tag']}/x"], g[f"{case['tag']}/encoder_out"]
+    T = x.shape[2]
+    with torch.no_grad():
+        feat_cache, out = [None] * ref._n_cached_convs(), None
+        for i in range(1 + (T - 1) // 4):  # AutoencoderKLWanEncoder.moments without the final quant_conv
+            chunk = x[:, :, :1] if i == 0 else x[:, :, 1 + 4 * (i - 1):1 + 4 * i]
+            o = ref.encoder(chunk, feat_cache, [0])
+            out = o if out is None else torch.cat([out, o], 2)
+        assert out.shape == want.shape and torch.allclose(out, want, rtol=1e-5, atol=1e-6), (out - want).abs().max()
+        want_mom = ref.quant_conv(want)
+    mom, (Tl, h, w) = nat.moments(x[0].permute(1, 0, 2, 3))
+    got = mom.view(Tl, h, w, want_mom.shape[1]).permute(3, 0, 1, 2).unsqueeze(0)
+    assert torch.allclose(got, want_mom, rtol=1e-4, atol=1e-5), (got - want_mom).abs().max()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/toolkit"), reason="the reference tree is not mounted here")
+def test_committed_wan_vae_flow_fixture_is_what_the_reference_file_produces_today(tmp_path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_wan_vae_flow'](%r)"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    new, old = load_file(str(tmp_path / "wan_vae_flow.safetensors")), load_file(FLOW)
+    assert set(new) == set(old) and all(torch.equal(new[k], old[k]) for k in old)
