@@ -1521,8 +1521,18 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         self.tokenizer = HashTokenizer(99, 16)
         return self.text_encoder
 
-    Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355}[kind]
-    Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip}[kind]
+    def tiny_clip_xl(self, path=None):
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+
+        torch.manual_seed(31)
+        ccfg = dict(vocab_size=99, intermediate_size=48, num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=16, eos_token_id=1, pad_token_id=0, bos_token_id=2)
+        self.text_encoder = [CLIPTextModel(CLIPTextConfig(hidden_size=8, **ccfg)).eval().requires_grad_(False),
+                             CLIPTextModelWithProjection(CLIPTextConfig(hidden_size=16, projection_dim=16, **ccfg)).eval().requires_grad_(False)]
+        self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
+        return self.text_encoder
+
+    Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
+    Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
 
     rec = {"calls": [], "targets": []}
@@ -1543,14 +1553,15 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         rec["targets"].append(t.detach().clone())
         return t
 
-    if kind == "sd15":  # the legacy-StableDiffusion mirror answers `predict_noise` itself (stable_diffusion_model.py:1878), one level above
+    if kind in ("sd15", "sdxl"):  # the legacy-StableDiffusion mirror answers `predict_noise` itself (stable_diffusion_model.py:1878), one level above
         orig_pn = Plug.predict_noise
 
         @functools.wraps(orig_pn)
         def rec_pn(self, latents, text_embeddings=None, timestep=1, **kw):
             te = text_embeddings if text_embeddings is not None else kw.get("conditional_embeddings")
-            rec["calls"].append((latents.detach().clone(), torch.as_tensor(timestep).detach().clone(), te.text_embeds.detach().clone(), torch.zeros(0),
-                                 bool(torch.is_grad_enabled()), {k: v for k, v in kw.items() if isinstance(v, (int, float, bool))}))
+            pooled = getattr(te, "pooled_embeds", None)
+            rec["calls"].append((latents.detach().clone(), torch.as_tensor(timestep).detach().clone(), te.text_embeds.detach().clone(),
+                                 torch.zeros(0) if pooled is None else pooled.detach().clone(), bool(torch.is_grad_enabled()), {k: v for k, v in kw.items() if isinstance(v, (int, float, bool))}))
             return orig_pn(self, latents, text_embeddings=text_embeddings, timestep=timestep, **kw)
 
         Plug.predict_noise, Plug.get_loss_target = rec_pn, rec_target
@@ -1565,16 +1576,18 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         nat = FluxTransformer2DModel(**ADOPT_CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
         cfg_json = dict(ADOPT_CFG, guidance_embeds=True, _class_name="FluxTransformer2DModel")
         lat_shape, txt_dim, pooled_dim = (16, 8, 4), ADOPT_CFG["joint_attention_dim"], ADOPT_CFG["pooled_projection_dim"]
-    elif kind == "sd15":  # SD1.5 UNet (BASELINE config 1): eps-prediction over the DDPM schedule, CLIP hidden states
+    elif kind in ("sd15", "sdxl"):  # SD1.5 / SDXL UNet (BASELINE configs 1, 2): eps-prediction over the DDPM schedule, CLIP hidden states (+ pooled, time ids)
         from ai_toolkit_amd.unet import UNet2DConditionModel
         from oracle import unet_ref
-        from tests.test_unet_cpu import TINY_SD15
+        from tests.test_unet_cpu import TINY_SD15, TINY_SDXL
 
-        ref = unet_ref.UNet2DConditionModel(**TINY_SD15)
+        ucfg = TINY_SDXL if kind == "sdxl" else TINY_SD15
+        ref = unet_ref.UNet2DConditionModel(**ucfg)
         unet_ref.init_synthetic_(ref, seed=5, std=0.05)
-        nat = UNet2DConditionModel(**TINY_SD15, dtype=torch.float32, device="cpu", ops=ref_ops)
-        cfg_json = dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in TINY_SD15.items()}, _class_name="UNet2DConditionModel")
-        lat_shape, txt_dim, pooled_dim = (4, 8, 8), TINY_SD15["cross_attention_dim"], None
+        nat = UNet2DConditionModel(**ucfg, dtype=torch.float32, device="cpu", ops=ref_ops)
+        cfg_json = dict({k: (list(v) if isinstance(v, tuple) else v) for k, v in ucfg.items()}, _class_name="UNet2DConditionModel")
+        lat_shape, txt_dim = (4, 8, 8), ucfg["cross_attention_dim"]
+        pooled_dim = ucfg["projection_class_embeddings_input_dim"] - 6 * ucfg["addition_time_embed_dim"] if kind == "sdxl" else None
     else:  # Wan2.1 (BASELINE config 4): video latents [B, 16, F, H, W], UMT5 text states, no pooled vector
         from ai_toolkit_amd.wan import WanTransformer3DModel
         from oracle import wan_ref
@@ -1586,7 +1599,7 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         cfg_json = dict(WCFG, patch_size=[1, 2, 2], _class_name="WanTransformer3DModel")
         lat_shape, txt_dim, pooled_dim = (16, 3, 8, 4), WCFG["text_dim"], None
     nat.load_state_dict(ref.state_dict())
-    comp = "unet" if kind == "sd15" else "transformer"
+    comp = "unet" if kind in ("sd15", "sdxl") else "transformer"
     loader.save_component(nat, os.path.join(tmp, "ckpt", comp))
     with open(os.path.join(tmp, "ckpt", comp, "config.json"), "w") as f:
         json.dump(cfg_json, f)
@@ -1650,10 +1663,10 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
                          save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
                          datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
                          train=dict(batch_size=2, steps=steps, gradient_accumulation=1, train_unet=True, train_text_encoder=False,
-                                    gradient_checkpointing=True, noise_scheduler="ddpm" if kind == "sd15" else "flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
+                                    gradient_checkpointing=True, noise_scheduler="ddpm" if kind in ("sd15", "sdxl") else "flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
                                     disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
                                     ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
-                         model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355"}[kind], name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
+                         model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355", "sdxl": "sd_mi355"}[kind], **({"is_xl": True} if kind == "sdxl" else {}), name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
                          sample=dict(sample_every=10 ** 9, prompts=[]))
     job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
                                 raw_config={"config": {"name": "aitk_trainer_run"}}, log_dir=None, training_seed=7,
@@ -1694,7 +1707,7 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
     assert sd_.unet.network.foreign is net_ and type(net_).__name__ == "LoRASpecialNetwork"
     # sd15: diffusers is not installed here, toolkit/sampler.py hands back an import stub, and the plug-in falls back to its native DDPM schedule
     # (a real DDPMScheduler is kept: tests/test_plugin_cpu.py); FLUX / Wan train on the reference's own flow-match scheduler object
-    assert type(sd_.noise_scheduler).__name__ == ("DDPMTrainSchedule" if kind == "sd15" else "CustomFlowMatchEulerDiscreteScheduler"), type(sd_.noise_scheduler)
+    assert type(sd_.noise_scheduler).__name__ == ("DDPMTrainSchedule" if kind in ("sd15", "sdxl") else "CustomFlowMatchEulerDiscreteScheduler"), type(sd_.noise_scheduler)
     tes_ = sd_.text_encoder if isinstance(sd_.text_encoder, (list, tuple)) else [sd_.text_encoder]
     assert all(type(t).__name__ == "FakeTextEncoder" for t in tes_)  # unloaded by toolkit/unloader.py after the static prompts
     train_calls = [c for c in rec["calls"] if c[4]]
@@ -1799,6 +1812,10 @@ def golden_trainer_loop_sd15(out_dir=None):
     golden_trainer_loop(out_dir, kind="sd15")
 
 
+def golden_trainer_loop_sdxl(out_dir=None):
+    golden_trainer_loop(out_dir, kind="sdxl")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:
@@ -1830,3 +1847,4 @@ if __name__ == "__main__":
     golden_trainer_loop()
     golden_trainer_loop(kind="wan")
     golden_trainer_loop(kind="sd15")
+    golden_trainer_loop(kind="sdxl")

@@ -21,7 +21,7 @@ from ai_toolkit_amd.plugin import Flux1MI355Model, StableDiffusionMI355Model, Wa
 from ai_toolkit_amd.unet import UNet2DConditionModel
 from ai_toolkit_amd.wan import WanTransformer3DModel
 from oracle import flux_ref, ref_ops, unet_ref, wan_ref
-from tests.test_unet_cpu import TINY_SD15
+from tests.test_unet_cpu import TINY_SD15, TINY_SDXL
 
 import pytest
 
@@ -41,11 +41,15 @@ KINDS = {
     "sd15": (StableDiffusionMI355Model, UNet2DConditionModel, unet_ref.UNet2DConditionModel, unet_ref.init_synthetic_, TINY_SD15, 5,
              {"bypass_guidance_embedding": False, "detach_unconditional": False, "guidance_embedding_scale": 1.0, "guidance_scale": 1.0, "rescale_cfg": 1.0},
              "lora_unet_"),
+    # SDXL UNet (BASELINE config 2): + pooled text embedding and the (H, W, 0, 0, H, W) time ids the mirror derives from the latents
+    "sdxl": (StableDiffusionMI355Model, UNet2DConditionModel, unet_ref.UNet2DConditionModel, unet_ref.init_synthetic_, TINY_SDXL, 5,
+             {"bypass_guidance_embedding": False, "detach_unconditional": False, "guidance_embedding_scale": 1.0, "guidance_scale": 1.0, "rescale_cfg": 1.0},
+             "lora_unet_"),
 }
 SCHEDULER = {"flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
-             "sd15": "DDPMTrainSchedule"}
+             "sd15": "DDPMTrainSchedule", "sdxl": "DDPMTrainSchedule"}
 
 
 def gold(kind):
@@ -63,7 +67,7 @@ def test_the_run_was_the_references_own_trainer_network_and_scheduler(kind):
     assert meta["opt_group"] == {"betas": [0.9, 0.999], "eps": 1e-06, "lr": 0.001, "weight_decay": 0.01}  # toolkit/optimizer.py:78-79 defaults
     assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
     assert meta["kw"] == kw
-    tails = ("lora_down.weight", "lora_up.weight", "alpha") if kind == "sd15" else ("lora_A.weight", "lora_B.weight")
+    tails = ("lora_down.weight", "lora_up.weight", "alpha") if kind in ("sd15", "sdxl") else ("lora_A.weight", "lora_B.weight")
     assert all(k.startswith(prefix) and k.endswith(tails) for k in meta["saved_keys"])
 
 
@@ -79,10 +83,11 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     nat = Native(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
     nat.load_state_dict(ref.state_dict(), strict=True)
     nat.prepare()
-    sd = Mirror("cpu", model=nat, dtype=torch.float32)
+    sd = Mirror("cpu", model=nat, dtype=torch.float32, **({"is_xl": True} if kind == "sdxl" else {}))
     # what BaseSDTrainProcess passes per family (jobs/process/BaseSDTrainProcess.py:1937-1990)
     extra = {"flux": {}, "wan": dict(target_lin_modules=tuple(sd.target_lora_modules), base_model_version="wan_2.1"),
-             "sd15": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sd1")}[kind]
+             "sd15": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sd1"),
+             "sdxl": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl")}[kind]
     net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
     init = {k[len("init/"):]: v for k, v in g.items() if k.startswith("init/")}
     with torch.no_grad():  # the adapter as the trainer's RNG stream initialised it
