@@ -68,17 +68,31 @@ __device__ __forceinline__ float wave_max(float v) {
 // of libm tanhf (~60 instructions): the GELU / dGELU GEMM epilogues were spending ~50 us per 256x256 tile round on it.
 // |error| ~1e-6 relative, far below the bf16 rounding of the stored result.
 __device__ __forceinline__ float sigmoid_fast_f(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  return x * sigmoid_fast_f(2.0f * k0 * (x + k1 * x * x * x));
+// GELU(tanh) and its derivative on PAIRS (the two bf16 halves of a packed word): every fp32 step is a packed instruction (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32: two elements per issue slot), only v_exp_f32 and v_rcp_f32 stay per element — 3 + 2 issue slots per element for
+// the forward (was 7 + 2 with the scalar chain the compiler formed) and 5.5 + 2 for the derivative (12.5 + 2): the GELU / dGELU GEMM epilogues
+// are VALU-issue bound (profiles/r04_gemm8_tile_switch.md).  s = sigmoid(2u) = 1 / (1 + 2^(c x (1 + k1 x^2))), c = -2 k0 log2(e) folded.
+// The operation ORDER below is the definition: every user (GEMM epilogues, the lora_wgrad GELU re-evaluation, the scalar wrappers) goes
+// through these two functions, explicit fma only, so all of them produce the same bits.
+__device__ __forceinline__ f32x2_t gelu_sigmoid_2(f32x2_t x, f32x2_t x2) {
+  const float k1 = 0.044715f, c = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+  const f32x2_t p = __builtin_elementwise_fma(x2, f32x2_t{k1, k1}, f32x2_t{1.0f, 1.0f});
+  const f32x2_t z = (x * p) * f32x2_t{c, c};
+  const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + f32x2_t{1.0f, 1.0f};
+  return f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
-// d/dx = 0.5 (1 + t) + 0.5 x (1 - t^2) u'(x)  with t = 2s - 1:  s + 2 x s (1 - s) u'(x),  u'(x) = k0 (1 + 3 k1 x^2)
-__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float x2 = x * x;
-  const float s = sigmoid_fast_f(2.0f * k0 * (x + k1 * x * x2));
-  return s + 2.0f * x * s * (1.0f - s) * (k0 * (1.0f + 3.0f * k1 * x2));
+__device__ __forceinline__ f32x2_t gelu_tanh_2(f32x2_t x) { return x * gelu_sigmoid_2(x, x * x); }
+// d/dx = 0.5 (1 + t) + 0.5 x (1 - t^2) u'(x)  with t = 2s - 1:  s + (s x (1 - s)) (2 k0 + 6 k0 k1 x^2)
+__device__ __forceinline__ f32x2_t gelu_tanh_grad_2(f32x2_t x) {
+  const float c1 = 2.0f * 0.7978845608028654f, c2 = 6.0f * 0.7978845608028654f * 0.044715f;
+  const f32x2_t x2 = x * x;
+  const f32x2_t s = gelu_sigmoid_2(x, x2);
+  const f32x2_t q = __builtin_elementwise_fma(x2, f32x2_t{c2, c2}, f32x2_t{c1, c1});
+  const f32x2_t w = x * (f32x2_t{1.0f, 1.0f} - s);
+  return __builtin_elementwise_fma(s * w, q, s);
 }
+__device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_2(f32x2_t{x, x}).x; }
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) { return gelu_tanh_grad_2(f32x2_t{x, x}).x; }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // bijective XCD-aware remap of a linear block id: blocks that land on one XCD (bid % 8) get a contiguous

@@ -710,13 +710,21 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               float u8[8];
               unpack8f(w, u8);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(u8[e]);
+              for (int e = 0; e < 8; e += 2) {
+                const f32x2_t h2 = gelu_tanh_2(f32x2_t{u8[e], u8[e + 1]});
+                v[e] = h2.x;
+                v[e + 1] = h2.y;
+              }
             }
             if constexpr (DGELU) {
               float u8[8];
               unpack8f(pin[2 * blk + it], u8);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad_f(u8[e]);
+              for (int e = 0; e < 8; e += 2) {
+                const f32x2_t g2 = f32x2_t{v[e], v[e + 1]} * gelu_tanh_grad_2(f32x2_t{u8[e], u8[e + 1]});
+                v[e] = g2.x;
+                v[e + 1] = g2.y;
+              }
             }
             if constexpr (GATE) {
               // y = bf16(linear out) saved when asked (d_gate needs it); x_new = res + gate[sample] * y
