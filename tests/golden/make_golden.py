@@ -1456,7 +1456,7 @@ def golden_text_encoders():
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
-def golden_trainer_loop(out_dir=None, kind="flux"):
+def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32"):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1531,6 +1531,7 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
         return self.text_encoder
 
+    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "")
     Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
     Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
@@ -1662,8 +1663,8 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
                          network=dict(type="lora", linear=8, linear_alpha=8),
                          save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
                          datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
-                         train=dict(batch_size=2, steps=steps, gradient_accumulation=1, train_unet=True, train_text_encoder=False,
-                                    gradient_checkpointing=True, noise_scheduler="ddpm" if kind in ("sd15", "sdxl") else "flowmatch", optimizer="adamw", lr=1e-3, dtype="fp32",
+                         train=dict(batch_size=2, steps=steps, gradient_accumulation=accum, train_unet=True, train_text_encoder=False,
+                                    gradient_checkpointing=True, noise_scheduler="ddpm" if kind in ("sd15", "sdxl") else "flowmatch", optimizer="adamw", lr=1e-3, dtype=dtype,
                                     disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
                                     ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
                          model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355", "sdxl": "sd_mi355"}[kind], **({"is_xl": True} if kind == "sdxl" else {}), name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
@@ -1711,7 +1712,7 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
     tes_ = sd_.text_encoder if isinstance(sd_.text_encoder, (list, tuple)) else [sd_.text_encoder]
     assert all(type(t).__name__ == "FakeTextEncoder" for t in tes_)  # unloaded by toolkit/unloader.py after the static prompts
     train_calls = [c for c in rec["calls"] if c[4]]
-    assert len(train_calls) == steps and len(rec["targets"]) == steps, (len(rec["calls"]), len(train_calls), len(rec["targets"]))
+    assert len(train_calls) == steps * accum and len(rec["targets"]) == steps * accum, (len(rec["calls"]), len(train_calls), len(rec["targets"]))
     out = {"losses": torch.tensor(losses, dtype=torch.float64)}
     for i, ((lat, ts, emb, pooled, _, kw), tgt) in enumerate(zip(train_calls, rec["targets"])):
         out[f"step{i}/latent_model_input"], out[f"step{i}/timestep"], out[f"step{i}/text"], out[f"step{i}/pooled"], out[f"step{i}/target"] = lat, ts, emb, pooled, tgt
@@ -1726,12 +1727,12 @@ def golden_trainer_loop(out_dir=None, kind="flux"):
         out[f"init/{k}"] = v
     for i, sp in enumerate(ema_.shadow_params):
         out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
     out_dir = out_dir or HERE
-    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, f"trainer_loop_{kind}_tiny.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
+    save_file({k: v.contiguous() for k, v in out.items()}, os.path.join(out_dir, f"trainer_loop_{tag}_tiny.safetensors"), {"meta": json.dumps(meta, sort_keys=True)})
     print("trainer loop golden:", meta["trainer"], meta["model"], meta["network"], meta["scheduler"], "losses", [round(x, 5) for x in losses], meta["files"])
 
 
@@ -1816,6 +1817,18 @@ def golden_trainer_loop_sdxl(out_dir=None):
     golden_trainer_loop(out_dir, kind="sdxl")
 
 
+def golden_trainer_loop_flux_bf16(out_dir=None):
+    """train.dtype: bf16 — the reference's default training dtype: base model and activations bf16, the network forced to fp32
+    (BaseSDTrainProcess.py:1983), latents / embeddings cast by the trainer before predict_noise."""
+    golden_trainer_loop(out_dir, kind="flux", dtype="bf16")
+
+
+def golden_trainer_loop_flux_accum2(out_dir=None):
+    """train.gradient_accumulation: 2 — two micro-batches per hook_train_loop call: `optimizer.zero_grad()` (set_to_none) at its top drops the
+    adopted parameters' .grad views, two backward passes accumulate, one clip / step / EMA (SDTrainer.py:2246-2293)."""
+    golden_trainer_loop(out_dir, kind="flux", accum=2)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # python tests/golden/make_golden.py golden_ema_options ...: only the named generators
         for name in sys.argv[1:]:
@@ -1848,3 +1861,5 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="wan")
     golden_trainer_loop(kind="sd15")
     golden_trainer_loop(kind="sdxl")
+    golden_trainer_loop(kind="flux", accum=2)
+    golden_trainer_loop(kind="flux", dtype="bf16")

@@ -46,7 +46,9 @@ KINDS = {
              {"bypass_guidance_embedding": False, "detach_unconditional": False, "guidance_embedding_scale": 1.0, "guidance_scale": 1.0, "rescale_cfg": 1.0},
              "lora_unet_"),
 }
-SCHEDULER = {"flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
+KINDS["flux_accum2"] = KINDS["flux"]  # train.gradient_accumulation: 2 (two micro-batches per optimizer step; zero_grad(set_to_none) drops the grad views)
+KINDS["flux_bf16"] = KINDS["flux"]    # train.dtype: bf16 (the reference's default): bf16 base + activations, fp32 network
+SCHEDULER = {"flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
              "sd15": "DDPMTrainSchedule", "sdxl": "DDPMTrainSchedule"}
@@ -63,7 +65,8 @@ def test_the_run_was_the_references_own_trainer_network_and_scheduler(kind):
         meta = json.loads(fh.metadata()["meta"])
     assert meta["trainer"] == "SDTrainer" and meta["network"] == "LoRASpecialNetwork" and meta["scheduler"] == SCHEDULER[kind]
     assert meta["model_mro"][1] == Mirror.__name__ and meta["model_mro"][0] == Mirror.__name__[:-len("Model")]  # the real BaseModel subclass of the extension, hooks from the mirror
-    assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5  # three steps, then a second process resumed for two more
+    accum = meta.get("accum", 1)
+    assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5 * accum  # three steps, then a second process resumed for two more
     assert meta["opt_group"] == {"betas": [0.9, 0.999], "eps": 1e-06, "lr": 0.001, "weight_decay": 0.01}  # toolkit/optimizer.py:78-79 defaults
     assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
     assert meta["kw"] == kw
@@ -77,17 +80,19 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     g = load_file(gold(kind))
     with safe_open(gold(kind), "pt") as fh:
         meta = json.loads(fh.metadata()["meta"])
+    accum = meta.get("accum", 1)
     torch.manual_seed(0)
     ref = Ref(**cfg)
     init_(ref, seed=seed, std=0.05)
-    nat = Native(**cfg, dtype=torch.float32, device="cpu", ops=ref_ops)
-    nat.load_state_dict(ref.state_dict(), strict=True)
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[meta.get("dtype", "fp32")]
+    nat = Native(**cfg, dtype=dt, device="cpu", ops=ref_ops)
+    nat.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()}, strict=True)
     nat.prepare()
-    sd = Mirror("cpu", model=nat, dtype=torch.float32, **({"is_xl": True} if kind == "sdxl" else {}))
+    sd = Mirror("cpu", model=nat, dtype=dt, **({"is_xl": True} if kind == "sdxl" else {}))
     # what BaseSDTrainProcess passes per family (jobs/process/BaseSDTrainProcess.py:1937-1990)
     extra = {"flux": {}, "wan": dict(target_lin_modules=tuple(sd.target_lora_modules), base_model_version="wan_2.1"),
              "sd15": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sd1"),
-             "sdxl": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl")}[kind]
+             "sdxl": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl")}[kind.split("_")[0]]
     net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
     init = {k[len("init/"):]: v for k, v in g.items() if k.startswith("init/")}
     with torch.no_grad():  # the adapter as the trainer's RNG stream initialised it
@@ -113,14 +118,18 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
                     p_.copy_(e_)
             ema = [p_.detach().clone() for p_ in plist]
             net.refresh_shadows(ref_ops)
-        pe = SimpleNamespace(text_embeds=g[f"step{i}/text"], pooled_embeds=g[f"step{i}/pooled"] if g[f"step{i}/pooled"].numel() else None)
         opt.zero_grad()
-        with net:
-            pred = sd.get_noise_prediction(g[f"step{i}/latent_model_input"], g[f"step{i}/timestep"], pe, **meta["kw"])
-            # SDTrainer.calculate_loss default branch (SDTrainer.py:903-1013): mse(reduction none) -> mean over all but the batch axis (:987-990; 5-D for video) -> * loss_multiplier (1) -> mean
-            loss = torch.nn.functional.mse_loss(pred.float(), g[f"step{i}/target"].float(), reduction="none")
-            loss = loss.mean(list(range(1, loss.dim()))).mean()
-            loss.backward()
+        step_loss = 0.0
+        for a in range(accum):  # SDTrainer.hook_train_loop: one backward per micro-batch, gradients accumulate (SDTrainer.py:2246-2271)
+            j = i * accum + a
+            pe = SimpleNamespace(text_embeds=g[f"step{j}/text"], pooled_embeds=g[f"step{j}/pooled"] if g[f"step{j}/pooled"].numel() else None)
+            with net:
+                pred = sd.get_noise_prediction(g[f"step{j}/latent_model_input"], g[f"step{j}/timestep"], pe, **meta["kw"])
+                # SDTrainer.calculate_loss default branch (SDTrainer.py:903-1013): mse(reduction none) -> mean over all but the batch axis (:987-990; 5-D for video) -> * loss_multiplier (1) -> mean
+                loss = torch.nn.functional.mse_loss(pred.float(), g[f"step{j}/target"].float(), reduction="none")
+                loss = loss.mean(list(range(1, loss.dim()))).mean()
+                loss.backward()
+            step_loss += loss.item()
         torch.nn.utils.clip_grad_norm_(plist, meta["max_grad_norm"])
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -130,7 +139,7 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
                 tmp.mul_(1.0 - meta["ema_decay"])
                 s.sub_(tmp)
         net.refresh_shadows(ref_ops)
-        losses.append(loss.item())
+        losses.append(step_loss / accum)  # the trainer logs the mean over its micro-batches
     assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-6, atol=0)
     saved = sd.convert_lora_weights_before_save(net.get_state_dict(dtype=torch.float32))
     assert sorted(saved) == sorted(meta["saved_keys"])
@@ -163,8 +172,8 @@ def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_
     and compare with the committed fixture"""
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r)"
-            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind))
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r)"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
