@@ -1456,7 +1456,7 @@ def golden_text_encoders():
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
-def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32"):
+def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1531,7 +1531,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32"):
         self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
         return self.text_encoder
 
-    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "")
+    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "")
     Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
     Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
@@ -1667,7 +1667,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32"):
                                     gradient_checkpointing=True, noise_scheduler="ddpm" if kind in ("sd15", "sdxl") else "flowmatch", optimizer="adamw", lr=1e-3, dtype=dtype,
                                     disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
                                     ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
-                         model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355", "sdxl": "sd_mi355"}[kind], **({"is_xl": True} if kind == "sdxl" else {}), name_or_path=os.path.join(tmp, "ckpt"), quantize=False),
+                         model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355", "sdxl": "sd_mi355"}[kind], **({"is_xl": True} if kind == "sdxl" else {}), name_or_path=os.path.join(tmp, "ckpt"), quantize=quantize),
                          sample=dict(sample_every=10 ** 9, prompts=[]))
     job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
                                 raw_config={"config": {"name": "aitk_trainer_run"}}, log_dir=None, training_seed=7,
@@ -1727,7 +1727,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32"):
         out[f"init/{k}"] = v
     for i, sp in enumerate(ema_.shadow_params):
         out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "accum": accum, "dtype": dtype, "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
@@ -1823,6 +1823,12 @@ def golden_trainer_loop_flux_bf16(out_dir=None):
     golden_trainer_loop(out_dir, kind="flux", dtype="bf16")
 
 
+def golden_trainer_loop_flux_bf16_fp8base(out_dir=None):
+    """model.quantize: true (BASELINE config 5's base): load_model quantises the block Linears to e4m3 + per-channel scale and releases the bf16
+    weights; the trainer's network is adopted over the quantised base."""
+    golden_trainer_loop(out_dir, kind="flux", dtype="bf16", quantize=True)
+
+
 def golden_trainer_loop_flux_accum2(out_dir=None):
     """train.gradient_accumulation: 2 — two micro-batches per hook_train_loop call: `optimizer.zero_grad()` (set_to_none) at its top drops the
     adopted parameters' .grad views, two backward passes accumulate, one clip / step / EMA (SDTrainer.py:2246-2293)."""
@@ -1863,3 +1869,4 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="sdxl")
     golden_trainer_loop(kind="flux", accum=2)
     golden_trainer_loop(kind="flux", dtype="bf16")
+    golden_trainer_loop(kind="flux", dtype="bf16", quantize=True)

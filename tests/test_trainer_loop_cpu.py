@@ -48,7 +48,8 @@ KINDS = {
 }
 KINDS["flux_accum2"] = KINDS["flux"]  # train.gradient_accumulation: 2 (two micro-batches per optimizer step; zero_grad(set_to_none) drops the grad views)
 KINDS["flux_bf16"] = KINDS["flux"]    # train.dtype: bf16 (the reference's default): bf16 base + activations, fp32 network
-SCHEDULER = {"flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
+KINDS["flux_bf16_fp8base"] = KINDS["flux"]  # model.quantize: true — e4m3 weight-only base under the adopted network (BASELINE config 5's base)
+SCHEDULER = {"flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
              "sd15": "DDPMTrainSchedule", "sdxl": "DDPMTrainSchedule"}
@@ -88,6 +89,9 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     nat = Native(**cfg, dtype=dt, device="cpu", ops=ref_ops)
     nat.load_state_dict({k: v.to(dt) for k, v in ref.state_dict().items()}, strict=True)
     nat.prepare()
+    if meta.get("quantize"):
+        assert meta["base_is_quantized"]
+        nat.quantize_base_fp8(release_bf16=True)  # what load_model does for model.quantize (plugin.py)
     sd = Mirror("cpu", model=nat, dtype=dt, **({"is_xl": True} if kind == "sdxl" else {}))
     # what BaseSDTrainProcess passes per family (jobs/process/BaseSDTrainProcess.py:1937-1990)
     extra = {"flux": {}, "wan": dict(target_lin_modules=tuple(sd.target_lora_modules), base_model_version="wan_2.1"),
@@ -172,8 +176,8 @@ def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_
     and compare with the committed fixture"""
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r)"
-            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32"))
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r)"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
