@@ -199,3 +199,90 @@ def test_reference_built_network_adopted_on_the_hip_kernels_equals_the_fused_net
     # inactive network == base model, bit for bit with the fused network's inactive pass
     with torch.no_grad():
         assert torch.equal(sd_a.get_noise_prediction(noisy, ts, pe, 1.0), sd_f.get_noise_prediction(noisy, ts, pe, 1.0))
+
+
+@pytest.mark.parametrize("sdxl", [False, True], ids=["sd15", "sdxl"])
+def test_reference_built_conv_network_adopted_on_the_unet_hip_kernels_bit_for_bit(sdxl):
+    """The UNet leg of the adoption on the GPU (CPU twin + the reference's own LoRASpecialNetwork run: tests/test_adoption_cpu.py): a network the
+    "trainer" built by class-name discovery over the native UNet — Linear, 1x1-conv and (network.conv) 3x3-conv adapters with diffusers-shaped
+    4-D Conv2d weights, kohya names — is adopted: its Parameters are re-pointed at [rank_pad, in*k*k] / [out, rank_pad] arena blocks and the HIP
+    kernels (implicit-GEMM conv + conv-adapter epilogues) run it.  Bit-identical to a FusedLoRANetwork over the same model."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.adopt import AdoptedNetwork
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.plugin import StableDiffusionMI355Model
+    from ai_toolkit_amd.unet import UNet2DConditionModel
+    from oracle import lora_ref, unet_ref
+    from tests.test_gpu_unet import MID_SD15, MID_SDXL, _batch
+
+    cfg = dict(unet_ref.SDXL if sdxl else unet_ref.SD15, **(MID_SDXL if sdxl else MID_SD15))
+    torch.manual_seed(0)
+    ref = unet_ref.UNet2DConditionModel(**cfg)
+    unet_ref.init_synthetic_(ref, seed=11)
+    state = {k: v.to(bf) for k, v in ref.state_dict().items()}
+
+    def native():
+        nat = UNet2DConditionModel(**cfg, dtype=bf, device="cuda", ops=ops)
+        nat.load_state_dict(state, strict=True)
+        nat.prepare()
+        return nat, StableDiffusionMI355Model("cuda", model=nat, dtype=bf, is_xl=sdxl)
+
+    nat_a, sd_a = native()
+    nat_f, sd_f = native()
+    torch.manual_seed(99)
+    net_a = lora_ref.RefLoRANetwork(sd_a.get_model_to_train(), 8, 1.0, target=tuple(sd_a.target_lora_modules), kohya_unet=True, alpha=4.0,
+                                    conv_lora_dim=4, conv_alpha=2.0)
+    torch.manual_seed(99)
+    net_f = FusedLoRANetwork(nat_f, lora_dim=8, alpha=4.0, conv_lora_dim=4, conv_alpha=2.0, target_lin_modules=("Transformer2DModel",),
+                             is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl" if sdxl else "sd1")
+    assert [m.lora_name for m in net_a.unet_loras] == [m.lora_name for m in net_f.unet_loras]
+    assert any(m.lora_down.weight.dim() == 4 and m.lora_down.weight.shape[2:] == (3, 3) for m in net_a.unet_loras)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net_a.unet_loras, net_f.unet_loras):
+            b.lora_down.weight.copy_(a.lora_down.weight.reshape(b.lora_down.weight.shape))
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.03
+            a.lora_up.weight.copy_(up.reshape(a.lora_up.weight.shape))
+            b.lora_up.weight.copy_(up)
+    # --- the trainer's side
+    net_a.force_to(torch.device("cuda"), torch.float32)
+    sd_a.network = net_a
+    net_a._update_torch_multiplier()
+    net_a.apply_to(None, sd_a.unet, False, True)
+    pa = [p for grp in net_a.prepare_optimizer_params(None, 1e-3, 1e-3) for p in grp["params"]]
+    # --- the fused network
+    net_f.apply_to()
+    net_f.build_arena("cuda", groups=nat_f.lora_groups())
+    net_f.refresh_shadows(ops)
+    nat_f.attach_network(net_f)
+    pf = net_f.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    oa = torch.optim.AdamW(pa, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    of = torch.optim.AdamW(pf, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    for k in range(2):
+        lat, ctx, pooled, noise, ts = _batch(cfg, seed=50 + k)
+        noisy = sd_f.add_noise(lat, noise, ts)
+        pe = SimpleNamespace(text_embeds=ctx, pooled_embeds=pooled)
+        out = []
+        for net, sd, opt, plist in ((net_a, sd_a, oa, pa), (net_f, sd_f, of, pf)):
+            opt.zero_grad()
+            with net:
+                pred = sd.predict_noise(noisy, text_embeddings=pe, timestep=ts)
+                loss = torch.nn.functional.mse_loss(pred.float(), noise.float(), reduction="none").mean([1, 2, 3]).mean()
+                loss.backward()
+            grads = (nat_a.network if net is net_a else net_f).arena_g.clone()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append((loss.detach(), grads))
+        net_f.refresh_shadows(ops)
+        assert math.isfinite(out[0][0].item()) and torch.equal(out[0][0], out[1][0]), (k, out[0][0].item(), out[1][0].item())
+        assert torch.equal(out[0][1], out[1][1]), (k, _rel(out[0][1], out[1][1]))
+        assert out[0][1].abs().sum().item() > 0
+    ad = nat_a.network
+    assert isinstance(ad, AdoptedNetwork) and ad.foreign is net_a and ad.aliasing_intact() and torch.equal(ad.arena_p, net_f.arena_p)
+    for a, b in zip(pa, pf):
+        assert a.is_cuda and torch.equal(a.detach().reshape(b.shape), b.detach())
+    # what the reference-side object would save: Conv2d-shaped tensors with the arena's values, the fused network's kohya keys
+    sa, sf = net_a.state_dict(), net_f.get_state_dict(dtype=torch.float32)
+    for key, v in sf.items():
+        assert torch.equal(sa[key].detach().reshape(v.shape).float().cpu(), v.cpu()), key
