@@ -13,7 +13,7 @@ import ai_toolkit_amd  # noqa: F401
 from ai_toolkit_amd.flux import FluxTransformer2DModel
 from ai_toolkit_amd.lora import FusedLoRANetwork
 from ai_toolkit_amd.trainer import FluxLoRATrainStep
-from oracle import flux_ref, lora_ref, ref_ops, train_ref
+from oracle import flux_ref, lora_ref, ref_ops
 from tests.test_oracle_golden import TINY, oracle_model, tiny_inputs
 
 G = os.path.join(os.path.dirname(__file__), "golden")

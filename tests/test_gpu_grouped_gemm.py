@@ -1,7 +1,6 @@
 """aitk_gemm_nt_grouped: two problems (same N, K, K2, flags; different operands and row counts) in one persistent launch must give
 bitwise the results of two aitk_gemm_nt calls — every output tile is computed by the same code on the same operands — and the FLUX
 double block with its image / text launches merged (graph.FusedGraphBase._paired) must be bitwise the sequential graph."""
-import ctypes as C
 
 import pytest
 import torch

@@ -3,7 +3,6 @@ HIP path as on the oracle (same hyper-parameters, same inputs), and the two loss
 import math
 
 import pytest
-import torch
 
 pytestmark = pytest.mark.gpu
 

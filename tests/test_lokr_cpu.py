@@ -15,7 +15,6 @@ from ai_toolkit_amd.lora import FusedLoRANetwork, factorization
 from ai_toolkit_amd.trainer import FluxLoRATrainStep
 from oracle import lora_ref, ref_ops, train_ref
 from tests.test_oracle_golden import G, TINY, oracle_model, tiny_inputs
-from tests.test_train_step_cpu import batch
 
 BIG = 9999999999  # lokr_full_rank (toolkit/config_modules.py:204-209)
 

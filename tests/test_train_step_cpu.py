@@ -229,7 +229,6 @@ def test_latent_multipliers_of_the_trainer():
     """latent_multiplier / adaptive_scaling_factor / noisy_latent_multiplier (jobs/process/BaseSDTrainProcess.py:1393-1401, 1467-1470):
     the step with the option == the plain step on the pre-scaled latents (batch.latents IS the scaled tensor, so the flow target follows it);
     the noisy-latent multiplier scales the model input only."""
-    from ai_toolkit_amd import flowmatch
     from tests.test_host_graph_cpu import build_pair
 
     def run(kw, lat_scale=None):

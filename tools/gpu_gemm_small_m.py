@@ -1,6 +1,6 @@
 import sys, torch
 sys.path.insert(0, ".")
-import ai_toolkit_amd
+import ai_toolkit_amd  # noqa: F401  (registers the `ai_toolkit_amd` package alias)
 from ai_toolkit_amd import ops
 def t(fn, n=5, it=10):
     for _ in range(3): fn()
