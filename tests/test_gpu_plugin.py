@@ -286,3 +286,81 @@ def test_reference_built_conv_network_adopted_on_the_unet_hip_kernels_bit_for_bi
     sa, sf = net_a.state_dict(), net_f.get_state_dict(dtype=torch.float32)
     for key, v in sf.items():
         assert torch.equal(sa[key].detach().reshape(v.shape).float().cpu(), v.cpu()), key
+
+
+def test_reference_built_network_adopted_on_the_wan_hip_kernels_bit_for_bit():
+    """The Wan2.1 leg of the adoption on the GPU (BASELINE config 4; CPU twin + the reference's own LoRASpecialNetwork run:
+    tests/test_adoption_cpu.py): a network built the trainer's way over the native video DiT (block filter `blocks`, 5-D latents, UMT5 text
+    states, no pooled vector) is adopted and must be bit-identical to a FusedLoRANetwork over the same model on the HIP kernels."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.adopt import AdoptedNetwork
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.plugin import Wan21MI355Model
+    from ai_toolkit_amd.wan import WanTransformer3DModel
+    from oracle import lora_ref, wan_ref
+    from tests.test_gpu_wan import CFG as WCFG
+
+    torch.manual_seed(0)
+    ref = wan_ref.WanTransformer3DModel(**WCFG)
+    wan_ref.init_synthetic_(ref, seed=99, std=0.03)
+    state = {k: v.to(bf) for k, v in ref.state_dict().items()}
+
+    def native():
+        nat = WanTransformer3DModel(**WCFG, dtype=bf, device="cuda", ops=ops)
+        nat.load_state_dict(state, strict=True)
+        nat.prepare()
+        return nat, Wan21MI355Model("cuda", model=nat, dtype=bf)
+
+    nat_a, sd_a = native()
+    nat_f, sd_f = native()
+    net_a = lora_ref.RefLoRANetwork(sd_a.get_model_to_train(), 16, 1.0, target=tuple(sd_a.target_lora_modules), block_names=tuple(sd_a.get_transformer_block_names()))
+    net_f = FusedLoRANetwork(nat_f, lora_dim=16, target_lin_modules=tuple(sd_f.target_lora_modules), transformer_block_names=sd_f.get_transformer_block_names(),
+                             base_model_version="wan_2.1", base_model=sd_f)
+    assert [m.lora_name for m in net_a.unet_loras] == [m.lora_name for m in net_f.unet_loras] and len(net_f.unet_loras) == 10 * WCFG["num_layers"]
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net_a.unet_loras, net_f.unet_loras):
+            b.lora_down.weight.copy_(a.lora_down.weight)
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.02
+            a.lora_up.weight.copy_(up)
+            b.lora_up.weight.copy_(up)
+    net_a.force_to(torch.device("cuda"), torch.float32)
+    sd_a.network = net_a
+    net_a._update_torch_multiplier()
+    net_a.apply_to(None, sd_a.unet, False, True)
+    pa = [p for grp in net_a.prepare_optimizer_params(None, 1e-3, 1e-3) for p in grp["params"]]
+    net_f.apply_to()
+    net_f.build_arena("cuda", groups=nat_f.lora_groups())
+    net_f.refresh_shadows(ops)
+    nat_f.attach_network(net_f)
+    pf = net_f.prepare_optimizer_params(default_lr=1e-3)[0]["params"]
+    oa = torch.optim.AdamW(pa, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    of = torch.optim.AdamW(pf, lr=1e-3, eps=1e-6, weight_decay=0.01)
+    gen = torch.Generator().manual_seed(3)
+    for k in range(2):
+        lat = torch.randn(2, 16, 3, 16, 8, generator=gen).to(bf).cuda()
+        tgt = torch.randn(2, 16, 3, 16, 8, generator=gen).to(bf).cuda()
+        pe = SimpleNamespace(text_embeds=(torch.randn(2, 24, WCFG["text_dim"], generator=gen) * 0.5).to(bf).cuda(), pooled_embeds=None)
+        ts = torch.tensor([310.0, 845.0], device="cuda")
+        out = []
+        for net, sd, opt, plist in ((net_a, sd_a, oa, pa), (net_f, sd_f, of, pf)):
+            opt.zero_grad()
+            with net:
+                pred = sd.get_noise_prediction(lat, ts, pe)
+                loss = torch.nn.functional.mse_loss(pred.float(), tgt.float(), reduction="none").mean([1, 2, 3, 4]).mean()
+                loss.backward()
+            grads = (nat_a.network if net is net_a else net_f).arena_g.clone()
+            torch.nn.utils.clip_grad_norm_(plist, 1.0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append((loss.detach(), grads))
+        net_f.refresh_shadows(ops)
+        assert math.isfinite(out[0][0].item()) and torch.equal(out[0][0], out[1][0]), (k, out[0][0].item(), out[1][0].item())
+        assert torch.equal(out[0][1], out[1][1]) and out[0][1].abs().sum().item() > 0, (k, _rel(out[0][1], out[1][1]))
+    ad = nat_a.network
+    assert isinstance(ad, AdoptedNetwork) and ad.foreign is net_a and ad.aliasing_intact() and torch.equal(ad.arena_p, net_f.arena_p)
+    # the file the reference-side object would write, through the plug-in's key converter (diffusion_model.* names): the fused network's
+    sa = sd_a.convert_lora_weights_before_save(net_a.peft_state_dict(dtype=torch.float32))
+    sf = net_f.get_state_dict(dtype=torch.float32)
+    assert sorted(sa) == sorted(sf) and next(iter(sf)).startswith("diffusion_model.blocks.0.")
+    assert all(torch.equal(sa[key].cpu(), sf[key].cpu()) for key in sf)
