@@ -31,7 +31,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from .lora import FusedLoRANetwork, _ParamProxy
+from .lora import FusedLoRANetwork, _ParamProxy, check_kron_fits
 
 # class names of the reference's adapter modules (toolkit/lora_special.py:46, toolkit/models/DoRA.py:36, toolkit/models/lokr.py:79) and of the
 # oracle's restatements of them (oracle/lora_ref.py: tests drive the adoption without importing the reference)
@@ -128,6 +128,10 @@ def register_foreign_adapter(layer, new_forward):
         out_k = getattr(m, "_out_k", getattr(m, "out_k", None))
         if in_n is None or out_k is None or in_n % 8 or out_k % 8:
             raise AdoptionError(f"{name}: LoKr factor {out_k}x{in_n}: the kron kernel needs multiples of 8")
+        try:
+            check_kron_fits(name, int(layer.in_features) // int(in_n), int(in_n), int(layer.out_features) // int(out_k), int(out_k))
+        except NotImplementedError as e:
+            raise AdoptionError(str(e)) from None
     object.__setattr__(layer, "lora", m)
     object.__setattr__(layer, "_foreign_adapter", True)
 

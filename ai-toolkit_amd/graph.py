@@ -471,7 +471,8 @@ class FusedGraphBase(nn.Module):
 
     def _skinny_tn(self, s, g, out, *, rows, g_seg=None, accumulate=True):
         """out[R, L] (fp32) += s[rows, R]^T @ g[rows, L] through aitk_lora_wgrad (rank blocks of <= 64 columns, R % 16 == 0);
-        when R is not a multiple of 16 but L is (and L <= 64, unsegmented) the roles are swapped and the result written transposed."""
+        when R is not a multiple of 16 but L is (and L <= 64, unsegmented) the roles are swapped and the result written transposed; anything
+        else goes through zero-padded copies (small factors: network.lokr_factor 4 / 8)."""
         R, L = s.shape[1], g.shape[1]
         if R % 16 == 0:
             for c0 in range(0, R, 64):
@@ -480,7 +481,30 @@ class FusedGraphBase(nn.Module):
         elif L % 16 == 0 and L <= 64 and g_seg is None and R % 8 == 0:
             self.ops.lora_wgrad(g, s, out, transpose_out=True, accumulate=accumulate, M=rows)
         else:
-            raise NotImplementedError(f"LoKr factor gradient {R}x{L}: needs a factor dimension that is a multiple of 16")
+            # small / odd Kronecker factors (network.lokr_factor 4 or 8: lokr_w1 is 4 x 4 / 8 x 8; a b_out such as 24): zero-pad the operands to the
+            # kernel's granules (R -> 16, L -> 8), reduce into a scratch, add the valid block.  The padded copy of `s` is rows x 16 bf16 (up to 4x
+            # the layer's dY for factor 4): the slow path of an unusual configuration, not a tuned one — it runs and it is exact.
+            if L % 8 and g_seg is not None:
+                raise NotImplementedError(f"LoKr factor gradient {R}x{L} over a segmented row map: the operand width must be a multiple of 8")
+            R16, L8 = -(-R // 16) * 16, -(-L // 8) * 8
+            ops = self.ops
+            sp = torch.empty(s.shape[0], R16, dtype=s.dtype, device=s.device) if (R16 != R or not s.is_contiguous()) else s
+            gp = torch.empty(g.shape[0], L8, dtype=g.dtype, device=g.device) if L8 != L else g
+            scratch = torch.empty(R16, L8, dtype=torch.float32, device=out.device)
+
+            def fill():  # torch-side, but in launch order (ops.host_call): under the paired image / text launch lists the producers of s / g are deferred too
+                if sp is not s:
+                    sp.zero_()
+                    sp[:, :R].copy_(s)
+                if gp is not g:
+                    gp.zero_()
+                    gp[:, :L].copy_(g)
+
+            ops.host_call(fill)
+            for c0 in range(0, R16, 64):
+                c1 = min(R16, c0 + 64)
+                ops.lora_wgrad(sp[:, c0:c1], gp, scratch[c0:c1], accumulate=False, g_seg=g_seg, M=rows)
+            ops.host_call((lambda: out.add_(scratch[:R, :L])) if accumulate else (lambda: out.copy_(scratch[:R, :L])))
 
     def _lora_grads(self, lin, dy, T, x_in, *, M, rows_per_batch, B, x_seg=None, dT_out=None):
         """Adapter weight gradients into the fp32 arena; returns dT = c * (dy B) ([M, 3r] split slab layout) or None.

@@ -189,6 +189,25 @@ class _ParamProxy:
         setattr(self._m, self._n, value)
 
 
+def kron_lds_bytes(a_in, b_in, a_out, b_out):
+    """LDS footprint of aitk_kron_apply with both factors resident (csrc/kron.hip kron_layout): the per-token Kronecker kernel keeps lokr_w1
+    [a_out, a_in], W2 [b_out, b_in] and one token's X / intermediate / output tiles in the CU's 160-KB LDS."""
+    c16, c32, c8 = (lambda v: -(-v // 16) * 16), (lambda v: -(-v // 32) * 32), (lambda v: -(-v // 8) * 8)
+    xs, as_ = c32(b_in) + 8, c32(a_in) + 8
+    return 2 * (c16(a_in) * xs + c16(b_out) * xs + c16(a_out) * as_ + c16(b_out) * as_ + c8(a_out * b_out))
+
+
+def check_kron_fits(name, in_m, in_n, out_l, out_k):
+    """A LoKr layer the per-token kernel cannot hold: an explicit small `network.lokr_factor` on a wide layer makes W2 [out/f, in/f] a large
+    matrix (factor 4 on a 3072 x 3072 Linear: 768 x 768) — a GEMM-shaped product, not this kernel's shape.  Refused where the adapter is
+    attached, with the numbers, instead of AITK_ERR_SHAPE at the first forward."""
+    need = max(kron_lds_bytes(in_m, in_n, out_l, out_k), kron_lds_bytes(out_l, out_k, in_m, in_n))  # forward and data gradient (transposed factors)
+    if need > 160 * 1024:
+        raise NotImplementedError(
+            f"{name}: LoKr factors lokr_w1 {out_l}x{in_m}, W2 {out_k}x{in_n} need {need // 1024} KiB of LDS in the per-token Kronecker kernel "
+            "(160 KiB per CU): use the default factorisation (network.lokr_factor: -1, factors near sqrt(dim)) or a larger factor")
+
+
 class LoKrModule(LoRAModule):
     """toolkit/models/lokr.py:76-242 for a Linear: delta W = kron(lokr_w1 [out_l, in_m], W2 [out_k, in_n]) * scale,
     (out_l, out_k) = factorization(out), (in_m, in_n) = factorization(in).
@@ -217,6 +236,7 @@ class LoKrModule(LoRAModule):
         self.out_l, self.out_k = factorization(out_dim, int(factor))
         if self.in_n % 8 or self.out_k % 8:
             raise NotImplementedError(f"LoKr factor {self.out_k}x{self.in_n}: the kron kernel needs multiples of 8")
+        check_kron_fits(lora_name, self.in_m, self.in_n, self.out_l, self.out_k)
         self.use_w1 = True
         self.use_w2 = lora_dim >= max(self.out_k, self.in_n) / 2
         self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))

@@ -42,6 +42,9 @@ def _gemm_shape(ref):
 def _emit(name, args):
     if name == "_keepalive":
         return
+    if name == "_host":
+        args[0]()
+        return
     timed = _gemm_hook is not None and name in ("aitk_gemm_nt", "aitk_gemm_nt_grouped")
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,6 +61,15 @@ def _call(name, *args):
         _REC.append((name, args))
         return
     _emit(name, args)
+
+
+def host_call(fn):
+    """Torch-side work (a pad, an add into the arena) that must keep its place among the launches: run now, or — while `recording()` — when the
+    launch list is replayed, in list order.  Tensors the closure holds live as long as the list."""
+    if _REC is not None:
+        _REC.append(("_host", (fn,)))
+        return
+    fn()
 
 
 class recording:

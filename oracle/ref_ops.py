@@ -845,3 +845,8 @@ def attn_small_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, D, scale, Skv=0)
         out.backward(_heads_d(do, B, S, H, D))
     for dst, src, n in ((dq, qf, S), (dk, kf, Skv), (dv, vf, Skv)):
         dst[: B * n, : H * D].copy_(src.grad.transpose(1, 2).reshape(B * n, H * D).to(dst.dtype))
+
+
+def host_call(fn):
+    """ops.host_call: deferred torch-side work of a recorded launch list; the oracle table launches nothing and runs it at once."""
+    fn()

@@ -112,7 +112,10 @@ def test_kron_apply_segmented_rows():
     assert _rel(dst[:, St:], want.reshape(B, Si, C)) < 8e-3
 
 
-def test_lokr_train_step_vs_fp32_oracle():
+@pytest.mark.parametrize("factor", [-1, 4, 8])
+def test_lokr_train_step_vs_fp32_oracle(factor):
+    """factor -1: the default factorisation; 4 / 8 (`network.lokr_factor`): lokr_w1 is 4 x 4 / 8 x 8, below the 16-column granule of
+    aitk_lora_wgrad — graph._skinny_tn reduces zero-padded copies and adds the valid block."""
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -133,9 +136,11 @@ def test_lokr_train_step_vs_fp32_oracle():
     nat = FluxTransformer2DModel(**CFG, dtype=BF, device=dev, ops=ops)
     nat.load_state_dict({k: v.to(BF) for k, v in ref.state_dict().items()}, strict=True)
     torch.manual_seed(5)
-    ref_net = lora_ref.RefLoRANetwork(ref, big, network_type="lokr").to(dev)
+    ref_net = lora_ref.RefLoRANetwork(ref, big, network_type="lokr", lokr_factor=factor).to(dev)
     torch.manual_seed(5)
-    net = FusedLoRANetwork(nat, lora_dim=big, alpha=big, network_type="lokr")
+    net = FusedLoRANetwork(nat, lora_dim=big, alpha=big, network_type="lokr", lokr_factor=factor)
+    if factor > 0:
+        assert any(tuple(m.lokr_w1.shape) == (factor, factor) for m in net.unet_loras)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for a, b in zip(net.unet_loras, ref_net.unet_loras):

@@ -65,12 +65,12 @@ def test_oracle_lokr_matches_reference_lokr_network(gold):
         assert torch.equal(v, t[f"saved/{k}"]), k
 
 
-def native_pair():
+def native_pair(factor=-1):
     ref = oracle_model()
     nat = FluxTransformer2DModel(**TINY, dtype=torch.float32, device="cpu", ops=ref_ops)
     nat.load_state_dict(ref.state_dict(), strict=True)
     torch.manual_seed(99)
-    net = FusedLoRANetwork(nat, lora_dim=BIG, alpha=BIG, network_type="lokr")
+    net = FusedLoRANetwork(nat, lora_dim=BIG, alpha=BIG, network_type="lokr", lokr_factor=factor)
     return ref, nat, net
 
 
@@ -112,10 +112,16 @@ def test_native_lokr_network_and_host_graph_match_reference_vectors(gold, tmp_pa
     assert params[0] is net.unet_loras[0].lokr_w1 and params[1] is net.unet_loras[0].lokr_w2
 
 
-def test_lokr_train_steps_match_autograd_oracle():
-    ref, nat, net = native_pair()
+@pytest.mark.parametrize("factor", [-1, 4, 8])
+def test_lokr_train_steps_match_autograd_oracle(factor):
+    """factor -1: the reference's default factorisation (factors near sqrt(dim), multiples of 16 on the model sizes); 4 / 8: `network.lokr_factor`
+    — lokr_w1 is 4 x 4 / 8 x 8, below the granule of the weight-gradient kernel: graph._skinny_tn's zero-padded path."""
+    ref, nat, net = native_pair(factor)
     torch.manual_seed(99)
-    ref_net = lora_ref.RefLoRANetwork(ref, BIG, network_type="lokr")
+    ref_net = lora_ref.RefLoRANetwork(ref, BIG, network_type="lokr", lokr_factor=factor)
+    if factor > 0:
+        assert all(tuple(m.lokr_w1.shape) == (factor, factor) for m in net.unet_loras if m.lokr_w1.shape[0] == m.lokr_w1.shape[1]) and any(
+            tuple(m.lokr_w1.shape) == (factor, factor) for m in net.unet_loras)
     g = torch.Generator().manual_seed(5)
     for a, b in zip(net.unet_loras, ref_net.unet_loras):
         with torch.no_grad():
@@ -176,3 +182,34 @@ def test_lokr_merge_in_equals_reference_merge_in(gold):
     for k in keys:
         lin = mods[k].org_module[0]
         assert torch.allclose(lin.weight, before[k][0], rtol=1e-5, atol=1e-6) and torch.allclose(lin.weight_t, before[k][1], rtol=1e-5, atol=1e-6)
+
+
+def test_lokr_factors_the_per_token_kernel_cannot_hold_are_refused_where_the_adapter_is_attached():
+    """An explicit small `network.lokr_factor` on a wide layer makes W2 a GEMM-sized matrix (factor 4 on 3072 x 3072: 768 x 768) that does not fit the
+    160-KiB LDS of aitk_kron_apply: refused at construction / apply_to with the numbers (not AITK_ERR_SHAPE at the first forward).  The default
+    factorisation of every FLUX / Wan / SD layer size fits."""
+    from types import SimpleNamespace
+
+    from ai_toolkit_amd.adopt import AdoptionError, register_foreign_adapter
+    from ai_toolkit_amd.graph import Linear
+    from ai_toolkit_amd.lora import LoKrModule, check_kron_fits, kron_lds_bytes
+
+    for d_in, d_out in ((3072, 3072), (3072, 9216), (3072, 12288), (12288, 3072), (15360, 3072), (3072, 21504), (1536, 8960), (320, 320), (1280, 10240), (2048, 2048)):
+        im, inn = factorization(d_in)
+        ol, ok = factorization(d_out)
+        if inn % 8 == 0 and ok % 8 == 0:
+            check_kron_fits("default", im, inn, ol, ok)
+    assert kron_lds_bytes(48, 64, 48, 64) == 38400  # = 2 * kron_layout(48, 64, 48, 64).total of csrc/kron.hip
+    wide, narrow = Linear(3072, 3072, bias=False, dtype=torch.float32, device="meta"), Linear(256, 256, bias=False, dtype=torch.float32, device="meta")
+    for f in (4, 8):
+        with pytest.raises(NotImplementedError, match="KiB of LDS"):
+            LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=f)
+    LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=16)  # W2 192 x 192: fits
+    with pytest.raises(NotImplementedError, match="KiB of LDS"):      # ... but not on the 3072 -> 12288 MLP projection (W2 768 x 192)
+        LoKrModule("mlp", Linear(3072, 12288, bias=False, dtype=torch.float32, device="meta"), lora_dim=BIG, alpha=BIG, factor=16)
+    LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=-1)
+    LoKrModule("narrow", narrow, lora_dim=BIG, alpha=BIG, factor=4)
+    # the same check on a LokrModule the reference built (adoption): the oracle's restatement stands in for it
+    m = lora_ref.RefLokrModule("lokr_wide", wide, BIG, BIG, SimpleNamespace(is_lorm=False), factor=4)
+    with pytest.raises(AdoptionError, match="KiB of LDS"):
+        register_foreign_adapter(wide, m.forward)
