@@ -237,7 +237,7 @@ class FluxTransformer2DModel(FusedGraphBase):
         pred = self.forward_native(hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,
                                    guidance, save_for_backward=torch.is_grad_enabled())
         if torch.is_grad_enabled() and self.network is not None and self.network.is_active:
-            pred = _FluxGraphFn.apply(pred, self, self.network.arena_p.requires_grad_(True))
+            pred = _FluxGraphFn.apply(pred.detach(), self, self.network.arena_p.requires_grad_(True))  # detach: the explicit graph is the only history (a torch-backed kernel table would otherwise leave autograd history of its own on pred)
         return (pred,)
 
     def forward_native(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, img_ids, txt_ids,

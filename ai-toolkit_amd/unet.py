@@ -832,6 +832,6 @@ class UNet2DConditionModel(FusedGraphBase):
         if torch.is_grad_enabled() and self.network is not None and self.network.is_active:
             from .flux import _FluxGraphFn
 
-            pred = _FluxGraphFn.apply(pred, self, self.network.arena_p.requires_grad_(True))
+            pred = _FluxGraphFn.apply(pred.detach(), self, self.network.arena_p.requires_grad_(True))  # detach: the explicit graph is the only history (a torch-backed kernel table would otherwise leave autograd history of its own on pred)
         out = pred.reshape(B, H, W, -1).permute(0, 3, 1, 2)
         return UNet2DConditionOutput((out,)) if return_dict else (out,)

@@ -191,7 +191,7 @@ class WanTransformer3DModel(FusedGraphBase):
         if torch.is_grad_enabled() and self.network is not None and self.network.is_active:
             from .flux import _FluxGraphFn
 
-            pred = _FluxGraphFn.apply(pred, self, self.network.arena_p.requires_grad_(True))
+            pred = _FluxGraphFn.apply(pred.detach(), self, self.network.arena_p.requires_grad_(True))  # detach: the explicit graph is the only history (a torch-backed kernel table would otherwise leave autograd history of its own on pred)
         return (self.unpack_tokens(pred, grid),)
 
     def forward_native(self, tokens, timestep, encoder_hidden_states, grid, save_for_backward=True):

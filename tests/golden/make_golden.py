@@ -1456,7 +1456,7 @@ def golden_text_encoders():
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
-def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False):
+def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora"):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1531,7 +1531,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
         self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
         return self.text_encoder
 
-    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "")
+    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "") + (f"_{network}" if network != "lora" else "")
     Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
     Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
@@ -1660,7 +1660,9 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
     steps = 3
     config = OrderedDict(type="sd_trainer", training_folder=os.path.join(tmp, "out"), device="cpu",
-                         network=dict(type="lora", linear=8, linear_alpha=8),
+                         network={"lora": dict(type="lora", linear=8, linear_alpha=8), "dora": dict(type="dora", linear=8, linear_alpha=8),
+                                  "lokr": dict(type="lokr", linear=8, linear_alpha=8),  # lokr_full_rank default: both Kronecker factors full
+                                  "lokr_lowrank": dict(type="lokr", linear=4, linear_alpha=4, lokr_full_rank=False)}[network],
                          save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
                          datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
                          train=dict(batch_size=2, steps=steps, gradient_accumulation=accum, train_unet=True, train_text_encoder=False,
@@ -1721,13 +1723,15 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     for k, v in sd_final.items():
         out[f"saved/{k}"] = v
     opt_sd = torch.load(os.path.join(save_root, "optimizer.pt"), weights_only=True)
-    for i, st in opt_sd["state"].items():
-        out[f"opt/{i}/exp_avg"], out[f"opt/{i}/exp_avg_sq"] = st["exp_avg"], st["exp_avg_sq"]
+    if network == "lora":  # the adapter-type variants keep the fixture small: the saved file (= the EMA weights) and the losses carry the comparison
+        for i, st in opt_sd["state"].items():
+            out[f"opt/{i}/exp_avg"], out[f"opt/{i}/exp_avg_sq"] = st["exp_avg"], st["exp_avg_sq"]
     for k, v in keep["init"].items():
         out[f"init/{k}"] = v
-    for i, sp in enumerate(ema_.shadow_params):
-        out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "accum": accum, "dtype": dtype, "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    if network == "lora":
+        for i, sp in enumerate(ema_.shadow_params):
+            out[f"ema/{i}"] = sp.detach().clone()
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
@@ -1829,6 +1833,16 @@ def golden_trainer_loop_flux_bf16_fp8base(out_dir=None):
     golden_trainer_loop(out_dir, kind="flux", dtype="bf16", quantize=True)
 
 
+def golden_trainer_loop_flux_dora(out_dir=None):
+    """network.type: dora — the reference's DoRAModule (magnitude vector) built, trained, saved and resumed by its own trainer over the plug-in."""
+    golden_trainer_loop(out_dir, kind="flux", network="dora")
+
+
+def golden_trainer_loop_flux_lokr_lowrank(out_dir=None):
+    """network.type: lokr with lokr_full_rank: false — LokrModule with W2 = lokr_w2_a @ lokr_w2_b."""
+    golden_trainer_loop(out_dir, kind="flux", network="lokr_lowrank")
+
+
 def golden_trainer_loop_flux_accum2(out_dir=None):
     """train.gradient_accumulation: 2 — two micro-batches per hook_train_loop call: `optimizer.zero_grad()` (set_to_none) at its top drops the
     adopted parameters' .grad views, two backward passes accumulate, one clip / step / EMA (SDTrainer.py:2246-2293)."""
@@ -1870,3 +1884,5 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="flux", accum=2)
     golden_trainer_loop(kind="flux", dtype="bf16")
     golden_trainer_loop(kind="flux", dtype="bf16", quantize=True)
+    golden_trainer_loop(kind="flux", network="dora")
+    golden_trainer_loop(kind="flux", network="lokr_lowrank")

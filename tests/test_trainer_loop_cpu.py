@@ -48,8 +48,11 @@ KINDS = {
 }
 KINDS["flux_accum2"] = KINDS["flux"]  # train.gradient_accumulation: 2 (two micro-batches per optimizer step; zero_grad(set_to_none) drops the grad views)
 KINDS["flux_bf16"] = KINDS["flux"]    # train.dtype: bf16 (the reference's default): bf16 base + activations, fp32 network
+KINDS["flux_dora"] = KINDS["flux"]          # network.type: dora (light fixture: losses + saved file)
+KINDS["flux_lokr_lowrank"] = KINDS["flux"]  # network.type: lokr, lokr_full_rank: false
 KINDS["flux_bf16_fp8base"] = KINDS["flux"]  # model.quantize: true — e4m3 weight-only base under the adopted network (BASELINE config 5's base)
-SCHEDULER = {"flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
+SCHEDULER = {"flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
+             "flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
              "sd15": "DDPMTrainSchedule", "sdxl": "DDPMTrainSchedule"}
@@ -72,6 +75,7 @@ def test_the_run_was_the_references_own_trainer_network_and_scheduler(kind):
     assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
     assert meta["kw"] == kw
     tails = ("lora_down.weight", "lora_up.weight", "alpha") if kind in ("sd15", "sdxl") else ("lora_A.weight", "lora_B.weight")
+    tails = {"flux_dora": tails + ("magnitude",), "flux_lokr_lowrank": ("lokr_w1", "lokr_w2_a", "lokr_w2_b", "alpha")}.get(kind, tails)
     assert all(k.startswith(prefix) and k.endswith(tails) for k in meta["saved_keys"])
 
 
@@ -97,12 +101,16 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     extra = {"flux": {}, "wan": dict(target_lin_modules=tuple(sd.target_lora_modules), base_model_version="wan_2.1"),
              "sd15": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sd1"),
              "sdxl": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl")}[kind.split("_")[0]]
-    net = FusedLoRANetwork(nat, lora_dim=8, alpha=8, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
+    nk = meta.get("network_kind", "lora")
+    rank = 4 if nk == "lokr_lowrank" else 8
+    if nk != "lora":
+        extra = dict(extra, network_type={"dora": "dora", "lokr_lowrank": "lokr"}[nk])
+    net = FusedLoRANetwork(nat, lora_dim=rank, alpha=rank, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
     init = {k[len("init/"):]: v for k, v in g.items() if k.startswith("init/")}
     with torch.no_grad():  # the adapter as the trainer's RNG stream initialised it
         for m in net.unet_loras:
-            m.lora_down.weight.copy_(init[f"{m.lora_name}.lora_down.weight"].reshape(m.lora_down.weight.shape))  # 1x1-conv adapters: [r, in, 1, 1]
-            m.lora_up.weight.copy_(init[f"{m.lora_name}.lora_up.weight"].reshape(m.lora_up.weight.shape))
+            for pname, p_ in m.named_parameters():  # lora_down / lora_up (+ magnitude), or the LoKr factors; 1x1-conv adapters: [r, in, 1, 1] in the reference
+                p_.copy_(init[f"{m.lora_name}.{pname}"].reshape(p_.shape))
     net.apply_to()
     net.build_arena("cpu", groups=nat.lora_groups())
     net.refresh_shadows(ref_ops)
@@ -120,6 +128,13 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
             with torch.no_grad():
                 for p_, e_ in zip(plist, ema):
                     p_.copy_(e_)
+                if nk == "dora":
+                    # the reference's PEFT-format load path un-escapes only the lora_down / lora_up (and LoKr) keys (toolkit/network_mixins.py:702-718):
+                    # `...to_k.magnitude` becomes `...to_k$$magnitude`, matches nothing and is dropped ("Missing keys") — a resumed DoRA run restarts
+                    # from the INITIAL magnitudes (row norms of the base weight) with the restored AdamW moments.  The adopted network holds whatever
+                    # the reference's objects hold, so the twin does the same.
+                    for m in net.unet_loras:
+                        m.magnitude.copy_(init[f"{m.lora_name}.magnitude"])
             ema = [p_.detach().clone() for p_ in plist]
             net.refresh_shadows(ref_ops)
         opt.zero_grad()
@@ -157,9 +172,11 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     assert sorted(ema_sd) == sorted(meta["saved_keys"])
     for k, v in ema_sd.items():
         assert torch.equal(v.reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]), k
-    ups = [k for k in live_sd if k.endswith(("lora_B.weight", "lora_up.weight"))]
+    ups = [k for k in live_sd if k.endswith(("lora_B.weight", "lora_up.weight", "lokr_w2_b"))]
     differ = sum(not torch.equal(live_sd[k].reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]) for k in ups)
     assert ups and differ >= 0.9 * len(ups), (differ, len(ups))  # ... and not the live weights (an adapter whose gradient is exactly 0 stays at its zero init in both)
+    if nk != "lora":
+        return  # light fixtures (adapter-type variants): losses + the saved file (= the EMA weights) carry the comparison
     for i, p in enumerate(plist):  # (reshape: the reference's 1x1-conv adapters keep [.., 1, 1] axes)
         assert torch.equal(opt.state[p]["exp_avg"], g[f"opt/{i}/exp_avg"].reshape(p.shape)) and torch.equal(opt.state[p]["exp_avg_sq"], g[f"opt/{i}/exp_avg_sq"].reshape(p.shape)), i
         assert torch.equal(ema[i], g[f"ema/{i}"].reshape(p.shape)), i
@@ -176,8 +193,9 @@ def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_
     and compare with the committed fixture"""
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r)"
-            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind))
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r, network=%r)"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind,
+               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
