@@ -1456,7 +1456,7 @@ def golden_text_encoders():
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
-def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora"):
+def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora", uncached=False):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1531,7 +1531,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
         self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
         return self.text_encoder
 
-    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "") + (f"_{network}" if network != "lora" else "")
+    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "") + (f"_{network}" if network != "lora" else "") + ("_uncached" if uncached else "")
     Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
     Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
@@ -1600,6 +1600,29 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
         cfg_json = dict(WCFG, patch_size=[1, 2, 2], _class_name="WanTransformer3DModel")
         lat_shape, txt_dim, pooled_dim = (16, 3, 8, 4), WCFG["text_dim"], None
     nat.load_state_dict(ref.state_dict())
+    if uncached:  # a VAE in the pipeline directory: the trainer gets images and calls the plug-in's encode_images (native AutoencoderKL encoder)
+        from ai_toolkit_amd.vae import AutoencoderKLEncoder
+
+        assert kind == "flux"
+        vsrc = AutoencoderKLEncoder(latent_channels=16, block_out_channels=(32, 64), layers_per_block=1, dtype=torch.float32, device="cpu", ops=ref_ops)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            for p_ in vsrc.parameters():
+                p_.copy_(torch.randn_like(p_) * 0.05)
+        loader.save_component(vsrc, os.path.join(tmp, "ckpt", "vae"))
+        with open(os.path.join(tmp, "ckpt", "vae", "config.json"), "w") as f:
+            json.dump(dict(latent_channels=16, block_out_channels=[32, 64], layers_per_block=1, scaling_factor=0.3611, shift_factor=0.1159, norm_num_groups=32,
+                           use_quant_conv=False, _class_name="AutoencoderKL"), f)
+        orig_enc = Plug.encode_images
+
+        def rec_enc(self, image_list, *a, **k):
+            rng = torch.get_rng_state()  # latent_dist.sample() draws from the global CPU generator: the state in front of the call makes the draw replayable
+            out_ = orig_enc(self, image_list, *a, **k)
+            rec.setdefault("encode", []).append((torch.stack([im.detach().clone() for im in image_list]) if isinstance(image_list, (list, tuple)) else image_list.detach().clone(),
+                                                 out_.detach().clone(), rng.clone()))
+            return out_
+
+        Plug.encode_images = rec_enc
     comp = "unet" if kind in ("sd15", "sdxl") else "transformer"
     loader.save_component(nat, os.path.join(tmp, "ckpt", comp))
     with open(os.path.join(tmp, "ckpt", comp, "config.json"), "w") as f:
@@ -1620,7 +1643,9 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
             pe = PromptEmbeds(torch.randn(B, 6, txt_dim, generator=g) * 0.5)
             if pooled_dim is not None:
                 pe.pooled_embeds = torch.randn(B, pooled_dim, generator=g) * 0.5
-            super().__init__(latents=torch.randn(B, *lat_shape, generator=g), tensor=None, prompt_embeds=pe, loss_multiplier_list=[1.0] * B,
+            # (uncached: images instead of latents; the tiny VAE halves H and W once)
+            super().__init__(latents=None if uncached else torch.randn(B, *lat_shape, generator=g),
+                             tensor=(torch.rand(B, 3, 2 * lat_shape[1], 2 * lat_shape[2], generator=g) * 2 - 1) if uncached else None, prompt_embeds=pe, loss_multiplier_list=[1.0] * B,
                              file_items=[Duck(path=f"img{i}.png", dataset_config=Duck(), is_reg=False, prior_reg=False, network_weight=1.0) for i in range(B)])
             self.B = B
 
@@ -1723,15 +1748,18 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     for k, v in sd_final.items():
         out[f"saved/{k}"] = v
     opt_sd = torch.load(os.path.join(save_root, "optimizer.pt"), weights_only=True)
-    if network == "lora":  # the adapter-type variants keep the fixture small: the saved file (= the EMA weights) and the losses carry the comparison
+    if uncached:
+        assert len(rec["encode"]) == steps * accum
+        out["encode/images"], out["encode/latents"], out["encode/rng_state"] = rec["encode"][0]
+    if network == "lora" and not uncached:  # the adapter-type variants keep the fixture small: the saved file (= the EMA weights) and the losses carry the comparison
         for i, st in opt_sd["state"].items():
             out[f"opt/{i}/exp_avg"], out[f"opt/{i}/exp_avg_sq"] = st["exp_avg"], st["exp_avg_sq"]
     for k, v in keep["init"].items():
         out[f"init/{k}"] = v
-    if network == "lora":
+    if network == "lora" and not uncached:
         for i, sp in enumerate(ema_.shadow_params):
             out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "uncached": bool(uncached), "light": bool(network != "lora" or uncached), "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
@@ -1843,6 +1871,12 @@ def golden_trainer_loop_flux_lokr_lowrank(out_dir=None):
     golden_trainer_loop(out_dir, kind="flux", network="lokr_lowrank")
 
 
+def golden_trainer_loop_flux_uncached(out_dir=None):
+    """datasets without cached latents: the batch carries images, process_general_training_batch calls `sd.encode_images` (BaseSDTrainProcess.py:1106-1140) — the
+    plug-in's native AutoencoderKL encoder, loaded by load_model from the pipeline directory's vae/ folder."""
+    golden_trainer_loop(out_dir, kind="flux", uncached=True)
+
+
 def golden_trainer_loop_flux_accum2(out_dir=None):
     """train.gradient_accumulation: 2 — two micro-batches per hook_train_loop call: `optimizer.zero_grad()` (set_to_none) at its top drops the
     adopted parameters' .grad views, two backward passes accumulate, one clip / step / EMA (SDTrainer.py:2246-2293)."""
@@ -1885,4 +1919,5 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="flux", dtype="bf16")
     golden_trainer_loop(kind="flux", dtype="bf16", quantize=True)
     golden_trainer_loop(kind="flux", network="dora")
+    golden_trainer_loop(kind="flux", uncached=True)
     golden_trainer_loop(kind="flux", network="lokr_lowrank")

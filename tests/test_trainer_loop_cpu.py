@@ -48,10 +48,11 @@ KINDS = {
 }
 KINDS["flux_accum2"] = KINDS["flux"]  # train.gradient_accumulation: 2 (two micro-batches per optimizer step; zero_grad(set_to_none) drops the grad views)
 KINDS["flux_bf16"] = KINDS["flux"]    # train.dtype: bf16 (the reference's default): bf16 base + activations, fp32 network
+KINDS["flux_uncached"] = KINDS["flux"]      # images instead of cached latents: the trainer calls the plug-in's encode_images (native VAE encoder)
 KINDS["flux_dora"] = KINDS["flux"]          # network.type: dora (light fixture: losses + saved file)
 KINDS["flux_lokr_lowrank"] = KINDS["flux"]  # network.type: lokr, lokr_full_rank: false
 KINDS["flux_bf16_fp8base"] = KINDS["flux"]  # model.quantize: true — e4m3 weight-only base under the adopted network (BASELINE config 5's base)
-SCHEDULER = {"flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
+SCHEDULER = {"flux_uncached": "CustomFlowMatchEulerDiscreteScheduler", "flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
              "flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
@@ -175,7 +176,23 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     ups = [k for k in live_sd if k.endswith(("lora_B.weight", "lora_up.weight", "lokr_w2_b"))]
     differ = sum(not torch.equal(live_sd[k].reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]) for k in ups)
     assert ups and differ >= 0.9 * len(ups), (differ, len(ups))  # ... and not the live weights (an adapter whose gradient is exactly 0 stays at its zero init in both)
-    if nk != "lora":
+    if meta.get("uncached"):
+        # what the trainer got from `sd.encode_images(images)`: the native AutoencoderKL encoder over the pipeline directory's vae/ weights, sampled with the
+        # generator state the trainer's process had at that call
+        from ai_toolkit_amd.vae import AutoencoderKLEncoder
+
+        vae = AutoencoderKLEncoder(latent_channels=16, block_out_channels=(32, 64), layers_per_block=1, dtype=torch.float32, device="cpu", ops=ref_ops)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            for p_ in vae.parameters():
+                p_.copy_(torch.randn_like(p_) * 0.05)
+        sdv = Mirror("cpu", model=nat, vae=vae, dtype=dt)
+        keep_rng = torch.get_rng_state()
+        torch.set_rng_state(g["encode/rng_state"])
+        lat = sdv.encode_images(list(g["encode/images"]))
+        torch.set_rng_state(keep_rng)
+        assert tuple(lat.shape) == tuple(g["encode/latents"].shape) == (2, 16, 8, 4) and torch.equal(lat, g["encode/latents"])
+    if nk != "lora" or meta.get("uncached"):
         return  # light fixtures (adapter-type variants): losses + the saved file (= the EMA weights) carry the comparison
     for i, p in enumerate(plist):  # (reshape: the reference's 1x1-conv adapters keep [.., 1, 1] axes)
         assert torch.equal(opt.state[p]["exp_avg"], g[f"opt/{i}/exp_avg"].reshape(p.shape)) and torch.equal(opt.state[p]["exp_avg_sq"], g[f"opt/{i}/exp_avg_sq"].reshape(p.shape)), i
@@ -193,9 +210,9 @@ def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_
     and compare with the committed fixture"""
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r, network=%r)"
+            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r, network=%r, uncached=%r)"
             % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind,
-               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora"))
+               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora", "uncached" in kind))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
