@@ -1456,6 +1456,10 @@ def golden_text_encoders():
     print("text encoder golden:", {k: tuple(v.shape) for k, v in out.items()})
 
 
+PARTIAL_ONLY = ["transformer_blocks.0.attn.to_q", "transformer_blocks.0.attn.add_k_proj", "single_transformer_blocks.1.proj_mlp", "single_transformer_blocks.0.attn.to_v",
+                "transformer_blocks.1.ff.net.2", "transformer_blocks.1.ff_context.net.0.proj"]
+
+
 def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora", uncached=False):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
@@ -1687,7 +1691,9 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     config = OrderedDict(type="sd_trainer", training_folder=os.path.join(tmp, "out"), device="cpu",
                          network={"lora": dict(type="lora", linear=8, linear_alpha=8), "dora": dict(type="dora", linear=8, linear_alpha=8),
                                   "lokr": dict(type="lokr", linear=8, linear_alpha=8),  # lokr_full_rank default: both Kronecker factors full
-                                  "lokr_lowrank": dict(type="lokr", linear=4, linear_alpha=4, lokr_full_rank=False)}[network],
+                                  "lokr_lowrank": dict(type="lokr", linear=4, linear_alpha=4, lokr_full_rank=False),
+                                  # adapters on a subset of the Linears: same-input groups (q / k / v, the single blocks' fused projections) with members missing
+                                  "lora_partial": dict(type="lora", linear=8, linear_alpha=8, network_kwargs=dict(only_if_contains=PARTIAL_ONLY))}[network],
                          save=dict(dtype="float32", save_every=2, max_step_saves_to_keep=2),
                          datasets=[dict(folder_path=os.path.join(tmp, "data"), cache_latents_to_disk=True, resolution=[64])],
                          train=dict(batch_size=2, steps=steps, gradient_accumulation=accum, train_unet=True, train_text_encoder=False,
@@ -1759,7 +1765,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     if network == "lora" and not uncached:
         for i, sp in enumerate(ema_.shadow_params):
             out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "uncached": bool(uncached), "light": bool(network != "lora" or uncached), "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "only_if_contains": PARTIAL_ONLY if network == "lora_partial" else None, "uncached": bool(uncached), "light": bool(network != "lora" or uncached), "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
@@ -1871,6 +1877,11 @@ def golden_trainer_loop_flux_lokr_lowrank(out_dir=None):
     golden_trainer_loop(out_dir, kind="flux", network="lokr_lowrank")
 
 
+def golden_trainer_loop_flux_lora_partial(out_dir=None):
+    """network_kwargs.only_if_contains: adapters on a few Linears only — members of the native graph's same-input groups with and without an adapter side by side."""
+    golden_trainer_loop(out_dir, kind="flux", network="lora_partial")
+
+
 def golden_trainer_loop_flux_uncached(out_dir=None):
     """datasets without cached latents: the batch carries images, process_general_training_batch calls `sd.encode_images` (BaseSDTrainProcess.py:1106-1140) — the
     plug-in's native AutoencoderKL encoder, loaded by load_model from the pipeline directory's vae/ folder."""
@@ -1920,4 +1931,5 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="flux", dtype="bf16", quantize=True)
     golden_trainer_loop(kind="flux", network="dora")
     golden_trainer_loop(kind="flux", uncached=True)
+    golden_trainer_loop(kind="flux", network="lora_partial")
     golden_trainer_loop(kind="flux", network="lokr_lowrank")

@@ -49,10 +49,11 @@ KINDS = {
 KINDS["flux_accum2"] = KINDS["flux"]  # train.gradient_accumulation: 2 (two micro-batches per optimizer step; zero_grad(set_to_none) drops the grad views)
 KINDS["flux_bf16"] = KINDS["flux"]    # train.dtype: bf16 (the reference's default): bf16 base + activations, fp32 network
 KINDS["flux_uncached"] = KINDS["flux"]      # images instead of cached latents: the trainer calls the plug-in's encode_images (native VAE encoder)
+KINDS["flux_lora_partial"] = KINDS["flux"]  # network_kwargs.only_if_contains: same-input groups with members missing
 KINDS["flux_dora"] = KINDS["flux"]          # network.type: dora (light fixture: losses + saved file)
 KINDS["flux_lokr_lowrank"] = KINDS["flux"]  # network.type: lokr, lokr_full_rank: false
 KINDS["flux_bf16_fp8base"] = KINDS["flux"]  # model.quantize: true — e4m3 weight-only base under the adopted network (BASELINE config 5's base)
-SCHEDULER = {"flux_uncached": "CustomFlowMatchEulerDiscreteScheduler", "flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
+SCHEDULER = {"flux_lora_partial": "CustomFlowMatchEulerDiscreteScheduler", "flux_uncached": "CustomFlowMatchEulerDiscreteScheduler", "flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
              "flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
@@ -104,7 +105,9 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
              "sdxl": dict(target_lin_modules=tuple(sd.target_lora_modules), is_transformer=False, peft_format=False, transformer_only=False, base_model_version="sdxl")}[kind.split("_")[0]]
     nk = meta.get("network_kind", "lora")
     rank = 4 if nk == "lokr_lowrank" else 8
-    if nk != "lora":
+    if nk == "lora_partial":
+        extra = dict(extra, only_if_contains=meta["only_if_contains"])
+    elif nk != "lora":
         extra = dict(extra, network_type={"dora": "dora", "lokr_lowrank": "lokr"}[nk])
     net = FusedLoRANetwork(nat, lora_dim=rank, alpha=rank, transformer_block_names=sd.get_transformer_block_names(), base_model=sd, **extra)
     init = {k[len("init/"):]: v for k, v in g.items() if k.startswith("init/")}
@@ -150,6 +153,8 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
                 loss = loss.mean(list(range(1, loss.dim()))).mean()
                 loss.backward()
             step_loss += loss.item()
+            if nk == "lora_partial" and j == 0:
+                first_grads = {m.lora_name: (m.lora_down.weight.grad.clone(), m.lora_up.weight.grad.clone()) for m in net.unet_loras}
         torch.nn.utils.clip_grad_norm_(plist, meta["max_grad_norm"])
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -176,6 +181,35 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
     ups = [k for k in live_sd if k.endswith(("lora_B.weight", "lora_up.weight", "lokr_w2_b"))]
     differ = sum(not torch.equal(live_sd[k].reshape(g[f"saved/{k}"].shape), g[f"saved/{k}"]) for k in ups)
     assert ups and differ >= 0.9 * len(ups), (differ, len(ups))  # ... and not the live weights (an adapter whose gradient is exactly 0 stays at its zero init in both)
+    if nk == "lora_partial":
+        # ... and the partially covered graph itself against autograd: the oracle network over the oracle model, the same seven adapters, call 0
+        from oracle import lora_ref
+
+        names = [m.lora_name for m in net.unet_loras]
+        assert len(names) == 7 and any("to_q" in n for n in names) and not any("attn$$to_k" in n for n in names)
+        ref_net = lora_ref.RefLoRANetwork(ref, 8)
+        keep_mods = [m for m in ref_net.unet_loras if m.lora_name in names]
+        for m in ref_net.unet_loras:
+            if m.lora_name not in names:
+                delattr(ref_net, m.lora_name)
+        ref_net.unet_loras = keep_mods
+        assert [m.lora_name for m in keep_mods] == names
+        with torch.no_grad():
+            for m in keep_mods:
+                m.lora_down.weight.copy_(init[f"{m.lora_name}.lora_down.weight"])
+                m.lora_up.weight.copy_(init[f"{m.lora_name}.lora_up.weight"])
+        ref_net.apply_to()
+        lat0, ts0 = g["step0/latent_model_input"], g["step0/timestep"]
+        img_ids, txt_ids = flux_ref.make_ids(lat0.shape[2], lat0.shape[3], g["step0/text"].shape[1])
+        with ref_net:
+            p_ref = flux_ref.unpack_latents(ref(flux_ref.pack_latents(lat0), g["step0/text"], g["step0/pooled"], ts0 / 1000, img_ids, txt_ids,
+                                                torch.full((lat0.shape[0],), 1.0)), lat0.shape[2], lat0.shape[3])
+            l_ref = torch.nn.functional.mse_loss(p_ref.float(), g["step0/target"].float(), reduction="none").mean([1, 2, 3]).mean()
+            l_ref.backward()
+        assert abs(l_ref.item() - g["losses"][0].item()) <= 1e-5 * abs(l_ref.item()), (l_ref.item(), g["losses"][0].item())
+        for m in keep_mods:  # lora_up starts at zero: its gradient is the informative one at step 0
+            assert torch.allclose(first_grads[m.lora_name][1], m.lora_up.weight.grad, rtol=5e-4, atol=1e-7), m.lora_name
+            assert torch.allclose(first_grads[m.lora_name][0], m.lora_down.weight.grad, rtol=5e-4, atol=1e-7), m.lora_name
     if meta.get("uncached"):
         # what the trainer got from `sd.encode_images(images)`: the native AutoencoderKL encoder over the pipeline directory's vae/ weights, sampled with the
         # generator state the trainer's process had at that call
@@ -212,7 +246,7 @@ def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_
     code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
             "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r, network=%r, uncached=%r)"
             % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind,
-               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora", "uncached" in kind))
+               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora_partial" if "lora_partial" in kind else "lora", "uncached" in kind))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
