@@ -8,9 +8,9 @@ CFG = dict(in_channels=64, num_layers=2, num_single_layers=3, attention_head_dim
            joint_attention_dim=256, pooled_projection_dim=64)
 
 
-def build(rank=16, dev="cuda", attach=True, dropout_cfg=None, mask_provider=None):
+def build(rank=16, dev="cuda", attach=True, dropout_cfg=None, mask_provider=None, only=None):
     """attach=False: the native model is returned WITHOUT an adapter network (4th value None) — for the adoption tests, where the
-    reference-side network is built over it afterwards"""
+    reference-side network is built over it afterwards.  only = substrings (network_kwargs.only_if_contains): adapters on the matching Linears only"""
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -30,7 +30,14 @@ def build(rank=16, dev="cuda", attach=True, dropout_cfg=None, mask_provider=None
     ref = ref.to(dev)
     nat = FluxTransformer2DModel(**CFG, dtype=torch.bfloat16, device=dev, ops=ops)
     nat.load_state_dict({k: v.to(torch.bfloat16) for k, v in ref.state_dict().items()}, strict=True)
-    ref_net = lora_ref.RefLoRANetwork(ref, rank).to(dev)
+    ref_net = lora_ref.RefLoRANetwork(ref, rank)
+    if only is not None:  # prune the oracle network to the same subset (before the forward swap)
+        keep = [m for m in ref_net.unet_loras if any(w in m.lora_name.replace("$$", ".") for w in only)]
+        for m in ref_net.unet_loras:
+            if m not in keep:
+                delattr(ref_net, m.lora_name)
+        ref_net.unet_loras = keep
+    ref_net = ref_net.to(dev)
     if not attach:
         g = torch.Generator().manual_seed(7)
         with torch.no_grad():
@@ -40,7 +47,8 @@ def build(rank=16, dev="cuda", attach=True, dropout_cfg=None, mask_provider=None
         ref_net.apply_to()
         nat.prepare()
         return ref, ref_net, nat, None
-    net = FusedLoRANetwork(nat, lora_dim=rank, **(dropout_cfg or {}))
+    net = FusedLoRANetwork(nat, lora_dim=rank, **(dropout_cfg or {}), **({"only_if_contains": list(only)} if only is not None else {}))
+    assert [m.lora_name for m in net.unet_loras] == [m.lora_name for m in ref_net.unet_loras]
     if dropout_cfg:  # LoRA dropout / rank_dropout / module_dropout: both sides draw their uniforms from the same keyed provider
         ref_net.dropout_cfg, ref_net.mask_provider = dict(dropout_cfg), mask_provider
         net.mask_provider = mask_provider

@@ -76,6 +76,42 @@ def test_step_gradients_and_loss_vs_oracle(rank):
     assert max(per_o) <= 1.5 * max(per_r) + 2e-3, (max(per_o), max(per_r))
 
 
+def test_partial_adapter_coverage_step_vs_oracle():
+    """network_kwargs.only_if_contains: adapters on a few Linears — the same-input groups of the graph (q / k / v and their text twins, the single
+    blocks' q / k / v / proj_mlp) have members WITH and WITHOUT an adapter: the grouped K-slab, the concatenated data gradient and the group
+    weight-gradient launch must fall back per member without dropping or double-counting a term.  Against the fp32 autograd oracle over the same subset."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import train_ref
+    from oracle.pairs import build
+
+    only = ["transformer_blocks.0.attn.to_q", "transformer_blocks.0.attn.add_k_proj", "single_transformer_blocks.1.proj_mlp", "single_transformer_blocks.0.attn.to_v",
+            "transformer_blocks.1.ff.net.2", "transformer_blocks.1.ff_context.net.0.proj", "single_transformer_blocks.2.proj_out"]
+    ref, ref_net, nat, net = build(16, only=only)
+    assert len(net.unet_loras) == 8  # "transformer_blocks.0.attn.to_q" also names the single block 0 projection (substring match, as the reference does)
+    lat, emb, pooled, noise, ts = _batch(2)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = [p.grad.clone() for p in oracle.params]
+    ref.to(torch.bfloat16)
+    oracle.step(lat, emb, pooled, noise, ts, dtype=torch.bfloat16)
+    g16 = [p.grad.clone() for p in oracle.params]
+    ref.float()
+    ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1e-3 * abs(loss32), (loss, loss32)
+    mine = []
+    for m in net.unet_loras:
+        mine += [m.lora_down.weight.grad, m.lora_up.weight.grad]
+    assert all(g_.abs().sum().item() > 0 for g_ in mine[1::2])  # every lora_up gradient is live
+    den = sum((b ** 2).sum().item() for b in g32)
+    e_ours = math.sqrt(sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32)) / den)
+    e_ref16 = math.sqrt(sum(((a - b) ** 2).sum().item() for a, b in zip(g16, g32)) / den)
+    print(f"partial coverage: loss ours {loss:.6f} fp32 {loss32:.6f}; grad rel err ours {e_ours:.4e} bf16-oracle {e_ref16:.4e}")
+    assert e_ours <= 1.5 * e_ref16 + 1e-3, (e_ours, e_ref16)
+    assert max(_rel(a, b) for a, b in zip(mine, g32)) <= 2.0 * max(_rel(a, b) for a, b in zip(g16, g32)) + 3e-3
+
+
 def test_three_training_steps_track_oracle():
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.trainer import FluxLoRATrainStep
