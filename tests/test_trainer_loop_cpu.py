@@ -237,19 +237,27 @@ import subprocess  # noqa: E402
 import sys  # noqa: E402
 
 
+RUN_KW = {"flux": dict(kind="flux"), "wan": dict(kind="wan"), "sd15": dict(kind="sd15"), "sdxl": dict(kind="sdxl"), "flux_accum2": dict(kind="flux", accum=2),
+          "flux_bf16": dict(kind="flux", dtype="bf16"), "flux_bf16_fp8base": dict(kind="flux", dtype="bf16", quantize=True), "flux_dora": dict(kind="flux", network="dora"),
+          "flux_lokr_lowrank": dict(kind="flux", network="lokr_lowrank"), "flux_uncached": dict(kind="flux", uncached=True),
+          "flux_lora_partial": dict(kind="flux", network="lora_partial")}
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/toolkit"), reason="the reference tree is not mounted here")
-@pytest.mark.parametrize("kind", list(KINDS))
-def test_committed_trainer_loop_fixture_is_what_the_references_trainer_produces_today(tmp_path, kind):
-    """run the reference's SDTrainer over the plug-in again (separate process: the import shims and accelerate's state stay out of this one)
-    and compare with the committed fixture"""
+def test_committed_trainer_loop_fixtures_are_what_the_references_trainer_produces_today(tmp_path):
+    """run the reference's SDTrainer over the plug-in again — every committed run, one after the other in ONE separate process (the import shims and
+    accelerate's state stay out of this one) — and compare with the committed fixtures, tensor for tensor"""
+    assert set(RUN_KW) == set(KINDS)
     here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
-            "g = runpy.run_path(%r, run_name='not_main'); g['golden_trainer_loop'](%r, kind=%r, accum=%d, dtype=%r, quantize=%r, network=%r, uncached=%r)"
-            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), str(tmp_path), kind.split("_")[0], 2 if "accum2" in kind else 1, "bf16" if "bf16" in kind else "fp32", "fp8base" in kind,
-               "dora" if "dora" in kind else "lokr_lowrank" if "lokr_lowrank" in kind else "lora_partial" if "lora_partial" in kind else "lora", "uncached" in kind))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    code = ("import sys, io, contextlib; sys.argv=['make_golden.py']; sys.path.insert(0, %r); import runpy; "
+            "g = runpy.run_path(%r, run_name='not_main')\n"
+            "for kw in %r:\n"
+            "    g['golden_trainer_loop'](%r, **kw)\n"
+            % (os.path.join(here, "golden"), os.path.join(here, "golden", "make_golden.py"), list(RUN_KW.values()), str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-3000:]
-    new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
-    assert set(new) == set(old)
-    for k in old:
-        assert torch.equal(new[k], old[k]), k
+    for kind in KINDS:
+        new, old = load_file(str(tmp_path / f"trainer_loop_{kind}_tiny.safetensors")), load_file(gold(kind))
+        assert set(new) == set(old), kind
+        for k in old:
+            assert torch.equal(new[k], old[k]), (kind, k)
