@@ -162,6 +162,7 @@ def _graft(m, layer):
         put("in_n", getattr(m, "_in_n", getattr(m, "in_n", None)))
         put("out_l", getattr(m, "_out_l", getattr(m, "out_l", None)))
         put("out_k", getattr(m, "_out_k", getattr(m, "out_k", None)))
+        put("kron_two_stage", check_kron_fits(m.lora_name, int(m.in_m), int(m.in_n), int(m.out_l), int(m.out_k)) == "two_stage")
         put("_in", layer.in_features)
         put("_out", layer.out_features)
         put("lora_up", _ParamProxy(m, "lokr_w1"))

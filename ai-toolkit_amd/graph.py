@@ -439,8 +439,51 @@ class FusedGraphBase(nn.Module):
 
     def _kron(self, lo, x, out, *, M, x_seg=None, out_seg=None):
         """out = scale * per-token lokr_w1 . X . lokr_w2^T  (the LoKr delta of one layer)."""
-        self.ops.kron_apply(x, lo.sh_up, lo.sh_down, out, a_in=lo.in_m, b_in=lo.in_n, a_out=lo.out_l, b_out=lo.out_k,
-                            scale=self._lokr_scale(lo), x_seg=x_seg, out_seg=out_seg, M=M)
+        self._kron_any(x, lo.sh_up, lo.sh_down, out, a_in=lo.in_m, b_in=lo.in_n, a_out=lo.out_l, b_out=lo.out_k, scale=self._lokr_scale(lo),
+                       x_seg=x_seg, out_seg=out_seg, M=M, two_stage=getattr(lo, "kron_two_stage", False))
+
+    def _rows_view(self, t, a, b, seg, M):
+        """[rows, a * b] (rows of one token) -> ([rows * a, b] view, segment map in those rows) for a GEMM over (token x factor-index) rows; a column
+        window of a wider buffer (row stride != a * b) cannot be viewed that way and is gathered into a contiguous copy first."""
+        if t.stride(0) != a * b:
+            c = self._new(M, a * b)
+            self.ops.kron_apply(t, None, None, c, a_in=a, b_in=b, a_out=a, b_out=b, x_seg=seg, M=M)
+            t, seg = c, None
+        return t.view(-1, b), (None if seg is None else (seg[0] * a, seg[1]))
+
+    def _kron_any(self, x, A, Bm, out, *, a_in, b_in, a_out, b_out, scale, M, x_seg=None, out_seg=None, accumulate=False, two_stage=False,
+                  col0=0, ncols=0):
+        """out (+)= scale * (A kron Bm) applied per token.  two_stage (lora.check_kron_fits: Bm too large for the per-token kernel's LDS, an explicit
+        small network.lokr_factor on a wide layer): a plain GEMM with Bm over (token x factor-index) rows + the per-token mix with the small factor
+        A on the NARROWER side of Bm, so that the mix's tiles fit:
+            b_in <= b_out:  V_m = A X_m  [a_out, b_in]   then  out[(m, p), :] = V[(m, p), :] Bm^T
+            b_in >  b_out:  T[(m, q), :] = X[(m, q), :] Bm^T   then  out_m = A T_m
+        The intermediate is bf16, as the per-token kernel's LDS intermediate is."""
+        ops = self.ops
+        if not two_stage:
+            ops.kron_apply(x, A, Bm, out, a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_out, scale=scale, accumulate=accumulate, col0=col0, ncols=ncols,
+                           x_seg=x_seg, out_seg=out_seg, M=M)
+            return
+        if ncols:  # a column window of the product (the single blocks' proj_out data gradient goes out in two windows): the whole product into a scratch, the window copied / added
+            tmp = self._new(M, a_out * b_out)
+            self._kron_any(x, A, Bm, tmp, a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_out, scale=scale, M=M, x_seg=x_seg, two_stage=True)
+            ops.kron_apply(tmp[:, col0:col0 + ncols], None, None, out, a_in=1, b_in=ncols, a_out=1, b_out=ncols, accumulate=accumulate, out_seg=out_seg, M=M)
+            return
+        if b_in <= b_out:
+            V = self._new(M, a_out * b_in)
+            ops.kron_apply(x, A, None, V, a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_in, scale=scale, x_seg=x_seg, M=M)
+            if out.stride(0) != a_out * b_out:  # destination is a column window: product into a contiguous scratch, then a (transposing-free) row copy
+                tmp = self._new(M, a_out * b_out)
+                ops.gemm_nt(V.view(M * a_out, b_in), Bm, tmp.view(M * a_out, b_out), M=M * a_out)
+                ops.kron_apply(tmp, None, None, out, a_in=a_out, b_in=b_out, a_out=a_out, b_out=b_out, accumulate=accumulate, out_seg=out_seg, M=M)
+                return
+            o2, c_seg = out.view(-1, b_out), (None if out_seg is None else (out_seg[0] * a_out, out_seg[1]))
+            ops.gemm_nt(V.view(M * a_out, b_in), Bm, o2, flags=EPI_ACCUM if accumulate else 0, c_seg=c_seg, M=M * a_out)
+        else:
+            x2, a_seg = self._rows_view(x, a_in, b_in, x_seg, M)
+            T = self._new(M, a_in * b_out)
+            ops.gemm_nt(x2, Bm, T.view(M * a_in, b_out), a_seg=a_seg, M=M * a_in)
+            ops.kron_apply(T, A, None, out, a_in=a_in, b_in=b_out, a_out=a_out, b_out=b_out, scale=scale, accumulate=accumulate, out_seg=out_seg, M=M)
 
     def _lokr_grads(self, lo, dy, x_in, *, M, x_seg=None):
         """Factor gradients into the fp32 arena (autograd of the reference's two einsums):
@@ -449,6 +492,8 @@ class FusedGraphBase(nn.Module):
         out with the contracted index leading: aitk_kron_apply writes them (transposed where needed), aitk_lora_wgrad reduces."""
         ops, sc = self.ops, self._lokr_scale(lo)
         a_in, b_in, a_out, b_out = lo.in_m, lo.in_n, lo.out_l, lo.out_k
+        if getattr(lo, "kron_two_stage", False):
+            return self._lokr_grads_two_stage(lo, dy, x_in, M=M, x_seg=x_seg)
         tmpT = self._new(M, b_out * a_in)   # [m, o, q] = (X_m w2^T)^T
         ops.kron_apply(x_in, None, lo.sh_down, tmpT, a_in=a_in, b_in=b_in, a_out=a_in, b_out=b_out, transpose_out=True, x_seg=x_seg, M=M)
         dyT = self._new(M, b_out * a_out)   # [m, o, p] = scale * dY_m^T
@@ -468,6 +513,48 @@ class FusedGraphBase(nn.Module):
         else:  # low-rank W2 = a @ b: gradient of the composed factor into its scratch, then d a = dW2 b^T, d b = a^T dW2 into the arena
             self._skinny_tn(U.view(M * a_in, b_out), xg, lo.g_down, rows=M * a_in, g_seg=g_seg, accumulate=False)
             ops.lokr_lowrank_grad(lo.g_down, lo.lokr_w2_a.data, lo.lokr_w2_b.data, lo.g_w2a, lo.g_w2b, accumulate=True)
+
+    def _lokr_grads_two_stage(self, lo, dy, x_in, *, M, x_seg=None):
+        """_lokr_grads when W2 does not fit the per-token kernel (lora.check_kron_fits "two_stage"): the same two contractions, with every per-token
+        product that involves W2 replaced by a GEMM over (token x factor-index) rows and every mix with lokr_w1 kept on the narrower side.
+          b_out <= b_in ("out" side narrow):  T = X w2^T [M, a_in, b_out];  d w1[p,q] = sum_{m,o} dY[m,p,o] T[m,q,o]
+                                              U = w1^T dY [M, a_in, b_out];  d w2[o,s] = sum_{m,q} U[m,q,o] X[m,q,s]
+          b_in  <  b_out ("in" side narrow):  dV = dY w2 [M, a_out, b_in];  d w1[p,q] = sum_{m,s} dV[m,p,s] X[m,q,s]
+                                              V = w1 X [M, a_out, b_in];    d w2[o,s] = sum_{m,p} dY[m,p,o] V[m,p,s]"""
+        ops, sc = self.ops, self._lokr_scale(lo)
+        a_in, b_in, a_out, b_out = lo.in_m, lo.in_n, lo.out_l, lo.out_k
+
+        def w2_grad(s_rows, g_rows, rows, g_seg=None):
+            if lo.use_w2:
+                self._skinny_tn(s_rows, g_rows, lo.g_down, rows=rows, g_seg=g_seg)
+            else:  # low-rank W2 = a @ b: gradient of the composed factor into its scratch, then the pair's gradients into the arena
+                self._skinny_tn(s_rows, g_rows, lo.g_down, rows=rows, g_seg=g_seg, accumulate=False)
+                ops.lokr_lowrank_grad(lo.g_down, lo.lokr_w2_a.data, lo.lokr_w2_b.data, lo.g_w2a, lo.g_w2b, accumulate=True)
+
+        if b_out <= b_in:
+            x2, a_seg = self._rows_view(x_in, a_in, b_in, x_seg, M)  # contiguous (token x q) rows of X (gathered when x_in is a column window)
+            T = self._new(M, a_in * b_out)
+            ops.gemm_nt(x2, lo.sh_down, T.view(M * a_in, b_out), a_seg=a_seg, M=M * a_in)
+            TT = self._new(M, b_out * a_in)   # [m, o, q]
+            ops.kron_apply(T, None, None, TT, a_in=a_in, b_in=b_out, a_out=a_in, b_out=b_out, transpose_out=True, M=M)
+            dyT = self._new(M, b_out * a_out)  # [m, o, p] = scale * dY_m^T
+            ops.kron_apply(dy, None, None, dyT, a_in=a_out, b_in=b_out, a_out=a_out, b_out=b_out, transpose_out=True, scale=sc, M=M)
+            self._skinny_tn(dyT.view(M * b_out, a_out), TT.view(M * b_out, a_in), lo.g_up, rows=M * b_out)
+            U = self._new(M, a_in * b_out)     # [m, q, o] = scale * (w1^T dY_m)
+            ops.kron_apply(dy, lo.sh_upT, None, U, a_in=a_out, b_in=b_out, a_out=a_in, b_out=b_out, scale=sc, M=M)
+            w2_grad(U.view(M * a_in, b_out), x2, M * a_in, g_seg=a_seg)
+        else:
+            dy2, d_seg = self._rows_view(dy, a_out, b_out, None, M)
+            dV = self._new(M, a_out * b_in)    # [m, p, s] = dY_m w2
+            ops.gemm_nt(dy2, lo.sh_downT, dV.view(M * a_out, b_in), a_seg=d_seg, M=M * a_out)
+            dVT = self._new(M, b_in * a_out)   # [m, s, p] (scaled)
+            ops.kron_apply(dV, None, None, dVT, a_in=a_out, b_in=b_in, a_out=a_out, b_out=b_in, transpose_out=True, scale=sc, M=M)
+            XT = self._new(M, b_in * a_in)     # [m, s, q]
+            ops.kron_apply(x_in, None, None, XT, a_in=a_in, b_in=b_in, a_out=a_in, b_out=b_in, transpose_out=True, x_seg=x_seg, M=M)
+            self._skinny_tn(dVT.view(M * b_in, a_out), XT.view(M * b_in, a_in), lo.g_up, rows=M * b_in)
+            V = self._new(M, a_out * b_in)     # [m, p, s] = scale * (w1 X_m)
+            ops.kron_apply(x_in, lo.sh_up, None, V, a_in=a_in, b_in=b_in, a_out=a_out, b_out=b_in, scale=sc, x_seg=x_seg, M=M)
+            w2_grad(dy2, V.view(M * a_out, b_in), M * a_out)
 
     def _skinny_tn(self, s, g, out, *, rows, g_seg=None, accumulate=True):
         """out[R, L] (fp32) += s[rows, R]^T @ g[rows, L] through aitk_lora_wgrad (rank blocks of <= 64 columns, R % 16 == 0);
@@ -640,8 +727,8 @@ class FusedGraphBase(nn.Module):
         if dT is _KRON:  # dX_m = w1^T . dY_m . w2, written (or added) into dx ahead of the base dgrad GEMM
             lo = lin.lora
             c0, nc = (0, 0) if w_rows is None else (w_rows[0], w_rows[1] - w_rows[0])
-            self.ops.kron_apply(dy, lo.sh_upT, lo.sh_downT, dx, a_in=lo.out_l, b_in=lo.out_k, a_out=lo.in_m, b_out=lo.in_n,
-                                scale=self._lokr_scale(lo), accumulate=bool(flags & EPI_ACCUM), col0=c0, ncols=nc, out_seg=dx_seg, M=M)
+            self._kron_any(dy, lo.sh_upT, lo.sh_downT, dx, a_in=lo.out_l, b_in=lo.out_k, a_out=lo.in_m, b_out=lo.in_n, scale=self._lokr_scale(lo),
+                           accumulate=bool(flags & EPI_ACCUM), col0=c0, ncols=nc, out_seg=dx_seg, M=M, two_stage=getattr(lo, "kron_two_stage", False))
             flags |= EPI_ACCUM
             dT = None
         if dT is not None:

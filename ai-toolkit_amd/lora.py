@@ -197,15 +197,29 @@ def kron_lds_bytes(a_in, b_in, a_out, b_out):
     return 2 * (c16(a_in) * xs + c16(b_out) * xs + c16(a_out) * as_ + c16(b_out) * as_ + c8(a_out * b_out))
 
 
+def kron_mix_lds_bytes(a_in, b, a_out):
+    """LDS footprint of aitk_kron_apply with ONLY the small factor resident (B = identity: out_m = A X_m, X_m [a_in, b])."""
+    c16, c32, c8 = (lambda v: -(-v // 16) * 16), (lambda v: -(-v // 32) * 32), (lambda v: -(-v // 8) * 8)
+    as_ = c32(a_in) + 8
+    return 2 * (c16(a_out) * as_ + c16(b) * as_ + c8(a_out * b))
+
+
 def check_kron_fits(name, in_m, in_n, out_l, out_k):
-    """A LoKr layer the per-token kernel cannot hold: an explicit small `network.lokr_factor` on a wide layer makes W2 [out/f, in/f] a large
-    matrix (factor 4 on a 3072 x 3072 Linear: 768 x 768) — a GEMM-shaped product, not this kernel's shape.  Refused where the adapter is
-    attached, with the numbers, instead of AITK_ERR_SHAPE at the first forward."""
+    """How a LoKr layer runs: "token" — both factors resident in the per-token Kronecker kernel (every layer size of FLUX / Wan / the UNets under the
+    reference's default factorisation) — or "two_stage": an explicit small `network.lokr_factor` on a wide layer makes W2 [out / f, in / f] a
+    GEMM-sized matrix (factor 4 on a 3072 x 3072 Linear: 768 x 768) that does not fit the kernel's LDS; the product is then split into a plain GEMM
+    with W2 over (token x factor-index) rows and the per-token mix with the small factor lokr_w1 on the NARROWER side (graph._kron_any).
+    Raises, where the adapter is attached and with the numbers, when even the small-factor mix does not fit."""
     need = max(kron_lds_bytes(in_m, in_n, out_l, out_k), kron_lds_bytes(out_l, out_k, in_m, in_n))  # forward and data gradient (transposed factors)
-    if need > 160 * 1024:
-        raise NotImplementedError(
-            f"{name}: LoKr factors lokr_w1 {out_l}x{in_m}, W2 {out_k}x{in_n} need {need // 1024} KiB of LDS in the per-token Kronecker kernel "
-            "(160 KiB per CU): use the default factorisation (network.lokr_factor: -1, factors near sqrt(dim)) or a larger factor")
+    if need <= 160 * 1024:
+        return "token"
+    b = min(in_n, out_k)
+    mix = max(kron_mix_lds_bytes(in_m, b, out_l), kron_mix_lds_bytes(out_l, b, in_m))
+    if mix <= 160 * 1024:
+        return "two_stage"
+    raise NotImplementedError(
+        f"{name}: LoKr factors lokr_w1 {out_l}x{in_m}, W2 {out_k}x{in_n} need {need // 1024} KiB of LDS in the per-token Kronecker kernel and "
+        f"{mix // 1024} KiB in the two-stage form (160 KiB per CU): use the default factorisation (network.lokr_factor: -1) or a larger factor")
 
 
 class LoKrModule(LoRAModule):
@@ -236,7 +250,7 @@ class LoKrModule(LoRAModule):
         self.out_l, self.out_k = factorization(out_dim, int(factor))
         if self.in_n % 8 or self.out_k % 8:
             raise NotImplementedError(f"LoKr factor {self.out_k}x{self.in_n}: the kron kernel needs multiples of 8")
-        check_kron_fits(lora_name, self.in_m, self.in_n, self.out_l, self.out_k)
+        self.kron_two_stage = check_kron_fits(lora_name, self.in_m, self.in_n, self.out_l, self.out_k) == "two_stage"
         self.use_w1 = True
         self.use_w2 = lora_dim >= max(self.out_k, self.in_n) / 2
         self.lokr_w1 = nn.Parameter(torch.empty(self.out_l, self.in_m))

@@ -112,8 +112,30 @@ def test_kron_apply_segmented_rows():
     assert _rel(dst[:, St:], want.reshape(B, Si, C)) < 8e-3
 
 
+@pytest.mark.parametrize("factor", [-1, 4])
+def test_two_stage_lokr_train_step_vs_fp32_oracle(monkeypatch, factor):
+    """lora.check_kron_fits "two_stage" forced on the tiny model: W2 through aitk_gemm_nt over (token x factor-index) rows, lokr_w1 mixed in by
+    aitk_kron_apply (B = identity) on the narrower side — forward delta, data gradient (incl. the windowed proj_out one) and both factor gradients."""
+    from ai_toolkit_amd import lora as L
+
+    real = L.check_kron_fits
+
+    def forced(name, in_m, in_n, out_l, out_k):
+        real(name, in_m, in_n, out_l, out_k)
+        return "two_stage"
+
+    monkeypatch.setattr(L, "check_kron_fits", forced)
+    test_lokr_train_step_vs_fp32_oracle(factor, expect_two_stage=True)
+
+
+def test_two_stage_lokr_at_flux_width_with_factor_4():
+    """The case the two-stage form exists for: d = 3072 (24 heads), `network.lokr_factor: 4` -> lokr_w1 4 x 4, W2 768 x 768 / 3072 x 768 / 768 x 3840 ...
+    — none fits the per-token kernel (1.2 MiB of LDS).  One double + one single block at FLUX width, a short sequence, vs the fp32 oracle."""
+    test_lokr_train_step_vs_fp32_oracle(4, expect_two_stage=True, cfg_over=dict(num_attention_heads=24, num_layers=1, num_single_layers=1), hw=(8, 8), n_txt=16, tol=3e-2, check_update=False)
+
+
 @pytest.mark.parametrize("factor", [-1, 4, 8])
-def test_lokr_train_step_vs_fp32_oracle(factor):
+def test_lokr_train_step_vs_fp32_oracle(factor, expect_two_stage=False, cfg_over=None, hw=(16, 12), n_txt=40, tol=2e-2, check_update=True):
     """factor -1: the default factorisation; 4 / 8 (`network.lokr_factor`): lokr_w1 is 4 x 4 / 8 x 8, below the 16-column granule of
     aitk_lora_wgrad — graph._skinny_tn reduces zero-padded copies and adds the valid block."""
     import ai_toolkit_amd  # noqa: F401
@@ -125,6 +147,7 @@ def test_lokr_train_step_vs_fp32_oracle(factor):
     from tests.test_gpu_e2e import CFG as CFG3
 
     CFG = dict(CFG3, num_attention_heads=2)  # d = 256: every Kronecker factor of the model is a multiple of 8
+    CFG.update(cfg_over or {})
     dev, big = "cuda", 9999999999
     torch.manual_seed(0)
     ref = flux_ref.FluxTransformer2DModel(**CFG)
@@ -141,6 +164,7 @@ def test_lokr_train_step_vs_fp32_oracle(factor):
     net = FusedLoRANetwork(nat, lora_dim=big, alpha=big, network_type="lokr", lokr_factor=factor)
     if factor > 0:
         assert any(tuple(m.lokr_w1.shape) == (factor, factor) for m in net.unet_loras)
+    assert any(m.kron_two_stage for m in net.unet_loras) == expect_two_stage
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for a, b in zip(net.unet_loras, ref_net.unet_loras):
@@ -156,7 +180,7 @@ def test_lokr_train_step_vs_fp32_oracle(factor):
     nat.attach_network(net)
     nat.prepare()
     gb = torch.Generator().manual_seed(5)
-    Bn, Hl, Wl, n_txt = 2, 16, 12, 40
+    Bn, (Hl, Wl) = 2, hw
     lat = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
     emb = (torch.randn(Bn, n_txt, CFG["joint_attention_dim"], generator=gb) * 0.5).to(BF).to(dev)
     pooled = (torch.randn(Bn, CFG["pooled_projection_dim"], generator=gb) * 0.5).to(BF).to(dev)
@@ -178,7 +202,9 @@ def test_lokr_train_step_vs_fp32_oracle(factor):
             worst = max(worst, math.sqrt(d2 / (n2 + 1e-30)))
     e = math.sqrt(num / den)
     print(f"lokr loss ours {loss:.6f} fp32 {loss32:.6f}; factor-gradient rel err {e:.3e} (worst layer {worst:.3e})")
-    assert e < 2e-2, e
+    assert e < tol, e
+    if not check_update:  # (synthetic N(0, 0.03^2) weights at d = 3072 give a loss of ~5: an AdamW step of 1e-3 on 768 x 768 factors overshoots there)
+        return
     # a real update moves the loss and keeps the adapter finite
     ours2 = FluxLoRATrainStep(nat, net, ops, lr=1e-3, max_grad_norm=1.0)
     l0 = ours2.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
@@ -278,7 +304,7 @@ def test_lowrank_lokr_train_step_vs_fp32_oracle():
     nat.attach_network(net)
     nat.prepare()
     gb = torch.Generator().manual_seed(5)
-    Bn, Hl, Wl, n_txt = 2, 16, 12, 40
+    Bn, (Hl, Wl) = 2, hw
     lat = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
     emb = (torch.randn(Bn, n_txt, CFG["joint_attention_dim"], generator=gb) * 0.5).to(BF).to(dev)
     pooled = (torch.randn(Bn, CFG["pooled_projection_dim"], generator=gb) * 0.5).to(BF).to(dev)

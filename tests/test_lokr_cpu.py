@@ -112,11 +112,37 @@ def test_native_lokr_network_and_host_graph_match_reference_vectors(gold, tmp_pa
     assert params[0] is net.unet_loras[0].lokr_w1 and params[1] is net.unet_loras[0].lokr_w2
 
 
+@pytest.fixture
+def force_two_stage(monkeypatch):
+    """every LoKr layer takes the two-stage form (W2 through a GEMM over (token x factor-index) rows + the small-factor mix on the narrower side) —
+    what lora.check_kron_fits selects when W2 does not fit the per-token kernel's LDS (explicit small lokr_factor on a wide layer)"""
+    from ai_toolkit_amd import lora as L
+
+    real = L.check_kron_fits
+
+    def forced(name, in_m, in_n, out_l, out_k):
+        real(name, in_m, in_n, out_l, out_k)
+        return "two_stage"
+
+    monkeypatch.setattr(L, "check_kron_fits", forced)
+    import ai_toolkit_amd.adopt as A
+
+    monkeypatch.setattr(A, "check_kron_fits", forced)
+
+
 @pytest.mark.parametrize("factor", [-1, 4, 8])
-def test_lokr_train_steps_match_autograd_oracle(factor):
+def test_two_stage_lokr_train_steps_match_autograd_oracle(force_two_stage, factor):
+    """the double blocks' segmented joint buffers, the single blocks' windowed proj_out data gradient, adaLN projections and both narrow-side cases
+    (b_in <= b_out, b_in > b_out) all occur in the tiny FLUX"""
+    test_lokr_train_steps_match_autograd_oracle(factor, expect_two_stage=True)
+
+
+@pytest.mark.parametrize("factor", [-1, 4, 8])
+def test_lokr_train_steps_match_autograd_oracle(factor, expect_two_stage=False):
     """factor -1: the reference's default factorisation (factors near sqrt(dim), multiples of 16 on the model sizes); 4 / 8: `network.lokr_factor`
     — lokr_w1 is 4 x 4 / 8 x 8, below the granule of the weight-gradient kernel: graph._skinny_tn's zero-padded path."""
     ref, nat, net = native_pair(factor)
+    assert all(bool(m.kron_two_stage) == expect_two_stage for m in net.unet_loras)
     torch.manual_seed(99)
     ref_net = lora_ref.RefLoRANetwork(ref, BIG, network_type="lokr", lokr_factor=factor)
     if factor > 0:
@@ -184,32 +210,37 @@ def test_lokr_merge_in_equals_reference_merge_in(gold):
         assert torch.allclose(lin.weight, before[k][0], rtol=1e-5, atol=1e-6) and torch.allclose(lin.weight_t, before[k][1], rtol=1e-5, atol=1e-6)
 
 
-def test_lokr_factors_the_per_token_kernel_cannot_hold_are_refused_where_the_adapter_is_attached():
-    """An explicit small `network.lokr_factor` on a wide layer makes W2 a GEMM-sized matrix (factor 4 on 3072 x 3072: 768 x 768) that does not fit the
-    160-KiB LDS of aitk_kron_apply: refused at construction / apply_to with the numbers (not AITK_ERR_SHAPE at the first forward).  The default
-    factorisation of every FLUX / Wan / SD layer size fits."""
+def test_lokr_factor_modes_token_two_stage_and_refusal():
+    """lora.check_kron_fits: every layer size of FLUX / Wan / the UNets runs in the per-token kernel under the reference's default factorisation; an explicit
+    small `network.lokr_factor` (the reference UI offers 4 / 8 / 16 / 32) on a wide layer makes W2 a GEMM-sized matrix (factor 4 on 3072 x 3072: 768 x 768)
+    and selects the two-stage form; what fits neither is refused where the adapter is attached (construction / apply_to), with the numbers."""
     from types import SimpleNamespace
 
     from ai_toolkit_amd.adopt import AdoptionError, register_foreign_adapter
     from ai_toolkit_amd.graph import Linear
     from ai_toolkit_amd.lora import LoKrModule, check_kron_fits, kron_lds_bytes
 
-    for d_in, d_out in ((3072, 3072), (3072, 9216), (3072, 12288), (12288, 3072), (15360, 3072), (3072, 21504), (1536, 8960), (320, 320), (1280, 10240), (2048, 2048)):
+    sizes = ((3072, 3072), (3072, 9216), (3072, 12288), (12288, 3072), (15360, 3072), (3072, 21504), (1536, 8960), (320, 320), (1280, 10240), (2048, 2048))
+    for d_in, d_out in sizes:
         im, inn = factorization(d_in)
         ol, ok = factorization(d_out)
         if inn % 8 == 0 and ok % 8 == 0:
-            check_kron_fits("default", im, inn, ol, ok)
+            assert check_kron_fits("default", im, inn, ol, ok) == "token", (d_in, d_out)
     assert kron_lds_bytes(48, 64, 48, 64) == 38400  # = 2 * kron_layout(48, 64, 48, 64).total of csrc/kron.hip
-    wide, narrow = Linear(3072, 3072, bias=False, dtype=torch.float32, device="meta"), Linear(256, 256, bias=False, dtype=torch.float32, device="meta")
-    for f in (4, 8):
-        with pytest.raises(NotImplementedError, match="KiB of LDS"):
-            LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=f)
-    LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=16)  # W2 192 x 192: fits
-    with pytest.raises(NotImplementedError, match="KiB of LDS"):      # ... but not on the 3072 -> 12288 MLP projection (W2 768 x 192)
-        LoKrModule("mlp", Linear(3072, 12288, bias=False, dtype=torch.float32, device="meta"), lora_dim=BIG, alpha=BIG, factor=16)
-    LoKrModule("wide", wide, lora_dim=BIG, alpha=BIG, factor=-1)
-    LoKrModule("narrow", narrow, lora_dim=BIG, alpha=BIG, factor=4)
+    for f in (4, 8, 16, 32):  # the FLUX layer sizes under every factor the reference's UI offers
+        for d_in, d_out in sizes[:6]:
+            im, inn = factorization(d_in, f)
+            ol, ok = factorization(d_out, f)
+            assert check_kron_fits(f"f{f}", im, inn, ol, ok) in ("token", "two_stage"), (f, d_in, d_out)
+    mk = lambda i, o: Linear(i, o, bias=False, dtype=torch.float32, device="meta")  # noqa: E731
+    assert LoKrModule("wide", mk(3072, 3072), lora_dim=BIG, alpha=BIG, factor=4).kron_two_stage
+    assert LoKrModule("mlp", mk(3072, 12288), lora_dim=BIG, alpha=BIG, factor=4).kron_two_stage
+    assert not LoKrModule("wide", mk(3072, 3072), lora_dim=BIG, alpha=BIG, factor=-1).kron_two_stage
+    assert not LoKrModule("narrow", mk(256, 256), lora_dim=BIG, alpha=BIG, factor=4).kron_two_stage
+    with pytest.raises(NotImplementedError, match="KiB of LDS"):  # the small-factor mix itself does not fit: 8192-wide sides
+        LoKrModule("huge", mk(16384, 16384), lora_dim=BIG, alpha=BIG, factor=2)
     # the same check on a LokrModule the reference built (adoption): the oracle's restatement stands in for it
-    m = lora_ref.RefLokrModule("lokr_wide", wide, BIG, BIG, SimpleNamespace(is_lorm=False), factor=4)
+    huge = mk(16384, 16384)
+    m = lora_ref.RefLokrModule("lokr_huge", huge, BIG, BIG, SimpleNamespace(is_lorm=False), factor=2)
     with pytest.raises(AdoptionError, match="KiB of LDS"):
-        register_foreign_adapter(wide, m.forward)
+        register_foreign_adapter(huge, m.forward)

@@ -175,3 +175,18 @@ def test_full_and_lowrank_files_do_not_cross_load(tmp_path):
     base = m0.lora_name.replace("$$", ".")
     extra = net.load_weights({f"{base}.lokr_w1": m0.lokr_w1.detach().clone(), f"{base}.lokr_w2": torch.zeros(m0.out_k, m0.in_n)})
     assert list(extra.keys()) == [f"{base}.lokr_w2"]
+
+
+def test_two_stage_lowrank_lokr_train_steps_match_autograd_oracle(monkeypatch):
+    """the low-rank pair's gradients (d a = dW2 b^T, d b = a^T dW2 from the composed factor's gradient) behind the two-stage form of the products
+    (lora.check_kron_fits "two_stage": W2 through a GEMM, lokr_w1 mixed in on the narrower side)"""
+    from ai_toolkit_amd import lora as L
+
+    real = L.check_kron_fits
+
+    def forced(name, in_m, in_n, out_l, out_k):
+        real(name, in_m, in_n, out_l, out_k)
+        return "two_stage"
+
+    monkeypatch.setattr(L, "check_kron_fits", forced)
+    test_lowrank_lokr_train_steps_match_autograd_oracle()
