@@ -304,7 +304,7 @@ def test_lowrank_lokr_train_step_vs_fp32_oracle():
     nat.attach_network(net)
     nat.prepare()
     gb = torch.Generator().manual_seed(5)
-    Bn, (Hl, Wl) = 2, hw
+    Bn, Hl, Wl, n_txt = 2, 16, 12, 40
     lat = torch.randn(Bn, 16, Hl, Wl, generator=gb).to(BF).to(dev)
     emb = (torch.randn(Bn, n_txt, CFG["joint_attention_dim"], generator=gb) * 0.5).to(BF).to(dev)
     pooled = (torch.randn(Bn, CFG["pooled_projection_dim"], generator=gb) * 0.5).to(BF).to(dev)
