@@ -215,7 +215,7 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
-ABI_VERSION = 8  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+ABI_VERSION = 9  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
 
 
 def lib():
@@ -248,6 +248,7 @@ def lib():
     L.aitk_rows_per_block.restype = i32
     L.aitk_mse_workspace_bytes.restype = C.c_int64
     L.aitk_mse_workspace_bytes.argtypes = [i32, i64]
+    L.aitk_ema_update.argtypes = [vp, vp, i64, C.c_float, C.c_float, C.c_float, vp]
     L.aitk_adamw_workspace_bytes.restype = C.c_int64
     L.aitk_adamw_workspace_bytes.argtypes = [i64]
     L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]

@@ -26,6 +26,8 @@ objects the reference made:
   * If something replaced a Parameter's storage behind our back (`network.to(...)`, a rank-changing `load_weights`: network_mixins.py:737-775),
     the next forward notices the pointer mismatch, copies the current values into the arena and re-points again (`AdoptedNetwork.sync`).
 """
+import os as _os
+import sys as _sys
 import weakref
 
 import torch
@@ -202,9 +204,11 @@ class AdoptedNetwork(FusedLoRANetwork):
     network object the reference constructed; everything the trainer talks to stays the reference's own object."""
 
     _repoint = True
+    fuse_trainer_step = True  # the trainer's optimizer.step() / ema.update() on the arena kernels when that is the same computation (below)
 
     def __init__(self, foreign, model, ops, device=None):
         nn.Module.__init__(self)
+        self._fusions = []  # weak references to the _OptimizerFusion / _EmaFusion objects whose state lives in this network's arenas
         object.__setattr__(self, "_foreign", foreign)          # not a registered sub-module: its Parameters have one owner, the reference's network
         object.__setattr__(self, "_model_ref", weakref.ref(model))
         mods = list(foreign.get_all_modules() if hasattr(foreign, "get_all_modules") else foreign.unet_loras)
@@ -258,6 +262,9 @@ class AdoptedNetwork(FusedLoRANetwork):
         self._expect = None
         self._record_pointers()
         self.refresh_shadows(ops)
+        _LIVE.add(self)
+        _GEN[0] += 1
+        install_trainer_fusion()
 
     # ---- state that lives on the reference's network object
     @property
@@ -337,6 +344,7 @@ class AdoptedNetwork(FusedLoRANetwork):
     # ---- Parameter <-> arena aliasing
     def _record_pointers(self):
         self._expect = [(p, p.data_ptr()) for m in self.unet_loras for p in _trainable(m)]
+        self._expect_by_id = {id(p): p for p, _ in self._expect}
 
     def aliasing_intact(self):
         return all(p.data_ptr() == ptr for p, ptr in self._expect)
@@ -354,6 +362,10 @@ class AdoptedNetwork(FusedLoRANetwork):
                             raise AdoptionError(f"{m.lora_name}: adapter moved to {p.device}/{p.dtype}; the fused path needs it on {dev} in fp32")
             # same module set, possibly new shapes: rebuild (values are taken from the Parameters as they are now)
             grads = [(p, None if p.grad is None else p.grad.detach().clone()) for p, _ in self._expect]
+            for ref in self._fusions:  # AdamW moments / EMA shadows that live in the arenas about to be replaced become tensors of their own
+                fus = ref()
+                if fus is not None:
+                    fus.materialise()
             model = self._model_ref()
             self.build_arena(dev, ema=False, groups=model.lora_groups() if hasattr(model, "lora_groups") else None)
             with torch.no_grad():
@@ -455,3 +467,332 @@ def resolve_network(model):
         return net  # shadows are fresh
     net.sync(refresh=net.is_active)
     return net
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# The trainer's optimizer tail on the arena kernels.
+#
+# Per step the reference's trainer runs (extensions_built_in/sd_trainer/SDTrainer.py:2278-2293)
+#
+#     self.accelerator.clip_grad_norm_(self.params, max_grad_norm)     torch foreach ops over the 988 .grad views
+#     self.optimizer.step()                                            torch.optim.AdamW(eps=1e-6) (toolkit/optimizer.py:78-79): foreach over 988 tensors
+#     self.optimizer.zero_grad(set_to_none=True)
+#     self.ema.update()                                                toolkit/ema.py:126-152: a Python loop, >= 3 tiny kernels per parameter
+#
+# over Parameters that, after adoption, are views of ONE flat arena.  Without touching the trainer, the two objects it calls are served from
+# the arena kernels when — and only when — that is the same computation:
+#
+#   * `torch.optim.Optimizer` step hooks (torch.optim.optimizer.register_optimizer_step_pre_hook / _post_hook, process-global, installed when
+#     the first network is adopted): a plain `torch.optim.AdamW` whose parameter set is exactly the adopted network's, all groups with the same
+#     hyper-parameters, no amsgrad / maximize / closure, every parameter with its arena-view gradient -> ONE `aitk_adamw_ema_step` over the
+#     arenas (no clip: the trainer's clip_grad_norm_ already ran on the same memory), its moments living in `arena_m` / `arena_v` with the
+#     optimizer's own `state[p]['exp_avg' / 'exp_avg_sq']` re-pointed at views of them (so `optimizer.state_dict()`, the reference's
+#     optimizer.pt, resumes and `load_state_dict` keep working), and torch's own step finds no gradients (they are hidden for the duration of
+#     the call and handed back by the post-hook).  Anything else (8-bit Adam, Adafactor, Prodigy, per-group learning rates, a partial
+#     gradient set) runs torch's / the optimizer's own code as before.
+#   * `install_ema_fusion(cls)` wraps `cls.update` of the reference's `ExponentialMovingAverage` (called with toolkit.ema's class by
+#     integration/extensions/aitk_mi355, or found in sys.modules at adoption): an EMA over exactly the adopted parameters, fp32 shadows on the
+#     arena's device -> shadows re-pointed at views of `arena_ema`, `update()` = the class's own decay bookkeeping + ONE `aitk_ema_update`.
+#
+# AITK_FUSE_TRAINER_STEP=0 (or AdoptedNetwork.fuse_trainer_step = False) leaves both objects alone.
+_LIVE = weakref.WeakSet()  # AdoptedNetworks alive in this process
+_GEN = [0]                 # bumped whenever a network is adopted: negative matches cached on optimizers / EMAs are re-examined
+_HOOKS_INSTALLED = [False]
+STATS = {"adamw_fused": 0, "adamw_fallback": 0, "ema_fused": 0, "ema_fallback": 0}  # calls served by the arena kernels / left to torch (process-wide)
+
+
+def fusion_enabled():
+    return bool(AdoptedNetwork.fuse_trainer_step) and _os.environ.get("AITK_FUSE_TRAINER_STEP", "1") != "0"
+
+
+def _arena_twin(net, par, arena):
+    """The view of `arena` (arena_m / arena_v / arena_ema) with the geometry `par` has inside arena_p."""
+    off = par.storage_offset() - net.arena_p.storage_offset()
+    return torch.as_strided(arena, par.shape, par.stride(), arena.storage_offset() + off)
+
+
+def _match_network(param_ids):
+    for net in list(_LIVE):
+        if net._expect is not None and len(net._expect) == len(param_ids) and {id(p) for p, _ in net._expect} == param_ids:
+            return net
+    return None
+
+
+class _OptimizerFusion:
+    """One torch.optim.AdamW instance served by `aitk_adamw_ema_step` over the arenas of the network whose parameters it holds."""
+
+    def __init__(self, opt, net):
+        self.opt = weakref.ref(opt)
+        self.net = weakref.ref(net)
+        self.params = [p for g in opt.param_groups for p in g["params"]]
+        self.step_count = 0
+        self.steps_current = True   # state[p]['step'] tensors hold step_count (they are only written when somebody looks)
+        self.arena_m = None         # the arena objects the state views were cut from (a rebuilt arena is a new object)
+        self.hidden = None
+        self.fused_steps = 0
+        opt.register_state_dict_pre_hook(lambda o: self.flush_steps())
+        net._fusions.append(weakref.ref(self))
+
+    # -- eligibility, per call (cheap: group hyper-parameters and a pointer spot check)
+    def _hyper(self):
+        opt = self.opt()
+        if type(opt) is not torch.optim.AdamW:
+            return None
+        g0 = opt.param_groups[0]
+        n = 0
+        for g in opt.param_groups:
+            if g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or g.get("capturable"):
+                return None
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                a, b = g[k], g0[k]
+                if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+                    a, b = (float(x) if not isinstance(x, tuple) else x for x in (a, b))
+                if a != b:
+                    return None  # per-group hyper-parameters: torch's own step
+            n += len(g["params"])
+        if n != len(self.params):
+            return None          # add_param_group since the match
+        return float(g0["lr"]), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), float(g0["weight_decay"])
+
+    def _state_in_arena(self, net):
+        if self.arena_m is not net.arena_m:
+            return False
+        st = self.opt().state
+        for p in (self.params[0], self.params[-1]):
+            s = st.get(p)
+            if not s or "exp_avg" not in s or s["exp_avg"].data_ptr() != _arena_twin(net, p, net.arena_m).data_ptr():
+                return False
+        return True
+
+    def _adopt_state(self, net):
+        """Moments into arena_m / arena_v, `state[p]` re-pointed at views of them.  Returns False (nothing changed) when the optimizer's
+        state cannot be expressed by one step count."""
+        opt = self.opt()
+        steps = set()
+        for p in self.params:
+            s = opt.state.get(p)
+            steps.add(float(s["step"]) if s and "step" in s else 0.0)
+        if len(steps) != 1:
+            return False
+        with torch.no_grad():
+            for p in self.params:
+                s = opt.state.get(p)
+                mv, vv = _arena_twin(net, p, net.arena_m), _arena_twin(net, p, net.arena_v)
+                if s and "exp_avg" in s:
+                    if s["exp_avg"].data_ptr() != mv.data_ptr():
+                        mv.copy_(s["exp_avg"])
+                        vv.copy_(s["exp_avg_sq"])
+                    step_t = s["step"] if isinstance(s.get("step"), torch.Tensor) and s["step"].device.type == "cpu" else torch.tensor(0.0, dtype=torch.float32)
+                else:
+                    mv.zero_()
+                    vv.zero_()
+                    step_t = torch.tensor(0.0, dtype=torch.float32)
+                opt.state[p] = {"step": step_t, "exp_avg": mv, "exp_avg_sq": vv}
+        self.step_count = int(steps.pop())
+        self.steps_current = False
+        self.flush_steps()
+        self.arena_m = net.arena_m
+        return True
+
+    def _fallback(self):
+        STATS["adamw_fallback"] += 1
+        return self.flush_steps()
+
+    def flush_steps(self):
+        """state[p]['step'] <- the number of steps applied (before anybody reads the state: state_dict(), torch's own step)."""
+        if self.steps_current:
+            return
+        opt = self.opt()
+        if opt is None:
+            return
+        for p in self.params:
+            s = opt.state.get(p)
+            if s and "step" in s:
+                s["step"].fill_(float(self.step_count))
+        self.steps_current = True
+
+    def materialise(self):
+        """Before the arenas are rebuilt (AdoptedNetwork.sync): the moments become tensors of their own again; the next fused step moves them
+        into the new arena."""
+        opt = self.opt()
+        if opt is None or self.arena_m is None:
+            return
+        self.flush_steps()
+        for p in self.params:
+            s = opt.state.get(p)
+            if s and "exp_avg" in s:
+                s["exp_avg"], s["exp_avg_sq"] = s["exp_avg"].clone(), s["exp_avg_sq"].clone()
+        self.arena_m = None
+
+    # -- the hooks
+    def pre(self, args, kwargs):
+        self.hidden = None
+        net, opt = self.net(), self.opt()
+        if net is None or not fusion_enabled():
+            return self._fallback()
+        if (len(args) > 1 and args[1] is not None) or kwargs.get("closure") is not None:  # args = (optimizer, closure?) as torch's step wrapper passes them
+            return self._fallback()
+        hp = self._hyper()
+        if hp is None or not net.aliasing_intact():
+            return self._fallback()
+        grads = [p.grad for p in self.params]
+        n_none = sum(g is None for g in grads)
+        if n_none == len(grads):
+            return None              # nothing to step (torch skips parameters without .grad): no state change either way
+        if n_none or any(grads[i].data_ptr() != _arena_twin(net, self.params[i], net.arena_g).data_ptr() for i in (0, -1)):
+            return self._fallback()  # a partial gradient set / gradients that are not the arena's: torch's own step
+        if not self._state_in_arena(net):
+            if not self._adopt_state(net):
+                return self._fallback()
+        elif self.steps_current:     # torch's own step may have run since (a fallback call): the tensors are the truth
+            self.step_count = int(float(opt.state[self.params[0]]["step"]))
+        lr, b1, b2, eps, wd = hp
+        self.step_count += 1
+        self.steps_current = False
+        with torch.no_grad():  # step hooks run outside the optimizer's own no_grad region
+            net._ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd,
+                                    step=self.step_count, max_norm=0.0, ema=None)
+        self.fused_steps += 1
+        STATS["adamw_fused"] += 1
+        for p in self.params:        # torch's own step now finds nothing to do
+            p.grad = None
+        self.hidden = grads
+
+    def post(self):
+        if self.hidden is not None:
+            for p, g in zip(self.params, self.hidden):
+                if p.grad is None:
+                    p.grad = g
+            self.hidden = None
+
+
+def _fusion_of(opt):
+    ent = opt.__dict__.get("_aitk_fusion")
+    if ent is not None and (ent[0] is not None or ent[1] == _GEN[0]):
+        return ent[0]
+    fus = None
+    if type(opt) is torch.optim.AdamW and _LIVE:
+        net = _match_network({id(p) for g in opt.param_groups for p in g["params"]})
+        if net is not None:
+            fus = _OptimizerFusion(opt, net)
+    opt.__dict__["_aitk_fusion"] = (fus, _GEN[0])
+    return fus
+
+
+def _optimizer_pre_hook(opt, args, kwargs):
+    if not _LIVE:
+        return None
+    fus = _fusion_of(opt)
+    if fus is not None:
+        fus.pre(args, kwargs)
+    return None
+
+
+def _optimizer_post_hook(opt, args, kwargs):
+    ent = opt.__dict__.get("_aitk_fusion")
+    if ent is not None and ent[0] is not None:
+        ent[0].post()
+    return None
+
+
+class _EmaFusion:
+    """One `ExponentialMovingAverage` (toolkit/ema.py) whose shadows live in `arena_ema` of the network whose parameters it averages."""
+
+    def __init__(self, ema, net):
+        self.ema = weakref.ref(ema)
+        self.net = weakref.ref(net)
+        self.arena = None
+        self.fused_updates = 0
+        net._fusions.append(weakref.ref(self))
+
+    def _in_arena(self, net, ema, params):
+        if self.arena is None or self.arena is not net.arena_ema or len(ema.shadow_params) != len(params):
+            return False
+        return all(ema.shadow_params[i].data_ptr() == _arena_twin(net, params[i], net.arena_ema).data_ptr() for i in (0, -1))
+
+    def _adopt(self, net, ema, params):
+        dev = net.arena_p.device
+        if any(s.dtype != torch.float32 or s.device != dev or s.shape != p.shape for s, p in zip(ema.shadow_params, params)):
+            return False
+        if net.arena_ema is None or net.arena_ema.numel() != net.arena_p.numel():
+            net.arena_ema = torch.zeros_like(net.arena_p)
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                view = _arena_twin(net, p, net.arena_ema)
+                if ema.shadow_params[i].data_ptr() != view.data_ptr():
+                    view.copy_(ema.shadow_params[i])
+                ema.shadow_params[i] = view
+        self.arena = net.arena_ema
+        return True
+
+    def materialise(self):
+        ema = self.ema()
+        if ema is None or self.arena is None:
+            return
+        ema.shadow_params = [s.clone() for s in ema.shadow_params]
+        self.arena = None
+
+    def update(self, ema, params):
+        """True when the arena kernel did the update."""
+        net = self.net()
+        if net is None or not fusion_enabled() or not net.aliasing_intact():
+            return False
+        if any(p.dtype != torch.float32 for p in (params[0], params[-1])):
+            return False
+        if not self._in_arena(net, ema, params) and not self._adopt(net, ema, params):
+            return False
+        decay = ema.decay  # toolkit/ema.py:117-125
+        if ema.num_updates is not None:
+            ema.num_updates += 1
+            decay = min(decay, (1 + ema.num_updates) / (10 + ema.num_updates))
+        with torch.no_grad():
+            net._ops.ema_update(net.arena_p, net.arena_ema, decay=decay, ema_feedback=10.0 if getattr(ema, "use_feedback", False) else 0.0,
+                                param_multiplier=float(getattr(ema, "param_multiplier", 1.0)))
+        self.fused_updates += 1
+        STATS["ema_fused"] += 1
+        return True
+
+
+def install_ema_fusion(cls):
+    """Wrap `cls.update` (the reference's toolkit.ema.ExponentialMovingAverage, or a class with its attributes: shadow_params, decay,
+    num_updates, use_feedback, param_multiplier, _get_parameters).  Idempotent."""
+    if getattr(cls.update, "_aitk_wrapped", False):
+        return cls
+    orig = cls.update
+
+    def update(self, parameters=None):
+        if _LIVE and fusion_enabled():
+            ent = self.__dict__.get("_aitk_fusion")
+            params = None
+            if ent is None or (ent[0] is None and ent[1] != _GEN[0]):
+                params = list(self._get_parameters(parameters))
+                net = _match_network({id(p) for p in params}) if params else None
+                ent = (_EmaFusion(self, net) if net is not None else None, _GEN[0])
+                self.__dict__["_aitk_fusion"] = ent
+            if ent[0] is not None:
+                params = params if params is not None else list(self._get_parameters(parameters))
+                net = ent[0].net()
+                if net is not None and len(params) == len(net._expect) and params[0] is net._expect_by_id.get(id(params[0])) \
+                        and params[-1] is net._expect_by_id.get(id(params[-1])) and ent[0].update(self, params):
+                    return None
+            STATS["ema_fallback"] += 1
+        return orig(self, parameters)
+
+    update._aitk_wrapped = True
+    update._aitk_orig = orig
+    cls.update = update
+    return cls
+
+
+def install_trainer_fusion():
+    """Process-global optimizer step hooks (once) + the EMA wrap when the reference's toolkit.ema is loaded."""
+    if not _HOOKS_INSTALLED[0]:
+        from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+
+        register_optimizer_step_pre_hook(_optimizer_pre_hook)
+        register_optimizer_step_post_hook(_optimizer_post_hook)
+        _HOOKS_INSTALLED[0] = True
+    mod = _sys.modules.get("toolkit.ema")
+    cls = getattr(mod, "ExponentialMovingAverage", None) if mod is not None else None
+    if cls is not None:
+        install_ema_fusion(cls)

@@ -371,6 +371,57 @@ extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream)
   return AITK_OK;
 }
 
+// EMA alone, for trainers that call the optimizer and the EMA separately (the reference: `self.optimizer.step()` ... `self.ema.update()`,
+// extensions_built_in/sd_trainer/SDTrainer.py:2284-2293): toolkit/ema.py:126-152 over the flat arenas in ONE launch instead of its Python loop
+// over every parameter (>= 3 tiny kernels each).  Same arithmetic, same order as the tail of adamw_ema_kernel:
+//   tmp = (1 - d)(s - p); s -= tmp; p += feedback * tmp (use_feedback: 10); p *= param_multiplier.
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ p, float* __restrict__ ema, long n, float one_minus_decay,
+                                                         float feedback, float mult) {
+  const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
+  const bool writes_p = feedback != 0.f || (mult != 0.f && mult != 1.0f);
+#pragma unroll
+  for (int i = 0; i < OPT_BLOCK_ELEMS / (256 * 4); ++i) {
+    const long j = base + (long)(i * 256 + threadIdx.x) * 4;
+    if (j + 3 < n) {
+      float4 w = *reinterpret_cast<const float4*>(p + j);
+      float4 s = *reinterpret_cast<const float4*>(ema + j);
+      float* wv = reinterpret_cast<float*>(&w);
+      float* sv = reinterpret_cast<float*>(&s);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tmp = __fmul_rn(one_minus_decay, __fsub_rn(sv[k], wv[k]));
+        sv[k] = __fsub_rn(sv[k], tmp);
+        if (feedback != 0.f) wv[k] = __fadd_rn(wv[k], __fmul_rn(feedback, tmp));
+        if (mult != 0.f && mult != 1.0f) wv[k] = __fmul_rn(wv[k], mult);
+      }
+      *reinterpret_cast<float4*>(ema + j) = s;
+      if (writes_p) *reinterpret_cast<float4*>(p + j) = w;
+    } else {
+      for (long k = j; k < n && k < j + 4; ++k) {
+        float w = p[k];
+        const float s = ema[k];
+        const float tmp = __fmul_rn(one_minus_decay, __fsub_rn(s, w));
+        ema[k] = __fsub_rn(s, tmp);
+        if (feedback != 0.f) w = __fadd_rn(w, __fmul_rn(feedback, tmp));
+        if (mult != 0.f && mult != 1.0f) w = __fmul_rn(w, mult);
+        if (writes_p) p[k] = w;
+      }
+    }
+  }
+}
+
+extern "C" int aitk_ema_update(float* p, float* ema, int64_t n, float one_minus_decay, float feedback, float param_multiplier,
+                               aitk_stream_t stream) {
+  if (n <= 0) return AITK_ERR_SHAPE;
+  if (!p || !ema) return AITK_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(ema)) & 15) return AITK_ERR_ALIGN;
+  const long n1 = (n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS;
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)n1), dim3(256), 0, (hipStream_t)stream, p, ema, (long)n, one_minus_decay, feedback,
+                     param_multiplier);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ bf16 shadows
 // For every adapter matrix in the fp32 arena (row-major [rows, cols]) write its bf16 shadows in the layouts the skinny kernels
 // and the GEMM K-slab read (AitkShadowDesc in the header): hi = bf16(w), lo = bf16(w - hi) — the split representation that keeps

@@ -638,6 +638,13 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
     _call("aitk_adamw_ema_step", C.byref(a))
 
 
+def ema_update(p, ema, *, decay, ema_feedback=0.0, param_multiplier=1.0):
+    """toolkit/ema.py:126-152 over the flat arenas in one launch (`decay` already min'ed with the num_updates warm-up by the caller):
+    ema -= (1 - decay)(ema - p); p += ema_feedback * that; p *= param_multiplier."""
+    assert p.dtype == torch.float32 and ema.dtype == torch.float32 and p.is_contiguous() and ema.is_contiguous() and p.numel() == ema.numel()
+    _call("aitk_ema_update", _ptr(p), _ptr(ema), p.numel(), 1.0 - decay, float(ema_feedback), float(param_multiplier))
+
+
 def make_shadow_table(entries, device):
     """entries: list of (src_off, rows, cols, kind, d0, d1, d2[, aux]) (AitkShadowDesc) -> device table for refresh_shadows."""
     arr = (_capi.ShadowDesc * len(entries))()

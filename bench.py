@@ -25,7 +25,9 @@ PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
 PEAK_FP8 = 5000.0  # TFLOP/s dense fp8 MFMA (MX-scaled K = 64 / 128 forms; measured ceiling 4.65 PF, MI355X_MICROARCH.md)
 
 
-def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False, network_type="lora", fp8_mfma=False):
+def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=False, network_type="lora", fp8_mfma=False, attach=True):
+    """attach=False: the bare native model (frozen base, prepared) with no adapter network — what a plug-in's load_model leaves for the
+    reference's trainer to build its own network over (leg `trainer_path`)."""
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
     from ai_toolkit_amd.flux import FluxTransformer2DModel
@@ -38,6 +40,13 @@ def build_flux(dev, rank=16, num_layers=19, num_single=38, ema=True, fp8_base=Fa
             if mod.__class__.__name__ == "Linear":
                 mod.weight.copy_((torch.randn(mod.weight.shape, device=dev, generator=g) * 0.02).to(torch.bfloat16))
     torch.manual_seed(1234)
+    if not attach:
+        for p in model.parameters():
+            p.requires_grad_(False)
+        if fp8_base:
+            model.quantize_base_fp8(release_bf16=True, mfma=fp8_mfma)
+        model.prepare()
+        return model, None, ops
     if network_type == "lokr":  # full Kronecker factors (the reference's lokr_full_rank default), not the headline metric
         net = FusedLoRANetwork(model, lora_dim=9999999999, alpha=9999999999, network_type="lokr")
     else:

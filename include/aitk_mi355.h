@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 8 /* 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 9 /* 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -362,6 +362,13 @@ typedef struct AitkAdamWArgs {
 } AitkAdamWArgs;
 int64_t aitk_adamw_workspace_bytes(int64_t n);
 int aitk_adamw_ema_step(const AitkAdamWArgs* args, aitk_stream_t stream);
+
+/* toolkit/ema.py:126-152 (`ExponentialMovingAverage.update`) over the flat fp32 arenas in one launch, for callers that keep the reference's
+ * call order — `optimizer.step()` (SDTrainer.py:2285) ... `self.ema.update()` (SDTrainer.py:2291-2293) — instead of the fused
+ * aitk_adamw_ema_step: per element tmp = one_minus_decay * (s - p); s -= tmp; p += feedback * tmp (use_feedback: 10, else 0);
+ * p *= param_multiplier (0 is read as 1), each operation rounded on its own like the reference's tensor ops.  p is only written when
+ * feedback / param_multiplier ask for it.  Both pointers 16-byte aligned. */
+int aitk_ema_update(float* p, float* ema, int64_t n, float one_minus_decay, float feedback, float param_multiplier, aitk_stream_t stream);
 
 /* bf16 shadows of every adapter matrix of the fp32 arena (row-major [rows, cols] at src_off), refreshed after each optimizer
  * step.  hi = bf16(w), lo = bf16(w - hi).  Offsets are elements into `shadow`.

@@ -428,12 +428,14 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
         guard[4 if skip else 3] += 1
         step = int(guard[3]) + (1 if skip else 0)
     if not skip:
+        # the tensor ops of torch/optim/adam.py::_single_tensor_adam (decoupled weight decay), in its order — so that a trainer whose
+        # optimizer.step() is served by this entry (ai_toolkit_amd/adopt.py) lands on the bits torch.optim.AdamW produces on the CPU
         p.mul_(1 - lr * weight_decay)
-        m.mul_(beta1).add_(gs, alpha=1 - beta1)
+        m.lerp_(gs, 1 - beta1)
         v.mul_(beta2).addcmul_(gs, gs, value=1 - beta2)
         bc1 = 1 - beta1 ** step
-        bc2s = math.sqrt(1 - beta2 ** step)
-        p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
+        bc2s = (1 - beta2 ** step) ** 0.5
+        p.addcdiv_(m, (v.sqrt() / bc2s).add_(eps), value=-(lr / bc1))
     if ema is not None:  # toolkit/ema.py:135-143
         tmp = (1 - ema_decay) * (ema - p)
         ema.sub_(tmp)
@@ -441,6 +443,17 @@ def adamw_ema_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, max
             p.add_(tmp * ema_feedback)
         if param_multiplier != 1.0:
             p.mul_(param_multiplier)
+
+
+def ema_update(p, ema, *, decay, ema_feedback=0.0, param_multiplier=1.0):
+    """toolkit/ema.py:126-152, the tensor ops of its loop body in their order, over the whole arena"""
+    tmp = ema - p
+    tmp.mul_(1.0 - decay)
+    ema.sub_(tmp)
+    if ema_feedback:
+        p.add_(tmp * ema_feedback)
+    if param_multiplier != 1.0:
+        p.mul_(param_multiplier)
 
 
 def make_shadow_table(entries, device):

@@ -21,6 +21,14 @@ pytestmark = pytest.mark.gpu
 bf = torch.bfloat16
 
 
+@pytest.fixture(autouse=True)
+def _torch_optimizer_tail(monkeypatch):
+    """These tests compare an ADOPTED network with a FusedLoRANetwork twin bit for bit, both stepped by torch.optim.AdamW: the adopted side's
+    optimizer must then run torch's own step too (by default it is served by aitk_adamw_ema_step — a second fp32 formulation of the same
+    update, tests/test_gpu_trainer_path.py — and would differ from the twin in the last bit)."""
+    monkeypatch.setenv("AITK_FUSE_TRAINER_STEP", "0")
+
+
 def _rel(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
 
