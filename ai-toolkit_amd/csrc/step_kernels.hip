@@ -200,13 +200,15 @@ __global__ void mse_finish_kernel(AitkMseArgs p, int nchunk) {
     for (int k = 0; k < p.B; ++k) t += ls[k];
     t /= (float)p.B;
     if (p.guard) {
-      // SDTrainer.py:1049-1050: loss = clamp(loss, max=max_loss) — above the bound the clamp's derivative is 0, nothing flows back;
-      // SDTrainer.py:2221-2224: a non-finite loss is replaced by a fresh zero (no graph): this micro-batch contributes no gradient.
-      // guard[0] counts the gated micro-batches of the current step (the optimizer reads and clears it), [1] / [2] are running totals.
+      // SDTrainer.py:1049-1050: loss = clamp(loss, max=max_loss) — above the bound the clamp's derivative is 0: autograd still runs and
+      //   every parameter receives a ZERO gradient, so the optimizer steps (weight decay, moment decay, step count) on g = 0;
+      // SDTrainer.py:2221-2224: a non-finite loss is replaced by a fresh zero WITHOUT a graph: backward reaches no parameter, .grad stays
+      //   None and torch.optim.AdamW skips the parameters altogether.
+      // Both zero this micro-batch's dpred (guard[6]); only the non-finite kind counts toward the all-gated skip of the optimizer launch:
+      // guard[0] = micro-batches of the current step that left no gradient at all (the optimizer reads and clears it), [1] / [2] running totals.
       int gate = 0;
-      if (!isfinite(t)) { t = 0.f; gate = 1; p.guard[1] += 1; }
+      if (!isfinite(t)) { t = 0.f; gate = 1; p.guard[1] += 1; p.guard[0] += 1; }
       else if (p.max_loss > 0.f && t > p.max_loss) { t = p.max_loss; gate = 1; p.guard[2] += 1; }
-      if (gate) p.guard[0] += 1;
       p.guard[6] = gate;
     }
     p.loss[0] = t;
@@ -237,6 +239,7 @@ extern "C" int aitk_mse_loss_grad(const AitkMseArgs* a, aitk_stream_t stream) {
   hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *a, nchunk);
   AITK_LAUNCH_CHECK();
   if (a->guard) {
+    if (reinterpret_cast<uintptr_t>(a->dpred) & 15) return AITK_ERR_ALIGN;  // the gate clears dpred in 16-byte stores (n_per_sample % 8 == 0 is checked above)
     const long n16 = (long)a->B * a->n_per_sample / 8;
     hipLaunchKernelGGL(mse_gate_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, n16);
     AITK_LAUNCH_CHECK();
@@ -375,6 +378,12 @@ extern "C" int aitk_adamw_ema_step(const AitkAdamWArgs* a, aitk_stream_t stream)
 // extensions_built_in/sd_trainer/SDTrainer.py:2284-2293): toolkit/ema.py:126-152 over the flat arenas in ONE launch instead of its Python loop
 // over every parameter (>= 3 tiny kernels each).  Same arithmetic, same order as the tail of adamw_ema_kernel:
 //   tmp = (1 - d)(s - p); s -= tmp; p += feedback * tmp (use_feedback: 10); p *= param_multiplier.
+// a product that must be ROUNDED before it is added: the file is built with -ffp-contract=fast, under which the backend fuses a multiply into
+// the following add whatever pragma the source carries; an empty asm the value passes through keeps the two instructions apart
+static __device__ __forceinline__ float rounded(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ p, float* __restrict__ ema, long n, float one_minus_decay,
                                                          float feedback, float mult) {
   const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
@@ -389,10 +398,10 @@ __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ p, 
       float* sv = reinterpret_cast<float*>(&s);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float tmp = __fmul_rn(one_minus_decay, __fsub_rn(sv[k], wv[k]));
-        sv[k] = __fsub_rn(sv[k], tmp);
-        if (feedback != 0.f) wv[k] = __fadd_rn(wv[k], __fmul_rn(feedback, tmp));
-        if (mult != 0.f && mult != 1.0f) wv[k] = __fmul_rn(wv[k], mult);
+        const float tmp = rounded(one_minus_decay * (sv[k] - wv[k]));
+        sv[k] = sv[k] - tmp;
+        if (feedback != 0.f) wv[k] = wv[k] + rounded(feedback * tmp);
+        if (mult != 0.f && mult != 1.0f) wv[k] = wv[k] * mult;
       }
       *reinterpret_cast<float4*>(ema + j) = s;
       if (writes_p) *reinterpret_cast<float4*>(p + j) = w;
@@ -400,10 +409,10 @@ __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ p, 
       for (long k = j; k < n && k < j + 4; ++k) {
         float w = p[k];
         const float s = ema[k];
-        const float tmp = __fmul_rn(one_minus_decay, __fsub_rn(s, w));
-        ema[k] = __fsub_rn(s, tmp);
-        if (feedback != 0.f) w = __fadd_rn(w, __fmul_rn(feedback, tmp));
-        if (mult != 0.f && mult != 1.0f) w = __fmul_rn(w, mult);
+        const float tmp = rounded(one_minus_decay * (s - w));
+        ema[k] = s - tmp;
+        if (feedback != 0.f) w = w + rounded(feedback * tmp);
+        if (mult != 0.f && mult != 1.0f) w = w * mult;
         if (writes_p) p[k] = w;
       }
     }

@@ -27,11 +27,15 @@ class _LoRATrainStepBase:
                  nonfinite_guard=True, max_loss=None):
         self.model, self.network, self.ops = model, network, ops
         # Failure handling of the reference's loop, on the device (no host sync; the reference reads loss.item(), we never do):
-        #   * non-finite loss -> the micro-batch contributes no gradient and reports 0 (SDTrainer.py:2221-2224);
-        #   * train.max_loss -> clamp(loss, max=max_loss): above it the gradient is zero (SDTrainer.py:1049-1050);
-        #   * a step whose every micro-batch was gated, or whose gradient arena holds a NaN / Inf (norm not finite), is SKIPPED: p, m, v and
-        #     the AdamW step count stay as they are — what torch.optim.AdamW does when no parameter has a .grad — and one bad batch cannot
-        #     poison the moments, the EMA or the bf16 shadows.  `guard_counters()` reads the tallies back (a host sync, call it rarely).
+        #   * non-finite loss -> the micro-batch contributes no gradient and reports 0 (SDTrainer.py:2221-2224: the replacement has no graph,
+        #     so no parameter receives a .grad);
+        #   * train.max_loss -> clamp(loss, max=max_loss): above it the gradient is ZERO but present (SDTrainer.py:1049-1050: autograd runs
+        #     through the clamp), so the optimizer still steps on g = 0 — weight decay, moment decay, step count — like torch.optim.AdamW does;
+        #   * a step whose every micro-batch had a non-finite loss, or whose gradient arena holds a NaN / Inf (norm not finite), is SKIPPED: p,
+        #     m, v and the AdamW step count stay as they are — what torch.optim.AdamW does when no parameter has a .grad — and one bad batch
+        #     cannot poison the moments, the EMA or the bf16 shadows.  `guard_counters()` reads the tallies back (a host sync, call it rarely).
+        #     Under data parallelism the count of gradient-less micro-batches is summed over the ranks before the decision (one 4-byte
+        #     all-reduce): the gradients every rank applies are the all-reduced ones, so every rank must take the SAME decision.
         self.max_loss = float(max_loss) if max_loss else None
         self.guard = torch.zeros(8, dtype=torch.int32, device=network.arena_p.device) if (nonfinite_guard or self.max_loss) else None
         self._n_micro = 0
@@ -299,7 +303,13 @@ class _LoRATrainStepBase:
             if self.ema_feedback or self.ema_param_multiplier != 1.0:
                 kw = dict(ema_feedback=self.ema_feedback, param_multiplier=self.ema_param_multiplier)
         if self.guard is not None:
-            kw.update(guard=self.guard, n_micro=self._n_micro)
+            n_micro = self._n_micro
+            if self.dp:  # the skip decision must be the same on every rank (they all apply the same averaged gradient): sum the local counts
+                import torch.distributed as dist
+
+                dist.all_reduce(self.guard[0:1], op=dist.ReduceOp.SUM, group=self.pg)
+                n_micro *= self.world
+            kw.update(guard=self.guard, n_micro=n_micro)
             self._n_micro = 0
         ops.adamw_ema_step(net.arena_p, net.arena_g, net.arena_m, net.arena_v, lr=self.lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay, step=self.step_num,

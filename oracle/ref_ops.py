@@ -392,16 +392,16 @@ def mse_loss_grad(pred, target, dpred, loss_per_sample, loss, weight=None, mask=
     dpred.copy_((gr * mk * w[:, None] / (n * B)).reshape(dpred.shape).to(dpred.dtype))
     if guard is not None:  # SDTrainer.py:2221-2224 (non-finite loss -> a fresh zero) and 1049-1050 (clamp(loss, max=max_loss): zero derivative above)
         gate = 0
-        if not bool(torch.isfinite(loss).all()):
+        if not bool(torch.isfinite(loss).all()):  # no graph behind the replacement: no .grad anywhere -> counts toward the skipped step
             loss.zero_()
             gate = 1
             guard[1] += 1
-        elif max_loss and float(loss) > max_loss:
+            guard[0] += 1
+        elif max_loss and float(loss) > max_loss:  # clamp: zero gradients DO arrive, the optimizer steps on them
             loss.fill_(max_loss)
             gate = 1
             guard[2] += 1
         if gate:
-            guard[0] += 1
             dpred.zero_()
         guard[6] = gate
 

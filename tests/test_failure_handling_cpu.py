@@ -84,12 +84,17 @@ def test_max_loss_clamp_reports_the_bound_and_passes_no_gradient():
     hi = FluxLoRATrainStep(nat3, net3, ref_ops, max_loss=10.0 * l_free, **KW)
     assert hi.step(*b[:3], noise=b[3], timesteps=b[4]).item() == l_free
     assert torch.equal(net3.arena_p, net2.arena_p) and torch.equal(net3.arena_ema, net2.arena_ema)
-    # (b) bound below: loss == max_loss, nothing flows back, the step is skipped (its only micro-batch was gated)
+    # (b) bound below: loss == max_loss and the clamp passes ZERO gradients back (not none): the optimizer still steps, like torch.optim.AdamW on
+    # zero .grad tensors — decoupled weight decay p *= 1 - lr * wd, moments stay 0, the step count advances (a clamped step is not skipped)
     p0 = net.arena_p.clone()
     lo = FluxLoRATrainStep(nat, net, ref_ops, max_loss=0.5 * l_free, **KW)
     assert abs(lo.step(*b[:3], noise=b[3], timesteps=b[4]).item() - 0.5 * l_free) < 1e-7
-    assert torch.equal(net.arena_p, p0) and not net.arena_m.any() and not net.arena_v.any() and not net.arena_g.any()
-    assert lo.guard_counters() == {"nonfinite_losses": 0, "clamped_losses": 1, "steps_applied": 0, "steps_skipped": 1, "last_step_skipped": True}
+    assert not net.arena_m.any() and not net.arena_v.any() and not net.arena_g.any()
+    tw = torch.nn.Parameter(p0.clone())
+    tw.grad = torch.zeros_like(tw)
+    torch.optim.AdamW([tw], lr=KW["lr"], eps=KW.get("eps", 1e-6), weight_decay=KW.get("weight_decay", 0.01)).step()
+    assert torch.equal(net.arena_p, tw.detach())
+    assert lo.guard_counters() == {"nonfinite_losses": 0, "clamped_losses": 1, "steps_applied": 1, "steps_skipped": 0, "last_step_skipped": False}
 
 
 def test_gated_micro_batch_of_an_accumulation_list_contributes_nothing_the_others_train():

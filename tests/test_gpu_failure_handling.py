@@ -104,10 +104,14 @@ def test_planted_nan_batch_leaves_the_adapter_state_bit_identical_and_training_c
     l_a = step.step(b2[0], b2[1], b2[2], noise=b2[3], timesteps=b2[4])
     l_b = twin.step(b2[0], b2[1], b2[2], noise=b2[3], timesteps=b2[4])
     assert torch.equal(l_a, l_b) and torch.equal(net.arena_p, net2.arena_p) and torch.equal(net.arena_m, net2.arena_m) and torch.equal(net.arena_v, net2.arena_v)
-    # max_loss on the device: a bound under the loss reports the bound and moves nothing
+    # max_loss on the device: a bound under the loss reports the bound and passes ZERO gradients on — the optimizer still steps on them like
+    # torch.optim.AdamW on zero .grad tensors (decoupled weight decay only: p *= 1 - lr * wd; moments stay 0; the step is counted as applied)
     _, _, nat3, net3 = _build()
     ml = 0.5 * l_b.item()
     capped = FluxLoRATrainStep(nat3, net3, ops, max_loss=ml, **kw)
     p3 = net3.arena_p.clone()
     assert abs(capped.step(b2[0], b2[1], b2[2], noise=b2[3], timesteps=b2[4]).item() - ml) < 1e-6
-    assert torch.equal(net3.arena_p, p3) and capped.guard_counters()["clamped_losses"] == 1
+    want = p3 * (1.0 - kw["lr"] * kw["weight_decay"])
+    assert float((net3.arena_p - want).abs().max()) <= 1e-7 * float(want.abs().max()) and not net3.arena_m.any() and not net3.arena_v.any()
+    c3 = capped.guard_counters()
+    assert c3["clamped_losses"] == 1 and c3["steps_applied"] == 1 and c3["steps_skipped"] == 0

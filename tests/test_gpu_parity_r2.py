@@ -116,8 +116,10 @@ def test_tiny_step_four_way_parity():
           " ".join(f"{k}={v:.3e}" for k, v in e.items()))
     assert e["fp32_self"] <= 1e-4, e  # control: the two backends agree in fp32 (summation order only)
     # THE closing statistic (measured: DESIGN.md section 7, profiles/r05_ref16_self_*.json): the reference's own bf16 arithmetic does not
-    # reproduce itself to north_star's 1e-3 on a second backend — same op sequence, same rounding points, only the kernels differ
-    assert e["ref16_self"] > 1e-3, e
+    # reproduce itself to north_star's 1e-3 on a second backend — same op sequence, same rounding points, only the kernels differ.  It is a
+    # noise floor, printed above and recorded in DESIGN.md, not a correctness property: bounded from ABOVE only (a backend that became more
+    # accurate must not fail this test)
+    assert e["ref16_self"] <= 5e-2, e
     assert abs(lo - l32) <= 1e-3 * abs(l32), (lo, l32)
     assert abs(lo - lrm) <= 1e-3 * abs(lrm), (lo, lrm)
     # the kernels against the same computation with the same rounding points (measured 4.0e-3: flash attention's bf16 P / dS and
