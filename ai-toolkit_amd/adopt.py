@@ -405,15 +405,13 @@ class AdoptedNetwork(FusedLoRANetwork):
     def attach_grad_views(self):
         super().attach_grad_views()
         # a Parameter whose .grad the trainer replaced by its own tensor (not a view of the arena) would swallow the kernels' output
-        for m in self.unet_loras:
-            if m.is_lokr:
-                continue
-            for par, which in ((m.lora_down.weight, "down"), (m.lora_up.weight, "up")):
-                want = self.arena_view(self.arena_g, m, which)
-                if par.grad.data_ptr() != want.data_ptr():
-                    with torch.no_grad():
-                        want.copy_(par.grad.reshape(want.shape))
-                    par.grad = self._shaped_like(par, want)
+        if self.network_type == "lokr":
+            return
+        for par, want, ptr in self._grad_views():
+            if par.grad.data_ptr() != ptr:
+                with torch.no_grad():
+                    want.copy_(par.grad.reshape(want.shape))
+                par.grad = want
 
     # ---- the reference's own object does the I/O: these are here so that code written against FusedLoRANetwork keeps working
     def get_state_dict(self, *a, **k):

@@ -27,6 +27,7 @@ class Linear(nn.Module):
         self.weight_t = None  # [in,out] copy for the data-gradient GEMM (built by prepare())
         self._dgroup = None   # (W^T_cat [in, sum(out)], column offset, ids of the group's Linears) when laid out with its same-input group
         self.qweight = self.qweight_t = self.wscale = None  # weight-only fp8 base (quantize_base_fp8)
+        self._register_load_state_dict_pre_hook(_note_loaded_keys, with_module=True)
         self.register_load_state_dict_post_hook(_linear_weights_loaded)
 
     def forward(self, x):
@@ -45,9 +46,17 @@ class Linear(nn.Module):
         super().__setattr__(name, value)
 
 
+def _note_loaded_keys(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    """load_state_dict pre-hook (it knows the layer's key prefix, the post-hook does not): did THIS layer's weight / bias arrive?  A parent
+    `load_state_dict(strict=False)` that carries nothing for a layer must leave its derived operands — and an fp8-quantised layer — alone."""
+    object.__setattr__(module, "_sd_touched", (prefix + "weight") in state_dict or (prefix + "bias") in state_dict)
+
+
 def _linear_weights_loaded(module, incompatible_keys):
     """`load_state_dict` on a prepared layer (the reference's `merge_in` writes the merged weight back this way, toolkit/network_mixins.py:
     452-462): the transposed copy the data-gradient GEMM reads follows the new weight."""
+    if not module.__dict__.pop("_sd_touched", True):
+        return
     if getattr(module, "qweight", None) is not None:
         raise NotImplementedError("load_state_dict into a weight-only fp8 Linear: merge through FusedLoRANetwork.merge_in (re-quantises), "
                                   "or reload the base model")

@@ -740,19 +740,33 @@ class FusedLoRANetwork(nn.Module):
     def attach_grad_views(self):
         """Every Parameter's .grad is a view of the flat gradient arena; optimizer.zero_grad(set_to_none=True) — what the reference's
         trainer calls after each step (SDTrainer.py:2288) — drops them, so they are re-attached before gradients are written."""
+        for par, view, _ in self._grad_views():
+            if par.grad is None:
+                par.grad = view
+        for m in self.get_all_modules():
+            if m.is_lokr and not m.use_w2:
+                m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
+
+    def _grad_views(self):
+        """[(Parameter, its view of arena_g, the view's address)] — built once per gradient arena: the reference's trainer drops every .grad
+        after every step (zero_grad(set_to_none=True)) and re-attaching 988 views must not cost 988 x (slice, view, slice) of host time on a
+        GPU that the trainer's mid-step `isfinite(loss)` sync has just drained (tools/gpu_trainer_path.py: 10 ms of a 225-ms step at B = 1)."""
+        cache = self.__dict__.get("_grad_view_cache")
+        if cache is not None and cache[0] is self.arena_g:
+            return cache[1]
+        out = []
         for m in self.get_all_modules():
             if m.is_lokr and not m.use_w2:  # low-rank LoKr: the pair a | b shares the `down` slot
                 for par, which in ((m.lokr_w2_a, "w2_a"), (m.lokr_w2_b, "w2_b"), (m.lokr_w1, "up")):
-                    if par.grad is None:
-                        par.grad = self.arena_view(self.arena_g, m, which)
-                m.g_w2a, m.g_w2b = m.lokr_w2_a.grad, m.lokr_w2_b.grad
+                    out.append((par, self.arena_view(self.arena_g, m, which)))
                 continue
-            if m.lora_down.weight.grad is None:
-                m.lora_down.weight.grad = self._shaped_like(m.lora_down.weight, self.arena_view(self.arena_g, m, "down"))
-            if m.lora_up.weight.grad is None:
-                m.lora_up.weight.grad = self._shaped_like(m.lora_up.weight, self.arena_view(self.arena_g, m, "up"))
-            if m.magnitude is not None and m.magnitude.grad is None:
-                m.magnitude.grad = m.g_mag
+            out.append((m.lora_down.weight, self._shaped_like(m.lora_down.weight, self.arena_view(self.arena_g, m, "down"))))
+            out.append((m.lora_up.weight, self._shaped_like(m.lora_up.weight, self.arena_view(self.arena_g, m, "up"))))
+            if m.magnitude is not None:
+                out.append((m.magnitude, m.g_mag))
+        out = [(par, v, v.data_ptr()) for par, v in out]
+        self.__dict__["_grad_view_cache"] = (self.arena_g, out)
+        return out
 
     def grads_dropped(self):
         """True when optimizer.zero_grad(set_to_none=True) removed the .grad views (any adapter type: asks the first trainable

@@ -561,12 +561,9 @@ class Flux1MI355Model(_PluginBase):
         text, pooled = _embeds(text_embeddings)
         with torch.no_grad():
             packed = latent_model_input.reshape(bs, c, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(bs, (h // 2) * (w // 2), c * 4)
-            img_ids = torch.zeros(h // 2, w // 2, 3)
-            img_ids[..., 1] = img_ids[..., 1] + torch.arange(h // 2)[:, None]
-            img_ids[..., 2] = img_ids[..., 2] + torch.arange(w // 2)[None, :]
-            img_ids = img_ids.reshape(-1, 3).to(dev)
-            img_ids._aitk_grid = (h // 2, w // 2, text.shape[1])
-            txt_ids = torch.zeros(text.shape[1], 3, device=dev)
+            from .trainer import make_ids
+
+            img_ids, txt_ids = make_ids(h, w, text.shape[1], dev)  # (0, row, col) ids of the 2x2-packed grid, cached per bucket (no host-to-device copy per step)
             if bypass_guidance_embedding:  # toolkit/models/flux.py:9-35: the guidance embedder is skipped for this call
                 guidance = None
             elif isinstance(guidance_embedding_scale, list):

@@ -79,6 +79,13 @@ class Conv3x3(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout, dtype=dtype, device=device), requires_grad=False)
         self.wk = self.wd = self.bias_k = None
         object.__setattr__(self, "lora", None)  # set by LoRAModule.apply_to when network.conv wraps 3x3 convolutions
+        # load_state_dict on a prepared layer (the reference's merge_in / merge_out of a network.conv adapter writes the merged filter back
+        # through org_module.load_state_dict, toolkit/network_mixins.py:452-462; a whole-model load after prepare() does the same): the
+        # implicit-GEMM operands wk / wd / bias_k are rebuilt from the new weight, like graph.Linear refreshes its transposed copy
+        from .graph import _note_loaded_keys
+
+        self._register_load_state_dict_pre_hook(_note_loaded_keys, with_module=True)
+        self.register_load_state_dict_post_hook(_conv3x3_weights_loaded)
 
     @torch.no_grad()
     def prepare(self, need_dgrad=True):
@@ -103,6 +110,12 @@ class Conv3x3(nn.Module):
             register_foreign_adapter(self, value)
             return
         super().__setattr__(name, value)
+
+
+def _conv3x3_weights_loaded(module, incompatible_keys):
+    if not module.__dict__.pop("_sd_touched", True) or module.wk is None:
+        return
+    module.prepare(need_dgrad=module.wd is not None)
 
 
 # The reference's adapter discovery goes by CLASS NAME: a child is wrapped when `child.__class__.__name__` is in LINEAR_MODULES / CONV_MODULES
