@@ -310,13 +310,17 @@ __global__ void adamw_decide_kernel(AitkAdamWArgs p, int n2, float* ctl) {
   ctl[1] = skip ? 1.0f : 0.0f;
   ctl[2] = bc1;
   ctl[3] = bc2s;
+  // 1 - beta as torch forms it: in double from the Python float, THEN rounded to fp32 (lerp weight / addcmul value).  1.0f - 0.999f is
+  // 1.29e-5 off that value — a systematic scale on v, i.e. 6.5e-6 on every update (tools/gpu_trainer_fusion_diag.py, round 6)
+  ctl[4] = p.beta1_d != 0.0 ? (float)(1.0 - p.beta1_d) : 1.0f - p.beta1;
+  ctl[5] = p.beta2_d != 0.0 ? (float)(1.0 - p.beta2_d) : 1.0f - p.beta2;
   if (p.norm_out) p.norm_out[0] = norm;
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, const float* ctl) {
   const float coef = ctl[0];
   const bool skip = ctl[1] != 0.f;
-  const float bc1 = ctl[2], bc2s = ctl[3];
+  const float bc1 = ctl[2], bc2s = ctl[3], omb1 = ctl[4], omb2 = ctl[5];
   const long base = (long)blockIdx.x * OPT_BLOCK_ELEMS;
 #pragma unroll
   for (int i = 0; i < OPT_BLOCK_ELEMS / 256; ++i) {
@@ -326,8 +330,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AitkAdamWArgs p, const f
       if (!skip) {
         const float g = p.g[j] * coef;
         w -= p.lr * p.weight_decay * w;
-        const float m = p.beta1 * p.m[j] + (1.0f - p.beta1) * g;
-        const float v = p.beta2 * p.v[j] + (1.0f - p.beta2) * g * g;
+        const float m = p.beta1 * p.m[j] + omb1 * g;
+        const float v = p.beta2 * p.v[j] + omb2 * g * g;
         const float denom = sqrtf(v) / bc2s + p.eps;
         w -= (p.lr / bc1) * (m / denom);
         p.m[j] = m;

@@ -39,6 +39,9 @@ def _gemm_shape(ref):
     return (g.M, g.N, g.K, g.K2, g.flags)
 
 
+_attn_hook = None  # bench.py: fn(name, e0, e1, flops, (B, H, S, Skv, Dv)) with events around every aitk_attn_fwd / aitk_attn_bwd call
+
+
 def _emit(name, args):
     if name == "_keepalive":
         return
@@ -46,7 +49,8 @@ def _emit(name, args):
         args[0]()
         return
     timed = _gemm_hook is not None and name in ("aitk_gemm_nt", "aitk_gemm_nt_grouped")
-    if timed:
+    timed_attn = _attn_hook is not None and name in ("aitk_attn_fwd", "aitk_attn_bwd")
+    if timed or timed_attn:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _capi.check(getattr(_capi.lib(), name)(*args, _capi.stream_ptr()), name)
@@ -54,6 +58,13 @@ def _emit(name, args):
         e1.record()
         shapes = tuple(_gemm_shape(a) for a in args)
         _gemm_hook(e0, e1, sum(2.0 * m * n * (k + k2) for m, n, k, k2, _ in shapes), shapes if len(shapes) > 1 else shapes[0])
+    elif timed_attn:
+        e1.record()
+        a = args[0]._obj
+        skv, dv = a.Skv or a.S, a.Dv or 128
+        # algorithmic matmuls of 2 S Skv Dv flop per (batch, head): forward 2 (Q K^T, P V), backward 4 (dV, dP, dK, dQ; the recomputation
+        # of S the flash form needs is not algorithmic work — BASELINE.md section 3: 14.9 + 29.7 TFLOP per FLUX image)
+        _attn_hook(name, e0, e1, (2 if name == "aitk_attn_fwd" else 4) * 2.0 * a.B * a.H * a.S * skv * dv, (a.B, a.H, a.S, skv, dv))
 
 
 def _call(name, *args):

@@ -224,6 +224,33 @@ def gemm_roofline(step_fn, ops_mod):
             "tflops": fl / ms / 1e9 if ms > 0 else 0.0, "census": census}
 
 
+def attention_roofline(step_fn, ops_mod, peak=PEAK_BF16):
+    """One extra instrumented step: HIP events around every aitk_attn_fwd / aitk_attn_bwd call (the step's second kernel family, 35 % of the
+    headline step); algorithmic FLOPs = 2 (forward) / 4 (backward) matmuls of 2 S Skv d per (batch, head).  aitk_attn_bwd's time covers its
+    three kernels (delta, dK/dV, dQ)."""
+    recs = []
+    ops_mod._attn_hook = lambda name, e0, e1, fl, shape: recs.append((name, e0, e1, fl, shape))
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops_mod._attn_hook = None
+    out = {}
+    for which in ("aitk_attn_fwd", "aitk_attn_bwd"):
+        sel = [r for r in recs if r[0] == which]
+        ms = sum(r[1].elapsed_time(r[2]) for r in sel)
+        fl = sum(r[3] for r in sel)
+        if sel and ms > 0:
+            out[which] = {"calls": len(sel), "ms_per_step": ms, "achieved": fl / ms / 1e9, "frac": fl / ms / 1e9 / peak,
+                          "shape_BHSSkvD": list(sel[0][4])}
+    ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+    fl = sum(r[3] for r in recs)
+    out.update({"bound": "mfma", "kernel": "aitk_attn_fwd (attn_fwd_kernel) + aitk_attn_bwd (attn_delta_kernel, attn_bwd_dkdv_ws_kernel, attn_bwd_dq_kernel), all calls of one step",
+                "achieved": fl / ms / 1e9 if ms > 0 else 0.0, "peak": peak, "unit": "TFLOP/s", "frac": (fl / ms / 1e9 / peak) if ms > 0 else 0.0,
+                "attn_ms_per_step": ms, "note": "algorithmic flops (2 fwd + 4 bwd matmuls; the backward executes 7: S and dP are recomputed in both of its passes)"})
+    return out
+
+
 def cpu_baseline():
     """Oracle ('port') timed on this host's cores on a bounded sample: 1 double + 1 single FLUX.1-dev block at full
     width / full sequence (B=1, fp32), fwd + bwd + AdamW; extrapolated linearly to 19 + 38 blocks."""
@@ -254,6 +281,22 @@ def cpu_baseline():
 
 
 BUCKETS = [(1024, 1024), (832, 1216), (1216, 832), (896, 1152), (1152, 896)]  # BASELINE.md §2 bucket mix (W x H pixels)
+
+
+def _pmc_summaries():
+    """Committed rocprofv3 --pmc summaries under profiles/, newest round first: r<NN>_pmc_summary.json (rounds 5+, tools/pmc_round_summary.py)
+    and r<NN>_pmc*/summary.json (rounds 1-4)."""
+    import glob
+    import re
+
+    found = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc*summary*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc*", "summary.json"))
+
+    def key(path):
+        rel = os.path.relpath(path, os.path.join(ROOT, "profiles"))
+        m = re.match(r"r(\d\d)", rel)
+        return (int(m.group(1)) if m else 0, os.path.getmtime(path), rel)
+
+    return sorted(set(found), key=key, reverse=True)
 
 
 def _pct(xs, q):
@@ -980,6 +1023,7 @@ def main():
         rf = tmp["roofline"] if "error" not in tmp["roofline"] else None
         if rf is None:
             out["roofline"] = tmp["roofline"]
+        _run_leg(out, failed_legs, "roofline_attention", lambda: attention_roofline(one, ops, PEAK_BF16))
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
     out["config"]["peak_mem_GiB"] = round(peak_mem, 1)
     if not args.no_dvfs:
@@ -1104,11 +1148,7 @@ def main():
                 out["roofline"]["frac_at_step_clock"] = out["roofline"]["achieved"] / (out["roofline"]["peak"] * clk / 2400.0)
             # memory-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) for the dominant shape (B * 4608) x 3072 x 3072 (+ LoRA slab): newest round first
-            for pmc in (os.path.join(ROOT, "profiles", "r04_pmc", "summary.json"), os.path.join(ROOT, "profiles", "r03_pmc", "summary.json"),
-                        os.path.join(ROOT, "profiles", "r02_pmc", "summary.json"),
-                        os.path.join(ROOT, "profiles", "r01_pmc_v2", "summary.json")):
-                if not os.path.exists(pmc):
-                    continue
+            for pmc in _pmc_summaries():
                 by_m = json.load(open(pmc)).get("gemm_nt_8phase_f8_kernel_by_M" if args.fp8_mfma else "gemm_nt_8phase_kernel_by_M", {})
                 g8 = by_m.get(str(B * 4608))  # the most frequent launch of a step
                 if g8 is not None:
@@ -1121,6 +1161,30 @@ def main():
         del step, model, net, one
         import gc
 
+        gc.collect()
+        torch.cuda.empty_cache()
+        # ---- the step the REFERENCE'S TRAINER runs over the plug-in: SDTrainer.hook_train_loop's sequence over an ADOPTED
+        # network on a fresh bare model — get_noise_prediction through the autograd bridge, torch MSE + the mid-step isfinite sync,
+        # loss.backward(), clip_grad_norm_, torch.optim.AdamW(eps=1e-6).step(), zero_grad(set_to_none=True), ema.update(), loss.item() —
+        # timed at B = 1 (the reference's default batch size) and at the headline's B, with the optimizer / EMA served by the arena kernels
+        # (`trainer_path`, the default of ai_toolkit_amd/adopt.py) and left to torch's foreach AdamW + the EMA class's Python loop
+        # (`trainer_path_torch`), beside this run's fused-step numbers for the same batch sizes
+        def leg_trainer_path():
+            from tools.gpu_trainer_path import run_trainer_path
+
+            res = run_trainer_path(dev, sorted({1, B}), steps=3, warm=2, rank=args.rank, log=lambda *_: None)
+            fused = {str(B): 1e3 * dt / args.steps, **{k: v["ms_per_step"] for k, v in (out.get("batch_sweep") or {}).items() if isinstance(v, dict) and "ms_per_step" in v}}
+            for b2 in sorted({1, B}):
+                ent = res.get(str(b2))
+                if ent and str(b2) in fused:
+                    ent["fused_step_ms"] = fused[str(b2)]
+                    ent["gap_vs_fused_step"] = {k: v["ms_per_step"] / fused[str(b2)] - 1.0 for k, v in ent.items() if isinstance(v, dict) and "ms_per_step" in v}
+            res["note"] = ("tools/trainer_harness.TrainerLoop.hook_train_loop = extensions_built_in/sd_trainer/SDTrainer.py:2243-2318 over an adopted network "
+                           "(stand-in trainer-side objects with the reference's protocol; every kernel of the step is the HIP library's or one of the torch ops the "
+                           "reference's loop issues itself); 3 timed steps after 2, host clock around the loop (it syncs every step like the reference: loss.item())")
+            return res
+
+        _run_leg(out, failed_legs, "trainer_path", leg_trainer_path)
         gc.collect()
         torch.cuda.empty_cache()
         _run_leg(out, failed_legs, "gpu_comparator", lambda: gpu_comparator(dev, args.rank))
