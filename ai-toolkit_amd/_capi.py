@@ -133,6 +133,7 @@ class AttnArgs(C.Structure):
         ("dQ", vp), ("dK", vp), ("dV", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
         ("delta", vp),
         ("scale", C.c_float), ("B", i32), ("H", i32), ("S", i32), ("D", i32), ("Skv", i32), ("Dv", i32), ("hstride", i32),
+        ("dS", vp), ("ds_mode", i32), ("_pad_ds", i32),
     ]
 
 

@@ -830,7 +830,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_pipe_kernel(AitkAttnArgs p)
 #define DKDV_WS_LDS (DKDV_WS_SOFF + DKDV_WS_NSLOT * 512)
 // TRACE: workgroup 0 records s_memtime around every barrier of tiles 8-11 for one producer and one consumer wave (aitk_probe_attn_ws_trace)
 __device__ unsigned long long g_ws_trace[2 * 4 * 8];
-template <bool TRACE>
+// DS (AitkAttnArgs.ds_mode): 0 = off; 1 = the producer waves also write the packed dS they hand to the consumers to global memory, their two
+// operand vectors as they are: 2 KiB per wave and sub-tile in two coalesced non-temporal 16-byte stores per lane — the probe of the 5-matmul
+// backward (dQ = dS K as its own product).  (A row-major [q][kv] form — sixteen 2-byte stores per lane, what a plain GEMM would read — was
+// tried and dropped: it cannot be addressed without spilling 56-116 registers into the hand-scheduled loop.)
+template <bool TRACE, int DS>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   lds_char* const sm = (lds_char*)smem;
@@ -930,6 +934,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
     s16x8_t qa[8], da[8];    // row fragments of ONE sub-tile (AccVGPRs), fetched half a step ahead of their products
     f32x4_t lst[4], dst[4];  // statistics of the sub-tile whose arithmetic runs in the coming H2 (read at the end of H1)
     lds_char* const xw = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
+    // DS: this lane's first destination element: block (kv block of 32 = 4 tile_x + w, q block SUB) of 1024 elements, lane-linear
+    bf16_t* ds_base = nullptr;
+    if (DS == 1) {
+      const long nq32 = (S + 31) / 32, nkv32 = (Skv + 31) / 32;
+      ds_base = p.dS + (((long)b * p.H + hd) * nkv32 + (tile_x * 4 + w)) * nq32 * 1024 + lane * 8;
+    }
     // frag_rm_st's address = tile + ks * SUBP + row * 32 + ((h ^ ((row >> 3) & 1)) << 4): the lane part is the same for rows l31 and 32 + l31
     const unsigned ln_rm = (unsigned)(l31 * 32 + ((h ^ ((l31 >> 3) & 1)) << 4));
 #define DKDV_WS_FRAG1(RH, KS)                                                                                                       \
@@ -993,16 +1003,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
     }                                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                                              \
   }
-    // H2: the rest of the arithmetic of register set SET (dS = p * dd), packed operands into the pair's slot
-#define DKDV_WS_SOFTMAX(SET)                                                                                                        \
+    // H2: the rest of the arithmetic of register set SET (dS = p * dd), packed operands into the pair's slot; SUB = index of the 32-row
+    // query sub-tile these are the products of (DS: where its dS block goes)
+#define DKDV_WS_SOFTMAX(SET, SUB)                                                                                                   \
   {                                                                                                                                 \
     _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                                  \
       asm volatile("v_mul_f32 %0, %1, %2" : "=v"(dpA[SET][r]) : "v"(dpA[SET][r]), "v"(sA[SET][r]));                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                              \
     *reinterpret_cast<lds_s16x8*>(xw) = pack_acc8(sA[SET], 0);                                                                      \
     *reinterpret_cast<lds_s16x8*>(xw + 1024) = pack_acc8(sA[SET], 8);                                                               \
-    *reinterpret_cast<lds_s16x8*>(xw + 2048) = pack_acc8(dpA[SET], 0);                                                              \
-    *reinterpret_cast<lds_s16x8*>(xw + 3072) = pack_acc8(dpA[SET], 8);                                                              \
+    const s16x8_t ds_lo = pack_acc8(dpA[SET], 0), ds_hi = pack_acc8(dpA[SET], 8);                                                   \
+    *reinterpret_cast<lds_s16x8*>(xw + 2048) = ds_lo;                                                                               \
+    *reinterpret_cast<lds_s16x8*>(xw + 3072) = ds_hi;                                                                               \
+    if (DS == 1) {                                                                                                                  \
+      s16x8_t* dst = reinterpret_cast<s16x8_t*>(ds_base + (long)(SUB) * 1024);                                                      \
+      __builtin_nontemporal_store(ds_lo, dst);                                                                                      \
+      __builtin_nontemporal_store(ds_hi, dst + 64);                                                                                 \
+    }                                                                                                                               \
   }
     // prologue: S / dP of sub-tile 0 + its statistics, fragments of sub-tile 1
     DKDV_WS_FRAGS(0, sm)
@@ -1017,7 +1034,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       DKDV_WS_BAR(t)
       // H2: dS of sub-tile 2t, hand-over; fragments of sub-tile 2t + 2 = rows 0-31 of tile t + 1
       DKDV_WS_FRAGS(0, tn1)  // issued first: they return under the arithmetic (the barrier's lgkmcnt(0) waits for every LDS operation of the wave)
-      DKDV_WS_SOFTMAX(0)
+      DKDV_WS_SOFTMAX(0, 2 * t)
       DKDV_WS_BAR(t)
       // ---- step 2t + 1.  H1: products of sub-tile 2t + 2 -> set 0 (past the last tile: zeros, never read); pieces 0-1 of tile t + 3;
       //      statistics of sub-tile 2t + 1
@@ -1025,7 +1042,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       DKDV_WS_BAR(t)
       // H2: dS of sub-tile 2t + 1, hand-over; fragments of sub-tile 2t + 3 = rows 32-63 of tile t + 1
       DKDV_WS_FRAGS(1, tn1)
-      DKDV_WS_SOFTMAX(1)
+      DKDV_WS_SOFTMAX(1, 2 * t + 1)
       DKDV_WS_BAR(t)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DKDV_WS_PIN8A(qa), DKDV_WS_PIN8A(da));  // the last (unused) fetches retire before the wave ends
@@ -1348,13 +1365,16 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
   if (KS == 8 && DB == 4 && dkdv_ws_enabled()) {
     static bool wattr = false;
     if (!wattr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
       wattr = true;
     }
-    if (dkdv_ws_mode() == 2) hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<true>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
-    else hipLaunchKernelGGL(attn_bwd_dkdv_ws_kernel<false>, grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    const int dsm = (a->dS && (a->S % 64) == 0 && (Skv % 128) == 0) ? a->ds_mode : 0;  // the probe modes cover whole tiles only
+    if (dkdv_ws_mode() == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<true, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else if (dsm == 1) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 1>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     launch_dq<KS, DB>(a, grid, s);
     return;
   }

@@ -1004,10 +1004,18 @@ class FusedLoRANetwork(nn.Module):
         if self.network_type.lower() == "lokr":  # toolkit/models/lokr.py:261-309: W += kron(w1, w2) * scale * merge_weight
             for m in self.get_all_modules():
                 lin = m.org_module[0]
-                if getattr(lin, "qweight", None) is not None:
-                    raise NotImplementedError("LoKr merge into a weight-only fp8 base is not on the fused path")
                 a = float(merge_weight) * m.scale
                 w2 = m.composed_w2()
+                if getattr(lin, "qweight", None) is not None:
+                    # weight-only fp8 base: dequantise, add kron(w1, w2) * scale * merge_weight, re-quantise with a fresh per-channel scale —
+                    # what the reference does for any quantised org_module (toolkit/models/lokr.py:261-309 ends in the same
+                    # load_state_dict + requantise as LoRA's merge, toolkit/network_mixins.py:452-459); the model stays quantised
+                    from .graph import quantize_linear_fp8
+
+                    w = (lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]).to(self.shadow_dtype).contiguous()
+                    ops.kron_merge(w, m.lokr_w1.data.contiguous(), w2.contiguous(), a)
+                    quantize_linear_fp8(lin, w)
+                    continue
                 ops.kron_merge(lin.weight.data, m.lokr_w1.data.contiguous(), w2.contiguous(), a)
                 if getattr(lin, "weight_t", None) is not None:
                     ops.kron_merge(lin.weight_t, m.lokr_w1.data.t().contiguous(), w2.t().contiguous(), a)

@@ -552,8 +552,13 @@ def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0, hstride=0):
     return o
 
 
-def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0, hstride=0):
+def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0, hstride=0, ds=None, ds_mode=0):
+    """ds / ds_mode: probe of the 5-matmul backward — the dK/dV pass also writes its bf16 dS (AitkAttnArgs.dS; ds_mode 1 = accumulator-native
+    2-KiB blocks)."""
     a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dvalid, hstride)
+    if ds is not None and ds_mode:
+        assert ds.dtype == BF16 and ds.is_contiguous() and ds.numel() >= B * H * ((S + 31) // 32 * 32) * (((Skv or S) + 31) // 32 * 32)
+        a.dS, a.ds_mode = _ptr(ds), int(ds_mode)
     a.dO, a.lddo = _ptr(do), _row_major(do, "do")
     a.dQ, a.dK, a.dV = _ptr(dq), _ptr(dk), _ptr(dv)
     a.lddq, a.lddk, a.lddv = _row_major(dq, "dq"), _row_major(dk, "dk"), _row_major(dv, "dv")

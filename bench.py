@@ -630,11 +630,21 @@ def secondary_configs(dev, steps=3):
 
     out = {}
 
-    def timed(fn, B):
+    def timed(fn, B, ops=None, peak=PEAK_BF16, flop_per_unit=None):
         fn()
         dt, _, _ = timed_steps(fn, steps, torch.cuda.synchronize)
-        return {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "per_gpu_batch": B, "steps": steps,
-                "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        r = {"value": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "per_gpu_batch": B, "steps": steps,
+             "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        if ops is not None:  # one more, instrumented step: the GEMM (+ implicit-GEMM convolution) launches against the MFMA peak of their operand type
+            try:
+                rf = gemm_roofline(fn, ops)
+                r["roofline"] = {"bound": "mfma", "kernel": "aitk_gemm_nt / aitk_gemm_nt_grouped, all launches of one step", "achieved": rf["tflops"], "peak": peak,
+                                 "unit": "TFLOP/s", "frac": rf["tflops"] / peak, "gemm_ms_per_step": rf["gemm_ms_per_step"], "launches_per_step": rf["launches"]}
+            except Exception as ex:  # noqa: BLE001
+                r["roofline"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        if flop_per_unit:
+            r["step_frac_of_bf16_peak"] = flop_per_unit * r["value"] / (PEAK_BF16 * 1e12)
+        return r
 
     def unet(kind):
         model, net, ops = build_unet(dev, kind, rank=8 if kind == "sdxl" else 4)
@@ -644,7 +654,7 @@ def secondary_configs(dev, steps=3):
         lat = torch.randn(B, 4, side, side, device=dev, generator=gen).to(torch.bfloat16)
         ctx = (torch.randn(B, 77, model.config["cross_attention_dim"], device=dev, generator=gen) * 0.5).to(torch.bfloat16)
         pooled = (torch.randn(B, 1280, device=dev, generator=gen) * 0.5).to(torch.bfloat16) if kind == "sdxl" else None
-        r = timed(lambda: st.step(lat, ctx, pooled), B)
+        r = timed(lambda: st.step(lat, ctx, pooled), B, ops)
         r.update(unit="images/s", workload="SDXL UNet LoRA r8 @1024^2 (config 2)" if kind == "sdxl" else "SD1.5 UNet LoRA r4 @512^2 (config 1 architecture)")
         return r
 
@@ -654,7 +664,7 @@ def secondary_configs(dev, steps=3):
         B = 4
         lat = torch.randn(B, 16, 13, 64, 64, device=dev).to(torch.bfloat16)
         txt = (torch.randn(B, 512, 4096, device=dev) * 0.3).to(torch.bfloat16)
-        r = timed(lambda: st.step(lat, txt), B)
+        r = timed(lambda: st.step(lat, txt), B, ops)
         r.update(unit="videos/s", workload="Wan2.1-T2V-1.3B LoRA r16, 49 x 512 x 512 clip = 13 x 64 x 64 latents, 13 312 tokens (config 4, per-GPU shape)")
         return r
 
@@ -663,12 +673,25 @@ def secondary_configs(dev, steps=3):
         st = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, timestep_type="linear", seed=1000)
         B = 7 if (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30 >= 232 else 4
         lat, emb, pooled = make_batch(dev, B, seed=42)
-        r = timed(lambda: st.step(lat, emb, pooled), B)
+        r = timed(lambda: st.step(lat, emb, pooled), B, ops, PEAK_FP8, FLOP_PER_IMAGE)
         r.update(unit="images/s", workload="FLUX.1-dev LoRA r32 on the fp8 e4m3 base, W8A8 on v_mfma_scale_f32_32x32x64_f8f6f4 (config 5; opt-in mode: "
                                            "per-token e4m3 activations are not the reference's weight-only arithmetic)")
         return r
 
-    for name, fn in (("config2_sdxl", lambda: unet("sdxl")), ("config1_sd15", lambda: unet("sd15")), ("config4_wan21", wan), ("config5_flux_fp8_w8a8", flux_w8a8)):
+    def flux_fp8_weight_only():
+        """BASELINE config 5 in the REFERENCE'S arithmetic (toolkit/util/quantize.py:43-75 -> optimum-quanto qfloat8 weights, bf16 activations):
+        e4m3 weights with a per-output-channel scale, expanded to bf16 on the way to LDS, bf16 MFMA, bf16 / fp32 rank-32 adapter"""
+        model, net, ops = build_flux(dev, rank=32, fp8_base=True, fp8_mfma=False)
+        st = FluxLoRATrainStep(model, net, ops, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99, timestep_type="linear", seed=1000)
+        B = 7 if (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30 >= 232 else 4
+        lat, emb, pooled = make_batch(dev, B, seed=42)
+        r = timed(lambda: st.step(lat, emb, pooled), B, ops, PEAK_BF16, FLOP_PER_IMAGE)
+        r.update(unit="images/s", workload="FLUX.1-dev LoRA r32 over the weight-only fp8 e4m3 base (config 5 as the reference computes it: "
+                                           "weights dequantised to bf16 inside the GEMM's staging, bf16 MFMA, bf16 activations)")
+        return r
+
+    for name, fn in (("config2_sdxl", lambda: unet("sdxl")), ("config1_sd15", lambda: unet("sd15")), ("config4_wan21", wan),
+                     ("config5_flux_fp8_weight_only", flux_fp8_weight_only), ("config5_flux_fp8_w8a8", flux_w8a8)):
         torch.cuda.reset_peak_memory_stats()
         _run_leg(out, [], name, fn)
         gc.collect()

@@ -283,6 +283,13 @@ typedef struct AitkAttnArgs {
                       all-zero contraction steps and output blocks are skipped, the padded output columns are written as zeros.
                       hstride (0 = 128): elements between consecutive heads.  hstride == Dv in {64, 96} reads / writes the heads where
                       the projections put them ([B, S, H*Dv] — SDXL's 64-wide heads), no padded copies; other widths must be padded */
+  /* ABI 9, probe of the 5-matmul backward (dQ = dS K as a product of its own instead of recomputing S and dP in a second pass): with
+   * ds_mode != 0 the wave-specialised dK/dV kernel (head_dim 128) also writes the bf16 dS it forms for its own dK product to `dS`:
+   *   1 = accumulator-native blocks: [b][h][kv block of 32][q block of 32] x 2 KiB, each block = the producer wave's two packed operand
+   *       vectors as they sit in registers ([vector 2][lane 64][8 bf16]: lane = kv row, slot e of vector v = q row 16 v + 8 (e >> 2) +
+   *       4 (lane >> 5) + (e & 3)), written with two coalesced 16-byte non-temporal stores per lane (S % 64 == 0, Skv % 128 == 0).
+   * dQ is still produced by the recomputing kernel: the mode exists to MEASURE what emitting dS costs the dK/dV pass. */
+  aitk_bf16* dS; int32_t ds_mode; int32_t _pad_ds;
 } AitkAttnArgs;
 int aitk_attn_fwd(const AitkAttnArgs* args, aitk_stream_t stream);
 int aitk_attn_bwd(const AitkAttnArgs* args, aitk_stream_t stream);

@@ -118,14 +118,18 @@ def test_three_training_steps_track_oracle():
     from oracle import train_ref
 
     ref, ref_net, nat, net = _build()
+    ref_b, ref_net_b, _, _ = _build()  # a second oracle pair: the reference arithmetic in bf16 (adapter fp32), the yardstick of the bound below
+    ref_b.to(torch.bfloat16)
     kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.99)
     oracle = train_ref.RefTrainStep(ref, ref_net, **kw)
+    oracle16 = train_ref.RefTrainStep(ref_b, ref_net_b, **kw)
     ours = FluxLoRATrainStep(nat, net, ops, **kw)
     p_init = net.arena_p.clone()
     ref_init = [p.detach().clone() for p in oracle.params]
     for k in range(3):
         lat, emb, pooled, noise, ts = _batch(2, seed=10 + k)
         l32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+        oracle16.step(lat, emb, pooled, noise, ts, dtype=torch.bfloat16)
         l = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
         assert abs(l - l32) <= 2e-3 * abs(l32), (k, l, l32)
     # LoRA deltas: direction agreement with the fp32 oracle (AdamW steps are ~lr*sign(g): compare delta vectors)
@@ -139,12 +143,13 @@ def test_three_training_steps_track_oracle():
         num += ((d_ours - d_ref) ** 2).sum().item()
         den += (d_ref ** 2).sum().item()
     rel = math.sqrt(num / den)
-    print("LoRA parameter-delta rel err after 3 AdamW steps (vs fp32 oracle):", rel)
-    # The bound on LoRA deltas is stated and asserted in tests/test_gpu_parity_r2.py::test_three_adamw_steps_lora_delta_four_way
-    # (effective dW = B'A' - BA against the fp32 oracle, the reference's bf16 arithmetic and the rounding-matched oracle); here
-    # only the sanity envelope of the raw parameter deltas: AdamW's first steps are ~lr*sign(g), so entries whose gradient is
-    # below the bf16 noise flip sign in any bf16 implementation (the reference's own arithmetic measures the same).
-    assert rel < 0.08, rel
+    num16 = sum((((p16.detach() - p0) - (p32.detach() - p0)) ** 2).sum().item() for p16, p32, p0 in zip(oracle16.params, oracle.params, ref_init))
+    rel16 = math.sqrt(num16 / den)
+    print(f"LoRA parameter-delta rel err after 3 AdamW steps vs the fp32 oracle: ours {rel:.4e}, the reference's bf16 arithmetic {rel16:.4e}")
+    # AdamW's first steps are ~lr*sign(g): entries whose gradient is below the bf16 noise flip sign in ANY bf16 execution, the reference's own
+    # included — so the bound is the reference arithmetic's own distance from fp32 on the same three batches, not an absolute number
+    # (the effective-dW form of this statistic: tests/test_gpu_parity_r2.py::test_three_adamw_steps_lora_delta_four_way)
+    assert rel <= 1.25 * rel16 + 2e-3, (rel, rel16)
     assert net.arena_ema is not None and torch.isfinite(net.arena_ema).all()
 
 
@@ -167,10 +172,17 @@ def test_ragged_bucket_shapes_match_oracle(hw):
     assert abs(loss - loss32) <= 1.5e-3 * abs(loss32), (loss, loss32)
     mine = []
     for m in net.unet_loras:
-        mine += [m.lora_down.weight.grad, m.lora_up.weight.grad]
-    num = sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32))
+        mine += [m.lora_down.weight.grad.clone(), m.lora_up.weight.grad.clone()]
+    # the yardstick: the reference arithmetic in bf16 on the same ragged batch (adapter fp32), against the same fp32 gradients
+    ref.to(torch.bfloat16)
+    oracle.step(lat, emb, pooled, noise, ts, dtype=torch.bfloat16)
+    g16 = [p.grad.clone() for p in oracle.params]
+    ref.float()
     den = sum((b ** 2).sum().item() for b in g32)
-    assert math.sqrt(num / den) < 2e-2, math.sqrt(num / den)
+    e_ours = math.sqrt(sum(((a - b) ** 2).sum().item() for a, b in zip(mine, g32)) / den)
+    e_ref16 = math.sqrt(sum(((a - b) ** 2).sum().item() for a, b in zip(g16, g32)) / den)
+    print(f"ragged bucket {hw}: adapter-gradient rel err vs fp32: ours {e_ours:.4e}, reference bf16 arithmetic {e_ref16:.4e}")
+    assert e_ours <= 1.25 * e_ref16 + 1e-3, (e_ours, e_ref16)
 
 
 def test_batch_list_accumulation_and_preservation_pass_on_device():

@@ -244,3 +244,36 @@ def test_lokr_factor_modes_token_two_stage_and_refusal():
     m = lora_ref.RefLokrModule("lokr_huge", huge, BIG, BIG, SimpleNamespace(is_lorm=False), factor=2)
     with pytest.raises(AdoptionError, match="KiB of LDS"):
         register_foreign_adapter(huge, m.forward)
+
+
+def test_lokr_merge_into_a_weight_only_fp8_base_requantises(gold):
+    """Round 6 (first refusal lifted): LoKr merge_in over the e4m3 weight-only base = dequantise, W += kron(w1, w2) * scale *
+    merge_weight, re-quantise with a fresh per-output-channel scale (the reference's merge ends in the same write-back + requantise for any
+    quantised org_module, toolkit/models/lokr.py:261-309 / toolkit/network_mixins.py:452-459); the layer stays quantised, merge_out returns
+    to within two roundings of the original."""
+    t, meta = gold
+    ref, nat, net = native_pair()
+    net.apply_to(None, nat, False, True)
+    net.force_to("cpu", torch.float32)
+    with torch.no_grad():
+        for m in net.unet_loras:
+            m.lokr_w2.copy_(t[f"set/{m.lora_name}/w2"])
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    nat.quantize_base_fp8()
+    nat.prepare()
+    quantised = [x for x in net.unet_loras if getattr(x.org_module[0], "qweight", None) is not None]
+    assert quantised  # the block Linears are quantised (quantize_base_fp8 leaves embedders / adaLN projections in bf16)
+    m = quantised[0]
+    lin = m.org_module[0]
+    deq = lambda: lin.qweight.view(torch.float8_e4m3fn).float() * lin.wscale[:, None]  # noqa: E731
+    w0 = deq()
+    delta = 0.7 * m.scale * torch.kron(m.lokr_w1.detach().float(), m.composed_w2().float())
+    net.merge_in(0.7, ops=ref_ops)
+    assert net.is_merged_in and lin.qweight.dtype == torch.uint8
+    q_ref = ((w0 + delta) / lin.wscale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(lin.qweight, q_ref) and torch.equal(lin.qweight_t, lin.qweight.t())
+    assert not torch.equal(deq(), w0)
+    step = (w0 + delta).abs().amax(dim=1, keepdim=True) / 448.0 * 32
+    net.merge_out(0.7, ops=ref_ops)
+    assert ((deq() - w0).abs() <= step).all()

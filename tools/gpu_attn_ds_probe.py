@@ -1,0 +1,98 @@
+"""Probe of the 5-matmul attention backward: what does it cost the wave-specialised dK/dV pass to EMIT dS, and what would a
+product-form dQ = dS K cost — against the recomputing dQ kernel it would replace.  B x 24 heads x 4608 tokens, head_dim 128 (one FLUX layer).
+
+  attn_bwd total (delta + dK/dV + dQ), events around aitk_attn_bwd:   ds_mode 0 (today) / 1 (accumulator-native 2-KiB blocks, coalesced
+      non-temporal 16-byte stores) -> the difference to mode 0 is the price of emitting dS
+  dq_proxy: the existing GEMM kernels on M = B*24*4608, N = 128, K = 4608 (one shared B operand): the bytes (the 42-MB-per-head dS, read once)
+      and flops of dQ = dS K for every head as ONE launch — an optimistic stand-in for a batched product-form dQ pass
+  stream_read: a plain read of the dS bytes (torch sum), the HBM floor of any such pass
+Run under rocprofv3 --kernel-trace --stats for the per-kernel split (the three ws instantiations carry their DS mode in the name)."""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import ai_toolkit_amd  # noqa: F401,E402
+from ai_toolkit_amd import ops  # noqa: E402
+
+
+def med(fn, n=7):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sorted(ts)[n // 2]
+
+
+def main():
+    B, H, S = int(os.environ.get("AITK_AB_B", "7")), 24, 4608
+    d = H * 128
+    torch.manual_seed(0)
+    q, k, v, do = [torch.randn(B * S, d, device="cuda").to(torch.bfloat16) for _ in range(4)]
+    o = torch.empty_like(q)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
+    sc = 1 / math.sqrt(128)
+    ops.attn_fwd(q, k, v, o, lse, B=B, H=H, S=S, scale=sc)
+    ds = torch.empty(B * H * S * S, dtype=torch.bfloat16, device="cuda")
+    res = {"B": B, "H": H, "S": S, "dS_GB": ds.numel() * 2 / 1e9}
+    ref = None
+    for rep in range(2):
+        for mode in (0, 1, 0):
+            ms = med(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc, ds=ds if mode else None, ds_mode=mode))
+            res.setdefault(f"attn_bwd_ms_ds{mode}", []).append(round(ms, 3))
+            chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (dq, dk, dv)]
+            if ref is None:
+                ref = chk
+            assert chk == ref, (mode, chk, ref)  # the gradients are the same bits in every mode
+    # ---- dS content of mode 1 against its definition on (batch, head) = (0, 0), fp32 reference: dS = P (dP - delta), P = softmax(q k^T scale)
+    ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc, ds=ds, ds_mode=1)
+    n32 = S // 32
+    blk = ds[: S * S].view(n32, n32, 2, 64, 8)  # [kv32][q32][vector][lane][slot]
+    lane = torch.arange(64, device="cuda")
+    e = torch.arange(8, device="cuda")
+    vv = torch.arange(2, device="cuda")[:, None, None]
+    q0 = q.view(B, S, H, 128)[0, :, 0].float()
+    k0 = k.view(B, S, H, 128)[0, :, 0].float()
+    v0 = v.view(B, S, H, 128)[0, :, 0].float()
+    do0 = do.view(B, S, H, 128)[0, :, 0].float()
+    o0 = o.view(B, S, H, 128)[0, :, 0].float()
+    ds_ref = torch.softmax(q0 @ k0.t() * sc, -1) * (do0 @ v0.t() - (do0 * o0).sum(-1, keepdim=True))
+    worst = 0.0
+    for kvb, qb in ((0, 0), (5, 17), (n32 - 1, n32 - 1), (77, 3)):
+        qrow = 32 * qb + 16 * vv + 8 * (e[None, None, :] >> 2) + 4 * (lane[None, :, None] >> 5) + (e[None, None, :] & 3)
+        kvcol = (32 * kvb + (lane & 31))[None, :, None].expand(2, 64, 8)
+        want = ds_ref[qrow, kvcol]
+        worst = max(worst, (blk[kvb, qb].float() - want).abs().max().item() / ds_ref.abs().max().item())
+    res["ds_blocks_vs_fp32_definition_max_rel"] = worst
+    del blk, ds_ref
+    # ---- product-form dQ stand-in: one GEMM over all heads' dS rows
+    a = ds.view(B * H * S, S)
+    kt = torch.randn(128, S, device="cuda").to(torch.bfloat16)  # K^T of one head, [N = d][K = kv]
+    outp = torch.empty(B * H * S, 128, dtype=torch.bfloat16, device="cuda")
+    for tm, name in ((1, "dq_proxy_gemm128_ms"), (2, "dq_proxy_gemm256_ms")):
+        try:
+            res[name] = round(med(lambda: ops.gemm_nt(a, kt, outp, tile_mode=tm)), 3)
+        except Exception as ex:  # noqa: BLE001
+            res[name] = f"{type(ex).__name__}: {ex}"[:200]
+    res["stream_read_ms"] = round(med(lambda: ds.view(torch.int16).sum()), 3)
+    fl = 2.0 * S * S * 128 * B * H
+    res["dq_matmul_tflop"] = fl / 1e12
+    print("RESULT", json.dumps(res))
+    out = os.path.join(ROOT, "gpurun_out", "attn_ds_probe.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
