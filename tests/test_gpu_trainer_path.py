@@ -81,7 +81,7 @@ def test_trainer_loop_on_the_hip_kernels_arena_tail_against_torchs_loops():
         if twin_p is None:  # first step: adoption happens inside; the twin starts from the same values
             twin_p = [torch.nn.Parameter(p.detach().clone()) for p in a.params]
             twin_opt = torch.optim.AdamW(twin_p, lr=1e-3, eps=1e-6, weight_decay=0.01)
-            twin_shadow = [p.detach().clone() for p in twin_p]
+            twin_shadow = [s_.detach().clone() for s_ in a.ema.shadow_params]  # as the EMA was constructed (before _loop's warm start of lora_up)
         # the trainer's sequence by hand, so that the clipped gradients can be handed to the twin
         from types import SimpleNamespace
 
