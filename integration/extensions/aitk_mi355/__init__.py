@@ -51,3 +51,16 @@ Wan21MI355 = _real(_p.Wan21MI355Model, _flowmatch_scheduler(_p.WAN_SCHEDULER_CON
 StableDiffusionMI355 = _real(_p.StableDiffusionMI355Model, _ddpm_scheduler())
 
 AI_TOOLKIT_MODELS = [Flux1MI355, Wan21MI355, StableDiffusionMI355]
+
+# The trainer's optimizer tail on the arena kernels (ai_toolkit_amd/adopt.py, "The trainer's optimizer tail on the arena kernels"): once a network
+# is adopted, a plain torch.optim.AdamW over exactly its parameters is stepped by ONE aitk_adamw_ema_step (torch optimizer step hooks, installed at
+# adoption) and `ExponentialMovingAverage.update()` over the same parameters by ONE aitk_ema_update instead of its per-parameter Python loop
+# (toolkit/ema.py:126-152) — wrapped here, where the reference's class is importable; everything else falls through to the reference's own code.
+try:
+    from toolkit.ema import ExponentialMovingAverage as _EMA
+
+    from ai_toolkit_amd.adopt import install_ema_fusion as _install_ema_fusion
+
+    _install_ema_fusion(_EMA)
+except ImportError:  # a reference tree without toolkit/ema.py: nothing to wrap
+    pass
