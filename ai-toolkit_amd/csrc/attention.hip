@@ -936,7 +936,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
     lds_char* const xw = sm + DKDV_WS_XOFF + w * 4096 + lane * 16;
     // DS: this lane's first destination element: block (kv block of 32 = 4 tile_x + w, q block SUB) of 1024 elements, lane-linear
     bf16_t* ds_base = nullptr;
-    if (DS == 1) {
+    if (DS) {
       const long nq32 = (S + 31) / 32, nkv32 = (Skv + 31) / 32;
       ds_base = p.dS + (((long)b * p.H + hd) * nkv32 + (tile_x * 4 + w)) * nq32 * 1024 + lane * 8;
     }
@@ -1019,6 +1019,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       s16x8_t* dst = reinterpret_cast<s16x8_t*>(ds_base + (long)(SUB) * 1024);                                                      \
       __builtin_nontemporal_store(ds_lo, dst);                                                                                      \
       __builtin_nontemporal_store(ds_hi, dst + 64);                                                                                 \
+    } else if (DS == 2) { /* the same blocks with plain (L2-allocating) stores: A/B of the store flavour */                         \
+      s16x8_t* dst = reinterpret_cast<s16x8_t*>(ds_base + (long)(SUB) * 1024);                                                      \
+      dst[0] = ds_lo;                                                                                                               \
+      dst[64] = ds_hi;                                                                                                              \
     }                                                                                                                               \
   }
     // prologue: S / dP of sub-tile 0 + its statistics, fragments of sub-tile 1
@@ -1030,7 +1034,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       const lds_char* tn1 = sm + ((t + 1) % NSLOT) * TILE;
       // ---- step 2t.  H1: products of sub-tile 2t + 1 -> set 1 || t, dd, p of sub-tile 2t (set 0); pieces 2-3 of tile t + 2
       DKDV_WS_MMA(1, 1, issue_pieces(t + 2, 2);, t, 0)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's pieces of tile t + 1 have landed (the four younger ones stay in flight)
+      // this wave's pieces of tile t + 1 have landed (the four younger ones stay in flight).  DS: the four dS stores of the previous iteration
+      // sit in the same in-order queue BEHIND those pieces (gfx9 counts stores in vmcnt): old -> new = [tile t+1 ...] [tile t+2 p0-1]
+      // st st [tile t+2 p2-3]... i.e. eight younger operations, not four — with vmcnt(4) the wave would wait for the stores'
+      // acknowledgements and for half of the next tile (measured: +0.66 ms per layer-launch instead of the stores' own cost)
+      if (DS) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       DKDV_WS_BAR(t)
       // H2: dS of sub-tile 2t, hand-over; fragments of sub-tile 2t + 2 = rows 0-31 of tile t + 1
       DKDV_WS_FRAGS(0, tn1)  // issued first: they return under the arithmetic (the barrier's lgkmcnt(0) waits for every LDS operation of the wave)
@@ -1293,6 +1302,106 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AitkAttnArgs p) {
   }
 }
 
+// ============================================================================================ backward: dQ as a product of its own (5-matmul backward)
+// dQ = scale * dS K with the bf16 dS the dK/dV pass emitted (AitkAttnArgs.dS, ds_mode 1) instead of recomputing S and dP a second time: one
+// matmul where attn_bwd_dq_kernel runs three, at the price of streaming the [S, Skv] dS of every (batch, head) through HBM once (42 MB per
+// head at 4608 tokens) — an HBM-bound kernel whose matrix work hides under the stream.
+// Same ownership and accumulation order as attn_bwd_dq_kernel (wave w owns query rows [q0 + 32 w, +32); kv tiles of 64 ascending, sub-blocks
+// j, kk ascending; dQ^T[d][q] += sum_kv K^T[d][kv] dS^T[kv][q] with K^T through tr16 in the permuted contraction order), and the SAME bf16
+// dS values (the dK/dV pass forms them with the same instructions), so the result is the recomputing kernel's.
+// The dS blocks are accumulator-native (lane = kv row, slots = 8 q rows; see the header): the contraction index here is kv, i.e. each
+// 32 x 32 block must be read TRANSPOSED — it is staged by LDS-DMA into a wave-private slot with the 16-byte chunks reordered on the way
+// (DMA lane L fetches the chunk of dump-lane (L & 1) * 32 + (L >> 1): LDS chunk position = 2 kv + h'), which makes the 4-row x 16-column
+// patch of every ds_read_b64_tr_b16 group 128 contiguous bytes (conflict-free), and read with two transpose reads per 16 kv rows.
+// LDS per workgroup: K tile double buffer (2 x 17 KiB, sub-tiled like attn_bwd_dq_kernel's) + per wave 2 x 4 KiB of dS slots = 66 KiB -> 2 WG / CU.
+#define DQDS_SLOT 4096                                  /* one wave's two blocks (j = 0, 1) of a kv tile */
+#define DQDS_KOFF 0
+#define DQDS_SOFF (2 * SUBTILE_BYTES)                  /* [buffer 2][wave 4] slots */
+#define DQDS_LDS (DQDS_SOFF + 2 * 4 * DQDS_SLOT)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(AitkAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const sm = (lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
+  int tile_x, hd, b;
+  attn_wg_coords((S + 127) / 128, p.H, tile_x, hd, b);
+  const int q0 = tile_x * 128 + wave * 32;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  f32x16_t dq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dq[d] = zero16();
+  const int ntiles = Skv / 64;  // whole tiles only (checked at launch)
+  const int gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
+  const unsigned ln_tr_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);            // K^T: frag_tr_perm_st, rows with bit 3 clear
+  const unsigned ln_tr_hi = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2) + 8) * 32 + ((lh ^ 1) << 4);  // ... and the rows 8 further
+  // dS^T: rows R0 + (i16 >> 2), R0 = 16 kk + 4 h (+ 8); LDS chunk position 2 kv + h' with h' = i16 & 1, 8-byte half (i16 >> 1) & 1; q column
+  // half gq = the block's second 1-KiB vector
+  const unsigned ln_ds = gq * 1024 + ((4 * h + (i16 >> 2)) * 2 + (i16 & 1)) * 16 + ((i16 >> 1) & 1) * 8;
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv, 128);
+  unsigned vK[4];
+  st_voff(vK, p.ldk, wave, lane);
+  const unsigned stepK = (unsigned)(64 * p.ldk * 2);
+  // this wave's dS blocks: block (kv32 = 2 t + j, q32 = q0 / 32) of (b, hd) at ((kv32 * nq32 + q32) * 2048 bytes; per DMA piece v (1 KiB)
+  // lane L fetches 16 bytes at v * 1024 + ((L & 1) * 32 + (L >> 1)) * 16
+  const long nq32 = S / 32, nkv32 = Skv / 32;
+  const bf16_t* dSb = p.dS + ((long)b * p.H + hd) * nkv32 * nq32 * 1024;
+  const v4i_t srdS = slice_srd_bytes(dSb, nkv32 * nq32 * 2048);
+  const unsigned vS = (unsigned)((q0 >> 5) * 2048 + ((lane & 1) * 32 + (lane >> 1)) * 16);
+  const unsigned stepS = (unsigned)(nq32 * 2048);  // one kv32 block further
+  lds_char* const slot0 = sm + DQDS_SOFF + wave * DQDS_SLOT;
+  auto stage = [&](int t, int buf) {
+    dma_st64(sm + DQDS_KOFF + buf * SUBTILE_BYTES, vK, (unsigned)t * stepK, srdK, wave);
+    lds_char* sl = slot0 + buf * 4 * DQDS_SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)sl + j * 2048 + v * 1024), vS + (unsigned)(2 * t + j) * stepS + v * 1024, srdS);
+  };
+  stage(0, 0);
+  DMA_WAIT_ALL();
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) stage(t + 1, cur ^ 1);
+    const lds_char* ktc = sm + DQDS_KOFF + cur * SUBTILE_BYTES;
+    const lds_char* k_lo = ktc + ln_tr_lo;
+    const lds_char* k_hi = ktc + ln_tr_hi;
+    const lds_char* ds_l = slot0 + cur * 4 * DQDS_SLOT + ln_ds;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const s16x4_t dlo = tr16l(ds_l + j * 2048 + (16 * kk) * 32);        // rows 16 kk + 4 h + 0..3 of q column l31
+        const s16x4_t dhi = tr16l(ds_l + j * 2048 + (16 * kk + 8) * 32);    // rows 16 kk + 8 + 4 h + 0..3
+        const s16x8_t df = join_lohi(dlo, dhi);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const s16x4_t lo = tr16l(k_lo + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
+          const s16x4_t hi = tr16l(k_hi + 2 * d * SUBP + (32 * j + 16 * kk) * 32);
+          dq[d] = mfma32(join_lohi(lo, hi), df, dq[d]);
+        }
+      }
+    DMA_WAIT_ALL();
+    __syncthreads();
+  }
+  const int q = q0 + l31;
+  if (q < S) {
+    bf16_t* op = p.dQ + ((long)b * S + q) * p.lddq + hd * 128;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 u;
+        u.x = pack2bf(dq[d][4 * g + 0] * p.scale, dq[d][4 * g + 1] * p.scale);
+        u.y = pack2bf(dq[d][4 * g + 2] * p.scale, dq[d][4 * g + 3] * p.scale);
+        *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * h) = u;
+      }
+  }
+}
+
 static int attn_check(const AitkAttnArgs* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->S <= 0 || a->D != 128) return AITK_ERR_SHAPE;
   if (a->Dv < 0 || a->Dv > 128) return AITK_ERR_SHAPE;
@@ -1367,14 +1476,26 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
     if (!wattr) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
       wattr = true;
     }
-    const int dsm = (a->dS && (a->S % 64) == 0 && (Skv % 128) == 0) ? a->ds_mode : 0;  // the probe modes cover whole tiles only
+    // dS modes cover whole tiles only, full-width heads in the padded layout (FLUX, Wan self-attention); everything else recomputes
+    const int dsm = (a->dS && (a->S % 64) == 0 && (Skv % 128) == 0 && a->hstride == 0 && (a->Dv == 0 || a->Dv == 128)) ? a->ds_mode : 0;
     if (dkdv_ws_mode() == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<true, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
-    else if (dsm == 1) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 1>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else if (dsm == 1 || dsm == 3) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 1>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else if (dsm == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 2>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    if (dsm == 1) {  // the 5-matmul backward: dQ = dS K from the emitted blocks
+      static bool dattr = false;
+      if (!dattr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_ds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQDS_LDS);
+        dattr = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_dq_ds_kernel, grid, dim3(256), DQDS_LDS, s, *a);
+      return;
+    }
     launch_dq<KS, DB>(a, grid, s);
     return;
   }

@@ -1,8 +1,9 @@
 """Probe of the 5-matmul attention backward: what does it cost the wave-specialised dK/dV pass to EMIT dS, and what would a
 product-form dQ = dS K cost — against the recomputing dQ kernel it would replace.  B x 24 heads x 4608 tokens, head_dim 128 (one FLUX layer).
 
-  attn_bwd total (delta + dK/dV + dQ), events around aitk_attn_bwd:   ds_mode 0 (today) / 1 (accumulator-native 2-KiB blocks, coalesced
-      non-temporal 16-byte stores) -> the difference to mode 0 is the price of emitting dS
+  attn_bwd total (delta + dK/dV + dQ), events around aitk_attn_bwd:   ds_mode 0 (today) / 3 (dS emitted as accumulator-native 2-KiB
+      blocks with coalesced non-temporal 16-byte stores, dQ still recomputed: the price of emitting dS) / 2 (the same with plain stores) /
+      1 (the 5-matmul backward: dS emitted + attn_bwd_dq_ds_kernel, dQ = dS K)
   dq_proxy: the existing GEMM kernels on M = B*24*4608, N = 128, K = 4608 (one shared B operand): the bytes (the 42-MB-per-head dS, read once)
       and flops of dQ = dS K for every head as ONE launch — an optimistic stand-in for a batched product-form dQ pass
   stream_read: a plain read of the dS bytes (torch sum), the HBM floor of any such pass
@@ -47,14 +48,21 @@ def main():
     ds = torch.empty(B * H * S * S, dtype=torch.bfloat16, device="cuda")
     res = {"B": B, "H": H, "S": S, "dS_GB": ds.numel() * 2 / 1e9}
     ref = None
+    grads0 = None
     for rep in range(2):
-        for mode in (0, 1, 0):
+        for mode in (0, 3, 1, 2, 0):
             ms = med(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc, ds=ds if mode else None, ds_mode=mode))
             res.setdefault(f"attn_bwd_ms_ds{mode}", []).append(round(ms, 3))
             chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (dq, dk, dv)]
             if ref is None:
-                ref = chk
-            assert chk == ref, (mode, chk, ref)  # the gradients are the same bits in every mode
+                ref, grads0 = chk, dq.clone()
+            if mode == 1:  # the product-form dQ against the recomputing kernel's
+                res["dq_product_form_bit_identical"] = bool(torch.equal(dq, grads0))
+                res["dq_product_form_max_rel"] = float((dq.float() - grads0.float()).abs().max() / grads0.float().abs().max())
+                assert chk[1:] == ref[1:], (mode, chk, ref)
+            else:
+                assert chk == ref, (mode, chk, ref)  # the gradients are the same bits in every dump-only mode
+    del grads0
     # ---- dS content of mode 1 against its definition on (batch, head) = (0, 0), fp32 reference: dS = P (dP - delta), P = softmax(q k^T scale)
     ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc, ds=ds, ds_mode=1)
     n32 = S // 32
