@@ -552,7 +552,8 @@ def attn_fwd(q, k, v, o, lse, *, B, H, S, scale, Skv=0, dv=0, hstride=0):
     return o
 
 
-ATTN_DS = os.environ.get("AITK_ATTN_DS", "0") == "1"  # 5-matmul attention backward (dS emitted by the dK/dV pass, product-form dQ); DESIGN.md section 9
+ATTN_DS = os.environ.get("AITK_ATTN_DS", "1") != "0"  # 5-matmul attention backward (dS emitted by the dK/dV pass, product-form dQ; bit-identical to the
+# recomputing backward, step +2.7 % same box: profiles/r06_ab_attn_ds_*.json); AITK_ATTN_DS=0: the 7-matmul backward, no [B, H, S, Skv] scratch
 
 
 def attn_ds_eligible(S, Skv, dvalid=0, hstride=0):
@@ -563,12 +564,14 @@ def attn_ds_eligible(S, Skv, dvalid=0, hstride=0):
 def attn_bwd(q, k, v, o, lse, do, dq, dk, dv, *, B, H, S, scale, Skv=0, dvalid=0, hstride=0, ds=None, ds_mode=0):
     """ds / ds_mode (AitkAttnArgs.dS): 1 = the 5-matmul backward — the wave-specialised dK/dV pass also writes its bf16 dS (accumulator-native
     2-KiB blocks) and dQ = dS K runs as a product of its own (attn_bwd_dq_ds_kernel); 3 = emit dS but keep the recomputing dQ kernel, 2 = the
-    same with plain instead of non-temporal stores (probes).  Default: AITK_ATTN_DS."""
+    same with plain instead of non-temporal stores (probes), 4 = off whatever the default.  Default (ds_mode 0, ds None): AITK_ATTN_DS."""
     a = _attn_args(q, k, v, o, lse, B, H, S, scale, Skv, dvalid, hstride)
     if ds is None and ds_mode == 0 and ATTN_DS and attn_ds_eligible(S, Skv or S, dvalid, hstride):
         # the 5-matmul backward (AITK_ATTN_DS=1): the dK/dV pass emits dS, dQ = dS K is a product of its own; the [B, H, S, Skv] bf16 scratch
         # (7.1 GB at 7 x 24 x 4608^2) is one grow-only workspace shared by every layer
         ds, ds_mode = workspace(B * H * S * (Skv or S) * 2, q.device, "attn_ds").view(BF16), 1
+    if ds_mode == 4:  # explicitly off (tests: the recomputing backward whatever the default is)
+        ds, ds_mode = None, 0
     if ds is not None and ds_mode:
         assert ds.dtype == BF16 and ds.is_contiguous() and ds.numel() >= B * H * ((S + 31) // 32 * 32) * (((Skv or S) + 31) // 32 * 32)
         a.dS, a.ds_mode = _ptr(ds), int(ds_mode)

@@ -942,11 +942,11 @@ def main():
     if B <= 0:
         avail_gib = (torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev)) / 2 ** 30  # free + what this process holds
         # bf16 base: 245 GiB peak at B = 7; the fp8 base holds 23.8 GB less (weights as bytes, bf16 copies released): 7 fits from 232 GiB
-        need = 232 if args.fp8_base else 252
+        need = 239 if args.fp8_base else 259  # incl. the 6.6-GiB dS scratch of the 5-matmul attention backward (ops.ATTN_DS)
         B = 7 if (avail_gib >= need and args.network == "lora") else 4
         # between the two: B = 7 still fits once the GELU outputs are dropped after the forward pass (recompute_gelu: 196 GiB peak at B = 7
         # against 238, -0.7 % step time, bit-identical gradients; profiles/r04_recompute_gelu.json) — better than falling to B = 4
-        need_rg = 190 if args.fp8_base else 210
+        need_rg = 197 if args.fp8_base else 217
         if B == 4 and args.network == "lora" and avail_gib >= need_rg:
             B = 7
             model.recompute_gelu = True
