@@ -1023,6 +1023,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_ws_kernel(AitkAttnArgs p) {
       s16x8_t* dst = reinterpret_cast<s16x8_t*>(ds_base + (long)(SUB) * 1024);                                                      \
       dst[0] = ds_lo;                                                                                                               \
       dst[64] = ds_hi;                                                                                                              \
+    } else if (DS == 5) { /* probe: the same store instructions into ONE 2-KiB block per wave (stays in L2: issue cost without HBM) */ \
+      s16x8_t* dst = reinterpret_cast<s16x8_t*>(ds_base);                                                                           \
+      dst[0] = ds_lo;                                                                                                               \
+      dst[64] = ds_hi;                                                                                                              \
     }                                                                                                                               \
   }
     // prologue: S / dP of sub-tile 0 + its statistics, fragments of sub-tile 1
@@ -1402,6 +1406,122 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_ds_kernel(AitkAttnArgs p) 
   }
 }
 
+// ---- the same product with more bytes in flight: 8 waves (256 query rows) per workgroup, rings of THREE tiles, counted waits.
+// attn_bwd_dq_ds_kernel keeps 2 workgroups x 16 KiB of dS in flight per CU and drains the queue at every tile (5.0 TB/s on the 7.1-GB stream);
+// here a workgroup's eight waves share one K tile, every wave has the dS blocks of TWO tiles in flight behind the one it computes (64 KiB
+// per CU), and a tile is published by `vmcnt(6)` — a wave issues exactly six LDS-DMA pieces per tile (2 of K, 4 of dS), tiles past the end
+// are issued all the same (they arrive as zeros through the buffer windows) so that the count stays exact.  Transpose reads in their asm form:
+// the builtin would make the waitcnt pass drain the DMA queue in front of the first LDS read of every iteration (see tr16_issue).
+// LDS: K ring 3 x 17 KiB + dS slots 3 x 8 x 4 KiB = 147 KiB -> 1 workgroup per CU.  Same products in the same order -> the same bits.
+#define DQ8_KRING (3 * SUBTILE_BYTES)
+#define DQ8_LDS (DQ8_KRING + 3 * 8 * DQDS_SLOT)
+__global__ __launch_bounds__(512) void attn_bwd_dq_ds8_kernel(AitkAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lds_char* const sm = (lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int S = p.S;
+  const int Skv = p.Skv > 0 ? p.Skv : p.S;
+  int tile_x, hd, b;
+  attn_wg_coords((S + 255) / 256, p.H, tile_x, hd, b);
+  const int q0 = tile_x * 256 + wave * 32;
+  const bf16_t* Kb = p.K + (long)b * Skv * p.ldk + hd * 128;
+  f32x16_t dq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) dq[d] = zero16();
+  const int ntiles = Skv / 64;
+  const int gq = (lane >> 4) & 1, i16 = lane & 15, lh = (i16 & 3) >> 1;
+  const unsigned ln_tr_lo = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2)) * 32 + (lh << 4);
+  const unsigned ln_tr_hi = gq * SUBP + (i16 & 1) * 8 + (4 * h + (i16 >> 2) + 8) * 32 + ((lh ^ 1) << 4);
+  const unsigned ln_ds = gq * 1024 + ((4 * h + (i16 >> 2)) * 2 + (i16 & 1)) * 16 + ((i16 >> 1) & 1) * 8;
+  const v4i_t srdK = slice_srd(Kb, p.ldk, Skv, 128);
+  // K tile [64][128], sub-tiled: 16 pieces of 1 KiB (column block ins >> 1, row half ins & 1), two per wave: ins = wave + 8 ii
+  unsigned vK[2];
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    const int ins = wave + 8 * ii;
+    const int sub = ins >> 1, r = (ins & 1) * 32 + (lane >> 1);
+    const int lhk = (lane & 1) ^ ((r >> 3) & 1);
+    vK[ii] = (unsigned)((r * p.ldk + (2 * sub + lhk) * 8) * 2);
+  }
+  const unsigned stepK = (unsigned)(64 * p.ldk * 2);
+  const long nq32 = S / 32, nkv32 = Skv / 32;
+  const bf16_t* dSb = p.dS + ((long)b * p.H + hd) * nkv32 * nq32 * 1024;
+  const v4i_t srdS = slice_srd_bytes(dSb, nkv32 * nq32 * 2048);
+  // a wave past the last query block (S % 256 != 0) points its dS pieces past the window: zeros, and it writes nothing at the end
+  const unsigned vS = q0 < S ? (unsigned)((q0 >> 5) * 2048 + ((lane & 1) * 32 + (lane >> 1)) * 16) : 0xfff00000u;
+  const unsigned stepS = (unsigned)(nq32 * 2048);
+  lds_char* const slot0 = sm + DQ8_KRING + wave * DQDS_SLOT;
+  auto stage = [&](int t) {  // six pieces, always
+    const int buf = t % 3;
+    lds_char* kt = sm + buf * SUBTILE_BYTES;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int ins = wave + 8 * ii;
+      dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)kt + (ins >> 1) * SUBP + (ins & 1) * 1024), vK[ii] + (unsigned)t * stepK, srdK);
+    }
+    lds_char* sl = slot0 + buf * 8 * DQDS_SLOT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        dma16(__builtin_amdgcn_readfirstlane((unsigned)(size_t)sl + j * 2048 + v * 1024), vS + (unsigned)(2 * t + j) * stepS + v * 1024, srdS);
+  };
+  stage(0);
+  stage(1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    stage(t + 2);
+    const int cur = t % 3;
+    const unsigned kt = (unsigned)(size_t)(sm + cur * SUBTILE_BYTES);
+    const unsigned k_lo = kt + ln_tr_lo, k_hi = kt + ln_tr_hi;
+    const unsigned ds_l = (unsigned)(size_t)(slot0 + cur * 8 * DQDS_SLOT) + ln_ds;
+#define DQ8_STEP(J, KK)                                                                                              \
+  {                                                                                                                  \
+    s16x4_t dlo, dhi, klo[4], khi[4];                                                                                \
+    tr16_issue_off<(J) * 2048 + (16 * (KK)) * 32>(dlo, ds_l);                                                        \
+    tr16_issue_off<(J) * 2048 + (16 * (KK) + 8) * 32>(dhi, ds_l);                                                    \
+    tr16_issue_off<0 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(klo[0], k_lo);                                        \
+    tr16_issue_off<0 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(khi[0], k_hi);                                        \
+    tr16_issue_off<1 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(klo[1], k_lo);                                        \
+    tr16_issue_off<1 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(khi[1], k_hi);                                        \
+    tr16_issue_off<2 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(klo[2], k_lo);                                        \
+    tr16_issue_off<2 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(khi[2], k_hi);                                        \
+    tr16_issue_off<3 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(klo[3], k_lo);                                        \
+    tr16_issue_off<3 * 2 * SUBP + (32 * (J) + 16 * (KK)) * 32>(khi[3], k_hi);                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \
+                 : "+v"(dlo), "+v"(dhi), "+v"(klo[0]), "+v"(khi[0]), "+v"(klo[1]), "+v"(khi[1]), "+v"(klo[2]), "+v"(khi[2]), "+v"(klo[3]), \
+                   "+v"(khi[3]));                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    const s16x8_t df = join_lohi(dlo, dhi);                                                                          \
+    _Pragma("unroll") for (int d = 0; d < 4; ++d) dq[d] = mfma32(join_lohi(klo[d], khi[d]), df, dq[d]);              \
+  }
+    DQ8_STEP(0, 0)
+    DQ8_STEP(0, 1)
+    DQ8_STEP(1, 0)
+    DQ8_STEP(1, 1)
+#undef DQ8_STEP
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile t + 1 has landed; tile t + 2's six pieces stay in flight
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tiles issued past the end retire before the wave ends
+  const int q = q0 + l31;
+  if (q < S) {
+    bf16_t* op = p.dQ + ((long)b * S + q) * p.lddq + hd * 128;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 u;
+        u.x = pack2bf(dq[d][4 * g + 0] * p.scale, dq[d][4 * g + 1] * p.scale);
+        u.y = pack2bf(dq[d][4 * g + 2] * p.scale, dq[d][4 * g + 3] * p.scale);
+        *reinterpret_cast<uint2*>(op + 32 * d + 8 * g + 4 * h) = u;
+      }
+  }
+}
+
 static int attn_check(const AitkAttnArgs* a) {
   if (!a || a->B <= 0 || a->H <= 0 || a->S <= 0 || a->D != 128) return AITK_ERR_SHAPE;
   if (a->Dv < 0 || a->Dv > 128) return AITK_ERR_SHAPE;
@@ -1477,6 +1597,7 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<false, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_ws_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKDV_WS_LDS);
       hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<KS, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SUBTILE_BYTES);
       wattr = true;
@@ -1486,14 +1607,20 @@ static void launch_bwd(const AitkAttnArgs* a, hipStream_t s) {
     if (dkdv_ws_mode() == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<true, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     else if (dsm == 1 || dsm == 3) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 1>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     else if (dsm == 2) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 2>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
+    else if (dsm == 5) hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 5>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     else hipLaunchKernelGGL((attn_bwd_dkdv_ws_kernel<false, 0>), grid_kv, dim3(512), DKDV_WS_LDS, s, *a);
     if (dsm == 1) {  // the 5-matmul backward: dQ = dS K from the emitted blocks
       static bool dattr = false;
+      static int dq_variant = 2;  // AITK_ATTN_DQDS=1: the 4-wave / drain-every-tile kernel (same-box A/B)
       if (!dattr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_ds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQDS_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_ds8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQ8_LDS);
+        const char* e = getenv("AITK_ATTN_DQDS");
+        if (e && e[0] == '1') dq_variant = 1;
         dattr = true;
       }
-      hipLaunchKernelGGL(attn_bwd_dq_ds_kernel, grid, dim3(256), DQDS_LDS, s, *a);
+      if (dq_variant == 1) hipLaunchKernelGGL(attn_bwd_dq_ds_kernel, grid, dim3(256), DQDS_LDS, s, *a);
+      else hipLaunchKernelGGL(attn_bwd_dq_ds8_kernel, dim3((unsigned)(((a->S + 255) / 256) * a->H * a->B)), dim3(512), DQ8_LDS, s, *a);
       return;
     }
     launch_dq<KS, DB>(a, grid, s);

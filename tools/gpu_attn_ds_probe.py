@@ -50,7 +50,7 @@ def main():
     ref = None
     grads0 = None
     for rep in range(2):
-        for mode in (0, 3, 1, 2, 0):
+        for mode in (0, 3, 1, 2, 5, 0):
             ms = med(lambda: ops.attn_bwd(q, k, v, o, lse, do, dq, dk, dv, B=B, H=H, S=S, scale=sc, ds=ds if mode else None, ds_mode=mode or 4))
             res.setdefault(f"attn_bwd_ms_ds{mode}", []).append(round(ms, 3))
             chk = [float(t_.view(torch.int16).to(torch.int64).sum().item()) for t_ in (dq, dk, dv)]
