@@ -386,17 +386,58 @@ class AdoptedNetwork(FusedLoRANetwork):
     # initialised, every backward ends with ONE all-reduce(average) of the flat gradient arena (the same collective the fused train step
     # issues, RCCL over xGMI on the GPU).  Under gradient accumulation the arena holds avg(g_1) + local g_2 after the second backward and
     # averaging that again leaves avg(g_1) + avg(g_2): correct without a no_sync protocol.  dp_allreduce = False turns it off.
+    # Round 6: issued like the fused train step's (trainer._on_grads_ready) — in TWO pieces, asynchronously, as soon as the explicit backward
+    # declares a part of the arena final (FLUX: the single-stream blocks' adapters first, whose collective then runs behind the double-stream
+    # blocks' backward; model.grad_ready_hook), joined at the end of the backward.  dp_overlap = False: one blocking all-reduce at the end.
     dp_allreduce = True
+    dp_overlap = True
+
+    def _dp_world(self):
+        if not self.dp_allreduce:
+            return 0
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        w = dist.get_world_size()
+        return w if w > 1 else 0
+
+    def before_backward(self, model):
+        """Called by the autograd bridge in front of the explicit backward: arms the model's gradient-ready hook under data parallelism."""
+        self._pending = []
+        model.grad_ready_hook = self._on_grads_ready if (self._dp_world() and self.dp_overlap) else None
+
+    def _on_grads_ready(self, which):
+        import torch.distributed as dist
+
+        model = self._model_ref()
+        g = self.arena_g
+        split = model.grad_split_offset(self) if hasattr(model, "grad_split_offset") else 0
+        n_mat = getattr(self, "n_mat", g.numel())  # DoRA magnitude vectors sit at [n_mat, n): final only at the end
+        ranges = [(split, n_mat)] if which in ("single", "late") else [(0, split), (n_mat, g.numel())]
+        for a, b in ranges:
+            if b > a:
+                self._pending.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                self.dp_pieces_issued += 1
+
+    dp_pieces_issued = 0  # collectives issued from inside a backward (tests)
 
     def after_backward(self):
-        if not self.dp_allreduce:
+        world = self._dp_world()
+        model = self._model_ref()
+        if model is not None:
+            model.grad_ready_hook = None
+        if not world:
             return
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
-            return
-        dist.all_reduce(self.arena_g, op=dist.ReduceOp.SUM)
-        self.arena_g.div_(dist.get_world_size())
+        pending, self._pending = getattr(self, "_pending", []), []
+        if pending:
+            for w in pending:
+                w.wait()
+        else:
+            dist.all_reduce(self.arena_g, op=dist.ReduceOp.SUM)
+        self.arena_g.div_(world)
 
     def parameters(self, recurse=True):
         for p, _ in self._expect:

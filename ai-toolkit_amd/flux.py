@@ -570,6 +570,9 @@ class _FluxGraphFn(torch.autograd.Function):
             # the trainer's optimizer.zero_grad(set_to_none=True) (SDTrainer.py:2249, 2288) dropped the .grad views: "none" means
             # zero, so the arena they alias is cleared and the views are re-attached before this backward accumulates into it
             net.zero_grad_arena()
+        arm = getattr(net, "before_backward", None)
+        if arm is not None:
+            arm(ctx_.model)  # adopted reference networks under data parallelism: the gradient all-reduce goes out in pieces during this backward
         ctx_.model.backward_native(dpred)
         hook = getattr(net, "after_backward", None)
         if hook is not None:

@@ -245,6 +245,15 @@ class FusedGraphBase(nn.Module):
             lin._dgroup = None
             if release_bf16:
                 lin.weight.data = torch.empty(0, dtype=lin.weight.dtype, device=lin.weight.device)
+        if not mfma and self.concat_dgrad:
+            # weight-only base: a same-input group's data gradient still runs as ONE K-concatenated GEMM — the members' e4m3 W^T are expanded
+            # side by side into one [in, sum(out)] bf16 scratch right before it (_concat_dgrad_operand) instead of one scratch + one GEMM each
+            for lins in self._dgrad_groups():
+                if all(l.qweight is not None for l in lins) and len({l.in_features for l in lins}) == 1:
+                    c0 = 0
+                    for l in lins:
+                        l._dgroup = ("fp8", c0, tuple(id(x) for x in lins))
+                        c0 += l.out_features
         self._prepared = True
         self.is_quantized = True
         return self
@@ -711,7 +720,9 @@ class FusedGraphBase(nn.Module):
         weights were laid out together by prepare(), the output gradients are adjacent column windows of one buffer in the same order,
         and every layer is either a plain LoRA layer of one laid-out adapter group or has no active adapter; None otherwise."""
         dg = getattr(lins[0], "_dgroup", None)
-        if dg is None or dg[2] != tuple(id(l) for l in lins) or self.fp8_mfma or any(l.qweight is not None for l in lins):
+        if dg is None or dg[2] != tuple(id(l) for l in lins) or self.fp8_mfma:
+            return None
+        if any(l.qweight is not None for l in lins) and not (isinstance(dg[0], str) and all(l.qweight is not None for l in lins)):
             return None
         if grp is None and any(t is not None for t in Ts):
             return None
@@ -728,7 +739,20 @@ class FusedGraphBase(nn.Module):
         tot = sum(l.out_features for l in lins)
         if ld < tot:
             return None
-        return torch.as_strided(d0, (d0.shape[0], tot), (ld, 1), d0.storage_offset()), dg[0]
+        wt_cat = dg[0]
+        if isinstance(wt_cat, str):  # weight-only fp8 group: expand the members' W^T (scale along the contraction axis) into adjacent column windows
+            slot = getattr(self, "_dq_slot", 0)
+            pool = self.__dict__.setdefault("_dq_scratch", {})
+            n = lins[0].in_features * tot
+            buf = pool.get(("cat", slot))
+            if buf is None or buf.numel() < n:
+                buf = pool[("cat", slot)] = torch.empty(n, dtype=self.dt, device=d0.device)
+            wt_cat = buf[:n].view(lins[0].in_features, tot)
+            c0 = 0
+            for l in lins:
+                self.ops.dequant_fp8(l.qweight_t, l.wscale, 2, wt_cat[:, c0:c0 + l.out_features])
+                c0 += l.out_features
+        return torch.as_strided(d0, (d0.shape[0], tot), (ld, 1), d0.storage_offset()), wt_cat
 
     def _lin_dgrad(self, lin, dy, dT, dx, *, M, flags=0, aux_in=None, dx_seg=None, w_rows=None):
         """dx (+)= dy W + dT A; w_rows = (r0, r1) restricts to input columns [r0, r1) (rows of W^T / A^T)."""

@@ -446,8 +446,9 @@ def test_plugin_instance_flags_survive_basemodel_init_order():
     assert flags["StableDiffusionMI355"] == {"is_flow_matching": False, "is_transformer": False, "use_old_lokr_format": False}
 
 
-def _adopted_dp_worker(rank, world, port, out):
+def _adopted_dp_worker(rank, world, port, out, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    AdoptedNetwork.dp_overlap = bool(overlap)
     import datetime
 
     import torch.distributed as dist
@@ -467,6 +468,7 @@ def _adopted_dp_worker(rank, world, port, out):
         tsr = torch.tensor([700.0, 250.0, 999.0, 31.0])[sl]
         trainer_step(net, plist, opt, ema, sd, (lat[sl], emb[sl], pooled[sl], tsr, target[sl]))
     torch.save(nat.network.arena_p.clone(), os.path.join(out, f"p{rank}.pt"))
+    torch.save(int(nat.network.dp_pieces_issued), os.path.join(out, f"pieces{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -481,6 +483,13 @@ def test_adopted_network_under_two_ranks_averages_gradients_like_one_rank_on_the
     mp.spawn(_adopted_dp_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
     p0, p1 = torch.load(tmp_path / "p0.pt"), torch.load(tmp_path / "p1.pt")
     assert torch.equal(p0, p1)
+    # round 6: the collective went out in two pieces per backward from INSIDE the explicit backward (single-stream adapters first), like the
+    # fused train step's; one blocking all-reduce at the end (dp_overlap = False) gives the same bits
+    assert torch.load(tmp_path / "pieces0.pt") == 2 * 2
+    (tmp_path / "blocking").mkdir()
+    mp.spawn(_adopted_dp_worker, args=(2, free_port(), str(tmp_path / "blocking"), False), nprocs=2, join=True)
+    assert torch.load(tmp_path / "blocking" / "pieces0.pt") == 0
+    assert torch.equal(torch.load(tmp_path / "blocking" / "p0.pt"), p0)
     _, nat, sd = native_plugin()
     net, params, plist = ref_sequence(nat, sd, rank=4)
     with torch.no_grad():
