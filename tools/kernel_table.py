@@ -20,7 +20,8 @@ def main():
     fam = [("gemm_nt_8phase_grouped_kernel", "LoRA-fused GEMM, persistent 8-phase, image+text stream grouped", None),
            ("gemm_nt_8phase_kernel", "LoRA-fused GEMM, persistent 8-phase", None),
            ("gemm_nt_kernel", "LoRA-fused GEMM, 128x128 / other", None),
-           ("attn_bwd_dkdv", "attention backward dK, dV (4 matmuls; wave-specialised kernel at head_dim 128: 8 waves, two per SIMD)", 8 * PAIR),
+           ("attn_bwd_dkdv", "attention backward dK, dV (4 matmuls; wave-specialised kernel at head_dim 128: 8 waves, two per SIMD; round 6: also emits its bf16 dS, 7.1 GB per launch)", 8 * PAIR),
+           ("attn_bwd_dq_ds", "attention backward dQ = dS K as a product of its own (1 matmul; streams the dS the dK/dV pass emitted: HBM-bound)", 2 * PAIR),
            ("attn_bwd_dq_kernel", "attention backward dQ (3 matmuls, recomputes S, dP)", 6 * PAIR),
            ("attn_fwd_kernel", "attention forward", 4 * PAIR),
            ("lora_down16_kernel", "LoRA skinny down (T = x A^T, dT = dy B), split precision", 0),

@@ -10,7 +10,7 @@ import os
 import sys
 
 KEEP = ("gemm_nt_8phase_f8_kernel", "gemm_nt_8phase_kernel", "quant_rows_fp8_kernel", "attn_fwd_kernel", "attn_bwd_dkdv_ws_kernel", "attn_bwd_dkdv_pipe_kernel",
-        "attn_bwd_dkdv_kernel", "attn_bwd_dq_kernel")
+        "attn_bwd_dkdv_kernel", "attn_bwd_dq_ds8_kernel", "attn_bwd_dq_ds_kernel", "attn_bwd_dq_kernel")
 
 
 def main():
