@@ -153,38 +153,35 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // U = k-steps (of 32) whose loads are in flight before the first MFMA.  RB = 1 (one rank-16 adapter, 95 % of the launches of a FLUX
 // step) runs with U = 6: 116 VGPRs -> 4 waves per SIMD -> all 1008 workgroups of a 32256-row launch are resident at once (U = 8 needs
 // 132 VGPRs -> 3 per SIMD -> 768 slots -> a second, one-third-full round).
-// NB = 16-row blocks of X per workgroup: 2 (32 rows; one P fragment serves both) for the long launches; 1 for short ones (M < 16384: a
-// B = 1 FLUX launch has 4608 rows = 144 workgroups of 32 rows on 256 CUs — 16-row workgroups put 288 on the chip).  A row's sum does not
-// depend on its neighbours: both forms give the same bits.
-template <int RB, int U, int NB = 2>
+template <int RB, int U>
 __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p) {
-  __shared__ __attribute__((aligned(16))) float red[4 * RB * NB * 4 * 64];
+  __shared__ __attribute__((aligned(16))) float red[4 * RB * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * (16 * NB);
-  const bf16_t* xrow[NB];
+  const int m0 = blockIdx.x * 32;
+  const bf16_t* xrow[2];
 #pragma unroll
-  for (int blk = 0; blk < NB; ++blk)
+  for (int blk = 0; blk < 2; ++blk)
     xrow[blk] = seg_row2(p.X, p.ldx, p.x_seg_rows, p.x_seg_stride, min(m0 + blk * 16 + i16, p.M - 1)) + 8 * g;
   const bf16_t* prow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 16 + i16, p.R - 1) * p.ldp + 8 * g;
   const long lo_off = p.P_lo ? (p.P_lo - p.P) : 0;
-  f32x4_t acc[RB][NB];
+  f32x4_t acc[RB][2];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int ksteps = p.K / 32;
   const int kbeg = (ksteps * wave) / 4, kend = (ksteps * (wave + 1)) / 4;
   int ks = kbeg;
   for (; ks + U <= kend; ks += U) {
-    s16x8_t xa[U][NB], pa[U][RB];
+    s16x8_t xa[U][2], pa[U][RB];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = (ks + u) * 32;
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk) xa[u][blk] = *reinterpret_cast<const s16x8_t*>(xrow[blk] + k);
+      xa[u][0] = *reinterpret_cast<const s16x8_t*>(xrow[0] + k);
+      xa[u][1] = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) pa[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
     }
@@ -199,15 +196,15 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-          for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pa[u][rb], xa[u][blk], acc[rb][blk]);
+          acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);
+          acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
         }
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-          for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pl[u][rb], xa[u][blk], acc[rb][blk]);
+          acc[rb][0] = mfma16(pl[u][rb], xa[u][0], acc[rb][0]);
+          acc[rb][1] = mfma16(pl[u][rb], xa[u][1], acc[rb][1]);
         }
       continue;
     }
@@ -215,24 +212,22 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pa[u][rb], xa[u][blk], acc[rb][blk]);  // D rows = rank, cols = x row
+        acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);  // D rows = rank, cols = x row
+        acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
       }
   }
   for (; ks < kend; ++ks) {
     const int k = ks * 32;
-    s16x8_t xt[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) xt[blk] = *reinterpret_cast<const s16x8_t*>(xrow[blk] + k);
+    const s16x8_t x0 = *reinterpret_cast<const s16x8_t*>(xrow[0] + k), x1 = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
-#pragma unroll
-      for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pf, xt[blk], acc[rb][blk]);
+      acc[rb][0] = mfma16(pf, x0, acc[rb][0]);
+      acc[rb][1] = mfma16(pf, x1, acc[rb][1]);
       if (lo_off) {
         const s16x8_t pl = *reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + k);
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pl, xt[blk], acc[rb][blk]);
+        acc[rb][0] = mfma16(pl, x0, acc[rb][0]);
+        acc[rb][1] = mfma16(pl, x1, acc[rb][1]);
       }
     }
   }
@@ -240,15 +235,15 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
+    for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((wave * RB + rb) * NB + blk) * 4 + r) * 64 + lane] = acc[rb][blk][r];
+      for (int r = 0; r < 4; ++r) red[(((wave * RB + rb) * 2 + blk) * 4 + r) * 64 + lane] = acc[rb][blk][r];
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-      if (((rb * NB + blk) & 3) != wave) continue;
+    for (int blk = 0; blk < 2; ++blk) {
+      if (((rb * 2 + blk) & 3) != wave) continue;
       const int m = m0 + blk * 16 + i16;
       float c = p.scale;
       if (p.mult) c *= p.mult[min(m, p.M - 1) / p.rows_per_batch];
@@ -257,7 +252,7 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
       for (int r = 0; r < 4; ++r) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[(((w * RB + rb) * NB + blk) * 4 + r) * 64 + lane];
+        for (int w = 0; w < 4; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
         v[r] = s * c;
       }
       const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
@@ -265,14 +260,6 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
     }
 }
 
-static bool lora_down_small_m() {  // AITK_LORA_DOWN_SMALL_M=0: always 32-row workgroups (same-box A/B)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("AITK_LORA_DOWN_SMALL_M");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
 extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if (!a || a->M <= 0 || a->K <= 0 || a->R <= 0) return AITK_ERR_SHAPE;
   if ((a->K % 16) || (a->R % 4) || a->R > 64) return AITK_ERR_SHAPE;
@@ -282,15 +269,6 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
   // tmask rows are R wide = the ranks of THIS launch: a 64-rank chunk of a wider slab (split_rp > R) brings its own contiguous [rows, R] mask
   const int grid = (a->M + 31) / 32;
-  if (a->K % 32 == 0 && a->M < 16384 && lora_down_small_m()) {  // short launches: 16-row workgroups (twice as many on the chip), same bits
-    const int g16 = (a->M + 15) / 16;
-    if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, 1>), dim3(g16), dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->R <= 32) hipLaunchKernelGGL((lora_down16_kernel<2, 8, 1>), dim3(g16), dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->R <= 48) hipLaunchKernelGGL((lora_down16_kernel<3, 4, 1>), dim3(g16), dim3(256), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((lora_down16_kernel<4, 4, 1>), dim3(g16), dim3(256), 0, (hipStream_t)stream, *a);
-    AITK_LAUNCH_CHECK();
-    return AITK_OK;
-  }
   if (a->K % 32 == 0) {
     static int u1 = 0;  // AITK_LORA_DOWN_U=8 selects the 3-waves-per-SIMD variant (A/B measurements)
     if (!u1) {
