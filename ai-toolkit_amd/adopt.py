@@ -569,7 +569,11 @@ class _OptimizerFusion:
         self.arena_m = None         # the arena objects the state views were cut from (a rebuilt arena is a new object)
         self.hidden = None
         self.fused_steps = 0
-        opt.register_state_dict_pre_hook(lambda o: self.flush_steps())
+        # state[p]['step'] is written lazily — right before somebody reads the state (state_dict(), torch's own step); a torch without the
+        # state_dict pre-hook gets it written after every fused step instead (988 host-side fills)
+        self.eager_steps = not hasattr(opt, "register_state_dict_pre_hook")
+        if not self.eager_steps:
+            opt.register_state_dict_pre_hook(lambda o: self.flush_steps())
         net._fusions.append(weakref.ref(self))
 
     # -- eligibility, per call (cheap: group hyper-parameters and a pointer spot check)
@@ -693,6 +697,8 @@ class _OptimizerFusion:
                                     step=self.step_count, max_norm=0.0, ema=None)
         self.fused_steps += 1
         STATS["adamw_fused"] += 1
+        if self.eager_steps:
+            self.flush_steps()
         for p in self.params:        # torch's own step now finds nothing to do
             p.grad = None
         self.hidden = grads
@@ -707,6 +713,8 @@ class _OptimizerFusion:
 
 def _fusion_of(opt):
     ent = opt.__dict__.get("_aitk_fusion")
+    if ent is not None and ent[0] is not None and ent[0].net() is None:
+        ent = None  # the network this optimizer was matched with is gone (the model adopted the trainer's network anew): match again
     if ent is not None and (ent[0] is not None or ent[1] == _GEN[0]):
         return ent[0]
     fus = None
@@ -826,11 +834,14 @@ def install_ema_fusion(cls):
 def install_trainer_fusion():
     """Process-global optimizer step hooks (once) + the EMA wrap when the reference's toolkit.ema is loaded."""
     if not _HOOKS_INSTALLED[0]:
-        from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
-
-        register_optimizer_step_pre_hook(_optimizer_pre_hook)
-        register_optimizer_step_post_hook(_optimizer_post_hook)
-        _HOOKS_INSTALLED[0] = True
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+        except ImportError:  # a torch without global optimizer step hooks (< 2.0): the trainer's optimizer runs its own code
+            _HOOKS_INSTALLED[0] = True
+        else:
+            register_optimizer_step_pre_hook(_optimizer_pre_hook)
+            register_optimizer_step_post_hook(_optimizer_post_hook)
+            _HOOKS_INSTALLED[0] = True
     mod = _sys.modules.get("toolkit.ema")
     cls = getattr(mod, "ExponentialMovingAverage", None) if mod is not None else None
     if cls is not None:
