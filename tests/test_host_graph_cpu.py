@@ -167,10 +167,13 @@ def test_fp8_weight_only_base_matches_oracle_with_dequantised_weights():
         pred = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid)
         assert torch.allclose(pred, pred_ref, rtol=1e-4, atol=1e-5)
         net.zero_grad_arena()
+        nat.dgrad_census(reset=True)
         nat.backward_native((2 * pred).detach())
     for a, b in zip(net.unet_loras, ref_net.unet_loras):
         err = (a.lora_down.weight.grad - b.lora_down.weight.grad).norm() / (b.lora_down.weight.grad.norm() + 1e-12)
         assert err < 2e-4, (a.lora_name, err.item())
+    # round 6: the quantised same-input groups keep the K-concatenated data-gradient GEMM (their e4m3 W^T expanded side by side into one scratch)
+    assert nat.dgrad_census() == {"concat": CFG["num_single_layers"] + 2 * CFG["num_layers"], "fallback": 0}, nat.dgrad_census()
 
 
 def test_merge_into_weight_only_fp8_base_requantises():
