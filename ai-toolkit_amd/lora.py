@@ -311,6 +311,12 @@ class LoKrModule(LoRAModule):
         return self._out
 
 
+def _default_mask_provider(name, kind, shape, device):
+    """the reference's draws: torch.rand on the global generators (toolkit/network_mixins.py:200, 220) — the module_dropout coin on the host, the
+    element / rank masks on the adapter's device (graph-safe there: the CUDA generator's offset is advanced by every replay of a captured graph)"""
+    return torch.rand(shape, device="cpu" if kind == "module" else device)
+
+
 class FusedLoRANetwork(nn.Module):
     """Drop-in for LoRASpecialNetwork: transformer models in PEFT format (FLUX, Wan: `transformer.<path>.lora_A/B.weight`, alpha
     forced to the rank) and UNet models (SD1.5 / SDXL) in kohya format (`lora_unet_<path_with_underscores>.lora_down/up.weight` +
@@ -327,7 +333,7 @@ class FusedLoRANetwork(nn.Module):
             raise NotImplementedError("dropout variants: plain LoRA modules only on the fused path")
         # draws the random numbers of the dropout masks: (lora_name, kind, shape, device) -> uniform [0, 1) tensor; the default is
         # torch.rand on the adapter device like the reference (network_mixins.py:200, 220); tests inject a keyed provider
-        self.mask_provider = lambda name, kind, shape, device: torch.rand(shape, device="cpu" if kind == "module" else device)
+        self.mask_provider = _default_mask_provider
         # the reference holds a weak reference to the model plug-in for the save / load key-conversion hooks (lora_special.py:373-375)
         self.base_model_ref = weakref.ref(base_model) if base_model is not None else None
         assert network_type.lower() in ("lora", "dora", "lokr"), "locon / lorm / full-rank adapters are not on the fused path"
@@ -710,6 +716,13 @@ class FusedLoRANetwork(nn.Module):
     @property
     def has_dropout(self):
         return bool(self.dropout or self.rank_dropout or self.module_dropout)
+
+    def dropout_is_capturable(self):
+        """hipGraph replay draws fresh masks only if every draw is a device-side torch.rand on the default generator: no module_dropout (its coin is
+        a HOST decision that changes the launch list) and the default mask provider."""
+        if any(getattr(m, "module_dropout", None) for m in self.get_all_modules()) or self.module_dropout:
+            return False
+        return self.mask_provider is _default_mask_provider
 
     def dropout_plan(self, m, *, M, rows_per_batch, B):
         """Dropout decisions of one adapter for one forward, in the reference's order (toolkit/network_mixins.py:198-228; only in

@@ -192,10 +192,12 @@ class _LoRATrainStepBase:
         key = self._graph_key(prepared)
         if key in self._graphs:
             return self._graphs[key]
-        if self.network.training and self.network.has_dropout:
-            # dropout / rank_dropout masks and the module_dropout coin are host draws made while the launch list is built: a captured
-            # graph would replay ONE draw for ever (toolkit/network_mixins.py:197-239 draws per call)
-            raise NotImplementedError("hipGraph replay with LoRA dropout / rank_dropout / module_dropout: use step() (eager launches)")
+        if self.network.training and self.network.has_dropout and not getattr(self.network, "dropout_is_capturable", lambda: False)():
+            # the module_dropout coin is a HOST decision made while the launch list is built (an adapter is launched or not): a captured graph
+            # would replay ONE decision for ever (toolkit/network_mixins.py:197-239 draws per call); the same holds for a custom mask provider.
+            # dropout / rank_dropout alone are device-side torch.rand draws on the default generator, whose offset every replay advances:
+            # those graphs draw fresh masks (round 6)
+            raise NotImplementedError("hipGraph replay with LoRA module_dropout (or a custom mask provider): use step() (eager launches)")
         static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in prepared.items()}
         # warm-up on a side stream (workspaces, function attributes, RoPE tables are created here, not under capture)
         side = torch.cuda.Stream()

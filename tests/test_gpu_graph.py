@@ -71,3 +71,43 @@ def test_unet_graph_replay_is_bitwise_the_eager_step(sdxl):
         assert torch.equal(le, lg), (k, le.item(), lg.item())
         assert torch.equal(eager.network.arena_g, graphed.network.arena_g), k
         assert torch.equal(eager.network.arena_p, graphed.network.arena_p), k
+
+
+def test_flux_graph_replay_with_dropout_draws_fresh_masks_every_replay():
+    """Round 6 (one more refusal lifted): dropout / rank_dropout masks are device-side torch.rand draws on the default CUDA generator, whose offset
+    every replay of a captured graph advances — so `step_graphed` may capture a network with them (module_dropout, a host-side coin that changes
+    the launch list, is still refused).  Checked: the first replay equals the eager step started from the same generator state bit for bit (same
+    draws in the same order), consecutive replays on the same batch give different losses (fresh masks), eval mode replays are mask-free."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle.pairs import batch, build
+
+    cfg = dict(dropout=0.1, rank_dropout=0.25)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    _, _, nat_a, net_a = build(16, dropout_cfg=cfg, mask_provider=None)
+    _, _, nat_b, net_b = build(16, dropout_cfg=cfg, mask_provider=None)
+    from ai_toolkit_amd.lora import _default_mask_provider
+
+    net_a.mask_provider = net_b.mask_provider = _default_mask_provider
+    net_a.train()
+    net_b.train()
+    assert net_a.dropout_is_capturable()
+    eager, graphed = FluxLoRATrainStep(nat_a, net_a, ops, **kw), FluxLoRATrainStep(nat_b, net_b, ops, **kw)
+    lat, emb, pooled, noise, ts = batch(2, seed=90)
+    graphed.capture(latents=lat, prompt_embeds=emb, pooled_embeds=pooled, noise=noise, timesteps=ts)  # warm-up + capture consume draws of their own
+    p0 = net_b.arena_p.clone()
+    assert torch.equal(net_a.arena_p, p0)  # capture does not step
+    torch.cuda.manual_seed(1234)
+    l_e = eager.step(lat, emb, pooled, noise=noise, timesteps=ts).clone()
+    torch.cuda.manual_seed(1234)
+    l_g = graphed.step_graphed(latents=lat, prompt_embeds=emb, pooled_embeds=pooled, noise=noise, timesteps=ts).clone()
+    assert torch.equal(l_e, l_g), (l_e.item(), l_g.item())
+    assert torch.equal(net_a.arena_g, net_b.arena_g) and torch.equal(net_a.arena_p, net_b.arena_p)
+    losses = [graphed.step_graphed(latents=lat, prompt_embeds=emb, pooled_embeds=pooled, noise=noise, timesteps=ts).item() for _ in range(3)]
+    assert len({round(x, 7) for x in losses}) == 3, losses
+    # module_dropout is a host decision: still refused
+    _, _, nat_c, net_c = build(16, dropout_cfg=dict(module_dropout=0.2), mask_provider=None)
+    net_c.mask_provider = _default_mask_provider
+    net_c.train()
+    with pytest.raises(NotImplementedError, match="module_dropout"):
+        FluxLoRATrainStep(nat_c, net_c, ops, **kw).capture(latents=lat, prompt_embeds=emb, pooled_embeds=pooled, noise=noise, timesteps=ts)
