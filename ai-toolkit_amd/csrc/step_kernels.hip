@@ -608,11 +608,16 @@ extern "C" int aitk_lokr_lowrank_grad(const float* dW, const float* a, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ DoRA
-// c_j = magnitude_j / sqrt(||W_j||^2 + 2 s B_j.(W A^T)_j + s^2 B_j (A A^T) B_j^T); one thread per output channel (R <= 64)
+// c_j = magnitude_j / sqrt(||W_j||^2 + 2 s B_j.(W A^T)_j + s^2 B_j (A A^T) B_j^T); one thread per output channel.  The Gram matrix sits in LDS
+// up to rank 64 (16 KiB); larger ranks (toolkit/models/DoRA.py:126-148 has no rank limit) read it through the caches — the same sums in the same order.
+template <bool GRAM_LDS>
 __global__ void dora_colscale_kernel(AitkDoraColscaleArgs p) {
-  __shared__ float g[64 * 64];
-  for (int i = threadIdx.x; i < p.R * p.R; i += blockDim.x) g[i] = p.gram[i];
-  __syncthreads();
+  __shared__ float g_lds[GRAM_LDS ? 64 * 64 : 1];
+  if constexpr (GRAM_LDS) {
+    for (int i = threadIdx.x; i < p.R * p.R; i += blockDim.x) g_lds[i] = p.gram[i];
+    __syncthreads();
+  }
+  const float* g = GRAM_LDS ? g_lds : p.gram;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.N) return;
   const float* b = p.up + (long)j * p.R;
@@ -628,9 +633,10 @@ __global__ void dora_colscale_kernel(AitkDoraColscaleArgs p) {
   p.c[j] = p.mag[j] / sqrtf(n2);
 }
 extern "C" int aitk_dora_colscale(const AitkDoraColscaleArgs* a, aitk_stream_t stream) {
-  if (!a || a->N <= 0 || a->R <= 0 || a->R > 64) return AITK_ERR_SHAPE;
+  if (!a || a->N <= 0 || a->R <= 0 || a->R > 1024) return AITK_ERR_SHAPE;
   if (!a->w2 || !a->tw || !a->up || !a->gram || !a->mag || !a->c) return AITK_ERR_ARG;
-  hipLaunchKernelGGL(dora_colscale_kernel, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->R <= 64) hipLaunchKernelGGL(dora_colscale_kernel<true>, dim3((a->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(dora_colscale_kernel<false>, dim3((a->N + 63) / 64), dim3(64), 0, (hipStream_t)stream, *a);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

@@ -100,12 +100,21 @@ def test_linear_timesteps_force_the_linear_table():
 
 def test_graph_capture_refuses_dropout_and_keeps_per_batch_loss_buffers():
     """ADVICE r2 (low + medium): host-drawn dropout decisions cannot be replayed from a captured graph; the per-sample loss buffer of
-    a batch size is created once (a captured graph points at it)."""
+    a batch size is created once (a captured graph points at it).  Round 6: only the module_dropout coin (and a custom mask provider) is a
+    host decision — dropout / rank_dropout alone are device-side draws and capturable (tests/test_gpu_graph.py)."""
     ref, ref_net, nat, net = build_pair(rank=4)
     net.dropout = 0.25
     for m in net.unet_loras:
         m.dropout = 0.25
-    assert net.has_dropout
+    assert net.has_dropout and net.dropout_is_capturable()
+    net.mask_provider = lambda *a, **k: None  # a custom provider: draws are no longer known to be on the graph-safe generator
+    assert not net.dropout_is_capturable()
+    from ai_toolkit_amd.lora import _default_mask_provider
+    net.mask_provider = _default_mask_provider
+    net.module_dropout = 0.25
+    for m in net.unet_loras:
+        m.module_dropout = 0.25
+    assert not net.dropout_is_capturable()
     st = FluxLoRATrainStep(nat, net, ref_ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0, seed=1)
     net.train()
     g = torch.Generator().manual_seed(2)
