@@ -115,8 +115,8 @@ def register_foreign_adapter(layer, new_forward):
         has_dropout = any(getattr(m, k, None) for k in ("dropout", "rank_dropout", "module_dropout"))
         if isinstance(getattr(m, "dropout", None), nn.Module):
             raise AdoptionError(f"{name}: nn.Dropout-module dropout is not on the fused path (float probabilities are)")
-        if kind == "dora" and (r > 64 or has_dropout):
-            raise AdoptionError(f"{name}: DoRA at rank {r}{' with dropout' if has_dropout else ''}: the fused path runs DoRA up to rank 64 without dropout")
+        if kind == "dora" and has_dropout:
+            raise AdoptionError(f"{name}: DoRA with dropout: the fused path runs DoRA without dropout")
         if is3 and r > 64:
             raise AdoptionError(f"{name}: 3x3-conv adapters above rank 64 are not on the fused path")
         if is3 and (layer.cin_pad != layer.in_channels or layer.cout_pad != layer.out_channels):

@@ -561,6 +561,9 @@ class _FluxGraphFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, pred, model, arena_p):
         ctx_.model = model
+        # this forward's saved graph travels with this node: a second grad-enabled forward before loss.backward() (the trainer's preservation
+        # prediction, SDTrainer.py:2182-2219) must not replace it
+        ctx_.graph = model._take_graph_state()
         return pred.clone()
 
     @staticmethod
@@ -573,6 +576,10 @@ class _FluxGraphFn(torch.autograd.Function):
         arm = getattr(net, "before_backward", None)
         if arm is not None:
             arm(ctx_.model)  # adopted reference networks under data parallelism: the gradient all-reduce goes out in pieces during this backward
+        if ctx_.graph is None:
+            raise RuntimeError("backward through the same native prediction twice: its saved graph was released by the first pass (retain_graph is not supported)")
+        ctx_.model._put_graph_state(ctx_.graph)
+        ctx_.graph = None
         ctx_.model.backward_native(dpred)
         hook = getattr(net, "after_backward", None)
         if hook is not None:

@@ -128,6 +128,33 @@ class FusedGraphBase(nn.Module):
     def _device(self):
         return next(self.parameters()).device
 
+    # ---- what ONE forward saved for its backward, as an object the autograd bridge can hold.  The reference's trainer may run several
+    # grad-enabled predictions before one loss.backward() (diff_output_preservation / blank_prompt_preservation: the training prediction and a
+    # preservation prediction with other embeddings, extensions_built_in/sd_trainer/SDTrainer.py:2182-2219): each bridge node keeps its own
+    # forward's state and puts it back in front of its backward_native.  `self.ctx` (FLUX, Wan) / `self.tape` (UNets) stay the slot
+    # forward_native / backward_native use, so the fused step (one forward, one backward) is untouched.
+    _graph_slots = ("ctx",)
+
+    def _dora_modules(self):
+        net = self.network
+        return [m for m in net.get_all_modules() if getattr(m, "magnitude", None) is not None] if net is not None else []
+
+    def _take_graph_state(self):
+        state = {k: getattr(self, k, None) for k in self._graph_slots}
+        for k in self._graph_slots:
+            setattr(self, k, None)
+        # DoRA layers park this forward's linear output on the adapter (d magnitude needs it): it belongs to the forward, not to the layer
+        state["_dora_y"] = [(m, m.y_lin) for m in self._dora_modules() if getattr(m, "y_lin", None) is not None]
+        for m, _ in state["_dora_y"]:
+            m.y_lin = None
+        return state
+
+    def _put_graph_state(self, state):
+        for k in self._graph_slots:
+            setattr(self, k, state.get(k))
+        for m, y in state.get("_dora_y", ()):
+            m.y_lin = y
+
     # diffusers' ModelMixin surface the reference reads off the denoiser (toolkit/models/base_model.py:961-968: `self.unet.device`, `.dtype`)
     @property
     def device(self):

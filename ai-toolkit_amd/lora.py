@@ -350,9 +350,6 @@ class FusedLoRANetwork(nn.Module):
             target_lin_modules = tuple(target_lin_modules) + tuple(target_conv_modules)
         # toolkit/lora_special.py:403-408
         module_class = {"lora": LoRAModule, "dora": DoRAModule, "lokr": LoKrModule}[network_type.lower()]
-        if network_type.lower() == "dora" and lora_dim > 64:
-            raise NotImplementedError("DoRA ranks above 64 are not on the fused path (aitk_dora_colscale holds one output channel's rank row per "
-                                      "thread, R <= 64); plain LoRA runs any rank in 64-rank chunks")
         module_kwargs = {"factor": lokr_factor} if network_type.lower() == "lokr" else {}  # lora_special.py:601-602
         self.lora_dim = lora_dim
         self.network_type = network_type
@@ -677,8 +674,12 @@ class FusedLoRANetwork(nn.Module):
         self._ops = ops
         if self._shadow_table is None:
             self._shadow_table = ops.make_shadow_table(self._shadow_entries, self.arena_p.device)
-        ops.refresh_shadows(self.arena_p, self.arena_shadow, self._shadow_table)
-        self.refresh_dora(ops)
+        # never part of an autograd graph (the explicit backward is the only history); under no_grad also because the shadow views may have
+        # been created inside the trainer's no_grad prior prediction (first forward of a preservation run, SDTrainer.py:1244) — torch forbids
+        # writing a base in grad mode whose views were made without it (torch-backed kernel table; the HIP table writes through raw pointers)
+        with torch.no_grad():
+            ops.refresh_shadows(self.arena_p, self.arena_shadow, self._shadow_table)
+            self.refresh_dora(ops)
 
     def refresh_dora(self, ops):
         """c = magnitude / ||W + s*up@down||_row for every DoRA module, from the current adapter state:

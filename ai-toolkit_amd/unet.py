@@ -273,6 +273,8 @@ class _Tape:
 
 
 class UNet2DConditionModel(FusedGraphBase):
+    _graph_slots = ("tape", "_pred")  # what one forward leaves for its backward (FusedGraphBase._take_graph_state)
+
     def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  down_block_types=SD15_CONFIG["down_block_types"], up_block_types=SD15_CONFIG["up_block_types"],
                  cross_attention_dim=768, attention_head_dim=8, transformer_layers_per_block=1, use_linear_projection=False,

@@ -1460,7 +1460,7 @@ PARTIAL_ONLY = ["transformer_blocks.0.attn.to_q", "transformer_blocks.0.attn.add
                 "transformer_blocks.1.ff.net.2", "transformer_blocks.1.ff_context.net.0.proj"]
 
 
-def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora", uncached=False):
+def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quantize=False, network="lora", uncached=False, preservation=None):
     """THE END-TO-END BOUNDARY RUN: the reference's real `SDTrainer` (extensions_built_in/sd_trainer/SDTrainer.py) — its `run()`, unmodified —
     trains a LoRA for 3 steps over the plug-in of integration/extensions/aitk_mi355 on CPU: job / process config parsing, `get_model_class`
     picking `flux_mi355`, `ModelClass.get_train_scheduler()`, `sd.load_model()` (native FluxTransformer2DModel streamed from a diffusers-format
@@ -1535,7 +1535,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
         self.tokenizer = [HashTokenizer(99, 16), HashTokenizer(99, 16)]
         return self.text_encoder
 
-    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "") + (f"_{network}" if network != "lora" else "") + ("_uncached" if uncached else "")
+    tag = kind + (f"_accum{accum}" if accum > 1 else "") + (f"_{dtype}" if dtype != "fp32" else "") + ("_fp8base" if quantize else "") + (f"_{network}" if network != "lora" else "") + ("_uncached" if uncached else "") + (f"_{preservation}pp" if preservation else "")
     Plug = {"flux": ext.Flux1MI355, "wan": ext.Wan21MI355, "sd15": ext.StableDiffusionMI355, "sdxl": ext.StableDiffusionMI355}[kind]
     Plug.load_text_encoders = {"flux": tiny_te, "wan": tiny_umt5, "sd15": tiny_clip, "sdxl": tiny_clip_xl}[kind]
     Plug._load_text_side = lambda self, path: self.load_text_encoders(path)
@@ -1699,7 +1699,11 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
                          train=dict(batch_size=2, steps=steps, gradient_accumulation=accum, train_unet=True, train_text_encoder=False,
                                     gradient_checkpointing=True, noise_scheduler="ddpm" if kind in ("sd15", "sdxl") else "flowmatch", optimizer="adamw", lr=1e-3, dtype=dtype,
                                     disable_sampling=True, skip_first_sample=True, cache_text_embeddings=True,
-                                    ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid"),
+                                    ema_config=dict(use_ema=True, ema_decay=0.99), timestep_type="sigmoid",
+                                    # preservation="blank": train.blank_prompt_preservation (SDTrainer.py:1983-2016, 2182-2219) — per step a prior prediction
+                                    # (network off, no_grad, the cached "" embeddings), the training prediction and a SECOND grad-enabled prediction with the
+                                    # blank embeddings; loss + multiplier * mse(preservation_pred, prior_pred), one backward through both native graphs
+                                    **(dict(blank_prompt_preservation=True, blank_prompt_preservation_multiplier=0.5) if preservation == "blank" else {})),
                          model=dict(arch={"flux": "flux_mi355", "wan": "wan21_mi355", "sd15": "sd_mi355", "sdxl": "sd_mi355"}[kind], **({"is_xl": True} if kind == "sdxl" else {}), name_or_path=os.path.join(tmp, "ckpt"), quantize=quantize),
                          sample=dict(sample_every=10 ** 9, prompts=[]))
     job = types.SimpleNamespace(name="aitk_trainer_run", training_folder=os.path.join(tmp, "out"), device="cpu", meta=OrderedDict(),
@@ -1745,8 +1749,17 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     tes_ = sd_.text_encoder if isinstance(sd_.text_encoder, (list, tuple)) else [sd_.text_encoder]
     assert all(type(t).__name__ == "FakeTextEncoder" for t in tes_)  # unloaded by toolkit/unloader.py after the static prompts
     train_calls = [c for c in rec["calls"] if c[4]]
-    assert len(train_calls) == steps * accum and len(rec["targets"]) == steps * accum, (len(rec["calls"]), len(train_calls), len(rec["targets"]))
     out = {"losses": torch.tensor(losses, dtype=torch.float64)}
+    if preservation:
+        # three calls per micro-batch, in this order: prior (no_grad, network off), training, preservation (both grad-enabled)
+        assert len(rec["calls"]) == 3 * steps * accum and [c[4] for c in rec["calls"]] == [False, True, True] * (steps * accum), [c[4] for c in rec["calls"]]
+        pres_calls = train_calls[1::2]
+        priors = [c for c in rec["calls"] if not c[4]]
+        train_calls = train_calls[0::2]
+        for i, (pc, qc, tc) in enumerate(zip(pres_calls, priors, train_calls)):
+            assert torch.equal(pc[0], tc[0]) and torch.equal(pc[1], tc[1]) and torch.equal(qc[0], tc[0]) and torch.equal(qc[2], pc[2])  # same noisy latents / timesteps; prior and preservation share the embeddings
+            out[f"step{i}/pres_text"], out[f"step{i}/pres_pooled"] = pc[2], pc[3]
+    assert len(train_calls) == steps * accum and len(rec["targets"]) == steps * accum, (len(rec["calls"]), len(train_calls), len(rec["targets"]))
     for i, ((lat, ts, emb, pooled, _, kw), tgt) in enumerate(zip(train_calls, rec["targets"])):
         out[f"step{i}/latent_model_input"], out[f"step{i}/timestep"], out[f"step{i}/text"], out[f"step{i}/pooled"], out[f"step{i}/target"] = lat, ts, emb, pooled, tgt
     save_root = os.path.join(tmp, "out", "aitk_trainer_run")
@@ -1765,7 +1778,7 @@ def golden_trainer_loop(out_dir=None, kind="flux", accum=1, dtype="fp32", quanti
     if network == "lora" and not uncached:
         for i, sp in enumerate(ema_.shadow_params):
             out[f"ema/{i}"] = sp.detach().clone()
-    meta = {"steps": steps, "accum": accum, "dtype": dtype, "network_kind": network, "only_if_contains": PARTIAL_ONLY if network == "lora_partial" else None, "uncached": bool(uncached), "light": bool(network != "lora" or uncached), "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
+    meta = {"steps": steps, "accum": accum, "dtype": dtype, "preservation": ({"kind": preservation, "multiplier": 0.5} if preservation else None), "network_kind": network, "only_if_contains": PARTIAL_ONLY if network == "lora_partial" else None, "uncached": bool(uncached), "light": bool(network != "lora" or uncached), "quantize": bool(quantize), "base_is_quantized": bool(getattr(sd_.unet, "is_quantized", False)), "resume_at": n_before, "kw": train_calls[0][5], "opt_group": {k: v for k, v in opt_sd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")},
             "max_grad_norm": tr.train_config.max_grad_norm, "ema_decay": tr.train_config.ema_config.ema_decay, "saved_keys": list(sd_final.keys()),
             "files": sorted(os.listdir(save_root)), "n_predict_calls": len(rec["calls"]), "trainer": type(tr).__name__, "network": type(net_).__name__,
             "scheduler": type(sd_.noise_scheduler).__name__, "model": type(sd_).__name__, "model_mro": [k.__name__ for k in type(sd_).__mro__][:3]}
@@ -1888,6 +1901,11 @@ def golden_trainer_loop_flux_uncached(out_dir=None):
     golden_trainer_loop(out_dir, kind="flux", uncached=True)
 
 
+def golden_trainer_loop_flux_blankpp(out_dir=None):
+    """train.blank_prompt_preservation: true — the trainer's prior / training / preservation predictions per step and ONE backward through two native graphs."""
+    golden_trainer_loop(out_dir, kind="flux", preservation="blank")
+
+
 def golden_trainer_loop_flux_accum2(out_dir=None):
     """train.gradient_accumulation: 2 — two micro-batches per hook_train_loop call: `optimizer.zero_grad()` (set_to_none) at its top drops the
     adopted parameters' .grad views, two backward passes accumulate, one clip / step / EMA (SDTrainer.py:2246-2293)."""
@@ -1933,3 +1951,4 @@ if __name__ == "__main__":
     golden_trainer_loop(kind="flux", uncached=True)
     golden_trainer_loop(kind="flux", network="lora_partial")
     golden_trainer_loop(kind="flux", network="lokr_lowrank")
+    golden_trainer_loop(kind="flux", preservation="blank")

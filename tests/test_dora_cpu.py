@@ -5,6 +5,7 @@
 import json
 import os
 
+import pytest
 import torch
 from safetensors import safe_open
 from safetensors.torch import load_file
@@ -68,16 +69,19 @@ CFG = dict(in_channels=64, num_layers=1, num_single_layers=2, attention_head_dim
            joint_attention_dim=64, pooled_projection_dim=32)
 
 
-def test_dora_train_steps_match_oracle_autograd_adamw():
+@pytest.mark.parametrize("rank", [4, 80], ids=["r4", "r80_above_one_rank_chunk"])
+def test_dora_train_steps_match_oracle_autograd_adamw(rank):
+    """rank 80: above the 64 ranks one skinny launch contracts (toolkit/models/DoRA.py:126-148 has no rank limit) — the rank-space operands go out
+    in 64-rank chunks like plain LoRA's and aitk_dora_colscale reads the 80 x 80 Gram matrix through the caches."""
     torch.manual_seed(0)
     ref = flux_ref.FluxTransformer2DModel(**CFG)
     flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
     nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
     nat.load_state_dict(ref.state_dict(), strict=True)
     torch.manual_seed(5)
-    ref_net = lora_ref.RefLoRANetwork(ref, 4, network_type="dora")
+    ref_net = lora_ref.RefLoRANetwork(ref, rank, network_type="dora")
     torch.manual_seed(5)
-    net = FusedLoRANetwork(nat, lora_dim=4, network_type="dora")
+    net = FusedLoRANetwork(nat, lora_dim=rank, network_type="dora")
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for a, b in zip(net.unet_loras, ref_net.unet_loras):

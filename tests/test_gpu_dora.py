@@ -68,6 +68,21 @@ def test_gemv_col_scale_and_dora_kernels():
     assert torch.allclose(c, c_ref, rtol=1e-5, atol=1e-6)
     truth = mag / torch.linalg.norm(w.float() + 0.7 * Bup @ A.to(torch.bfloat16).float(), dim=1)
     assert torch.allclose(c, truth, rtol=2e-3), (c - truth).abs().max()
+    # rank 80 (above one rank chunk): Gram matrix from global memory, rank-space operands in 64-rank chunks
+    R8 = 80
+    A8 = (torch.randn(R8, K, generator=g) / math.sqrt(R8)).cuda()
+    B8 = (torch.randn(N, R8, generator=g) * 0.05).cuda().contiguous()
+    tw8 = torch.empty(N, R8, dtype=torch.bfloat16, device="cuda")
+    ops.lora_down(w, A8.to(torch.bfloat16), tw8, scale=1.0, M=N)
+    gram8 = torch.zeros(R8, R8, device="cuda")
+    At8 = A8.to(torch.bfloat16).t().contiguous()
+    ops.lora_wgrad(At8, At8, gram8, M=K)
+    c8, c8_ref = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.dora_colscale(w2, tw8, B8, gram8, mag, 0.7, c8)
+    ref_ops.dora_colscale(w2, tw8, B8, gram8, mag, 0.7, c8_ref)
+    assert torch.allclose(c8, c8_ref, rtol=1e-5, atol=1e-6)
+    truth8 = mag / torch.linalg.norm(w.float() + 0.7 * B8 @ A8.to(torch.bfloat16).float(), dim=1)
+    assert torch.allclose(c8, truth8, rtol=2e-3), (c8 - truth8).abs().max()
     # dz / d magnitude
     M = 1000
     dy = torch.randn(M, N + 64, generator=g).to(torch.bfloat16).cuda()[:, :N]
@@ -79,9 +94,9 @@ def test_gemv_col_scale_and_dora_kernels():
     assert _rel(dz, dz_ref) < 3e-3 and _rel(dm, dm_ref) < 1e-4
 
 
-@pytest.mark.parametrize("multiplier", [None, [1.0, 0.4]], ids=["uniform", "per_sample"])
-def test_dora_train_step_vs_fp32_oracle(multiplier):
-    """per_sample: slider-style batch — the LoRA term takes each sample's multiplier, the DoRA weight the mean (toolkit/network_mixins.py:313-340;
+@pytest.mark.parametrize("multiplier,rank", [(None, 16), ([1.0, 0.4], 16), (None, 80)], ids=["uniform", "per_sample", "uniform_r80"])
+def test_dora_train_step_vs_fp32_oracle(multiplier, rank):
+    """r80: above the 64 ranks of one skinny launch (rank chunks + aitk_dora_colscale's Gram matrix read through the caches).  per_sample: slider-style batch — the LoRA term takes each sample's multiplier, the DoRA weight the mean (toolkit/network_mixins.py:313-340;
     fused as a second un-scaled rank-r term, graph._DoraPS; pinned to the reference's own run on the CPU in tests/test_dora_cpu.py)."""
     import ai_toolkit_amd  # noqa: F401
     from ai_toolkit_amd import ops
@@ -102,9 +117,9 @@ def test_dora_train_step_vs_fp32_oracle(multiplier):
     nat = FluxTransformer2DModel(**CFG, dtype=torch.bfloat16, device=dev, ops=ops)
     nat.load_state_dict({k: v.to(torch.bfloat16) for k, v in ref.state_dict().items()}, strict=True)
     torch.manual_seed(5)
-    ref_net = lora_ref.RefLoRANetwork(ref, 16, network_type="dora").to(dev)
+    ref_net = lora_ref.RefLoRANetwork(ref, rank, network_type="dora").to(dev)
     torch.manual_seed(5)
-    net = FusedLoRANetwork(nat, lora_dim=16, network_type="dora")
+    net = FusedLoRANetwork(nat, lora_dim=rank, network_type="dora")
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for a, b in zip(net.unet_loras, ref_net.unet_loras):

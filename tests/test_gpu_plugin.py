@@ -372,3 +372,79 @@ def test_reference_built_network_adopted_on_the_wan_hip_kernels_bit_for_bit():
     sf = net_f.get_state_dict(dtype=torch.float32)
     assert sorted(sa) == sorted(sf) and next(iter(sf)).startswith("diffusion_model.blocks.0.")
     assert all(torch.equal(sa[key].cpu(), sf[key].cpu()) for key in sf)
+
+
+@pytest.mark.parametrize("network_type", ["lora", "dora"])
+def test_preservation_step_two_grad_predictions_one_backward_on_the_hip_kernels(network_type):
+    """blank_prompt_preservation / diff_output_preservation on the HIP kernels (SDTrainer.py:1983-2016, 2182-2219): prior prediction with the network off
+    under no_grad, the training prediction and a second grad-enabled prediction, ONE loss.backward() through two native graphs.  The arena must end
+    with the sum of what the two predictions give when each is back-propagated alone (same kernels, same inputs), and the prior prediction must be the
+    base model's (tests/test_plugin_cpu.py pins the same sequence to autograd over the oracle network; tests/test_trainer_loop_cpu.py to the
+    reference's real trainer)."""
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.plugin import Flux1MI355Model
+    from tests.test_gpu_e2e import _batch, _build
+
+    if network_type == "lora":
+        _, _, nat, net = _build()
+    else:  # DoRA: the forward parks its linear outputs on the adapters (d magnitude needs them) — they must travel with each graph too
+        from ai_toolkit_amd.flux import FluxTransformer2DModel
+        from ai_toolkit_amd.lora import FusedLoRANetwork
+        from tests.test_gpu_e2e import CFG
+
+        _, _, base, _ = _build(attach=False)
+        nat = FluxTransformer2DModel(**CFG, dtype=bf, device="cuda", ops=ops)
+        nat.load_state_dict(base.state_dict(), strict=True)
+        torch.manual_seed(5)
+        net = FusedLoRANetwork(nat, lora_dim=16, network_type="dora")
+        g_ = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for a in net.unet_loras:
+                a.lora_up.weight.copy_(torch.randn(a.lora_up.weight.shape, generator=g_) * 0.02)
+                a.magnitude.copy_(a.magnitude.cpu() * (1 + 0.03 * torch.randn(a.magnitude.shape, generator=g_)))
+        net.apply_to()
+        net.build_arena("cuda", groups=nat.lora_groups())
+        net.refresh_shadows(ops)
+        nat.attach_network(net)
+        nat.prepare()
+    plug = Flux1MI355Model("cuda", model=nat, dtype=bf)
+    lat, emb, pooled, noise, ts = _batch(2, seed=31)
+    _, emb2, pooled2, _, _ = _batch(2, seed=32)
+    pe, pe_blank = SimpleNamespace(text_embeds=emb, pooled_embeds=pooled), SimpleNamespace(text_embeds=emb2, pooled_embeds=pooled2)
+    tt = (ts / 1000).view(-1, 1, 1, 1)
+    noisy = ((1 - tt) * lat.float() + tt * noise.float()).to(bf)
+    target = (noise.float() - lat.float())
+    mult = 0.5
+
+    def loss_a(p):
+        return torch.nn.functional.mse_loss(p.float(), target, reduction="none").mean([1, 2, 3]).mean()
+
+    with net:
+        net.is_active = False
+        with torch.no_grad():
+            prior = plug.get_noise_prediction(noisy, ts, pe_blank, 1.0, False)
+        net.is_active = True
+        with torch.no_grad():
+            active_blank = plug.get_noise_prediction(noisy, ts, pe_blank, 1.0, False)
+        assert _rel(active_blank, prior) > 1e-3  # the adapter is not a no-op on this network: "network off" changed the prediction
+
+        def loss_b(p):
+            return torch.nn.functional.mse_loss(p, prior) * mult
+
+        # each prediction alone
+        net.zero_grad_arena()
+        loss_a(plug.get_noise_prediction(noisy, ts, pe, 1.0, False)).backward()
+        g_a = net.arena_g.clone()
+        net.zero_grad_arena()
+        loss_b(plug.get_noise_prediction(noisy, ts, pe_blank, 1.0, False)).backward()
+        g_b = net.arena_g.clone()
+        assert g_a.abs().max() > 0 and g_b.abs().max() > 0
+        # the trainer's sequence
+        net.zero_grad_arena()
+        pred = plug.get_noise_prediction(noisy, ts, pe, 1.0, False)
+        pres = plug.get_noise_prediction(noisy, ts, pe_blank, 1.0, False)
+        assert nat.ctx is None
+        (loss_a(pred) + loss_b(pres)).backward()
+        g = net.arena_g.clone()
+    assert torch.isfinite(g).all()
+    assert _rel(g, g_a + g_b) < 1e-6, _rel(g, g_a + g_b)

@@ -183,3 +183,62 @@ def test_stable_diffusion_wrapper_keeps_the_trainers_own_ddpm_scheduler():
     assert torch.allclose(sv.get_loss_target(noise=noise, batch=SimpleNamespace(latents=lat), timesteps=ts), sch.get_velocity(lat, noise, ts), atol=1e-6)
     for other in (None, SimpleNamespace(), type("Stub", (), {"__getattr__": lambda self, k: self})()):
         assert isinstance(StableDiffusionMI355Model("cpu", model=nat, dtype=torch.float32, noise_scheduler=other).noise_scheduler, DDPMTrainSchedule)
+
+
+@pytest.mark.parametrize("network_type", ["lora", "dora"])
+def test_preservation_step_two_grad_predictions_before_one_backward(network_type):
+    """diff_output_preservation / blank_prompt_preservation (extensions_built_in/sd_trainer/SDTrainer.py:1983-2016, 2182-2219): per step the trainer makes
+    a prior prediction with the network switched off under no_grad, the training prediction, and a SECOND grad-enabled prediction with the
+    preservation embeddings; loss = mse(pred, target) + multiplier * mse(preservation_pred, prior_pred), one loss.backward().  Each autograd-bridge
+    node carries its own forward's saved graph (DoRA: also that forward's linear outputs), so both explicit backwards run and the adapter gradients
+    equal autograd's over the oracle network."""
+    ref, ref_net, nat, net = build_pair(rank=4, network_type=network_type)
+    plug = Flux1MI355Model("cpu", model=nat, dtype=torch.float32)
+    g = torch.Generator().manual_seed(11)
+    B, Hl, Wl, n_txt = 2, 8, 4, 6
+    lat = torch.randn(B, 16, Hl, Wl, generator=g)
+    mk = lambda: SimpleNamespace(text_embeds=torch.randn(B, n_txt, CFG["joint_attention_dim"], generator=g) * 0.5,
+                                 pooled_embeds=torch.randn(B, CFG["pooled_projection_dim"], generator=g) * 0.5)
+    pe, pe_blank = mk(), mk()
+    ts = torch.tensor([700.0, 250.0])
+    target = torch.randn(B, 16, Hl, Wl, generator=g)
+    img_ids, txt_ids = flux_ref.make_ids(Hl, Wl, n_txt)
+    mult = 0.7
+
+    def ref_pred(e):
+        return flux_ref.unpack_latents(ref(flux_ref.pack_latents(lat), e.text_embeds, e.pooled_embeds, ts / 1000, img_ids, txt_ids, torch.full((B,), 1.0)), Hl, Wl)
+
+    with torch.no_grad():
+        ref_net.is_active = False
+        prior_ref = ref_pred(pe_blank)
+        ref_net.is_active = True
+    with ref_net:
+        loss_ref = torch.nn.functional.mse_loss(ref_pred(pe), target) + torch.nn.functional.mse_loss(ref_pred(pe_blank), prior_ref) * mult
+        loss_ref.backward()
+    net.zero_grad_arena()
+    with net:
+        net.is_active = False  # get_prior_prediction: network off, no_grad (SDTrainer.py:1228-1231, 1244)
+        with torch.no_grad():
+            prior = plug.get_noise_prediction(lat, ts, pe_blank, 1.0, False)
+        net.is_active = True
+        assert torch.allclose(prior, prior_ref, rtol=2e-4, atol=2e-5)
+        pred = plug.get_noise_prediction(lat, ts, pe, 1.0, False)
+        pres = plug.get_noise_prediction(lat, ts, pe_blank, 1.0, False)
+        assert nat.ctx is None  # both saved graphs live on their autograd nodes
+        loss = torch.nn.functional.mse_loss(pred, target) + torch.nn.functional.mse_loss(pres, prior) * mult
+        assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+        loss.backward()
+    def close(x, y):  # relative to the tensor's scale (the oracle table sums in another order than autograd)
+        return (x - y).abs().max().item() <= 2e-4 * y.abs().max().item() + 1e-7
+
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert close(a.lora_down.weight.grad, b.lora_down.weight.grad), a.lora_name
+        assert close(a.lora_up.weight.grad, b.lora_up.weight.grad), a.lora_name
+        if network_type == "dora":
+            assert close(a.magnitude.grad, b.magnitude.grad), a.lora_name
+    # a prediction whose graph was consumed cannot be back-propagated again
+    with net:
+        p2 = plug.get_noise_prediction(lat, ts, pe, 1.0, False)
+        p2.sum().backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match="twice"):
+            p2.sum().backward()

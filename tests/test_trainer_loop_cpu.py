@@ -53,7 +53,10 @@ KINDS["flux_lora_partial"] = KINDS["flux"]  # network_kwargs.only_if_contains: s
 KINDS["flux_dora"] = KINDS["flux"]          # network.type: dora (light fixture: losses + saved file)
 KINDS["flux_lokr_lowrank"] = KINDS["flux"]  # network.type: lokr, lokr_full_rank: false
 KINDS["flux_bf16_fp8base"] = KINDS["flux"]  # model.quantize: true — e4m3 weight-only base under the adopted network (BASELINE config 5's base)
-SCHEDULER = {"flux_lora_partial": "CustomFlowMatchEulerDiscreteScheduler", "flux_uncached": "CustomFlowMatchEulerDiscreteScheduler", "flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
+# train.blank_prompt_preservation: per step a prior prediction (network off, no_grad), the training prediction and a second grad-enabled prediction with the blank
+# embeddings; ONE loss.backward() through two native graphs (SDTrainer.py:1983-2016, 2182-2219)
+KINDS["flux_blankpp"] = KINDS["flux"]
+SCHEDULER = {"flux_blankpp": "CustomFlowMatchEulerDiscreteScheduler", "flux_lora_partial": "CustomFlowMatchEulerDiscreteScheduler", "flux_uncached": "CustomFlowMatchEulerDiscreteScheduler", "flux_dora": "CustomFlowMatchEulerDiscreteScheduler", "flux_lokr_lowrank": "CustomFlowMatchEulerDiscreteScheduler",
              "flux_bf16_fp8base": "CustomFlowMatchEulerDiscreteScheduler", "flux_accum2": "CustomFlowMatchEulerDiscreteScheduler", "flux_bf16": "CustomFlowMatchEulerDiscreteScheduler", "flux": "CustomFlowMatchEulerDiscreteScheduler", "wan": "CustomFlowMatchEulerDiscreteScheduler",
              # diffusers is not installed where the fixture is generated: toolkit/sampler.py returns an import stub there and the plug-in falls back to
              # its native DDPM table (a working DDPMScheduler is kept: tests/test_plugin_cpu.py)
@@ -72,7 +75,8 @@ def test_the_run_was_the_references_own_trainer_network_and_scheduler(kind):
     assert meta["trainer"] == "SDTrainer" and meta["network"] == "LoRASpecialNetwork" and meta["scheduler"] == SCHEDULER[kind]
     assert meta["model_mro"][1] == Mirror.__name__ and meta["model_mro"][0] == Mirror.__name__[:-len("Model")]  # the real BaseModel subclass of the extension, hooks from the mirror
     accum = meta.get("accum", 1)
-    assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5 * accum  # three steps, then a second process resumed for two more
+    calls_per_micro = 3 if meta.get("preservation") else 1  # preservation runs: prior + training + preservation prediction
+    assert meta["steps"] == 5 and meta["resume_at"] == 3 and meta["n_predict_calls"] == 5 * accum * calls_per_micro  # three steps, then a second process resumed for two more
     assert meta["opt_group"] == {"betas": [0.9, 0.999], "eps": 1e-06, "lr": 0.001, "weight_decay": 0.01}  # toolkit/optimizer.py:78-79 defaults
     assert {"aitk_trainer_run.safetensors", "optimizer.pt", "aitk_trainer_run_000000002.safetensors", "aitk_trainer_run_000000004.safetensors"} <= set(meta["files"])
     assert meta["kw"] == kw
@@ -147,10 +151,20 @@ def test_fused_twin_replaying_the_trainers_calls_reproduces_its_saved_lora_optim
             j = i * accum + a
             pe = SimpleNamespace(text_embeds=g[f"step{j}/text"], pooled_embeds=g[f"step{j}/pooled"] if g[f"step{j}/pooled"].numel() else None)
             with net:
+                pres = meta.get("preservation")
+                if pres:  # get_prior_prediction (SDTrainer.py:1211-1339): the network switched off, no_grad, the preservation embeddings
+                    ppe = SimpleNamespace(text_embeds=g[f"step{j}/pres_text"], pooled_embeds=g[f"step{j}/pres_pooled"])
+                    net.is_active = False
+                    with torch.no_grad():
+                        prior = sd.get_noise_prediction(g[f"step{j}/latent_model_input"], g[f"step{j}/timestep"], ppe, **meta["kw"])
+                    net.is_active = True
                 pred = sd.get_noise_prediction(g[f"step{j}/latent_model_input"], g[f"step{j}/timestep"], pe, **meta["kw"])
                 # SDTrainer.calculate_loss default branch (SDTrainer.py:903-1013): mse(reduction none) -> mean over all but the batch axis (:987-990; 5-D for video) -> * loss_multiplier (1) -> mean
                 loss = torch.nn.functional.mse_loss(pred.float(), g[f"step{j}/target"].float(), reduction="none")
                 loss = loss.mean(list(range(1, loss.dim()))).mean()
+                if pres:  # SDTrainer.py:2182-2219: a second grad-enabled prediction, held to the prior; one backward through both graphs
+                    pres_pred = sd.get_noise_prediction(g[f"step{j}/latent_model_input"], g[f"step{j}/timestep"], ppe, **meta["kw"])
+                    loss = loss + torch.nn.functional.mse_loss(pres_pred, prior) * pres["multiplier"]
                 loss.backward()
             step_loss += loss.item()
             if nk == "lora_partial" and j == 0:
@@ -240,7 +254,7 @@ import sys  # noqa: E402
 RUN_KW = {"flux": dict(kind="flux"), "wan": dict(kind="wan"), "sd15": dict(kind="sd15"), "sdxl": dict(kind="sdxl"), "flux_accum2": dict(kind="flux", accum=2),
           "flux_bf16": dict(kind="flux", dtype="bf16"), "flux_bf16_fp8base": dict(kind="flux", dtype="bf16", quantize=True), "flux_dora": dict(kind="flux", network="dora"),
           "flux_lokr_lowrank": dict(kind="flux", network="lokr_lowrank"), "flux_uncached": dict(kind="flux", uncached=True),
-          "flux_lora_partial": dict(kind="flux", network="lora_partial")}
+          "flux_lora_partial": dict(kind="flux", network="lora_partial"), "flux_blankpp": dict(kind="flux", preservation="blank")}
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/toolkit"), reason="the reference tree is not mounted here")
