@@ -245,9 +245,9 @@ def attention_roofline(step_fn, ops_mod, peak=PEAK_BF16):
                           "shape_BHSSkvD": list(sel[0][4])}
     ms = sum(r[1].elapsed_time(r[2]) for r in recs)
     fl = sum(r[3] for r in recs)
-    out.update({"bound": "mfma", "kernel": "aitk_attn_fwd (attn_fwd_kernel) + aitk_attn_bwd (attn_delta_kernel, attn_bwd_dkdv_ws_kernel, attn_bwd_dq_kernel), all calls of one step",
+    out.update({"bound": "mfma", "kernel": "aitk_attn_fwd (attn_fwd_kernel) + aitk_attn_bwd (attn_delta_kernel, attn_bwd_dkdv_ws_kernel emitting dS, attn_bwd_dq_ds8_kernel; AITK_ATTN_DS=0: attn_bwd_dq_kernel), all calls of one step",
                 "achieved": fl / ms / 1e9 if ms > 0 else 0.0, "peak": peak, "unit": "TFLOP/s", "frac": (fl / ms / 1e9 / peak) if ms > 0 else 0.0,
-                "attn_ms_per_step": ms, "note": "algorithmic flops (2 fwd + 4 bwd matmuls; the backward executes 7: S and dP are recomputed in both of its passes)"})
+                "attn_ms_per_step": ms, "note": "algorithmic flops (2 fwd + 4 bwd matmuls); the default backward executes 5 (S and dP once, in the dK/dV pass, which hands its bf16 dS to the dQ product through HBM); with AITK_ATTN_DS=0 it executes 7"})
     return out
 
 
