@@ -2,12 +2,13 @@
 UMT5 embeds [B,512,4096]) on one MI355X: synthetic weights / data, bf16, full step (noise mix .. AdamW).  Prints one JSON line."""
 import argparse
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # the repo root, wherever the profiler starts us
 import ai_toolkit_amd  # noqa: E402,F401
 from ai_toolkit_amd import ops  # noqa: E402
 from ai_toolkit_amd.lora import FusedLoRANetwork  # noqa: E402

@@ -11,7 +11,12 @@ import sys
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
-    steps = next(int(r["Calls"]) for r in rows if "adamw_ema_kernel" in r["Name"])
+    if "metric" not in bench:  # tools/gpu_wan_bench.py's line
+        bench = {"metric": bench["workload"], "value": bench["samples_per_s"], "unit": "videos/s", "ms_per_step": 1e3 * bench["s_per_step"],
+                 "config": {"per_gpu_batch": int(bench["workload"].rsplit("B=", 1)[-1])}}
+    steps = next((int(r["Calls"]) for r in rows if "adamw_ema_kernel" in r["Name"]), None)
+    if steps is None:  # (the optimizer kernel can fall below the CSV's cut) one shadow refresh per step + one at set-up
+        steps = next(int(r["Calls"]) for r in rows if "refresh_shadows_kernel" in r["Name"]) - 1
     agg = {}
     for r in rows:
         name = r["Name"]
