@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("b_scale", vp), ("b_scale_mode", i32), ("_pad4", i32),
         ("col_scale", vp),
         ("a_scale", vp),
+        ("t_partial", vp), ("t_p", vp), ("t_p_lo", vp), ("t_ldp", i64), ("t_tile0", i32), ("_pad5", i32),
     ]
 
 
@@ -208,7 +209,7 @@ class ShadowDesc(C.Structure):
     _fields_ = [("src_off", i64), ("d0", i64), ("d1", i64), ("d2", i64), ("rows", i32), ("cols", i32), ("kind", i32), ("aux", i32)]
 
 
-EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE, EPI_SPLIT_SLAB = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_BIAS, EPI_ACCUM, EPI_GELU, EPI_DGELU, EPI_GATE_RES, EPI_BIAS_ROW, EPI_ADD_AUX, EPI_COL_SCALE, EPI_SPLIT_SLAB, EPI_EMIT_T = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnModBwdArgs, 5: GateBwdArgs,
             6: ColsumFinishArgs, 7: QkvPostArgs, 8: EwArgs, 9: AttnArgs, 10: GemvArgs, 11: NoisePackArgs,
@@ -216,7 +217,7 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
-ABI_VERSION = 9  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+ABI_VERSION = 10  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
 
 
 def lib():
@@ -255,6 +256,8 @@ def lib():
     L.aitk_lora_refresh_shadows.argtypes = [vp, vp, vp, i32, vp]
     L.aitk_slab_rescale.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, vp]
     L.aitk_gemm_nt_grouped.argtypes = [vp, vp, vp]
+    L.aitk_lora_down_raw.argtypes = [vp, vp, vp]
+    L.aitk_lora_t_finish.argtypes = [vp, vp, i32, vp]
     L.aitk_lokr_lowrank_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.aitk_grad_compress_bf16.argtypes = [vp, vp, i64, vp]
     L.aitk_grad_expand_bf16.argtypes = [vp, vp, i64, vp]

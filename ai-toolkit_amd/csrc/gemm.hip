@@ -519,6 +519,11 @@ extern "C" int aitk_gemm_nt(const AitkGemmArgs* a, aitk_stream_t stream_) {
     AITK_LAUNCH_CHECK();
     return AITK_OK;
   }
+  if (a->flags & AITK_EPI_EMIT_T) {  // the emitting epilogue exists on the persistent 8-phase kernel only: outside its contract the caller keeps aitk_lora_down
+    if (aitk_gemm8_try_launch(a, st) != AITK_OK) return AITK_ERR_SHAPE;
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
   AitkGemmArgs tmp = *a;
   if (a->b_scale_mode == 3) {  // W8A8 on the MX-scaled fp8 MFMA: the persistent 8-phase kernel is the only implementation (no fallback)
     if (aitk_gemm8_try_launch(a, st) != AITK_OK) return AITK_ERR_SHAPE;

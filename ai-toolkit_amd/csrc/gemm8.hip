@@ -105,8 +105,15 @@ static_assert(sizeof(AitkGemmArgs) % 8 == 0, "two AitkGemmArgs must be contiguou
 // FE: the fast epilogue forms (see the epilogue).  TRACE: s_memtime at the tile-switch points of tiles 1-3 of workgroups 0 and 100, waves 0 and 4
 // (aitk_probe_gemm8_trace).
 __device__ unsigned g_gemm8_trace[2 * 2 * 3 * 5];
-template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false>
+// ET: AITK_EPI_EMIT_T instantiations (own kernels: the product kernels' code is the text without the `if constexpr (EMT)` blocks).  The BIAS | GELU fast
+// epilogue then also contracts the bf16 GELU values it stores against the consumer layer's lora_down rows: per 16-row group and 32-column block the
+// lane's eight packed values are moved to the v_mfma_f32_16x16x32_bf16 operand layout (row = lane & 15, column chunk = lane >> 4: a lane
+// permutation through ds_bpermute) and two matrix instructions (hi and lo shadow) add into 8 x 4 accumulator registers = the wave's 128 rows x 16
+// ranks over its 64 columns; the four waves of a row half then sum their slabs through the (idle) epilogue patches in a fixed order and write ONE
+// [128 rows][16] fp32 slab per workgroup row half and 256-column tile.  Needs whole tiles (every wave takes part in the workgroup barriers).
+template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, bool ET = false>
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
+  static_assert(!ET || (FE && !F8 && !CV), "EMIT_T: bf16 fast-epilogue kernels only");
   static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
   constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
@@ -603,8 +610,25 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         constexpr bool BIAS = (FL & AITK_EPI_BIAS) != 0, GELU = (FL & AITK_EPI_GELU) != 0, DGELU = (FL & AITK_EPI_DGELU) != 0;
         constexpr bool GATE = (FL & AITK_EPI_GATE_RES) != 0, ADDA = (FL & AITK_EPI_ADD_AUX) != 0, ACC = (FL & AITK_EPI_ACCUM) != 0;
         constexpr bool RD_IN = DGELU || GATE || ADDA;  // reads aux_in
+        constexpr bool EMT = ET && (FL & AITK_EPI_EMIT_T) != 0;
+        static_assert(!EMT || (GELU && !RD_IN && !ACC), "EMIT_T rides on the BIAS | GELU form");
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        // EMT: the consumer's lora_down rows over this wave's 64 columns, in the A-operand layout (rank = lane & 15, 8-column chunk = lane >> 4), hi and lo
+        s16x8_t awh[2], awl[2];
+        f32x4_t tacc[8];
+        int bperm_src = 0;
+        if constexpr (EMT) {
+          const long aoff = (long)(ln & 15) * q->t_ldp + (n0 + wc * 64) + (ln >> 4) * 8;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            awh[ni] = *reinterpret_cast<const s16x8_t*>(q->t_p + aoff + ni * 32);
+            awl[ni] = *reinterpret_cast<const s16x8_t*>(q->t_p_lo + aoff + ni * 32);
+          }
+#pragma unroll
+          for (int g = 0; g < 8; ++g) tacc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          bperm_src = ((((ln & 15) << 2) | (ln >> 4)) << 2);  // ds_bpermute byte address: this lane takes the words of lane (row << 2 | chunk)
+        }
         char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
         const int r_w = ln & 31, hh = ln >> 5, rr = ln >> 2, c4 = ln & 3;
         const long ldc = q->ldc;
@@ -742,12 +766,48 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = r8[e] + g8[e] * y8[e];
             }
-            *reinterpret_cast<uint4*>(crow) = pack8f(v);
+            const uint4 cw = pack8f(v);
+            *reinterpret_cast<uint4*>(crow) = cw;
+            if constexpr (EMT) {
+              v4i hb;
+              hb.x = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.x);
+              hb.y = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.y);
+              hb.z = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.z);
+              hb.w = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.w);
+              const s16x8_t hf = __builtin_bit_cast(s16x8_t, hb);
+              tacc[g] = mfma16(awh[ni], hf, tacc[g]);  // D[rank 4 (lane >> 4) + r][row lane & 15]
+              tacc[g] = mfma16(awl[ni], hf, tacc[g]);
+            }
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);  // patch reads retired before the next block overwrites it
         }
+        if constexpr (EMT) {
+          // the four column waves of this row half add their [128][16] slabs through the patches (4 KiB each: two halves of 64 rows), wave wc finishing
+          // row group wc of each half; lane (row = lane & 15, ranks 4 (lane >> 4) ..) writes 16 B, the wave 1 KiB contiguous
+          float* tp = q->t_partial + ((long)(q->t_tile0 + n0 / BN) * q->M + (m0 + wr * 128)) * 16;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) *reinterpret_cast<f32x4_t*>(patch + gg * 1024 + ln * 16) = tacc[half * 4 + gg];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            BAR();
+            f32x4_t sum4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(smem + EPI_OFF + (wr * 4 + w) * 4096 + wc * 1024 + ln * 16);
+              sum4[0] += t4[0]; sum4[1] += t4[1]; sum4[2] += t4[2]; sum4[3] += t4[3];
+            }
+            *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * 16 + 4 * (ln >> 4)) = sum4;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            BAR();  // the patches are rewritten next (second half / the next tile's epilogue)
+          }
+        }
       };
-      if (ok) {
+      if constexpr (ET) {
+        // launcher contract: whole tiles, no row maps, flags == BIAS | GELU | EMIT_T — every wave of the workgroup is here (the emission has workgroup barriers)
+        epi_done = true;
+        fast_epi(IC<(AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T)>{});
+      } else if (ok) {
         epi_done = true;
         switch (flags) {
           case 0: fast_epi(IC<0>{}); break;
@@ -897,6 +957,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_ge_kernel(AitkGemmArgs p) {
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_ge_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, false>(p, p2); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, true>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_ge_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, false, true>(p, p); }
+// AITK_EPI_EMIT_T (BIAS | GELU launches that also leave the column-tile partials of the consumer's lora_down product)
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_et_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, true>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, true>(p, p2); }
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true, false, false>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true, false, false>(p, p2); }
@@ -907,6 +970,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_conv_kernel(AitkGemmArgs p)
 // outside this kernel's contract (caller falls back to the 2-barrier kernels).
 static int gemm8_contract(const AitkGemmArgs* a) {
   const bool f8 = a->b_scale_mode == 3;
+  if (a->flags & AITK_EPI_EMIT_T) {  // whole tiles (workgroup barriers in the epilogue), the BIAS | GELU form, plain rows
+    if (a->flags != (AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T) || (a->M % BM) || (a->N % BN) || a->c_seg_rows || a->conv_mode || a->b_scale_mode) return 1;
+    if (!a->t_partial || !a->t_p || !a->t_p_lo || (a->t_ldp % 8) || a->t_tile0 < 0 || (((uintptr_t)a->t_p | (uintptr_t)a->t_p_lo | (uintptr_t)a->t_partial) & 15)) return 1;
+  }
   if (a->b_scale_mode && !f8) return 1;
   if (a->conv_mode) {
     // 2-D 3x3 form only, K-tiles inside one tap, the split-slab epilogue stays on the 2-barrier kernel, and the whole image batch (plus
@@ -944,7 +1011,8 @@ static int gemm8_cus() {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const void* kernels[] = {(const void*)gemm_nt_8phase_kernel,        (const void*)gemm_nt_8phase_grouped_kernel,    (const void*)gemm_nt_8phase_f8_kernel,
                              (const void*)gemm_nt_8phase_f8_grouped_kernel, (const void*)gemm_nt_8phase_conv_kernel,       (const void*)gemm_nt_8phase_ge_kernel,
-                             (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel};
+                             (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel,
+                             (const void*)gemm_nt_8phase_et_kernel,         (const void*)gemm_nt_8phase_grouped_et_kernel};
     for (const void* k : kernels)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_OFF + 32768) != hipSuccess) {
         n_cu = 0;
@@ -959,7 +1027,8 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  else if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else {
     const int fe = gemm8_env("AITK_GEMM8_FE", 1);
@@ -985,7 +1054,8 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
   const int tn = (a->N + BN - 1) / BN;
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (gemm8_env("AITK_GEMM8_FE", 1)) hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else hipLaunchKernelGGL(gemm_nt_8phase_grouped_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   return AITK_OK;

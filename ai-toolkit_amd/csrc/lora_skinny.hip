@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // U = k-steps (of 32) whose loads are in flight before the first MFMA.  RB = 1 (one rank-16 adapter, 95 % of the launches of a FLUX
 // step) runs with U = 6: 116 VGPRs -> 4 waves per SIMD -> all 1008 workgroups of a 32256-row launch are resident at once (U = 8 needs
 // 132 VGPRs -> 3 per SIMD -> 768 slots -> a second, one-third-full round).
-template <int RB, int U>
-__global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p) {
+// RAW (aitk_lora_down_raw): the un-scaled fp32 sums go to raw[m][r] instead of T — one more tile of a partial-sum slab that aitk_lora_t_finish turns into T.
+template <int RB, int U, bool RAW = false>
+__global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
   __shared__ __attribute__((aligned(16))) float red[4 * RB * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
@@ -253,10 +254,14 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
-        v[r] = s * c;
+        v[r] = RAW ? s : s * c;
       }
       const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
-      if (m < p.M && rr < p.R) store_t4(p, m, rr, v);
+      if constexpr (RAW) {
+        if (m < p.M && rr < p.R) *reinterpret_cast<f32x4_t*>(raw + (long)m * p.R + rr) = f32x4_t{v[0], v[1], v[2], v[3]};
+      } else {
+        if (m < p.M && rr < p.R) store_t4(p, m, rr, v);
+      }
     }
 }
 
@@ -284,6 +289,15 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
     hipLaunchKernelGGL(lora_down_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
   else
     hipLaunchKernelGGL(lora_down_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
+extern "C" int aitk_lora_down_raw(const AitkLoraDownArgs* a, float* raw, aitk_stream_t stream) {
+  if (!a || !raw || a->M <= 0 || a->K <= 0 || a->R != 16 || (a->K % 32)) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldp % 8) || ((uintptr_t)raw & 15)) return AITK_ERR_ALIGN;
+  if (!a->X || !a->P) return AITK_ERR_ARG;
+  hipLaunchKernelGGL((lora_down16_kernel<1, 6, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
@@ -546,6 +560,17 @@ __global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p,
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] *= c;
   store_t4(p, m, rr, v);
+}
+
+extern "C" int aitk_lora_t_finish(const AitkLoraDownArgs* a, const float* partial, int32_t ntiles, aitk_stream_t stream) {
+  if (!a || !partial || a->M <= 0 || a->R <= 0 || (a->R % 4) || ntiles <= 0) return AITK_ERR_SHAPE;
+  if (!a->T || (a->ldt % 4) || ((uintptr_t)partial & 15)) return AITK_ERR_ALIGN;
+  if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
+  const long nt = (long)a->M * (a->R / 4);
+  hipLaunchKernelGGL(lora_dt_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, partial, (int)ntiles);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
 }
 
 // 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four

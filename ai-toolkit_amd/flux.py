@@ -337,11 +337,14 @@ class FluxTransformer2DModel(FusedGraphBase):
                 ops.ln_mod_fwd(x1, mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], xn2, rows_per_batch=Ss, mean=mean, rstd=rstd)
                 u = self._new(M, 4 * d)
                 hbuf = self._new(M, 4 * d)
-                r["T_ff1"] = self._lin_fwd(ff.net[0].proj, xn2, hbuf, M=M, rows_per_batch=Ss, B=B, flags=EPI_GELU, aux_out=u)
+                em = self._emit_t_plan(ff.net[0].proj, ff.net[2], M=M, N=4 * d)  # ff.net.2's T = gelu(u) A^T from inside the GELU launch
+                r["T_ff1"] = self._lin_fwd(ff.net[0].proj, xn2, hbuf, M=M, rows_per_batch=Ss, B=B, flags=EPI_GELU, aux_out=u,
+                                           emit_t=None if em is None else em["args"])
                 y_ff = self._new(M, d)
                 x2 = self._newr(M, d)
+                T2 = None if em is None else self._emit_t_finish(em, ff.net[2], M=M, rows_per_batch=Ss, B=B, ntiles=em["ntiles"])
                 r["T_ff2"] = self._lin_fwd(ff.net[2], hbuf, x2, M=M, rows_per_batch=Ss, B=B, flags=EPI_GATE_RES,
-                                           aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss)
+                                           aux_out=y_ff, aux_in=x1, gate=mod[:, 5 * d:6 * d], gate_rows=Ss, T=T2)
                 r.update(y_attn=y_attn, x1=x1, mean2=mean, rstd2=rstd, xn2=xn2, u=u, h=None if self._drop_gelu_output(ff.net[2]) else hbuf,
                          y_ff=y_ff)
                 outs[name] = x2
@@ -372,8 +375,10 @@ class FluxTransformer2DModel(FusedGraphBase):
                           for j, lin in enumerate((a.to_q, a.to_k, a.to_v))]
             cat = self._new(Mj, 5 * d)
             u = self._new(Mj, 4 * d)
+            # proj_out's T over its [attn | gelu(mlp)] input: the GELU columns from inside this launch, the attention columns as one more tile below
+            em = self._emit_t_plan(blk.proj_mlp, blk.proj_out, M=Mj, N=4 * d, col0=d, extra_tiles=1)
             r["T_mlp"] = self._lin_fwd(blk.proj_mlp, xn, cat[:, d:], M=Mj, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u,
-                                       T=Tg.get(id(blk.proj_mlp)))
+                                       T=Tg.get(id(blk.proj_mlp)), emit_t=None if em is None else em["args"])
             # q, k: RMSNorm + RoPE into qkv_j; v needs neither and already sits in joint row order: attention reads it where the
             # projection wrote it (the third, copy-only job of qkv_post is gone: 12 KB of HBM traffic per token and layer, both directions)
             qkv_j = self._new(Mj, 2 * d)
@@ -391,8 +396,13 @@ class FluxTransformer2DModel(FusedGraphBase):
                 ops.attn_fwd(qkv_j[:, 0:d], qkv_j[:, d:2 * d], qkv_raw[:, 2 * d:], o_buf, lse, B=B, H=H, S=S, scale=scale)
             y = self._new(Mj, d)
             x_new = self._newr(Mj, d)
+            T_out = None
+            if em is not None:
+                lo_out = blk.proj_out.lora
+                ops.lora_down_raw(cat[:, 0:d], lo_out.sh_down[:, 0:d], em["partial"][em["ntiles"]], p_lo=lo_out.sh_down_lo[:, 0:d], M=Mj)
+                T_out = self._emit_t_finish(em, blk.proj_out, M=Mj, rows_per_batch=S, B=B, ntiles=em["ntiles"] + 1)
             r["T_out"] = self._lin_fwd(blk.proj_out, cat, x_new, M=Mj, rows_per_batch=S, B=B, flags=EPI_GATE_RES,
-                                       aux_out=y, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=S)
+                                       aux_out=y, aux_in=x, gate=mod[:, 2 * d:3 * d], gate_rows=S, T=T_out)
             r.update(mod=mod, x=x, mean=mean, rstd=rstd, xn=xn, qkv_raw=qkv_raw, cat=None if drop else cat, o=o_buf, u=u, qkv_j=qkv_j, lse=lse, y=y)
             if ctx is not None:
                 ctx["sgl"].append(r)

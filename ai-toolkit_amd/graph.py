@@ -405,12 +405,47 @@ class FusedGraphBase(nn.Module):
             out[id(l)] = Tcat[:, c0:c0 + 3 * l.lora.rank_pad]
         return out
 
+    # ------------------------------------------------------------------ T = x A^T of a GELU-fed adapter from inside the producing GEMM (AITK_EPI_EMIT_T)
+    # The inputs of ff.net.2 / ff_context.net.2 / the single blocks' proj_out are GELU outputs: 792 MB per launch at B = 7 that aitk_lora_down reads back
+    # right after the GEMM wrote them (14 ms of the 1.2-s step).  With emit_t the BIAS | GELU launch leaves the per-column-tile partial products instead
+    # (+6 % bytes written next to u and gelu(u)) and aitk_lora_t_finish sums them.  Opt-in (AITK_EMIT_T=1 / model.emit_t = True): see DESIGN.md section 9 for
+    # the measured outcome.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias only; everything else keeps aitk_lora_down.
+    emit_t = os.environ.get("AITK_EMIT_T", "0") != "0"
+
+    def _emit_t_plan(self, producer, consumer, *, M, N, col0=0, extra_tiles=0):
+        """None, or the state of one emission: consumer's lora_down product over its input columns [col0, col0 + N) is left by `producer`'s GELU launch as
+        N / 256 tiles of a [tiles + extra_tiles, M, 16] fp32 slab (extra tiles: parts of the consumer's input that come from elsewhere, aitk_lora_down_raw)."""
+        ops, net = self.ops, self.network
+        if not self.emit_t or not hasattr(ops, "lora_t_finish") or not self._lora_active(consumer):
+            return None
+        lo = consumer.lora
+        rt = getattr(ops, "EMIT_T_ROW_TILE", 256)
+        if lo.is_lokr or lo.magnitude is not None or lo.rank_pad != 16 or (net.training and net.has_dropout) or M % rt or N % 256:
+            return None
+        pl = producer.lora if self._lora_active(producer) else None
+        if producer.bias is None or (pl is not None and (pl.is_lokr or pl.magnitude is not None)) or (producer.qweight is not None and self.fp8_mfma):
+            return None
+        ntiles = N // 256
+        nbytes = (ntiles + extra_tiles) * M * 16 * 4
+        ws = ops.workspace(nbytes, self._device(), f"emit_t{getattr(self, '_dq_slot', 0)}")  # the two merged streams of _paired must not share it
+        partial = ws[:nbytes // 4].view(ntiles + extra_tiles, M, 16)
+        return {"partial": partial, "ntiles": ntiles, "args": (lo.sh_down[:, col0:col0 + N], lo.sh_down_lo[:, col0:col0 + N], partial, 0)}
+
+    def _emit_t_finish(self, plan, consumer, *, M, rows_per_batch, B, ntiles):
+        lo = consumer.lora
+        T = self._new(M, 3 * lo.rank_pad)
+        mult, rpb = self._mult(rows_per_batch, B)
+        self.ops.lora_t_finish(plan["partial"], ntiles, T, scale=lo.scale, mult=mult, rows_per_batch=rpb, split=lo.rank_pad, M=M)
+        return T
+
     def _lin_fwd(self, lin, x, out, *, M, rows_per_batch, B, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-                 a_seg=None, c_seg=None, T=None):
+                 a_seg=None, c_seg=None, T=None, emit_t=None):
         """out = epi(x W^T + b + T B^T); returns T (saved for the weight gradient) or None.  A precomputed T (group
-        launch) may be passed in."""
+        launch) may be passed in.  emit_t: _emit_t_plan(...)["args"] — the launch also emits the consumer layer's lora_down partials."""
         ops = self.ops
         kw = {}
+        if emit_t is not None:
+            kw["emit_t"] = emit_t
         if self._lora_active(lin) and lin.lora.is_lokr:
             # LoKr: the Kronecker delta is written into the destination first, the base GEMM then accumulates onto it BEFORE its
             # activation / gate epilogue (ACCUM precedes GELU / GATE_RES in the epilogue order)
@@ -447,7 +482,7 @@ class FusedGraphBase(nn.Module):
                               p_lo=lo.sh_down_lo, split=lo.rank_pad, tmask=tm, tmask_rows_per_batch=tm_rpb)
                 if plan is not None:
                     T._tmask = plan  # the gradient of the masked activation takes the same mask (_lora_grads)
-            kw = dict(a2=T, b2=lo.sh_up3)  # [T_hi | T_lo | T_hi] . [B_hi | B_hi | B_lo]^T: the fp32 adapter product to 2^-17
+            kw.update(a2=T, b2=lo.sh_up3)  # [T_hi | T_lo | T_hi] . [B_hi | B_hi | B_lo]^T: the fp32 adapter product to 2^-17
             if lo.magnitude is not None:  # DoRA: y = c * (x W^T + T B^T) + b; the linear output is kept for d magnitude
                 kw["col_scale"] = lo.c
                 if (flags & EPI_GATE_RES) and aux_out is None:

@@ -131,7 +131,7 @@ def _row_major(t, name):
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None,
             gate_rows=0, a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0,
-            col_scale=None, a_scale=None):
+            col_scale=None, a_scale=None, emit_t=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T + a2[M,K2] @ b2[N,K2]^T + bias).
     b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA): a AND b are e4m3 bytes, out = epi(a_scale[m] b_scale[n] (a b^T) + a2 b2^T + bias);
     a_scale fp32 [M] comes from quant_rows_fp8, b_scale fp32 [N] (or None = 1) is the weight's per-channel scale.
@@ -193,6 +193,17 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
         assert col_scale.dtype == torch.float32 and col_scale.is_contiguous() and col_scale.numel() == N
         g.col_scale = _ptr(col_scale)
         flags |= _capi.EPI_COL_SCALE
+    if emit_t is not None:
+        # AITK_EPI_EMIT_T: (p_hi [16, >= N] view, p_lo likewise, partial fp32 [tiles, M, 16], first tile slot) — the BIAS | GELU launch also leaves
+        # the column-tile partials of `gelu output @ (p_hi + p_lo)^T` (the consumer layer's lora_down product); lora_t_finish turns them into T
+        p_hi, p_lo, partial, tile0 = emit_t
+        assert flags == (EPI_BIAS | EPI_GELU) and M % 256 == 0 and N % 256 == 0 and a_seg is None and c_seg is None and not b_scale_mode
+        assert p_hi.dtype == BF16 and p_lo.dtype == BF16 and p_hi.shape[0] == 16 and p_hi.shape[1] >= N and p_hi.stride(1) == 1
+        assert p_lo.shape == p_hi.shape and p_lo.stride() == p_hi.stride()
+        assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.dim() == 3 and partial.shape[1] == M and partial.shape[2] == 16
+        assert partial.shape[0] >= tile0 + N // 256
+        g.t_partial, g.t_p, g.t_p_lo, g.t_ldp, g.t_tile0 = _ptr(partial), _ptr(p_hi), _ptr(p_lo), p_hi.stride(0), int(tile0)
+        flags |= _capi.EPI_EMIT_T
     g.M, g.N, g.K, g.flags = M, N, K, flags
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
     g.tile_mode = TILE_MODE if tile_mode is None else tile_mode
@@ -286,6 +297,46 @@ def _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo,
     a.scale = float(scale)
     a.M, a.K, a.R = (x.shape[0] if M is None else M), K, R
     _call("aitk_lora_down", C.byref(a))
+    return out
+
+
+def lora_down_raw(x, pmat, raw, *, p_lo=None, x_seg=None, M=None):
+    """raw [M, 16] fp32 = x[M, K] @ (pmat + p_lo)[16, K]^T, un-scaled: one tile of a partial-sum slab (aitk_lora_down_raw)."""
+    a = _capi.LoraDownArgs()
+    a.ldx, a.ldp = _row_major(x, "x"), _row_major(pmat, "pmat")
+    R, K = pmat.shape
+    assert R == 16 and x.shape[1] == K and K % 32 == 0
+    M = x.shape[0] if M is None else M
+    assert raw.dtype == torch.float32 and raw.is_contiguous() and tuple(raw.shape) == (M, 16)
+    a.X, a.P = _ptr(x), _ptr(pmat)
+    if p_lo is not None:
+        assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == a.ldp
+        a.P_lo = _ptr(p_lo)
+    if x_seg is not None:
+        a.x_seg_rows, a.x_seg_stride = x_seg
+    a.scale, a.M, a.K, a.R = 1.0, M, K, R
+    _call("aitk_lora_down_raw", C.byref(a), _ptr(raw))
+    return raw
+
+
+def lora_t_finish(partial, ntiles, out, *, scale=1.0, mult=None, rows_per_batch=0, split=0, tmask=None, tmask_rows_per_batch=0, M=None):
+    """out = what lora_down writes (scale, mult, tmask; plain [M, R] or the [hi | lo | hi] slab) from the sum of the first `ntiles` tiles of
+    partial fp32 [tiles, M, R], in tile order (aitk_lora_t_finish)."""
+    a = _capi.LoraDownArgs()
+    R = partial.shape[2]
+    M = partial.shape[1] if M is None else M
+    assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.shape[1] == M and 0 < ntiles <= partial.shape[0]
+    assert out.shape[1] == (3 * R if split else R)
+    a.ldt, a.T = _row_major(out, "out"), _ptr(out)
+    a.split_rp, a.scale = int(split), float(scale)
+    if tmask is not None:
+        assert tmask.dtype == torch.float32 and tmask.is_contiguous() and tmask.shape[1] == R
+        a.tmask, a.tmask_rows_per_batch = _ptr(tmask), int(tmask_rows_per_batch)
+    if mult is not None:
+        assert mult.dtype == torch.float32 and mult.is_contiguous()
+        a.mult, a.rows_per_batch = _ptr(mult), rows_per_batch
+    a.M, a.K, a.R = M, 0, R
+    _call("aitk_lora_t_finish", C.byref(a), _ptr(partial), int(ntiles))
     return out
 
 

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 9 /* 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 10 /* 10: AITK_EPI_EMIT_T + AitkGemmArgs.t_* (a GELU launch emits the column-tile partials of the NEXT layer's lora_down product), aitk_lora_t_finish, aitk_lora_down_raw; 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -40,6 +40,11 @@ typedef uint16_t aitk_bf16;
                                   [hi(rp) | lo(rp) | hi(rp)] (C is [M, >= 3 rp]) — lora_down of a 3x3-conv adapter
                                   (toolkit/lora_special.py:95-104) on the implicit-GEMM kernel; only COL_SCALE may accompany it */
 #define AITK_EPI_COL_SCALE 128 /* product * col_scale[n] before the bias: DoRA magnitude / ||W + dW||_row (toolkit/models/DoRA.py:126-148) */
+#define AITK_EPI_EMIT_T 512 /* with BIAS | GELU only (opt-in, rank 16): the launch also leaves, per 256-column tile, the fp32 partial product of ITS OUTPUT with the
+                              lora_down matrix of the layer that consumes it — t_partial[t_tile0 + n / 256][m][0..15] = sum over the tile's columns of
+                              gelu(u)[m][n] * (t_p + t_p_lo)[r][n] on the bf16 value it stores — so that the consumer's T = x A^T (toolkit/network_mixins.py:309-321:
+                              lora_down on the layer input) needs no second pass over the 792-MB GELU output: aitk_lora_t_finish sums the tiles.  Persistent
+                              8-phase kernel only: M % 256 == 0, N % 256 == 0, no row maps; anything else is AITK_ERR_SHAPE (the caller keeps aitk_lora_down). */
 
 /*
  * C[M,N] = epi( A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T + bias )       (bf16 in/out, fp32 accumulate)
@@ -83,6 +88,9 @@ typedef struct AitkGemmArgs {
    * i.e. per-token dynamic activation quantisation (aitk_quant_rows_fp8) against per-output-channel weight scales; the rank-r LoRA slab
    * A2 B2^T stays bf16 (split hi + lo) and is added un-scaled.  Persistent 8-phase kernel only (any M, N % 8 == 0, K % 16 == 0). */
   const float* a_scale;
+  /* AITK_EPI_EMIT_T: t_partial fp32 [tiles][M][16]; t_p / t_p_lo = bf16 hi / lo shadows of the consumer's lora_down rows, indexed by THIS launch's output
+   * column (row stride t_ldp elements, 16-byte aligned; a column window of a wider matrix is a pointer offset); t_tile0 = first tile slot of this launch */
+  float* t_partial; const aitk_bf16* t_p; const aitk_bf16* t_p_lo; int64_t t_ldp; int32_t t_tile0; int32_t _pad5;
 } AitkGemmArgs;
 
 /* Per-token (per-row) dynamic fp8 quantisation of a GEMM A operand for b_scale_mode 3:
@@ -140,6 +148,13 @@ typedef struct AitkLoraDownArgs {
   const float* tmask; int32_t tmask_rows_per_batch; int32_t _pad1;
 } AitkLoraDownArgs;
 int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
+/* The two halves of aitk_lora_down around a partial-sum slab [tiles][M][R] fp32 (AITK_EPI_EMIT_T fills tiles from inside the producing GEMM):
+ *   aitk_lora_down_raw: raw[m][r] = sum_k X[m][k] (P + P_lo)[r][k]  — one more tile, un-scaled, nothing written to T (R = 16, K % 32 == 0): the part of
+ *     a consumer's input that did NOT come out of an emitting launch (the attention half of the single blocks' [attn | gelu(mlp)] operand);
+ *   aitk_lora_t_finish: T[m] = what aitk_lora_down writes (scale, mult, tmask, plain or [hi | lo | hi] slab) from the sum of `ntiles` tiles, fixed order.
+ * X / P / ldx / K of the finish call are ignored. */
+int aitk_lora_down_raw(const AitkLoraDownArgs* args, float* raw, aitk_stream_t stream);
+int aitk_lora_t_finish(const AitkLoraDownArgs* args, const float* partial, int32_t ntiles, aitk_stream_t stream);
 
 /*
  * out[r * out_stride_r + l * out_stride_l] (+)= sum_m S[m][r] * G[m][l]        fp32 out, R in {16,32,48,64}, L % 8 == 0

@@ -41,6 +41,19 @@ def rows_per_block():
     return 16
 
 
+EMIT_T_ROW_TILE = 1  # AITK_EPI_EMIT_T needs whole 256-row tiles on the HIP kernel; this table takes any row count (tiny CPU models exercise the graph path)
+_ws = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """grow-only fp32 scratch, like ai_toolkit_amd.ops.workspace"""
+    key = (tag, str(device))
+    n = (nbytes + 3) // 4
+    if key not in _ws or _ws[key].numel() < n:
+        _ws[key] = torch.empty(n, dtype=torch.float32, device=device)
+    return _ws[key]
+
+
 def quant_rows_fp8(x, q, row_scale, *, col_mul=None, x_seg=None, M=None):
     """Per-token dynamic e4m3 quantisation (the A operand of the W8A8 GEMM, b_scale_mode 3): row_scale = amax / 448 (IEEE division),
     q = e4m3(x * col_mul * (1 / row_scale)), round-to-nearest-even — the standard per-token activation recipe of fp8 training stacks;
@@ -58,7 +71,7 @@ def quant_rows_fp8(x, q, row_scale, *, col_mul=None, x_seg=None, M=None):
 
 
 def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, aux_in=None, gate=None, gate_rows=0,
-            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0, col_scale=None, a_scale=None):
+            a_seg=None, c_seg=None, M=None, stage_mode=None, tile_mode=None, b_scale=None, b_scale_mode=0, col_scale=None, a_scale=None, emit_t=None):
     """org Linear + LoRA up-projection + epilogue (toolkit/network_mixins.py:304-342).  b_scale: weight-only fp8 base,
     dequantised as (fp8 * scale) rounded to the activation dtype (quanto / torchao weight-only semantics)."""
     if M is None:
@@ -89,6 +102,13 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
     if flags & EPI_GELU:
         aux_out[:M].copy_(v.to(aux_out.dtype))
         v = F.gelu(aux_out[:M].float(), approximate="tanh")
+        if emit_t is not None:  # AITK_EPI_EMIT_T: per 256-column tile, the stored GELU values against the consumer's lora_down rows (hi + lo shadows)
+            p_hi, p_lo, partial, tile0 = emit_t
+            hq = v.to(out.dtype).float()
+            N = b.shape[0]
+            P = (p_hi.float() + p_lo.float())[:, :N]
+            for t in range(N // 256):
+                partial[tile0 + t, :M].copy_(hq[:, t * 256:(t + 1) * 256] @ P[:, t * 256:(t + 1) * 256].t())
     if flags & EPI_DGELU:
         u = aux_in[:M].float().requires_grad_(True)
         with torch.enable_grad():
@@ -129,6 +149,39 @@ def lora_down(x, pmat, out, *, scale=1.0, mult=None, rows_per_batch=0, x_seg=Non
     hi = v.to(out.dtype)
     lo = (v - hi.float()).to(out.dtype)
     c_hi, c_lo, c_hi2 = _split_cols(pmat.shape[0], split)
+    out[:M, c_hi] = hi
+    out[:M, c_lo] = lo
+    out[:M, c_hi2] = hi
+    return out
+
+
+def lora_down_raw(x, pmat, raw, *, p_lo=None, x_seg=None, M=None):
+    """un-scaled fp32 x @ (pmat + p_lo)^T: one tile of a partial-sum slab (include/aitk_mi355.h aitk_lora_down_raw)."""
+    if M is None:
+        M = x.shape[0]
+    P = pmat.float() if p_lo is None else pmat.float() + p_lo.float()
+    raw[:M].copy_(_seg_view(x, x_seg, M).float() @ P.t())
+    return raw
+
+
+def lora_t_finish(partial, ntiles, out, *, scale=1.0, mult=None, rows_per_batch=0, split=0, tmask=None, tmask_rows_per_batch=0, M=None):
+    """T from the sum of the partial tiles (tile order), written as lora_down writes it (toolkit/network_mixins.py:309-318 on the summed product)."""
+    M = partial.shape[1] if M is None else M
+    R = partial.shape[2]
+    v = torch.zeros(M, R, dtype=torch.float32, device=partial.device)
+    for t in range(ntiles):
+        v = v + partial[t, :M]
+    v = v * scale
+    if mult is not None:
+        v = v * mult.repeat_interleave(rows_per_batch)[:M, None]
+    if tmask is not None:
+        v = v * (tmask.repeat_interleave(tmask_rows_per_batch, 0)[:M] if tmask_rows_per_batch else tmask[:M])
+    if not split:
+        out[:M].copy_(v.to(out.dtype))
+        return out
+    hi = v.to(out.dtype)
+    lo = (v - hi.float()).to(out.dtype)
+    c_hi, c_lo, c_hi2 = _split_cols(R, split)
     out[:M, c_hi] = hi
     out[:M, c_lo] = lo
     out[:M, c_hi2] = hi

@@ -58,7 +58,7 @@ def test_gemm8_k_loops_carry_only_the_counted_vmcnt_waits(tmp_path):
                     assert not bad, f"{m.group(1)}: compiler-inserted vmcnt{bad} inside a {stretch_mfma}-MFMA stretch"
                 stretch_mfma, stretch_waits = 0, []
                 continue
-            if ins.startswith("v_mfma"):
+            if ins.startswith("v_mfma_f32_32x32") or ins.startswith("v_mfma_scale_f32_32x32"):  # the K loops' tile products (the EMIT_T epilogue's 16x16x32 products wait for their operand loads: not a K loop)
                 stretch_mfma += 1
             w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", ins)
             if w:
