@@ -799,7 +799,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
             }
             *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * 16 + 4 * (ln >> 4)) = sum4;
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            BAR();  // the patches are rewritten next (second half / the next tile's epilogue)
+            if (half == 0) BAR();  // the patches are rewritten by the second half; after it, the next writer is the next tile's epilogue, behind the K loop's barriers
           }
         }
       };

@@ -408,9 +408,10 @@ class FusedGraphBase(nn.Module):
     # ------------------------------------------------------------------ T = x A^T of a GELU-fed adapter from inside the producing GEMM (AITK_EPI_EMIT_T)
     # The inputs of ff.net.2 / ff_context.net.2 / the single blocks' proj_out are GELU outputs: 792 MB per launch at B = 7 that aitk_lora_down reads back
     # right after the GEMM wrote them (14 ms of the 1.2-s step).  With emit_t the BIAS | GELU launch leaves the per-column-tile partial products instead
-    # (+6 % bytes written next to u and gelu(u)) and aitk_lora_t_finish sums them.  Opt-in (AITK_EMIT_T=1 / model.emit_t = True): see DESIGN.md section 9 for
-    # the measured outcome.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias only; everything else keeps aitk_lora_down.
-    emit_t = os.environ.get("AITK_EMIT_T", "0") != "0"
+    # (+6 % bytes written next to u and gelu(u)) and aitk_lora_t_finish sums them: step 1198.5 -> 1190.1 ms same box (profiles/r06_ab_emit_t.txt).  Default;
+    # AITK_EMIT_T=0 / model.emit_t = False turns it off.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias, whole
+    # 256-row tiles only; everything else keeps aitk_lora_down.
+    emit_t = os.environ.get("AITK_EMIT_T", "1") != "0"
 
     def _emit_t_plan(self, producer, consumer, *, M, N, col0=0, extra_tiles=0):
         """None, or the state of one emission: consumer's lora_down product over its input columns [col0, col0 + N) is left by `producer`'s GELU launch as

@@ -280,10 +280,13 @@ class WanTransformer3DModel(FusedGraphBase):
             ops.ln_mod_fwd(x2, mod[:, 3 * d:4 * d], mod[:, 4 * d:5 * d], xn3, rows_per_batch=S, mean=mean3, rstd=rstd3, eps=eps)
             ffn_dim = blk.ffn.net[0].proj.out_features
             u, hbuf = self._new(M, ffn_dim), self._new(M, ffn_dim)
-            r["T_ff1"] = self._lin_fwd(blk.ffn.net[0].proj, xn3, hbuf, M=M, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u)
+            em = self._emit_t_plan(blk.ffn.net[0].proj, blk.ffn.net[2], M=M, N=ffn_dim)  # ffn.net.2's T = gelu(u) A^T from inside the GELU launch (graph.py)
+            r["T_ff1"] = self._lin_fwd(blk.ffn.net[0].proj, xn3, hbuf, M=M, rows_per_batch=S, B=B, flags=EPI_GELU, aux_out=u,
+                                       emit_t=None if em is None else em["args"])
             x3 = self._new(M, d)
+            T2 = None if em is None else self._emit_t_finish(em, blk.ffn.net[2], M=M, rows_per_batch=S, B=B, ntiles=em["ntiles"])
             r["T_ff2"] = self._lin_fwd(blk.ffn.net[2], hbuf, x3, M=M, rows_per_batch=S, B=B, flags=EPI_GATE_RES, aux_in=x2,
-                                       gate=mod[:, 5 * d:6 * d], gate_rows=S)
+                                       gate=mod[:, 5 * d:6 * d], gate_rows=S, T=T2)
             if ctx is not None:
                 r.update(mod=mod, x=x, mean1=mean1, rstd1=rstd1, xn=xn, qk_raw=qk_raw, qkv=qkv, o1=o1, lse1=lse1, x1=x1,
                          mean2=mean2, rstd2=rstd2, xn2=xn2, q2_raw=q2_raw, q2=q2, k2_raw=k2_raw, kv2=kv2, o2=o2, lse2=lse2,

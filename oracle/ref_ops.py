@@ -41,7 +41,7 @@ def rows_per_block():
     return 16
 
 
-EMIT_T_ROW_TILE = 1  # AITK_EPI_EMIT_T needs whole 256-row tiles on the HIP kernel; this table takes any row count (tiny CPU models exercise the graph path)
+EMIT_T_ROW_TILE = 256  # AITK_EPI_EMIT_T: whole 256-row tiles, as on the HIP kernel (the graphs ask the table); tests/test_emit_t_cpu.py lowers it to 1 so that tiny CPU models walk the route
 _ws = {}
 
 

@@ -165,7 +165,7 @@ def test_fp8_weight_only_base_matches_oracle_with_dequantised_weights():
         pred_ref.square().sum().backward()
     with net:
         pred = nat.forward_native(hidden, enc, pooled, t, img_ids, txt_ids, guid)
-        assert torch.allclose(pred, pred_ref, rtol=1e-4, atol=1e-5)
+        assert (pred - pred_ref).abs().max().item() <= 2e-6 * pred_ref.abs().max().item(), (pred - pred_ref).abs().max().item()  # fp32: summation order only (scale of the tensor: ~30)
         net.zero_grad_arena()
         nat.dgrad_census(reset=True)
         nat.backward_native((2 * pred).detach())
