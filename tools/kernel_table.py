@@ -17,7 +17,9 @@ def main():
     bench = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
     steps = next(int(r["Calls"]) for r in rows if "attn_fwd_kernel" in r["Name"]) / 57.0
     gemm_flops = bench["roofline"]["achieved"] * 1e12 * bench["roofline"]["gemm_ms_per_step"] * 1e-3
-    fam = [("gemm_nt_8phase_grouped_kernel", "LoRA-fused GEMM, persistent 8-phase, image+text stream grouped", None),
+    fam = [("gemm_nt_8phase_grouped_et_kernel", "LoRA-fused GEMM, grouped, BIAS + GELU launches that also emit the next layer's lora_down partials (AITK_EPI_EMIT_T)", None),
+           ("gemm_nt_8phase_et_kernel", "LoRA-fused GEMM, BIAS + GELU launches that also emit the next layer's lora_down partials (AITK_EPI_EMIT_T)", None),
+           ("gemm_nt_8phase_grouped_kernel", "LoRA-fused GEMM, persistent 8-phase, image+text stream grouped", None),
            ("gemm_nt_8phase_kernel", "LoRA-fused GEMM, persistent 8-phase", None),
            ("gemm_nt_kernel", "LoRA-fused GEMM, 128x128 / other", None),
            ("attn_bwd_dkdv", "attention backward dK, dV (4 matmuls; wave-specialised kernel at head_dim 128: 8 waves, two per SIMD; round 6: also emits its bf16 dS, 7.1 GB per launch)", 8 * PAIR),
