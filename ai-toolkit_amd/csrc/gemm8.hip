@@ -618,6 +618,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         s16x8_t awh[2], awl[2];
         f32x4_t tacc[8];
         int bperm_src = 0;
+        const int m_rows = EMT ? q->M : 0;
         if constexpr (EMT) {
           const long aoff = (long)(ln & 15) * q->t_ldp + (n0 + wc * 64) + (ln >> 4) * 8;
 #pragma unroll
@@ -707,6 +708,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 #pragma unroll
           for (int it = 0; it < 2; ++it) {
             const int g = 2 * mi + it, r = it * 16 + rr;
+            const bool row_in = !EMT || (mw + 16 * g + rr < m_rows);
             const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4) ^ (r & 7)) << 4));
             const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(patch + r * 128 + (((2 * c4 + 1) ^ (r & 7)) << 4));
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -730,7 +732,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
             if constexpr (GELU) {
               // u = bf16(pre-activation) is saved for backward; h = gelu_tanh(u) on the rounded value: the packed words ARE the rounded values
               const uint4 w = pack8f(v);
-              *reinterpret_cast<uint4*>(Ob + ((long)(mw + 16 * g) * ldo) * 2 + lofO + ni * 64) = w;
+              if (!EMT || row_in)  // EMT launches may end in a ragged row tile (every wave walks the whole epilogue: workgroup barriers): stores are per-row predicated
+                *reinterpret_cast<uint4*>(Ob + ((long)(mw + 16 * g) * ldo) * 2 + lofO + ni * 64) = w;
               float u8[8];
               unpack8f(w, u8);
 #pragma unroll
@@ -767,7 +770,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               for (int e = 0; e < 8; ++e) v[e] = r8[e] + g8[e] * y8[e];
             }
             const uint4 cw = pack8f(v);
-            *reinterpret_cast<uint4*>(crow) = cw;
+            if (!EMT || row_in) *reinterpret_cast<uint4*>(crow) = cw;
             if constexpr (EMT) {
               v4i hb;
               hb.x = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.x);
@@ -784,7 +787,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         if constexpr (EMT) {
           // the four column waves of this row half add their [128][16] slabs through the patches (4 KiB each: two halves of 64 rows), wave wc finishing
           // row group wc of each half; lane (row = lane & 15, ranks 4 (lane >> 4) ..) writes 16 B, the wave 1 KiB contiguous
-          float* tp = q->t_partial + ((long)(q->t_tile0 + n0 / BN) * q->M + (m0 + wr * 128)) * 16;
+          float* tp = q->t_partial + ((long)(q->t_tile0 + n0 / BN) * m_rows + (m0 + wr * 128)) * 16;
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -797,14 +800,16 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(smem + EPI_OFF + (wr * 4 + w) * 4096 + wc * 1024 + ln * 16);
               sum4[0] += t4[0]; sum4[1] += t4[1]; sum4[2] += t4[2]; sum4[3] += t4[3];
             }
-            *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * 16 + 4 * (ln >> 4)) = sum4;
+            if (m0 + wr * 128 + (half * 4 + wc) * 16 + (ln & 15) < m_rows)
+              *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * 16 + 4 * (ln >> 4)) = sum4;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             if (half == 0) BAR();  // the patches are rewritten by the second half; after it, the next writer is the next tile's epilogue, behind the K loop's barriers
           }
         }
       };
       if constexpr (ET) {
-        // launcher contract: whole tiles, no row maps, flags == BIAS | GELU | EMIT_T — every wave of the workgroup is here (the emission has workgroup barriers)
+        // launcher contract: whole column tiles, no row maps, flags == BIAS | GELU | EMIT_T — every wave of the workgroup is here (the emission has workgroup
+        // barriers), also the waves of a ragged last row tile: their rows beyond M compute on clamped operand rows and store nothing
         epi_done = true;
         fast_epi(IC<(AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T)>{});
       } else if (ok) {
@@ -970,8 +975,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_conv_kernel(AitkGemmArgs p)
 // outside this kernel's contract (caller falls back to the 2-barrier kernels).
 static int gemm8_contract(const AitkGemmArgs* a) {
   const bool f8 = a->b_scale_mode == 3;
-  if (a->flags & AITK_EPI_EMIT_T) {  // whole tiles (workgroup barriers in the epilogue), the BIAS | GELU form, plain rows
-    if (a->flags != (AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T) || (a->M % BM) || (a->N % BN) || a->c_seg_rows || a->conv_mode || a->b_scale_mode) return 1;
+  if (a->flags & AITK_EPI_EMIT_T) {  // whole column tiles (the wave's 64 columns), any row count (stores predicated per row), the BIAS | GELU form, plain rows
+    if (a->flags != (AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T) || (a->N % BN) || a->c_seg_rows || a->conv_mode || a->b_scale_mode) return 1;
     if (!a->t_partial || !a->t_p || !a->t_p_lo || (a->t_ldp % 8) || a->t_tile0 < 0 || (((uintptr_t)a->t_p | (uintptr_t)a->t_p_lo | (uintptr_t)a->t_partial) & 15)) return 1;
   }
   if (a->b_scale_mode && !f8) return 1;

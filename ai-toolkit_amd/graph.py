@@ -409,8 +409,8 @@ class FusedGraphBase(nn.Module):
     # The inputs of ff.net.2 / ff_context.net.2 / the single blocks' proj_out are GELU outputs: 792 MB per launch at B = 7 that aitk_lora_down reads back
     # right after the GEMM wrote them (14 ms of the 1.2-s step).  With emit_t the BIAS | GELU launch leaves the per-column-tile partial products instead
     # (+6 % bytes written next to u and gelu(u)) and aitk_lora_t_finish sums them: step 1198.5 -> 1190.1 ms same box (profiles/r06_ab_emit_t.txt).  Default;
-    # AITK_EMIT_T=0 / model.emit_t = False turns it off.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias, whole
-    # 256-row tiles only; everything else keeps aitk_lora_down.
+    # AITK_EMIT_T=0 / model.emit_t = False turns it off.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias, N % 256 == 0
+    # (any row count on the HIP kernel; the oracle table keeps whole 256-row tiles so that the committed CPU fixtures stay put); everything else keeps aitk_lora_down.
     emit_t = os.environ.get("AITK_EMIT_T", "1") != "0"
 
     def _emit_t_plan(self, producer, consumer, *, M, N, col0=0, extra_tiles=0):

@@ -44,7 +44,7 @@ typedef uint16_t aitk_bf16;
                               lora_down matrix of the layer that consumes it — t_partial[t_tile0 + n / 256][m][0..15] = sum over the tile's columns of
                               gelu(u)[m][n] * (t_p + t_p_lo)[r][n] on the bf16 value it stores — so that the consumer's T = x A^T (toolkit/network_mixins.py:309-321:
                               lora_down on the layer input) needs no second pass over the 792-MB GELU output: aitk_lora_t_finish sums the tiles.  Persistent
-                              8-phase kernel only: M % 256 == 0, N % 256 == 0, no row maps; anything else is AITK_ERR_SHAPE (the caller keeps aitk_lora_down). */
+                              8-phase kernel only: N % 256 == 0 (any M), no row maps; anything else is AITK_ERR_SHAPE (the caller keeps aitk_lora_down). */
 
 /*
  * C[M,N] = epi( A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T + bias )       (bf16 in/out, fp32 accumulate)
