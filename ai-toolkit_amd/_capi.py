@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
         ("b_scale", vp), ("b_scale_mode", i32), ("_pad4", i32),
         ("col_scale", vp),
         ("a_scale", vp),
-        ("t_partial", vp), ("t_p", vp), ("t_p_lo", vp), ("t_ldp", i64), ("t_tile0", i32), ("_pad5", i32),
+        ("t_partial", vp), ("t_p", vp), ("t_p_lo", vp), ("t_ldp", i64), ("t_tile0", i32), ("t_rank", i32),
     ]
 
 

@@ -111,9 +111,9 @@ __device__ unsigned g_gemm8_trace[2 * 2 * 3 * 5];
 // permutation through ds_bpermute) and two matrix instructions (hi and lo shadow) add into 8 x 4 accumulator registers = the wave's 128 rows x 16
 // ranks over its 64 columns; the four waves of a row half then sum their slabs through the (idle) epilogue patches in a fixed order and write ONE
 // [128 rows][16] fp32 slab per workgroup row half and 256-column tile.  Needs whole tiles (every wave takes part in the workgroup barriers).
-template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, bool ET = false>
+template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, int ET = 0>  // ET = 16-rank blocks of the emitted product (0: no emission)
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
-  static_assert(!ET || (FE && !F8 && !CV), "EMIT_T: bf16 fast-epilogue kernels only");
+  static_assert(ET == 0 || (FE && !F8 && !CV && ET <= 2), "EMIT_T: bf16 fast-epilogue kernels only, rank 16 or 32");
   static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
   constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
@@ -610,24 +610,30 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         constexpr bool BIAS = (FL & AITK_EPI_BIAS) != 0, GELU = (FL & AITK_EPI_GELU) != 0, DGELU = (FL & AITK_EPI_DGELU) != 0;
         constexpr bool GATE = (FL & AITK_EPI_GATE_RES) != 0, ADDA = (FL & AITK_EPI_ADD_AUX) != 0, ACC = (FL & AITK_EPI_ACCUM) != 0;
         constexpr bool RD_IN = DGELU || GATE || ADDA;  // reads aux_in
-        constexpr bool EMT = ET && (FL & AITK_EPI_EMIT_T) != 0;
+        constexpr bool EMT = ET > 0 && (FL & AITK_EPI_EMIT_T) != 0;
+        constexpr int ERB = ET > 0 ? ET : 1;  // 16-rank blocks of the emitted product
         static_assert(!EMT || (GELU && !RD_IN && !ACC), "EMIT_T rides on the BIAS | GELU form");
         int ln = lane;
         asm volatile("" : "+v"(ln));
         // EMT: the consumer's lora_down rows over this wave's 64 columns, in the A-operand layout (rank = lane & 15, 8-column chunk = lane >> 4), hi and lo
-        s16x8_t awh[2], awl[2];
-        f32x4_t tacc[8];
+        s16x8_t awh[2][ERB], awl[2][ERB];
+        f32x4_t tacc[8][ERB];
         int bperm_src = 0;
         const int m_rows = EMT ? q->M : 0;
         if constexpr (EMT) {
-          const long aoff = (long)(ln & 15) * q->t_ldp + (n0 + wc * 64) + (ln >> 4) * 8;
+          const long ldp = q->t_ldp;
+          const long aoff = (long)(ln & 15) * ldp + (n0 + wc * 64) + (ln >> 4) * 8;
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            awh[ni] = *reinterpret_cast<const s16x8_t*>(q->t_p + aoff + ni * 32);
-            awl[ni] = *reinterpret_cast<const s16x8_t*>(q->t_p_lo + aoff + ni * 32);
-          }
+          for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-          for (int g = 0; g < 8; ++g) tacc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int rb = 0; rb < ERB; ++rb) {
+              awh[ni][rb] = *reinterpret_cast<const s16x8_t*>(q->t_p + aoff + rb * 16 * ldp + ni * 32);
+              awl[ni][rb] = *reinterpret_cast<const s16x8_t*>(q->t_p_lo + aoff + rb * 16 * ldp + ni * 32);
+            }
+#pragma unroll
+          for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int rb = 0; rb < ERB; ++rb) tacc[g][rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           bperm_src = ((((ln & 15) << 2) | (ln >> 4)) << 2);  // ds_bpermute byte address: this lane takes the words of lane (row << 2 | chunk)
         }
         char* patch = smem + EPI_OFF + (tid >> 6) * 4096;
@@ -778,8 +784,11 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               hb.z = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.z);
               hb.w = __builtin_amdgcn_ds_bpermute(bperm_src, (int)cw.w);
               const s16x8_t hf = __builtin_bit_cast(s16x8_t, hb);
-              tacc[g] = mfma16(awh[ni], hf, tacc[g]);  // D[rank 4 (lane >> 4) + r][row lane & 15]
-              tacc[g] = mfma16(awl[ni], hf, tacc[g]);
+#pragma unroll
+              for (int rb = 0; rb < ERB; ++rb) {
+                tacc[g][rb] = mfma16(awh[ni][rb], hf, tacc[g][rb]);  // D[rank 16 rb + 4 (lane >> 4) + r][row lane & 15]
+                tacc[g][rb] = mfma16(awl[ni][rb], hf, tacc[g][rb]);
+              }
             }
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);  // patch reads retired before the next block overwrites it
@@ -787,11 +796,14 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         if constexpr (EMT) {
           // the four column waves of this row half add their [128][16] slabs through the patches (4 KiB each: two halves of 64 rows), wave wc finishing
           // row group wc of each half; lane (row = lane & 15, ranks 4 (lane >> 4) ..) writes 16 B, the wave 1 KiB contiguous
-          float* tp = q->t_partial + ((long)(q->t_tile0 + n0 / BN) * m_rows + (m0 + wr * 128)) * 16;
+          constexpr int RT = 16 * ERB;  // ranks per row of the slab
+          float* tp = q->t_partial + ((long)(q->t_tile0 + n0 / BN) * m_rows + (m0 + wr * 128)) * RT;
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
+          for (int pass = 0; pass < 2 * ERB; ++pass) {  // (row half, rank block): 4 KiB of every wave's patch per pass
+            const int half = pass / ERB, rb = pass % ERB;
+            if (pass > 0) BAR();  // the previous pass's reads are done in every wave before the patches are rewritten
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) *reinterpret_cast<f32x4_t*>(patch + gg * 1024 + ln * 16) = tacc[half * 4 + gg];
+            for (int gg = 0; gg < 4; ++gg) *reinterpret_cast<f32x4_t*>(patch + gg * 1024 + ln * 16) = tacc[half * 4 + gg][rb];
             __builtin_amdgcn_s_waitcnt(0xc07f);
             BAR();
             f32x4_t sum4 = {0.f, 0.f, 0.f, 0.f};
@@ -801,13 +813,12 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
               sum4[0] += t4[0]; sum4[1] += t4[1]; sum4[2] += t4[2]; sum4[3] += t4[3];
             }
             if (m0 + wr * 128 + (half * 4 + wc) * 16 + (ln & 15) < m_rows)
-              *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * 16 + 4 * (ln >> 4)) = sum4;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (half == 0) BAR();  // the patches are rewritten by the second half; after it, the next writer is the next tile's epilogue, behind the K loop's barriers
+              *reinterpret_cast<f32x4_t*>(tp + (long)((half * 4 + wc) * 16 + (ln & 15)) * RT + rb * 16 + 4 * (ln >> 4)) = sum4;
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // (after the last pass the next writer of a patch is the next tile's epilogue, behind the K loop's barriers)
           }
         }
       };
-      if constexpr (ET) {
+      if constexpr (ET > 0) {
         // launcher contract: whole column tiles, no row maps, flags == BIAS | GELU | EMIT_T — every wave of the workgroup is here (the emission has workgroup
         // barriers), also the waves of a ragged last row tile: their rows beyond M compute on clamped operand rows and store nothing
         epi_done = true;
@@ -963,8 +974,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_ge_kernel(AitkGemmA
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, true>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_tr_ge_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, false, true>(p, p); }
 // AITK_EPI_EMIT_T (BIAS | GELU launches that also leave the column-tile partials of the consumer's lora_down product)
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_et_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, true>(p, p); }
-__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, true>(p, p2); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_et_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, 1>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, 1>(p, p2); }
+// ... for a rank-32 consumer (two 16-rank blocks: t_rank = 32)
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_et32_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, 2>(p, p); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et32_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, 2>(p, p2); }
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true, false, false>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true, false, false>(p, p2); }
@@ -977,6 +991,7 @@ static int gemm8_contract(const AitkGemmArgs* a) {
   const bool f8 = a->b_scale_mode == 3;
   if (a->flags & AITK_EPI_EMIT_T) {  // whole column tiles (the wave's 64 columns), any row count (stores predicated per row), the BIAS | GELU form, plain rows
     if (a->flags != (AITK_EPI_BIAS | AITK_EPI_GELU | AITK_EPI_EMIT_T) || (a->N % BN) || a->c_seg_rows || a->conv_mode || a->b_scale_mode) return 1;
+    if (a->t_rank != 0 && a->t_rank != 16 && a->t_rank != 32) return 1;
     if (!a->t_partial || !a->t_p || !a->t_p_lo || (a->t_ldp % 8) || a->t_tile0 < 0 || (((uintptr_t)a->t_p | (uintptr_t)a->t_p_lo | (uintptr_t)a->t_partial) & 15)) return 1;
   }
   if (a->b_scale_mode && !f8) return 1;
@@ -1017,7 +1032,8 @@ static int gemm8_cus() {
     const void* kernels[] = {(const void*)gemm_nt_8phase_kernel,        (const void*)gemm_nt_8phase_grouped_kernel,    (const void*)gemm_nt_8phase_f8_kernel,
                              (const void*)gemm_nt_8phase_f8_grouped_kernel, (const void*)gemm_nt_8phase_conv_kernel,       (const void*)gemm_nt_8phase_ge_kernel,
                              (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel,
-                             (const void*)gemm_nt_8phase_et_kernel,         (const void*)gemm_nt_8phase_grouped_et_kernel};
+                             (const void*)gemm_nt_8phase_et_kernel,         (const void*)gemm_nt_8phase_grouped_et_kernel,     (const void*)gemm_nt_8phase_et32_kernel,
+                             (const void*)gemm_nt_8phase_grouped_et32_kernel};
     for (const void* k : kernels)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_OFF + 32768) != hipSuccess) {
         n_cu = 0;
@@ -1032,7 +1048,8 @@ extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  if ((a->flags & AITK_EPI_EMIT_T) && a->t_rank == 32) hipLaunchKernelGGL(gemm_nt_8phase_et32_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
+  else if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else {
@@ -1059,7 +1076,9 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
   const int tn = (a->N + BN - 1) / BN;
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  if ((a->flags & AITK_EPI_EMIT_T) && (a->t_rank == 32) != (b->t_rank == 32)) return 1;
+  if ((a->flags & AITK_EPI_EMIT_T) && a->t_rank == 32) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et32_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
+  else if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (gemm8_env("AITK_GEMM8_FE", 1)) hipLaunchKernelGGL(gemm_nt_8phase_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else hipLaunchKernelGGL(gemm_nt_8phase_grouped_ge_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);

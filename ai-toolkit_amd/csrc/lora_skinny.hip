@@ -294,10 +294,11 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
 }
 
 extern "C" int aitk_lora_down_raw(const AitkLoraDownArgs* a, float* raw, aitk_stream_t stream) {
-  if (!a || !raw || a->M <= 0 || a->K <= 0 || a->R != 16 || (a->K % 32)) return AITK_ERR_SHAPE;
+  if (!a || !raw || a->M <= 0 || a->K <= 0 || (a->R != 16 && a->R != 32) || (a->K % 32)) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ldp % 8) || ((uintptr_t)raw & 15)) return AITK_ERR_ALIGN;
   if (!a->X || !a->P) return AITK_ERR_ARG;
-  hipLaunchKernelGGL((lora_down16_kernel<1, 6, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
+  if (a->R == 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
+  else hipLaunchKernelGGL((lora_down16_kernel<2, 8, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

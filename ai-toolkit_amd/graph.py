@@ -409,27 +409,27 @@ class FusedGraphBase(nn.Module):
     # The inputs of ff.net.2 / ff_context.net.2 / the single blocks' proj_out are GELU outputs: 792 MB per launch at B = 7 that aitk_lora_down reads back
     # right after the GEMM wrote them (14 ms of the 1.2-s step).  With emit_t the BIAS | GELU launch leaves the per-column-tile partial products instead
     # (+6 % bytes written next to u and gelu(u)) and aitk_lora_t_finish sums them: step 1198.5 -> 1190.1 ms same box (profiles/r06_ab_emit_t.txt).  Default;
-    # AITK_EMIT_T=0 / model.emit_t = False turns it off.  Plain rank-16 LoRA consumers without dropout behind plain / LoRA producers with a bias, N % 256 == 0
+    # AITK_EMIT_T=0 / model.emit_t = False turns it off.  Plain LoRA consumers of rank <= 32 without dropout behind plain / LoRA producers with a bias, N % 256 == 0
     # (any row count on the HIP kernel; the oracle table keeps whole 256-row tiles so that the committed CPU fixtures stay put); everything else keeps aitk_lora_down.
     emit_t = os.environ.get("AITK_EMIT_T", "1") != "0"
 
     def _emit_t_plan(self, producer, consumer, *, M, N, col0=0, extra_tiles=0):
         """None, or the state of one emission: consumer's lora_down product over its input columns [col0, col0 + N) is left by `producer`'s GELU launch as
-        N / 256 tiles of a [tiles + extra_tiles, M, 16] fp32 slab (extra tiles: parts of the consumer's input that come from elsewhere, aitk_lora_down_raw)."""
+        N / 256 tiles of a [tiles + extra_tiles, M, rank_pad] fp32 slab (extra tiles: parts of the consumer's input that come from elsewhere, aitk_lora_down_raw)."""
         ops, net = self.ops, self.network
         if not self.emit_t or not hasattr(ops, "lora_t_finish") or not self._lora_active(consumer):
             return None
         lo = consumer.lora
         rt = getattr(ops, "EMIT_T_ROW_TILE", 256)
-        if lo.is_lokr or lo.magnitude is not None or lo.rank_pad != 16 or (net.training and net.has_dropout) or M % rt or N % 256:
+        if lo.is_lokr or lo.magnitude is not None or lo.rank_pad not in (16, 32) or (net.training and net.has_dropout) or M % rt or N % 256:
             return None
         pl = producer.lora if self._lora_active(producer) else None
         if producer.bias is None or (pl is not None and (pl.is_lokr or pl.magnitude is not None)) or (producer.qweight is not None and self.fp8_mfma):
             return None
         ntiles = N // 256
-        nbytes = (ntiles + extra_tiles) * M * 16 * 4
+        nbytes = (ntiles + extra_tiles) * M * lo.rank_pad * 4
         ws = ops.workspace(nbytes, self._device(), f"emit_t{getattr(self, '_dq_slot', 0)}")  # the two merged streams of _paired must not share it
-        partial = ws[:nbytes // 4].view(ntiles + extra_tiles, M, 16)
+        partial = ws[:nbytes // 4].view(ntiles + extra_tiles, M, lo.rank_pad)
         return {"partial": partial, "ntiles": ntiles, "args": (lo.sh_down[:, col0:col0 + N], lo.sh_down_lo[:, col0:col0 + N], partial, 0)}
 
     def _emit_t_finish(self, plan, consumer, *, M, rows_per_batch, B, ntiles):

@@ -194,15 +194,16 @@ def gemm_nt(a, b, out, *, bias=None, a2=None, b2=None, flags=0, aux_out=None, au
         g.col_scale = _ptr(col_scale)
         flags |= _capi.EPI_COL_SCALE
     if emit_t is not None:
-        # AITK_EPI_EMIT_T: (p_hi [16, >= N] view, p_lo likewise, partial fp32 [tiles, M, 16], first tile slot) — the BIAS | GELU launch also leaves
+        # AITK_EPI_EMIT_T: (p_hi [16 | 32, >= N] view, p_lo likewise, partial fp32 [tiles, M, 16 | 32], first tile slot) — the BIAS | GELU launch also leaves
         # the column-tile partials of `gelu output @ (p_hi + p_lo)^T` (the consumer layer's lora_down product); lora_t_finish turns them into T
         p_hi, p_lo, partial, tile0 = emit_t
         assert flags == (EPI_BIAS | EPI_GELU) and N % 256 == 0 and a_seg is None and c_seg is None and not b_scale_mode
-        assert p_hi.dtype == BF16 and p_lo.dtype == BF16 and p_hi.shape[0] == 16 and p_hi.shape[1] >= N and p_hi.stride(1) == 1
+        Rt = p_hi.shape[0]
+        assert p_hi.dtype == BF16 and p_lo.dtype == BF16 and Rt in (16, 32) and p_hi.shape[1] >= N and p_hi.stride(1) == 1
         assert p_lo.shape == p_hi.shape and p_lo.stride() == p_hi.stride()
-        assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.dim() == 3 and partial.shape[1] == M and partial.shape[2] == 16
+        assert partial.dtype == torch.float32 and partial.is_contiguous() and partial.dim() == 3 and partial.shape[1] == M and partial.shape[2] == Rt
         assert partial.shape[0] >= tile0 + N // 256
-        g.t_partial, g.t_p, g.t_p_lo, g.t_ldp, g.t_tile0 = _ptr(partial), _ptr(p_hi), _ptr(p_lo), p_hi.stride(0), int(tile0)
+        g.t_partial, g.t_p, g.t_p_lo, g.t_ldp, g.t_tile0, g.t_rank = _ptr(partial), _ptr(p_hi), _ptr(p_lo), p_hi.stride(0), int(tile0), Rt
         flags |= _capi.EPI_EMIT_T
     g.M, g.N, g.K, g.flags = M, N, K, flags
     g.stage_mode = STAGE_MODE if stage_mode is None else stage_mode
@@ -304,13 +305,13 @@ EMIT_T_ROW_TILE = 1  # AITK_EPI_EMIT_T takes any row count on the HIP kernel (th
 
 
 def lora_down_raw(x, pmat, raw, *, p_lo=None, x_seg=None, M=None):
-    """raw [M, 16] fp32 = x[M, K] @ (pmat + p_lo)[16, K]^T, un-scaled: one tile of a partial-sum slab (aitk_lora_down_raw)."""
+    """raw [M, R] fp32 = x[M, K] @ (pmat + p_lo)[R, K]^T (R = 16 or 32), un-scaled: one tile of a partial-sum slab (aitk_lora_down_raw)."""
     a = _capi.LoraDownArgs()
     a.ldx, a.ldp = _row_major(x, "x"), _row_major(pmat, "pmat")
     R, K = pmat.shape
-    assert R == 16 and x.shape[1] == K and K % 32 == 0
+    assert R in (16, 32) and x.shape[1] == K and K % 32 == 0
     M = x.shape[0] if M is None else M
-    assert raw.dtype == torch.float32 and raw.is_contiguous() and tuple(raw.shape) == (M, 16)
+    assert raw.dtype == torch.float32 and raw.is_contiguous() and tuple(raw.shape) == (M, R)
     a.X, a.P = _ptr(x), _ptr(pmat)
     if p_lo is not None:
         assert p_lo.shape == pmat.shape and _row_major(p_lo, "p_lo") == a.ldp

@@ -40,7 +40,7 @@ typedef uint16_t aitk_bf16;
                                   [hi(rp) | lo(rp) | hi(rp)] (C is [M, >= 3 rp]) — lora_down of a 3x3-conv adapter
                                   (toolkit/lora_special.py:95-104) on the implicit-GEMM kernel; only COL_SCALE may accompany it */
 #define AITK_EPI_COL_SCALE 128 /* product * col_scale[n] before the bias: DoRA magnitude / ||W + dW||_row (toolkit/models/DoRA.py:126-148) */
-#define AITK_EPI_EMIT_T 512 /* with BIAS | GELU only (opt-in, rank 16): the launch also leaves, per 256-column tile, the fp32 partial product of ITS OUTPUT with the
+#define AITK_EPI_EMIT_T 512 /* with BIAS | GELU only (rank 16 or 32): the launch also leaves, per 256-column tile, the fp32 partial product of ITS OUTPUT with the
                               lora_down matrix of the layer that consumes it — t_partial[t_tile0 + n / 256][m][0..15] = sum over the tile's columns of
                               gelu(u)[m][n] * (t_p + t_p_lo)[r][n] on the bf16 value it stores — so that the consumer's T = x A^T (toolkit/network_mixins.py:309-321:
                               lora_down on the layer input) needs no second pass over the 792-MB GELU output: aitk_lora_t_finish sums the tiles.  Persistent
@@ -88,9 +88,9 @@ typedef struct AitkGemmArgs {
    * i.e. per-token dynamic activation quantisation (aitk_quant_rows_fp8) against per-output-channel weight scales; the rank-r LoRA slab
    * A2 B2^T stays bf16 (split hi + lo) and is added un-scaled.  Persistent 8-phase kernel only (any M, N % 8 == 0, K % 16 == 0). */
   const float* a_scale;
-  /* AITK_EPI_EMIT_T: t_partial fp32 [tiles][M][16]; t_p / t_p_lo = bf16 hi / lo shadows of the consumer's lora_down rows, indexed by THIS launch's output
+  /* AITK_EPI_EMIT_T: t_partial fp32 [tiles][M][t_rank]; t_p / t_p_lo = bf16 hi / lo shadows of the consumer's lora_down rows, indexed by THIS launch's output
    * column (row stride t_ldp elements, 16-byte aligned; a column window of a wider matrix is a pointer offset); t_tile0 = first tile slot of this launch */
-  float* t_partial; const aitk_bf16* t_p; const aitk_bf16* t_p_lo; int64_t t_ldp; int32_t t_tile0; int32_t _pad5;
+  float* t_partial; const aitk_bf16* t_p; const aitk_bf16* t_p_lo; int64_t t_ldp; int32_t t_tile0; int32_t t_rank; /* t_rank: 16 (or 0) / 32 = rows of t_p and ranks per slab row */
 } AitkGemmArgs;
 
 /* Per-token (per-row) dynamic fp8 quantisation of a GEMM A operand for b_scale_mode 3:
@@ -149,7 +149,7 @@ typedef struct AitkLoraDownArgs {
 } AitkLoraDownArgs;
 int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
 /* The two halves of aitk_lora_down around a partial-sum slab [tiles][M][R] fp32 (AITK_EPI_EMIT_T fills tiles from inside the producing GEMM):
- *   aitk_lora_down_raw: raw[m][r] = sum_k X[m][k] (P + P_lo)[r][k]  — one more tile, un-scaled, nothing written to T (R = 16, K % 32 == 0): the part of
+ *   aitk_lora_down_raw: raw[m][r] = sum_k X[m][k] (P + P_lo)[r][k]  — one more tile, un-scaled, nothing written to T (R = 16 or 32, K % 32 == 0): the part of
  *     a consumer's input that did NOT come out of an emitting launch (the attention half of the single blocks' [attn | gelu(mlp)] operand);
  *   aitk_lora_t_finish: T[m] = what aitk_lora_down writes (scale, mult, tmask, plain or [hi | lo | hi] slab) from the sum of `ntiles` tiles, fixed order.
  * X / P / ldx / K of the finish call are ignored. */

@@ -46,8 +46,9 @@ def _run(nat, net, emit):
     return pred.clone(), net.arena_g.clone(), calls
 
 
-def test_emitted_t_equals_the_separate_lora_down_launch():
-    ref, ref_net, nat, net = build_pair(rank=16)
+@pytest.mark.parametrize("rank", [16, 32, 8])
+def test_emitted_t_equals_the_separate_lora_down_launch(rank):
+    ref, ref_net, nat, net = build_pair(rank=rank)
     p0, g0, c0 = _run(nat, net, False)
     p1, g1, c1 = _run(nat, net, True)
     n_dbl, n_sgl = len(nat.transformer_blocks), len(nat.single_transformer_blocks)

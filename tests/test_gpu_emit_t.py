@@ -21,7 +21,8 @@ def _slab_value(T, rp=16):
 
 
 @pytest.mark.parametrize("M,N,K,slab", [(4608, 3072, 256, True), (7168, 12288, 512, True), (512, 1024, 128, False), (4464, 3072, 256, True), (300, 1024, 128, False), (136, 512, 128, True)])
-def test_emitting_gelu_launch_matches_plain_launch_and_lora_down(M, N, K, slab):
+@pytest.mark.parametrize("R", [16, 32])
+def test_emitting_gelu_launch_matches_plain_launch_and_lora_down(M, N, K, slab, R):
     from ai_toolkit_amd import ops
     from ai_toolkit_amd._capi import EPI_GELU
 
@@ -31,14 +32,14 @@ def test_emitting_gelu_launch_matches_plain_launch_and_lora_down(M, N, K, slab):
     bias = (torch.randn(N, device="cuda", generator=g) * 0.1).to(bf)
     a2 = (torch.randn(M, 48, device="cuda", generator=g) * 0.1).to(bf) if slab else None
     b2 = (torch.randn(N, 48, device="cuda", generator=g) * 0.05).to(bf) if slab else None
-    A = torch.randn(16, N, device="cuda", generator=g) * 0.05
+    A = torch.randn(R, N, device="cuda", generator=g) * 0.05
     a_hi = A.to(bf)
     a_lo = (A - a_hi.float()).to(bf)
     h0, u0 = torch.empty(M, N, dtype=bf, device="cuda"), torch.empty(M, N, dtype=bf, device="cuda")
     ops.gemm_nt(x, w, h0, bias=bias, a2=a2, b2=b2, flags=EPI_GELU, aux_out=u0, stage_mode=4)
     h1, u1 = torch.empty(M, N, dtype=bf, device="cuda"), torch.empty(M, N, dtype=bf, device="cuda")
     nt = N // 256
-    partial = torch.full((nt + 1, M, 16), float("nan"), device="cuda")
+    partial = torch.full((nt + 1, M, R), float("nan"), device="cuda")
     ops.gemm_nt(x, w, h1, bias=bias, a2=a2, b2=b2, flags=EPI_GELU, aux_out=u1, emit_t=(a_hi, a_lo, partial, 0), stage_mode=4)
     torch.cuda.synchronize()
     assert torch.equal(h0, h1) and torch.equal(u0, u1)
@@ -49,11 +50,18 @@ def test_emitting_gelu_launch_matches_plain_launch_and_lora_down(M, N, K, slab):
     # T as the consumer's GEMM takes it: finish vs aitk_lora_down on the stored GELU output (scale + per-sample multipliers)
     rpb = (M + 3) // 4
     mult = torch.tensor([1.0, 0.4, 2.0, 0.7], device="cuda")
-    T_ref, T = torch.empty(M, 48, dtype=bf, device="cuda"), torch.empty(M, 48, dtype=bf, device="cuda")
-    ops.lora_down(h1, a_hi, T_ref, scale=0.5, mult=mult, rows_per_batch=rpb, p_lo=a_lo, split=16)
-    ops.lora_t_finish(partial, nt, T, scale=0.5, mult=mult, rows_per_batch=rpb, split=16)
-    assert torch.equal(T[:, :16], T[:, 32:48])
-    assert _rel(_slab_value(T), _slab_value(T_ref)) < 1e-5, _rel(_slab_value(T), _slab_value(T_ref))
+    T_ref, T = torch.empty(M, 3 * R, dtype=bf, device="cuda"), torch.empty(M, 3 * R, dtype=bf, device="cuda")
+    ops.lora_down(h1, a_hi, T_ref, scale=0.5, mult=mult, rows_per_batch=rpb, p_lo=a_lo, split=R)
+    ops.lora_t_finish(partial, nt, T, scale=0.5, mult=mult, rows_per_batch=rpb, split=R)
+    assert torch.equal(T[:, :R], T[:, 2 * R:3 * R])
+    assert _rel(_slab_value(T, R), _slab_value(T_ref, R)) < 1e-5, _rel(_slab_value(T, R), _slab_value(T_ref, R))
+    # one more tile from aitk_lora_down_raw (the attention third of a single block's proj_out input) rides along at either rank
+    xa = (torch.randn(M, 256, device="cuda", generator=g) * 0.5).to(bf)
+    Aa = torch.randn(R, 256, device="cuda", generator=g) * 0.05
+    ops.lora_down_raw(xa, Aa.to(bf), partial[nt], p_lo=(Aa - Aa.to(bf).float()).to(bf))
+    torch.cuda.synchronize()
+    want_raw = xa.float() @ (Aa.to(bf).float() + (Aa - Aa.to(bf).float()).to(bf).float()).t()
+    assert _rel(partial[nt], want_raw) < 2e-6
 
 
 def test_column_window_plus_raw_tile_and_grouped_launch():
