@@ -111,9 +111,73 @@ __device__ unsigned g_gemm8_trace[2 * 2 * 3 * 5];
 // permutation through ds_bpermute) and two matrix instructions (hi and lo shadow) add into 8 x 4 accumulator registers = the wave's 128 rows x 16
 // ranks over its 64 columns; the four waves of a row half then sum their slabs through the (idle) epilogue patches in a fixed order and write ONE
 // [128 rows][16] fp32 slab per workgroup row half and 256-column tile.  Needs whole tiles (every wave takes part in the workgroup barriers).
-template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, int ET = 0>  // ET = 16-rank blocks of the emitted product (0: no emission)
+// SK: stream-K tail (own instantiations, OPT-IN: AITK_GEMM8_SK=1 picks them when the last tile round would leave a large part of the chip idle — small
+// batches: 216 tiles on 256 CUs at B = 1 —, =2 whenever the contract allows).  Measured and NOT the default (profiles/r06_gemm8_stream_k.md): the K loop
+// of these shapes runs at the 1,400-W cap, and a round that fills 216 of 256 CUs is answered with an ~18 % higher clock on the busy ones (1.47 us per
+// K-tile at 216 active CUs against 1.67 at 256), so the "idle" 16 % is not there to be won — the balanced schedule ties at best (-2 % at K >= 9216,
+// B = 3, 4) and loses 5-25 % at B = 1, where the 256-KiB partial exchange is not amortised.  What it does:  The workgroup's full rounds stay data-parallel (tiles w, w + G, ...); the R = ntiles % G tiles that are left are dealt
+// round the eight XCDs exactly as the data-parallel order deals them (virtual tile ndp + 8 j + x belongs to XCD x: xcd_remap gives the tiles of one XCD
+// neighbouring positions, so that its L2 sees few A / B panels), and PER XCD they form an iteration space of cnt_x * nsteps K-tiles that is cut into G / 8
+// equal ranges, one per workgroup of that XCD (workgroup w = 8 wl + x takes [sk_bound(wl), sk_bound(wl + 1))).  A range is at most: the END of
+// one tile's K loop (the FINAL chunk: it holds the K tail and the LoRA slab, sums the other chunks' partial accumulators and runs the epilogue), whole
+// tiles, and the START (or a middle piece) of another tile — a chunk that does not reach the tile's last K-tile leaves its fp32 accumulators in the
+// workspace slot of its workgroup (one slot each: only the last segment of a range can be open) and raises the slot's flag; a chunk that does not START
+// at K-tile 0 first adds the slot of the workgroup below, which therefore holds everything the tile has accumulated so far (a chain: one contributor
+// per chunk).  Every workgroup computes its open chunk FIRST, so that by the time anybody's final chunk reaches its fix-up the partial it needs is
+// (nearly always) there: the spin is a formality, and it cannot deadlock (a workgroup only ever waits for a lower-numbered one — w - 8, w - 16, ... —
+// dispatched before it, and the chain ends at a chunk that starts a tile).  The order of the fp32 sums is fixed by the schedule:
+// results are deterministic, and differ from the data-parallel kernel's only by the order of that fp32 sum.  A boundary one K-tile away from a tile's
+// end is snapped onto it so that no chunk is shorter than TWO K-tiles — all the K loop's software pipeline needs (K-tiles t + 1, t + 2 are staged during
+// K-tile t): it runs unchanged inside [kb, ke), and "the next tile's first K-tiles" become K-tiles kbn, kbn + 1 of the next item; a chunk may begin or
+// end anywhere, also inside the LoRA slab.
+struct AitkSkArgs { float* ws; int* flags; };
+__host__ __device__ __forceinline__ int sk_bound(int w, int G, int I, int ns) {
+  const int b = (int)((unsigned)w * (unsigned)I / (unsigned)G);  // launcher: (G + 1) * I < 2^31
+  const int kk = b % ns;
+  return kk == 1 ? b - 1 : (kk == ns - 1 ? b + 1 : b);
+}
+// item s (s = 0, 1, ...) of the stream-K range [lo, hi): tile (relative to the first stream-K tile) and [kb, ke); false past the end.  Natural order = first
+// tile's end, whole tiles, last tile's start; the last segment goes FIRST when it is open.
+__host__ __device__ __forceinline__ bool sk_segment(int lo, int hi, int ns, int s, int& tile, int& kb, int& ke) {
+  if (lo >= hi) return false;
+  const int t0 = lo / ns, tl = (hi - 1) / ns;
+  const int n = tl - t0 + 1;
+  if (s >= n) return false;
+  const bool open = hi - tl * ns < ns;
+  const int idx = open ? (s == 0 ? n - 1 : s - 1) : s;
+  tile = t0 + idx;
+  kb = idx == 0 ? lo - t0 * ns : 0;
+  ke = idx == n - 1 ? hi - tl * ns : ns;
+  return true;
+}
+// THE schedule (kernel and host probe): item i of workgroup w of G (G % 8 == 0) -> virtual tile v, K-tiles [kb, ke); false past the workgroup's last item.
+__host__ __device__ __forceinline__ bool sk_item_of(int G, int w, int ntiles, int ns, int i, int& v, int& kb, int& ke) {
+  const int ndp = ntiles - ntiles % G, rounds = ndp / G;
+  if (i < rounds) {
+    v = w + i * G;
+    kb = 0;
+    ke = ns;
+    return true;
+  }
+  const int x = w & 7, wl = w >> 3, Gl = G >> 3;
+  const int cnt = (ntiles - ndp - x + 7) >> 3;  // tail tiles of this XCD
+  int tile = 0;
+  if (!sk_segment(sk_bound(wl, Gl, cnt * ns, ns), sk_bound(wl + 1, Gl, cnt * ns, ns), ns, i - rounds, tile, kb, ke)) return false;
+  v = ndp + 8 * tile + x;
+  return true;
+}
+// the workgroup whose slot holds what the tile of a chunk with kb > 0 has accumulated so far: the nearest one below on the same XCD with a non-empty range
+__host__ __device__ __forceinline__ int sk_predecessor(int G, int w, int ntiles, int ns) {
+  const int x = w & 7, Gl = G >> 3;
+  const int cnt = (ntiles - (ntiles - ntiles % G) - x + 7) >> 3;
+  int wl = (w >> 3) - 1;
+  while (wl > 0 && sk_bound(wl, Gl, cnt * ns, ns) >= sk_bound(wl + 1, Gl, cnt * ns, ns)) --wl;
+  return 8 * wl + x;
+}
+template <bool GR, bool F8, bool CV = false, bool FE = true, bool TRACE = false, int ET = 0, bool SK = false>  // ET = 16-rank blocks of the emitted product (0: no emission)
 __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemmArgs& p2) {
   static_assert(ET == 0 || (FE && !F8 && !CV && ET <= 2), "EMIT_T: bf16 fast-epilogue kernels only, rank 16 or 32");
+  static_assert(!SK || (FE && !F8 && !CV && !TRACE), "stream-K tail: bf16 fast-epilogue kernels");
   static_assert(!(CV && (GR || F8)), "convolution mode: single bf16 problem");
   constexpr int KB = F8 ? 128 : BK;  // base-segment elements per K-tile (128 B per LDS row either way; the LoRA slab stays bf16, 64 wide)
   constexpr int CH = F8 ? 16 : 8;    // base-segment elements per 16-B chunk
@@ -130,11 +194,24 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
   const int nsteps = nk1 + nk2;   // >= 2 (launcher)
   const int nfast = p.K / KB;     // K-tiles [0, nfast) are full tiles of the base segment
+  // SK: item i of this workgroup: virtual tile v, K-tiles [kb, ke) (launcher: gridDim.x % 8 == 0, nsteps >= 8, every XCD's share >= 8 K-tiles per workgroup).
+  // Recomputed at item switches and in the fix-up rather than kept in SGPRs across the K loop.
+  auto sk_item = [&](int i, int& v, int& kb, int& ke) -> bool {
+    int nt_ = ntiles;
+    asm volatile("" : "+s"(nt_));
+    return sk_item_of((int)gridDim.x, (int)blockIdx.x, nt_, nsteps, i, v, kb, ke);
+  };
 
   // ---- staging geometry: thread owns physical 16-B chunk pc of LDS rows srow + 64 i (i = 0..3) of A and of B
   // (recomputed from an opaque copy of tid at each use: these are needed once per output tile, and values the compiler
   //  would otherwise hoist out of the tile loop cost VGPRs the K loop does not have)
-  auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+  // (SK: rebuilt from the wave index — a scalar — and mbcnt, so that no copy of tid has to stay in a VGPR, or in scratch, across the K loop)
+  const int wave_s = SK ? __builtin_amdgcn_readfirstlane(wave) : 0;
+  auto opaque_tid = [&]() {
+    int t_ = SK ? (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : tid;
+    asm volatile("" : "+v"(t_));
+    return t_;
+  };
 #define SROW(t_) ((t_) >> 3)
 #define CC(t_) (((t_) & 7) ^ ((SROW(t_) >> 1) & 7))  /* logical chunk at physical slot tid&7 (same key for rows srow + 64 i) */
   // kernel arguments re-read through an opaque pointer where they are needed rarely (K tails, epilogue): keeping all ~45
@@ -200,7 +277,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
   v4i srdA2 = make_srd(p.A2), srdB2 = make_srd(p.B2);
   // lanes whose 16-B chunk of the LAST slab K-tile lies beyond K2 (K2 = 48 for rank 16: chunks 6, 7): OR-ed into the lane offset, which then points
   // outside the buffer window and reads zeros
-  constexpr bool SLAB_PRE = !F8;  // the W8A8 instantiation has no registers left for the eight precomputed offsets (it would spill 50 more)
+  constexpr bool SLAB_PRE = !F8 && !SK;  // the W8A8 instantiation (and the stream-K one: three more scalars live across the K loop) has no registers left for the eight precomputed offsets (it would spill 50 more)
   unsigned slab_tail_oob = 0;
   if (SLAB_PRE && nk2 > 0) {
     const int t_ = opaque_tid();
@@ -445,16 +522,20 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
 
   // ---- first output tile: offsets + the six prologue half-tiles (K-tile 0: A0 B0 B1 A1, K-tile 1: A0 B0)
   int vt = blockIdx.x;
+  int item = 0, kb = 0, ke = nsteps;  // SK: the item being computed and its K-tile range (else: whole tiles)
+  if constexpr (SK) {
+    if (!sk_item(0, vt, kb, ke)) return;  // nothing for this workgroup (wave-uniform, before any barrier)
+  }
   tile_origin(vt, m0, n0, cprob);
   set_offsets(m0, n0, cprob);
   if constexpr (F8) fetch_scales(m0, n0, cprob);  // ahead of the prologue DMAs: the first VMCNT8 covers them
-  int gk = 0;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
-  stage_half(0, 0, 0, 0, false);
-  stage_half(0, 0, 1, 0, false);
-  stage_half(0, 0, 1, 1, false);
-  stage_half(0, 0, 0, 1, false);
-  stage_half(1, 1, 0, 0, false);
-  stage_half(1, 1, 1, 0, false);
+  int gk = -kb;  // K-tile counter across output tiles: K-tile t of this output tile lives in buffer (gk + t) & 1
+  stage_half(kb, 0, 0, 0, false);
+  stage_half(kb, 0, 1, 0, false);
+  stage_half(kb, 0, 1, 1, false);
+  stage_half(kb, 0, 0, 1, false);
+  stage_half(kb + 1, 1, 0, 0, false);
+  stage_half(kb + 1, 1, 1, 0, false);
   VMCNT8();  // first tile: K-tile 0 landed (the later tiles wait at the bottom of the loop)
   int tix = 0;   // output tiles this workgroup has finished
   unsigned tr[3][5] = {};
@@ -466,8 +547,11 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     else if (tix == 3) tr[2][k_] = t_;                                                                              \
   }
   while (true) {
-    const int vnext = vt + gridDim.x;
-    const bool has_next = vnext < ntiles;
+    int vnext = vt + gridDim.x, kbn = 0, ken = nsteps;
+    bool has_next;
+    if constexpr (SK) has_next = sk_item(item + 1, vnext, kbn, ken);
+    else has_next = vnext < ntiles;
+    const int k_end = SK ? ke : nsteps;  // this item's K-tiles are [kb, k_end); the K-tiles staged past it are kbn, kbn + 1 of the next item
     int m0n = 0, n0n = 0, probn = 0;
     if (has_next) tile_origin(vnext, m0n, n0n, probn);
 #pragma unroll
@@ -502,8 +586,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
         baddr[ks] ^= BUF_BYTES;
       }
     };
-    const int nsteady = min(nfast, nsteps) - 2;  // iterations t < nsteady stage only fast tiles (t + 2 < nfast)
-    int t = 0;
+    const int nsteady = min(nfast, k_end) - 2;  // iterations t < nsteady stage only fast tiles (t + 2 < nfast)
+    int t = SK ? kb : 0;
     for (; t < nsteady; ++t) {
       const unsigned lb1 = lds_wave + ((gk + t + 1) & 1) * BUF_BYTES, lb2 = lds_wave + ((gk + t) & 1) * BUF_BYTES;
       read_frags(IC<0>{}, IC<0>{}, &b0f);
@@ -537,8 +621,8 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       constexpr bool f8t = decltype(f8_c)::value != 0;
       // K-tiles t+1 / t+2 past this output tile are K-tiles 0 / 1 of the next one (or dead)
       const int t1 = t + 1, t2 = t + 2;
-      const bool n1 = t1 >= nsteps, n2 = t2 >= nsteps;
-      const int k1 = n1 ? t1 - nsteps : t1, k2 = n2 ? t2 - nsteps : t2;
+      const bool n1 = t1 >= k_end, n2 = t2 >= k_end;
+      const int k1 = n1 ? kbn + t1 - k_end : t1, k2 = n2 ? kbn + t2 - k_end : t2;
       const int buf1 = (gk + t1) & 1, buf2 = (gk + t2) & 1;
       // phase 0
       read_frags(IC<0>{}, IC<0>{}, &b0f);
@@ -578,10 +662,10 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
       if (nk2 > 0) scale_acc();  // base segment complete: the bf16 slab accumulates on top of the scaled products
       for (; t < nsteps; ++t) tail_iter(t, IC<0>{});
     } else {
-      for (; t < nsteps; ++t) tail_iter(t, IC<0>{});
+      for (; t < k_end; ++t) tail_iter(t, IC<0>{});
     }
     if (wr == 0) BAR();  // pair the extra barrier of the second group
-    gk += nsteps;
+    gk += k_end - kbn;
     if (F8 && nk2 == 0) scale_acc();
 
     // ---------------- epilogue (tile m0, n0; wave block rows wr*128.., cols wc*64..) ----------------
@@ -598,7 +682,69 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     // front of the stores of the blocks in between.  Same arithmetic, same order: bit-identical to the generic form.
     STAMP(3);
     bool epi_done = false;
+    if constexpr (SK) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      // the workspace / flag pointers ride behind the problem descriptors in the kernarg segment; read where they are needed (scalar loads)
+      auto skargs = [&]() {
+        const __attribute__((address_space(4))) char* q = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(q));
+        return (const __attribute__((address_space(4))) AitkSkArgs*)(q + (GR ? 2 : 1) * sizeof(AitkGemmArgs));
+      };
+      // A slot is [wave][64 register pairs][lane] fp32x2: wave w owns 32 KiB, one instruction moves 512 B contiguous.  Partials and flags travel as relaxed
+      // agent-scope atomics (8-byte ones for the data: global_load / store_dwordx2 sc1 — the cache policy that is coherent across the eight XCDs' L2s)
+      // instead of behind release / acquire fences: a fence here is buffer_wbl2 / buffer_inv over the whole L2, once per wave.
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      typedef unsigned long long u64_t;
+      if (kb > 0) {
+        // this chunk continues a tile: the workgroup below (the nearest one with a non-empty range) holds everything the tile has accumulated before K-tile
+        // kb — its own chunk plus, if that was a continuation too, what IT was handed: one contributor, straight-line code (a loop over contributors
+        // carries 128 accumulators round a back edge and the allocator answers with scratch)
+        int nt_ = ntiles;
+        asm volatile("" : "+s"(nt_));
+        const int w2 = sk_predecessor((int)gridDim.x, (int)blockIdx.x, nt_, nsteps);
+        if (tid == 0) {
+          int* fl = skargs()->flags + w2;
+          while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+          __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed: the slot's next writer is a later launch
+        }
+        __syncthreads();
+        const u64_t* wsp = reinterpret_cast<const u64_t*>(skargs()->ws + (long)w2 * (BM * BN) + wv * 8192) + ln;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+              const f32x2_t pv = __builtin_bit_cast(f32x2_t, __hip_atomic_load(wsp + ((mi * 2 + ni) * 8 + r2) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              acc[mi][ni][2 * r2] += pv.x;
+              acc[mi][ni][2 * r2 + 1] += pv.y;
+            }
+        // the staging offsets of the NEXT tile (set when the K loop switched) are a pure function of its origin: recomputed here, they are not live across
+        // the fix-up (the allocator otherwise spills them for the whole tail of the K loop, and a reload in front of a DMA drains the pipeline)
+        if (has_next) set_offsets(m0n, n0n, probn);
+      }
+      if (k_end < nsteps) {
+        // open chunk: accumulators -> this workgroup's slot, then the flag
+        u64_t* wsp = reinterpret_cast<u64_t*>(skargs()->ws + (long)blockIdx.x * (BM * BN) + wv * 8192) + ln;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2)
+              __hip_atomic_store(wsp + ((mi * 2 + ni) * 8 + r2) * 64, __builtin_bit_cast(u64_t, f32x2_t{acc[mi][ni][2 * r2], acc[mi][ni][2 * r2 + 1]}), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(skargs()->flags + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        epi_done = true;
+      }
+#endif
+    }
     if constexpr (FE) {
+     if (!epi_done) {
       KArgsPtr q = kargs(cprob);
       const int flags = q->flags;
       const int mw = __builtin_amdgcn_readfirstlane(m0 + wr * 128), nw = __builtin_amdgcn_readfirstlane(n0 + wc * 64);
@@ -836,6 +982,7 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
           default: epi_done = false; break;
         }
       }
+     }
     }
     if (!epi_done) {
       KArgsPtr q = kargs(cprob);
@@ -944,6 +1091,11 @@ __device__ __forceinline__ void gemm8_body(const AitkGemmArgs& p, const AitkGemm
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (!has_next) break;
     vt = vnext;
+    if constexpr (SK) {
+      ++item;
+      kb = kbn;
+      ke = ken;
+    }
     m0 = m0n;
     n0 = n0n;
     cprob = probn;
@@ -979,6 +1131,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et_kernel(AitkGemmA
 // ... for a rank-32 consumer (two 16-rank blocks: t_rank = 32)
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_et32_kernel(AitkGemmArgs p) { gemm8_body<false, false, false, true, false, 2>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et32_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, false, false, true, false, 2>(p, p2); }
+// stream-K tail (opt-in, AITK_GEMM8_SK; mode 1 picks these when the last tile round leaves >= AITK_GEMM8_SK_MIN_IDLE % of a tile time idle)
+// Only the two-problem form is instantiated: it reads the problem descriptors through the kernarg pointer where it needs them and keeps its K loop free of
+// scratch traffic (the one-problem form holds the descriptor in SGPRs and spilt staging offsets in the loop's tail: a reload in front of a DMA waits for
+// vmcnt(0) and drains the pipeline — measured 2.5x slower); a single problem is launched with an empty second one (M = 0: no tiles).
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_sk_kernel(AitkGemmArgs p, AitkGemmArgs p2, AitkSkArgs sk) { gemm8_body<true, false, false, true, false, 0, true>(p, p2); }
+__global__ __launch_bounds__(NT) void gemm_nt_8phase_grouped_et_sk_kernel(AitkGemmArgs p, AitkGemmArgs p2, AitkSkArgs sk) { gemm8_body<true, false, false, true, false, 1, true>(p, p2); }
 // W8A8: e4m3 activations (per-row scale) x e4m3 weights (per-row-of-B scale) on the MX-scaled fp8 MFMA, bf16 LoRA slab on top
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_kernel(AitkGemmArgs p) { gemm8_body<false, true, false, false>(p, p); }
 __global__ __launch_bounds__(NT) void gemm_nt_8phase_f8_grouped_kernel(AitkGemmArgs p, AitkGemmArgs p2) { gemm8_body<true, true, false, false>(p, p2); }
@@ -1033,7 +1191,7 @@ static int gemm8_cus() {
                              (const void*)gemm_nt_8phase_f8_grouped_kernel, (const void*)gemm_nt_8phase_conv_kernel,       (const void*)gemm_nt_8phase_ge_kernel,
                              (const void*)gemm_nt_8phase_grouped_ge_kernel, (const void*)gemm_nt_8phase_tr_kernel,         (const void*)gemm_nt_8phase_tr_ge_kernel,
                              (const void*)gemm_nt_8phase_et_kernel,         (const void*)gemm_nt_8phase_grouped_et_kernel,     (const void*)gemm_nt_8phase_et32_kernel,
-                             (const void*)gemm_nt_8phase_grouped_et32_kernel};
+                             (const void*)gemm_nt_8phase_grouped_et32_kernel,   (const void*)gemm_nt_8phase_grouped_sk_kernel,     (const void*)gemm_nt_8phase_grouped_et_sk_kernel};
     for (const void* k : kernels)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, EPI_OFF + 32768) != hipSuccess) {
         n_cu = 0;
@@ -1042,12 +1200,75 @@ static int gemm8_cus() {
   }
   return n_cu;
 }
+// ---- stream-K tail: when it pays, and its workspace (one 256-KiB accumulator slot + one flag per CU, per (device, stream): launches on one stream are
+// ordered, two streams must not share slots).  Allocated on first use outside graph capture; a launch that cannot have one stays data-parallel.
+static bool gemm8_sk_plan(const AitkGemmArgs* a, int tiles, int n_cu) {
+  const int mode = gemm8_env("AITK_GEMM8_SK", 0);  // 0 off (default: see the SK note at gemm8_body), 1 when the last round is poorly filled, 2 whenever the contract allows
+  if (!mode || a->b_scale_mode || a->conv_mode || tiles % n_cu == 0 || (n_cu & 7)) return false;
+  if ((a->flags & AITK_EPI_EMIT_T) && a->t_rank == 32) return false;
+  if (!gemm8_env("AITK_GEMM8_FE", 1) || gemm8_env("AITK_GEMM8_TRACE", 0)) return false;
+  const int nk1 = (a->K + BK - 1) / BK, nk2 = a->K2 > 0 ? (a->K2 + BK - 1) / BK : 0, nsteps = nk1 + nk2;
+  if (nsteps < 8) return false;
+  const long R = tiles % n_cu;
+  if ((R / 8) * nsteps / (n_cu / 8) < 8 || (long)(n_cu + 1) * R * nsteps >= 0x7fffffffL) return false;  // every workgroup's share of its XCD's tail: >= 8 K-tiles
+  if (mode >= 2) return true;
+  const int rounds = tiles / n_cu + 1;
+  const double idle = rounds - (double)tiles / n_cu;  // tile times the data-parallel schedule leaves idle (chip average)
+  return idle * 100.0 >= gemm8_env("AITK_GEMM8_SK_MIN_IDLE", 15);
+}
+struct Gemm8SkWs { int dev; hipStream_t st; AitkSkArgs args; };
+static bool gemm8_sk_workspace(hipStream_t st, int n_cu, AitkSkArgs* out) {
+  static Gemm8SkWs table[16];
+  static int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  for (int i = 0; i < n; ++i)
+    if (table[i].dev == dev && table[i].st == st) {
+      *out = table[i].args;
+      return true;
+    }
+  if (n == 16) return false;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+  AitkSkArgs w = {nullptr, nullptr};
+  if (hipMalloc((void**)&w.ws, (size_t)n_cu * BM * BN * sizeof(float)) != hipSuccess) return false;
+  if (hipMalloc((void**)&w.flags, (size_t)n_cu * sizeof(int)) != hipSuccess || hipMemsetAsync(w.flags, 0, (size_t)n_cu * sizeof(int), st) != hipSuccess) {
+    hipFree(w.ws);
+    if (w.flags) hipFree(w.flags);
+    return false;
+  }
+  table[n].dev = dev;
+  table[n].st = st;
+  table[n].args = w;
+  ++n;
+  *out = w;
+  return true;
+}
+// host view of the schedule (tests/test_capi_symbols.py: every K-tile of every tail tile is covered exactly once, chunk lengths respect the pipeline's minima)
+extern "C" int aitk_probe_gemm8_sk_item(int32_t G, int32_t w, int32_t ntiles, int32_t nsteps, int32_t i, int32_t* out3) {
+  if (G <= 0 || w < 0 || w >= G || ntiles <= 0 || nsteps <= 0 || i < 0 || !out3) return AITK_ERR_ARG;
+  int v = 0, kb = 0, ke = 0;
+  if ((G & 7) || !sk_item_of(G, w, ntiles, nsteps, i, v, kb, ke)) return 1;
+  out3[0] = v;
+  out3[1] = kb;
+  out3[2] = ke;
+  return AITK_OK;
+}
+extern "C" int aitk_probe_gemm8_sk_predecessor(int32_t G, int32_t w, int32_t ntiles, int32_t nsteps) { return sk_predecessor(G, w, ntiles, nsteps); }
 extern "C" int aitk_gemm8_try_launch(const AitkGemmArgs* a, hipStream_t st) {
   if (gemm8_contract(a)) return 1;
   const int n_cu = gemm8_cus();
   if (!n_cu) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int grid = tiles < n_cu ? tiles : n_cu;
+  AitkSkArgs sk;
+  if (gemm8_sk_plan(a, tiles, n_cu) && gemm8_sk_workspace(st, n_cu, &sk)) {
+    AitkGemmArgs none = *a;  // the empty second problem
+    none.M = 0;
+    if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_sk_kernel, dim3(n_cu), dim3(NT), EPI_OFF + 32768, st, *a, none, sk);
+    else hipLaunchKernelGGL(gemm_nt_8phase_grouped_sk_kernel, dim3(n_cu), dim3(NT), EPI_OFF + 32768, st, *a, none, sk);
+    return AITK_OK;
+  }
   if ((a->flags & AITK_EPI_EMIT_T) && a->t_rank == 32) hipLaunchKernelGGL(gemm_nt_8phase_et32_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
   else if (a->conv_mode) hipLaunchKernelGGL(gemm_nt_8phase_conv_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a);
@@ -1077,6 +1298,12 @@ extern "C" int aitk_gemm8_try_launch_grouped(const AitkGemmArgs* a, const AitkGe
   const int tiles = ((a->M + BM - 1) / BM + (b->M + BM - 1) / BM) * tn;
   const int grid = tiles < n_cu ? tiles : n_cu;
   if ((a->flags & AITK_EPI_EMIT_T) && (a->t_rank == 32) != (b->t_rank == 32)) return 1;
+  AitkSkArgs sk;
+  if (gemm8_sk_plan(a, tiles, n_cu) && gemm8_sk_workspace(st, n_cu, &sk)) {
+    if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_sk_kernel, dim3(n_cu), dim3(NT), EPI_OFF + 32768, st, *a, *b, sk);
+    else hipLaunchKernelGGL(gemm_nt_8phase_grouped_sk_kernel, dim3(n_cu), dim3(NT), EPI_OFF + 32768, st, *a, *b, sk);
+    return AITK_OK;
+  }
   if ((a->flags & AITK_EPI_EMIT_T) && a->t_rank == 32) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et32_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (a->flags & AITK_EPI_EMIT_T) hipLaunchKernelGGL(gemm_nt_8phase_grouped_et_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);
   else if (a->b_scale_mode == 3) hipLaunchKernelGGL(gemm_nt_8phase_f8_grouped_kernel, dim3(grid), dim3(NT), EPI_OFF + 32768, st, *a, *b);

@@ -113,6 +113,11 @@ int aitk_probe_attn_ws_trace(uint64_t* out64);
 /* diagnostics: s_memtime stamps the persistent GEMM's TRACE build (AITK_GEMM8_TRACE=1) left at its tile-switch points: 60 values = [workgroup 0 / 100][wave 0 / 4][tile 1-3]
  * [top of the tile, after the top barrier, end of the steady K loop, end of the K loop, end of the epilogue] (tools/gpu_gemm8_ev.py trace) */
 int aitk_probe_gemm8_trace(uint32_t* out60);
+/* diagnostics: the work list of the persistent GEMM's opt-in stream-K tail (AITK_GEMM8_SK, csrc/gemm8.hip) evaluated on the host: item i of workgroup w of G
+ * (G % 8 == 0) over ntiles output tiles of nsteps K-tiles -> out3 = {virtual tile, first K-tile, end K-tile}; 1 past the workgroup's last item.
+ * aitk_probe_gemm8_sk_predecessor: the workgroup whose workspace slot a chunk of w that starts past K-tile 0 adds before it goes on. */
+int aitk_probe_gemm8_sk_item(int32_t G, int32_t w, int32_t ntiles, int32_t nsteps, int32_t i, int32_t* out3);
+int aitk_probe_gemm8_sk_predecessor(int32_t G, int32_t w, int32_t ntiles, int32_t nsteps);
 int aitk_sizeof(int32_t which); /* 0: AitkGemmArgs, 1: AitkLoraDownArgs, 2: AitkLoraWgradArgs, ... — struct-size handshake for FFI mirrors */
 int aitk_gemm_nt(const AitkGemmArgs* args, aitk_stream_t stream);
 /* Two independent problems in one call (e.g. the image- and text-stream projections of a FLUX double block:

@@ -112,3 +112,48 @@ def test_attention_workgroup_order_is_a_bijection_that_keeps_a_head_on_one_xcd()
         if n >= 8 * ntiles:  # an XCD's share is at least one head long: a head spans at most two XCDs (one boundary)
             assert max(len(v) for v in xcds.values()) <= 2, (ntiles, H, B)
     assert lib.aitk_probe_attn_wg_coords(8, 8, 2, 2, out) == -3 and lib.aitk_probe_attn_wg_coords(8, 0, 2, 2, None) == -3
+
+
+def test_stream_k_tail_schedule_covers_every_k_tile_once_and_only_waits_downwards():
+    """aitk_probe_gemm8_sk_item evaluates, on the host, the work list the stream-K instantiations of the persistent GEMM walk (gemm8.hip, sk_item_of): full
+    tile rounds data-parallel, the remaining tiles cut per XCD into one K-tile range per workgroup.  Every (tile, K-tile) exactly once; no chunk shorter
+    than the two K-tiles the software pipeline needs; a workgroup's open chunk (one that does not reach its tile's last K-tile) comes first and is the only
+    one; a chunk that continues a tile finds the previous chunk of that tile as the last item of its predecessor (a lower workgroup on the same XCD); the
+    longest work list is within three K-tiles of the ideal share."""
+    lib = _capi.lib()
+    item = lib.aitk_probe_gemm8_sk_item
+    pred = lib.aitk_probe_gemm8_sk_predecessor
+    out = (ctypes.c_int32 * 3)()
+    for G, ntiles, ns in ((256, 216, 49), (256, 216, 51), (256, 648, 49), (256, 864, 193), (256, 432, 241), (256, 1512, 49), (256, 100, 145), (256, 297, 64),
+                          (256, 220, 49), (64, 54, 17), (8, 13, 40)):
+        cover = {}
+        lists = {}
+        ndp = ntiles - ntiles % G
+        for w in range(G):
+            lst = []
+            while item(G, w, ntiles, ns, len(lst), out) == 0:
+                lst.append((out[0], out[1], out[2]))
+                assert len(lst) <= ntiles // G + 3
+            lists[w] = lst
+            tail = [x for x in lst if x[0] >= ndp]
+            assert lst[:len(lst) - len(tail)] == [(w + r * G, 0, ns) for r in range(ndp // G)]
+            opens = [j for j, (_, _, ke) in enumerate(tail) if ke < ns]
+            assert opens in ([], [0]), (G, ntiles, ns, w, tail)
+            for v, kb, ke in lst:
+                assert 0 <= v < ntiles and 0 <= kb and kb + 2 <= ke <= ns
+                assert v < ndp or (v - ndp) % 8 == w % 8  # tail tiles stay on the XCD the data-parallel order would give them
+                for k in range(kb, ke):
+                    assert (v, k) not in cover
+                    cover[(v, k)] = w
+        assert len(cover) == ntiles * ns
+        for w, lst in lists.items():
+            for v, kb, ke in lst:
+                if kb > 0:
+                    p = pred(G, w, ntiles, ns)
+                    assert 0 <= p < w and p % 8 == w % 8
+                    pv, pkb, pke = lists[p][ndp // G]  # the predecessor's open chunk is the first item of its tail
+                    assert pv == v and pke == kb and pke < ns, (w, (v, kb, ke), p, lists[p])
+        work = [sum(ke - kb for _, kb, ke in lst) for lst in lists.values()]
+        cnt_max = ((ntiles - ndp) + 7) // 8  # tail tiles of the fullest XCD
+        assert max(work) <= (ndp // G) * ns + cnt_max * ns / (G // 8) + 3, (G, ntiles, ns, max(work))
+    assert item(0, 0, 1, 1, 0, out) == -3 and item(12, 0, 20, 9, 0, out) == 1  # needs a grid that is a multiple of the XCD count
