@@ -459,14 +459,15 @@ class FusedGraphBase(nn.Module):
         ps = self._dora_ps(lin, rows_per_batch, B) if self._lora_active(lin) else None
         if ps is not None:
             lo = lin.lora
-            assert T is None and c_seg is None and lin.qweight is None
+            assert T is None and c_seg is None and not (lin.qweight is not None and self.fp8_mfma)
             mbar, dvec, rpb = ps
             rp = lo.rank_pad
             Tb, Td = self._new(M, 3 * rp), self._new(M, 3 * rp)
             ops.lora_down(x, lo.sh_down, Tb, scale=lo.scale * mbar, x_seg=a_seg, M=M, p_lo=lo.sh_down_lo, split=rp)
             ops.lora_down(x, lo.sh_down, Td, scale=lo.scale, mult=dvec, rows_per_batch=rpb, x_seg=a_seg, M=M, p_lo=lo.sh_down_lo, split=rp)
             ylin = self._new(M, lin.out_features)  # c * (x W^T + T_mean B^T) + b: kept for d magnitude
-            ops.gemm_nt(x, lin.weight, ylin, bias=lin.bias, a_seg=a_seg, M=M, a2=Tb, b2=lo.sh_up3, col_scale=lo.c)
+            wps = lin.weight if lin.qweight is None else self._dequant(lin.qweight, lin.wscale, 1)
+            ops.gemm_nt(x, wps, ylin, bias=lin.bias, a_seg=a_seg, M=M, a2=Tb, b2=lo.sh_up3, col_scale=lo.c)
             lo.y_lin = ylin
             ops.ew(1, ylin, out[:M])
             # out = epi(ylin + T_dev B^T): the accumulate epilogue precedes GELU / gate-residual in the epilogue order

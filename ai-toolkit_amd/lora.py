@@ -125,7 +125,10 @@ class DoRAModule(LoRAModule):
         self.lora_up.weight.data = torch.zeros_like(self.lora_up.weight.data)
         self.lora_down = nn.Linear(in_dim, lora_dim, bias=False)
         self.lora_down.weight.data = torch.randn_like(self.lora_down.weight.data) * (1 / torch.sqrt(torch.tensor(lora_dim).float()))
-        w = org_module.weight.data.detach().float().cpu()
+        if getattr(org_module, "qweight", None) is not None:  # quantised base: the norm of the DEQUANTISED weight (DoRA.py:105-109, get_orig_weight)
+            w = (org_module.qweight.view(torch.float8_e4m3fn).float() * org_module.wscale[:, None].float()).to(org_module.weight.dtype).float().cpu()
+        else:
+            w = org_module.weight.data.detach().float().cpu()
         self.magnitude = nn.Parameter(torch.linalg.norm(w, dim=1).clone())  # lora_up = 0 at init: ||W + up@down|| = ||W||
         self.multiplier = multiplier
         self.org_module = [org_module]
@@ -611,7 +614,8 @@ class FusedLoRANetwork(nn.Module):
             m.off_mag = off
             m.c = torch.ones(cnt, dtype=torch.float32, device=device)
             w = m.org_module[0].weight.data
-            m.w2 = w.float().pow(2).sum(1).to(device)
+            # (a layer quantised to e4m3 has released this copy: refresh_dora takes ||W_j||^2 from the dequantised codes instead)
+            m.w2 = w.float().pow(2).sum(1).to(device) if w.numel() else torch.zeros(cnt, dtype=torch.float32, device=device)
             off += cnt
         for m in mods:
             if hasattr(m, "alpha"):
@@ -694,11 +698,20 @@ class FusedLoRANetwork(nn.Module):
         self._dora_mbar = mbar
         for m in mods:
             lin = m.org_module[0]
-            if getattr(lin, "qweight", None) is not None:
-                raise NotImplementedError("DoRA over a weight-only fp8 base is not on the fused path")
             dev, r = self.arena_p.device, m.rank_pad
+            wsrc = lin.weight.data
+            q = getattr(lin, "qweight", None)
+            if q is not None:
+                # weight-only fp8 base: the reference's DoRAModule takes the norm over the DEQUANTISED weight (DoRA.py:105-109: get_orig_weight ->
+                # weight.dequantize()); the bf16 copy of a quantised layer is released, so the e4m3 codes are expanded for the skinny pass (the same
+                # expansion the base GEMM multiplies with), and ||W_j||^2 follows the codes it was taken from
+                wsrc = torch.empty(q.shape[0], q.shape[1], dtype=self.shadow_dtype, device=dev)
+                ops.dequant_fp8(q, lin.wscale, 1, wsrc)
+                if getattr(m, "_w2_of", None) is not q:
+                    m.w2 = wsrc.float().pow(2).sum(1)
+                    m._w2_of = q
             tw = torch.empty(lin.out_features, r, dtype=self.shadow_dtype, device=dev)
-            ops.lora_down(lin.weight.data, m.sh_down, tw, scale=1.0, M=lin.out_features, p_lo=m.sh_down_lo)
+            ops.lora_down(wsrc, m.sh_down, tw, scale=1.0, M=lin.out_features, p_lo=m.sh_down_lo)
             gram = torch.zeros(r, r, dtype=torch.float32, device=dev)
             at = m.sh_downT3[:, :r]  # A^T_hi [in, r] (row stride 3r)
             ops.lora_wgrad(at, at, gram, M=m.in_features)

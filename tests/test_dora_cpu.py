@@ -165,3 +165,76 @@ def test_dora_per_sample_multipliers_match_reference_golden():
     with net:
         pred = nat.forward_native(*tiny_inputs())
     assert torch.allclose(pred, t["fwd/pred"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("per_sample", [False, True], ids=["uniform_multiplier", "per_sample_multipliers"])
+def test_dora_over_the_weight_only_fp8_base_matches_autograd_on_the_dequantised_weights(per_sample):
+    """network.type dora with model.quantize: the reference's DoRAModule takes its norm over the DEQUANTISED weight (toolkit/models/DoRA.py:105-109,
+    126-148: get_orig_weight -> weight.dequantize()).  The fused path expands the e4m3 codes for the skinny pass of refresh_dora and takes ||W_j||^2
+    from the same codes (the quantised layer has released its bf16 copy); forward / backward multiply with the expansion the base GEMM uses anyway.
+    Oracle: autograd over the restated DoRA module on a model holding the dequantised weights."""
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.05)
+    nat = FluxTransformer2DModel(**CFG, dtype=torch.float32, device="cpu", ops=ref_ops)
+    nat.load_state_dict(ref.state_dict(), strict=True)
+    nat.prepare()
+    nat.quantize_base_fp8(release_bf16=True)  # before the network exists, as in the reference's load order; the plug-in releases the bf16 copies
+    with torch.no_grad():
+        mods = dict(ref.named_modules())
+        nq = 0
+        for n, lin in nat.named_modules():
+            if getattr(lin, "qweight", None) is not None:
+                assert lin.weight.numel() == 0  # the bf16 copy is gone: nothing but the codes can feed the norm
+                mods[n].weight.copy_(nat.dequantized_weight(lin).float())
+                nq += 1
+        assert nq > 0
+    torch.manual_seed(5)
+    ref_net = lora_ref.RefLoRANetwork(ref, 4, network_type="dora")
+    torch.manual_seed(5)
+    net = FusedLoRANetwork(nat, lora_dim=4, network_type="dora")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.equal(a.lora_down.weight, b.lora_down.weight)
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.05
+            a.lora_up.weight.copy_(up)
+            b.lora_up.weight.copy_(up)
+            assert torch.allclose(a.magnitude, b.magnitude, rtol=1e-6, atol=0)  # both built over the dequantised weight (DoRA.py:105-109)
+            a.magnitude.copy_(b.magnitude)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena("cpu", groups=nat.lora_groups())
+    net.refresh_shadows(ref_ops)
+    nat.attach_network(net)
+    mult = [0.5, 1.25] if per_sample else 1.0
+    net.multiplier = mult
+    ref_net.multiplier = mult
+    net.refresh_dora(ref_ops)
+    kw = dict(lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    ours = FluxLoRATrainStep(nat, net, ref_ops, **kw)
+    params = [p for m in ref_net.unet_loras for p in (m.magnitude, m.lora_up.weight, m.lora_down.weight)]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, eps=1e-6)
+    for it in range(2):
+        gi = torch.Generator().manual_seed(20 + it)
+        lat = torch.randn(2, 16, 8, 4, generator=gi)
+        emb = torch.randn(2, 6, 64, generator=gi)
+        pooled = torch.randn(2, 32, generator=gi)
+        noise = torch.randn(2, 16, 8, 4, generator=gi)
+        ts = torch.tensor([310.0, 845.0])
+        loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts)
+        tt = (ts / 1000).view(-1, 1, 1, 1)
+        noisy = flux_ref.pack_latents((1 - tt) * lat + tt * noise)
+        img_ids, txt_ids = flux_ref.make_ids(8, 4, 6)
+        opt.zero_grad()
+        with ref_net:
+            pred = ref(noisy, emb, pooled, ts / 1000, img_ids, txt_ids, torch.ones(2))
+            loss_ref = (pred - flux_ref.pack_latents(noise - lat)).pow(2).mean()
+            loss_ref.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        assert abs(loss.item() - loss_ref.item()) < 2e-4 * max(1.0, abs(loss_ref.item())), (it, loss.item(), loss_ref.item())
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        assert torch.allclose(a.magnitude, b.magnitude, rtol=2e-3, atol=2e-6), a.lora_name
+        assert torch.allclose(a.lora_up.weight, b.lora_up.weight, rtol=2e-3, atol=2e-6), a.lora_name
+        assert torch.allclose(a.lora_down.weight, b.lora_down.weight, rtol=2e-3, atol=2e-6), a.lora_name

@@ -157,3 +157,71 @@ def test_dora_train_step_vs_fp32_oracle(multiplier, rank):
     e, e_m = math.sqrt(num / den), math.sqrt(num_m / den_m)
     print(f"dora loss ours {loss:.6f} fp32 {loss32:.6f}; grad rel err matrices {e:.3e} magnitude {e_m:.3e}")
     assert e < 2e-2 and e_m < 2e-2, (e, e_m)
+
+
+def test_dora_over_the_weight_only_fp8_base_vs_fp32_oracle_on_the_dequantised_weights():
+    """network.type dora + model.quantize (toolkit/models/DoRA.py:105-109: the norm is taken over weight.dequantize()): the quantised layers have
+    released their bf16 copies, refresh_dora expands the e4m3 codes for its skinny pass and ||W_j||^2, the base GEMMs multiply with the same expansion.
+    Oracle: the fp32 restatement on a model that holds the dequantised weights.  CPU twin: tests/test_dora_cpu.py."""
+    import ai_toolkit_amd  # noqa: F401
+    from ai_toolkit_amd import ops
+    from ai_toolkit_amd.flux import FluxTransformer2DModel
+    from ai_toolkit_amd.lora import FusedLoRANetwork
+    from ai_toolkit_amd.trainer import FluxLoRATrainStep
+    from oracle import flux_ref, lora_ref, train_ref
+    from tests.test_gpu_e2e import CFG, _batch
+
+    dev = "cuda"
+    torch.manual_seed(0)
+    ref = flux_ref.FluxTransformer2DModel(**CFG)
+    flux_ref.init_synthetic_(ref, seed=1234, std=0.03)
+    nat = FluxTransformer2DModel(**CFG, dtype=torch.bfloat16, device=dev, ops=ops)
+    nat.load_state_dict({k: v.to(torch.bfloat16) for k, v in ref.state_dict().items()}, strict=True)
+    nat.prepare()
+    nat.quantize_base_fp8(release_bf16=True)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+        mods = dict(ref.named_modules())
+        for n, lin in nat.named_modules():
+            if getattr(lin, "qweight", None) is not None:
+                assert lin.weight.numel() == 0
+                mods[n].weight.copy_(nat.dequantized_weight(lin).float().cpu())
+    ref = ref.to(dev)
+    torch.manual_seed(5)
+    ref_net = lora_ref.RefLoRANetwork(ref, 16, network_type="dora").to(dev)
+    torch.manual_seed(5)
+    net = FusedLoRANetwork(nat, lora_dim=16, network_type="dora")
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for a, b in zip(net.unet_loras, ref_net.unet_loras):
+            assert torch.allclose(a.magnitude.cpu(), b.magnitude.cpu(), rtol=1e-5, atol=0)  # both from the dequantised weight
+            up = torch.randn(b.lora_up.weight.shape, generator=g) * 0.02
+            b.lora_up.weight.copy_(up)
+            a.lora_up.weight.copy_(up)
+            mg = b.magnitude.cpu() * (1 + 0.03 * torch.randn(b.magnitude.shape, generator=g))
+            b.magnitude.copy_(mg)
+            a.magnitude.copy_(mg)
+    ref_net.torch_multiplier = ref_net.torch_multiplier.to(dev)
+    ref_net.apply_to()
+    net.apply_to()
+    net.build_arena(dev, groups=nat.lora_groups())
+    net.refresh_shadows(ops)
+    nat.attach_network(net)
+    lat, emb, pooled, noise, ts = _batch(2)
+    oracle = train_ref.RefTrainStep(ref, ref_net, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss32 = oracle.step(lat.float(), emb.float(), pooled.float(), noise.float(), ts).item()
+    g32 = {id(p): p.grad.clone() for p in oracle.params}
+    ours = FluxLoRATrainStep(nat, net, ops, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+    loss = ours.step(lat, emb, pooled, noise=noise, timesteps=ts).item()
+    assert abs(loss - loss32) <= 1.5e-3 * abs(loss32), (loss, loss32)
+    num = den = num_m = den_m = 0.0
+    for a, b in zip(net.unet_loras, ref_net.unet_loras):
+        for pa, pb in ((a.lora_down.weight, b.lora_down.weight), (a.lora_up.weight, b.lora_up.weight)):
+            num += ((pa.grad - g32[id(pb)]) ** 2).sum().item()
+            den += (g32[id(pb)] ** 2).sum().item()
+        num_m += ((a.magnitude.grad - g32[id(b.magnitude)]) ** 2).sum().item()
+        den_m += (g32[id(b.magnitude)] ** 2).sum().item()
+    e, e_m = math.sqrt(num / den), math.sqrt(num_m / den_m)
+    print(f"dora over fp8 base: loss ours {loss:.6f} fp32 {loss32:.6f}; grad rel err matrices {e:.3e} magnitude {e_m:.3e}")
+    assert e < 2e-2 and e_m < 2e-2, (e, e_m)
