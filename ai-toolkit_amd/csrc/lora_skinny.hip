@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // step) runs with U = 6: 116 VGPRs -> 4 waves per SIMD -> all 1008 workgroups of a 32256-row launch are resident at once (U = 8 needs
 // 132 VGPRs -> 3 per SIMD -> 768 slots -> a second, one-third-full round).
 // RAW (aitk_lora_down_raw): the un-scaled fp32 sums go to raw[m][r] instead of T — one more tile of a partial-sum slab that aitk_lora_t_finish turns into T.
-template <int RB, int U, bool RAW = false>
-__global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
-  __shared__ __attribute__((aligned(16))) float red[4 * RB * 2 * 4 * 64];
+// NW = waves per workgroup = K slices: 4, or 8 for SHORT launches (below 16384 rows: B <= 3 at 1024^2) — there the chip is not full (144 workgroups at
+// B = 1) and a launch is a latency chain of K / (NW * 32 * U) load batches per wave: eight waves halve the chain (the sum over K slices has another order:
+// equal to the 4-wave kernel to fp32 rounding, chosen by row count only, so a sample's result does not depend on the other samples of a short batch).
+template <int RB, int U, bool RAW = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
+  __shared__ __attribute__((aligned(16))) float red[NW * RB * 2 * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 32;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int ksteps = p.K / 32;
-  const int kbeg = (ksteps * wave) / 4, kend = (ksteps * (wave + 1)) / 4;
+  const int kbeg = (ksteps * wave) / NW, kend = (ksteps * (wave + 1)) / NW;
   int ks = kbeg;
   for (; ks + U <= kend; ks += U) {
     s16x8_t xa[U][2], pa[U][RB];
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, (RB == 1 && U <= 6) ? 4 : 1) void lora_down16_
       for (int r = 0; r < 4; ++r) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
+        for (int w = 0; w < NW; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
         v[r] = RAW ? s : s * c;
       }
       const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
@@ -280,7 +283,13 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
       const char* e = getenv("AITK_LORA_DOWN_U");
       u1 = (e && atoi(e) == 8) ? 8 : 6;
     }
-    if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    static int short8 = -1;  // AITK_LORA_DOWN_SHORT8=0: the 4-wave kernel for short launches too (A/B)
+    if (short8 < 0) {
+      const char* e = getenv("AITK_LORA_DOWN_SHORT8");
+      short8 = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (a->R <= 16 && short8 && a->M < 16384 && a->K >= 32 * 6 * 8) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 32) hipLaunchKernelGGL((lora_down16_kernel<2, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 48) hipLaunchKernelGGL((lora_down16_kernel<3, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
