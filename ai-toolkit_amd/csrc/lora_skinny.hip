@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // RAW (aitk_lora_down_raw): the un-scaled fp32 sums go to raw[m][r] instead of T — one more tile of a partial-sum slab that aitk_lora_t_finish turns into T.
 // NW = waves per workgroup = K slices: 4, or 8 for SHORT launches (below 16384 rows: B <= 3 at 1024^2) — there the chip is not full (144 workgroups at
 // B = 1) and a launch is a latency chain of K / (NW * 32 * U) load batches per wave: eight waves halve the chain (the sum over K slices has another order:
-// equal to the 4-wave kernel to fp32 rounding, chosen by row count only, so a sample's result does not depend on the other samples of a short batch).
+// equal to the 4-wave kernel to fp32 rounding, chosen by row count only, so a sample's result does not depend on the other samples of a short batch);
+// 16 for launches of ONE workgroup (M <= 32 rows: the adaLN adapters' B x 18432 backward operand was a 24-batch chain on four waves).
 template <int RB, int U, bool RAW = false, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
   __shared__ __attribute__((aligned(16))) float red[NW * RB * 2 * 4 * 64];
@@ -288,7 +289,9 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
       const char* e = getenv("AITK_LORA_DOWN_SHORT8");
       short8 = (e && atoi(e) == 0) ? 0 : 1;
     }
-    if (a->R <= 16 && short8 && a->M < 16384 && a->K >= 32 * 6 * 8) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
+    // one workgroup for the whole launch (M <= 32: the adaLN adapters, B rows x K = 3 d / 6 d in their backward): 16 K slices
+    if (a->R <= 16 && short8 && a->M <= 32 && a->K >= 32 * 6 * 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 16>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 16 && short8 && a->M < 16384 && a->K >= 32 * 6 * 8) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 32) hipLaunchKernelGGL((lora_down16_kernel<2, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);

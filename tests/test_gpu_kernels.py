@@ -120,6 +120,9 @@ def test_norm_and_elementwise_kernels():
     _ok(g.t_ln_mod(2, 200, 3072))
     _ok(g.t_ln_mod(1, 37, 1536))
     _ok(g.t_gate_bwd(2, 200, 3072))
+    _ok(g.t_ln_mod(2, 1000, 3072))   # 63 row blocks per sample: the 16-group column-sum finish (colsum_finish16_kernel, from 32 row blocks up)
+    _ok(g.t_gate_bwd(3, 4608, 3072))  # 288 row blocks per sample, as in the FLUX single blocks
+    _ok(g.t_ln_mod(1, 520, 1536))
     _ok(g.t_qkv_post(2, 24, 100, 4))
     _ok(g.t_qkv_post(1, 7, 33, 3))  # heads not a multiple of the four a wave walks at a time
     _ok(g.t_small())
