@@ -439,10 +439,74 @@ extern "C" int aitk_ema_update(float* p, float* ema, int64_t n, float one_minus_
 // For every adapter matrix in the fp32 arena (row-major [rows, cols]) write its bf16 shadows in the layouts the skinny kernels
 // and the GEMM K-slab read (AitkShadowDesc in the header): hi = bf16(w), lo = bf16(w - hi) — the split representation that keeps
 // the adapter branch at fp32-class precision (|w - hi - lo| <= 2^-17 |w|) on bf16 MFMA.
+// TILED (default): the plain LoRA matrices (kind 1 / 2, rank <= 64) go through LDS in tiles of 64 columns (A) / 64 rows (B), so that the transposed
+// layouts are written with consecutive lanes on consecutive addresses — the element-per-thread form below scatters 2-byte stores 96 B (the [in, 3 R] block)
+// or a whole row (the transposes) apart: 1.8 ms for the 988 matrices of FLUX r16, once per step (and once per adapter-active forward of the trainer path).
+// Same values to the same places: bit-identical.
+template <bool TILED>
 __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena, bf16_t* shadow, const AitkShadowDesc* table) {
   const AitkShadowDesc d = table[blockIdx.y];
   const long n = (long)d.rows * d.cols;
   const float* src = arena + d.src_off;
+  if constexpr (TILED) {
+    __shared__ bf16_t sh[2][64][66];  // [hi | lo][tile row][tile column] (+ 2: the transposed reads walk the banks)
+    const int tid = threadIdx.x;
+    if (d.kind == 1 && d.rows <= 64) {  // A [R, in]: tile = R ranks x 64 columns
+      const int R = d.rows, w3 = 3 * R;
+      const long stride = d.aux > 0 ? (long)d.aux : (long)w3;
+      for (int c0 = blockIdx.x * 64; c0 < d.cols; c0 += gridDim.x * 64) {
+        const int nc = min(64, d.cols - c0);
+        for (int t = tid; t < R * 64; t += 256) {
+          const int r = t >> 6, cc = t & 63;
+          if (cc < nc) {
+            const long i = (long)r * d.cols + c0 + cc;
+            const float w = src[i];
+            const bf16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+            sh[0][r][cc] = hi;
+            sh[1][r][cc] = lo;
+            shadow[d.d0 + i] = hi;
+            shadow[d.d1 + i] = lo;
+          }
+        }
+        __syncthreads();
+        for (int t = tid; t < nc * w3; t += 256) {
+          const int col = t / w3, j = t - col * w3;
+          const int blk = j / R, rr = j - blk * R;
+          shadow[d.d2 + (long)(c0 + col) * stride + j] = sh[blk == 2][rr][col];
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    if (d.kind == 2 && d.cols <= 64) {  // B [out, R]: tile = 64 rows x R ranks
+      const int R = d.cols, w3 = 3 * R;
+      for (int r0 = blockIdx.x * 64; r0 < d.rows; r0 += gridDim.x * 64) {
+        const int nr = min(64, d.rows - r0);
+        for (int t = tid; t < nr * R; t += 256) {
+          const int rr = t / R, c = t - rr * R;
+          const float w = src[(long)r0 * R + t];
+          const bf16_t hi = f2bf(w), lo = f2bf(w - bf2f(hi));
+          sh[0][rr][c] = hi;
+          sh[1][rr][c] = lo;
+        }
+        __syncthreads();
+        for (int t = tid; t < nr * w3; t += 256) {  // [out, 3 R] rows [hi | hi | lo]: one contiguous block per tile
+          const int rr = t / w3, j = t - rr * w3;
+          const int blk = j / R, c = j - blk * R;
+          shadow[d.d0 + (long)(r0 + rr) * w3 + j] = sh[blk == 2][rr][c];
+        }
+        for (int t = tid; t < R * 64; t += 256) {  // the two transposes [R, out]
+          const int c = t >> 6, rr = t & 63;
+          if (rr < nr) {
+            shadow[d.d1 + (long)c * d.rows + r0 + rr] = sh[0][rr][c];
+            shadow[d.d2 + (long)c * d.rows + r0 + rr] = sh[1][rr][c];
+          }
+        }
+        __syncthreads();
+      }
+      return;
+    }
+  }
   if (d.kind == 3) {  // low-rank LoKr factor: W2 = a [rows, r] @ b [r, cols] composed in fp32 (b follows a in the arena)
     const int r = d.aux;
     const float* a = src;
@@ -510,7 +574,9 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* arena
 extern "C" int aitk_lora_refresh_shadows(const float* arena, aitk_bf16* shadow, const AitkShadowDesc* table, int32_t ntensors,
                                          aitk_stream_t stream) {
   if (!arena || !shadow || !table || ntensors <= 0) return AITK_ERR_ARG;
-  hipLaunchKernelGGL(refresh_shadows_kernel, dim3(16, ntensors), dim3(256), 0, (hipStream_t)stream, arena, shadow, table);
+  const char* e = getenv("AITK_REFRESH_TILED");  // read per launch (one launch per step): =0 -> the element-per-thread form for every matrix (A/B, bit-equality test)
+  if (e && atoi(e) == 0) hipLaunchKernelGGL(refresh_shadows_kernel<false>, dim3(16, ntensors), dim3(256), 0, (hipStream_t)stream, arena, shadow, table);
+  else hipLaunchKernelGGL(refresh_shadows_kernel<true>, dim3(16, ntensors), dim3(256), 0, (hipStream_t)stream, arena, shadow, table);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
