@@ -177,8 +177,11 @@ __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) vo
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int ksteps = p.K / 32;
-  const int kbeg = (ksteps * wave) / NW, kend = (ksteps * (wave + 1)) / NW;
+  // gridDim.y > 1 (aitk_lora_down_ksplit, RAW only): workgroup (x, y) contracts the y-th slice of K for its 32 rows into raw tile y
+  const int ksteps_all = p.K / 32;
+  const int sbeg = (int)(((long)ksteps_all * blockIdx.y) / gridDim.y), ksteps = (int)(((long)ksteps_all * (blockIdx.y + 1)) / gridDim.y) - sbeg;
+  const int kbeg = sbeg + (ksteps * wave) / NW, kend = sbeg + (ksteps * (wave + 1)) / NW;
+  if constexpr (RAW) raw += (long)blockIdx.y * p.M * p.R;
   int ks = kbeg;
   for (; ks + U <= kend; ks += U) {
     s16x8_t xa[U][2], pa[U][RB];
@@ -585,6 +588,25 @@ extern "C" int aitk_lora_t_finish(const AitkLoraDownArgs* a, const float* partia
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
+
+// aitk_lora_down for launches of a FEW rows over a LONG contraction (the adaLN adapters' backward: dT [B, 16] = dmod [B, 6 d] lora_up — one workgroup
+// pulling 1.2 MB of projection through one CU: 35 - 63 us): the contraction is cut into `nsplit` slices, one workgroup each (eight waves), their raw
+// fp32 tiles are summed in slice order by the finish pass that also applies scale / multiplier / mask and writes T like aitk_lora_down would.
+extern "C" int64_t aitk_lora_down_ksplit_workspace_bytes(int32_t M, int32_t R, int32_t nsplit) { return (int64_t)nsplit * M * R * 4; }
+extern "C" int aitk_lora_down_ksplit(const AitkLoraDownArgs* a, float* partial, int32_t nsplit, aitk_stream_t stream) {
+  if (!a || a->M <= 0 || a->K <= 0 || a->R != 16 || (a->K % 32) || nsplit < 1 || nsplit > a->K / 32) return AITK_ERR_SHAPE;
+  if ((a->ldx % 8) || (a->ldp % 8) || ((uintptr_t)partial & 15)) return AITK_ERR_ALIGN;
+  if (!a->X || !a->P || !a->T || !partial) return AITK_ERR_ARG;
+  if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 4) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
+  if (a->mult && a->rows_per_batch <= 0) return AITK_ERR_ARG;
+  hipLaunchKernelGGL((lora_down16_kernel<1, 6, true, 8>), dim3((a->M + 31) / 32, nsplit), dim3(512), 0, (hipStream_t)stream, *a, partial);
+  AITK_LAUNCH_CHECK();
+  const long nt = (long)a->M * (a->R / 4);
+  hipLaunchKernelGGL(lora_dt_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a, (const float*)partial, nsplit);
+  AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+
 
 // 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four
 // partial sums are combined through LDS in a fixed order (deterministic; 4x shorter dependent-load chain than one thread per

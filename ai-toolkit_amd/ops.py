@@ -297,10 +297,17 @@ def _lora_down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo,
         a.mult, a.rows_per_batch = _ptr(mult), rows_per_batch
     a.scale = float(scale)
     a.M, a.K, a.R = (x.shape[0] if M is None else M), K, R
+    if KSPLIT and a.M <= 32 and R == 16 and K >= 6144 and K % 1536 == 0:
+        # a few rows over a long contraction (adaLN adapters' backward): K slices of 1536 across workgroups + one finish pass (aitk_lora_down_ksplit)
+        nsplit = K // 1536
+        ws = workspace(_capi.lib().aitk_lora_down_ksplit_workspace_bytes(a.M, R, nsplit), x.device, "down_ksplit")
+        _call("aitk_lora_down_ksplit", C.byref(a), _ptr(ws), nsplit)
+        return out
     _call("aitk_lora_down", C.byref(a))
     return out
 
 
+KSPLIT = os.environ.get("AITK_LORA_DOWN_KSPLIT", "1") != "0"  # 0: single-workgroup launches stay single-workgroup launches (A/B)
 EMIT_T_ROW_TILE = 1  # AITK_EPI_EMIT_T takes any row count on the HIP kernel (the graphs ask the kernel table: oracle/ref_ops.py keeps whole 256-row tiles)
 
 

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 10 /* 10: AITK_EPI_EMIT_T + AitkGemmArgs.t_* (a GELU launch emits the column-tile partials of the NEXT layer's lora_down product), aitk_lora_t_finish, aitk_lora_down_raw; 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 11 /* 11: aitk_lora_down_ksplit (aitk_lora_down for a few rows over a long contraction: K slices across workgroups + the aitk_lora_t_finish pass, one call); 10: AITK_EPI_EMIT_T + AitkGemmArgs.t_* (a GELU launch emits the column-tile partials of the NEXT layer's lora_down product), aitk_lora_t_finish, aitk_lora_down_raw; 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -160,6 +160,13 @@ int aitk_lora_down(const AitkLoraDownArgs* args, aitk_stream_t stream);
  * X / P / ldx / K of the finish call are ignored. */
 int aitk_lora_down_raw(const AitkLoraDownArgs* args, float* raw, aitk_stream_t stream);
 int aitk_lora_t_finish(const AitkLoraDownArgs* args, const float* partial, int32_t ntiles, aitk_stream_t stream);
+/* aitk_lora_down when M is a few rows and K is long (the adaLN adapters' backward, toolkit/network_mixins.py:309-321 under autograd: dT [B, r] = dmod [B, 6 d] lora_up):
+ * one workgroup per 32 rows would pull the whole projection through one CU.  The contraction is cut into `nsplit` slices (1 <= nsplit <= K / 32), one workgroup
+ * each; their raw fp32 tiles land in `partial` (aitk_lora_down_ksplit_workspace_bytes(M, R, nsplit) bytes, 16-byte aligned) and are summed in slice order
+ * (deterministic) by a finish pass that applies scale / mult / tmask and writes T exactly like aitk_lora_down (same argument block, R == 16).  Equal to
+ * aitk_lora_down up to the fp32 summation order. */
+int64_t aitk_lora_down_ksplit_workspace_bytes(int32_t M, int32_t R, int32_t nsplit);
+int aitk_lora_down_ksplit(const AitkLoraDownArgs* args, float* partial, int32_t nsplit, aitk_stream_t stream);
 
 /*
  * out[r * out_stride_r + l * out_stride_l] (+)= sum_m S[m][r] * G[m][l]        fp32 out, R in {16,32,48,64}, L % 8 == 0

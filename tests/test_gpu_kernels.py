@@ -101,6 +101,10 @@ def test_split_precision_skinny_kernels():
     _ok(g.t_lora_wgrad_split(2, 16, 16, 18432, transpose=True))
     _ok(g.t_lora_down_mask(1000, 3072, 16, per_sample=True))     # rank_dropout: one mask row per sample
     _ok(g.t_lora_down_mask(1000, 3072, 16, per_sample=False))    # neuron dropout: one mask row per token
+    # a few rows over a long contraction (adaLN adapters' backward): K slices across workgroups + finish pass (aitk_lora_down_ksplit, ABI 11)
+    _ok(g.t_lora_down_mask(8, 18432, 16, per_sample=True))
+    _ok(g.t_lora_down_mask(7, 9216, 16, per_sample=False))
+    _ok(g.t_lora_down_split(32, 18432, 16, 16, mult=True))
 
 
 def test_adapter_branch_matches_fp32_adapter_arithmetic():
@@ -112,6 +116,37 @@ def test_adapter_branch_matches_fp32_adapter_arithmetic():
     _ok(r)
     assert r["dA_single_bf16"] > 1e-3 and r["dB_single_bf16"] > 1e-3, r
     _ok(g.t_adapter_branch(2048, 3072, 12288, 32))
+
+
+def test_lora_down_ksplit_equals_the_single_workgroup_launch():
+    """Same operands through both routes: equal up to the fp32 summation order (and the route is really taken: the entry point is called)."""
+    import torch
+
+    from ai_toolkit_amd import _capi, ops
+
+    dev, bf = "cuda", torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    for M, K in ((7, 18432), (1, 9216), (32, 6144)):
+        x = torch.randn(M, K, generator=g).to(bf).to(dev)
+        p32 = (torch.randn(16, K, generator=g) * 0.05).to(dev)
+        p_hi = p32.to(bf)
+        p_lo = (p32 - p_hi.float()).to(bf)
+        mult = torch.rand(M, generator=g).to(dev) + 0.5
+        outs = []
+        for on in (False, True):
+            old, ops.KSPLIT = ops.KSPLIT, on
+            try:
+                out = torch.zeros(M, 48, dtype=bf, device=dev)
+                ops.lora_down(x, p_hi, out, scale=0.5, mult=mult, rows_per_batch=1, p_lo=p_lo, split=16)
+                outs.append(out[:, :16].float() + out[:, 16:32].float())
+            finally:
+                ops.KSPLIT = old
+        torch.cuda.synchronize()
+        want = 0.5 * mult[:, None] * (x.float() @ p32.t())
+        e_route = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+        e_ref = ((outs[1] - want).norm() / want.norm()).item()
+        assert e_route < 1e-5 and e_ref < 2e-3, (M, K, e_route, e_ref)
+    assert _capi.lib().aitk_lora_down_ksplit_workspace_bytes(7, 16, 12) == 7 * 16 * 12 * 4
 
 
 def test_norm_and_elementwise_kernels():
