@@ -158,25 +158,28 @@ __global__ __launch_bounds__(256) void lora_down_kernel(AitkLoraDownArgs p) {
 // B = 1) and a launch is a latency chain of K / (NW * 32 * U) load batches per wave: eight waves halve the chain (the sum over K slices has another order:
 // equal to the 4-wave kernel to fp32 rounding, chosen by row count only, so a sample's result does not depend on the other samples of a short batch);
 // 16 for launches of ONE workgroup (M <= 32 rows: the adaLN adapters' B x 18432 backward operand was a 24-batch chain on four waves).
-template <int RB, int U, bool RAW = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
-  __shared__ __attribute__((aligned(16))) float red[NW * RB * 2 * 4 * 64];
+// NB = 16-row blocks per workgroup (2, or 4 for LONG launches of wide rank groups): every workgroup re-reads the whole projection (hi + lo) through its L1, and that
+// L2 -> L1 traffic is what a launch costs beside its X stream (tools/gpu_lora_down_bench.py: 32 us + 11 us per 16-rank half at M = 32256, K = 3072 — 120 us for the
+// 64-rank q,k,v,proj_mlp group); 64-row workgroups halve it.  Each (row, rank) sum keeps its own order of contributions for a given U.
+template <int RB, int U, bool RAW = false, int NW = 4, int NB = 2>
+__global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4 && NB == 2) ? 4 : 1) void lora_down16_kernel(AitkLoraDownArgs p, float* raw = nullptr) {
+  __shared__ __attribute__((aligned(16))) float red[NW * RB * NB * 4 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 32;
-  const bf16_t* xrow[2];
+  const int m0 = blockIdx.x * (16 * NB);
+  const bf16_t* xrow[NB];
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
+  for (int blk = 0; blk < NB; ++blk)
     xrow[blk] = seg_row2(p.X, p.ldx, p.x_seg_rows, p.x_seg_stride, min(m0 + blk * 16 + i16, p.M - 1)) + 8 * g;
   const bf16_t* prow[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) prow[rb] = p.P + (long)min(rb * 16 + i16, p.R - 1) * p.ldp + 8 * g;
   const long lo_off = p.P_lo ? (p.P_lo - p.P) : 0;
-  f32x4_t acc[RB][2];
+  f32x4_t acc[RB][NB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   // gridDim.y > 1 (aitk_lora_down_ksplit, RAW only): workgroup (x, y) contracts the y-th slice of K for its 32 rows into raw tile y
   const int ksteps_all = p.K / 32;
   const int sbeg = (int)(((long)ksteps_all * blockIdx.y) / gridDim.y), ksteps = (int)(((long)ksteps_all * (blockIdx.y + 1)) / gridDim.y) - sbeg;
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) vo
   if constexpr (RAW) raw += (long)blockIdx.y * p.M * p.R;
   int ks = kbeg;
   for (; ks + U <= kend; ks += U) {
-    s16x8_t xa[U][2], pa[U][RB];
+    s16x8_t xa[U][NB], pa[U][RB];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = (ks + u) * 32;
-      xa[u][0] = *reinterpret_cast<const s16x8_t*>(xrow[0] + k);
-      xa[u][1] = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) xa[u][blk] = *reinterpret_cast<const s16x8_t*>(xrow[blk] + k);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) pa[u][rb] = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
     }
@@ -203,39 +206,38 @@ __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) vo
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);
-          acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
-        }
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pa[u][rb], xa[u][blk], acc[rb][blk]);
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-          acc[rb][0] = mfma16(pl[u][rb], xa[u][0], acc[rb][0]);
-          acc[rb][1] = mfma16(pl[u][rb], xa[u][1], acc[rb][1]);
-        }
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pl[u][rb], xa[u][blk], acc[rb][blk]);
       continue;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        acc[rb][0] = mfma16(pa[u][rb], xa[u][0], acc[rb][0]);  // D rows = rank, cols = x row
-        acc[rb][1] = mfma16(pa[u][rb], xa[u][1], acc[rb][1]);
-      }
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pa[u][rb], xa[u][blk], acc[rb][blk]);  // D rows = rank, cols = x row
   }
   for (; ks < kend; ++ks) {
     const int k = ks * 32;
-    const s16x8_t x0 = *reinterpret_cast<const s16x8_t*>(xrow[0] + k), x1 = *reinterpret_cast<const s16x8_t*>(xrow[1] + k);
+    s16x8_t xt[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) xt[blk] = *reinterpret_cast<const s16x8_t*>(xrow[blk] + k);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(prow[rb] + k);
-      acc[rb][0] = mfma16(pf, x0, acc[rb][0]);
-      acc[rb][1] = mfma16(pf, x1, acc[rb][1]);
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pf, xt[blk], acc[rb][blk]);
       if (lo_off) {
         const s16x8_t pl = *reinterpret_cast<const s16x8_t*>(prow[rb] + lo_off + k);
-        acc[rb][0] = mfma16(pl, x0, acc[rb][0]);
-        acc[rb][1] = mfma16(pl, x1, acc[rb][1]);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) acc[rb][blk] = mfma16(pl, xt[blk], acc[rb][blk]);
       }
     }
   }
@@ -243,15 +245,15 @@ __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) vo
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
+    for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((wave * RB + rb) * 2 + blk) * 4 + r) * 64 + lane] = acc[rb][blk][r];
+      for (int r = 0; r < 4; ++r) red[(((wave * RB + rb) * NB + blk) * 4 + r) * 64 + lane] = acc[rb][blk][r];
   __syncthreads();
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      if (((rb * 2 + blk) & 3) != wave) continue;
+    for (int blk = 0; blk < NB; ++blk) {
+      if (((rb * NB + blk) & 3) != wave) continue;
       const int m = m0 + blk * 16 + i16;
       float c = p.scale;
       if (p.mult) c *= p.mult[min(m, p.M - 1) / p.rows_per_batch];
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64 * NW, (RB == 1 && U <= 6 && NW == 4) ? 4 : 1) vo
       for (int r = 0; r < 4; ++r) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += red[(((w * RB + rb) * 2 + blk) * 4 + r) * 64 + lane];
+        for (int w = 0; w < NW; ++w) s += red[(((w * RB + rb) * NB + blk) * 4 + r) * 64 + lane];
         v[r] = RAW ? s : s * c;
       }
       const int rr = rb * 16 + 4 * g;  // lane holds ranks rr..rr+3 of row m (mfma16 D layout: row 4*(l>>4)+reg, col l&15)
@@ -292,8 +294,21 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
       const char* e = getenv("AITK_LORA_DOWN_SHORT8");
       short8 = (e && atoi(e) == 0) ? 0 : 1;
     }
+    // LONG launches (>= 16384 rows: B >= 4 at 1024^2): 64-row workgroups for the rank widths in the mask AITK_LORA_DOWN_NB4 (bit 0: <= 16 ranks, 1: <= 32, 2: <= 48,
+    // 3: <= 64) — half the projection traffic per row (kernel comment)
+    static int nb4 = -1;
+    if (nb4 < 0) {
+      const char* e = getenv("AITK_LORA_DOWN_NB4");
+      nb4 = e ? atoi(e) : 15;
+    }
+    const int grid64 = (a->M + 63) / 64;
+    const bool lng = a->M >= 16384;
+    if (lng && a->R > 48 && (nb4 & 8)) hipLaunchKernelGGL((lora_down16_kernel<4, 2, false, 4, 4>), dim3(grid64), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (lng && a->R > 32 && a->R <= 48 && (nb4 & 4)) hipLaunchKernelGGL((lora_down16_kernel<3, 2, false, 4, 4>), dim3(grid64), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (lng && a->R > 16 && a->R <= 32 && (nb4 & 2)) hipLaunchKernelGGL((lora_down16_kernel<2, 4, false, 4, 4>), dim3(grid64), dim3(256), 0, (hipStream_t)stream, *a);
+    else if (lng && a->R <= 16 && (nb4 & 1)) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 4, 4>), dim3(grid64), dim3(256), 0, (hipStream_t)stream, *a);
     // one workgroup for the whole launch (M <= 32: the adaLN adapters, B rows x K = 3 d / 6 d in their backward): 16 K slices
-    if (a->R <= 16 && short8 && a->M <= 32 && a->K >= 32 * 6 * 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 16>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, *a);
+    else if (a->R <= 16 && short8 && a->M <= 32 && a->K >= 32 * 6 * 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 16>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16 && short8 && a->M < 16384 && a->K >= 32 * 6 * 8) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
@@ -312,7 +327,8 @@ extern "C" int aitk_lora_down_raw(const AitkLoraDownArgs* a, float* raw, aitk_st
   if (!a || !raw || a->M <= 0 || a->K <= 0 || (a->R != 16 && a->R != 32) || (a->K % 32)) return AITK_ERR_SHAPE;
   if ((a->ldx % 8) || (a->ldp % 8) || ((uintptr_t)raw & 15)) return AITK_ERR_ALIGN;
   if (!a->X || !a->P) return AITK_ERR_ARG;
-  if (a->R == 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
+  if (a->R == 16 && a->M >= 16384) hipLaunchKernelGGL((lora_down16_kernel<1, 6, true, 4, 4>), dim3((a->M + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a, raw);  // 64-row workgroups (kernel comment)
+  else if (a->R == 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
   else hipLaunchKernelGGL((lora_down16_kernel<2, 8, true>), dim3((a->M + 31) / 32), dim3(256), 0, (hipStream_t)stream, *a, raw);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
