@@ -577,9 +577,9 @@ __global__ __launch_bounds__(256) void lora_bwd_fused_ct_kernel(AitkLoraWgradArg
 
 // dT[m][r..r+3] = c[m] * sum over the column tiles (fixed order: deterministic) of the partials, written like aitk_lora_down writes it
 // (bf16, or the [hi | lo | hi] K-slab of the rank block; dropout mask applied on the fp32 value)
-__global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p, const float* part, int ntiles) {
+__device__ __forceinline__ void lora_dt_finish_body(const AitkLoraDownArgs& p, const float* part, int ntiles, long block) {
   const int per_row = p.R / 4;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long idx = block * 256 + threadIdx.x;
   if (idx >= (long)p.M * per_row) return;
   const int m = (int)(idx / per_row), rr = (int)(idx - (long)m * per_row) * 4;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -592,6 +592,9 @@ __global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p,
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] *= c;
   store_t4(p, m, rr, v);
+}
+__global__ __launch_bounds__(256) void lora_dt_finish_kernel(AitkLoraDownArgs p, const float* part, int ntiles) {
+  lora_dt_finish_body(p, part, ntiles, (long)blockIdx.x);
 }
 
 extern "C" int aitk_lora_t_finish(const AitkLoraDownArgs* a, const float* partial, int32_t ntiles, aitk_stream_t stream) {
@@ -627,10 +630,9 @@ extern "C" int aitk_lora_down_ksplit(const AitkLoraDownArgs* a, float* partial, 
 // 64 outputs per 256-thread block: thread (j = tid & 63, k = tid >> 6) sums the chunks c = k, k+4, ... of output j, the four
 // partial sums are combined through LDS in a fixed order (deterministic; 4x shorter dependent-load chain than one thread per
 // output, which matters for the LoKr factor gradients whose row count M * factor runs into the millions).
-__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(AitkLoraWgradArgs p, int nchunks) {
-  __shared__ float red[256];
+__device__ __forceinline__ void lora_wgrad_finish_body(const AitkLoraWgradArgs& p, int nchunks, long block, float* red) {
   const int j = threadIdx.x & 63, k = threadIdx.x >> 6;
-  const long idx = (long)blockIdx.x * 64 + j;
+  const long idx = block * 64 + j;
   const long total = (long)p.R * p.L;
   float s = 0.f;
   if (idx < total)
@@ -642,6 +644,17 @@ __global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(AitkLoraWgradArg
   const int r = (int)(idx / p.L), l = (int)(idx - (long)r * p.L);
   float* o = p.out + (long)r * p.out_stride_r + (long)l * p.out_stride_l;
   *o = p.accumulate ? (*o + s) : s;
+}
+__global__ __launch_bounds__(256) void lora_wgrad_finish_kernel(AitkLoraWgradArgs p, int nchunks) {
+  __shared__ float red[256];
+  lora_wgrad_finish_body(p, nchunks, (long)blockIdx.x, red);
+}
+// the two finish passes of aitk_lora_bwd_fused (lora_up gradient: blocks [0, nblk_w); dT slab: the rest) as ONE launch: they are independent, and at short
+// batches a launch of their size is mostly its own start-up
+__global__ __launch_bounds__(256) void lora_bwd_finish2_kernel(AitkLoraWgradArgs w, int nchunks, int nblk_w, AitkLoraDownArgs d, const float* dt_part, int ntiles) {
+  __shared__ float red[256];
+  if ((int)blockIdx.x < nblk_w) lora_wgrad_finish_body(w, nchunks, (long)blockIdx.x, red);  // block-uniform branch: the barrier inside is reached by all or none
+  else lora_dt_finish_body(d, dt_part, ntiles, (long)blockIdx.x - nblk_w);
 }
 
 extern "C" int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t L) {
@@ -749,9 +762,20 @@ extern "C" int aitk_lora_bwd_fused(const AitkLoraWgradArgs* a, const AitkLoraDow
   }
   AITK_LAUNCH_CHECK();
   const long total = (long)a->R * a->L;
+  const long nt = (long)d->M * (d->R / 4);
+  static int merged = -1;  // AITK_LORA_FINISH_MERGED=0: the two finish passes as two launches (A/B)
+  if (merged < 0) {
+    const char* e = getenv("AITK_LORA_FINISH_MERGED");
+    merged = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (merged) {
+    const int nblk_w = (int)((total + 63) / 64);
+    hipLaunchKernelGGL(lora_bwd_finish2_kernel, dim3((unsigned)(nblk_w + (nt + 255) / 256)), dim3(256), 0, s, *a, nchunks, nblk_w, *d, (const float*)dt_partial, ntiles);
+    AITK_LAUNCH_CHECK();
+    return AITK_OK;
+  }
   hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
   AITK_LAUNCH_CHECK();
-  const long nt = (long)d->M * (d->R / 4);
   hipLaunchKernelGGL(lora_dt_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, *d, (const float*)dt_partial, ntiles);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
