@@ -78,6 +78,13 @@ def test_lora_skinny_kernels():
     _ok(g.t_lora_down(512, 3072, 48, mult=True))
     _ok(g.t_lora_down(600, 1024, 64, seg=True))
     _ok(g.t_lora_down(2, 18432, 16))
+    # long launches (>= 16384 rows): 64-row workgroups, every rank width, row counts that are no multiple of 64, segmented rows, per-sample multipliers
+    _ok(g.t_lora_down(16400, 1024, 16))
+    _ok(g.t_lora_down(16418, 1024, 32, mult=True))
+    _ok(g.t_lora_down(16450, 1024, 48, seg=True))
+    _ok(g.t_lora_down(16390, 1024, 64, mult=True, seg=True))
+    _ok(g.t_lora_down_split(16400, 1024, 64, 16, mult=True))
+    _ok(g.t_lora_down_split(16434, 1024, 48, 16, seg=True))
     _ok(g.t_lora_wgrad(4608, 16, 3072))
     _ok(g.t_lora_wgrad(1000, 16, 3072, transpose=True))
     _ok(g.t_lora_wgrad(700, 48, 1024, accumulate=True))
