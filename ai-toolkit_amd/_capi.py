@@ -217,7 +217,7 @@ _STRUCTS = {0: GemmArgs, 1: LoraDownArgs, 2: LoraWgradArgs, 3: LnModArgs, 4: LnM
             19: KronApplyArgs, 20: GroupNormBwdArgs, 21: DdpmNoiseArgs, 22: QuantRowsArgs, 23: WgradSrc2}
 
 
-ABI_VERSION = 11  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
+ABI_VERSION = 12  # AITK_ABI_VERSION of include/aitk_mi355.h this mirror was written against
 
 
 def lib():
@@ -261,6 +261,8 @@ def lib():
     L.aitk_lora_down_ksplit_workspace_bytes.restype = C.c_int64
     L.aitk_lora_down_ksplit_workspace_bytes.argtypes = [i32, i32, i32]
     L.aitk_lora_down_ksplit.argtypes = [vp, vp, i32, vp]
+    L.aitk_lora_wgrad_main.argtypes = [vp, vp, vp]
+    L.aitk_lora_wgrad_finish_multi.argtypes = [vp, i32, vp]
     L.aitk_lokr_lowrank_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.aitk_grad_compress_bf16.argtypes = [vp, vp, i64, vp]
     L.aitk_grad_expand_bf16.argtypes = [vp, vp, i64, vp]

@@ -662,17 +662,21 @@ extern "C" int64_t aitk_lora_wgrad_workspace_bytes(int32_t M, int32_t R, int32_t
   return nchunks * (int64_t)R * L * 4;
 }
 
-extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream) {
+static int wgrad_row_chunk(int M) {
+  int mc = M >= 8192 ? 2 * WG_MC : WG_MC;
+  if ((M + mc - 1) / mc > 512) mc = ((M + 511) / 512 + 63) / 64 * 64;  // millions of rows (LoKr): at most 512 row chunks
+  return mc;
+}
+// the producing launch of aitk_lora_wgrad (chunk partials only)
+static int wgrad_main(const AitkLoraWgradArgs* a, hipStream_t s) {
   if (!a || a->M <= 0 || a->R <= 0 || a->L <= 0) return AITK_ERR_SHAPE;
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->ldg % 8) || (a->lds % 8)) return AITK_ERR_ALIGN;
   if (!a->partial || !a->out) return AITK_ERR_ARG;
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
-  int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
-  if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;  // millions of rows (LoKr): at most 512 row chunks
+  const int mc = wgrad_row_chunk(a->M);
   const int nchunks = (a->M + mc - 1) / mc;
   dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
-  hipStream_t s = (hipStream_t)stream;
   switch (a->R / 16) {
     case 1: hipLaunchKernelGGL(lora_wgrad_kernel<1>, grid, dim3(256), 0, s, *a, mc); break;
     case 2: hipLaunchKernelGGL(lora_wgrad_kernel<2>, grid, dim3(256), 0, s, *a, mc); break;
@@ -680,16 +684,25 @@ extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream)
     default: hipLaunchKernelGGL(lora_wgrad_kernel<4>, grid, dim3(256), 0, s, *a, mc); break;
   }
   AITK_LAUNCH_CHECK();
+  return AITK_OK;
+}
+static int wgrad_finish(const AitkLoraWgradArgs* a, hipStream_t s) {
+  const int mc = wgrad_row_chunk(a->M);
+  const int nchunks = (a->M + mc - 1) / mc;
   const long total = (long)a->R * a->L;
   hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }
+extern "C" int aitk_lora_wgrad(const AitkLoraWgradArgs* a, aitk_stream_t stream) {
+  const int rc = wgrad_main(a, (hipStream_t)stream);
+  return rc != AITK_OK ? rc : wgrad_finish(a, (hipStream_t)stream);
+}
 
 // aitk_lora_wgrad with a two-part G operand: out[r][l] += sum_m S[m][r] * X[m][l],  X[m][l] = G[m][l] for l < split_col and
 // act(G2[m][l - split_col]) beyond — the lora_down gradient of a layer whose input is [attention output | gelu(pre-activation)] (FLUX single
 // blocks' proj_out) or gelu(pre-activation) alone (ff.net.2, split_col = 0) WITHOUT keeping the GELU output resident: 6.4 GB per image at 1024^2.
-extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2* q, aitk_stream_t stream) {
+static int wgrad2_main(const AitkLoraWgradArgs* a, const AitkWgradSrc2* q, hipStream_t s) {
   if (!a || !q || a->M <= 0 || a->R <= 0 || a->L <= 0) return AITK_ERR_SHAPE;
   if ((a->R % 16) || a->R > 64 || (a->L % 8)) return AITK_ERR_SHAPE;
   if ((a->lds % 8) || (q->ldg2 % 8)) return AITK_ERR_ALIGN;
@@ -697,11 +710,9 @@ extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2*
   if (q->split_col < 0 || q->split_col >= a->L || (q->split_col % WG_LT) || (q->act != 0 && q->act != 1)) return AITK_ERR_ARG;
   if (q->split_col > 0 && (!a->G || (a->ldg % 8))) return AITK_ERR_ARG;
   if (a->split_rp < 0 || (a->split_rp > 0 && ((a->split_rp % 8) || (a->split_rp < a->R && (a->R % a->split_rp))))) return AITK_ERR_ARG;
-  int mc = a->M >= 8192 ? 2 * WG_MC : WG_MC;
-  if ((a->M + mc - 1) / mc > 512) mc = ((a->M + 511) / 512 + 63) / 64 * 64;
+  const int mc = wgrad_row_chunk(a->M);
   const int nchunks = (a->M + mc - 1) / mc;
   dim3 grid((a->L + WG_LT - 1) / WG_LT, nchunks);
-  hipStream_t s = (hipStream_t)stream;
   switch (a->R / 16) {
     case 1: hipLaunchKernelGGL(lora_wgrad2_kernel<1>, grid, dim3(256), 0, s, *a, *q, mc); break;
     case 2: hipLaunchKernelGGL(lora_wgrad2_kernel<2>, grid, dim3(256), 0, s, *a, *q, mc); break;
@@ -709,8 +720,53 @@ extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2*
     default: hipLaunchKernelGGL(lora_wgrad2_kernel<4>, grid, dim3(256), 0, s, *a, *q, mc); break;
   }
   AITK_LAUNCH_CHECK();
-  const long total = (long)a->R * a->L;
-  hipLaunchKernelGGL(lora_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, *a, nchunks);
+  return AITK_OK;
+}
+extern "C" int aitk_lora_wgrad2(const AitkLoraWgradArgs* a, const AitkWgradSrc2* q, aitk_stream_t stream) {
+  const int rc = wgrad2_main(a, q, (hipStream_t)stream);
+  return rc != AITK_OK ? rc : wgrad_finish(a, (hipStream_t)stream);
+}
+
+// ---- deferred finish (ABI 12) ----
+// aitk_lora_wgrad_main: the producing launch alone (src2 == NULL: aitk_lora_wgrad's, else aitk_lora_wgrad2's); `partial` then holds the chunk partials and `out`
+// is untouched until aitk_lora_wgrad_finish_multi is handed the same argument block.  Nothing in a backward pass reads a weight gradient before the optimizer, so a
+// trainer may collect up to AITK_WGRAD_FINISH_MAX finishes (each with its own `partial` buffer, outputs pairwise distinct) and run them as ONE launch: at short
+// batches a finish launch is mostly its own start-up (5 us behind a 10-us producer, 380 of them per FLUX step).  Same arithmetic as the separate launch, bit for bit.
+#define AITK_WGRAD_FINISH_MAX 8
+struct WgradFinishJobs {
+  AitkLoraWgradArgs p[AITK_WGRAD_FINISH_MAX];
+  int nchunks[AITK_WGRAD_FINISH_MAX];
+  int blk_end[AITK_WGRAD_FINISH_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void lora_wgrad_finish_multi_kernel(WgradFinishJobs j) {
+  __shared__ float red[256];
+  int i = 0;
+  while (i + 1 < j.n && (int)blockIdx.x >= j.blk_end[i]) ++i;
+  const int first = i ? j.blk_end[i - 1] : 0;
+  lora_wgrad_finish_body(j.p[i], j.nchunks[i], (long)blockIdx.x - first, red);
+}
+extern "C" int aitk_lora_wgrad_main(const AitkLoraWgradArgs* a, const AitkWgradSrc2* src2, aitk_stream_t stream) {
+  return src2 ? wgrad2_main(a, src2, (hipStream_t)stream) : wgrad_main(a, (hipStream_t)stream);
+}
+extern "C" int aitk_lora_wgrad_finish_multi(const AitkLoraWgradArgs* jobs, int32_t njobs, aitk_stream_t stream) {
+  if (!jobs || njobs < 1 || njobs > AITK_WGRAD_FINISH_MAX) return AITK_ERR_ARG;
+  WgradFinishJobs j;
+  int blocks = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const AitkLoraWgradArgs& a = jobs[i];
+    if (a.M <= 0 || a.R <= 0 || a.L <= 0) return AITK_ERR_SHAPE;
+    if (!a.partial || !a.out) return AITK_ERR_ARG;
+    for (int k = 0; k < i; ++k)
+      if (jobs[k].out == a.out) return AITK_ERR_ARG;  // two accumulations into one matrix inside one launch would race
+    const int mc = wgrad_row_chunk(a.M);
+    j.p[i] = a;
+    j.nchunks[i] = (a.M + mc - 1) / mc;
+    blocks += (int)(((long)a.R * a.L + 63) / 64);
+    j.blk_end[i] = blocks;
+  }
+  j.n = njobs;
+  hipLaunchKernelGGL(lora_wgrad_finish_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, j);
   AITK_LAUNCH_CHECK();
   return AITK_OK;
 }

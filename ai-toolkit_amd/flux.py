@@ -439,6 +439,9 @@ class FluxTransformer2DModel(FusedGraphBase):
         scale = 1.0 / math.sqrt(128.0)
         Cin = self.in_channels
 
+        # the finish passes of the lora_down / adaLN weight gradients are collected and go out eight at a time (ops.wgrad_defer_begin); flushed before
+        # the gradient is handed on (all-reduce pieces, optimizer)
+        wdefer = getattr(ops, "wgrad_defer_begin", None) is not None and ops.wgrad_defer_begin(dpred.device)
         # ---- head
         dxn = self._new(Mi, d)
         ops.gemm_nt(dpred.to(self.dt).reshape(Mi, Cin).contiguous(), self.proj_out.weight_t, dxn)
@@ -490,6 +493,8 @@ class FluxTransformer2DModel(FusedGraphBase):
             r.clear()
 
         if self.grad_ready_hook is not None:
+            if wdefer:
+                ops.wgrad_defer_flush()
             self.grad_ready_hook("single")
 
         # ---- split the joint gradient
@@ -558,6 +563,8 @@ class FluxTransformer2DModel(FusedGraphBase):
                                             (blk.attn.norm_added_q, blk.attn.norm_added_k))])
             dx_img, dx_txt = new_grads["img"], new_grads["txt"]
             rec.clear()
+        if wdefer:
+            ops.wgrad_defer_end()
         if self.grad_ready_hook is not None:
             self.grad_ready_hook("double")
         self._q8_reset()

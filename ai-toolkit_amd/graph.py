@@ -350,6 +350,10 @@ class FusedGraphBase(nn.Module):
     def _new(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dt, device=self._device())
 
+    def _defer_kw(self):
+        """{'defer': True} on a kernel table that can collect weight-gradient finishes (the MI355X table), {} on the others."""
+        return {"defer": True} if hasattr(self.ops, "wgrad_defer_begin") else {}
+
     def _lora_active(self, lin):
         net = self.network
         return (lin.lora is not None and net is not None and net.is_active and not net.is_merged_in
@@ -713,11 +717,12 @@ class FusedGraphBase(nn.Module):
                           tmask_rows_per_batch=tm_rpb)
             ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
         if dT_out is None:
+            # nothing reads lora_down.weight.grad before the optimizer: its finish pass may be collected (ops.wgrad_defer_begin)
             if isinstance(x_in, _ActInput):  # the input is [g | gelu(pre-activation)] and only the pre-activation was kept
                 assert x_seg is None
-                ops.lora_wgrad(dT, x_in.g, lo.g_down, accumulate=True, M=M, split=rp, g2=x_in.g2, g2_act=x_in.act)
+                ops.lora_wgrad(dT, x_in.g, lo.g_down, accumulate=True, M=M, split=rp, g2=x_in.g2, g2_act=x_in.act, **self._defer_kw())
             else:
-                ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp)
+                ops.lora_wgrad(dT, x_in, lo.g_down, accumulate=True, g_seg=x_seg, M=M, split=rp, **self._defer_kw())
         return dT
 
     def _dora_dz(self, lin, dy, M):
@@ -758,7 +763,7 @@ class FusedGraphBase(nn.Module):
             kw = dict(a2=dTcat, b2=grp["sh_downT3"]) if grp is not None else {}
             self.ops.gemm_nt(cat[0], cat[1], dx, flags=first_flags, M=M, **kw)
             if grp is not None:
-                self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
+                self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"], **self._defer_kw())
             return
         for j, (lin, dy, T) in enumerate(zip(lins, dys, Ts)):
             dy = self._dora_dz(lin, dy, M)
@@ -769,7 +774,7 @@ class FusedGraphBase(nn.Module):
             dT = self._lora_grads(lin, dy, T, x_in, M=M, rows_per_batch=rows_per_batch, B=B, dT_out=dT_out)
             self._lin_dgrad(lin, dy, dT, dx, M=M, flags=(first_flags if j == 0 else EPI_ACCUM))
         if grp is not None:
-            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"])
+            self.ops.lora_wgrad(dTcat, x_in, grp["g_down"], accumulate=True, M=M, split=grp["rp"], **self._defer_kw())
 
     def dgrad_census(self, reset=False):
         """{'concat': n, 'fallback': n} of the same-input groups seen by _group_bwd since the last reset (groups laid out for the concatenated
@@ -914,5 +919,5 @@ class FusedGraphBase(nn.Module):
         tm, tm_rpb = getattr(T, "_tmask", (None, 0))
         ops.lora_down(dmod, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=B, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
                       tmask_rows_per_batch=tm_rpb)
-        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B, split=rp)
-        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B, split=rp)
+        ops.lora_wgrad(T, dmod, lo.g_up, transpose_out=True, accumulate=True, M=B, split=rp, **self._defer_kw())
+        ops.lora_wgrad(dT, silu_temb, lo.g_down, accumulate=True, M=B, split=rp, **self._defer_kw())

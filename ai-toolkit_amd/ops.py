@@ -48,6 +48,9 @@ def _emit(name, args):
     if name == "_host":
         args[0]()
         return
+    if name == "_wgrad_defer":
+        _emit_wgrad_defer(*args)
+        return
     timed = _gemm_hook is not None and name in ("aitk_gemm_nt", "aitk_gemm_nt_grouped")
     timed_attn = _attn_hook is not None and name in ("aitk_attn_fwd", "aitk_attn_bwd")
     if timed or timed_attn:
@@ -81,6 +84,76 @@ def host_call(fn):
         _REC.append(("_host", (fn,)))
         return
     fn()
+
+
+# ---------------------------------------------------------------------------------------------------------- deferred weight-gradient finishes
+# aitk_lora_wgrad = a producing launch (chunk partials) + a finish launch (sum of the chunks into the gradient arena).  Nothing in a backward pass reads a weight
+# gradient, so between wgrad_defer_begin() and wgrad_defer_end() the finishes of launches flagged `defer` are collected — each producer writes into its own slot of a
+# ring of partial buffers — and go out eight at a time as ONE launch (aitk_lora_wgrad_finish_multi, ABI 12; same sums, bit for bit).  At B = 1 a finish launch is
+# 5 us of start-up behind a 10-us producer, 380 times per step.  Everything is decided when a launch is EMITTED (ring slot, batch boundaries), so the merged image /
+# text launch lists of the double blocks keep one consistent order.
+WGRAD_DEFER = os.environ.get("AITK_WGRAD_DEFER", "1") != "0"
+WGRAD_DEFER_MAX = 8
+_wdefer = None  # {"jobs": [(args, keep)], "slot": int} while a backward pass collects
+
+
+def wgrad_defer_begin(device):
+    global _wdefer
+    if _wdefer is not None:  # a backward pass that raised half way: its gradients are void anyway
+        _wdefer = None
+    if not WGRAD_DEFER or _REC is not None or torch.device(device).type != "cuda" or not hasattr(_capi.lib(), "aitk_lora_wgrad_finish_multi"):
+        return False
+    _wdefer = {"jobs": [], "slot": 0}
+    return True
+
+
+def _wgrad_defer_flush():
+    st = _wdefer
+    if st is None or not st["jobs"]:
+        return
+    n = len(st["jobs"])
+    arr = (_capi.LoraWgradArgs * n)()
+    for i, (a, _) in enumerate(st["jobs"]):
+        C.memmove(C.byref(arr[i]), C.byref(a), C.sizeof(_capi.LoraWgradArgs))
+    _capi.check(_capi.lib().aitk_lora_wgrad_finish_multi(arr, n, _capi.stream_ptr()), "aitk_lora_wgrad_finish_multi")
+    st["jobs"] = []
+
+
+def wgrad_defer_flush():
+    """Every collected finish goes out now (in launch order while recording): call before anything reads the gradient arena."""
+    if _REC is not None:
+        _REC.append(("_host", (_wgrad_defer_flush,)))
+        return
+    _wgrad_defer_flush()
+
+
+def wgrad_defer_end():
+    global _wdefer
+    assert _REC is None
+    _wgrad_defer_flush()
+    _wdefer = None
+
+
+def _emit_wgrad_defer(a, q, nbytes, device, keep):
+    st = _wdefer
+    lib = _capi.lib()
+    if st is None:  # no backward pass is collecting: the plain two-launch call
+        ws = workspace(nbytes, device, "wgrad")
+        a.partial = C.c_void_p(ws.data_ptr())
+        if q is None:
+            _capi.check(lib.aitk_lora_wgrad(C.byref(a), _capi.stream_ptr()), "aitk_lora_wgrad")
+        else:
+            _capi.check(lib.aitk_lora_wgrad2(C.byref(a), C.byref(q), _capi.stream_ptr()), "aitk_lora_wgrad2")
+        return
+    if any(j[0].out == a.out for j in st["jobs"]):  # a second accumulation into the same matrix: not inside one finish launch
+        _wgrad_defer_flush()
+    ws = workspace(nbytes, device, f"wgrad_ring{st['slot']}")
+    st["slot"] = (st["slot"] + 1) % WGRAD_DEFER_MAX
+    a.partial = C.c_void_p(ws.data_ptr())
+    _capi.check(lib.aitk_lora_wgrad_main(C.byref(a), C.byref(q) if q is not None else None, _capi.stream_ptr()), "aitk_lora_wgrad_main")
+    st["jobs"].append((a, keep))
+    if len(st["jobs"]) == WGRAD_DEFER_MAX:
+        _wgrad_defer_flush()
 
 
 class recording:
@@ -400,8 +473,9 @@ def slab_rescale(T, rp, *, mult=None, rows_per_batch=0, tmask=None, tmask_rows_p
     return T
 
 
-def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None, g2=None, g2_act=None):
+def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, M=None, split=0, out_strides=None, g2=None, g2_act=None, defer=False):
     """out (fp32) (+)= s[M,R]^T @ g[M,L]:  out is [R,L], or [L,R] when transpose_out (lora_up.weight.grad).
+    defer: `out` is read by nobody before wgrad_defer_flush / wgrad_defer_end — the finish pass may be collected (wgrad_defer_begin).
     g2 [M, L2] (aitk_lora_wgrad2): the operand is [g | act(g2)] — `g` may be None (L = L2) — with act "gelu" = tanh-GELU of a saved
     pre-activation, so that the GELU output itself need not be kept for the backward pass.
     split = rank-block width: s is the [M,3R] slab layout written by lora_down(split=...) and is read as hi + lo.
@@ -415,7 +489,7 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
         if R > 64:
             raise NotImplementedError("lora_wgrad with a two-part operand: ranks above 64")
         return _lora_wgrad_launch(s, g, out, R, L, accumulate, None, M, split, out_strides, transpose_out,
-                                  second=(g2, split_col, 1 if g2_act == "gelu" else 0))
+                                  second=(g2, split_col, 1 if g2_act == "gelu" else 0), defer=defer)
     R, L = (s.shape[1] // 3 if split else s.shape[1]), g.shape[1]
     if R > 64:  # 64-rank chunks of one slab (see lora_down): rank r of the output at r * stride_r
         if split and split < R:
@@ -430,10 +504,10 @@ def lora_wgrad(s, g, out, *, transpose_out=False, accumulate=False, g_seg=None, 
             sc = s[:, c0:] if split else s[:, c0:c1]
             _lora_wgrad_launch(sc, g, flat[c0 * sr:], c1 - c0, L, accumulate, g_seg, M, split, (sr, sl), False)
         return out
-    return _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out)
+    return _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out, defer=defer)
 
 
-def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out, second=None):
+def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out, second=None, defer=False):
     a = _capi.LoraWgradArgs()
     a.lds = _row_major(s, "s")
     a.ldg = _row_major(g, "g") if g is not None else 0
@@ -452,10 +526,22 @@ def _lora_wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides
     if g_seg is not None:
         a.g_seg_rows, a.g_seg_stride = g_seg
     nbytes = _capi.lib().aitk_lora_wgrad_workspace_bytes(M, R, L)
-    ws = workspace(nbytes, s.device, "wgrad")
-    a.S, a.G, a.partial, a.out = _ptr(s), _ptr(g), _ptr(ws), _ptr(out)
     a.accumulate = int(accumulate)
     a.M, a.R, a.L = M, R, L
+    if defer and (_wdefer is not None or _REC is not None):
+        # the finish may wait (wgrad_defer_begin): the partial buffer (a ring slot) and the batch the finish joins are chosen when the launch is emitted
+        a.S, a.G, a.out = _ptr(s), _ptr(g), _ptr(out)
+        q = None
+        keep = [s, g, out]
+        if second is not None:
+            g2, split_col, act = second
+            q = _capi.WgradSrc2()
+            q.G2, q.ldg2, q.split_col, q.act = _ptr(g2), _row_major(g2, "g2"), split_col, act
+            keep.append(g2)
+        _call("_wgrad_defer", a, q, nbytes, s.device, keep)
+        return out
+    ws = workspace(nbytes, s.device, "wgrad")
+    a.S, a.G, a.partial, a.out = _ptr(s), _ptr(g), _ptr(ws), _ptr(out)
     if second is not None:
         g2, split_col, act = second
         q = _capi.WgradSrc2()

@@ -25,7 +25,7 @@ extern "C" {
 typedef void* aitk_stream_t;
 typedef uint16_t aitk_bf16;
 
-#define AITK_ABI_VERSION 11 /* 11: aitk_lora_down_ksplit (aitk_lora_down for a few rows over a long contraction: K slices across workgroups + the aitk_lora_t_finish pass, one call); 10: AITK_EPI_EMIT_T + AitkGemmArgs.t_* (a GELU launch emits the column-tile partials of the NEXT layer's lora_down product), aitk_lora_t_finish, aitk_lora_down_raw; 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
+#define AITK_ABI_VERSION 12 /* 12: aitk_lora_wgrad_main + aitk_lora_wgrad_finish_multi (the finish pass of up to 8 weight-gradient launches as one launch, deferred until something reads the gradient); 11: aitk_lora_down_ksplit (aitk_lora_down for a few rows over a long contraction: K slices across workgroups + the aitk_lora_t_finish pass, one call); 10: AITK_EPI_EMIT_T + AitkGemmArgs.t_* (a GELU launch emits the column-tile partials of the NEXT layer's lora_down product), aitk_lora_t_finish, aitk_lora_down_raw; 9: aitk_ema_update (the EMA of toolkit/ema.py over the flat arenas as its own launch: trainers that call optimizer.step() and ema.update() separately), AitkAttnArgs.dS (the dK/dV pass can emit dS for a GEMM-form dQ); 8: AitkMseArgs.max_loss / guard and AitkAdamWArgs.guard / n_micro (device-side failure handling of the train loop: non-finite loss, max_loss clamp, skipped optimizer step with device-resident step count); aitk_adamw_workspace_bytes grew by the 32-byte control block; 7: aitk_probe_gemm8_trace (no struct or semantic change: the fast epilogue forms of the persistent GEMM, the single-pass LN-modulate backward and the wave-per-token QK-norm + RoPE kernels keep their entry points' contracts); 6: aitk_grad_compress_bf16 / aitk_grad_expand_bf16 (bf16 transport of the DP all-reduce), aitk_lora_wgrad2 (lora_down gradient from a two-part operand [g | gelu(pre-activation)]), AitkShadowDesc.aux = row stride of the kind-1 data-gradient block (same-input groups share one [in, 3R] matrix); 5: aitk_slab_rescale, AitkAttnArgs.hstride (heads read in their native [tokens, H*d] layout), AITK_EPI_SPLIT_SLAB for N = 2 rp <= 128 with the stacked rows in 16-rank blocks (shadow kind 4 writes that order), aitk_lora_down / aitk_lora_wgrad accept split_rp > R (64-rank chunks of one slab); 4: AitkMseArgs.loss_type / huber_c (mae, pseudo_huber), AitkAdamWArgs.ema_feedback / param_multiplier, AitkGemmArgs.a_scale + b_scale_mode 3 (W8A8 on the MX-scaled fp8 MFMA), aitk_quant_rows_fp8, aitk_image_resize_to_nhwc8; 3: 3: conv_t3d (3-D convolution), AITK_EPI_SPLIT_SLAB, K-slab in conv mode, shadow kind 4, aitk_rmsnorm_rows, aitk_latent_sample_affine, aitk_pad_nhwc */
 
 /* ---- GEMM epilogue flags ---- */
 #define AITK_EPI_BIAS 1      /* + bias[n]                                                        */
@@ -195,6 +195,12 @@ typedef struct AitkWgradSrc2 {
   int32_t split_col; int32_t act;
 } AitkWgradSrc2;
 int aitk_lora_wgrad2(const AitkLoraWgradArgs* args, const AitkWgradSrc2* second, aitk_stream_t stream);
+/* The two halves of aitk_lora_wgrad / aitk_lora_wgrad2 as calls of their own.  aitk_lora_wgrad_main (src2 NULL or the second operand part of aitk_lora_wgrad2) leaves
+ * the chunk partials in args->partial and does not touch args->out; aitk_lora_wgrad_finish_multi takes 1..8 such argument blocks (each with its OWN partial buffer,
+ * pairwise different `out`) and adds / stores their sums in one launch — bit for bit what the finish pass inside aitk_lora_wgrad does.  Nothing in a backward pass reads a
+ * weight gradient (autograd of toolkit/network_mixins.py:309-321 ends in the optimizer), so a trainer can batch the 380 finish launches of a FLUX step eight at a time. */
+int aitk_lora_wgrad_main(const AitkLoraWgradArgs* args, const AitkWgradSrc2* src2, aitk_stream_t stream);
+int aitk_lora_wgrad_finish_multi(const AitkLoraWgradArgs* jobs, int32_t njobs, aitk_stream_t stream);
 /* The two adapter-side products of a layer's backward that stream dY, from ONE read of it (autograd of toolkit/network_mixins.py:309-321:
  * lora_up.weight.grad = dY^T T and the gradient of the rank-r activation dT = c (dY B)):
  *   wgrad : aitk_lora_wgrad's arguments with S = T (slab), G = dY, out = lora_up.weight.grad (strides (1, R))

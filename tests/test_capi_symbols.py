@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(repo_root):
 
 def test_struct_size_handshake_and_abi_version():
     lib = _capi.lib()  # raises on any Python/C struct size mismatch
-    assert lib.aitk_abi_version() == _capi.ABI_VERSION == 11
+    assert lib.aitk_abi_version() == _capi.ABI_VERSION == 12
     assert lib.aitk_sizeof(0) == ctypes.sizeof(_capi.GemmArgs)
     assert lib.aitk_sizeof(99) == -1
 

@@ -24,7 +24,7 @@ def _rel(a, b):
 def test_native_library_loaded_and_fails_loudly_without_it(monkeypatch):
     from ai_toolkit_amd import _capi
 
-    assert _capi.lib().aitk_abi_version() == _capi.ABI_VERSION == 11
+    assert _capi.lib().aitk_abi_version() == _capi.ABI_VERSION == 12
     monkeypatch.setattr(_capi, "_lib", None)
     monkeypatch.setattr(_capi, "LIB_PATH", "/nonexistent/libaitk.so")
     with pytest.raises(RuntimeError):

@@ -31,7 +31,7 @@ def _down_launch(x, pmat, out, scale, mult, rows_per_batch, x_seg, M, p_lo, spli
     return out
 
 
-def _wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out):
+def _wgrad_launch(s, g, out, R, L, accumulate, g_seg, M, split, out_strides, transpose_out, second=None, defer=False):
     assert R <= 64 and g_seg is None
     M = s.shape[0] if M is None else M
     sv = (s[:M, :R].float() + s[:M, split:split + R].float()) if split else s[:M, :R].float()
