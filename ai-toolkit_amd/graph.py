@@ -715,7 +715,7 @@ class FusedGraphBase(nn.Module):
         else:
             ops.lora_down(dy, lo.sh_upT, dT, scale=lo.scale, mult=mult, rows_per_batch=rpb, M=M, p_lo=lo.sh_upT_lo, split=rp, tmask=tm,
                           tmask_rows_per_batch=tm_rpb)
-            ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp)
+            ops.lora_wgrad(T, dy, lo.g_up, transpose_out=True, accumulate=True, M=M, split=rp, **self._defer_kw())  # only the finish waits: dy is consumed now
         if dT_out is None:
             # nothing reads lora_down.weight.grad before the optimizer: its finish pass may be collected (ops.wgrad_defer_begin)
             if isinstance(x_in, _ActInput):  # the input is [g | gelu(pre-activation)] and only the pre-activation was kept

@@ -828,7 +828,13 @@ class UNet2DConditionModel(FusedGraphBase):
         Co = self.config["out_channels"]
         d8 = torch.zeros(self._pred.shape, dtype=self.dt, device=self._pred.device)
         self.ops.copy_rows(d8[:, :Co], dpred.to(self.dt).reshape(-1, Co).contiguous())
-        tape.backward(self._pred, d8)
+        ops = self.ops
+        wdefer = getattr(ops, "wgrad_defer_begin", None) is not None and ops.wgrad_defer_begin(d8.device)  # weight-gradient finishes eight at a time (flux.py)
+        try:
+            tape.backward(self._pred, d8)
+        finally:
+            if wdefer:
+                ops.wgrad_defer_end()
         self.tape = self._pred = None
         if self.grad_ready_hook is not None:
             self.grad_ready_hook("single")

@@ -319,6 +319,7 @@ class WanTransformer3DModel(FusedGraphBase):
         cos, sin, enc = ctx["cos"], ctx["sin"], ctx["enc"]
         scale = 1.0 / math.sqrt(128.0)
         eps = self.eps
+        wdefer = getattr(ops, "wgrad_defer_begin", None) is not None and ops.wgrad_defer_begin(dpred.device)  # weight-gradient finishes eight at a time (flux.py)
 
         dxn = self._new(M, d)
         ops.gemm_nt(dpred.to(self.dt).reshape(M, -1).contiguous(), self._proj_wt, dxn)
@@ -382,7 +383,11 @@ class WanTransformer3DModel(FusedGraphBase):
             dx = dx0
             r.clear()
             if self.grad_ready_hook is not None and i == nblk // 2 - 1:
+                if wdefer:
+                    ops.wgrad_defer_flush()
                 self.grad_ready_hook("late")
+        if wdefer:
+            ops.wgrad_defer_end()
         if self.grad_ready_hook is not None:
             self.grad_ready_hook("early")
         self.ctx = None
