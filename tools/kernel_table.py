@@ -30,6 +30,7 @@ def main():
            ("lora_wgrad_fused", "LoRA backward, one read of dY: dT partials + lora_up gradient (aitk_lora_bwd_fused, 128 columns per workgroup)", 0),
            ("lora_bwd_fused_ct", "LoRA backward, one read of dY: dT partials + lora_up gradient (aitk_lora_bwd_fused, 2 / 4 column tiles per workgroup)", 0),
            ("lora_bwd_finish2", "the two finish passes of aitk_lora_bwd_fused as one launch (lora_up gradient chunks -> arena, dT column partials -> slab)", 0),
+           ("lora_wgrad_finish_multi", "up to eight weight-gradient finish passes as one launch (deferred finishes, ABI 12)", 0),
            ("lora_dt_finish", "dT finish (sum of the column partials -> [hi | lo | hi] slab)", 0),
            ("lora_wgrad", "LoRA weight gradients (lora_down gradient; + finish passes)", 0),
            ("ln_mod_", "adaLN LayerNorm fwd / bwd", 0), ("qkv_post", "QK-RMSNorm + RoPE fwd / bwd", 0), ("gate_bwd", "gate backward", 0),
