@@ -294,7 +294,32 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(AitkGateBwdArgs p) {
     unpack8(*reinterpret_cast<const uint4*>(gt + c), g8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int r = 0; r < nrows; ++r) {
+    // four rows of loads in flight before the first store (the compiler cannot move a load across the dy store: the buffers may alias for all it knows, and
+    // a row at a time is a chain of 16 round trips per thread at short batches); rows are added in order: the column sums are the one-row loop's, bit for bit
+    int r = 0;
+    for (; r + 4 <= nrows; r += 4) {
+      uint4 dq[4], yq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long m = mbase + r + u;
+        dq[u] = *reinterpret_cast<const uint4*>(p.dx + m * p.ld_dx + c);
+        yq[u] = p.y ? *reinterpret_cast<const uint4*>(p.y + m * p.ld_y + c) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long m = mbase + r + u;
+        float dv[8], yv[8], o[8];
+        unpack8(dq[u], dv);
+        unpack8(yq[u], yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = g8[e] * dv[e];
+          if (p.y) acc[e] += dv[e] * yv[e];
+        }
+        *reinterpret_cast<uint4*>(p.dy + m * p.ld_dy + c) = pack8(o);
+      }
+    }
+    for (; r < nrows; ++r) {
       const long m = mbase + r;
       float dv[8], yv[8], o[8];
       unpack8(*reinterpret_cast<const uint4*>(p.dx + m * p.ld_dx + c), dv);
