@@ -296,6 +296,11 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
     }
     // LONG launches (>= 16384 rows: B >= 4 at 1024^2): 64-row workgroups for the rank widths in the mask AITK_LORA_DOWN_NB4 (bit 0: <= 16 ranks, 1: <= 32, 2: <= 48,
     // 3: <= 64) — half the projection traffic per row (kernel comment)
+    static int short8w = -1;
+    if (short8w < 0) {
+      const char* e = getenv("AITK_LORA_DOWN_SHORT8W");
+      short8w = (e && atoi(e) == 0) ? 0 : 1;
+    }
     static int nb4 = -1;
     if (nb4 < 0) {
       const char* e = getenv("AITK_LORA_DOWN_NB4");
@@ -310,6 +315,10 @@ extern "C" int aitk_lora_down(const AitkLoraDownArgs* a, aitk_stream_t stream) {
     // one workgroup for the whole launch (M <= 32: the adaLN adapters, B rows x K = 3 d / 6 d in their backward): 16 K slices
     else if (a->R <= 16 && short8 && a->M <= 32 && a->K >= 32 * 6 * 16) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 16>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16 && short8 && a->M < 16384 && a->K >= 32 * 6 * 8) hipLaunchKernelGGL((lora_down16_kernel<1, 6, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
+    // the wider rank groups of a short launch (q,k,v[,proj_mlp] at B <= 3): eight K slices too (AITK_LORA_DOWN_SHORT8W=0: four, A/B)
+    else if (short8w && a->M < 16384 && a->K >= 32 * 4 * 8 && a->R > 48) hipLaunchKernelGGL((lora_down16_kernel<4, 4, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
+    else if (short8w && a->M < 16384 && a->K >= 32 * 4 * 8 && a->R > 32) hipLaunchKernelGGL((lora_down16_kernel<3, 4, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
+    else if (short8w && a->M < 16384 && a->K >= 32 * 8 * 8 && a->R > 16) hipLaunchKernelGGL((lora_down16_kernel<2, 8, false, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16 && u1 == 6) hipLaunchKernelGGL((lora_down16_kernel<1, 6>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 16) hipLaunchKernelGGL((lora_down16_kernel<1, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->R <= 32) hipLaunchKernelGGL((lora_down16_kernel<2, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
